@@ -1,0 +1,183 @@
+/*
+ * splat_one_amd.h -- C ABI of the MI355X-native 3D-Gaussian-splatting training path.
+ *
+ * This is the drop-in boundary for the ONE hot path of inuex35/splat_one: everything that
+ * `Runner.rasterize_splats` reaches through `gsplat.rendering.rasterization(...)`
+ * (/root/reference/utils/gsplat_utils/gsplat_trainer.py:446-497, call at :477-494), its
+ * backward (`loss.backward()` at :655), the optimiser step (:726-742) and the densification
+ * strategy hooks (:616-622, :744-763).  In the reference those live in the CUDA extension of the
+ * un-vendored gsplat fork (/root/reference/.gitmodules:13-16); each entry point below names the
+ * gsplat operator it replaces and the reference line that reaches it.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into HBM unless it is named host_*; tensors are dense,
+ *     row-major, float32 / int32 / int64 as declared; "nullable" pointers may be NULL.
+ *   - inputs are borrowed; outputs are written into caller-owned buffers; no entry point allocates,
+ *     frees or synchronises (all are hipGraph-capturable).  Scratch comes from caller workspaces.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - return value: SO_OK or an SO_ERR_* code; so_last_error() gives a thread-local message.
+ *   - (C, N): cameras x Gaussians.  Flattened (camera, Gaussian) index g = c*N + n.
+ *   - camera_model: SO_CAM_PINHOLE / SO_CAM_ORTHO / SO_CAM_FISHEYE (trainer Config.camera_model,
+ *     gsplat_trainer.py:89; "spherical" is fork-only and unspecified -> SO_ERR_UNSUPPORTED).
+ *
+ * Reference-side bindings (ctypes / torch autograd.Function) are shown in INTEGRATION.md.
+ */
+#ifndef SPLAT_ONE_AMD_H
+#define SPLAT_ONE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SO_ABI_VERSION 1
+
+enum so_status {
+  SO_OK = 0,
+  SO_ERR_INVALID_ARG = 1, /* bad shape / null pointer / unsupported size           */
+  SO_ERR_UNSUPPORTED = 2, /* valid request this build does not implement           */
+  SO_ERR_WORKSPACE = 3,   /* caller workspace too small                            */
+  SO_ERR_LAUNCH = 4       /* HIP reported an error at launch                       */
+};
+
+enum so_camera_model { SO_CAM_PINHOLE = 0, SO_CAM_ORTHO = 1, SO_CAM_FISHEYE = 2 };
+
+int so_abi_version(void);
+const char *so_last_error(void);
+/* number of compute units / XCDs of the current device (launch sizing on the host side) */
+int so_device_cu_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K1/K2  3D -> 2D EWA projection.   Replaces gsplat `fully_fused_projection` (legacy
+ * `project_gaussians`) forward/backward, reached from gsplat_trainer.py:477.
+ *   means[N,3]; covars6[N,6] (xx,xy,xz,yy,yz,zz) nullable; quats[N,4] (w,x,y,z, un-normalised),
+ *   scales[N,3] (used when covars6 == NULL); viewmats[C,4,4] world->camera; Ks[C,3,3].
+ *   -> radii[C,N] i32 (0 = culled), means2d[C,N,2], depths[C,N], conics[C,N,3],
+ *      compensations[C,N] nullable.  Culled entries are written as zeros.
+ * ---------------------------------------------------------------------------------------- */
+int so_projection_fwd(int C, int N, const float *means, const float *covars6, const float *quats,
+                      const float *scales, const float *viewmats, const float *Ks, int width, int height,
+                      float eps2d, float near_plane, float far_plane, float radius_clip, int camera_model,
+                      int32_t *radii, float *means2d, float *depths, float *conics, float *compensations,
+                      void *stream);
+
+/* Backward.  v_means[N,3], v_quats[N,4], v_scales[N,3] (or v_covars6[N,6]) are OVERWRITTEN with
+ * the sum over cameras (one thread owns one Gaussian: no atomics, bitwise reproducible).
+ * v_viewmats[C,4,4] nullable: if given it must be zero-initialised; it is accumulated atomically. */
+int so_projection_bwd(int C, int N, const float *means, const float *covars6, const float *quats,
+                      const float *scales, const float *viewmats, const float *Ks, int width, int height,
+                      float eps2d, int camera_model, const int32_t *radii, const float *v_means2d,
+                      const float *v_depths, const float *v_conics, const float *v_compensations,
+                      float *v_means, float *v_covars6, float *v_quats, float *v_scales, float *v_viewmats,
+                      void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K4/K5  spherical harmonics.   Replaces gsplat `spherical_harmonics` (reached with
+ * sh_degree=... from gsplat_trainer.py:591).
+ *   dirs[C,N,3] (not normalised); coeffs[N,K,3] (coeffs_per_camera=0) or [C,N,K,3] (=1);
+ *   masks[C,N] u8 nullable (0 -> output 0, no gradient); degrees_to_use <= 4, (deg+1)^2 <= K.
+ *   -> colors[C,N,3]   (the caller adds 0.5 and clamps, as gsplat's `rasterization` does)
+ * Backward: v_coeffs (same shape as coeffs) is OVERWRITTEN (sum over cameras when shared);
+ * v_dirs[C,N,3] nullable, overwritten.
+ * ---------------------------------------------------------------------------------------- */
+int so_sh_fwd(int C, int N, int K, int degrees_to_use, const float *dirs, const float *coeffs,
+              int coeffs_per_camera, const uint8_t *masks, float *colors, void *stream);
+int so_sh_bwd(int C, int N, int K, int degrees_to_use, const float *dirs, const float *coeffs,
+              int coeffs_per_camera, const uint8_t *masks, const float *v_colors, float *v_coeffs,
+              float *v_dirs, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K6-K8  tile binning + per-tile depth sort.   Replaces gsplat `isect_tiles` (two launches +
+ * cub radix sort) and `isect_offset_encode`, reached inside `rasterization` (:477).
+ *
+ * MI355X design: counting sort by tile (histogram + scan gives `isect_offsets` directly), then
+ * one workgroup per tile sorts its (fp32 depth bits, flatten id) keys in LDS.  Result is identical
+ * to the reference's global stable radix sort of (camera | tile | depth) keys: ties in depth are
+ * ordered by ascending flatten id.
+ *
+ * Step 1  so_isect_count : tiles_per_gauss[C,N] i32, tile_counts[C*tile_h*tile_w] i32 (must be
+ *         zeroed by the caller), then exclusive scan -> isect_offsets[C,tile_h,tile_w] i32 and
+ *         n_isects (1 x i32, device).
+ * Step 2  so_isect_fill  : scatters keys into key_buf[capacity] (u64: depth_bits<<32 | g),
+ *         sorts each tile, writes flatten_ids[capacity] i32 and, if non-NULL,
+ *         isect_ids[capacity] i64 (= cam << (32+tile_bits) | tile << 32 | depth_bits).
+ *         `capacity` is the size of the caller's buffers; if n_isects > capacity nothing beyond
+ *         capacity is written and *overflow (device i32, nullable) is set to 1.
+ *         tile_cursor[C*tile_h*tile_w] i32 must be zeroed by the caller.
+ *         Lists longer than SO_TILE_SORT_LDS_MAX fall back to an in-kernel global-memory sort.
+ * ---------------------------------------------------------------------------------------- */
+int so_isect_count(int C, int N, const float *means2d, const int32_t *radii, int tile_size, int tile_width,
+                   int tile_height, int32_t *tiles_per_gauss, int32_t *tile_counts, int32_t *isect_offsets,
+                   int32_t *n_isects, void *stream);
+int so_isect_fill(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
+                  int tile_size, int tile_width, int tile_height, const int32_t *isect_offsets,
+                  const int32_t *n_isects, int32_t *tile_cursor, int64_t capacity, uint64_t *key_buf,
+                  int32_t *flatten_ids, int64_t *isect_ids, int32_t *overflow, void *stream);
+
+/* gsplat `isect_tiles(sort=False)`: Gaussian-major, row-major-tile emission order.
+ * cum_tiles[C*N] i64 = inclusive prefix sum of tiles_per_gauss (caller-provided). */
+int so_isect_emit_unsorted(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
+                           const int64_t *cum_tiles, int tile_size, int tile_width, int tile_height,
+                           int64_t *isect_ids, int32_t *flatten_ids, void *stream);
+
+/* gsplat `isect_offset_encode`: offsets[c,ty,tx] = first index of that tile's run in sorted ids */
+int so_isect_offset_encode(int64_t n_isects, const int64_t *isect_ids, int C, int tile_width,
+                           int tile_height, int32_t *isect_offsets, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K9/K10  tile rasteriser.   Replaces gsplat `rasterize_to_pixels` forward/backward.
+ *   means2d[C,N,2] conics[C,N,3] colors[C,N,D] opacities[C,N]; backgrounds[C,D] nullable;
+ *   tile_masks[C,tile_h,tile_w] u8 nullable; isect_offsets[C,tile_h,tile_w]; flatten_ids[>=n_isects].
+ *   n_isects is read from the device pointer `n_isects_dev` when it is non-NULL, else the host
+ *   value `n_isects_host` is used.  D in {1,2,3,4,5,8,9,16,17,32,33}.  tile_size in {8,16}.
+ *   -> render_colors[C,H,W,D], render_alphas[C,H,W], last_ids[C,H,W] i32.
+ * Backward: v_means2d[C,N,2], v_conics[C,N,3], v_colors[C,N,D], v_opacities[C,N] and the
+ * nullable v_means2d_abs[C,N,2] (`absgrad`) must be zero-initialised; they are accumulated with
+ * float atomics (one per tile and Gaussian).
+ * ---------------------------------------------------------------------------------------- */
+int so_rasterize_fwd(int C, int N, int D, int width, int height, int tile_size, const float *means2d,
+                     const float *conics, const float *colors, const float *opacities,
+                     const float *backgrounds, const uint8_t *tile_masks, const int32_t *isect_offsets,
+                     const int32_t *flatten_ids, const int32_t *n_isects_dev, int64_t n_isects_host,
+                     float *render_colors, float *render_alphas, int32_t *last_ids, void *stream);
+int so_rasterize_bwd(int C, int N, int D, int width, int height, int tile_size, const float *means2d,
+                     const float *conics, const float *colors, const float *opacities,
+                     const float *backgrounds, const uint8_t *tile_masks, const int32_t *isect_offsets,
+                     const int32_t *flatten_ids, const int32_t *n_isects_dev, int64_t n_isects_host,
+                     const float *render_alphas, const int32_t *last_ids, const float *v_render_colors,
+                     const float *v_render_alphas, float *v_means2d, float *v_means2d_abs, float *v_conics,
+                     float *v_colors, float *v_opacities, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimiser.  Replaces the six torch.optim.Adam steps + zero_grad of gsplat_trainer.py:726-731
+ * (hyper-parameters per :266-280) with ONE launch over up to SO_ADAM_MAX_GROUPS tensors.
+ *   per group g: param/grad/exp_avg/exp_avg_sq [numel[g]] f32; step_size = lr/bias_correction1,
+ *   bc2_sqrt = sqrt(1-beta2^t) are computed by the caller (host) from its step counter.
+ *   Semantics = torch.optim.Adam(amsgrad=False, weight_decay=0, maximize=False):
+ *     m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= step_size * m / (sqrt(v)/bc2_sqrt + eps)
+ *   beta1/beta2/eps are doubles so that (1-beta) is rounded to float32 once, exactly as torch does.
+ *   If `zero_grad` != 0 the gradient is zeroed in the same pass.
+ *   visibility[g] (u8 per ROW of row_len[g] elements, nullable): rows with 0 are skipped entirely
+ *   (gsplat `SelectiveAdam`, gsplat_trainer.py:269-270, 719-728).
+ * ---------------------------------------------------------------------------------------- */
+#define SO_ADAM_MAX_GROUPS 8
+typedef struct so_adam_group {
+  float *param;
+  float *grad;
+  float *exp_avg;
+  float *exp_avg_sq;
+  const uint8_t *visibility; /* nullable */
+  int64_t numel;
+  int32_t row_len;
+  float lr_step_size; /* lr / (1 - beta1^t) */
+  float bc2_sqrt;     /* sqrt(1 - beta2^t)  */
+} so_adam_group;
+int so_adam_step(int n_groups, const so_adam_group *host_groups, double beta1, double beta2, double eps,
+                 int zero_grad, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPLAT_ONE_AMD_H */

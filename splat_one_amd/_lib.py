@@ -1,0 +1,91 @@
+"""ctypes binding of libsplat_one_amd.so (the C ABI declared in include/splat_one_amd.h).
+
+The library is the product; there is NO fallback.  If it is missing or an entry point reports
+an error this module raises -- the HIP path is the only path (see DESIGN.md "boundary").
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsplat_one_amd.so")
+
+c_int, c_i64, c_f32, c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+SO_ADAM_MAX_GROUPS = 8
+
+
+class AdamGroup(ctypes.Structure):
+    _fields_ = [("param", c_ptr), ("grad", c_ptr), ("exp_avg", c_ptr), ("exp_avg_sq", c_ptr),
+                ("visibility", c_ptr), ("numel", c_i64), ("row_len", ctypes.c_int32),
+                ("lr_step_size", c_f32), ("bc2_sqrt", c_f32)]
+
+
+# name -> argtypes, exactly the prototypes of include/splat_one_amd.h
+_SIGS = {
+    "so_projection_fwd": [c_int, c_int] + [c_ptr] * 6 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int] + [c_ptr] * 6,
+    "so_projection_bwd": [c_int, c_int] + [c_ptr] * 6 + [c_int, c_int, c_f32, c_int] + [c_ptr] * 11,
+    "so_sh_fwd": [c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr],
+    "so_sh_bwd": [c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
+    "so_isect_count": [c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_int] + [c_ptr] * 5,
+    "so_isect_fill": [c_int, c_int, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_i64] + [c_ptr] * 5,
+    "so_isect_emit_unsorted": [c_int, c_int] + [c_ptr] * 4 + [c_int, c_int, c_int] + [c_ptr] * 3,
+    "so_isect_offset_encode": [c_i64, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr],
+    "so_rasterize_fwd": [c_int] * 6 + [c_ptr] * 9 + [c_i64] + [c_ptr] * 4,
+    "so_rasterize_bwd": [c_int] * 6 + [c_ptr] * 9 + [c_i64] + [c_ptr] * 10,
+    "so_adam_step": [c_int, ctypes.POINTER(AdamGroup), ctypes.c_double, ctypes.c_double, ctypes.c_double, c_int, c_ptr],
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def exported_symbols():
+    return ["so_abi_version", "so_last_error", "so_device_cu_count"] + list(_SIGS)
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared library (built by `__graft_entry__.build()` / splat_one_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU or PyTorch fallback for this path)")
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.so_abi_version.restype = c_int
+        lib.so_last_error.restype = ctypes.c_char_p
+        lib.so_device_cu_count.restype = c_int
+        for name, argtypes in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = c_int
+        assert lib.so_abi_version() == 1, "ABI version mismatch"
+        _lib = lib
+    return _lib
+
+
+def ptr(t: Optional[torch.Tensor]) -> int:
+    """Device pointer of a contiguous CUDA(HIP) tensor, or NULL."""
+    if t is None:
+        return 0
+    if not t.is_cuda:
+        raise RuntimeError("splat_one_amd: tensors must live on a HIP device (no CPU path exists)")
+    if not t.is_contiguous():
+        raise RuntimeError("splat_one_amd: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args) -> None:
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.so_last_error().decode()
+        raise RuntimeError(f"{name} failed with status {rc}: {msg}")

@@ -1,0 +1,372 @@
+// isect.hip -- K6/K7/K8: tile binning, per-tile depth sort and tile offsets for gfx950.
+//
+// Replaces gsplat `isect_tiles` (count + emit kernels and a global cub radix sort of 64-bit
+// camera|tile|depth keys) and `isect_offset_encode`, reached inside `rasterization`
+// (/root/reference/utils/gsplat_utils/gsplat_trainer.py:477).
+//
+// MI355X design (HBM-bound integer work, no dense contraction):
+//   1. k_isect_count   one lane per (camera, Gaussian): AABB in tiles, tiles_per_gauss, and a
+//                      histogram over (camera, tile) with fire-and-forget int atomics.
+//   2. k_scan_tiles    exclusive scan of the histogram = `isect_offsets` (K8 comes for free) and
+//                      the total n_isects, all on the device: no host round trip, capturable.
+//   3. k_isect_scatter counting-sort scatter: slot = offsets[tile] + atomic cursor; writes one
+//                      64-bit key (fp32 depth bits << 32 | flatten id) per intersection.
+//   4. k_tile_sort_*   one workgroup per tile sorts its keys in LDS (bitonic network, all
+//                      comparisons ascending so ragged sizes need no padding) and writes
+//                      flatten_ids / isect_ids.  Ties in depth resolve by ascending flatten id, which
+//                      is exactly what the reference's stable radix sort of Gaussian-major keys gives.
+// Traffic per intersection: 8 B written + 8 B read + 4 (+8) B written, versus >=6 radix passes of
+// 24 B for the global 64-bit sort.
+#include "so_common.hpp"
+
+namespace so {
+
+struct TileBox {
+  int x0, x1, y0, y1;
+};
+
+// float32 AABB arithmetic exactly as published
+__device__ __forceinline__ TileBox tile_box(float mx, float my, float radius, float tile_size, int tile_w, int tile_h) {
+  const float tile_r = radius / tile_size;
+  const float tx = mx / tile_size, ty = my / tile_size;
+  TileBox b;
+  b.x0 = (int)fminf(fmaxf(floorf(tx - tile_r), 0.f), (float)tile_w);
+  b.x1 = (int)fminf(fmaxf(ceilf(tx + tile_r), 0.f), (float)tile_w);
+  b.y0 = (int)fminf(fmaxf(floorf(ty - tile_r), 0.f), (float)tile_h);
+  b.y1 = (int)fminf(fmaxf(ceilf(ty + tile_r), 0.f), (float)tile_h);
+  return b;
+}
+
+__global__ void __launch_bounds__(256)
+k_isect_count(int C, int N, const float *__restrict__ means2d, const int32_t *__restrict__ radii, float tile_size,
+              int tile_w, int tile_h, int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ tile_counts) {
+  const int64_t total = (int64_t)C * N;
+  const int n_tiles = tile_w * tile_h;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int r = radii[idx];
+    int cnt = 0;
+    if (r > 0) {
+      const float2 m = *reinterpret_cast<const float2 *>(means2d + 2 * idx);
+      const TileBox b = tile_box(m.x, m.y, (float)r, tile_size, tile_w, tile_h);
+      cnt = (b.x1 - b.x0) * (b.y1 - b.y0);
+      int32_t *row = tile_counts + (idx / N) * n_tiles;
+      for (int y = b.y0; y < b.y1; ++y)
+        for (int x = b.x0; x < b.x1; ++x) atomicAdd(row + y * tile_w + x, 1);
+    }
+    tiles_per_gauss[idx] = cnt;
+  }
+}
+
+// single-workgroup exclusive scan over M = C*n_tiles counters (M is at most a few 100k)
+__global__ void __launch_bounds__(1024)
+k_scan_tiles(int64_t M, const int32_t *__restrict__ counts, int32_t *__restrict__ offsets, int32_t *__restrict__ total) {
+  __shared__ int32_t wave_sums[16];
+  __shared__ int32_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < M; base += 1024 * 4) {
+    // each thread owns 4 consecutive counters
+    const int64_t i0 = base + (int64_t)tid * 4;
+    int32_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (i0 + k < M) ? counts[i0 + k] : 0;
+    const int32_t mine = v[0] + v[1] + v[2] + v[3];
+    // inclusive wave scan
+    int32_t s = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int32_t o = __shfl_up(s, d, 64);
+      if (lane >= d) s += o;
+    }
+    if (lane == 63) wave_sums[wid] = s;
+    __syncthreads();
+    int32_t wave_off = 0;
+    for (int w = 0; w < wid; ++w) wave_off += wave_sums[w];
+    int32_t block_total = 0;
+    for (int w = 0; w < 16; ++w) block_total += wave_sums[w];
+    int32_t run = carry_s + wave_off + s - mine;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i0 + k < M) offsets[i0 + k] = run;
+      run += v[k];
+    }
+    __syncthreads();
+    if (tid == 0) carry_s += block_total;
+    __syncthreads();
+  }
+  if (tid == 0) *total = carry_s;
+}
+
+__global__ void __launch_bounds__(256)
+k_isect_scatter(int C, int N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
+                const float *__restrict__ depths, float tile_size, int tile_w, int tile_h,
+                const int32_t *__restrict__ offsets, int32_t *__restrict__ cursor, int64_t capacity,
+                uint64_t *__restrict__ key_buf, int32_t *__restrict__ overflow) {
+  const int64_t total = (int64_t)C * N;
+  const int n_tiles = tile_w * tile_h;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int r = radii[idx];
+    if (r <= 0) continue;
+    const float2 m = *reinterpret_cast<const float2 *>(means2d + 2 * idx);
+    const TileBox b = tile_box(m.x, m.y, (float)r, tile_size, tile_w, tile_h);
+    const uint64_t key = ((uint64_t)__float_as_uint(depths[idx]) << 32) | (uint64_t)(uint32_t)idx;
+    const int64_t row = (idx / N) * n_tiles;
+    for (int y = b.y0; y < b.y1; ++y)
+      for (int x = b.x0; x < b.x1; ++x) {
+        const int64_t t = row + y * tile_w + x;
+        const int64_t pos = (int64_t)offsets[t] + atomicAdd(cursor + t, 1);
+        if (pos < capacity) key_buf[pos] = key;
+        else if (overflow) *overflow = 1;
+      }
+  }
+}
+
+// Bitonic network with every comparison ascending ("flip" then "disperse" steps): elements past
+// n behave as +inf and never move, so ragged sizes need no padding.
+template <int THREADS>
+__device__ __forceinline__ void bitonic_sort_shared(uint64_t *keys, int n) {
+  int np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  const int half = np2 >> 1;
+  for (int k = 2; k <= np2; k <<= 1) {
+    const int hk = k >> 1;
+    for (int i = threadIdx.x; i < half; i += THREADS) {  // flip
+      const int blk = i / hk, off = i - blk * hk;
+      const int a = blk * k + off, b = blk * k + k - 1 - off;
+      if (b < n) {
+        const uint64_t ka = keys[a], kb = keys[b];
+        if (ka > kb) { keys[a] = kb; keys[b] = ka; }
+      }
+    }
+    __syncthreads();
+    for (int j = hk >> 1; j >= 1; j >>= 1) {  // disperse
+      for (int i = threadIdx.x; i < half; i += THREADS) {
+        const int a = (i / j) * 2 * j + (i % j), b = a + j;
+        if (b < n) {
+          const uint64_t ka = keys[a], kb = keys[b];
+          if (ka > kb) { keys[a] = kb; keys[b] = ka; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__device__ __forceinline__ void tile_range(int64_t t, int64_t M, const int32_t *offsets, const int32_t *n_isects,
+                                           int64_t capacity, int64_t &lo, int64_t &hi) {
+  lo = offsets[t];
+  hi = (t == M - 1) ? (int64_t)*n_isects : (int64_t)offsets[t + 1];
+  if (hi > capacity) hi = capacity;
+  if (lo > hi) lo = hi;
+}
+
+__device__ __forceinline__ void write_sorted(uint64_t key, int64_t pos, int64_t t, int n_tiles, int tile_bits,
+                                             int32_t *flatten_ids, int64_t *isect_ids) {
+  flatten_ids[pos] = (int32_t)(uint32_t)(key & 0xffffffffull);
+  if (isect_ids) {
+    const int64_t cam = t / n_tiles, tile = t - cam * n_tiles;
+    isect_ids[pos] = (cam << (32 + tile_bits)) | (tile << 32) | (int64_t)(key >> 32);
+  }
+}
+
+// LDS sort for lists with MIN_LEN < L <= CAP (CAP keys of 8 B in LDS)
+template <int THREADS, int CAP, int MIN_LEN>
+__global__ void __launch_bounds__(THREADS)
+k_tile_sort_lds(int64_t M, int n_tiles, int tile_bits, const int32_t *__restrict__ offsets,
+                const int32_t *__restrict__ n_isects, int64_t capacity, const uint64_t *__restrict__ key_buf,
+                int32_t *__restrict__ flatten_ids, int64_t *__restrict__ isect_ids) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
+  for (int64_t t = blockIdx.x; t < M; t += gridDim.x) {
+    int64_t lo, hi;
+    tile_range(t, M, offsets, n_isects, capacity, lo, hi);
+    const int64_t L = hi - lo;
+    if (L <= MIN_LEN || L > CAP) continue;
+    for (int i = threadIdx.x; i < L; i += THREADS) s_keys[i] = key_buf[lo + i];
+    __syncthreads();
+    bitonic_sort_shared<THREADS>(s_keys, (int)L);
+    for (int i = threadIdx.x; i < L; i += THREADS) write_sorted(s_keys[i], lo + i, t, n_tiles, tile_bits, flatten_ids, isect_ids);
+    __syncthreads();
+  }
+}
+
+// Fallback for lists longer than the LDS capacity: the same network on the global key buffer
+// (one workgroup per tile; rare: > CAP Gaussians overlapping one 16x16 tile).
+template <int THREADS, int CAP>
+__global__ void __launch_bounds__(THREADS)
+k_tile_sort_global(int64_t M, int n_tiles, int tile_bits, const int32_t *__restrict__ offsets,
+                   const int32_t *__restrict__ n_isects, int64_t capacity, uint64_t *__restrict__ key_buf,
+                   int32_t *__restrict__ flatten_ids, int64_t *__restrict__ isect_ids) {
+  for (int64_t t = blockIdx.x; t < M; t += gridDim.x) {
+    int64_t lo, hi;
+    tile_range(t, M, offsets, n_isects, capacity, lo, hi);
+    const int64_t n = hi - lo;
+    if (n <= CAP) continue;
+    uint64_t *keys = key_buf + lo;
+    int64_t np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    const int64_t half = np2 >> 1;
+    for (int64_t k = 2; k <= np2; k <<= 1) {
+      const int64_t hk = k >> 1;
+      for (int64_t i = threadIdx.x; i < half; i += THREADS) {
+        const int64_t blk = i / hk, off = i - blk * hk;
+        const int64_t a = blk * k + off, b = blk * k + k - 1 - off;
+        if (b < n) {
+          const uint64_t ka = keys[a], kb = keys[b];
+          if (ka > kb) { keys[a] = kb; keys[b] = ka; }
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+      for (int64_t j = hk >> 1; j >= 1; j >>= 1) {
+        for (int64_t i = threadIdx.x; i < half; i += THREADS) {
+          const int64_t a = (i / j) * 2 * j + (i % j), b = a + j;
+          if (b < n) {
+            const uint64_t ka = keys[a], kb = keys[b];
+            if (ka > kb) { keys[a] = kb; keys[b] = ka; }
+          }
+        }
+        __threadfence_block();
+        __syncthreads();
+      }
+    }
+    for (int64_t i = threadIdx.x; i < n; i += THREADS) write_sorted(keys[i], lo + i, t, n_tiles, tile_bits, flatten_ids, isect_ids);
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_isect_emit_unsorted(int C, int N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
+                      const float *__restrict__ depths, const int64_t *__restrict__ cum_tiles, float tile_size,
+                      int tile_w, int tile_h, int tile_bits, int64_t *__restrict__ isect_ids,
+                      int32_t *__restrict__ flatten_ids) {
+  const int64_t total = (int64_t)C * N;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int r = radii[idx];
+    if (r <= 0) continue;
+    const float2 m = *reinterpret_cast<const float2 *>(means2d + 2 * idx);
+    const TileBox b = tile_box(m.x, m.y, (float)r, tile_size, tile_w, tile_h);
+    int64_t cur = (idx == 0) ? 0 : cum_tiles[idx - 1];
+    const int64_t cam_enc = (idx / N) << (32 + tile_bits);
+    const int64_t dbits = (int64_t)__float_as_uint(depths[idx]);
+    for (int y = b.y0; y < b.y1; ++y)
+      for (int x = b.x0; x < b.x1; ++x) {
+        isect_ids[cur] = cam_enc | ((int64_t)(y * tile_w + x) << 32) | dbits;
+        flatten_ids[cur] = (int32_t)idx;
+        ++cur;
+      }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_isect_offset_encode(int64_t n_isects, const int64_t *__restrict__ isect_ids, int C, int n_tiles, int tile_bits,
+                      int32_t *__restrict__ offsets) {
+  const int64_t M = (int64_t)C * n_tiles;
+  const int64_t tile_mask = ((int64_t)1 << tile_bits) - 1;
+  // offsets[t] = lower_bound of t in the sorted (camera, tile) sequence
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < M; t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t lo = 0, hi = n_isects;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      const int64_t key = isect_ids[mid] >> 32;
+      const int64_t lin = (key >> tile_bits) * n_tiles + (key & tile_mask);
+      if (lin < t) lo = mid + 1; else hi = mid;
+    }
+    offsets[t] = (int32_t)lo;
+  }
+}
+
+static inline int tile_bits_of(int n_tiles) {
+  int b = 0;
+  while ((1 << b) <= n_tiles) ++b;  // floor(log2(n)) + 1
+  return n_tiles > 0 ? b : 0;
+}
+
+static inline int grid_1d(int64_t total, int block, int cap = 4096) {
+  int64_t g = ceil_div(total, block);
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace so
+
+extern "C" int so_isect_count(int C, int N, const float *means2d, const int32_t *radii, int tile_size,
+                              int tile_width, int tile_height, int32_t *tiles_per_gauss, int32_t *tile_counts,
+                              int32_t *isect_offsets, int32_t *n_isects, void *stream) {
+  SO_REQUIRE(C >= 0 && N >= 0 && tile_size > 0 && tile_width > 0 && tile_height > 0, "so_isect_count: bad sizes");
+  SO_REQUIRE(tile_counts && isect_offsets && n_isects, "so_isect_count: null pointer");
+  SO_REQUIRE((int64_t)C * N < ((int64_t)1 << 31), "so_isect_count: C*N must fit int32 flatten ids");
+  hipStream_t st = so::as_stream(stream);
+  const int64_t M = (int64_t)C * tile_width * tile_height;
+  if ((int64_t)C * N > 0) {
+    SO_REQUIRE(means2d && radii && tiles_per_gauss, "so_isect_count: null pointer");
+    hipLaunchKernelGGL(so::k_isect_count, dim3(so::grid_1d((int64_t)C * N, 256)), dim3(256), 0, st, C, N, means2d,
+                       radii, (float)tile_size, tile_width, tile_height, tiles_per_gauss, tile_counts);
+  }
+  hipLaunchKernelGGL(so::k_scan_tiles, dim3(1), dim3(1024), 0, st, M, tile_counts, isect_offsets, n_isects);
+  return so::check_launch("so_isect_count");
+}
+
+extern "C" int so_isect_fill(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
+                             int tile_size, int tile_width, int tile_height, const int32_t *isect_offsets,
+                             const int32_t *n_isects, int32_t *tile_cursor, int64_t capacity, uint64_t *key_buf,
+                             int32_t *flatten_ids, int64_t *isect_ids, int32_t *overflow, void *stream) {
+  SO_REQUIRE(C >= 0 && N >= 0 && tile_size > 0 && tile_width > 0 && tile_height > 0 && capacity >= 0,
+             "so_isect_fill: bad sizes");
+  if ((int64_t)C * N == 0 || capacity == 0) return SO_OK;
+  SO_REQUIRE(means2d && radii && depths && isect_offsets && n_isects && tile_cursor && key_buf && flatten_ids,
+             "so_isect_fill: null pointer");
+  hipStream_t st = so::as_stream(stream);
+  const int n_tiles = tile_width * tile_height;
+  const int64_t M = (int64_t)C * n_tiles;
+  const int tb = so::tile_bits_of(n_tiles);
+  hipLaunchKernelGGL(so::k_isect_scatter, dim3(so::grid_1d((int64_t)C * N, 256)), dim3(256), 0, st, C, N, means2d,
+                     radii, depths, (float)tile_size, tile_width, tile_height, isect_offsets, tile_cursor, capacity,
+                     key_buf, overflow);
+  const int gridM = (int)(M < 65535 * 8 ? M : 65535 * 8);
+  static bool lds_attr_set = false;  // 128 KiB of dynamic LDS needs an explicit opt-in
+  if (!lds_attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&so::k_tile_sort_lds<1024, 16384, 1024>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8) != hipSuccess) {
+      (void)hipGetLastError();
+    }
+    lds_attr_set = true;
+  }
+  // small lists: 256 threads, up to 1024 keys (8 KiB LDS) -> many workgroups per CU
+  hipLaunchKernelGGL((so::k_tile_sort_lds<256, 1024, 0>), dim3(gridM), dim3(256), 1024 * 8, st, M, n_tiles, tb,
+                     isect_offsets, n_isects, capacity, key_buf, flatten_ids, isect_ids);
+  // long lists: 1024 threads, up to 16384 keys (128 KiB LDS)
+  hipLaunchKernelGGL((so::k_tile_sort_lds<1024, 16384, 1024>), dim3(gridM), dim3(1024), 16384 * 8, st, M, n_tiles,
+                     tb, isect_offsets, n_isects, capacity, key_buf, flatten_ids, isect_ids);
+  // pathological lists: global-memory network
+  hipLaunchKernelGGL((so::k_tile_sort_global<1024, 16384>), dim3(gridM), dim3(1024), 0, st, M, n_tiles, tb,
+                     isect_offsets, n_isects, capacity, key_buf, flatten_ids, isect_ids);
+  return so::check_launch("so_isect_fill");
+}
+
+extern "C" int so_isect_emit_unsorted(int C, int N, const float *means2d, const int32_t *radii,
+                                      const float *depths, const int64_t *cum_tiles, int tile_size,
+                                      int tile_width, int tile_height, int64_t *isect_ids, int32_t *flatten_ids,
+                                      void *stream) {
+  SO_REQUIRE(C >= 0 && N >= 0 && tile_size > 0 && tile_width > 0 && tile_height > 0, "so_isect_emit_unsorted: bad sizes");
+  if ((int64_t)C * N == 0) return SO_OK;
+  SO_REQUIRE(means2d && radii && depths && cum_tiles && isect_ids && flatten_ids, "so_isect_emit_unsorted: null pointer");
+  const int tb = so::tile_bits_of(tile_width * tile_height);
+  hipLaunchKernelGGL(so::k_isect_emit_unsorted, dim3(so::grid_1d((int64_t)C * N, 256)), dim3(256), 0,
+                     so::as_stream(stream), C, N, means2d, radii, depths, cum_tiles, (float)tile_size, tile_width,
+                     tile_height, tb, isect_ids, flatten_ids);
+  return so::check_launch("so_isect_emit_unsorted");
+}
+
+extern "C" int so_isect_offset_encode(int64_t n_isects, const int64_t *isect_ids, int C, int tile_width,
+                                      int tile_height, int32_t *isect_offsets, void *stream) {
+  SO_REQUIRE(n_isects >= 0 && C >= 0 && tile_width > 0 && tile_height > 0, "so_isect_offset_encode: bad sizes");
+  if (C == 0) return SO_OK;
+  SO_REQUIRE(isect_offsets && (n_isects == 0 || isect_ids), "so_isect_offset_encode: null pointer");
+  const int n_tiles = tile_width * tile_height;
+  hipLaunchKernelGGL(so::k_isect_offset_encode, dim3(so::grid_1d((int64_t)C * n_tiles, 256)), dim3(256), 0,
+                     so::as_stream(stream), n_isects, isect_ids, C, n_tiles, so::tile_bits_of(n_tiles), isect_offsets);
+  return so::check_launch("so_isect_offset_encode");
+}

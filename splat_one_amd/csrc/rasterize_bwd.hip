@@ -1,0 +1,234 @@
+// rasterize_bwd.hip -- K10: backward of the tile rasteriser, one workgroup per tile (gfx950).
+//
+// Replaces gsplat `rasterize_to_pixels` backward (`loss.backward()` at
+// /root/reference/utils/gsplat_utils/gsplat_trainer.py:655).  Algorithm: SURVEY.md B.2.
+//
+// Each pixel walks its tile list back to front from `last_ids`, rebuilding T; per-pixel gradient
+// contributions are summed over the wave with DPP row reductions (no LDS round trip) and one lane
+// per wave issues the float atomics.  As in the forward, a wave first ballots which staged
+// Gaussians can touch its 8x8 quadrant at all and only walks those; whole batches behind the
+// tile's last contributor are never loaded.
+#include "rasterize_common.hpp"
+
+namespace so {
+
+template <int D, int TS, bool ABS>
+__global__ void __launch_bounds__(TS *TS)
+k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2 *__restrict__ means2d,
+                const float *__restrict__ conics, const float *__restrict__ colors,
+                const float *__restrict__ opacities, const float *__restrict__ backgrounds,
+                const uint8_t *__restrict__ tile_masks, const int32_t *__restrict__ offsets,
+                const int32_t *__restrict__ flatten_ids, const int32_t *__restrict__ n_isects_dev,
+                int64_t n_isects_host, const float *__restrict__ render_alphas,
+                const int32_t *__restrict__ last_ids, const float *__restrict__ v_render_colors,
+                const float *__restrict__ v_render_alphas, float *__restrict__ v_means2d,
+                float *__restrict__ v_means2d_abs, float *__restrict__ v_conics, float *__restrict__ v_colors,
+                float *__restrict__ v_opacities) {
+  constexpr int BLOCK = TS * TS;
+  constexpr int NWAVES = (BLOCK + 63) / 64;
+  __shared__ float4 s_xyoa[BLOCK];
+  __shared__ float2 s_bc[BLOCK];
+  __shared__ float4 s_box[BLOCK];
+  __shared__ float s_col[BLOCK * D];
+  __shared__ int32_t s_id[BLOCK];
+  __shared__ int32_t s_wave_last[NWAVES];
+
+  const int n_tiles = tile_w * tile_h;
+  const int64_t M = (int64_t)C * n_tiles;
+  const int64_t ct = xcd_remap(blockIdx.x, M);
+  if (tile_masks && !tile_masks[ct]) return;
+  const int c = (int)(ct / n_tiles);
+  const int t = (int)(ct - (int64_t)c * n_tiles);
+  const int ty = t / tile_w, tx = t - ty * tile_w;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  int lx, ly, wx0, wy0;
+  PixelMap<TS>::get(tid, lx, ly, wx0, wy0);
+  const int j = tx * TS + lx, i = ty * TS + ly;
+  const bool inside = (i < H) && (j < W);
+  const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+  const int64_t pix = ((int64_t)c * H + i) * W + j;
+  const float qx0 = (float)(tx * TS + wx0) + 0.5f, qx1 = qx0 + 7.f;
+  const float qy0 = (float)(ty * TS + wy0) + 0.5f, qy1 = qy0 + 7.f;
+
+  const int64_t n_isects = n_isects_dev ? (int64_t)*n_isects_dev : n_isects_host;
+  int64_t lo = offsets[ct];
+  int64_t hi = (ct == M - 1) ? n_isects : (int64_t)offsets[ct + 1];
+  if (hi > n_isects) hi = n_isects;
+  if (hi <= lo) return;  // uniform over the block
+
+  const float T_final = inside ? 1.f - render_alphas[pix] : 1.f;
+  float T = T_final;
+  float buffer[D], v_c[D];
+  float bg_dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    buffer[k] = 0.f;
+    v_c[k] = inside ? v_render_colors[pix * D + k] : 0.f;
+    if (backgrounds) bg_dot += backgrounds[c * D + k] * v_c[k];
+  }
+  const float v_a = inside ? v_render_alphas[pix] : 0.f;
+  // last contributor of this pixel; pixels that nothing reached keep lo-1 (no Gaussian valid)
+  int32_t bin_final = (int32_t)lo - 1;
+  if (inside && T_final < 1.f) bin_final = last_ids[pix];
+  // wave / block maxima
+  int32_t wave_last = bin_final;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, d, 64));
+  if (lane == 0) s_wave_last[wid] = wave_last;
+  __syncthreads();
+  int32_t block_last = s_wave_last[0];
+#pragma unroll
+  for (int w = 1; w < NWAVES; ++w) block_last = max(block_last, s_wave_last[w]);
+  if (block_last < lo) return;  // uniform
+
+  for (int64_t batch_end = block_last; batch_end >= lo; batch_end -= BLOCK) {
+    __syncthreads();
+    const int64_t idx = batch_end - tid;
+    if (idx >= lo) {
+      const int32_t g = flatten_ids[idx];
+      const float2 xy = means2d[g];
+      const float op = opacities[g];
+      const float ca = conics[3 * (int64_t)g], cb = conics[3 * (int64_t)g + 1], cc = conics[3 * (int64_t)g + 2];
+      s_id[tid] = g;
+      s_xyoa[tid] = make_float4(xy.x, xy.y, op, ca);
+      s_bc[tid] = make_float2(cb, cc);
+      s_box[tid] = alpha_bound_box(xy.x, xy.y, op, ca, cb, cc);
+#pragma unroll
+      for (int k = 0; k < D; ++k) s_col[tid * D + k] = colors[(int64_t)g * D + k];
+    }
+    __syncthreads();
+    const int batch_size = (int)((batch_end + 1 - lo) < BLOCK ? (batch_end + 1 - lo) : BLOCK);
+#pragma unroll 1
+    for (int chunk = 0; chunk < NWAVES; ++chunk) {
+      const int cand = chunk * 64 + lane;
+      bool hit = false;
+      if (cand < batch_size && batch_end - cand <= wave_last) {
+        const float4 bx = s_box[cand];
+        hit = !(bx.y < qx0 || bx.x > qx1 || bx.w < qy0 || bx.z > qy1);
+      }
+      unsigned long long mask = __ballot(hit);
+      while (mask) {
+        const int bit = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const int tt = chunk * 64 + bit;
+        const float4 a = s_xyoa[tt];
+        const float2 bc = s_bc[tt];
+        const float opac = a.z;
+        const float dx = a.x - px, dy = a.y - py;
+        const float sigma = 0.5f * (a.w * dx * dx + bc.y * dy * dy) + bc.x * dx * dy;
+        const float vis = __expf(-sigma);
+        const float alpha = fminf(kAlphaMax, opac * vis);
+        const bool valid = inside && (batch_end - tt <= bin_final) && !(sigma < 0.f || alpha < kAlphaMin);
+        if (__ballot(valid) == 0ull) continue;
+        float g_col[D];
+        float g_cx = 0.f, g_cy = 0.f, g_cz = 0.f, g_x = 0.f, g_y = 0.f, g_ax = 0.f, g_ay = 0.f, g_op = 0.f;
+#pragma unroll
+        for (int k = 0; k < D; ++k) g_col[k] = 0.f;
+        if (valid) {
+          const float ra = 1.f / (1.f - alpha);
+          T *= ra;
+          const float fac = alpha * T;
+          float v_alpha = 0.f;
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
+            const float ck = s_col[tt * D + k];
+            g_col[k] = fac * v_c[k];
+            v_alpha += (ck * T - buffer[k] * ra) * v_c[k];
+            buffer[k] += ck * fac;
+          }
+          v_alpha += T_final * ra * v_a;
+          v_alpha -= T_final * ra * bg_dot;
+          if (opac * vis <= kAlphaMax) {
+            const float v_sigma = -opac * vis * v_alpha;
+            g_cx = 0.5f * v_sigma * dx * dx;
+            g_cy = v_sigma * dx * dy;
+            g_cz = 0.5f * v_sigma * dy * dy;
+            g_x = v_sigma * (a.w * dx + bc.x * dy);
+            g_y = v_sigma * (bc.x * dx + bc.y * dy);
+            if (ABS) { g_ax = fabsf(g_x); g_ay = fabsf(g_y); }
+            g_op = vis * v_alpha;
+          }
+        }
+        // wave sums land in lane 63
+#pragma unroll
+        for (int k = 0; k < D; ++k) g_col[k] = wave_reduce_sum_to_last(g_col[k]);
+        g_cx = wave_reduce_sum_to_last(g_cx);
+        g_cy = wave_reduce_sum_to_last(g_cy);
+        g_cz = wave_reduce_sum_to_last(g_cz);
+        g_x = wave_reduce_sum_to_last(g_x);
+        g_y = wave_reduce_sum_to_last(g_y);
+        if (ABS) { g_ax = wave_reduce_sum_to_last(g_ax); g_ay = wave_reduce_sum_to_last(g_ay); }
+        g_op = wave_reduce_sum_to_last(g_op);
+        if (lane == 63) {
+          const int64_t g = s_id[tt];
+#pragma unroll
+          for (int k = 0; k < D; ++k) atomicAdd(v_colors + g * D + k, g_col[k]);
+          atomicAdd(v_conics + 3 * g, g_cx);
+          atomicAdd(v_conics + 3 * g + 1, g_cy);
+          atomicAdd(v_conics + 3 * g + 2, g_cz);
+          atomicAdd(v_means2d + 2 * g, g_x);
+          atomicAdd(v_means2d + 2 * g + 1, g_y);
+          if (ABS) {
+            atomicAdd(v_means2d_abs + 2 * g, g_ax);
+            atomicAdd(v_means2d_abs + 2 * g + 1, g_ay);
+          }
+          atomicAdd(v_opacities + g, g_op);
+        }
+      }
+    }
+  }
+}
+
+template <int D>
+static int launch_bwd(int TS, bool abs_, dim3 grid, hipStream_t st, int C, int N, int W, int H, int tile_w, int tile_h,
+                      const float *means2d, const float *conics, const float *colors, const float *opacities,
+                      const float *backgrounds, const uint8_t *tile_masks, const int32_t *offsets,
+                      const int32_t *flatten_ids, const int32_t *n_dev, int64_t n_host, const float *ra,
+                      const int32_t *last, const float *v_rc, const float *v_ra, float *v_m, float *v_abs, float *v_cn,
+                      float *v_col, float *v_op) {
+  const float2 *m2 = reinterpret_cast<const float2 *>(means2d);
+#define SO_GO(TSV, ABSV)                                                                                         \
+  hipLaunchKernelGGL((k_rasterize_bwd<D, TSV, ABSV>), grid, dim3(TSV * TSV), 0, st, C, N, W, H, tile_w, tile_h, \
+                     m2, conics, colors, opacities, backgrounds, tile_masks, offsets, flatten_ids, n_dev,       \
+                     n_host, ra, last, v_rc, v_ra, v_m, v_abs, v_cn, v_col, v_op)
+  if (TS == 16) { if (abs_) SO_GO(16, true); else SO_GO(16, false); }
+  else          { if (abs_) SO_GO(8, true);  else SO_GO(8, false); }
+#undef SO_GO
+  return check_launch("so_rasterize_bwd");
+}
+
+}  // namespace so
+
+extern "C" int so_rasterize_bwd(int C, int N, int D, int width, int height, int tile_size, const float *means2d,
+                                const float *conics, const float *colors, const float *opacities,
+                                const float *backgrounds, const uint8_t *tile_masks,
+                                const int32_t *isect_offsets, const int32_t *flatten_ids,
+                                const int32_t *n_isects_dev, int64_t n_isects_host, const float *render_alphas,
+                                const int32_t *last_ids, const float *v_render_colors,
+                                const float *v_render_alphas, float *v_means2d, float *v_means2d_abs,
+                                float *v_conics, float *v_colors, float *v_opacities, void *stream) {
+  SO_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, "so_rasterize_bwd: bad sizes");
+  SO_REQUIRE(tile_size == 16 || tile_size == 8, "so_rasterize_bwd: tile_size %d not in {8,16}", tile_size);
+  if (C == 0 || N == 0) return SO_OK;
+  SO_REQUIRE(means2d && conics && colors && opacities && isect_offsets && render_alphas && last_ids &&
+                 v_render_colors && v_render_alphas && v_means2d && v_conics && v_colors && v_opacities,
+             "so_rasterize_bwd: null pointer");
+  SO_REQUIRE(n_isects_dev || n_isects_host == 0 || flatten_ids, "so_rasterize_bwd: null flatten_ids");
+  const int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
+  const dim3 grid((unsigned)((int64_t)C * tile_w * tile_h));
+  hipStream_t st = so::as_stream(stream);
+#define SO_CASE(DD)                                                                                             \
+  case DD:                                                                                                      \
+    return so::launch_bwd<DD>(tile_size, v_means2d_abs != nullptr, grid, st, C, N, width, height, tile_w,       \
+                              tile_h, means2d, conics, colors, opacities, backgrounds, tile_masks,              \
+                              isect_offsets, flatten_ids, n_isects_dev, n_isects_host, render_alphas, last_ids, \
+                              v_render_colors, v_render_alphas, v_means2d, v_means2d_abs, v_conics, v_colors,   \
+                              v_opacities);
+  switch (D) {
+    SO_CASE(1) SO_CASE(2) SO_CASE(3) SO_CASE(4) SO_CASE(5) SO_CASE(8) SO_CASE(9) SO_CASE(16) SO_CASE(17) SO_CASE(32) SO_CASE(33)
+    default:
+      so::set_error("so_rasterize_bwd: unsupported channel count D=%d", D);
+      return SO_ERR_UNSUPPORTED;
+  }
+#undef SO_CASE
+}

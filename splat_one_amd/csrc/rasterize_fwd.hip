@@ -1,0 +1,178 @@
+// rasterize_fwd.hip -- K9: front-to-back alpha compositing, one workgroup per tile (gfx950).
+//
+// Replaces gsplat `rasterize_to_pixels` forward (reached inside `rasterization`,
+// /root/reference/utils/gsplat_utils/gsplat_trainer.py:477).  Algorithm: SURVEY.md B.1 step 7.
+//
+// wave64 structure: a 16x16 tile is 4 waves, each owning an 8x8 pixel quadrant.  The tile's
+// depth-sorted list is staged through LDS in batches of one Gaussian per thread (coalesced read
+// of flatten_ids, gathered 36+4D B per Gaussian).  Each wave then tests 64 staged Gaussians at a
+// time against its quadrant (one lane per Gaussian, `__ballot`) and walks only the set bits, so
+// Gaussians that cannot reach alpha >= 1/255 anywhere in the quadrant cost one lane-compare
+// instead of 64 pixel evaluations.  The cull is exact: it never changes a pixel.
+#include "rasterize_common.hpp"
+
+namespace so {
+
+template <int D, int TS>
+__global__ void __launch_bounds__(TS *TS)
+k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2 *__restrict__ means2d,
+                const float *__restrict__ conics, const float *__restrict__ colors,
+                const float *__restrict__ opacities, const float *__restrict__ backgrounds,
+                const uint8_t *__restrict__ tile_masks, const int32_t *__restrict__ offsets,
+                const int32_t *__restrict__ flatten_ids, const int32_t *__restrict__ n_isects_dev,
+                int64_t n_isects_host, float *__restrict__ render_colors, float *__restrict__ render_alphas,
+                int32_t *__restrict__ last_ids) {
+  constexpr int BLOCK = TS * TS;
+  constexpr int NWAVE_CHUNK = (BLOCK + 63) / 64;
+  __shared__ float4 s_xyoa[BLOCK];  // x, y, opacity, conic a
+  __shared__ float2 s_bc[BLOCK];    // conic b, c
+  __shared__ float4 s_box[BLOCK];   // xmin, xmax, ymin, ymax of the alpha>=1/255 region
+  __shared__ float s_col[BLOCK * D];
+
+  const int n_tiles = tile_w * tile_h;
+  const int64_t M = (int64_t)C * n_tiles;
+  const int64_t ct = xcd_remap(blockIdx.x, M);
+  const int c = (int)(ct / n_tiles);
+  const int t = (int)(ct - (int64_t)c * n_tiles);
+  const int ty = t / tile_w, tx = t - ty * tile_w;
+  const int tid = threadIdx.x;
+  int lx, ly, wx0, wy0;
+  PixelMap<TS>::get(tid, lx, ly, wx0, wy0);
+  const int j = tx * TS + lx, i = ty * TS + ly;
+  const bool inside = (i < H) && (j < W);
+  const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+  const int64_t pix = ((int64_t)c * H + i) * W + j;
+  // pixel-centre extent of this wave's quadrant
+  const float qx0 = (float)(tx * TS + wx0) + 0.5f, qx1 = qx0 + 7.f;
+  const float qy0 = (float)(ty * TS + wy0) + 0.5f, qy1 = qy0 + 7.f;
+
+  if (tile_masks && !tile_masks[ct]) {
+    if (inside) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) render_colors[pix * D + k] = backgrounds ? backgrounds[c * D + k] : 0.f;
+      render_alphas[pix] = 0.f;
+      last_ids[pix] = 0;
+    }
+    return;
+  }
+
+  const int64_t n_isects = n_isects_dev ? (int64_t)*n_isects_dev : n_isects_host;
+  int64_t lo = offsets[ct];
+  int64_t hi = (ct == M - 1) ? n_isects : (int64_t)offsets[ct + 1];
+  if (hi > n_isects) hi = n_isects;
+  if (lo > hi) lo = hi;
+
+  float T = 1.f;
+  float acc[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) acc[k] = 0.f;
+  int32_t cur_idx = 0;
+  bool done = !inside;
+  const int lane = tid & 63;
+
+  for (int64_t batch_start = lo; batch_start < hi; batch_start += BLOCK) {
+    if (__syncthreads_and(done)) break;
+    const int64_t idx = batch_start + tid;
+    if (idx < hi) {
+      const int32_t g = flatten_ids[idx];
+      const float2 xy = means2d[g];
+      const float op = opacities[g];
+      const float ca = conics[3 * (int64_t)g], cb = conics[3 * (int64_t)g + 1], cc = conics[3 * (int64_t)g + 2];
+      s_xyoa[tid] = make_float4(xy.x, xy.y, op, ca);
+      s_bc[tid] = make_float2(cb, cc);
+      s_box[tid] = alpha_bound_box(xy.x, xy.y, op, ca, cb, cc);
+#pragma unroll
+      for (int k = 0; k < D; ++k) s_col[tid * D + k] = colors[(int64_t)g * D + k];
+    }
+    __syncthreads();
+    const int batch_size = (int)((hi - batch_start) < BLOCK ? (hi - batch_start) : BLOCK);
+#pragma unroll 1
+    for (int chunk = 0; chunk < NWAVE_CHUNK; ++chunk) {
+      const int cand = chunk * 64 + lane;
+      bool hit = false;
+      if (cand < batch_size) {
+        const float4 bx = s_box[cand];
+        hit = !(bx.y < qx0 || bx.x > qx1 || bx.w < qy0 || bx.z > qy1);
+      }
+      unsigned long long mask = __ballot(hit);
+      while (mask) {
+        if (__ballot(!done) == 0ull) { mask = 0; break; }
+        const int bit = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const int tt = chunk * 64 + bit;
+        if (!done) {
+          const float4 a = s_xyoa[tt];
+          const float2 bc = s_bc[tt];
+          const float dx = a.x - px, dy = a.y - py;
+          const float sigma = 0.5f * (a.w * dx * dx + bc.y * dy * dy) + bc.x * dx * dy;
+          const float alpha = fminf(kAlphaMax, a.z * __expf(-sigma));
+          if (!(sigma < 0.f || alpha < kAlphaMin)) {
+            const float next_T = T * (1.f - alpha);
+            if (next_T <= kTStop) {
+              done = true;
+            } else {
+              const float vis = alpha * T;
+#pragma unroll
+              for (int k = 0; k < D; ++k) acc[k] += s_col[tt * D + k] * vis;
+              cur_idx = (int32_t)(batch_start + tt);
+              T = next_T;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (inside) {
+    render_alphas[pix] = 1.f - T;
+#pragma unroll
+    for (int k = 0; k < D; ++k) render_colors[pix * D + k] = backgrounds ? acc[k] + T * backgrounds[c * D + k] : acc[k];
+    last_ids[pix] = cur_idx;
+  }
+}
+
+template <int D>
+static int launch_fwd(int TS, dim3 grid, hipStream_t st, int C, int N, int W, int H, int tile_w, int tile_h,
+                      const float *means2d, const float *conics, const float *colors, const float *opacities,
+                      const float *backgrounds, const uint8_t *tile_masks, const int32_t *offsets,
+                      const int32_t *flatten_ids, const int32_t *n_dev, int64_t n_host, float *rc, float *ra,
+                      int32_t *last) {
+  const float2 *m2 = reinterpret_cast<const float2 *>(means2d);
+  if (TS == 16)
+    hipLaunchKernelGGL((k_rasterize_fwd<D, 16>), grid, dim3(256), 0, st, C, N, W, H, tile_w, tile_h, m2, conics, colors,
+                       opacities, backgrounds, tile_masks, offsets, flatten_ids, n_dev, n_host, rc, ra, last);
+  else
+    hipLaunchKernelGGL((k_rasterize_fwd<D, 8>), grid, dim3(64), 0, st, C, N, W, H, tile_w, tile_h, m2, conics, colors,
+                       opacities, backgrounds, tile_masks, offsets, flatten_ids, n_dev, n_host, rc, ra, last);
+  return check_launch("so_rasterize_fwd");
+}
+
+}  // namespace so
+
+extern "C" int so_rasterize_fwd(int C, int N, int D, int width, int height, int tile_size, const float *means2d,
+                                const float *conics, const float *colors, const float *opacities,
+                                const float *backgrounds, const uint8_t *tile_masks,
+                                const int32_t *isect_offsets, const int32_t *flatten_ids,
+                                const int32_t *n_isects_dev, int64_t n_isects_host, float *render_colors,
+                                float *render_alphas, int32_t *last_ids, void *stream) {
+  SO_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, "so_rasterize_fwd: bad sizes");
+  SO_REQUIRE(tile_size == 16 || tile_size == 8, "so_rasterize_fwd: tile_size %d not in {8,16}", tile_size);
+  if (C == 0) return SO_OK;
+  SO_REQUIRE(isect_offsets && render_colors && render_alphas && last_ids, "so_rasterize_fwd: null pointer");
+  SO_REQUIRE(N == 0 || (means2d && conics && colors && opacities), "so_rasterize_fwd: null pointer");
+  SO_REQUIRE(n_isects_dev || n_isects_host == 0 || flatten_ids, "so_rasterize_fwd: null flatten_ids");
+  const int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
+  const dim3 grid((unsigned)((int64_t)C * tile_w * tile_h));
+  hipStream_t st = so::as_stream(stream);
+#define SO_CASE(DD)                                                                                              \
+  case DD:                                                                                                       \
+    return so::launch_fwd<DD>(tile_size, grid, st, C, N, width, height, tile_w, tile_h, means2d, conics, colors, \
+                              opacities, backgrounds, tile_masks, isect_offsets, flatten_ids, n_isects_dev,      \
+                              n_isects_host, render_colors, render_alphas, last_ids);
+  switch (D) {
+    SO_CASE(1) SO_CASE(2) SO_CASE(3) SO_CASE(4) SO_CASE(5) SO_CASE(8) SO_CASE(9) SO_CASE(16) SO_CASE(17) SO_CASE(32) SO_CASE(33)
+    default:
+      so::set_error("so_rasterize_fwd: unsupported channel count D=%d", D);
+      return SO_ERR_UNSUPPORTED;
+  }
+#undef SO_CASE
+}

@@ -13,8 +13,10 @@
 
 #if defined(__HIPCC__)
 #define SO_HD __host__ __device__ __forceinline__
+#define SO_UNROLL _Pragma("unroll")
 #else
 #define SO_HD inline
+#define SO_UNROLL
 #endif
 
 namespace so {
@@ -39,16 +41,22 @@ template <typename T> SO_HD T tmax(T a, T b) { return a > b ? a : b; }
 // small 3x3 helpers, row-major arrays  A[3*i+j]
 // ---------------------------------------------------------------------------------------------
 template <typename T> SO_HD void mat3_mul(const T *A, const T *B, T *C) {
+  SO_UNROLL
   for (int i = 0; i < 3; ++i)
+    SO_UNROLL
     for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
 }
 template <typename T> SO_HD void mat3_mul_bt(const T *A, const T *B, T *C) {  // C = A * B^T
+  SO_UNROLL
   for (int i = 0; i < 3; ++i)
+    SO_UNROLL
     for (int j = 0; j < 3; ++j)
       C[3 * i + j] = A[3 * i] * B[3 * j] + A[3 * i + 1] * B[3 * j + 1] + A[3 * i + 2] * B[3 * j + 2];
 }
 template <typename T> SO_HD void mat3_mul_at(const T *A, const T *B, T *C) {  // C = A^T * B
+  SO_UNROLL
   for (int i = 0; i < 3; ++i)
+    SO_UNROLL
     for (int j = 0; j < 3; ++j) C[3 * i + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
 }
 
@@ -65,7 +73,9 @@ template <typename T> SO_HD void quat_to_rotmat(const T *q, T *R, T *qn, T &inv_
 // Sigma = (R S)(R S)^T ; M = R S is returned for the backward.
 template <typename T> SO_HD void quat_scale_to_covar(const T *q, const T *s, T *cov, T *M, T *Rq, T *qn, T &inv_norm) {
   quat_to_rotmat(q, Rq, qn, inv_norm);
+  SO_UNROLL
   for (int i = 0; i < 3; ++i)
+    SO_UNROLL
     for (int j = 0; j < 3; ++j) M[3 * i + j] = Rq[3 * i + j] * s[j];
   mat3_mul_bt(M, M, cov);
 }
@@ -121,7 +131,9 @@ SO_HD void camera_project(int model, const T *mc, T fx, T fy, T cx, T cy, int W,
 // cov2d = J cov_c J^T  -> (a, b, d)
 template <typename T> SO_HD void project_cov(const T *J, const T *cc, T &a, T &b, T &d) {
   T JC[6];
+  SO_UNROLL
   for (int i = 0; i < 2; ++i)
+    SO_UNROLL
     for (int j = 0; j < 3; ++j) JC[3 * i + j] = J[3 * i] * cc[j] + J[3 * i + 1] * cc[3 + j] + J[3 * i + 2] * cc[6 + j];
   a = JC[0] * J[0] + JC[1] * J[1] + JC[2] * J[2];
   b = JC[0] * J[3] + JC[1] * J[4] + JC[2] * J[5];
@@ -145,6 +157,7 @@ SO_HD void project_fwd(const T *mean, const T *covar6, const T *quat, const T *s
   o.radius = 0;
   o.m2d[0] = o.m2d[1] = o.depth = o.conic[0] = o.conic[1] = o.conic[2] = o.comp = 0;
   T mc[3];
+  SO_UNROLL
   for (int i = 0; i < 3; ++i) mc[i] = Rw[3 * i] * mean[0] + Rw[3 * i + 1] * mean[1] + Rw[3 * i + 2] * mean[2] + tw[i];
   if (mc[2] < near_plane || mc[2] > far_plane) return;
   T cov[9];
@@ -193,6 +206,7 @@ SO_HD void project_bwd(const T *mean, const T *covar6, const T *quat, const T *s
                        const T *v_m2d, T v_depth, const T *v_conic, T v_comp,
                        T *v_mean, T *v_covar6, T *v_quat, T *v_scale, T *v_Rw, T *v_tw) {
   T mc[3];
+  SO_UNROLL
   for (int i = 0; i < 3; ++i) mc[i] = Rw[3 * i] * mean[0] + Rw[3 * i + 1] * mean[1] + Rw[3 * i + 2] * mean[2] + tw[i];
   T cov[9], M[9], Rq[9], qn[4], inv_norm = 1;
   if (covar6) {
@@ -235,15 +249,20 @@ SO_HD void project_bwd(const T *mean, const T *covar6, const T *quat, const T *s
   }
   // v_cc = J^T Vx J (3x3 symmetric) ; v_J = 2 Vx J cc (2x3)
   T VJ[6];  // Vx * J
+  SO_UNROLL
   for (int j = 0; j < 3; ++j) {
     VJ[j] = Vxa * J[j] + Vxb * J[3 + j];
     VJ[3 + j] = Vxb * J[j] + Vxd * J[3 + j];
   }
   T v_cc[9];
+  SO_UNROLL
   for (int i = 0; i < 3; ++i)
+    SO_UNROLL
     for (int j = 0; j < 3; ++j) v_cc[3 * i + j] = J[i] * VJ[j] + J[3 + i] * VJ[3 + j];
   T v_J[6];
+  SO_UNROLL
   for (int i = 0; i < 2; ++i)
+    SO_UNROLL
     for (int j = 0; j < 3; ++j)
       v_J[3 * i + j] = 2 * (VJ[3 * i] * cc[j] + VJ[3 * i + 1] * cc[3 + j] + VJ[3 * i + 2] * cc[6 + j]);
   // camera model VJP -> v_mc
@@ -314,12 +333,15 @@ SO_HD void project_bwd(const T *mean, const T *covar6, const T *quat, const T *s
     v_mc[0] += vx; v_mc[1] += vy; v_mc[2] += vz;
   }
   // world -> camera
+  SO_UNROLL
   for (int j = 0; j < 3; ++j) v_mean[j] += Rw[j] * v_mc[0] + Rw[3 + j] * v_mc[1] + Rw[6 + j] * v_mc[2];
   T t2[9], v_cov[9];
   mat3_mul_at(Rw, v_cc, t2);   // Rw^T v_cc
   mat3_mul(t2, Rw, v_cov);     // Rw^T v_cc Rw
   if (v_Rw) {
+    SO_UNROLL
     for (int i = 0; i < 3; ++i) {
+      SO_UNROLL
       for (int j = 0; j < 3; ++j) v_Rw[3 * i + j] += v_mc[i] * mean[j];
       v_tw[i] += v_mc[i];
     }
@@ -327,6 +349,7 @@ SO_HD void project_bwd(const T *mean, const T *covar6, const T *quat, const T *s
     T rc[9], add[9];
     mat3_mul(Rw, cov, rc);
     mat3_mul(v_cc, rc, add);
+    SO_UNROLL
     for (int i = 0; i < 9; ++i) v_Rw[i] += 2 * add[i];
   }
   if (covar6) {
@@ -337,10 +360,14 @@ SO_HD void project_bwd(const T *mean, const T *covar6, const T *quat, const T *s
   // cov = M M^T -> v_M = 2 v_cov M
   T v_M[9];
   mat3_mul(v_cov, M, v_M);
+  SO_UNROLL
   for (int i = 0; i < 9; ++i) v_M[i] *= 2;
   T G[9];
+  SO_UNROLL
   for (int i = 0; i < 3; ++i)
+    SO_UNROLL
     for (int j = 0; j < 3; ++j) G[3 * i + j] = v_M[3 * i + j] * scale[j];   // v_Rq
+  SO_UNROLL
   for (int j = 0; j < 3; ++j) v_scale[j] += Rq[j] * v_M[j] + Rq[3 + j] * v_M[3 + j] + Rq[6 + j] * v_M[6 + j];
   const T w = qn[0], qx = qn[1], qy = qn[2], qz = qn[3];
   T vq[4];
@@ -349,77 +376,56 @@ SO_HD void project_bwd(const T *mean, const T *covar6, const T *quat, const T *s
   vq[2] = 2 * (-2 * qy * G[0] + qx * G[1] + w * G[2] + qx * G[3] + qz * G[5] - w * G[6] + qz * G[7] - 2 * qy * G[8]);
   vq[3] = 2 * (-2 * qz * G[0] - w * G[1] + qx * G[2] + w * G[3] - 2 * qz * G[4] + qy * G[5] + qx * G[6] + qy * G[7]);
   const T dot = vq[0] * w + vq[1] * qx + vq[2] * qy + vq[3] * qz;
+  SO_UNROLL
   for (int k = 0; k < 4; ++k) v_quat[k] += (vq[k] - dot * qn[k]) * inv_norm;
 }
 
 // ---------------------------------------------------------------------------------------------
 // spherical harmonics (3DGS sign convention), degree <= 4
 // ---------------------------------------------------------------------------------------------
-// bases Y[k] for the unit vector (x,y,z); when dY != null also dY[k][3] = gradient w.r.t. (x,y,z)
-// of the polynomial form (tangential part is what survives the normalisation backward).
-template <typename T> SO_HD void sh_bases(int degree, T x, T y, T z, T *Y, T (*dY)[3]) {
-  Y[0] = T(kShC0);
-  if (dY) { dY[0][0] = dY[0][1] = dY[0][2] = 0; }
+// Calls f(k, Y_k, dY_k/dx, dY_k/dy, dY_k/dz) for every basis k < (degree+1)^2 of the unit vector
+// (x,y,z).  The derivatives are those of the polynomial form (their tangential part is what
+// survives the normalisation backward); unused values are dead-code-eliminated after inlining.
+template <typename T, typename F> SO_HD void sh_eval(int degree, T x, T y, T z, F &&f) {
+  f(0, T(kShC0), T(0), T(0), T(0));
   if (degree < 1) return;
   const T c1 = T(kShC1);
-  Y[1] = -c1 * y; Y[2] = c1 * z; Y[3] = -c1 * x;
-  if (dY) {
-    dY[1][0] = 0; dY[1][1] = -c1; dY[1][2] = 0;
-    dY[2][0] = 0; dY[2][1] = 0; dY[2][2] = c1;
-    dY[3][0] = -c1; dY[3][1] = 0; dY[3][2] = 0;
-  }
+  f(1, -c1 * y, T(0), T(-c1), T(0));
+  f(2, c1 * z, T(0), T(0), T(c1));
+  f(3, -c1 * x, T(-c1), T(0), T(0));
   if (degree < 2) return;
   const T xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-  Y[4] = T(kShC2[0]) * xy;
-  Y[5] = T(kShC2[1]) * yz;
-  Y[6] = T(kShC2[2]) * (2 * zz - xx - yy);
-  Y[7] = T(kShC2[3]) * xz;
-  Y[8] = T(kShC2[4]) * (xx - yy);
-  if (dY) {
-    dY[4][0] = T(kShC2[0]) * y; dY[4][1] = T(kShC2[0]) * x; dY[4][2] = 0;
-    dY[5][0] = 0; dY[5][1] = T(kShC2[1]) * z; dY[5][2] = T(kShC2[1]) * y;
-    dY[6][0] = T(kShC2[2]) * (-2 * x); dY[6][1] = T(kShC2[2]) * (-2 * y); dY[6][2] = T(kShC2[2]) * (4 * z);
-    dY[7][0] = T(kShC2[3]) * z; dY[7][1] = 0; dY[7][2] = T(kShC2[3]) * x;
-    dY[8][0] = T(kShC2[4]) * (2 * x); dY[8][1] = T(kShC2[4]) * (-2 * y); dY[8][2] = 0;
-  }
+  f(4, T(kShC2[0]) * xy, T(T(kShC2[0]) * y), T(T(kShC2[0]) * x), T(0));
+  f(5, T(kShC2[1]) * yz, T(0), T(T(kShC2[1]) * z), T(T(kShC2[1]) * y));
+  f(6, T(kShC2[2]) * (2 * zz - xx - yy), T(T(kShC2[2]) * (-2 * x)), T(T(kShC2[2]) * (-2 * y)), T(T(kShC2[2]) * (4 * z)));
+  f(7, T(kShC2[3]) * xz, T(T(kShC2[3]) * z), T(0), T(T(kShC2[3]) * x));
+  f(8, T(kShC2[4]) * (xx - yy), T(T(kShC2[4]) * (2 * x)), T(T(kShC2[4]) * (-2 * y)), T(0));
   if (degree < 3) return;
-  Y[9] = T(kShC3[0]) * y * (3 * xx - yy);
-  Y[10] = T(kShC3[1]) * xy * z;
-  Y[11] = T(kShC3[2]) * y * (4 * zz - xx - yy);
-  Y[12] = T(kShC3[3]) * z * (2 * zz - 3 * xx - 3 * yy);
-  Y[13] = T(kShC3[4]) * x * (4 * zz - xx - yy);
-  Y[14] = T(kShC3[5]) * z * (xx - yy);
-  Y[15] = T(kShC3[6]) * x * (xx - 3 * yy);
-  if (dY) {
-    dY[9][0] = T(kShC3[0]) * 6 * xy; dY[9][1] = T(kShC3[0]) * (3 * xx - 3 * yy); dY[9][2] = 0;
-    dY[10][0] = T(kShC3[1]) * yz; dY[10][1] = T(kShC3[1]) * xz; dY[10][2] = T(kShC3[1]) * xy;
-    dY[11][0] = T(kShC3[2]) * (-2 * xy); dY[11][1] = T(kShC3[2]) * (4 * zz - xx - 3 * yy); dY[11][2] = T(kShC3[2]) * 8 * yz;
-    dY[12][0] = T(kShC3[3]) * (-6 * xz); dY[12][1] = T(kShC3[3]) * (-6 * yz); dY[12][2] = T(kShC3[3]) * (6 * zz - 3 * xx - 3 * yy);
-    dY[13][0] = T(kShC3[4]) * (4 * zz - 3 * xx - yy); dY[13][1] = T(kShC3[4]) * (-2 * xy); dY[13][2] = T(kShC3[4]) * 8 * xz;
-    dY[14][0] = T(kShC3[5]) * 2 * xz; dY[14][1] = T(kShC3[5]) * (-2 * yz); dY[14][2] = T(kShC3[5]) * (xx - yy);
-    dY[15][0] = T(kShC3[6]) * (3 * xx - 3 * yy); dY[15][1] = T(kShC3[6]) * (-6 * xy); dY[15][2] = 0;
-  }
+  f(9, T(kShC3[0]) * y * (3 * xx - yy), T(T(kShC3[0]) * 6 * xy), T(T(kShC3[0]) * (3 * xx - 3 * yy)), T(0));
+  f(10, T(kShC3[1]) * xy * z, T(T(kShC3[1]) * yz), T(T(kShC3[1]) * xz), T(T(kShC3[1]) * xy));
+  f(11, T(kShC3[2]) * y * (4 * zz - xx - yy), T(T(kShC3[2]) * (-2 * xy)), T(T(kShC3[2]) * (4 * zz - xx - 3 * yy)), T(T(kShC3[2]) * 8 * yz));
+  f(12, T(kShC3[3]) * z * (2 * zz - 3 * xx - 3 * yy), T(T(kShC3[3]) * (-6 * xz)), T(T(kShC3[3]) * (-6 * yz)), T(T(kShC3[3]) * (6 * zz - 3 * xx - 3 * yy)));
+  f(13, T(kShC3[4]) * x * (4 * zz - xx - yy), T(T(kShC3[4]) * (4 * zz - 3 * xx - yy)), T(T(kShC3[4]) * (-2 * xy)), T(T(kShC3[4]) * 8 * xz));
+  f(14, T(kShC3[5]) * z * (xx - yy), T(T(kShC3[5]) * 2 * xz), T(T(kShC3[5]) * (-2 * yz)), T(T(kShC3[5]) * (xx - yy)));
+  f(15, T(kShC3[6]) * x * (xx - 3 * yy), T(T(kShC3[6]) * (3 * xx - 3 * yy)), T(T(kShC3[6]) * (-6 * xy)), T(0));
   if (degree < 4) return;
-  Y[16] = T(kShC4[0]) * xy * (xx - yy);
-  Y[17] = T(kShC4[1]) * yz * (3 * xx - yy);
-  Y[18] = T(kShC4[2]) * xy * (7 * zz - 1);
-  Y[19] = T(kShC4[3]) * yz * (7 * zz - 3);
-  Y[20] = T(kShC4[4]) * (zz * (35 * zz - 30) + 3);
-  Y[21] = T(kShC4[5]) * xz * (7 * zz - 3);
-  Y[22] = T(kShC4[6]) * (xx - yy) * (7 * zz - 1);
-  Y[23] = T(kShC4[7]) * xz * (xx - 3 * yy);
-  Y[24] = T(kShC4[8]) * (xx * (xx - 3 * yy) - yy * (3 * xx - yy));
-  if (dY) {
-    dY[16][0] = T(kShC4[0]) * (3 * xx * y - yy * y); dY[16][1] = T(kShC4[0]) * (xx * x - 3 * x * yy); dY[16][2] = 0;
-    dY[17][0] = T(kShC4[1]) * 6 * xy * z; dY[17][1] = T(kShC4[1]) * z * (3 * xx - 3 * yy); dY[17][2] = T(kShC4[1]) * y * (3 * xx - yy);
-    dY[18][0] = T(kShC4[2]) * y * (7 * zz - 1); dY[18][1] = T(kShC4[2]) * x * (7 * zz - 1); dY[18][2] = T(kShC4[2]) * 14 * xy * z;
-    dY[19][0] = 0; dY[19][1] = T(kShC4[3]) * z * (7 * zz - 3); dY[19][2] = T(kShC4[3]) * y * (21 * zz - 3);
-    dY[20][0] = 0; dY[20][1] = 0; dY[20][2] = T(kShC4[4]) * (140 * zz * z - 60 * z);
-    dY[21][0] = T(kShC4[5]) * z * (7 * zz - 3); dY[21][1] = 0; dY[21][2] = T(kShC4[5]) * x * (21 * zz - 3);
-    dY[22][0] = T(kShC4[6]) * 2 * x * (7 * zz - 1); dY[22][1] = T(kShC4[6]) * (-2 * y) * (7 * zz - 1); dY[22][2] = T(kShC4[6]) * 14 * z * (xx - yy);
-    dY[23][0] = T(kShC4[7]) * z * (3 * xx - 3 * yy); dY[23][1] = T(kShC4[7]) * (-6 * xy * z); dY[23][2] = T(kShC4[7]) * x * (xx - 3 * yy);
-    dY[24][0] = T(kShC4[8]) * (4 * xx * x - 12 * x * yy); dY[24][1] = T(kShC4[8]) * (4 * yy * y - 12 * xx * y); dY[24][2] = 0;
-  }
+  f(16, T(kShC4[0]) * xy * (xx - yy), T(T(kShC4[0]) * (3 * xx * y - yy * y)), T(T(kShC4[0]) * (xx * x - 3 * x * yy)), T(0));
+  f(17, T(kShC4[1]) * yz * (3 * xx - yy), T(T(kShC4[1]) * 6 * xy * z), T(T(kShC4[1]) * z * (3 * xx - 3 * yy)), T(T(kShC4[1]) * y * (3 * xx - yy)));
+  f(18, T(kShC4[2]) * xy * (7 * zz - 1), T(T(kShC4[2]) * y * (7 * zz - 1)), T(T(kShC4[2]) * x * (7 * zz - 1)), T(T(kShC4[2]) * 14 * xy * z));
+  f(19, T(kShC4[3]) * yz * (7 * zz - 3), T(0), T(T(kShC4[3]) * z * (7 * zz - 3)), T(T(kShC4[3]) * y * (21 * zz - 3)));
+  f(20, T(kShC4[4]) * (zz * (35 * zz - 30) + 3), T(0), T(0), T(T(kShC4[4]) * (140 * zz * z - 60 * z)));
+  f(21, T(kShC4[5]) * xz * (7 * zz - 3), T(T(kShC4[5]) * z * (7 * zz - 3)), T(0), T(T(kShC4[5]) * x * (21 * zz - 3)));
+  f(22, T(kShC4[6]) * (xx - yy) * (7 * zz - 1), T(T(kShC4[6]) * 2 * x * (7 * zz - 1)), T(T(kShC4[6]) * (-2 * y) * (7 * zz - 1)), T(T(kShC4[6]) * 14 * z * (xx - yy)));
+  f(23, T(kShC4[7]) * xz * (xx - 3 * yy), T(T(kShC4[7]) * z * (3 * xx - 3 * yy)), T(T(kShC4[7]) * (-6 * xy * z)), T(T(kShC4[7]) * x * (xx - 3 * yy)));
+  f(24, T(kShC4[8]) * (xx * (xx - 3 * yy) - yy * (3 * xx - yy)), T(T(kShC4[8]) * (4 * xx * x - 12 * x * yy)), T(T(kShC4[8]) * (4 * yy * y - 12 * xx * y)), T(0));
+}
+
+// bases Y[k]; when dY != null also dY[k][3]
+template <typename T> SO_HD void sh_bases(int degree, T x, T y, T z, T *Y, T (*dY)[3]) {
+  sh_eval<T>(degree, x, y, z, [&](int k, T yk, T dx, T dy, T dz) {
+    Y[k] = yk;
+    if (dY) { dY[k][0] = dx; dY[k][1] = dy; dY[k][2] = dz; }
+  });
 }
 
 }  // namespace so

@@ -1,0 +1,366 @@
+"""Operator surface of the path -- same names, arguments and error behaviour as the gsplat
+operators the reference reaches through `rasterization`:
+
+    fully_fused_projection (legacy alias project_gaussians), spherical_harmonics, isect_tiles,
+    isect_offset_encode, rasterize_to_pixels
+
+Each is a thin torch.autograd.Function over the C ABI of libsplat_one_amd.so
+(include/splat_one_amd.h).  PyTorch supplies device memory, the current HIP stream and the
+autograd tape; all arithmetic runs in the hand-written gfx950 kernels.  There is no CPU path.
+
+Reference call site: /root/reference/utils/gsplat_utils/gsplat_trainer.py:477-494.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+CAMERA_MODELS = {"pinhole": 0, "ortho": 1, "fisheye": 2}
+SUPPORTED_CHANNELS = (1, 2, 3, 4, 5, 8, 9, 16, 17, 32, 33)
+
+
+def _f32(t: Tensor) -> Tensor:
+    assert t.dtype == torch.float32, f"expected float32, got {t.dtype}"
+    return t.contiguous()
+
+
+def _camera_model_id(camera_model: str) -> int:
+    assert camera_model in CAMERA_MODELS, (
+        f"camera_model must be one of {list(CAMERA_MODELS)}, got {camera_model!r} "
+        "(the gsplat fork's 'spherical' model has no published specification)")
+    return CAMERA_MODELS[camera_model]
+
+
+# ---------------------------------------------------------------------------------------------
+# K1/K2 projection
+# ---------------------------------------------------------------------------------------------
+def _covars_to_6(covars: Tensor) -> Tensor:
+    """[N,3,3] (symmetric) or [N,6] -> [N,6] (xx,xy,xz,yy,yz,zz)."""
+    if covars.shape[-2:] == (3, 3):
+        i = torch.tensor([0, 0, 0, 1, 1, 2], device=covars.device)
+        j = torch.tensor([0, 1, 2, 1, 2, 2], device=covars.device)
+        return covars[..., i, j]
+    assert covars.shape[-1] == 6, covars.shape
+    return covars
+
+
+class _FullyFusedProjection(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, covars6, quats, scales, viewmats, Ks, width, height, eps2d, near_plane,
+                far_plane, radius_clip, calc_compensations, camera_model):
+        C, N = viewmats.shape[0], means.shape[0]
+        dev = means.device
+        radii = torch.empty(C, N, dtype=torch.int32, device=dev)
+        means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
+        depths = torch.empty(C, N, dtype=torch.float32, device=dev)
+        conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
+        comps = torch.empty(C, N, dtype=torch.float32, device=dev) if calc_compensations else None
+        call("so_projection_fwd", C, N, ptr(means), ptr(covars6), ptr(quats), ptr(scales), ptr(viewmats),
+             ptr(Ks), width, height, eps2d, near_plane, far_plane, radius_clip, camera_model, ptr(radii),
+             ptr(means2d), ptr(depths), ptr(conics), ptr(comps), stream())
+        ctx.save_for_backward(means, covars6, quats, scales, viewmats, Ks, radii, conics, comps)
+        ctx.cfg = (width, height, eps2d, camera_model)
+        ctx.mark_non_differentiable(radii)
+        if comps is None:
+            return radii, means2d, depths, conics
+        return radii, means2d, depths, conics, comps
+
+    @staticmethod
+    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_comps=None):
+        means, covars6, quats, scales, viewmats, Ks, radii, conics, comps = ctx.saved_tensors
+        width, height, eps2d, camera_model = ctx.cfg
+        C, N = viewmats.shape[0], means.shape[0]
+        dev = means.device
+        z = lambda t, shape: torch.zeros(shape, dtype=torch.float32, device=dev) if t is None else t.contiguous()
+        v_means2d = z(v_means2d, (C, N, 2))
+        v_depths = z(v_depths, (C, N))
+        v_conics = z(v_conics, (C, N, 3))
+        v_comps = None if comps is None else z(v_comps, (C, N))
+        v_means = torch.empty_like(means)
+        v_covars6 = torch.empty_like(covars6) if covars6 is not None else None
+        v_quats = torch.empty_like(quats) if covars6 is None else None
+        v_scales = torch.empty_like(scales) if covars6 is None else None
+        v_viewmats = torch.zeros_like(viewmats) if ctx.needs_input_grad[4] else None
+        call("so_projection_bwd", C, N, ptr(means), ptr(covars6), ptr(quats), ptr(scales), ptr(viewmats),
+             ptr(Ks), width, height, eps2d, camera_model, ptr(radii), ptr(v_means2d), ptr(v_depths),
+             ptr(v_conics), ptr(v_comps), ptr(v_means), ptr(v_covars6), ptr(v_quats), ptr(v_scales),
+             ptr(v_viewmats), stream())
+        return (v_means, v_covars6, v_quats, v_scales, v_viewmats) + (None,) * 9
+
+
+def fully_fused_projection(
+    means: Tensor, covars: Optional[Tensor], quats: Optional[Tensor], scales: Optional[Tensor],
+    viewmats: Tensor, Ks: Tensor, width: int, height: int, eps2d: float = 0.3,
+    near_plane: float = 0.01, far_plane: float = 1e10, radius_clip: float = 0.0, packed: bool = False,
+    sparse_grad: bool = False, calc_compensations: bool = False, camera_model: str = "pinhole",
+) -> Tuple[Tensor, Tensor, Tensor, Tensor, Optional[Tensor]]:
+    """means[N,3], covars[N,6]|[N,3,3]|None, quats[N,4], scales[N,3], viewmats[C,4,4], Ks[C,3,3] ->
+    (radii[C,N] i32, means2d[C,N,2], depths[C,N], conics[C,N,3], compensations[C,N]|None)."""
+    C, N = viewmats.shape[0], means.shape[0]
+    assert means.shape == (N, 3), means.shape
+    assert viewmats.shape == (C, 4, 4), viewmats.shape
+    assert Ks.shape == (C, 3, 3), Ks.shape
+    assert not packed, "packed projection is not implemented yet (reference default: packed=False, gsplat_trainer.py:133)"
+    assert not sparse_grad, "sparse_grad requires packed=True"
+    if covars is not None:
+        covars6 = _f32(_covars_to_6(covars))
+        assert covars6.shape == (N, 6), covars6.shape
+        quats = scales = None
+    else:
+        covars6 = None
+        assert quats is not None and scales is not None, "covars or quats/scales is required"
+        assert quats.shape == (N, 4), quats.shape
+        assert scales.shape == (N, 3), scales.shape
+        quats, scales = _f32(quats), _f32(scales)
+    out = _FullyFusedProjection.apply(
+        _f32(means), covars6, quats, scales, _f32(viewmats), _f32(Ks), int(width), int(height),
+        float(eps2d), float(near_plane), float(far_plane), float(radius_clip), bool(calc_compensations),
+        _camera_model_id(camera_model))
+    if len(out) == 4:
+        return out + (None,)
+    return out
+
+
+project_gaussians = fully_fused_projection  # legacy gsplat name used by north_star
+
+
+# ---------------------------------------------------------------------------------------------
+# K4/K5 spherical harmonics
+# ---------------------------------------------------------------------------------------------
+class _SphericalHarmonics(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, degree, dirs, coeffs, masks, per_camera, C, N):
+        K = coeffs.shape[-2]
+        colors = torch.empty(dirs.shape, dtype=torch.float32, device=dirs.device)
+        call("so_sh_fwd", C, N, K, degree, ptr(dirs), ptr(coeffs), per_camera, ptr(masks), ptr(colors), stream())
+        ctx.save_for_backward(dirs, coeffs, masks)
+        ctx.cfg = (degree, per_camera, C, N, K)
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        dirs, coeffs, masks = ctx.saved_tensors
+        degree, per_camera, C, N, K = ctx.cfg
+        v_colors = v_colors.contiguous()
+        v_coeffs = torch.empty_like(coeffs)
+        v_dirs = torch.empty_like(dirs) if ctx.needs_input_grad[1] else None
+        call("so_sh_bwd", C, N, K, degree, ptr(dirs), ptr(coeffs), per_camera, ptr(masks), ptr(v_colors),
+             ptr(v_coeffs), ptr(v_dirs), stream())
+        return None, v_dirs, v_coeffs, None, None, None, None
+
+
+def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor, masks: Optional[Tensor] = None) -> Tensor:
+    """dirs[...,3], coeffs[...,K,3], masks[...] -> colors[...,3].
+
+    Leading dims are either equal, or coeffs is an expanded (stride-0) view over the first dim
+    of dirs -- the `shs = colors.expand(C,...)` pattern of `rasterization` -- which is evaluated
+    without materialising C copies."""
+    assert (degrees_to_use + 1) ** 2 <= coeffs.shape[-2], coeffs.shape
+    assert dirs.shape[:-1] == coeffs.shape[:-2], (dirs.shape, coeffs.shape)
+    assert dirs.shape[-1] == 3 and coeffs.shape[-1] == 3, (dirs.shape, coeffs.shape)
+    if masks is not None:
+        assert masks.shape == dirs.shape[:-1], masks.shape
+        masks = masks.to(torch.uint8).contiguous() if masks.dtype != torch.uint8 else masks.contiguous()
+    lead = dirs.shape[:-1]
+    shared = coeffs.dim() >= 4 and coeffs.stride(0) == 0 and dirs.dim() >= 3
+    if shared:
+        C = lead[0]
+        N = int(torch.Size(lead[1:]).numel())
+        c = _f32(coeffs[0]).reshape(N, coeffs.shape[-2], 3)
+        per_camera = 0
+    else:
+        C, N = 1, int(torch.Size(lead).numel())
+        c = _f32(coeffs).reshape(N, coeffs.shape[-2], 3)
+        per_camera = 0
+    d = _f32(dirs).reshape(C, N, 3)
+    m = None if masks is None else masks.reshape(C, N)
+    out = _SphericalHarmonics.apply(int(degrees_to_use), d, c, m, per_camera, C, N)
+    return out.reshape(lead + (3,))
+
+
+# ---------------------------------------------------------------------------------------------
+# K6-K8 tile binning / sort / offsets  (non-differentiable)
+# ---------------------------------------------------------------------------------------------
+@torch.no_grad()
+def isect_tiles(
+    means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int, tile_height: int,
+    sort: bool = True, packed: bool = False, n_cameras: Optional[int] = None,
+    camera_ids: Optional[Tensor] = None, gaussian_ids: Optional[Tensor] = None,
+    return_offsets: bool = False,
+):
+    """means2d[C,N,2], radii[C,N] i32, depths[C,N] -> (tiles_per_gauss[C,N] i32, isect_ids[I] i64,
+    flatten_ids[I] i32).  Exact-size outputs need I on the host: this entry point performs ONE
+    device->host read (the sync-free path with preallocated capacity is `isect_tiles_static`)."""
+    assert not packed, "packed mode is not implemented yet"
+    C, N = radii.shape
+    assert means2d.shape == (C, N, 2), means2d.shape
+    assert depths.shape == (C, N), depths.shape
+    dev = means2d.device
+    means2d, depths = _f32(means2d), _f32(depths)
+    radii = radii.to(torch.int32).contiguous()
+    M = C * tile_width * tile_height
+    tiles_per_gauss = torch.empty(C, N, dtype=torch.int32, device=dev)
+    counters = torch.zeros(2 * M + 2, dtype=torch.int32, device=dev)  # counts | cursor | n | overflow
+    tile_counts, cursor, n_isects, overflow = counters[:M], counters[M:2 * M], counters[2 * M:2 * M + 1], counters[2 * M + 1:]
+    offsets = torch.empty(C, tile_height, tile_width, dtype=torch.int32, device=dev)
+    call("so_isect_count", C, N, ptr(means2d), ptr(radii), tile_size, tile_width, tile_height,
+         ptr(tiles_per_gauss), ptr(tile_counts), ptr(offsets), ptr(n_isects), stream())
+    total = int(n_isects.item())
+    isect_ids = torch.empty(total, dtype=torch.int64, device=dev)
+    flatten_ids = torch.empty(total, dtype=torch.int32, device=dev)
+    if total > 0:
+        if sort:
+            keys = torch.empty(total, dtype=torch.int64, device=dev)
+            call("so_isect_fill", C, N, ptr(means2d), ptr(radii), ptr(depths), tile_size, tile_width,
+                 tile_height, ptr(offsets), ptr(n_isects), ptr(cursor), total, ptr(keys), ptr(flatten_ids),
+                 ptr(isect_ids), ptr(overflow), stream())
+        else:
+            cum = torch.cumsum(tiles_per_gauss.reshape(-1).to(torch.int64), 0).contiguous()
+            call("so_isect_emit_unsorted", C, N, ptr(means2d), ptr(radii), ptr(depths), ptr(cum), tile_size,
+                 tile_width, tile_height, ptr(isect_ids), ptr(flatten_ids), stream())
+    if return_offsets:
+        return tiles_per_gauss, isect_ids, flatten_ids, offsets
+    return tiles_per_gauss, isect_ids, flatten_ids
+
+
+@torch.no_grad()
+def isect_tiles_static(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int,
+                       tile_height: int, capacity: int, workspace: Optional[dict] = None,
+                       want_isect_ids: bool = False) -> dict:
+    """Sync-free binning into caller-sized buffers (hipGraph-capturable).  Returns a dict with
+    tiles_per_gauss, isect_offsets, flatten_ids[capacity], n_isects (device i32[1]), overflow
+    (device i32[1]) and optionally isect_ids[capacity].  Nothing is read back to the host."""
+    C, N = radii.shape
+    dev = means2d.device
+    M = C * tile_width * tile_height
+    ws = workspace if workspace is not None else {}
+    def buf(name, shape, dtype):
+        t = ws.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.device != dev:
+            t = torch.empty(shape, dtype=dtype, device=dev)
+            ws[name] = t
+        return t
+    tiles_per_gauss = buf("tiles_per_gauss", (C, N), torch.int32)
+    counters = buf("counters", (2 * M + 2,), torch.int32)
+    counters.zero_()
+    offsets = buf("isect_offsets", (C, tile_height, tile_width), torch.int32)
+    keys = buf("keys", (capacity,), torch.int64)
+    flatten_ids = buf("flatten_ids", (capacity,), torch.int32)
+    isect_ids = buf("isect_ids", (capacity,), torch.int64) if want_isect_ids else None
+    tile_counts, cursor = counters[:M], counters[M:2 * M]
+    n_isects, overflow = counters[2 * M:2 * M + 1], counters[2 * M + 1:]
+    means2d, depths = _f32(means2d), _f32(depths)
+    call("so_isect_count", C, N, ptr(means2d), ptr(radii), tile_size, tile_width, tile_height,
+         ptr(tiles_per_gauss), ptr(tile_counts), ptr(offsets), ptr(n_isects), stream())
+    call("so_isect_fill", C, N, ptr(means2d), ptr(radii), ptr(depths), tile_size, tile_width, tile_height,
+         ptr(offsets), ptr(n_isects), ptr(cursor), capacity, ptr(keys), ptr(flatten_ids), ptr(isect_ids),
+         ptr(overflow), stream())
+    return dict(tiles_per_gauss=tiles_per_gauss, isect_offsets=offsets, flatten_ids=flatten_ids,
+                isect_ids=isect_ids, n_isects=n_isects, overflow=overflow)
+
+
+@torch.no_grad()
+def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile_height: int) -> Tensor:
+    """isect_ids[I] (sorted) -> offsets[C,tile_h,tile_w] i32."""
+    assert isect_ids.dtype == torch.int64, isect_ids.dtype
+    isect_ids = isect_ids.contiguous()
+    offsets = torch.empty(n_cameras, tile_height, tile_width, dtype=torch.int32, device=isect_ids.device)
+    call("so_isect_offset_encode", isect_ids.numel(), ptr(isect_ids), n_cameras, tile_width, tile_height,
+         ptr(offsets), stream())
+    return offsets
+
+
+# ---------------------------------------------------------------------------------------------
+# K9/K10 rasterise
+# ---------------------------------------------------------------------------------------------
+class _RasterizeToPixels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means2d, conics, colors, opacities, backgrounds, masks, width, height, tile_size,
+                isect_offsets, flatten_ids, n_isects_dev, absgrad):
+        C, N = opacities.shape
+        D = colors.shape[-1]
+        dev = means2d.device
+        render_colors = torch.empty(C, height, width, D, dtype=torch.float32, device=dev)
+        render_alphas = torch.empty(C, height, width, 1, dtype=torch.float32, device=dev)
+        last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
+        n_host = 0 if n_isects_dev is not None else flatten_ids.numel()
+        call("so_rasterize_fwd", C, N, D, width, height, tile_size, ptr(means2d), ptr(conics), ptr(colors),
+             ptr(opacities), ptr(backgrounds), ptr(masks), ptr(isect_offsets), ptr(flatten_ids),
+             ptr(n_isects_dev), n_host, ptr(render_colors), ptr(render_alphas), ptr(last_ids), stream())
+        ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, masks, isect_offsets,
+                              flatten_ids, n_isects_dev, render_alphas, last_ids)
+        ctx.cfg = (width, height, tile_size, absgrad, n_host)
+        return render_colors, render_alphas
+
+    @staticmethod
+    def backward(ctx, v_render_colors, v_render_alphas):
+        (means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids, n_isects_dev,
+         render_alphas, last_ids) = ctx.saved_tensors
+        width, height, tile_size, absgrad, n_host = ctx.cfg
+        C, N = opacities.shape
+        D = colors.shape[-1]
+        v_render_colors = v_render_colors.contiguous()
+        v_render_alphas = v_render_alphas.contiguous()
+        v_means2d = torch.zeros_like(means2d)
+        v_conics = torch.zeros_like(conics)
+        v_colors = torch.zeros_like(colors)
+        v_opacities = torch.zeros_like(opacities)
+        v_abs = torch.zeros_like(means2d) if absgrad else None
+        call("so_rasterize_bwd", C, N, D, width, height, tile_size, ptr(means2d), ptr(conics), ptr(colors),
+             ptr(opacities), ptr(backgrounds), ptr(masks), ptr(isect_offsets), ptr(flatten_ids),
+             ptr(n_isects_dev), n_host, ptr(render_alphas), ptr(last_ids), ptr(v_render_colors),
+             ptr(v_render_alphas), ptr(v_means2d), ptr(v_abs), ptr(v_conics), ptr(v_colors), ptr(v_opacities),
+             stream())
+        if absgrad:
+            means2d.absgrad = v_abs          # same side channel as gsplat: strategy reads `.absgrad`
+        v_bg = None
+        if backgrounds is not None and ctx.needs_input_grad[4]:
+            v_bg = (v_render_colors * (1.0 - render_alphas)).sum(dim=(1, 2))
+        return v_means2d, v_conics, v_colors, v_opacities, v_bg, None, None, None, None, None, None, None, None
+
+
+def rasterize_to_pixels(
+    means2d: Tensor, conics: Tensor, colors: Tensor, opacities: Tensor, image_width: int,
+    image_height: int, tile_size: int, isect_offsets: Tensor, flatten_ids: Tensor,
+    backgrounds: Optional[Tensor] = None, masks: Optional[Tensor] = None, packed: bool = False,
+    absgrad: bool = False, n_isects: Optional[Tensor] = None,
+) -> Tuple[Tensor, Tensor]:
+    """means2d[C,N,2] conics[C,N,3] colors[C,N,D] opacities[C,N] -> (render_colors[C,H,W,D],
+    render_alphas[C,H,W,1]).  `n_isects` (device i32[1]) switches to the static-capacity mode of
+    `isect_tiles_static`.  Channel counts outside the compiled set are zero-padded (as gsplat does)."""
+    assert not packed, "packed mode is not implemented yet"
+    C, N = opacities.shape
+    assert means2d.shape == (C, N, 2), means2d.shape
+    assert conics.shape == (C, N, 3), conics.shape
+    assert colors.shape[:2] == (C, N), colors.shape
+    assert tile_size in (8, 16), f"tile_size {tile_size} not supported (8 or 16)"
+    th, tw = isect_offsets.shape[1:]
+    assert isect_offsets.shape[0] == C
+    assert tw * tile_size >= image_width and th * tile_size >= image_height, "tile grid does not cover the image"
+    D = colors.shape[-1]
+    if backgrounds is not None:
+        assert backgrounds.shape == (C, D), backgrounds.shape
+        backgrounds = _f32(backgrounds)
+    if masks is not None:
+        assert masks.shape == isect_offsets.shape, masks.shape
+        masks = masks.to(torch.uint8).contiguous()
+    pad = 0
+    if D not in SUPPORTED_CHANNELS:
+        assert D <= SUPPORTED_CHANNELS[-1], f"too many channels: {D} (chunk them, as `rasterization` does)"
+        Dp = min(d for d in SUPPORTED_CHANNELS if d >= D)
+        pad = Dp - D
+        colors = torch.cat([colors, torch.zeros(C, N, pad, dtype=colors.dtype, device=colors.device)], -1)
+        if backgrounds is not None:
+            backgrounds = torch.cat([backgrounds, torch.zeros(C, pad, dtype=torch.float32, device=colors.device)], -1)
+    rc, ra = _RasterizeToPixels.apply(
+        _f32(means2d), _f32(conics), _f32(colors), _f32(opacities), backgrounds, masks, int(image_width),
+        int(image_height), int(tile_size), isect_offsets.to(torch.int32).contiguous(),
+        flatten_ids.to(torch.int32).contiguous(), n_isects, bool(absgrad))
+    if pad:
+        rc = rc[..., :D]
+    return rc, ra

@@ -1,0 +1,168 @@
+"""`rasterization(...)` -- drop-in for `gsplat.rendering.rasterization` as the reference calls it at
+/root/reference/utils/gsplat_utils/gsplat_trainer.py:477-494 (same keyword names, same return triple,
+same `meta` keys the densification strategy consumes: SURVEY.md 8b).
+
+Pipeline (all HIP, gfx950): projection (K1) -> SH colour (K4, +0.5, clamp) -> tile binning + per-tile
+depth sort (K6-K8) -> tile rasteriser (K9); backward through K10, K5, K2 via torch.autograd.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from .ops import (fully_fused_projection, isect_offset_encode, isect_tiles, isect_tiles_static,
+                  rasterize_to_pixels, spherical_harmonics)
+
+RENDER_MODES = ("RGB", "D", "ED", "RGB+D", "RGB+ED")
+
+
+def rasterization(
+    means: Tensor,  # [N, 3]
+    quats: Tensor,  # [N, 4]
+    scales: Tensor,  # [N, 3]
+    opacities: Tensor,  # [N]
+    colors: Tensor,  # [(C,) N, D] or [(C,) N, K, 3]
+    viewmats: Tensor,  # [C, 4, 4]
+    Ks: Tensor,  # [C, 3, 3]
+    width: int,
+    height: int,
+    near_plane: float = 0.01,
+    far_plane: float = 1e10,
+    radius_clip: float = 0.0,
+    eps2d: float = 0.3,
+    sh_degree: Optional[int] = None,
+    packed: bool = True,
+    tile_size: int = 16,
+    backgrounds: Optional[Tensor] = None,
+    render_mode: str = "RGB",
+    sparse_grad: bool = False,
+    absgrad: bool = False,
+    rasterize_mode: str = "classic",
+    channel_chunk: int = 32,
+    distributed: bool = False,
+    camera_model: str = "pinhole",
+    covars: Optional[Tensor] = None,
+    isect_capacity: Optional[int] = None,
+    workspace: Optional[dict] = None,
+) -> Tuple[Tensor, Tensor, Dict]:
+    """Rasterise N Gaussians to C cameras.  Returns (render_colors[C,H,W,X], render_alphas[C,H,W,1], meta).
+
+    Differences from the gsplat call, all explicit:
+      * `packed=True` (gsplat's default) is accepted and executed in the dense [C,N] layout -- the
+        reference passes packed=False (`Config.packed`, gsplat_trainer.py:133); results are identical,
+        `meta` has the non-packed layout.
+      * `distributed=True` is refused here: multi-GPU runs of this build are view-sharded
+        (splat_one_amd.distributed), not Gaussian-sharded.
+      * `isect_capacity` / `workspace` (extensions): preallocated intersection buffers make the call
+        free of host synchronisation (hipGraph-capturable); `meta["n_isects"]` then lives on the device.
+    """
+    meta: Dict = {}
+    N = means.shape[0]
+    C = viewmats.shape[0]
+    device = means.device
+    assert means.shape == (N, 3), means.shape
+    if covars is None:
+        assert quats.shape == (N, 4), quats.shape
+        assert scales.shape == (N, 3), scales.shape
+    else:
+        assert covars.shape == (N, 3, 3), covars.shape
+        quats, scales = None, None
+    assert opacities.shape == (N,), opacities.shape
+    assert viewmats.shape == (C, 4, 4), viewmats.shape
+    assert Ks.shape == (C, 3, 3), Ks.shape
+    assert render_mode in RENDER_MODES, render_mode
+    assert rasterize_mode in ("classic", "antialiased"), rasterize_mode
+    assert not distributed, ("Gaussian-sharded `distributed=True` is not provided; use "
+                             "splat_one_amd.distributed (view-sharded data parallelism)")
+    assert not sparse_grad, "sparse_grad needs packed mode, which is not implemented yet"
+
+    if sh_degree is None:
+        # treat colors as post-activation values, [N, D] or [C, N, D]
+        assert (colors.dim() == 2 and colors.shape[0] == N) or (colors.dim() == 3 and colors.shape[:2] == (C, N)), colors.shape
+    else:
+        # treat colors as SH coefficients, [N, K, 3] or [C, N, K, 3]
+        assert (colors.dim() == 3 and colors.shape[0] == N and colors.shape[2] == 3) or (
+            colors.dim() == 4 and colors.shape[:2] == (C, N) and colors.shape[3] == 3), colors.shape
+        assert (sh_degree + 1) ** 2 <= colors.shape[-2], colors.shape
+
+    # K1 projection
+    radii, means2d, depths, conics, compensations = fully_fused_projection(
+        means, covars, quats, scales, viewmats, Ks, width, height, eps2d=eps2d, packed=False,
+        near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip, sparse_grad=False,
+        calc_compensations=(rasterize_mode == "antialiased"), camera_model=camera_model)
+    opacities = opacities[None, :].expand(C, N)
+    if compensations is not None:
+        opacities = opacities * compensations
+    opacities = opacities.contiguous()
+
+    meta.update({"camera_ids": None, "gaussian_ids": None, "radii": radii, "means2d": means2d,
+                 "depths": depths, "conics": conics, "opacities": opacities})
+
+    # K4 colours
+    if sh_degree is None:
+        if colors.dim() == 2:
+            colors = colors[None].expand(C, -1, -1)
+    else:
+        camtoworlds = torch.inverse(viewmats)
+        dirs = means[None, :, :] - camtoworlds[:, None, :3, 3]  # [C, N, 3]
+        masks = radii > 0
+        shs = colors[None].expand(C, -1, -1, -1) if colors.dim() == 3 else colors
+        colors = spherical_harmonics(sh_degree, dirs, shs, masks=masks)  # [C, N, 3]
+        colors = torch.clamp_min(colors + 0.5, 0.0)
+
+    if render_mode in ("RGB+D", "RGB+ED"):
+        colors = torch.cat((colors, depths[..., None]), dim=-1)
+        if backgrounds is not None:
+            backgrounds = torch.cat([backgrounds, torch.zeros(C, 1, device=device)], dim=-1)
+    elif render_mode in ("D", "ED"):
+        colors = depths[..., None]
+        if backgrounds is not None:
+            backgrounds = torch.zeros(C, 1, device=device)
+
+    # K6-K8 binning + sort + offsets
+    tile_width = math.ceil(width / float(tile_size))
+    tile_height = math.ceil(height / float(tile_size))
+    n_isects_dev = None
+    if isect_capacity is None:
+        tiles_per_gauss, isect_ids, flatten_ids, isect_offsets = isect_tiles(
+            means2d, radii, depths, tile_size, tile_width, tile_height, packed=False, n_cameras=C,
+            return_offsets=True)
+    else:
+        st = isect_tiles_static(means2d, radii, depths, tile_size, tile_width, tile_height, int(isect_capacity),
+                                workspace=workspace, want_isect_ids=False)
+        tiles_per_gauss, isect_ids, flatten_ids, isect_offsets = (
+            st["tiles_per_gauss"], st["isect_ids"], st["flatten_ids"], st["isect_offsets"])
+        n_isects_dev = st["n_isects"]
+        meta.update({"n_isects": st["n_isects"], "isect_overflow": st["overflow"]})
+
+    meta.update({"tile_width": tile_width, "tile_height": tile_height, "tiles_per_gauss": tiles_per_gauss,
+                 "isect_ids": isect_ids, "flatten_ids": flatten_ids, "isect_offsets": isect_offsets,
+                 "width": width, "height": height, "tile_size": tile_size, "n_cameras": C})
+
+    # K9 rasterise (channel-chunked like gsplat when D > channel_chunk)
+    colors = colors.contiguous()
+    if colors.shape[-1] > channel_chunk:
+        n_chunks = (colors.shape[-1] + channel_chunk - 1) // channel_chunk
+        render_colors, render_alphas = [], []
+        for i in range(n_chunks):
+            colors_chunk = colors[..., i * channel_chunk:(i + 1) * channel_chunk].contiguous()
+            bg_chunk = backgrounds[..., i * channel_chunk:(i + 1) * channel_chunk] if backgrounds is not None else None
+            rc, ra = rasterize_to_pixels(means2d, conics, colors_chunk, opacities, width, height, tile_size,
+                                         isect_offsets, flatten_ids, backgrounds=bg_chunk, packed=False,
+                                         absgrad=absgrad, n_isects=n_isects_dev)
+            render_colors.append(rc)
+            render_alphas.append(ra)
+        render_colors = torch.cat(render_colors, dim=-1)
+        render_alphas = render_alphas[0]
+    else:
+        render_colors, render_alphas = rasterize_to_pixels(
+            means2d, conics, colors, opacities, width, height, tile_size, isect_offsets, flatten_ids,
+            backgrounds=backgrounds, packed=False, absgrad=absgrad, n_isects=n_isects_dev)
+    if render_mode in ("ED", "RGB+ED"):
+        # normalise the accumulated depth to get the expected depth
+        render_colors = torch.cat(
+            [render_colors[..., :-1], render_colors[..., -1:] / render_alphas.clamp(min=1e-10)], dim=-1)
+    return render_colors, render_alphas, meta

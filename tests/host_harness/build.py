@@ -1,0 +1,20 @@
+"""Builds tests/host_harness/_build/libhh.so: a TEST-ONLY g++ build of the product's per-Gaussian
+math header (splat_one_amd/csrc/splat_math.hpp).  Nothing under splat_one_amd/ loads it."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "_build", "libhh.so")
+
+
+def build() -> str:
+    src = os.path.join(HERE, "harness.cpp")
+    hdr = os.path.join(HERE, "..", "..", "splat_one_amd", "csrc", "splat_math.hpp")
+    if (not os.path.exists(OUT)) or os.path.getmtime(OUT) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        os.makedirs(os.path.dirname(OUT), exist_ok=True)
+        subprocess.run(["g++", "-O1", "-g", "-fPIC", "-shared", "-std=c++17", "-Wall", "-o", OUT, src], check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build())

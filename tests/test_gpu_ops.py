@@ -1,0 +1,276 @@
+"""GPU parity of every operator of the path against the float64 oracle, on identical inputs.
+Bars (BASELINE.json north_star): forward <= 1e-4 per-pixel L1, gradients <= 1e-3 relative
+(||g-g*||/||g*|| per tensor); integer / index outputs bit-exact."""
+import math
+
+import pytest
+import torch
+
+from oracle import c_oracle as CO
+from oracle import torch_oracle as O
+from tests.util import rel_err, small_scene, two_cameras
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 1e-4
+GRAD_TOL = 1e-3
+
+
+@pytest.mark.parametrize("camera_model", ["pinhole", "ortho", "fisheye"])
+@pytest.mark.parametrize("use_covars", [False, True])
+def test_projection_fwd_bwd(dev, camera_model, use_covars):
+    from splat_one_amd.ops import fully_fused_projection
+    W, H, N = 96, 64, 3000
+    means, quats, scales, _, _ = small_scene(N)
+    viewmats, Ks = two_cameras(W, H)
+    if camera_model == "ortho":
+        Ks[:, 0, 0], Ks[:, 1, 1] = 12.0, 11.0
+    C = viewmats.shape[0]
+    g = torch.Generator().manual_seed(3)
+    wm, wd, wc, wp = (torch.randn(C, N, 2, generator=g), torch.randn(C, N, generator=g),
+                      torch.randn(C, N, 3, generator=g), torch.randn(C, N, generator=g))
+
+    def run(fn, to, dt):
+        m = means.to(to).requires_grad_()
+        V = viewmats.to(to).requires_grad_()
+        if use_covars:
+            cov = O.quat_scale_to_covar(quats.double(), scales.double()).to(dt).to(to).requires_grad_()
+            q = s = None
+        else:
+            cov = None
+            q, s = quats.to(to).requires_grad_(), scales.to(to).requires_grad_()
+        radii, m2, dep, con, comp = fn(m, cov, q, s, V, Ks.to(to), W, H, eps2d=0.3, near_plane=0.01,
+                                       far_plane=100.0, calc_compensations=True, camera_model=camera_model)
+        loss = (m2 * wm.to(m2)).sum() + (dep * wd.to(dep)).sum() + (con * wc.to(con)).sum() + (comp * wp.to(comp)).sum()
+        loss.backward()
+        grads = {"means": m.grad, "viewmats": V.grad[:, :3, :]}
+        if use_covars:
+            grads["covars"] = cov.grad + cov.grad.transpose(-1, -2)   # symmetric part is what is defined
+        else:
+            grads.update(quats=q.grad, scales=s.grad)
+        return radii, m2, dep, con, comp, grads
+
+    r_h, m2_h, d_h, c_h, p_h, g_h = run(fully_fused_projection, dev, torch.float32)
+    r_o, m2_o, d_o, c_o, p_o, g_o = run(O.fully_fused_projection, "cpu", torch.float32)
+    r_h = r_h.cpu()
+    # radii: integer; fp32 vs fp64 may differ by one on ceil() boundaries / culling borderline
+    same = (r_h == r_o)
+    assert same.float().mean() > 0.999, same.float().mean()
+    assert (r_h - r_o).abs()[(r_h > 0) & (r_o > 0)].max() <= 1
+    vis = ((r_h > 0) & (r_o > 0))
+    assert vis.sum() > 500
+    assert (m2_h.cpu().double() - m2_o)[vis].abs().max() < 2e-3          # pixels
+    assert rel_err(d_h.cpu()[vis], d_o[vis]) < 1e-5
+    assert rel_err(c_h.cpu()[vis], c_o[vis]) < 1e-4
+    assert (p_h.cpu().double() - p_o)[vis].abs().max() < 1e-4
+    if same.all():
+        for k in g_o:
+            gh = g_h[k]
+            if k == "covars":
+                pass
+            assert rel_err(gh, g_o[k]) < GRAD_TOL, (k, rel_err(gh, g_o[k]))
+
+
+@pytest.mark.parametrize("degree", [0, 1, 2, 3, 4])
+def test_spherical_harmonics(dev, degree):
+    from splat_one_amd.ops import spherical_harmonics
+    N, C, K = 4000, 3, 25
+    g = torch.Generator().manual_seed(degree)
+    dirs = torch.randn(C, N, 3, generator=g) * 3
+    coeffs = torch.randn(N, K, 3, generator=g)
+    masks = torch.rand(C, N, generator=g) > 0.2
+    w = torch.randn(C, N, 3, generator=g)
+
+    def run(fn, to):
+        d = dirs.to(to).requires_grad_()
+        c = coeffs.to(to).requires_grad_()
+        out = fn(degree, d, c[None].expand(C, -1, -1, -1), masks=masks.to(to))
+        (out * w.to(out)).sum().backward()
+        return out, d.grad, c.grad
+
+    o_h, vd_h, vc_h = run(spherical_harmonics, dev)
+    o_o, vd_o, vc_o = run(O.spherical_harmonics, "cpu")
+    assert (o_h.cpu().double() - o_o).abs().max() < 2e-5
+    assert rel_err(vc_h, vc_o) < 1e-5
+    if degree > 0:
+        assert rel_err(vd_h, vd_o) < 1e-4
+    nb = (degree + 1) ** 2
+    if nb < K:
+        assert vc_h[:, nb:].abs().max().item() == 0.0      # bands above the degree: zero gradient
+    assert o_h[~masks.to(dev)].abs().max().item() == 0.0   # masked out
+
+
+def _projected_inputs(N, W, H, scale, seed=1):
+    means, quats, scales, opac, sh = small_scene(N, seed=seed, scale=scale, K=1)
+    viewmats, Ks = two_cameras(W, H)
+    radii, m2, dep, con, _ = O.fully_fused_projection(means, None, quats, scales, viewmats, Ks, W, H,
+                                                      near_plane=0.01, far_plane=100.0)
+    C = viewmats.shape[0]
+    g = torch.Generator().manual_seed(seed + 100)
+    colors = torch.rand(C, N, 3, generator=g)
+    opacs = opac[None].expand(C, N).contiguous()
+    return radii, m2.float(), dep.float(), con.float(), colors, opacs
+
+
+@pytest.mark.parametrize("tile_size,W,H,scale", [(16, 200, 120, 0.25), (16, 64, 64, 1.5), (8, 100, 60, 0.1)])
+def test_isect_bit_exact(dev, tile_size, W, H, scale):
+    from splat_one_amd.ops import isect_offset_encode, isect_tiles
+    radii, m2, dep, con, _, _ = _projected_inputs(4000, W, H, scale)
+    C = radii.shape[0]
+    tw, th = math.ceil(W / tile_size), math.ceil(H / tile_size)
+    tpg_o, ids_o, flat_o = O.isect_tiles(m2, radii, dep, tile_size, tw, th)
+    off_o = O.isect_offset_encode(ids_o, C, tw, th)
+    tpg_h, ids_h, flat_h, off_fill = isect_tiles(m2.to(dev), radii.to(dev), dep.to(dev), tile_size, tw, th,
+                                                 return_offsets=True)
+    assert ids_o.numel() > 1000
+    assert torch.equal(tpg_h.cpu(), tpg_o)
+    assert torch.equal(ids_h.cpu(), ids_o)
+    assert torch.equal(flat_h.cpu(), flat_o)
+    assert torch.equal(off_fill.cpu(), off_o)
+    off_h = isect_offset_encode(ids_h, C, tw, th)
+    assert torch.equal(off_h.cpu(), off_o)
+    # unsorted emission order (Gaussian-major, row-major tiles)
+    _, ids_u_o, flat_u_o = O.isect_tiles(m2, radii, dep, tile_size, tw, th, sort=False)
+    _, ids_u_h, flat_u_h = isect_tiles(m2.to(dev), radii.to(dev), dep.to(dev), tile_size, tw, th, sort=False)
+    assert torch.equal(ids_u_h.cpu(), ids_u_o) and torch.equal(flat_u_h.cpu(), flat_u_o)
+
+
+def test_isect_empty_and_ties(dev):
+    from splat_one_amd.ops import isect_tiles
+    # nothing visible
+    C, N = 2, 50
+    z = torch.zeros(C, N, device=dev)
+    tpg, ids, flat, off = isect_tiles(torch.zeros(C, N, 2, device=dev), torch.zeros(C, N, dtype=torch.int32, device=dev),
+                                      z, 16, 4, 4, return_offsets=True)
+    assert ids.numel() == 0 and flat.numel() == 0 and tpg.sum().item() == 0 and off.abs().sum().item() == 0
+    # equal depths: ties resolve by ascending flatten id (stable sort of Gaussian-major emission)
+    m2 = torch.full((1, 300, 2), 20.0)
+    radii = torch.full((1, 300), 5, dtype=torch.int32)
+    dep = torch.full((1, 300), 2.5)
+    _, ids_o, flat_o = O.isect_tiles(m2, radii, dep, 16, 4, 4)
+    _, ids_h, flat_h = isect_tiles(m2.to(dev), radii.to(dev), dep.to(dev), 16, 4, 4)
+    assert torch.equal(flat_h.cpu(), flat_o) and torch.equal(ids_h.cpu(), ids_o)
+
+
+def test_isect_long_lists(dev):
+    """Lists longer than the small (1024) and the large (16384) LDS sort capacities."""
+    from splat_one_amd.ops import isect_tiles
+    g = torch.Generator().manual_seed(0)
+    for N in (3000, 20000):
+        m2 = torch.rand(1, N, 2, generator=g) * 8 + 4          # all inside tile (0,0) of a 16x16 image
+        radii = torch.ones(1, N, dtype=torch.int32)
+        dep = torch.rand(1, N, generator=g) + 0.5
+        dep[0, ::7] = 1.0                                      # plenty of ties
+        _, ids_o, flat_o = O.isect_tiles(m2, radii, dep, 16, 1, 1)
+        _, ids_h, flat_h = isect_tiles(m2.to(dev), radii.to(dev), dep.to(dev), 16, 1, 1)
+        assert ids_o.numel() == N
+        assert torch.equal(flat_h.cpu(), flat_o), N
+        assert torch.equal(ids_h.cpu(), ids_o), N
+
+
+@pytest.mark.parametrize("tile_size,D,with_bg,W,H,scale", [
+    (16, 3, False, 200, 120, 0.25), (16, 3, True, 70, 50, 1.0), (16, 4, True, 64, 64, 0.5),
+    (8, 3, False, 100, 60, 0.2), (16, 1, False, 64, 48, 0.5), (16, 7, True, 48, 48, 0.5)])
+def test_rasterize_fwd_bwd(dev, tile_size, D, with_bg, W, H, scale):
+    from splat_one_amd.ops import rasterize_to_pixels
+    N = 4000
+    radii, m2, dep, con, colors, opacs = _projected_inputs(N, W, H, scale)
+    C = radii.shape[0]
+    g = torch.Generator().manual_seed(9)
+    colors = torch.rand(C, N, D, generator=g)
+    bg = torch.rand(C, D, generator=g) if with_bg else None
+    tw, th = math.ceil(W / tile_size), math.ceil(H / tile_size)
+    _, ids, flat = O.isect_tiles(m2, radii, dep, tile_size, tw, th)
+    off = O.isect_offset_encode(ids, C, tw, th)
+    w_c = torch.rand(C, H, W, D, generator=g)
+    w_a = torch.rand(C, H, W, 1, generator=g)
+
+    def run(host):
+        to = "cpu" if host else dev
+        dt = torch.float64 if host else torch.float32
+        ins = [t.to(dt).to(to).requires_grad_() for t in (m2, con, colors, opacs)]
+        b = None if bg is None else bg.to(dt).to(to).requires_grad_()
+        if host:
+            absout = []
+            rc, ra = CO.rasterize_to_pixels(*ins, W, H, tile_size, off, flat, backgrounds=b, absgrad_out=absout)
+        else:
+            rc, ra = rasterize_to_pixels(*ins, W, H, tile_size, off.to(dev), flat.to(dev), backgrounds=b, absgrad=True)
+        ((rc * w_c.to(rc)).sum() + (ra * w_a.to(ra)).sum()).backward()
+        ab = absout[0] if host else ins[0].absgrad
+        return rc, ra, [t.grad for t in ins] + [ab] + ([b.grad] if b is not None else [])
+
+    rc_h, ra_h, g_h = run(False)
+    rc_o, ra_o, g_o = run(True)
+    assert (rc_h.cpu().double() - rc_o).abs().mean().item() < FWD_TOL
+    assert (rc_h.cpu().double() - rc_o).abs().max().item() < 5e-3
+    assert (ra_h.cpu().double() - ra_o).abs().mean().item() < FWD_TOL
+    names = ["means2d", "conics", "colors", "opacities", "absgrad", "backgrounds"]
+    for n, a, b in zip(names, g_h, g_o):
+        assert rel_err(a, b) < GRAD_TOL, (n, rel_err(a, b))
+    assert (g_h[4] * (1 + 1e-4) + 1e-9 >= g_h[0].abs()).all()   # KAT-10: absgrad >= |grad| (up to fp32 summation order)
+
+
+def test_rasterize_tile_masks_and_static_mode(dev):
+    from splat_one_amd.ops import isect_tiles_static, rasterize_to_pixels
+    W, H, ts, N = 96, 80, 16, 3000
+    radii, m2, dep, con, colors, opacs = _projected_inputs(N, W, H, 0.4)
+    C = radii.shape[0]
+    tw, th = math.ceil(W / ts), math.ceil(H / ts)
+    _, ids, flat = O.isect_tiles(m2, radii, dep, ts, tw, th)
+    off = O.isect_offset_encode(ids, C, tw, th)
+    ins = [t.to(dev) for t in (m2, con, colors, opacs)]
+    ref_c, ref_a = rasterize_to_pixels(*ins, W, H, ts, off.to(dev), flat.to(dev))
+    # static-capacity binning gives the same image without any host read-back
+    st = isect_tiles_static(ins[0], radii.to(dev), dep.to(dev), ts, tw, th, capacity=flat.numel() + 1000)
+    assert int(st["n_isects"].item()) == flat.numel() and int(st["overflow"].item()) == 0
+    assert torch.equal(st["flatten_ids"][:flat.numel()].cpu(), flat)
+    c2, a2 = rasterize_to_pixels(*ins, W, H, ts, st["isect_offsets"], st["flatten_ids"], n_isects=st["n_isects"])
+    assert torch.equal(c2, ref_c) and torch.equal(a2, ref_a)
+    # overflow is reported, never written past capacity
+    st2 = isect_tiles_static(ins[0], radii.to(dev), dep.to(dev), ts, tw, th, capacity=flat.numel() // 2)
+    assert int(st2["overflow"].item()) == 1
+    # tile masks: masked tiles render the background only
+    masks = torch.ones(C, th, tw, dtype=torch.bool)
+    masks[:, ::2, ::2] = False
+    bg = torch.rand(C, 3)
+    mc, ma = rasterize_to_pixels(*ins, W, H, ts, off.to(dev), flat.to(dev), backgrounds=bg.to(dev), masks=masks.to(dev))
+    fc, fa = rasterize_to_pixels(*ins, W, H, ts, off.to(dev), flat.to(dev), backgrounds=bg.to(dev))
+    pm = masks.repeat_interleave(ts, 1).repeat_interleave(ts, 2)[:, :H, :W].to(dev)
+    assert torch.equal(mc[pm], fc[pm])
+    assert torch.allclose(mc[~pm], bg.to(dev)[:, None, None, :].expand(C, H, W, 3)[~pm])
+    assert ma[~pm].abs().max().item() == 0.0
+
+
+def test_adam_matches_torch(dev):
+    import ctypes
+    from splat_one_amd import _lib
+    g = torch.Generator().manual_seed(0)
+    shapes = [(1000, 3), (1000, 4), (1000,), (1000, 15, 3), (37,), (5, 1, 3)]
+    lrs = [1.6e-4, 5e-3, 1e-3, 5e-2, 2.5e-3, 1.25e-4]
+    b1, b2, eps = 0.9, 0.999, 1e-15
+    ps = [torch.randn(s, generator=g) for s in shapes]
+    ref = [p.clone().requires_grad_() for p in ps]
+    opts = [torch.optim.Adam([r], lr=lr, betas=(b1, b2), eps=eps) for r, lr in zip(ref, lrs)]
+    mine = [p.clone().to(dev) for p in ps]
+    ms = [torch.zeros_like(p) for p in mine]
+    vs = [torch.zeros_like(p) for p in mine]
+    for step in range(1, 6):
+        grads = [torch.randn(s, generator=g) * (10.0 ** (step - 3)) for s in shapes]
+        gd = [x.clone().to(dev) for x in grads]
+        for r, o, x in zip(ref, opts, grads):
+            r.grad = x.clone()
+            o.step()
+        arr = (_lib.AdamGroup * len(mine))()
+        for i, (p, x, m, v, lr) in enumerate(zip(mine, gd, ms, vs, lrs)):
+            arr[i] = _lib.AdamGroup(p.data_ptr(), x.data_ptr(), m.data_ptr(), v.data_ptr(), 0, p.numel(), 1,
+                                    lr / (1 - b1 ** step), math.sqrt(1 - b2 ** step))
+        _lib.call("so_adam_step", len(mine), arr, b1, b2, eps, 1, _lib.stream())
+        for x in gd:
+            assert x.abs().max().item() == 0.0                 # zero_grad fused
+        for p, r, o, m, v, lr in zip(mine, ref, opts, ms, vs, lrs):
+            # parameters: within 2 ulp of the value plus 1e-6 of the update size (the update is ~lr)
+            d = (p.cpu() - r.detach()).abs()
+            assert (d <= 2.4e-7 * r.detach().abs() + 1e-6 * lr).all(), (step, d.max())
+            st = o.state[r]
+            assert torch.allclose(m.cpu(), st["exp_avg"], rtol=1e-6, atol=1e-30)
+            assert torch.allclose(v.cpu(), st["exp_avg_sq"], rtol=1e-6, atol=1e-30)
