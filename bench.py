@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X-native 3DGS training path.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1], "c2"): 100k random Gaussians (reference init, trainer
+`mcmc` preset = trained-like small splats), 1920x1080, SH degree 3, ONE view per GPU per step;
+a step = forward + photometric loss + backward + fused Adam (+ densification statistics), i.e.
+one iteration of Runner.train (/root/reference/utils/gsplat_utils/gsplat_trainer.py:551-763).
+N GPUs = N views per step, replicated Gaussians, one RCCL all-reduce of the gradients (weak scaling).
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(N, V, I, P, K):
+    """algorithmic HBM bytes per launch of each kernel family (fp32, one view)."""
+    return {
+        "so_projection_fwd": 40 * N + 28 * N,
+        "so_sh_fwd": V * (12 * K + 12),
+        "so_isect_count": 12 * N + 12 * I,             # first half of the 24 B/intersection binning term
+        "so_isect_fill": 12 * N + 12 * I,
+        "so_rasterize_fwd": 40 * I + 20 * P,
+        "so_rasterize_bwd": 24 * P + 40 * I + 36 * I,
+        "so_sh_bwd": V * (12 + 12 * K),
+        "so_projection_bwd": 76 * V + 40 * N,
+        "so_adam_step": N * (11 + 3 * K) * 28,
+    }
+
+
+def cpu_baseline(n, width, height, regime, seconds_budget=20.0):
+    """The oracle (torch fp32 projection/SH/binning + plain-C fp32 rasteriser, OpenMP) timed on the
+    host cores for the SAME workload: full iterations (fwd + loss + bwd + torch Adam)."""
+    from oracle import torch_oracle as O, c_oracle as CO
+    from splat_one_amd.scene import make_scene
+    from oracle.ssim_oracle import photometric_loss as oracle_loss
+    threads = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(threads)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    splats, c2w, Ks = make_scene(n, width, height, regime=regime)
+    params = {k: v.clone().requires_grad_(True) for k, v in splats.items()}
+    opt = torch.optim.Adam(params.values(), lr=1e-3, eps=1e-15)
+    viewmats = torch.linalg.inv(c2w)
+    g = torch.Generator().manual_seed(7)
+    pixels = torch.rand(1, height, width, 3, generator=g)
+    raster = CO.raster_fn()
+    times, t_start = [], time.time()
+    fwd_times = []
+    while True:
+        t0 = time.time()
+        colors = torch.cat([params["sh0"], params["shN"]], 1)
+        rc, ra, meta = O.rasterization(params["means"], params["quats"], torch.exp(params["scales"]),
+                                       torch.sigmoid(params["opacities"]), colors, viewmats, Ks, width, height,
+                                       sh_degree=3, near_plane=0.01, far_plane=1e8, raster_fn=raster,
+                                       dtype=torch.float32)
+        t1 = time.time()
+        loss, _, _ = oracle_loss(rc, pixels, 0.2, dtype=torch.float32)
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        t2 = time.time()
+        times.append(t2 - t0)
+        fwd_times.append(t1 - t0)
+        if len(times) >= 3 and (time.time() - t_start > seconds_budget or len(times) >= 25):
+            break
+    times_s = sorted(times[1:])
+    med = times_s[len(times_s) // 2]
+    fwd = sorted(fwd_times[1:])[len(fwd_times[1:]) // 2]
+    return {"value": 1.0 / med, "unit": "it/s", "cores": threads, "kind": "port",
+            "sample": f"{len(times) - 1} full iterations (median) of the same {n}-Gaussian {width}x{height} "
+                      f"{regime} workload: torch fp32 projection/SH/binning/loss/Adam + oracle/c/raster_oracle.c (f32, OpenMP)",
+            "forward_mpix_per_s": width * height / fwd / 1e6}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=100_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--regime", default="mcmc", choices=["mcmc", "ref"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-table", action="store_true", help="print per-kernel times to stderr")
+    args = ap.parse_args()
+
+    from splat_one_amd import _lib, distributed as sdist
+    from splat_one_amd.scene import pinhole_K, ring_cameras, front_camera
+    from splat_one_amd.trainer import Config, Runner
+
+    local_rank, rank, world = sdist.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path exists for the product)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    W, H, N = args.width, args.height, args.n
+    init_scale, init_opa = (1.0, 0.1) if args.regime == "ref" else (0.1, 0.5)
+    cfg = Config(init_num_pts=N, init_scale=init_scale, init_opa=init_opa, batch_size=1, shN_init_std=0.1,
+                 camera_model="pinhole", sh_degree_interval=1)   # SH degree 3 from step 3 on
+    runner = Runner(local_rank, rank, world, cfg, scene_scale=1.0 / 1.1)   # effective scene_scale 1.0
+    cams = front_camera()[None] if world == 1 else ring_cameras(world)
+    c2w = cams[rank:rank + 1].to(dev)
+    Ks = pinhole_K(W, H)[None].to(dev)
+    g = torch.Generator().manual_seed(100 + rank)
+    pixels = torch.rand(1, H, W, 3, generator=g).to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up (also finds the dominant kernel with per-entry-point HIP events)
+    _lib.PROFILE = "all"
+    for _ in range(max(1, args.warmup)):
+        runner.train_step(c2w, Ks, pixels)
+    prof = _lib.profile_summary()
+    dominant = max(prof.items(), key=lambda kv: kv[1][0] * kv[1][1])[0]
+    if args.kernel_table and rank == 0:
+        tot = sum(n * ms for n, ms in prof.values())
+        for k, (n, ms) in sorted(prof.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+            print(f"  {k:24s} calls/step {n / max(1, args.warmup):4.1f}  mean {ms * 1e3:9.1f} us  share {n * ms / tot:5.1%}", file=sys.stderr)
+    _lib.PROFILE = {dominant}
+
+    # forward-only rate
+    with torch.no_grad():
+        barrier()
+        t0 = time.time()
+        for _ in range(20):
+            runner.rasterize_splats(c2w, Ks, W, H, sh_degree=3, near_plane=cfg.near_plane, far_plane=cfg.far_plane)
+        barrier()
+        fwd_s = (time.time() - t0) / 20
+    _lib.profile_summary()  # discard
+
+    # timed region: EXACTLY --steps iterations between barriers
+    barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        runner.train_step(c2w, Ks, pixels)
+    barrier()
+    elapsed = time.time() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    dom_calls, dom_ms = _lib.profile_summary()[dominant]
+    _lib.PROFILE = None
+
+    info = runner.last_info
+    V = int((info["radii"] > 0).sum().item())
+    I = int(info["flatten_ids"].numel()) if "n_isects" not in info else int(info["n_isects"].item())
+    P = W * H
+    K = (cfg.sh_degree + 1) ** 2
+    ab = algorithmic_bytes(N, V, I, P, K)
+    b_iter = sum(ab.values())
+    achieved = ab[dominant] / (dom_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dominant)
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "training iters/sec (100k Gaussians, 1080p, fwd+loss+bwd+Adam)",
+        "value": world * args.steps / elapsed,
+        "unit": "it/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"c2: {N} Gaussians (reference random init, '{args.regime}' preset), "
+                               f"{W}x{H}, SH degree 3, 1 view per GPU per step, pinhole",
+                   "views_per_step": world, "visible_gaussians": V, "tile_intersections": I,
+                   "parallelism": f"view-sharded dp{world}"},
+        "forward_mpix_per_s": world * P / fwd_s / 1e6,
+        "hbm_iter_fraction": b_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9),
+        "algorithmic_bytes_per_iter": b_iter,
+        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": ab[dominant], "mean_launch_us": dom_ms * 1e3,
+                     "launches_timed": dom_calls},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(N, W, H, args.regime)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

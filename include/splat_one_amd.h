@@ -177,6 +177,22 @@ typedef struct so_adam_group {
 int so_adam_step(int n_groups, const so_adam_group *host_groups, double beta1, double beta2, double eps,
                  int zero_grad, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Photometric loss.  Replaces F.l1_loss + the CUDA-only `fused_ssim(..., padding="valid")` of
+ * gsplat_trainer.py:624-628 with one forward and one backward kernel on the rasteriser's own
+ * channel-last layout.  SSIM: 11x11 Gaussian window (sigma 1.5), C1=0.01^2, C2=0.03^2.
+ *   img1 (rendered; receives the gradient), img2 (target): [B,H,W,CH] f32, CH in {1,3,4}.
+ *   sums[2] (zeroed by the caller): sums[0] += sum|img1-img2| ; sums[1] += sum of the SSIM map over
+ *   all pixels, or over the interior (5-pixel crop) when padding_valid != 0.
+ *   dmaps[3,B,H,W,CH]: derivative maps saved for the backward (nullable when no gradient is needed).
+ * Backward: v_img1 = v_loss * ( w_l1 * sign(img1-img2) + w_ssim * d(sum SSIM)/d img1 ), with
+ *   v_loss a device scalar (nullable = 1).
+ * ---------------------------------------------------------------------------------------- */
+int so_ssim_l1_fwd(int B, int H, int W, int CH, const float *img1, const float *img2, int padding_valid,
+                   float *sums, float *dmaps, void *stream);
+int so_ssim_l1_bwd(int B, int H, int W, int CH, const float *img1, const float *img2, const float *dmaps,
+                   float w_l1, float w_ssim, const float *v_loss, float *v_img1, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,8 @@ _SIGS = {
     "so_isect_offset_encode": [c_i64, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr],
     "so_rasterize_fwd": [c_int] * 6 + [c_ptr] * 9 + [c_i64] + [c_ptr] * 4,
     "so_rasterize_bwd": [c_int] * 6 + [c_ptr] * 9 + [c_i64] + [c_ptr] * 10,
+    "so_ssim_l1_fwd": [c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr],
+    "so_ssim_l1_bwd": [c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_ptr, c_ptr, c_ptr],
     "so_adam_step": [c_int, ctypes.POINTER(AdamGroup), ctypes.c_double, ctypes.c_double, ctypes.c_double, c_int, c_ptr],
 }
 
@@ -83,9 +85,35 @@ def stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional per-entry-point timing with HIP events on the launch stream (bench.py / profiling only).
+# PROFILE = None (off) | set of names to time | "all".  Results accumulate in PROFILE_EVENTS.
+PROFILE = None
+PROFILE_EVENTS: dict = {}
+
+
 def call(name: str, *args) -> None:
     lib = load()
+    timed = PROFILE is not None and (PROFILE == "all" or name in PROFILE)
+    if timed:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = getattr(lib, name)(*args)
+    if timed:
+        e1.record()
+        PROFILE_EVENTS.setdefault(name, []).append((e0, e1))
     if rc != 0:
         msg = lib.so_last_error().decode()
         raise RuntimeError(f"{name} failed with status {rc}: {msg}")
+
+
+def profile_summary(reset: bool = True) -> dict:
+    """{name: (n_calls, mean_ms)} from the recorded events (synchronises the device)."""
+    torch.cuda.synchronize()
+    out = {}
+    for name, evs in PROFILE_EVENTS.items():
+        ms = [a.elapsed_time(b) for a, b in evs]
+        out[name] = (len(ms), sum(ms) / max(1, len(ms)))
+    if reset:
+        PROFILE_EVENTS.clear()
+    return out

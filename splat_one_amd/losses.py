@@ -1,0 +1,68 @@
+"""Photometric loss of the training step: 0.8 * L1 + 0.2 * (1 - SSIM)
+(/root/reference/utils/gsplat_utils/gsplat_trainer.py:624-628), as ONE forward and ONE backward HIP
+kernel (`so_ssim_l1_fwd/bwd`) on the rasteriser's channel-last output.
+
+`fused_ssim(img1, img2, padding="valid")` mirrors the call the reference makes into the CUDA-only
+`fused_ssim` package (Dockerfile:55-60): 11x11 Gaussian window, sigma 1.5, C1=0.01^2, C2=0.03^2,
+NCHW, mean of the SSIM map; "valid" crops the 5-pixel border where the window leaves the image.
+"""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from ._lib import call, ptr, stream
+
+
+class _L1SSIM(torch.autograd.Function):
+    """a * mean|x-y| + b * mean SSIM(x,y) + c   on channel-last [B,H,W,CH] images."""
+
+    @staticmethod
+    def forward(ctx, img1: Tensor, img2: Tensor, a: float, b: float, c: float, valid: bool):
+        B, H, W, CH = img1.shape
+        need_grad = img1.requires_grad
+        sums = torch.zeros(2, dtype=torch.float32, device=img1.device)
+        dmaps = torch.empty(3, B, H, W, CH, dtype=torch.float32, device=img1.device) if need_grad else None
+        call("so_ssim_l1_fwd", B, H, W, CH, ptr(img1), ptr(img2), 1 if valid else 0, ptr(sums), ptr(dmaps), stream())
+        n_l1 = float(B * H * W * CH)
+        n_ss = float(B * CH * ((H - 10) * (W - 10) if valid else H * W))
+        l1 = sums[0] / n_l1
+        ssim = sums[1] / n_ss
+        ctx.save_for_backward(img1, img2, dmaps)
+        ctx.w = (a / n_l1, b / n_ss)
+        ctx.mark_non_differentiable(l1, ssim)
+        return a * l1 + b * ssim + c, l1, ssim
+
+    @staticmethod
+    def backward(ctx, v_loss, _v_l1, _v_ssim):
+        img1, img2, dmaps = ctx.saved_tensors
+        B, H, W, CH = img1.shape
+        v_img1 = torch.empty_like(img1)
+        v_loss = v_loss.contiguous().to(torch.float32)
+        call("so_ssim_l1_bwd", B, H, W, CH, ptr(img1), ptr(img2), ptr(dmaps), ctx.w[0], ctx.w[1], ptr(v_loss),
+             ptr(v_img1), stream())
+        return v_img1, None, None, None, None, None
+
+
+def _prep(x: Tensor) -> Tensor:
+    assert x.dtype == torch.float32, x.dtype
+    return x.contiguous()
+
+
+def photometric_loss(colors: Tensor, pixels: Tensor, ssim_lambda: float = 0.2):
+    """colors, pixels: [B,H,W,3] in 0..1.  Returns (loss, l1loss, ssimloss) as at gsplat_trainer.py:624-628."""
+    assert colors.shape == pixels.shape and colors.dim() == 4, (colors.shape, pixels.shape)
+    assert colors.shape[1] > 10 and colors.shape[2] > 10, "image smaller than the 11x11 SSIM window"
+    loss, l1, ssim = _L1SSIM.apply(_prep(colors), _prep(pixels.detach()), 1.0 - ssim_lambda, -ssim_lambda,
+                                   ssim_lambda, True)
+    return loss, l1, 1.0 - ssim
+
+
+def fused_ssim(img1: Tensor, img2: Tensor, padding: str = "same", train: bool = True) -> Tensor:
+    """Mean SSIM of NCHW images; the gradient flows to img1 only (img2 is the target)."""
+    assert padding in ("same", "valid"), padding
+    assert img1.shape == img2.shape and img1.dim() == 4, (img1.shape, img2.shape)
+    a = img1.permute(0, 2, 3, 1)
+    b = img2.detach().permute(0, 2, 3, 1)
+    out, _, _ = _L1SSIM.apply(_prep(a), _prep(b), 0.0, 1.0, 0.0, padding == "valid")
+    return out
