@@ -1,0 +1,63 @@
+"""N>1 path on CPU: world_size 2 over gloo.  Covers the launcher (`cli`), the single flattened
+gradient all-reduce of the view-sharded data parallelism and the densification-statistics
+all-reduce that keeps replicated Gaussians identical on every rank."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker_fn(local_rank, world_rank, world_size, out_dir):
+    from splat_one_amd import distributed as sdist
+    assert dist.is_initialized() and dist.get_world_size() == world_size == 2
+    torch.manual_seed(0)
+    shapes = [(10, 3), (10, 4), (10,), (10, 15, 3)]
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    for i, p in enumerate(params):
+        p.grad = torch.full(p.shape, float(world_rank + 1) * (i + 1))
+    red = sdist.GradientReducer()
+    red.reduce(params)
+    for i, p in enumerate(params):
+        assert torch.allclose(p.grad, torch.full(p.shape, 1.5 * (i + 1))), (world_rank, i)
+    # one flat buffer backs every gradient (single all-reduce)
+    base = params[0].grad.untyped_storage().data_ptr()
+    assert all(p.grad.untyped_storage().data_ptr() == base for p in params)
+    state = {"grad2d": torch.full((10,), float(world_rank + 1)), "count": torch.ones(10) * (world_rank + 2),
+             "scene_scale": 1.0}
+    sdist.all_reduce_strategy_state(state)
+    assert torch.allclose(state["grad2d"], torch.full((10,), 3.0)) and torch.allclose(state["count"], torch.full((10,), 5.0))
+    torch.save({"ok": True, "rank": world_rank}, os.path.join(out_dir, f"rank{world_rank}.pt"))
+
+
+def test_view_sharded_dp_world2_gloo(tmp_path):
+    from splat_one_amd import distributed as sdist
+    env_backup = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        sdist.cli(_worker_fn, str(tmp_path), world_size=2, backend="gloo", port=_free_port())
+    finally:
+        for k, v in env_backup.items():
+            if v is not None:
+                os.environ[k] = v
+            else:
+                os.environ.pop(k, None)
+    for r in range(2):
+        assert torch.load(os.path.join(tmp_path, f"rank{r}.pt"))["ok"]
+
+
+def test_adam_rule_scales_with_world_size():
+    """gsplat_trainer.py:266-278 with BS = batch_size * world_size."""
+    from splat_one_amd.trainer import adam_hyperparameters
+    lr, eps, betas = adam_hyperparameters(1.6e-4, 1, 8)
+    assert abs(lr - 1.6e-4 * 8 ** 0.5) < 1e-18 and abs(eps - 1e-15 / 8 ** 0.5) < 1e-30
+    assert abs(betas[0] - 0.2) < 1e-12 and abs(betas[1] - 0.992) < 1e-12

@@ -1,0 +1,143 @@
+"""Host logic of the densification strategy on CPU tensors (the structural edits are tensor
+surgery shared by CPU and GPU; the kernels are not involved), against the loop-level oracle."""
+import math
+
+import pytest
+import torch
+
+from oracle import strategy_oracle as SO
+from splat_one_amd.strategy import DefaultStrategy, duplicate, remove, reset_opa, split
+
+
+def _params(N, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    vals = {
+        "means": torch.randn(N, 3, generator=g),
+        "scales": torch.log(torch.rand(N, 3, generator=g) * 0.05 + 0.001),
+        "quats": torch.randn(N, 4, generator=g),
+        "opacities": torch.logit(torch.rand(N, generator=g) * 0.98 + 0.001),
+        "sh0": torch.randn(N, 1, 3, generator=g),
+        "shN": torch.randn(N, 15, 3, generator=g),
+    }
+    params = torch.nn.ParameterDict({k: torch.nn.Parameter(v) for k, v in vals.items()})
+    opts = {k: torch.optim.Adam([{"params": params[k], "lr": 1e-3, "name": k}], eps=1e-15) for k in vals}
+    for k in vals:   # populate the moments with one step
+        params[k].grad = torch.randn(params[k].shape, generator=g)
+        opts[k].step()
+        opts[k].zero_grad(set_to_none=True)
+    return params, opts
+
+
+def _check_consistent(params, opts, N):
+    for k, p in params.items():
+        assert p.shape[0] == N, k
+        st = opts[k].state[p]
+        assert st["exp_avg"].shape == p.shape and st["exp_avg_sq"].shape == p.shape
+        assert opts[k].param_groups[0]["params"][0] is p
+        assert float(st["step"]) == 1.0
+
+
+def test_update_state_matches_loop_oracle():
+    C, N, W, H = 3, 40, 64, 48
+    g = torch.Generator().manual_seed(1)
+    radii = (torch.rand(C, N, generator=g) > 0.4).int() * 5
+    grads = torch.randn(C, N, 2, generator=g) * 1e-3
+    s = DefaultStrategy()
+    state = s.initialize_state(scene_scale=1.0)
+    params, _ = _params(N)
+    m2 = torch.zeros(C, N, 2, requires_grad=True)
+    m2.grad = grads
+    info = dict(width=W, height=H, n_cameras=C, radii=radii, means2d=m2)
+    for _ in range(2):
+        s._update_state(params, state, info)
+    g2, cn = torch.zeros(N), torch.zeros(N)
+    for _ in range(2):
+        g2, cn = SO.update_state(g2, cn, grads, radii, W, H, C)
+    assert torch.allclose(state["grad2d"], g2, rtol=1e-5, atol=1e-7) and torch.equal(state["count"], cn)
+
+
+@pytest.mark.parametrize("step", [600, 3100])
+def test_refine_step_matches_loop_oracle(step):
+    N = 60
+    params, opts = _params(N, seed=2)
+    s = DefaultStrategy()
+    state = s.initialize_state(scene_scale=2.0)
+    g = torch.Generator().manual_seed(3)
+    state["grad2d"] = torch.rand(N, generator=g) * 6e-4
+    state["count"] = torch.randint(0, 3, (N,), generator=g).float()
+    with torch.no_grad():
+        params["scales"][:20] = math.log(0.3)      # some large ones -> split / too big
+        params["opacities"][5:9] = -8.0            # transparent -> pruned
+    before = {k: v.detach().clone() for k, v in params.items()}
+    dup, spl, prune_fn = SO.refine_masks(state["grad2d"], state["count"], before["scales"], before["opacities"], step, 2.0)
+    n_dup, n_spl = int(dup.sum()), int(spl.sum())
+    assert n_dup > 0 and n_spl > 0
+    gen = torch.Generator().manual_seed(9)
+    nd, ns = s._grow_gs(params, opts, state, step, gen)
+    assert (nd, ns) == (n_dup, n_spl)
+    N2 = N + n_dup + n_spl            # dup appends n_dup, split replaces n_spl by 2 n_spl
+    _check_consistent(params, opts, N2)
+    keep = ~spl
+    # layout after grow: [not-split originals | duplicates (not split)] then the 2*n_spl samples
+    expect_head = torch.cat([before["means"][keep], before["means"][dup]])
+    assert torch.equal(params["means"][:N2 - 2 * n_spl], expect_head)
+    new_scales = params["scales"][N2 - 2 * n_spl:]
+    assert torch.allclose(new_scales[:n_spl], torch.log(torch.exp(before["scales"][spl]) / 1.6))
+    assert torch.equal(new_scales[:n_spl], new_scales[n_spl:])
+    assert torch.equal(params["shN"][N2 - 2 * n_spl:N2 - n_spl], before["shN"][spl])
+    # moments of new rows are zero, of kept rows unchanged
+    st = opts["means"].state[params["means"]]
+    assert st["exp_avg"][N - n_spl:].abs().max() == 0
+    # split samples are means + R diag(s) eps with the generator's normal draws
+    gen2 = torch.Generator().manual_seed(9)
+    eps = torch.randn(2, n_spl, 3, generator=gen2)
+    q = torch.nn.functional.normalize(before["quats"][spl], dim=-1)
+    from oracle.torch_oracle import quat_to_rotmat
+    R = quat_to_rotmat(q.double()).float()
+    samples = torch.einsum("nij,nj,bnj->bni", R, torch.exp(before["scales"][spl]), eps)
+    assert torch.allclose(params["means"][N2 - 2 * n_spl:], (before["means"][spl] + samples).reshape(-1, 3), atol=1e-5)
+    # prune
+    want = prune_fn(params["scales"].detach(), params["opacities"].detach())
+    n_pr = s._prune_gs(params, opts, state, step)
+    assert n_pr == int(want.sum()) and n_pr > 0
+    _check_consistent(params, opts, N2 - n_pr)
+    assert state["grad2d"].shape[0] == N2 - n_pr and state["count"].shape[0] == N2 - n_pr
+
+
+def test_reset_opacity_and_schedule():
+    N = 30
+    params, opts = _params(N, seed=4)
+    s = DefaultStrategy()
+    state = s.initialize_state()
+    reset_opa(params, opts, state, value=s.prune_opa * 2.0)
+    cap = math.log(0.01 / 0.99)
+    assert params["opacities"].max().item() <= cap + 1e-6
+    st = opts["opacities"].state[params["opacities"]]
+    assert st["exp_avg"].abs().max() == 0 and st["exp_avg_sq"].abs().max() == 0
+    # schedule: refine only at step > refine_start_iter, multiple of refine_every, before refine_stop_iter
+    calls = []
+    s2 = DefaultStrategy()
+    s2._grow_gs = lambda *a, **k: (calls.append(a[3]) or (0, 0))
+    s2._prune_gs = lambda *a, **k: 0
+    s2._update_state = lambda *a, **k: None
+    st2 = {"grad2d": torch.zeros(N), "count": torch.zeros(N), "scene_scale": 1.0}
+    for step in (100, 500, 600, 650, 700, 3000, 14900, 15000, 15100):
+        s2.step_post_backward(params, opts, st2, step, {})
+    assert calls == [600, 700, 3000, 14900]
+
+
+def test_duplicate_remove_roundtrip():
+    N = 25
+    params, opts = _params(N, seed=5)
+    state = {"grad2d": torch.arange(N).float(), "count": torch.ones(N)}
+    before = params["means"].detach().clone()
+    mask = torch.zeros(N, dtype=torch.bool)
+    mask[[3, 7]] = True
+    duplicate(params, opts, state, mask)
+    _check_consistent(params, opts, N + 2)
+    assert torch.equal(params["means"][N:], before[[3, 7]]) and state["grad2d"][N:].tolist() == [3.0, 7.0]
+    rm = torch.zeros(N + 2, dtype=torch.bool)
+    rm[N:] = True
+    remove(params, opts, state, rm)
+    _check_consistent(params, opts, N)
+    assert torch.equal(params["means"].detach(), before)
