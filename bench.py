@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--regime", default="mcmc", choices=["mcmc", "ref"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--operator-path", action="store_true",
+                    help="time the operator-level autograd path instead of the fused engine")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel times to stderr")
     args = ap.parse_args()
 
@@ -112,7 +114,8 @@ def main():
     W, H, N = args.width, args.height, args.n
     init_scale, init_opa = (1.0, 0.1) if args.regime == "ref" else (0.1, 0.5)
     cfg = Config(init_num_pts=N, init_scale=init_scale, init_opa=init_opa, batch_size=1, shN_init_std=0.1,
-                 camera_model="pinhole", sh_degree_interval=1)   # SH degree 3 from step 3 on
+                 camera_model="pinhole", sh_degree_interval=1,    # SH degree 3 from step 3 on
+                 fused=not args.operator_path)
     runner = Runner(local_rank, rank, world, cfg, scene_scale=1.0 / 1.1)   # effective scene_scale 1.0
     cams = front_camera()[None] if world == 1 else ring_cameras(world)
     c2w = cams[rank:rank + 1].to(dev)
@@ -125,20 +128,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warm-up (also finds the dominant kernel with per-entry-point HIP events)
-    _lib.PROFILE = "all"
+    fused = cfg.fused
+    lib = _lib.load()
+
+    # warm-up
+    if not fused:
+        _lib.PROFILE = "all"     # operator path: per-entry-point HIP events from Python
     for _ in range(max(1, args.warmup)):
         runner.train_step(c2w, Ks, pixels)
-    prof = _lib.profile_summary()
-    dominant = max(prof.items(), key=lambda kv: kv[1][0] * kv[1][1])[0]
-    if args.kernel_table and rank == 0:
-        tot = sum(n * ms for n, ms in prof.values())
-        for k, (n, ms) in sorted(prof.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
-            print(f"  {k:24s} calls/step {n / max(1, args.warmup):4.1f}  mean {ms * 1e3:9.1f} us  share {n * ms / tot:5.1%}", file=sys.stderr)
-    _lib.PROFILE = {dominant}
+    torch.cuda.synchronize()
+    if not fused:
+        prof = _lib.profile_summary()
+        dominant = max(prof.items(), key=lambda kv: kv[1][0] * kv[1][1])[0]
+        _lib.PROFILE = {dominant}
 
-    # forward-only rate
+    # forward-only rate (operator-level `rasterization` under no_grad: the viewer / eval path)
     with torch.no_grad():
+        for _ in range(3):
+            runner.rasterize_splats(c2w, Ks, W, H, sh_degree=3, near_plane=cfg.near_plane, far_plane=cfg.far_plane)
         barrier()
         t0 = time.time()
         for _ in range(20):
@@ -158,8 +165,29 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    dom_calls, dom_ms = _lib.profile_summary()[dominant]
-    _lib.PROFILE = None
+
+    if fused:
+        # Per-kernel durations with HIP events on the launch stream.  Events cannot be recorded
+        # inside a hipGraph replay, so the same --steps iterations are re-run un-captured with the
+        # library's stage timers on (same kernels, same inputs; parameters keep training).
+        eng = runner._engine
+        saved_graph_flag = eng.use_graph
+        eng.use_graph = False
+        lib.so_profile_enable(1)
+        for _ in range(args.steps):
+            runner.train_step(c2w, Ks, pixels)
+        prof = _lib.stage_profile()
+        lib.so_profile_enable(0)
+        eng.use_graph = saved_graph_flag
+        dominant = max(prof.items(), key=lambda kv: kv[1][0] * kv[1][1])[0]
+        dom_calls, dom_ms = prof[dominant]
+    else:
+        dom_calls, dom_ms = _lib.profile_summary()[dominant]
+        _lib.PROFILE = None
+    if args.kernel_table and rank == 0:
+        tot = sum(n * ms for n, ms in prof.values())
+        for k, (n, ms) in sorted(prof.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+            print(f"  {k:24s} calls {n:5d}  mean {ms * 1e3:9.1f} us  share {n * ms / tot:5.1%}", file=sys.stderr)
 
     info = runner.last_info
     V = int((info["radii"] > 0).sum().item())
@@ -167,7 +195,14 @@ def main():
     P = W * H
     K = (cfg.sh_degree + 1) ** 2
     ab = algorithmic_bytes(N, V, I, P, K)
-    b_iter = sum(ab.values())
+    ab["so_preprocess_fwd"] = ab["so_projection_fwd"] + ab["so_sh_fwd"] + 12 * N          # fused K1+K4+count
+    ab["so_preprocess_bwd"] = ab["so_projection_bwd"] + ab["so_sh_bwd"]                    # fused K2+K5
+    ab["so_adam_step_dev"] = ab["so_adam_step"]
+    ab["so_isect_scan"] = 8 * (W // 16 + 1) * (H // 16 + 1)
+    ab["so_ssim_l1_fwd"] = 24 * P + 36 * P
+    ab["so_ssim_l1_bwd"] = 60 * P + 12 * P
+    b_iter = sum(ab[k] for k in ("so_projection_fwd", "so_sh_fwd", "so_isect_count", "so_isect_fill", "so_rasterize_fwd",
+                                 "so_rasterize_bwd", "so_sh_bwd", "so_projection_bwd", "so_adam_step"))
     achieved = ab[dominant] / (dom_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -185,6 +220,7 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "path": "fused engine (hipGraph replay)" if fused else "operator-level autograd path",
         "config": {"workload": f"c2: {N} Gaussians (reference random init, '{args.regime}' preset), "
                                f"{W}x{H}, SH degree 3, 1 view per GPU per step, pinhole",
                    "views_per_step": world, "visible_gaussians": V, "tile_intersections": I,

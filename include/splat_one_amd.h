@@ -111,6 +111,9 @@ int so_sh_bwd(int C, int N, int K, int degrees_to_use, const float *dirs, const 
 int so_isect_count(int C, int N, const float *means2d, const int32_t *radii, int tile_size, int tile_width,
                    int tile_height, int32_t *tiles_per_gauss, int32_t *tile_counts, int32_t *isect_offsets,
                    int32_t *n_isects, void *stream);
+/* the exclusive scan of step 1 alone (when the histogram was filled by so_preprocess_fwd) */
+int so_isect_scan(int C, int tile_width, int tile_height, const int32_t *tile_counts, int32_t *isect_offsets,
+                  int32_t *n_isects, void *stream);
 int so_isect_fill(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                   int tile_size, int tile_width, int tile_height, const int32_t *isect_offsets,
                   const int32_t *n_isects, int32_t *tile_cursor, int64_t capacity, uint64_t *key_buf,
@@ -176,6 +179,87 @@ typedef struct so_adam_group {
 } so_adam_group;
 int so_adam_step(int n_groups, const so_adam_group *host_groups, double beta1, double beta2, double eps,
                  int zero_grad, void *stream);
+
+/* Device-scheduled variant for hipGraph replay: `step_counter` (device i32, number of optimiser
+ * steps done so far) is read by the kernel, which evaluates lr = lr0[g] * lr_gamma[g]^step
+ * (ExponentialLR, gsplat_trainer.py:512-516 and :741-742), the bias corrections for t = step+1, and
+ * increments the counter afterwards.  Launch arguments are therefore constant across iterations. */
+int so_adam_step_dev(int n_groups, const so_adam_group *host_groups, const float *host_lr0,
+                     const float *host_lr_gamma, double beta1, double beta2, double eps, int32_t *step_counter,
+                     int zero_grad, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused front end / back end on the RAW parameters (what `Runner.rasterize_splats` holds,
+ * gsplat_trainer.py:456-474): exp / sigmoid activations, SH concat, camera centre, projection, SH
+ * colour (+0.5, clamp) and the first binning pass in ONE forward kernel; projection bwd + SH bwd +
+ * activation bwd + opacity/scale regularisers (:650-653) + the densification statistics of
+ * `DefaultStrategy._update_state` (:744-752) in ONE backward kernel.
+ *   means[N,3] log_scales[N,3] quats[N,4] logit_opacities[N] sh0[N,1,3] shN[N,K-1,3]
+ *   -> radii, means2d, depths, conics, opacities[C,N] (sigmoid, x compensation if antialiased),
+ *      colors[C,N,3], tiles_per_gauss[C,N], tile_counts[C*tiles] (+=, zeroed by the caller)
+ * Backward overwrites v_means, v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN and adds
+ * to grad2d[N] / count[N] (nullable pair).  v_means2d_abs / v_depths nullable.
+ * ---------------------------------------------------------------------------------------- */
+int so_preprocess_fwd(int C, int N, int K, int sh_degree, const float *means, const float *log_scales,
+                      const float *quats, const float *logit_opacities, const float *sh0, const float *shN,
+                      const float *viewmats, const float *Ks, int width, int height, float eps2d,
+                      float near_plane, float far_plane, float radius_clip, int camera_model, int antialiased,
+                      int tile_size, int32_t *radii, float *means2d, float *depths, float *conics,
+                      float *opacities, float *colors, int32_t *tiles_per_gauss, int32_t *tile_counts,
+                      void *stream);
+int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float *means, const float *log_scales,
+                      const float *quats, const float *logit_opacities, const float *sh0, const float *shN,
+                      const float *viewmats, const float *Ks, int width, int height, float eps2d,
+                      int camera_model, int antialiased, const int32_t *radii, const float *opacities,
+                      const float *colors, const float *v_means2d, const float *v_means2d_abs,
+                      const float *v_depths, const float *v_conics, const float *v_colors,
+                      const float *v_opacities, float opacity_reg, float scale_reg, float *v_means,
+                      float *v_log_scales, float *v_quats, float *v_logit_opacities, float *v_sh0, float *v_shN,
+                      float *grad2d, float *count, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One training iteration (gsplat_trainer.py:586-655: render -> loss -> backward) as ONE call on
+ * caller-owned static buffers: memsets + 11 launches, no allocation, no host read-back, capturable
+ * in a hipGraph.  Gradients of the raw parameters are overwritten; loss_sums[2] = (sum|x-y|,
+ * sum SSIM_valid).  counters: int32[2*C*tiles + 2] (histogram | cursor | n_isects | overflow);
+ * v_inter: float[(9 or 11) * C*N]; zero_v_alphas: float[C*H*W] of zeros (the photometric loss does
+ * not depend on alpha).  `abi_size` must be sizeof(so_step_desc).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct so_step_desc {
+  /* raw parameters */
+  const float *means, *log_scales, *quats, *logit_opacities, *sh0, *shN;
+  /* cameras and target */
+  const float *viewmats, *Ks, *pixels, *backgrounds /* nullable [C,3] */;
+  /* per-view intermediates */
+  int32_t *radii;
+  float *means2d, *depths, *conics, *opacities, *colors;
+  int32_t *tiles_per_gauss, *counters, *isect_offsets;
+  uint64_t *key_buf;
+  int32_t *flatten_ids;
+  float *render_colors, *render_alphas;
+  int32_t *last_ids;
+  float *loss_sums, *dmaps, *v_render_colors;
+  const float *zero_v_alphas;
+  float *v_inter;
+  /* gradients of the raw parameters */
+  float *v_means, *v_log_scales, *v_quats, *v_logit_opacities, *v_sh0, *v_shN;
+  /* densification statistics (nullable pair) */
+  float *grad2d, *count;
+  int64_t isect_capacity;
+  int32_t abi_size, C, N, K, width, height, tile_size, sh_degree, camera_model, antialiased, absgrad;
+  float eps2d, near_plane, far_plane, radius_clip, ssim_lambda, opacity_reg, scale_reg;
+} so_step_desc;
+int so_train_step_fwd_bwd(const so_step_desc *desc, void *stream);
+
+/* Per-stage HIP-event timing of so_train_step_fwd_bwd / so_adam_step_dev on their launch stream
+ * (measurement only, not thread-safe; events cannot be recorded inside a hipGraph replay, so
+ * profile un-captured launches).  so_profile_read synchronises the device, returns the summed
+ * milliseconds and call counts of the so_profile_num_stages() stages and clears the log. */
+int so_profile_enable(int enabled);
+int so_profile_num_stages(void);
+const char *so_profile_stage_name(int stage);
+int so_profile_read(float *host_ms_sum, int *host_calls);
+void so_profile_stage_begin_end(int stage, int begin, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Photometric loss.  Replaces F.l1_loss + the CUDA-only `fused_ssim(..., padding="valid")` of

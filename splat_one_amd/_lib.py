@@ -25,6 +25,24 @@ class AdamGroup(ctypes.Structure):
                 ("lr_step_size", c_f32), ("bc2_sqrt", c_f32)]
 
 
+class StepDesc(ctypes.Structure):
+    """Mirror of `so_step_desc` (include/splat_one_amd.h) -- same field order and types."""
+    _fields_ = (
+        [(n, c_ptr) for n in ("means", "log_scales", "quats", "logit_opacities", "sh0", "shN",
+                              "viewmats", "Ks", "pixels", "backgrounds",
+                              "radii", "means2d", "depths", "conics", "opacities", "colors",
+                              "tiles_per_gauss", "counters", "isect_offsets", "key_buf", "flatten_ids",
+                              "render_colors", "render_alphas", "last_ids", "loss_sums", "dmaps",
+                              "v_render_colors", "zero_v_alphas", "v_inter",
+                              "v_means", "v_log_scales", "v_quats", "v_logit_opacities", "v_sh0", "v_shN",
+                              "grad2d", "count")]
+        + [("isect_capacity", c_i64)]
+        + [(n, ctypes.c_int32) for n in ("abi_size", "C", "N", "K", "width", "height", "tile_size", "sh_degree",
+                                         "camera_model", "antialiased", "absgrad")]
+        + [(n, c_f32) for n in ("eps2d", "near_plane", "far_plane", "radius_clip", "ssim_lambda", "opacity_reg",
+                                "scale_reg")])
+
+
 # name -> argtypes, exactly the prototypes of include/splat_one_amd.h
 _SIGS = {
     "so_projection_fwd": [c_int, c_int] + [c_ptr] * 6 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int] + [c_ptr] * 6,
@@ -39,6 +57,14 @@ _SIGS = {
     "so_rasterize_bwd": [c_int] * 6 + [c_ptr] * 9 + [c_i64] + [c_ptr] * 10,
     "so_ssim_l1_fwd": [c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr],
     "so_ssim_l1_bwd": [c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_ptr, c_ptr, c_ptr],
+    "so_isect_scan": [c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
+    "so_preprocess_fwd": [c_int] * 4 + [c_ptr] * 8 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_int] + [c_ptr] * 9,
+    "so_preprocess_bwd": [c_int] * 4 + [c_ptr] * 8 + [c_int, c_int, c_f32, c_int, c_int] + [c_ptr] * 9 + [c_f32, c_f32] + [c_ptr] * 9,
+    "so_train_step_fwd_bwd": [ctypes.POINTER(StepDesc), c_ptr],
+    "so_profile_enable": [c_int],
+    "so_profile_read": [ctypes.POINTER(c_f32), ctypes.POINTER(c_int)],
+    "so_adam_step_dev": [c_int, ctypes.POINTER(AdamGroup), ctypes.POINTER(c_f32), ctypes.POINTER(c_f32),
+                         ctypes.c_double, ctypes.c_double, ctypes.c_double, c_ptr, c_int, c_ptr],
     "so_adam_step": [c_int, ctypes.POINTER(AdamGroup), ctypes.c_double, ctypes.c_double, ctypes.c_double, c_int, c_ptr],
 }
 
@@ -46,7 +72,8 @@ _lib: Optional[ctypes.CDLL] = None
 
 
 def exported_symbols():
-    return ["so_abi_version", "so_last_error", "so_device_cu_count"] + list(_SIGS)
+    return ["so_abi_version", "so_last_error", "so_device_cu_count", "so_profile_num_stages",
+            "so_profile_stage_name", "so_profile_stage_begin_end"] + list(_SIGS)
 
 
 def load() -> ctypes.CDLL:
@@ -61,6 +88,9 @@ def load() -> ctypes.CDLL:
         lib.so_abi_version.restype = c_int
         lib.so_last_error.restype = ctypes.c_char_p
         lib.so_device_cu_count.restype = c_int
+        lib.so_profile_num_stages.restype = c_int
+        lib.so_profile_stage_name.restype = ctypes.c_char_p
+        lib.so_profile_stage_name.argtypes = [c_int]
         for name, argtypes in _SIGS.items():
             fn = getattr(lib, name)
             fn.argtypes = argtypes
@@ -105,6 +135,16 @@ def call(name: str, *args) -> None:
     if rc != 0:
         msg = lib.so_last_error().decode()
         raise RuntimeError(f"{name} failed with status {rc}: {msg}")
+
+
+def stage_profile() -> dict:
+    """{stage name: (n_calls, mean_ms)} of the C-side stage timers (so_profile_enable); synchronises."""
+    lib = load()
+    n = lib.so_profile_num_stages()
+    ms = (c_f32 * n)()
+    calls = (c_int * n)()
+    call("so_profile_read", ms, calls)
+    return {lib.so_profile_stage_name(i).decode(): (calls[i], ms[i] / max(1, calls[i])) for i in range(n) if calls[i]}
 
 
 def profile_summary(reset: bool = True) -> dict:

@@ -6,6 +6,8 @@
 // 16 B read + 12 B written per parameter float (+4 B when the gradient is zeroed in place).
 #include "so_common.hpp"
 
+extern "C" void so_profile_stage_begin_end(int stage, int begin, void *stream);
+
 namespace so {
 
 struct AdamGroups {
@@ -60,7 +62,90 @@ k_adam(AdamGroups groups, AdamHyper h, int zero_grad) {
   }
 }
 
+// ---- device-scheduled variant: step counter, LR schedule and bias corrections live on the device,
+// so the launch arguments never change and the whole training step can be replayed as a hipGraph.
+struct AdamDevGroups {
+  so_adam_group g[SO_ADAM_MAX_GROUPS];
+  float lr0[SO_ADAM_MAX_GROUPS];
+  float lr_gamma[SO_ADAM_MAX_GROUPS];
+};
+
+__global__ void __launch_bounds__(256)
+k_adam_dev(AdamDevGroups groups, double beta1, double beta2, AdamHyper h, const int32_t *__restrict__ step_ptr,
+           int zero_grad) {
+  __shared__ float s_step_size, s_bc2_sqrt;
+  so_adam_group G = groups.g[blockIdx.y];
+  if (threadIdx.x == 0) {
+    const int step = *step_ptr;                 // optimiser steps completed so far
+    const double t = (double)(step + 1);
+    const double lr = (double)groups.lr0[blockIdx.y] * pow((double)groups.lr_gamma[blockIdx.y], (double)step);
+    s_step_size = (float)(lr / (1.0 - pow(beta1, t)));
+    s_bc2_sqrt = (float)sqrt(1.0 - pow(beta2, t));
+  }
+  __syncthreads();
+  const float step_size = s_step_size, bc2_sqrt = s_bc2_sqrt;
+  const int64_t n4 = G.numel / 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float4 *p4 = reinterpret_cast<float4 *>(G.param);
+  float4 *g4 = reinterpret_cast<float4 *>(G.grad);
+  float4 *m4 = reinterpret_cast<float4 *>(G.exp_avg);
+  float4 *v4 = reinterpret_cast<float4 *>(G.exp_avg_sq);
+  for (int64_t i = t0; i < n4; i += stride) {
+    float4 p = p4[i], g = g4[i], m = m4[i], v = v4[i];
+    adam_one(p.x, g.x, m.x, v.x, h, step_size, bc2_sqrt);
+    adam_one(p.y, g.y, m.y, v.y, h, step_size, bc2_sqrt);
+    adam_one(p.z, g.z, m.z, v.z, h, step_size, bc2_sqrt);
+    adam_one(p.w, g.w, m.w, v.w, h, step_size, bc2_sqrt);
+    p4[i] = p; m4[i] = m; v4[i] = v;
+    if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int64_t i = n4 * 4 + t0; i < G.numel; i += stride) {
+    float p = G.param[i], m = G.exp_avg[i], v = G.exp_avg_sq[i];
+    adam_one(p, G.grad[i], m, v, h, step_size, bc2_sqrt);
+    G.param[i] = p; G.exp_avg[i] = m; G.exp_avg_sq[i] = v;
+    if (zero_grad) G.grad[i] = 0.f;
+  }
+}
+
+__global__ void k_step_inc(int32_t *step_ptr) { *step_ptr += 1; }
+
 }  // namespace so
+
+extern "C" int so_adam_step_dev(int n_groups, const so_adam_group *host_groups, const float *host_lr0,
+                                const float *host_lr_gamma, double beta1, double beta2, double eps,
+                                int32_t *step_counter, int zero_grad, void *stream) {
+  SO_REQUIRE(n_groups >= 0 && n_groups <= SO_ADAM_MAX_GROUPS, "so_adam_step_dev: n_groups %d not in [0,%d]", n_groups, SO_ADAM_MAX_GROUPS);
+  SO_REQUIRE(step_counter, "so_adam_step_dev: null step counter");
+  if (n_groups == 0) return SO_OK;
+  SO_REQUIRE(host_groups && host_lr0 && host_lr_gamma, "so_adam_step_dev: null groups");
+  so::AdamDevGroups G;
+  int64_t max_numel = 0;
+  for (int i = 0; i < n_groups; ++i) {
+    const so_adam_group &g = host_groups[i];
+    SO_REQUIRE(g.numel >= 0 && g.visibility == nullptr, "so_adam_step_dev: group %d bad numel / visibility unsupported", i);
+    SO_REQUIRE(g.numel == 0 || (g.param && g.grad && g.exp_avg && g.exp_avg_sq), "so_adam_step_dev: group %d null pointer", i);
+    SO_REQUIRE((((uintptr_t)g.param | (uintptr_t)g.grad | (uintptr_t)g.exp_avg | (uintptr_t)g.exp_avg_sq) & 15) == 0,
+               "so_adam_step_dev: group %d buffers must be 16-byte aligned", i);
+    G.g[i] = g;
+    G.lr0[i] = host_lr0[i];
+    G.lr_gamma[i] = host_lr_gamma[i];
+    if (g.numel > max_numel) max_numel = g.numel;
+  }
+  hipStream_t st = so::as_stream(stream);
+  so_profile_stage_begin_end(8, 1, stream);
+  if (max_numel > 0) {
+    int64_t gx = so::ceil_div(so::ceil_div(max_numel, 4), 256);
+    if (gx > 2048) gx = 2048;
+    if (gx < 1) gx = 1;
+    const so::AdamHyper H{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps};
+    hipLaunchKernelGGL(so::k_adam_dev, dim3((unsigned)gx, (unsigned)n_groups), dim3(256), 0, st, G, beta1, beta2, H,
+                       step_counter, zero_grad);
+  }
+  so_profile_stage_begin_end(8, 0, stream);
+  hipLaunchKernelGGL(so::k_step_inc, dim3(1), dim3(1), 0, st, step_counter);
+  return so::check_launch("so_adam_step_dev");
+}
 
 extern "C" int so_adam_step(int n_groups, const so_adam_group *host_groups, double beta1, double beta2, double eps,
                             int zero_grad, void *stream) {

@@ -309,6 +309,15 @@ extern "C" int so_isect_count(int C, int N, const float *means2d, const int32_t 
   return so::check_launch("so_isect_count");
 }
 
+extern "C" int so_isect_scan(int C, int tile_width, int tile_height, const int32_t *tile_counts,
+                             int32_t *isect_offsets, int32_t *n_isects, void *stream) {
+  SO_REQUIRE(C >= 0 && tile_width > 0 && tile_height > 0, "so_isect_scan: bad sizes");
+  SO_REQUIRE(tile_counts && isect_offsets && n_isects, "so_isect_scan: null pointer");
+  hipLaunchKernelGGL(so::k_scan_tiles, dim3(1), dim3(1024), 0, so::as_stream(stream),
+                     (int64_t)C * tile_width * tile_height, tile_counts, isect_offsets, n_isects);
+  return so::check_launch("so_isect_scan");
+}
+
 extern "C" int so_isect_fill(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                              int tile_size, int tile_width, int tile_height, const int32_t *isect_offsets,
                              const int32_t *n_isects, int32_t *tile_cursor, int64_t capacity, uint64_t *key_buf,

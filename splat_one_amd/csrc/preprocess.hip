@@ -1,0 +1,275 @@
+// preprocess.hip -- fused per-Gaussian front end / back end of the training step for gfx950.
+//
+// The reference does, per iteration, exp(scales), sigmoid(opacities), cat(sh0, shN), inv(camtoworld)
+// in `Runner.rasterize_splats` (/root/reference/utils/gsplat_utils/gsplat_trainer.py:456-474) and
+// then, inside `rasterization` (:477), projection, SH evaluation (+0.5, clamp) and the first
+// binning pass as separate launches with materialised intermediates.  Here ONE forward kernel reads
+// the RAW parameters once and writes everything the tile rasteriser needs (and the per-tile
+// histogram of the binning pass); ONE backward kernel turns the rasteriser's gradients into
+// gradients of the raw parameters (projection bwd + SH bwd + activation bwd + regularisers) and
+// accumulates the densification statistics of `DefaultStrategy._update_state` on the way.
+// Same math as projection.hip / sh.hip (splat_math.hpp); one lane per (camera, Gaussian) forward,
+// one lane per Gaussian backward (no atomics on parameter gradients).
+#include "so_common.hpp"
+#include "splat_math.hpp"
+
+namespace so {
+
+struct CamP {
+  float Rw[9], tw[3], fx, fy, cx, cy, pos[3];
+};
+
+__device__ __forceinline__ CamP load_camp(const float *__restrict__ viewmats, const float *__restrict__ Ks, int c) {
+  CamP p;
+  const float *V = viewmats + 16 * c;
+  p.Rw[0] = V[0]; p.Rw[1] = V[1]; p.Rw[2] = V[2];
+  p.Rw[3] = V[4]; p.Rw[4] = V[5]; p.Rw[5] = V[6];
+  p.Rw[6] = V[8]; p.Rw[7] = V[9]; p.Rw[8] = V[10];
+  p.tw[0] = V[3]; p.tw[1] = V[7]; p.tw[2] = V[11];
+  const float *K = Ks + 9 * c;
+  p.fx = K[0]; p.fy = K[4]; p.cx = K[2]; p.cy = K[5];
+  // camera centre of a rigid world->camera transform: -R^T t  (== inverse(viewmat)[:3,3])
+#pragma unroll
+  for (int j = 0; j < 3; ++j) p.pos[j] = -(p.Rw[j] * p.tw[0] + p.Rw[3 + j] * p.tw[1] + p.Rw[6 + j] * p.tw[2]);
+  return p;
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+template <int DEG>
+__global__ void __launch_bounds__(256)
+k_preprocess_fwd(int C, int N, int K, const float *__restrict__ means, const float *__restrict__ log_scales,
+                 const float *__restrict__ quats, const float *__restrict__ logit_opac,
+                 const float *__restrict__ sh0, const float *__restrict__ shN, const float *__restrict__ viewmats,
+                 const float *__restrict__ Ks, int W, int H, float eps2d, float near_plane, float far_plane,
+                 float radius_clip, int model, int antialiased, float tile_size, int tile_w, int tile_h,
+                 int32_t *__restrict__ radii, float *__restrict__ means2d, float *__restrict__ depths,
+                 float *__restrict__ conics, float *__restrict__ opacities, float *__restrict__ colors,
+                 int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ tile_counts) {
+  const int64_t total = (int64_t)C * N;
+  const int n_tiles = tile_w * tile_h;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx / N);
+    const int64_t n = idx - (int64_t)c * N;
+    const CamP cam = load_camp(viewmats, Ks, c);
+    const float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
+    const float4 qq = *reinterpret_cast<const float4 *>(quats + 4 * n);
+    const float q[4] = {qq.x, qq.y, qq.z, qq.w};
+    const float s[3] = {expf(log_scales[3 * n]), expf(log_scales[3 * n + 1]), expf(log_scales[3 * n + 2])};
+    ProjOut<float> o;
+    project_fwd<float>(mean, nullptr, q, s, cam.Rw, cam.tw, cam.fx, cam.fy, cam.cx, cam.cy, W, H, eps2d, near_plane,
+                       far_plane, radius_clip, model, o);
+    radii[idx] = o.radius;
+    *reinterpret_cast<float2 *>(means2d + 2 * idx) = make_float2(o.m2d[0], o.m2d[1]);
+    depths[idx] = o.depth;
+    conics[3 * idx] = o.conic[0]; conics[3 * idx + 1] = o.conic[1]; conics[3 * idx + 2] = o.conic[2];
+    float op = sigmoidf(logit_opac[n]);
+    if (antialiased) op *= o.comp;
+    opacities[idx] = op;
+    float r = 0.f, g = 0.f, b = 0.f;
+    int cnt = 0;
+    if (o.radius > 0) {
+      float dx = mean[0] - cam.pos[0], dy = mean[1] - cam.pos[1], dz = mean[2] - cam.pos[2];
+      const float inorm = rsqrtf(dx * dx + dy * dy + dz * dz);
+      dx *= inorm; dy *= inorm; dz *= inorm;
+      const float *c0 = sh0 + 3 * n;
+      const float *cN = shN + (int64_t)n * (K - 1) * 3;
+      sh_eval<float>(DEG, dx, dy, dz, [&](int k, float yk, float, float, float) {
+        const float *cf = (k == 0) ? c0 : cN + 3 * (k - 1);
+        r += yk * cf[0]; g += yk * cf[1]; b += yk * cf[2];
+      });
+      r = fmaxf(r + 0.5f, 0.f); g = fmaxf(g + 0.5f, 0.f); b = fmaxf(b + 0.5f, 0.f);
+      // first binning pass (same float arithmetic as isect.hip::tile_box)
+      const float tile_r = (float)o.radius / tile_size;
+      const float tx = o.m2d[0] / tile_size, ty = o.m2d[1] / tile_size;
+      const int x0 = (int)fminf(fmaxf(floorf(tx - tile_r), 0.f), (float)tile_w);
+      const int x1 = (int)fminf(fmaxf(ceilf(tx + tile_r), 0.f), (float)tile_w);
+      const int y0 = (int)fminf(fmaxf(floorf(ty - tile_r), 0.f), (float)tile_h);
+      const int y1 = (int)fminf(fmaxf(ceilf(ty + tile_r), 0.f), (float)tile_h);
+      cnt = (x1 - x0) * (y1 - y0);
+      int32_t *row = tile_counts + (int64_t)c * n_tiles;
+      for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) atomicAdd(row + y * tile_w + x, 1);
+    }
+    colors[3 * idx] = r; colors[3 * idx + 1] = g; colors[3 * idx + 2] = b;
+    tiles_per_gauss[idx] = cnt;
+  }
+}
+
+template <int DEG>
+__global__ void __launch_bounds__(256)
+k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const float *__restrict__ log_scales,
+                 const float *__restrict__ quats, const float *__restrict__ logit_opac,
+                 const float *__restrict__ sh0, const float *__restrict__ shN, const float *__restrict__ viewmats,
+                 const float *__restrict__ Ks, int W, int H, float eps2d, int model, int antialiased,
+                 const int32_t *__restrict__ radii, const float *__restrict__ opacities,
+                 const float *__restrict__ colors, const float *__restrict__ v_means2d,
+                 const float *__restrict__ v_means2d_abs, const float *__restrict__ v_depths,
+                 const float *__restrict__ v_conics, const float *__restrict__ v_colors,
+                 const float *__restrict__ v_opacities, float opacity_reg, float scale_reg,
+                 float *__restrict__ v_means, float *__restrict__ v_log_scales, float *__restrict__ v_quats,
+                 float *__restrict__ v_logit_opac, float *__restrict__ v_sh0, float *__restrict__ v_shN,
+                 float *__restrict__ grad2d, float *__restrict__ count, float stat_sx, float stat_sy) {
+  constexpr int NB = (DEG + 1) * (DEG + 1);
+  for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+    const float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
+    const float4 qq = *reinterpret_cast<const float4 *>(quats + 4 * n);
+    const float q[4] = {qq.x, qq.y, qq.z, qq.w};
+    const float s[3] = {expf(log_scales[3 * n]), expf(log_scales[3 * n + 1]), expf(log_scales[3 * n + 2])};
+    const float sig = sigmoidf(logit_opac[n]);
+    float vm[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f};
+    float v_sig = 0.f, g2 = 0.f, cn = 0.f;
+    float acc[NB][3];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const int64_t idx = (int64_t)c * N + n;
+      if (radii[idx] <= 0) continue;
+      const CamP cam = load_camp(viewmats, Ks, c);
+      const float2 vm2 = *reinterpret_cast<const float2 *>(v_means2d + 2 * idx);
+      const float v_m2d[2] = {vm2.x, vm2.y};
+      const float v_con[3] = {v_conics[3 * idx], v_conics[3 * idx + 1], v_conics[3 * idx + 2]};
+      const float v_op = v_opacities[idx];
+      float v_comp = 0.f;
+      if (antialiased) {
+        v_comp = v_op * sig;
+        v_sig += v_op * (opacities[idx] / sig);
+      } else {
+        v_sig += v_op;
+      }
+      project_bwd<float>(mean, nullptr, q, s, cam.Rw, cam.tw, cam.fx, cam.fy, cam.cx, cam.cy, W, H, eps2d, model,
+                         v_m2d, v_depths ? v_depths[idx] : 0.f, v_con, v_comp, vm, nullptr, vq, vs, nullptr, nullptr);
+      // SH backward (through +0.5 / clamp: the saved colour is 0 exactly where the clamp cut)
+      float vr = v_colors[3 * idx], vg = v_colors[3 * idx + 1], vb = v_colors[3 * idx + 2];
+      if (!(colors[3 * idx] > 0.f)) vr = 0.f;
+      if (!(colors[3 * idx + 1] > 0.f)) vg = 0.f;
+      if (!(colors[3 * idx + 2] > 0.f)) vb = 0.f;
+      const float ddx = mean[0] - cam.pos[0], ddy = mean[1] - cam.pos[1], ddz = mean[2] - cam.pos[2];
+      const float inorm = rsqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+      const float x = ddx * inorm, y = ddy * inorm, z = ddz * inorm;
+      const float *c0 = sh0 + 3 * n;
+      const float *cN = shN + n * (int64_t)(K - 1) * 3;
+      float vdn[3] = {0.f, 0.f, 0.f};
+      sh_eval<float>(DEG, x, y, z, [&](int k, float yk, float gx, float gy, float gz) {
+        acc[k][0] += yk * vr; acc[k][1] += yk * vg; acc[k][2] += yk * vb;
+        const float *cf = (k == 0) ? c0 : cN + 3 * (k - 1);
+        const float w = cf[0] * vr + cf[1] * vg + cf[2] * vb;
+        vdn[0] += gx * w; vdn[1] += gy * w; vdn[2] += gz * w;
+      });
+      const float dot = vdn[0] * x + vdn[1] * y + vdn[2] * z;
+      vm[0] += (vdn[0] - dot * x) * inorm;
+      vm[1] += (vdn[1] - dot * y) * inorm;
+      vm[2] += (vdn[2] - dot * z) * inorm;
+      // densification statistics (DefaultStrategy._update_state)
+      if (grad2d) {
+        float gx = vm2.x, gy = vm2.y;
+        if (v_means2d_abs) { gx = v_means2d_abs[2 * idx]; gy = v_means2d_abs[2 * idx + 1]; }
+        gx *= stat_sx; gy *= stat_sy;
+        g2 += sqrtf(gx * gx + gy * gy);
+        cn += 1.f;
+      }
+    }
+    v_means[3 * n] = vm[0]; v_means[3 * n + 1] = vm[1]; v_means[3 * n + 2] = vm[2];
+    *reinterpret_cast<float4 *>(v_quats + 4 * n) = make_float4(vq[0], vq[1], vq[2], vq[3]);
+    // d/d log s = s * d/ds ; scale regulariser: scale_reg * mean|exp(s)| over 3N entries
+    const float sreg = scale_reg / (3.f * (float)N);
+    v_log_scales[3 * n] = (vs[0] + sreg) * s[0];
+    v_log_scales[3 * n + 1] = (vs[1] + sreg) * s[1];
+    v_log_scales[3 * n + 2] = (vs[2] + sreg) * s[2];
+    v_logit_opac[n] = (v_sig + opacity_reg / (float)N) * sig * (1.f - sig);
+    v_sh0[3 * n] = acc[0][0]; v_sh0[3 * n + 1] = acc[0][1]; v_sh0[3 * n + 2] = acc[0][2];
+    float *o = v_shN + n * (int64_t)(K - 1) * 3;
+#pragma unroll
+    for (int k = 1; k < NB; ++k) { o[3 * (k - 1)] = acc[k][0]; o[3 * (k - 1) + 1] = acc[k][1]; o[3 * (k - 1) + 2] = acc[k][2]; }
+    for (int k = 3 * (NB - 1); k < 3 * (K - 1); ++k) o[k] = 0.f;
+    if (grad2d) { grad2d[n] += g2; count[n] += cn; }
+  }
+}
+
+static inline int pp_grid(int64_t total) {
+  int64_t g = ceil_div(total, 256);
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace so
+
+extern "C" int so_preprocess_fwd(int C, int N, int K, int sh_degree, const float *means, const float *log_scales,
+                                 const float *quats, const float *logit_opacities, const float *sh0,
+                                 const float *shN, const float *viewmats, const float *Ks, int width, int height,
+                                 float eps2d, float near_plane, float far_plane, float radius_clip,
+                                 int camera_model, int antialiased, int tile_size, int32_t *radii, float *means2d,
+                                 float *depths, float *conics, float *opacities, float *colors,
+                                 int32_t *tiles_per_gauss, int32_t *tile_counts, void *stream) {
+  SO_REQUIRE(C >= 0 && N >= 0 && K >= 1 && width > 0 && height > 0 && tile_size > 0, "so_preprocess_fwd: bad sizes");
+  SO_REQUIRE(sh_degree >= 0 && sh_degree <= 4 && (sh_degree + 1) * (sh_degree + 1) <= K,
+             "so_preprocess_fwd: sh_degree %d does not fit K=%d", sh_degree, K);
+  if (camera_model < 0 || camera_model > SO_CAM_FISHEYE) {
+    so::set_error("so_preprocess_fwd: unsupported camera_model %d", camera_model);
+    return SO_ERR_UNSUPPORTED;
+  }
+  if ((int64_t)C * N == 0) return SO_OK;
+  SO_REQUIRE(means && log_scales && quats && logit_opacities && sh0 && (shN || K == 1) && viewmats && Ks && radii &&
+                 means2d && depths && conics && opacities && colors && tiles_per_gauss && tile_counts,
+             "so_preprocess_fwd: null pointer");
+  const int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
+  const dim3 grid(so::pp_grid((int64_t)C * N)), block(256);
+  hipStream_t st = so::as_stream(stream);
+#define SO_LAUNCH(D)                                                                                               \
+  hipLaunchKernelGGL(so::k_preprocess_fwd<D>, grid, block, 0, st, C, N, K, means, log_scales, quats,               \
+                     logit_opacities, sh0, shN, viewmats, Ks, width, height, eps2d, near_plane, far_plane,         \
+                     radius_clip, camera_model, antialiased, (float)tile_size, tile_w, tile_h, radii, means2d,     \
+                     depths, conics, opacities, colors, tiles_per_gauss, tile_counts)
+  switch (sh_degree) {
+    case 0: SO_LAUNCH(0); break;
+    case 1: SO_LAUNCH(1); break;
+    case 2: SO_LAUNCH(2); break;
+    case 3: SO_LAUNCH(3); break;
+    default: SO_LAUNCH(4); break;
+  }
+#undef SO_LAUNCH
+  return so::check_launch("so_preprocess_fwd");
+}
+
+extern "C" int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float *means, const float *log_scales,
+                                 const float *quats, const float *logit_opacities, const float *sh0,
+                                 const float *shN, const float *viewmats, const float *Ks, int width, int height,
+                                 float eps2d, int camera_model, int antialiased, const int32_t *radii,
+                                 const float *opacities, const float *colors, const float *v_means2d,
+                                 const float *v_means2d_abs, const float *v_depths, const float *v_conics,
+                                 const float *v_colors, const float *v_opacities, float opacity_reg,
+                                 float scale_reg, float *v_means, float *v_log_scales, float *v_quats,
+                                 float *v_logit_opacities, float *v_sh0, float *v_shN, float *grad2d, float *count,
+                                 void *stream) {
+  SO_REQUIRE(C >= 0 && N >= 0 && K >= 1 && width > 0 && height > 0, "so_preprocess_bwd: bad sizes");
+  SO_REQUIRE(sh_degree >= 0 && sh_degree <= 4 && (sh_degree + 1) * (sh_degree + 1) <= K,
+             "so_preprocess_bwd: sh_degree %d does not fit K=%d", sh_degree, K);
+  if (camera_model < 0 || camera_model > SO_CAM_FISHEYE) {
+    so::set_error("so_preprocess_bwd: unsupported camera_model %d", camera_model);
+    return SO_ERR_UNSUPPORTED;
+  }
+  if (N == 0) return SO_OK;
+  SO_REQUIRE(means && log_scales && quats && logit_opacities && sh0 && (shN || K == 1) && viewmats && Ks && radii &&
+                 opacities && colors && v_means2d && v_conics && v_colors && v_opacities && v_means && v_log_scales &&
+                 v_quats && v_logit_opacities && v_sh0 && (v_shN || K == 1),
+             "so_preprocess_bwd: null pointer");
+  SO_REQUIRE((grad2d == nullptr) == (count == nullptr), "so_preprocess_bwd: grad2d and count go together");
+  const dim3 grid(so::pp_grid(N)), block(256);
+  hipStream_t st = so::as_stream(stream);
+  const float sx = 0.5f * (float)width * (float)C, sy = 0.5f * (float)height * (float)C;
+#define SO_LAUNCH(D)                                                                                              \
+  hipLaunchKernelGGL(so::k_preprocess_bwd<D>, grid, block, 0, st, C, N, K, means, log_scales, quats,              \
+                     logit_opacities, sh0, shN, viewmats, Ks, width, height, eps2d, camera_model, antialiased,    \
+                     radii, opacities, colors, v_means2d, v_means2d_abs, v_depths, v_conics, v_colors,            \
+                     v_opacities, opacity_reg, scale_reg, v_means, v_log_scales, v_quats, v_logit_opacities,      \
+                     v_sh0, v_shN, grad2d, count, sx, sy)
+  switch (sh_degree) {
+    case 0: SO_LAUNCH(0); break;
+    case 1: SO_LAUNCH(1); break;
+    case 2: SO_LAUNCH(2); break;
+    case 3: SO_LAUNCH(3); break;
+    default: SO_LAUNCH(4); break;
+  }
+#undef SO_LAUNCH
+  return so::check_launch("so_preprocess_bwd");
+}

@@ -1,0 +1,136 @@
+// step.hip -- the whole training iteration as two C-ABI calls (hipGraph-capturable).
+//
+// so_train_step_fwd_bwd : one iteration of the hot loop of
+//   /root/reference/utils/gsplat_utils/gsplat_trainer.py:586-655  (render -> loss -> backward)
+//   as a fixed sequence of launches on one stream, from RAW parameters to gradients of the raw
+//   parameters; every buffer is caller-owned and static, nothing is read back to the host.
+// so_train_step_optimize : :726-742 (all Adam steps + ExponentialLR on the means) with the step
+//   counter, learning-rate schedule and bias corrections evaluated on the device.
+// Between the two the caller may all-reduce the gradients (view-sharded data parallelism).
+#include "so_common.hpp"
+
+#include <vector>
+
+namespace so {
+// Optional per-stage timing with HIP events on the launch stream (bench.py's roofline leg).
+static const char *kStageNames[] = {"so_preprocess_fwd", "so_isect_scan", "so_isect_fill", "so_rasterize_fwd",
+                                    "so_ssim_l1_fwd", "so_ssim_l1_bwd", "so_rasterize_bwd", "so_preprocess_bwd",
+                                    "so_adam_step_dev"};
+constexpr int kNumStages = 9;
+static bool g_prof_on = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events[kNumStages];
+
+struct StageTimer {
+  int stage;
+  hipStream_t st;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  StageTimer(int s, hipStream_t stream) : stage(s), st(stream) {
+    if (g_prof_on) {
+      (void)hipEventCreate(&e0);
+      (void)hipEventCreate(&e1);
+      (void)hipEventRecord(e0, st);
+    }
+  }
+  ~StageTimer() {
+    if (e0) {
+      (void)hipEventRecord(e1, st);
+      g_prof_events[stage].emplace_back(e0, e1);
+    }
+  }
+};
+}  // namespace so
+
+namespace so {
+// plain zero-fill kernel (keeps driver memset nodes out of captured graphs)
+__global__ void __launch_bounds__(256) k_zero_u32(uint32_t *__restrict__ p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline void zero_async(void *p, int64_t n_words, hipStream_t st) {
+  int64_t g = (n_words + 255) / 256;
+  if (g > 1024) g = 1024;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(k_zero_u32, dim3((unsigned)g), dim3(256), 0, st, reinterpret_cast<uint32_t *>(p), n_words);
+}
+}  // namespace so
+
+extern "C" int so_profile_enable(int enabled) {
+  so::g_prof_on = enabled != 0;
+  return SO_OK;
+}
+extern "C" int so_profile_num_stages(void) { return so::kNumStages; }
+extern "C" const char *so_profile_stage_name(int i) { return (i >= 0 && i < so::kNumStages) ? so::kStageNames[i] : ""; }
+// Synchronises the device; writes the summed milliseconds and call counts per stage; clears the log.
+extern "C" int so_profile_read(float *host_ms_sum, int *host_calls) {
+  SO_REQUIRE(host_ms_sum && host_calls, "so_profile_read: null pointer");
+  if (hipDeviceSynchronize() != hipSuccess) return SO_ERR_LAUNCH;
+  for (int s = 0; s < so::kNumStages; ++s) {
+    float sum = 0.f;
+    for (auto &pr : so::g_prof_events[s]) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, pr.first, pr.second);
+      sum += ms;
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
+    host_ms_sum[s] = sum;
+    host_calls[s] = (int)so::g_prof_events[s].size();
+    so::g_prof_events[s].clear();
+  }
+  return SO_OK;
+}
+// used by adam.hip's device-scheduled step
+extern "C" void so_profile_stage_begin_end(int stage, int begin, void *stream) {
+  static thread_local so::StageTimer *cur = nullptr;
+  if (begin) { cur = new so::StageTimer(stage, so::as_stream(stream)); }
+  else if (cur) { delete cur; cur = nullptr; }
+}
+
+extern "C" int so_train_step_fwd_bwd(const so_step_desc *d, void *stream) {
+  SO_REQUIRE(d != nullptr, "so_train_step_fwd_bwd: null descriptor");
+  SO_REQUIRE(d->abi_size == (int32_t)sizeof(so_step_desc), "so_train_step_fwd_bwd: descriptor size %d != %d (ABI mismatch)",
+             d->abi_size, (int)sizeof(so_step_desc));
+  const int C = d->C, N = d->N, K = d->K, W = d->width, H = d->height, ts = d->tile_size;
+  SO_REQUIRE(C > 0 && N > 0 && W > 0 && H > 0 && (ts == 16 || ts == 8), "so_train_step_fwd_bwd: bad sizes");
+  const int tile_w = (W + ts - 1) / ts, tile_h = (H + ts - 1) / ts;
+  const int64_t M = (int64_t)C * tile_w * tile_h;
+  const int64_t CN = (int64_t)C * N;
+  hipStream_t st = so::as_stream(stream);
+  int rc;
+  // counters: tile_counts[M] | cursor[M] | n_isects | overflow        loss_sums: l1, ssim
+  int32_t *tile_counts = d->counters, *cursor = d->counters + M, *n_isects = d->counters + 2 * M,
+          *overflow = d->counters + 2 * M + 1;
+  so::zero_async(d->counters, 2 * M + 2, st);
+  so::zero_async(d->loss_sums, 2, st);
+#define SO_TRY(call) do { rc = (call); if (rc != SO_OK) return rc; } while (0)
+#define SO_STAGE(i, call) do { so::StageTimer _t(i, st); SO_TRY(call); } while (0)
+  SO_STAGE(0, so_preprocess_fwd(C, N, K, d->sh_degree, d->means, d->log_scales, d->quats, d->logit_opacities, d->sh0, d->shN,
+                           d->viewmats, d->Ks, W, H, d->eps2d, d->near_plane, d->far_plane, d->radius_clip,
+                           d->camera_model, d->antialiased, ts, d->radii, d->means2d, d->depths, d->conics,
+                           d->opacities, d->colors, d->tiles_per_gauss, tile_counts, stream));
+  SO_STAGE(1, so_isect_scan(C, tile_w, tile_h, tile_counts, d->isect_offsets, n_isects, stream));
+  SO_STAGE(2, so_isect_fill(C, N, d->means2d, d->radii, d->depths, ts, tile_w, tile_h, d->isect_offsets, n_isects, cursor,
+                       d->isect_capacity, d->key_buf, d->flatten_ids, nullptr, overflow, stream));
+  SO_STAGE(3, so_rasterize_fwd(C, N, 3, W, H, ts, d->means2d, d->conics, d->colors, d->opacities, d->backgrounds, nullptr,
+                          d->isect_offsets, d->flatten_ids, n_isects, 0, d->render_colors, d->render_alphas,
+                          d->last_ids, stream));
+  // loss = (1-l) * mean|.| + l * (1 - mean SSIM_valid)
+  SO_STAGE(4, so_ssim_l1_fwd(C, H, W, 3, d->render_colors, d->pixels, 1, d->loss_sums, d->dmaps, stream));
+  const float n_l1 = (float)C * H * W * 3.f, n_ss = (float)C * 3.f * (float)(H - 10) * (float)(W - 10);
+  SO_STAGE(5, so_ssim_l1_bwd(C, H, W, 3, d->render_colors, d->pixels, d->dmaps, (1.f - d->ssim_lambda) / n_l1,
+                        -d->ssim_lambda / n_ss, nullptr, d->v_render_colors, stream));
+  // gradients of the intermediates: v_means2d[CN,2] | v_conics[CN,3] | v_colors[CN,3] | v_opacities[CN] | abs[CN,2]
+  float *v_means2d = d->v_inter, *v_conics = v_means2d + 2 * CN, *v_colors = v_conics + 3 * CN,
+        *v_opac = v_colors + 3 * CN, *v_abs = d->absgrad ? v_opac + CN : nullptr;
+  so::zero_async(d->v_inter, CN * (d->absgrad ? 11 : 9), st);
+  SO_STAGE(6, so_rasterize_bwd(C, N, 3, W, H, ts, d->means2d, d->conics, d->colors, d->opacities, d->backgrounds, nullptr,
+                          d->isect_offsets, d->flatten_ids, n_isects, 0, d->render_alphas, d->last_ids,
+                          d->v_render_colors, d->zero_v_alphas, v_means2d, v_abs, v_conics, v_colors, v_opac, stream));
+  SO_STAGE(7, so_preprocess_bwd(C, N, K, d->sh_degree, d->means, d->log_scales, d->quats, d->logit_opacities, d->sh0, d->shN,
+                           d->viewmats, d->Ks, W, H, d->eps2d, d->camera_model, d->antialiased, d->radii, d->opacities,
+                           d->colors, v_means2d, v_abs, nullptr, v_conics, v_colors, v_opac, d->opacity_reg,
+                           d->scale_reg, d->v_means, d->v_log_scales, d->v_quats, d->v_logit_opacities, d->v_sh0,
+                           d->v_shN, d->grad2d, d->count, stream));
+#undef SO_STAGE
+#undef SO_TRY
+  return SO_OK;
+}

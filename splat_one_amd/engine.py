@@ -1,0 +1,243 @@
+"""FusedEngine -- the fast path of the training step: raw parameters -> gradients -> Adam as two
+C-ABI calls on static HBM buffers, replayed as ONE hipGraph per iteration.
+
+It computes exactly what `Runner.train_step` computes through the operator-level path
+(`rasterization` + autograd + `photometric_loss` + `step_all`, i.e. the reference's
+gsplat_trainer.py:586-742), but
+  * exp / sigmoid / cat / inverse / +0.5 / clamp and all their backward ops live inside the two
+    preprocess kernels (no torch elementwise launches, no materialised activated copies);
+  * every intermediate lives in a workspace sized once for 288 GB of HBM (intersection capacity is
+    preallocated; an overflow flag is raised on the device and checked lazily);
+  * nothing is read back to the host inside a step, so the whole iteration is captured into a
+    hipGraph (`torch.cuda.CUDAGraph`) and replayed with one launch.
+The workspace and graph are rebuilt when N changes (densification) or the SH degree ramps up.
+
+tests/test_gpu_engine.py pins it against the operator-level path and the float64 oracle.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from .ops import CAMERA_MODELS
+
+PARAM_ORDER = ("means", "scales", "quats", "opacities", "sh0", "shN")
+
+
+class FusedEngine:
+    def __init__(self, splats: torch.nn.ParameterDict, optimizers: Dict[str, torch.optim.Optimizer],
+                 width: int, height: int, n_views: int = 1, *, sh_degree: int = 3, camera_model: str = "pinhole",
+                 near_plane: float = 0.01, far_plane: float = 1e8, radius_clip: float = 0.0, eps2d: float = 0.3,
+                 antialiased: bool = False, absgrad: bool = False, ssim_lambda: float = 0.2,
+                 opacity_reg: float = 0.0, scale_reg: float = 0.0, tile_size: int = 16,
+                 strategy_state: Optional[dict] = None, lr_gamma_means: float = 1.0,
+                 isect_capacity: Optional[int] = None, use_graph: bool = True):
+        self.splats, self.optimizers = splats, optimizers
+        self.W, self.H, self.C = int(width), int(height), int(n_views)
+        self.cfg = dict(sh_degree=sh_degree, camera_model=camera_model, near_plane=near_plane, far_plane=far_plane,
+                        radius_clip=radius_clip, eps2d=eps2d, antialiased=antialiased, absgrad=absgrad,
+                        ssim_lambda=ssim_lambda, opacity_reg=opacity_reg, scale_reg=scale_reg, tile_size=tile_size)
+        self.strategy_state = strategy_state
+        self.lr_gamma_means = lr_gamma_means
+        self.use_graph = use_graph
+        self.device = splats["means"].device
+        assert self.device.type == "cuda", "FusedEngine needs HIP tensors (no CPU path exists)"
+        assert camera_model in CAMERA_MODELS, camera_model
+        self._capacity_hint = isect_capacity
+        self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._graph_key = None
+        self.steps_done = 0
+        self._step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._build_workspace()
+
+    # ---------------------------------------------------------------------------------------------
+    def _build_workspace(self) -> None:
+        dev, C, W, H = self.device, self.C, self.W, self.H
+        N = self.splats["means"].shape[0]
+        K = 1 + self.splats["shN"].shape[1]
+        ts = self.cfg["tile_size"]
+        tw, th = math.ceil(W / ts), math.ceil(H / ts)
+        M = C * tw * th
+        cap = self._capacity_hint or max(1 << 20, 8 * C * N)
+        self.N, self.K, self.M, self.capacity = N, K, M, int(cap)
+        f32, i32 = torch.float32, torch.int32
+        e = lambda *shape, dtype=f32: torch.empty(*shape, dtype=dtype, device=dev)
+        w = self.ws = {}
+        w["viewmats"], w["Ks"] = e(C, 4, 4), e(C, 3, 3)
+        w["pixels"] = e(C, H, W, 3)
+        w["radii"], w["tiles_per_gauss"] = e(C, N, dtype=i32), e(C, N, dtype=i32)
+        w["means2d"], w["depths"], w["conics"] = e(C, N, 2), e(C, N), e(C, N, 3)
+        w["opacities"], w["colors"] = e(C, N), e(C, N, 3)
+        w["counters"] = torch.zeros(2 * M + 2, dtype=i32, device=dev)
+        w["isect_offsets"] = e(C, th, tw, dtype=i32)
+        w["key_buf"] = e(cap, dtype=torch.int64)
+        w["flatten_ids"] = e(cap, dtype=i32)
+        w["render_colors"], w["render_alphas"] = e(C, H, W, 3), e(C, H, W, 1)
+        w["last_ids"] = e(C, H, W, dtype=i32)
+        w["loss_sums"] = torch.zeros(2, device=dev)
+        w["dmaps"] = e(3, C, H, W, 3)
+        w["v_render_colors"] = e(C, H, W, 3)
+        w["zero_v_alphas"] = torch.zeros(C, H, W, device=dev)
+        w["v_inter"] = e((11 if self.cfg["absgrad"] else 9) * C * N)
+        # gradients: static buffers bound to .grad so optimisers / reducers see them
+        w["grads"] = {k: torch.zeros_like(self.splats[k]) for k in PARAM_ORDER}
+        for k in PARAM_ORDER:
+            self.splats[k].grad = w["grads"][k]
+        if self.strategy_state is not None:
+            for k in ("grad2d", "count"):
+                if self.strategy_state.get(k) is None or self.strategy_state[k].shape[0] != N:
+                    self.strategy_state[k] = torch.zeros(N, device=dev)
+        self._graph = None
+
+    def _desc(self) -> _lib.StepDesc:
+        w, s, c = self.ws, self.splats, self.cfg
+        p = _lib.ptr
+        d = _lib.StepDesc()
+        d.means, d.log_scales, d.quats, d.logit_opacities = p(s["means"].data), p(s["scales"].data), p(s["quats"].data), p(s["opacities"].data)
+        d.sh0, d.shN = p(s["sh0"].data), p(s["shN"].data)
+        d.viewmats, d.Ks, d.pixels, d.backgrounds = p(w["viewmats"]), p(w["Ks"]), p(w["pixels"]), 0
+        for k in ("radii", "means2d", "depths", "conics", "opacities", "colors", "tiles_per_gauss", "counters",
+                  "isect_offsets", "key_buf", "flatten_ids", "render_colors", "render_alphas", "last_ids", "loss_sums",
+                  "dmaps", "v_render_colors", "zero_v_alphas", "v_inter"):
+            setattr(d, k, p(w[k]))
+        g = w["grads"]
+        d.v_means, d.v_log_scales, d.v_quats, d.v_logit_opacities = p(g["means"]), p(g["scales"]), p(g["quats"]), p(g["opacities"])
+        d.v_sh0, d.v_shN = p(g["sh0"]), p(g["shN"])
+        st = self.strategy_state
+        d.grad2d = p(st["grad2d"]) if st is not None else 0
+        d.count = p(st["count"]) if st is not None else 0
+        d.isect_capacity = self.capacity
+        d.abi_size = ctypes.sizeof(_lib.StepDesc)
+        d.C, d.N, d.K, d.width, d.height, d.tile_size = self.C, self.N, self.K, self.W, self.H, c["tile_size"]
+        d.sh_degree, d.camera_model = c["sh_degree"], CAMERA_MODELS[c["camera_model"]]
+        d.antialiased, d.absgrad = int(c["antialiased"]), int(c["absgrad"])
+        d.eps2d, d.near_plane, d.far_plane, d.radius_clip = c["eps2d"], c["near_plane"], c["far_plane"], c["radius_clip"]
+        d.ssim_lambda, d.opacity_reg, d.scale_reg = c["ssim_lambda"], c["opacity_reg"], c["scale_reg"]
+        return d
+
+    def _adam_args(self):
+        items = []
+        for k in PARAM_ORDER:
+            opt = self.optimizers[k]
+            grp = opt.param_groups[0]
+            prm = self.splats[k]
+            st = opt.state[prm]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(prm)
+                st["exp_avg_sq"] = torch.zeros_like(prm)
+            items.append((prm, st, grp))
+        betas, eps = items[0][2]["betas"], items[0][2]["eps"]
+        assert all(i[2]["betas"] == betas and i[2]["eps"] == eps for i in items), "one (betas, eps) class expected"
+        n = len(items)
+        arr = (_lib.AdamGroup * n)()
+        lr0 = (ctypes.c_float * n)()
+        gam = (ctypes.c_float * n)()
+        for i, (k, (prm, st, grp)) in enumerate(zip(PARAM_ORDER, items)):
+            arr[i] = _lib.AdamGroup(_lib.ptr(prm.data), _lib.ptr(self.ws["grads"][k]), _lib.ptr(st["exp_avg"]),
+                                    _lib.ptr(st["exp_avg_sq"]), 0, prm.numel(), 1, 0.0, 0.0)
+            # base LR of the schedule: the optimiser's current lr un-decayed to step 0
+            g = self.lr_gamma_means if k == "means" else 1.0
+            lr0[i] = grp["lr"] / (g ** self.steps_done)
+            gam[i] = g
+        return n, arr, lr0, gam, betas, eps
+
+    # ---------------------------------------------------------------------------------------------
+    def set_views(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor) -> None:
+        """Copy this step's cameras and target images into the static input buffers.
+        camtoworlds[C,4,4] (rigid; inverted here), Ks[C,3,3], pixels[C,H,W,3] in 0..1."""
+        assert camtoworlds.shape == (self.C, 4, 4) and Ks.shape == (self.C, 3, 3), (camtoworlds.shape, Ks.shape)
+        assert pixels.shape == (self.C, self.H, self.W, 3), pixels.shape
+        vm = torch.linalg.inv(camtoworlds.detach().to("cpu", torch.float64)).to(torch.float32) \
+            if not camtoworlds.is_cuda else torch.linalg.inv(camtoworlds.detach())
+        self.ws["viewmats"].copy_(vm, non_blocking=True)
+        self.ws["Ks"].copy_(Ks, non_blocking=True)
+        self.ws["pixels"].copy_(pixels, non_blocking=True)
+
+    def _launch_fwd_bwd(self) -> None:
+        d = self._desc()
+        _lib.call("so_train_step_fwd_bwd", ctypes.byref(d), _lib.stream())
+
+    def _launch_optimize(self) -> None:
+        n, arr, lr0, gam, betas, eps = self._adam_args()
+        _lib.call("so_adam_step_dev", n, arr, lr0, gam, float(betas[0]), float(betas[1]), float(eps),
+                  _lib.ptr(self._step_dev), 0, _lib.stream())
+
+    def fwd_bwd(self) -> None:
+        """Render -> loss -> backward on the current static inputs; gradients land in `.grad`."""
+        self._launch_fwd_bwd()
+
+    def optimize(self) -> None:
+        self._launch_optimize()
+        self._advance_host_counters()
+
+    def _advance_host_counters(self) -> None:
+        self.steps_done += 1
+        for k in PARAM_ORDER:
+            st = self.optimizers[k].state[self.splats[k]]
+            st["step"] += 1
+        self.optimizers["means"].param_groups[0]["lr"] *= self.lr_gamma_means
+
+    def step(self) -> None:
+        """One full iteration (fwd + loss + bwd + Adam); a hipGraph replay when `use_graph`."""
+        if not self.use_graph:
+            self._launch_fwd_bwd()
+            self._launch_optimize()
+        else:
+            key = (self.N, self.cfg["sh_degree"], id(self.ws))
+            if self._graph is None or self._graph_key != key:
+                self._capture(key)
+            self._graph.replay()
+        self._advance_host_counters()
+
+    def _capture(self, key) -> None:
+        # make sure lazily-created optimiser state exists before capture
+        self._adam_args()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):        # warm-up outside capture (module load, LDS attribute calls)
+            st = self.strategy_state
+            saved = [st[k].clone() for k in ("grad2d", "count")] if st is not None else None
+            self._launch_fwd_bwd()               # gradients only: parameters and step counter untouched
+            if saved is not None:
+                st["grad2d"].copy_(saved[0])
+                st["count"].copy_(saved[1])
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._launch_fwd_bwd()
+            self._launch_optimize()
+        self._graph, self._graph_key = g, key
+
+    # ---------------------------------------------------------------------------------------------
+    def set_sh_degree(self, deg: int) -> None:
+        if deg != self.cfg["sh_degree"]:
+            self.cfg["sh_degree"] = deg
+            self._graph = None
+
+    def rebuild(self) -> None:
+        """Call after the Gaussian set changed (densification rewrote params/optimiser state)."""
+        self._build_workspace()
+
+    def loss(self) -> Tensor:
+        """(loss, l1, ssimloss) of the last step as a device tensor [3] (no sync)."""
+        s = self.ws["loss_sums"]
+        n_l1 = float(self.C * self.H * self.W * 3)
+        n_ss = float(self.C * 3 * (self.H - 10) * (self.W - 10))
+        l1 = s[0] / n_l1
+        ss = 1.0 - s[1] / n_ss
+        lam = self.cfg["ssim_lambda"]
+        return torch.stack([l1 * (1 - lam) + ss * lam, l1, ss])
+
+    def stats(self) -> dict:
+        """Workload counters of the last step (synchronises)."""
+        c = self.ws["counters"]
+        return {"n_isects": int(c[2 * self.M].item()), "overflow": int(c[2 * self.M + 1].item()),
+                "visible": int((self.ws["radii"] > 0).sum().item())}

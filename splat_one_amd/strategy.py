@@ -210,7 +210,9 @@ class DefaultStrategy(Strategy):
             state["count"].zero_()
             if self.refine_scale2d_stop_iter > 0:
                 state["radii"].zero_()
-        if step % self.reset_every == 0:
+        if step % self.reset_every == 0 and step > 0:
+            # (`step > 0`: the schedule of Kerbl et al. starts counting at 1, so the first reset is at
+            # reset_every, not at the very first iteration)
             reset_opa(params=params, optimizers=optimizers, state=state, value=self.prune_opa * 2.0)
 
     @torch.no_grad()

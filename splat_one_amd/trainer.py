@@ -61,6 +61,7 @@ class Config:
     camera_model: str = "pinhole"   # reference default "spherical" is fork-only (no specification)
     # extensions of this build
     isect_capacity: Optional[int] = None   # preallocated intersections -> no host sync in the step
+    fused: bool = False                    # FusedEngine: whole step in two C-ABI calls, hipGraph replay
     shN_init_std: float = 0.0              # >0: noise instead of zeros in the higher SH bands (bench scenes)
 
     def adjust_steps(self, factor: float):
@@ -188,9 +189,71 @@ class Runner:
         return render_colors, render_alphas, info
 
     # ------------------------------------------------------------------------------ :551-763
+    # ------------------------------------------------------------------------------ fused fast path
+    def _fused_ok(self, masks) -> bool:
+        c = self.cfg
+        return (c.fused and masks is None and not c.random_bkgd and not c.visible_adam and not c.packed
+                and isinstance(c.strategy, DefaultStrategy) and c.strategy.refine_scale2d_stop_iter == 0)
+
+    def _train_step_fused(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor) -> Tensor:
+        from .engine import FusedEngine
+        cfg, step, s = self.cfg, self.step, self.cfg.strategy
+        B, H, W = pixels.shape[0], pixels.shape[1], pixels.shape[2]
+        eng = getattr(self, "_engine", None)
+        if eng is None or (eng.C, eng.H, eng.W) != (B, H, W):
+            eng = self._engine = FusedEngine(
+                self.splats, self.optimizers, W, H, B, sh_degree=0, camera_model=cfg.camera_model,
+                near_plane=cfg.near_plane, far_plane=cfg.far_plane, antialiased=cfg.antialiased, absgrad=s.absgrad,
+                ssim_lambda=cfg.ssim_lambda, opacity_reg=cfg.opacity_reg, scale_reg=cfg.scale_reg,
+                strategy_state=self.strategy_state, lr_gamma_means=self.lr_gamma,
+                isect_capacity=cfg.isect_capacity, use_graph=(self.world_size == 1))
+            eng.steps_done = step
+            eng._step_dev.fill_(step)
+        eng.set_sh_degree(min(step // cfg.sh_degree_interval, cfg.sh_degree))
+        # densification statistics are accumulated inside the backward kernel while refinement is active
+        stats_on = step < s.refine_stop_iter
+        if stats_on != (eng.strategy_state is not None):
+            eng.strategy_state = self.strategy_state if stats_on else None
+            eng._graph = None
+        eng.set_views(camtoworlds, Ks, pixels)
+        if self.world_size == 1:
+            eng.step()
+        else:
+            eng.fwd_bwd()
+            self._reducer.reduce(self.splats.values())
+            for k, v in self.splats.items():      # the reducer repoints .grad at its flat buffer
+                eng.ws["grads"][k] = v.grad
+            eng.optimize()
+        refine_now = (step < s.refine_stop_iter and step > s.refine_start_iter and step % s.refine_every == 0
+                      and step % s.reset_every >= s.pause_refine_after_reset)
+        reset_now = step < s.refine_stop_iter and step % s.reset_every == 0 and step > 0
+        if refine_now or reset_now:
+            n_before = len(self.splats["means"])
+            if refine_now:
+                if self.world_size > 1:
+                    sdist.all_reduce_strategy_state(self.strategy_state)
+                n_dupli, n_split = s._grow_gs(self.splats, self.optimizers, self.strategy_state, step, self._split_gen)
+                n_prune = s._prune_gs(self.splats, self.optimizers, self.strategy_state, step)
+                if s.verbose:
+                    print(f"Step {step}: {n_dupli} GSs duplicated, {n_split} GSs split, {n_prune} GSs pruned. "
+                          f"Now having {len(self.splats['means'])} GSs.")
+                self.strategy_state["grad2d"].zero_()
+                self.strategy_state["count"].zero_()
+            if reset_now:
+                from .strategy import reset_opa
+                reset_opa(params=self.splats, optimizers=self.optimizers, state=self.strategy_state,
+                          value=s.prune_opa * 2.0)
+            eng.rebuild()
+        self.last_info = {"radii": eng.ws["radii"], "n_isects": eng.ws["counters"][2 * eng.M:2 * eng.M + 1],
+                          "flatten_ids": eng.ws["flatten_ids"], "means2d": eng.ws["means2d"]}
+        self.step += 1
+        return eng.loss()[0]
+
     def train_step(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor, masks: Optional[Tensor] = None) -> Tensor:
         """One iteration on an already-on-device batch (camtoworlds[B,4,4], Ks[B,3,3],
         pixels[B,H,W,3] in 0..1).  Returns the loss tensor (no host sync)."""
+        if self._fused_ok(masks):
+            return self._train_step_fused(camtoworlds, Ks, pixels)
         cfg, step = self.cfg, self.step
         height, width = pixels.shape[1:3]
         sh_degree_to_use = min(step // cfg.sh_degree_interval, cfg.sh_degree)
@@ -245,7 +308,7 @@ class Runner:
                   f"Now having {len(self.splats['means'])} GSs.")
         self.strategy_state["grad2d"].zero_()
         self.strategy_state["count"].zero_()
-        if step % s.reset_every == 0:
+        if step % s.reset_every == 0 and step > 0:
             from .strategy import reset_opa
             reset_opa(params=self.splats, optimizers=self.optimizers, state=self.strategy_state,
                       value=s.prune_opa * 2.0)
