@@ -48,6 +48,8 @@ int so_abi_version(void);
 const char *so_last_error(void);
 /* number of compute units / XCDs of the current device (launch sizing on the host side) */
 int so_device_cu_count(void);
+/* test hook for the wave64 reduction primitives: in[n_waves*64,9] -> out[n_waves,10] */
+int so_debug_wave_reduce(int n_waves, const float *in, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K1/K2  3D -> 2D EWA projection.   Replaces gsplat `fully_fused_projection` (legacy
@@ -153,6 +155,17 @@ int so_rasterize_bwd(int C, int N, int D, int width, int height, int tile_size, 
                      const float *v_render_alphas, float *v_means2d, float *v_means2d_abs, float *v_conics,
                      float *v_colors, float *v_opacities, void *stream);
 
+/* Packed-record variants (D = 3): rec / vrec as written by so_preprocess_fwd. */
+int so_rasterize_fwd_packed(int C, int N, int width, int height, int tile_size, const float *rec,
+                            const float *backgrounds, const int32_t *isect_offsets, const int32_t *flatten_ids,
+                            const int32_t *n_isects_dev, int64_t n_isects_host, float *render_colors,
+                            float *render_alphas, int32_t *last_ids, void *stream);
+int so_rasterize_bwd_packed(int C, int N, int width, int height, int tile_size, const float *rec,
+                            const float *backgrounds, const int32_t *isect_offsets, const int32_t *flatten_ids,
+                            const int32_t *n_isects_dev, int64_t n_isects_host, const float *render_alphas,
+                            const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
+                            float *vrec, int absgrad, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Optimiser.  Replaces the six torch.optim.Adam steps + zero_grad of gsplat_trainer.py:726-731
  * (hyper-parameters per :266-280) with ONE launch over up to SO_ADAM_MAX_GROUPS tensors.
@@ -199,6 +212,11 @@ int so_adam_step_dev(int n_groups, const so_adam_group *host_groups, const float
  *      colors[C,N,3], tiles_per_gauss[C,N], tile_counts[C*tiles] (+=, zeroed by the caller)
  * Backward overwrites v_means, v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN and adds
  * to grad2d[N] / count[N] (nullable pair).  v_means2d_abs / v_depths nullable.
+ * Packed records (64-byte aligned, nullable): the forward also writes rec[C*N][16] =
+ *   {x, y, conic a, b, c, opacity, r, g, b, depth, radius bits, 0...} (one cache line per Gaussian
+ *   for the rasteriser's gathers) and zeroes vrec[C*N][16]; so_rasterize_bwd_packed accumulates
+ *   {v_x, v_y, v_ca, v_cb, v_cc, v_r, v_g, v_b, v_opacity, abs_x, abs_y, 0...} there and the backward
+ *   reads them from `vrec` instead of the five separate v_* arrays.
  * ---------------------------------------------------------------------------------------- */
 int so_preprocess_fwd(int C, int N, int K, int sh_degree, const float *means, const float *log_scales,
                       const float *quats, const float *logit_opacities, const float *sh0, const float *shN,
@@ -206,7 +224,7 @@ int so_preprocess_fwd(int C, int N, int K, int sh_degree, const float *means, co
                       float near_plane, float far_plane, float radius_clip, int camera_model, int antialiased,
                       int tile_size, int32_t *radii, float *means2d, float *depths, float *conics,
                       float *opacities, float *colors, int32_t *tiles_per_gauss, int32_t *tile_counts,
-                      void *stream);
+                      float *rec, float *vrec, void *stream);
 int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float *means, const float *log_scales,
                       const float *quats, const float *logit_opacities, const float *sh0, const float *shN,
                       const float *viewmats, const float *Ks, int width, int height, float eps2d,
@@ -215,14 +233,14 @@ int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float *means, co
                       const float *v_depths, const float *v_conics, const float *v_colors,
                       const float *v_opacities, float opacity_reg, float scale_reg, float *v_means,
                       float *v_log_scales, float *v_quats, float *v_logit_opacities, float *v_sh0, float *v_shN,
-                      float *grad2d, float *count, void *stream);
+                      float *grad2d, float *count, const float *vrec, int absgrad_stats, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * One training iteration (gsplat_trainer.py:586-655: render -> loss -> backward) as ONE call on
  * caller-owned static buffers: memsets + 11 launches, no allocation, no host read-back, capturable
  * in a hipGraph.  Gradients of the raw parameters are overwritten; loss_sums[2] = (sum|x-y|,
  * sum SSIM_valid).  counters: int32[2*C*tiles + 2] (histogram | cursor | n_isects | overflow);
- * v_inter: float[(9 or 11) * C*N]; zero_v_alphas: float[C*H*W] of zeros (the photometric loss does
+ * zero_v_alphas: float[C*H*W] of zeros (the photometric loss does
  * not depend on alpha).  `abi_size` must be sizeof(so_step_desc).
  * ---------------------------------------------------------------------------------------- */
 typedef struct so_step_desc {
@@ -240,7 +258,7 @@ typedef struct so_step_desc {
   int32_t *last_ids;
   float *loss_sums, *dmaps, *v_render_colors;
   const float *zero_v_alphas;
-  float *v_inter;
+  float *rec, *vrec; /* [C*N][16] packed records, 64-byte aligned */
   /* gradients of the raw parameters */
   float *v_means, *v_log_scales, *v_quats, *v_logit_opacities, *v_sh0, *v_shN;
   /* densification statistics (nullable pair) */

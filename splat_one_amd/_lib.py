@@ -33,7 +33,7 @@ class StepDesc(ctypes.Structure):
                               "radii", "means2d", "depths", "conics", "opacities", "colors",
                               "tiles_per_gauss", "counters", "isect_offsets", "key_buf", "flatten_ids",
                               "render_colors", "render_alphas", "last_ids", "loss_sums", "dmaps",
-                              "v_render_colors", "zero_v_alphas", "v_inter",
+                              "v_render_colors", "zero_v_alphas", "rec", "vrec",
                               "v_means", "v_log_scales", "v_quats", "v_logit_opacities", "v_sh0", "v_shN",
                               "grad2d", "count")]
         + [("isect_capacity", c_i64)]
@@ -57,9 +57,12 @@ _SIGS = {
     "so_rasterize_bwd": [c_int] * 6 + [c_ptr] * 9 + [c_i64] + [c_ptr] * 10,
     "so_ssim_l1_fwd": [c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr],
     "so_ssim_l1_bwd": [c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_ptr, c_ptr, c_ptr],
+    "so_debug_wave_reduce": [c_int, c_ptr, c_ptr, c_ptr],
     "so_isect_scan": [c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
-    "so_preprocess_fwd": [c_int] * 4 + [c_ptr] * 8 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_int] + [c_ptr] * 9,
-    "so_preprocess_bwd": [c_int] * 4 + [c_ptr] * 8 + [c_int, c_int, c_f32, c_int, c_int] + [c_ptr] * 9 + [c_f32, c_f32] + [c_ptr] * 9,
+    "so_preprocess_fwd": [c_int] * 4 + [c_ptr] * 8 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_int] + [c_ptr] * 11,
+    "so_preprocess_bwd": [c_int] * 4 + [c_ptr] * 8 + [c_int, c_int, c_f32, c_int, c_int] + [c_ptr] * 9 + [c_f32, c_f32] + [c_ptr] * 9 + [c_int, c_ptr],
+    "so_rasterize_fwd_packed": [c_int] * 5 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 4,
+    "so_rasterize_bwd_packed": [c_int] * 5 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 5 + [c_int, c_ptr],
     "so_train_step_fwd_bwd": [ctypes.POINTER(StepDesc), c_ptr],
     "so_profile_enable": [c_int],
     "so_profile_read": [ctypes.POINTER(c_f32), ctypes.POINTER(c_int)],

@@ -19,3 +19,31 @@ extern "C" int so_device_cu_count(void) {
   if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
   return n;
 }
+
+// ---- test hook for the wave-level reduction primitives (tests/test_gpu_ops.py) ----------------
+namespace so {
+__global__ void __launch_bounds__(64) k_debug_wave_reduce(const float *__restrict__ in, float *__restrict__ out) {
+  const int lane = threadIdx.x;
+  const float *row = in + ((int64_t)blockIdx.x * 64 + lane) * 9;
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = row[k];
+  const float e = row_reduce8_transposed(v, lane);
+  const float o = row_allreduce_sum(row[8]);
+  const float c = wave_reduce_sum(row[8]);
+  float *dst = out + (int64_t)blockIdx.x * 10;
+  // exactly the store pattern of the rasteriser backward: lanes (l&15) <= 8 of every row, one atomic
+  const int l15 = lane & 15;
+  if (l15 <= 8) atomicAdd(dst + (l15 < 8 ? slot_of_lane(lane) : 8), l15 < 8 ? e : o);
+  if (lane == 17) dst[9] = c;
+}
+}  // namespace so
+
+/* in[n_waves*64, 9] -> out[n_waves, 10] (zeroed by the caller): slots 0..7 += transposing butterfly
+ * row sums of columns 0..7, 8 += row sums of column 8, 9 = wave sum of column 8 (row_bcast DPP form). */
+extern "C" int so_debug_wave_reduce(int n_waves, const float *in, float *out, void *stream) {
+  SO_REQUIRE(n_waves >= 0 && (n_waves == 0 || (in && out)), "so_debug_wave_reduce: bad arguments");
+  if (n_waves == 0) return SO_OK;
+  hipLaunchKernelGGL(so::k_debug_wave_reduce, dim3(n_waves), dim3(64), 0, so::as_stream(stream), in, out);
+  return so::check_launch("so_debug_wave_reduce");
+}

@@ -45,7 +45,8 @@ k_preprocess_fwd(int C, int N, int K, const float *__restrict__ means, const flo
                  float radius_clip, int model, int antialiased, float tile_size, int tile_w, int tile_h,
                  int32_t *__restrict__ radii, float *__restrict__ means2d, float *__restrict__ depths,
                  float *__restrict__ conics, float *__restrict__ opacities, float *__restrict__ colors,
-                 int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ tile_counts) {
+                 int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ tile_counts,
+                 float4 *__restrict__ rec, float4 *__restrict__ vrec) {
   const int64_t total = (int64_t)C * N;
   const int n_tiles = tile_w * tile_h;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -94,6 +95,16 @@ k_preprocess_fwd(int C, int N, int K, const float *__restrict__ means, const flo
     }
     colors[3 * idx] = r; colors[3 * idx + 1] = g; colors[3 * idx + 2] = b;
     tiles_per_gauss[idx] = cnt;
+    if (rec) {   // 64-byte record gathered by the rasteriser: one cache line per Gaussian
+      rec[4 * idx] = make_float4(o.m2d[0], o.m2d[1], o.conic[0], o.conic[1]);
+      rec[4 * idx + 1] = make_float4(o.conic[2], op, r, g);
+      rec[4 * idx + 2] = make_float4(b, o.depth, __int_as_float(o.radius), 0.f);
+      rec[4 * idx + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (vrec) {  // gradient record, accumulated atomically by the rasteriser backward
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      vrec[4 * idx] = z; vrec[4 * idx + 1] = z; vrec[4 * idx + 2] = z; vrec[4 * idx + 3] = z;
+    }
   }
 }
 
@@ -110,7 +121,8 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
                  const float *__restrict__ v_opacities, float opacity_reg, float scale_reg,
                  float *__restrict__ v_means, float *__restrict__ v_log_scales, float *__restrict__ v_quats,
                  float *__restrict__ v_logit_opac, float *__restrict__ v_sh0, float *__restrict__ v_shN,
-                 float *__restrict__ grad2d, float *__restrict__ count, float stat_sx, float stat_sy) {
+                 float *__restrict__ grad2d, float *__restrict__ count, float stat_sx, float stat_sy,
+                 const float4 *__restrict__ vrec, int use_abs_stats) {
   constexpr int NB = (DEG + 1) * (DEG + 1);
   for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
     const float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
@@ -123,14 +135,27 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
     float acc[NB][3];
 #pragma unroll
     for (int k = 0; k < NB; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.f;
+    const bool use_abs = use_abs_stats != 0;
     for (int c = 0; c < C; ++c) {
       const int64_t idx = (int64_t)c * N + n;
       if (radii[idx] <= 0) continue;
       const CamP cam = load_camp(viewmats, Ks, c);
-      const float2 vm2 = *reinterpret_cast<const float2 *>(v_means2d + 2 * idx);
+      float2 vm2;
+      float v_con[3], v_op, vr, vg, vb, abs_x = 0.f, abs_y = 0.f;
+      if (vrec) {
+        const float4 q0 = vrec[4 * idx], q1 = vrec[4 * idx + 1], q2 = vrec[4 * idx + 2];
+        vm2 = make_float2(q0.x, q0.y);
+        v_con[0] = q0.z; v_con[1] = q0.w; v_con[2] = q1.x;
+        vr = q1.y; vg = q1.z; vb = q1.w;
+        v_op = q2.x; abs_x = q2.y; abs_y = q2.z;
+      } else {
+        vm2 = *reinterpret_cast<const float2 *>(v_means2d + 2 * idx);
+        v_con[0] = v_conics[3 * idx]; v_con[1] = v_conics[3 * idx + 1]; v_con[2] = v_conics[3 * idx + 2];
+        v_op = v_opacities[idx];
+        vr = v_colors[3 * idx]; vg = v_colors[3 * idx + 1]; vb = v_colors[3 * idx + 2];
+        if (v_means2d_abs) { abs_x = v_means2d_abs[2 * idx]; abs_y = v_means2d_abs[2 * idx + 1]; }
+      }
       const float v_m2d[2] = {vm2.x, vm2.y};
-      const float v_con[3] = {v_conics[3 * idx], v_conics[3 * idx + 1], v_conics[3 * idx + 2]};
-      const float v_op = v_opacities[idx];
       float v_comp = 0.f;
       if (antialiased) {
         v_comp = v_op * sig;
@@ -141,7 +166,6 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
       project_bwd<float>(mean, nullptr, q, s, cam.Rw, cam.tw, cam.fx, cam.fy, cam.cx, cam.cy, W, H, eps2d, model,
                          v_m2d, v_depths ? v_depths[idx] : 0.f, v_con, v_comp, vm, nullptr, vq, vs, nullptr, nullptr);
       // SH backward (through +0.5 / clamp: the saved colour is 0 exactly where the clamp cut)
-      float vr = v_colors[3 * idx], vg = v_colors[3 * idx + 1], vb = v_colors[3 * idx + 2];
       if (!(colors[3 * idx] > 0.f)) vr = 0.f;
       if (!(colors[3 * idx + 1] > 0.f)) vg = 0.f;
       if (!(colors[3 * idx + 2] > 0.f)) vb = 0.f;
@@ -163,8 +187,7 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
       vm[2] += (vdn[2] - dot * z) * inorm;
       // densification statistics (DefaultStrategy._update_state)
       if (grad2d) {
-        float gx = vm2.x, gy = vm2.y;
-        if (v_means2d_abs) { gx = v_means2d_abs[2 * idx]; gy = v_means2d_abs[2 * idx + 1]; }
+        float gx = use_abs ? abs_x : vm2.x, gy = use_abs ? abs_y : vm2.y;
         gx *= stat_sx; gy *= stat_sy;
         g2 += sqrtf(gx * gx + gy * gy);
         cn += 1.f;
@@ -200,7 +223,8 @@ extern "C" int so_preprocess_fwd(int C, int N, int K, int sh_degree, const float
                                  float eps2d, float near_plane, float far_plane, float radius_clip,
                                  int camera_model, int antialiased, int tile_size, int32_t *radii, float *means2d,
                                  float *depths, float *conics, float *opacities, float *colors,
-                                 int32_t *tiles_per_gauss, int32_t *tile_counts, void *stream) {
+                                 int32_t *tiles_per_gauss, int32_t *tile_counts, float *rec, float *vrec,
+                                 void *stream) {
   SO_REQUIRE(C >= 0 && N >= 0 && K >= 1 && width > 0 && height > 0 && tile_size > 0, "so_preprocess_fwd: bad sizes");
   SO_REQUIRE(sh_degree >= 0 && sh_degree <= 4 && (sh_degree + 1) * (sh_degree + 1) <= K,
              "so_preprocess_fwd: sh_degree %d does not fit K=%d", sh_degree, K);
@@ -219,7 +243,8 @@ extern "C" int so_preprocess_fwd(int C, int N, int K, int sh_degree, const float
   hipLaunchKernelGGL(so::k_preprocess_fwd<D>, grid, block, 0, st, C, N, K, means, log_scales, quats,               \
                      logit_opacities, sh0, shN, viewmats, Ks, width, height, eps2d, near_plane, far_plane,         \
                      radius_clip, camera_model, antialiased, (float)tile_size, tile_w, tile_h, radii, means2d,     \
-                     depths, conics, opacities, colors, tiles_per_gauss, tile_counts)
+                     depths, conics, opacities, colors, tiles_per_gauss, tile_counts,                              \
+                     reinterpret_cast<float4 *>(rec), reinterpret_cast<float4 *>(vrec))
   switch (sh_degree) {
     case 0: SO_LAUNCH(0); break;
     case 1: SO_LAUNCH(1); break;
@@ -240,7 +265,7 @@ extern "C" int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float
                                  const float *v_colors, const float *v_opacities, float opacity_reg,
                                  float scale_reg, float *v_means, float *v_log_scales, float *v_quats,
                                  float *v_logit_opacities, float *v_sh0, float *v_shN, float *grad2d, float *count,
-                                 void *stream) {
+                                 const float *vrec, int absgrad_stats, void *stream) {
   SO_REQUIRE(C >= 0 && N >= 0 && K >= 1 && width > 0 && height > 0, "so_preprocess_bwd: bad sizes");
   SO_REQUIRE(sh_degree >= 0 && sh_degree <= 4 && (sh_degree + 1) * (sh_degree + 1) <= K,
              "so_preprocess_bwd: sh_degree %d does not fit K=%d", sh_degree, K);
@@ -250,9 +275,11 @@ extern "C" int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float
   }
   if (N == 0) return SO_OK;
   SO_REQUIRE(means && log_scales && quats && logit_opacities && sh0 && (shN || K == 1) && viewmats && Ks && radii &&
-                 opacities && colors && v_means2d && v_conics && v_colors && v_opacities && v_means && v_log_scales &&
-                 v_quats && v_logit_opacities && v_sh0 && (v_shN || K == 1),
+                 opacities && colors && (vrec || (v_means2d && v_conics && v_colors && v_opacities)) && v_means &&
+                 v_log_scales && v_quats && v_logit_opacities && v_sh0 && (v_shN || K == 1),
              "so_preprocess_bwd: null pointer");
+  SO_REQUIRE((((uintptr_t)vrec) & 63) == 0, "so_preprocess_bwd: vrec must be 64-byte aligned");
+  if (!vrec && v_means2d_abs) absgrad_stats = 1;
   SO_REQUIRE((grad2d == nullptr) == (count == nullptr), "so_preprocess_bwd: grad2d and count go together");
   const dim3 grid(so::pp_grid(N)), block(256);
   hipStream_t st = so::as_stream(stream);
@@ -262,7 +289,7 @@ extern "C" int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float
                      logit_opacities, sh0, shN, viewmats, Ks, width, height, eps2d, camera_model, antialiased,    \
                      radii, opacities, colors, v_means2d, v_means2d_abs, v_depths, v_conics, v_colors,            \
                      v_opacities, opacity_reg, scale_reg, v_means, v_log_scales, v_quats, v_logit_opacities,      \
-                     v_sh0, v_shN, grad2d, count, sx, sy)
+                     v_sh0, v_shN, grad2d, count, sx, sy, reinterpret_cast<const float4 *>(vrec), absgrad_stats)
   switch (sh_degree) {
     case 0: SO_LAUNCH(0); break;
     case 1: SO_LAUNCH(1); break;

@@ -12,7 +12,10 @@
 
 namespace so {
 
-template <int D, int TS, bool ABS>
+// PACKED: inputs from the 64-byte records rec[g] (passed through `colors`), gradients into the
+// 64-byte records vrec[g] = {v_x,v_y,v_ca,v_cb,v_cc,v_r,v_g,v_b | v_opac,abs_x,abs_y,..} (passed
+// through `v_colors`): one atomic instruction = one memory-side request per (quadrant, Gaussian).
+template <int D, int TS, bool ABS, bool PACKED>
 __global__ void __launch_bounds__(TS *TS)
 k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2 *__restrict__ means2d,
                 const float *__restrict__ conics, const float *__restrict__ colors,
@@ -81,20 +84,48 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
   for (int w = 1; w < NWAVES; ++w) block_last = max(block_last, s_wave_last[w]);
   if (block_last < lo) return;  // uniform
 
+  // D == 3: per-row transposing butterfly; lane l of each DPP row owns one output slot
+  //   (l&15) < 8 : slot_of_lane(l) in {v_x,v_y,v_ca,v_cb,v_cc,v_r,v_g,v_b};  8: v_opac;  9,10: abs x,y
+  const int l15 = lane & 15;
+  const int slot = l15 < 8 ? slot_of_lane(lane) : l15;
+  float *out_base = nullptr;
+  int out_stride = 0;
+  if (D == 3) {
+    if (PACKED) { out_base = v_colors + slot; out_stride = 16; }
+    else if (slot < 2) { out_base = v_means2d + slot; out_stride = 2; }
+    else if (slot < 5) { out_base = v_conics + (slot - 2); out_stride = 3; }
+    else if (slot < 8) { out_base = v_colors + (slot - 5); out_stride = 3; }
+    else if (slot == 8) { out_base = v_opacities; out_stride = 1; }
+    else if (ABS && slot < 11) { out_base = v_means2d_abs + (slot - 9); out_stride = 2; }
+  }
+  const bool out_lane = (D == 3) && (l15 <= (ABS ? 10 : 8));
+
   for (int64_t batch_end = block_last; batch_end >= lo; batch_end -= BLOCK) {
     __syncthreads();
     const int64_t idx = batch_end - tid;
     if (idx >= lo) {
       const int32_t g = flatten_ids[idx];
-      const float2 xy = means2d[g];
-      const float op = opacities[g];
-      const float ca = conics[3 * (int64_t)g], cb = conics[3 * (int64_t)g + 1], cc = conics[3 * (int64_t)g + 2];
       s_id[tid] = g;
-      s_xyoa[tid] = make_float4(xy.x, xy.y, op, ca);
-      s_bc[tid] = make_float2(cb, cc);
-      s_box[tid] = alpha_bound_box(xy.x, xy.y, op, ca, cb, cc);
+      if (PACKED) {
+        const float4 *r4 = reinterpret_cast<const float4 *>(colors) + 4 * (int64_t)g;
+        const float4 q0 = r4[0], q1 = r4[1];
+        const float bb = reinterpret_cast<const float *>(r4 + 2)[0];
+        s_xyoa[tid] = make_float4(q0.x, q0.y, q1.y, q0.z);
+        s_bc[tid] = make_float2(q0.w, q1.x);
+        s_box[tid] = alpha_bound_box(q0.x, q0.y, q1.y, q0.z, q0.w, q1.x);
+        s_col[tid * D] = q1.z;
+        if (D > 1) s_col[tid * D + 1] = q1.w;
+        if (D > 2) s_col[tid * D + 2] = bb;
+      } else {
+        const float2 xy = means2d[g];
+        const float op = opacities[g];
+        const float ca = conics[3 * (int64_t)g], cb = conics[3 * (int64_t)g + 1], cc = conics[3 * (int64_t)g + 2];
+        s_xyoa[tid] = make_float4(xy.x, xy.y, op, ca);
+        s_bc[tid] = make_float2(cb, cc);
+        s_box[tid] = alpha_bound_box(xy.x, xy.y, op, ca, cb, cc);
 #pragma unroll
-      for (int k = 0; k < D; ++k) s_col[tid * D + k] = colors[(int64_t)g * D + k];
+        for (int k = 0; k < D; ++k) s_col[tid * D + k] = colors[(int64_t)g * D + k];
+      }
     }
     __syncthreads();
     const int batch_size = (int)((batch_end + 1 - lo) < BLOCK ? (batch_end + 1 - lo) : BLOCK);
@@ -149,7 +180,21 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
             g_op = vis * v_alpha;
           }
         }
-        // wave sums land in lane 63
+        if (D == 3) {
+          const float v8[8] = {g_x, g_y, g_cx, g_cy, g_cz, g_col[0], g_col[1 % D], g_col[2 % D]};
+          float val = row_reduce8_transposed(v8, lane);
+          const float r_op = row_allreduce_sum(g_op);
+          if (l15 == 8) val = r_op;
+          if (ABS) {
+            const float r_ax = row_allreduce_sum(g_ax), r_ay = row_allreduce_sum(g_ay);
+            if (l15 == 9) val = r_ax;
+            if (l15 == 10) val = r_ay;
+          }
+          // one atomic instruction: <= 4 rows x 9(11) lanes, all inside one 64-byte record when PACKED
+          if (out_lane && val != 0.f) atomicAdd(out_base + (int64_t)s_id[tt] * out_stride, val);
+          continue;
+        }
+        // generic channel counts: wave sums land in lane 63
 #pragma unroll
         for (int k = 0; k < D; ++k) g_col[k] = wave_reduce_sum_to_last(g_col[k]);
         g_cx = wave_reduce_sum_to_last(g_cx);
@@ -188,7 +233,7 @@ static int launch_bwd(int TS, bool abs_, dim3 grid, hipStream_t st, int C, int N
                       float *v_col, float *v_op) {
   const float2 *m2 = reinterpret_cast<const float2 *>(means2d);
 #define SO_GO(TSV, ABSV)                                                                                         \
-  hipLaunchKernelGGL((k_rasterize_bwd<D, TSV, ABSV>), grid, dim3(TSV * TSV), 0, st, C, N, W, H, tile_w, tile_h, \
+  hipLaunchKernelGGL((k_rasterize_bwd<D, TSV, ABSV, false>), grid, dim3(TSV * TSV), 0, st, C, N, W, H, tile_w, tile_h, \
                      m2, conics, colors, opacities, backgrounds, tile_masks, offsets, flatten_ids, n_dev,       \
                      n_host, ra, last, v_rc, v_ra, v_m, v_abs, v_cn, v_col, v_op)
   if (TS == 16) { if (abs_) SO_GO(16, true); else SO_GO(16, false); }
@@ -231,4 +276,30 @@ extern "C" int so_rasterize_bwd(int C, int N, int D, int width, int height, int 
       return SO_ERR_UNSUPPORTED;
   }
 #undef SO_CASE
+}
+
+extern "C" int so_rasterize_bwd_packed(int C, int N, int width, int height, int tile_size, const float *rec,
+                                       const float *backgrounds, const int32_t *isect_offsets,
+                                       const int32_t *flatten_ids, const int32_t *n_isects_dev,
+                                       int64_t n_isects_host, const float *render_alphas, const int32_t *last_ids,
+                                       const float *v_render_colors, const float *v_render_alphas, float *vrec,
+                                       int absgrad, void *stream) {
+  SO_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, "so_rasterize_bwd_packed: bad sizes");
+  SO_REQUIRE(tile_size == 16 || tile_size == 8, "so_rasterize_bwd_packed: tile_size %d not in {8,16}", tile_size);
+  if (C == 0 || N == 0) return SO_OK;
+  SO_REQUIRE(rec && isect_offsets && render_alphas && last_ids && v_render_colors && v_render_alphas && vrec,
+             "so_rasterize_bwd_packed: null pointer");
+  SO_REQUIRE(((((uintptr_t)rec) | ((uintptr_t)vrec)) & 63) == 0, "so_rasterize_bwd_packed: records must be 64-byte aligned");
+  const int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
+  const dim3 grid((unsigned)((int64_t)C * tile_w * tile_h));
+  hipStream_t st = so::as_stream(stream);
+#define SO_GO(TSV, ABSV)                                                                                          \
+  hipLaunchKernelGGL((so::k_rasterize_bwd<3, TSV, ABSV, true>), grid, dim3(TSV * TSV), 0, st, C, N, width, height, \
+                     tile_w, tile_h, nullptr, nullptr, rec, nullptr, backgrounds, nullptr, isect_offsets,         \
+                     flatten_ids, n_isects_dev, n_isects_host, render_alphas, last_ids, v_render_colors,          \
+                     v_render_alphas, nullptr, nullptr, nullptr, vrec, nullptr)
+  if (tile_size == 16) { if (absgrad) SO_GO(16, true); else SO_GO(16, false); }
+  else                 { if (absgrad) SO_GO(8, true);  else SO_GO(8, false); }
+#undef SO_GO
+  return so::check_launch("so_rasterize_bwd_packed");
 }

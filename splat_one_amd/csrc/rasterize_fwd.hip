@@ -13,7 +13,10 @@
 
 namespace so {
 
-template <int D, int TS>
+// PACKED: the four per-Gaussian inputs come from ONE 64-byte record rec[g] = {x,y,ca,cb | cc,opac,r,g |
+// b,..} written by so_preprocess_fwd (one cache line per gathered Gaussian instead of four); passed
+// through the `colors` pointer, D must be 3.
+template <int D, int TS, bool PACKED>
 __global__ void __launch_bounds__(TS *TS)
 k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2 *__restrict__ means2d,
                 const float *__restrict__ conics, const float *__restrict__ colors,
@@ -75,14 +78,26 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
     const int64_t idx = batch_start + tid;
     if (idx < hi) {
       const int32_t g = flatten_ids[idx];
-      const float2 xy = means2d[g];
-      const float op = opacities[g];
-      const float ca = conics[3 * (int64_t)g], cb = conics[3 * (int64_t)g + 1], cc = conics[3 * (int64_t)g + 2];
-      s_xyoa[tid] = make_float4(xy.x, xy.y, op, ca);
-      s_bc[tid] = make_float2(cb, cc);
-      s_box[tid] = alpha_bound_box(xy.x, xy.y, op, ca, cb, cc);
+      if (PACKED) {
+        const float4 *r4 = reinterpret_cast<const float4 *>(colors) + 4 * (int64_t)g;
+        const float4 q0 = r4[0], q1 = r4[1];
+        const float bb = reinterpret_cast<const float *>(r4 + 2)[0];
+        s_xyoa[tid] = make_float4(q0.x, q0.y, q1.y, q0.z);
+        s_bc[tid] = make_float2(q0.w, q1.x);
+        s_box[tid] = alpha_bound_box(q0.x, q0.y, q1.y, q0.z, q0.w, q1.x);
+        s_col[tid * D] = q1.z;
+        if (D > 1) s_col[tid * D + 1] = q1.w;
+        if (D > 2) s_col[tid * D + 2] = bb;
+      } else {
+        const float2 xy = means2d[g];
+        const float op = opacities[g];
+        const float ca = conics[3 * (int64_t)g], cb = conics[3 * (int64_t)g + 1], cc = conics[3 * (int64_t)g + 2];
+        s_xyoa[tid] = make_float4(xy.x, xy.y, op, ca);
+        s_bc[tid] = make_float2(cb, cc);
+        s_box[tid] = alpha_bound_box(xy.x, xy.y, op, ca, cb, cc);
 #pragma unroll
-      for (int k = 0; k < D; ++k) s_col[tid * D + k] = colors[(int64_t)g * D + k];
+        for (int k = 0; k < D; ++k) s_col[tid * D + k] = colors[(int64_t)g * D + k];
+      }
     }
     __syncthreads();
     const int batch_size = (int)((hi - batch_start) < BLOCK ? (hi - batch_start) : BLOCK);
@@ -138,10 +153,10 @@ static int launch_fwd(int TS, dim3 grid, hipStream_t st, int C, int N, int W, in
                       int32_t *last) {
   const float2 *m2 = reinterpret_cast<const float2 *>(means2d);
   if (TS == 16)
-    hipLaunchKernelGGL((k_rasterize_fwd<D, 16>), grid, dim3(256), 0, st, C, N, W, H, tile_w, tile_h, m2, conics, colors,
+    hipLaunchKernelGGL((k_rasterize_fwd<D, 16, false>), grid, dim3(256), 0, st, C, N, W, H, tile_w, tile_h, m2, conics, colors,
                        opacities, backgrounds, tile_masks, offsets, flatten_ids, n_dev, n_host, rc, ra, last);
   else
-    hipLaunchKernelGGL((k_rasterize_fwd<D, 8>), grid, dim3(64), 0, st, C, N, W, H, tile_w, tile_h, m2, conics, colors,
+    hipLaunchKernelGGL((k_rasterize_fwd<D, 8, false>), grid, dim3(64), 0, st, C, N, W, H, tile_w, tile_h, m2, conics, colors,
                        opacities, backgrounds, tile_masks, offsets, flatten_ids, n_dev, n_host, rc, ra, last);
   return check_launch("so_rasterize_fwd");
 }
@@ -175,4 +190,28 @@ extern "C" int so_rasterize_fwd(int C, int N, int D, int width, int height, int 
       return SO_ERR_UNSUPPORTED;
   }
 #undef SO_CASE
+}
+
+extern "C" int so_rasterize_fwd_packed(int C, int N, int width, int height, int tile_size, const float *rec,
+                                       const float *backgrounds, const int32_t *isect_offsets,
+                                       const int32_t *flatten_ids, const int32_t *n_isects_dev,
+                                       int64_t n_isects_host, float *render_colors, float *render_alphas,
+                                       int32_t *last_ids, void *stream) {
+  SO_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, "so_rasterize_fwd_packed: bad sizes");
+  SO_REQUIRE(tile_size == 16 || tile_size == 8, "so_rasterize_fwd_packed: tile_size %d not in {8,16}", tile_size);
+  if (C == 0) return SO_OK;
+  SO_REQUIRE(isect_offsets && render_colors && render_alphas && last_ids && (N == 0 || rec), "so_rasterize_fwd_packed: null pointer");
+  SO_REQUIRE((((uintptr_t)rec) & 63) == 0, "so_rasterize_fwd_packed: rec must be 64-byte aligned");
+  const int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
+  const dim3 grid((unsigned)((int64_t)C * tile_w * tile_h));
+  hipStream_t st = so::as_stream(stream);
+  if (tile_size == 16)
+    hipLaunchKernelGGL((so::k_rasterize_fwd<3, 16, true>), grid, dim3(256), 0, st, C, N, width, height, tile_w, tile_h,
+                       nullptr, nullptr, rec, nullptr, backgrounds, nullptr, isect_offsets, flatten_ids, n_isects_dev,
+                       n_isects_host, render_colors, render_alphas, last_ids);
+  else
+    hipLaunchKernelGGL((so::k_rasterize_fwd<3, 8, true>), grid, dim3(64), 0, st, C, N, width, height, tile_w, tile_h,
+                       nullptr, nullptr, rec, nullptr, backgrounds, nullptr, isect_offsets, flatten_ids, n_isects_dev,
+                       n_isects_host, render_colors, render_alphas, last_ids);
+  return so::check_launch("so_rasterize_fwd_packed");
 }

@@ -74,6 +74,49 @@ __device__ __forceinline__ float wave_reduce_sum(float v) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// Transposing butterfly reduction over the 16 lanes of each DPP row: 8 per-lane values are summed
+// in 22 VALU instructions (vs 8 x 4 for eight independent row reductions) and the row total of
+// slot s ends in the lanes l of that row with slot_of_lane(l) == s.  The four rows of a wave are
+// NOT combined: the caller issues ONE atomic instruction in which lanes (l & 15) < 8 of every row
+// add their row total to slot_of_lane(l) -- 32 active lanes, one 32-byte segment, the memory-side
+// atomic unit sums the four rows.  (v_permlane16/32_swap would finish the sum in registers, but
+// hipcc 7.2 miscompiles `r[0] + r[1]` of that builtin.)  EXEC must be all ones.
+//   xor1 / xor2 via quad_perm, rotate-4 / rotate-8 within the row via row_ror.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int slot_of_lane(int lane) {  // 4*b0 + 2*b1 + b2
+  return ((lane & 1) << 2) | (lane & 2) | ((lane >> 2) & 1);
+}
+
+__device__ __forceinline__ float row_reduce8_transposed(const float (&v)[8], int lane) {
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0;
+  float a[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float keep = b0 ? v[j + 4] : v[j], send = b0 ? v[j] : v[j + 4];
+    a[j] = keep + dpp_mov<0xB1, 0xf, 0xf, true>(0.f, send);  // quad_perm:[1,0,3,2]
+  }
+  float c[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float keep = b1 ? a[j + 2] : a[j], send = b1 ? a[j] : a[j + 2];
+    c[j] = keep + dpp_mov<0x4E, 0xf, 0xf, true>(0.f, send);  // quad_perm:[2,3,0,1]
+  }
+  const float keep = b2 ? c[1] : c[0], send = b2 ? c[0] : c[1];
+  float e = keep + dpp_mov<0x124, 0xf, 0xf, true>(0.f, send);  // row_ror:4
+  e += dpp_mov<0x128, 0xf, 0xf, true>(0.f, e);                 // row_ror:8
+  return e;
+}
+
+// Sum over the 16 lanes of each row, result in every lane of the row (4 VALU instructions).
+__device__ __forceinline__ float row_allreduce_sum(float x) {
+  x += dpp_mov<0xB1, 0xf, 0xf, true>(0.f, x);
+  x += dpp_mov<0x4E, 0xf, 0xf, true>(0.f, x);
+  x += dpp_mov<0x124, 0xf, 0xf, true>(0.f, x);
+  x += dpp_mov<0x128, 0xf, 0xf, true>(0.f, x);
+  return x;
+}
+
 __device__ __forceinline__ int lane_id() {
 #if defined(__HIP_DEVICE_COMPILE__)
   return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));

@@ -93,7 +93,6 @@ extern "C" int so_train_step_fwd_bwd(const so_step_desc *d, void *stream) {
   SO_REQUIRE(C > 0 && N > 0 && W > 0 && H > 0 && (ts == 16 || ts == 8), "so_train_step_fwd_bwd: bad sizes");
   const int tile_w = (W + ts - 1) / ts, tile_h = (H + ts - 1) / ts;
   const int64_t M = (int64_t)C * tile_w * tile_h;
-  const int64_t CN = (int64_t)C * N;
   hipStream_t st = so::as_stream(stream);
   int rc;
   // counters: tile_counts[M] | cursor[M] | n_isects | overflow        loss_sums: l1, ssim
@@ -106,30 +105,27 @@ extern "C" int so_train_step_fwd_bwd(const so_step_desc *d, void *stream) {
   SO_STAGE(0, so_preprocess_fwd(C, N, K, d->sh_degree, d->means, d->log_scales, d->quats, d->logit_opacities, d->sh0, d->shN,
                            d->viewmats, d->Ks, W, H, d->eps2d, d->near_plane, d->far_plane, d->radius_clip,
                            d->camera_model, d->antialiased, ts, d->radii, d->means2d, d->depths, d->conics,
-                           d->opacities, d->colors, d->tiles_per_gauss, tile_counts, stream));
+                           d->opacities, d->colors, d->tiles_per_gauss, tile_counts, d->rec, d->vrec, stream));
   SO_STAGE(1, so_isect_scan(C, tile_w, tile_h, tile_counts, d->isect_offsets, n_isects, stream));
   SO_STAGE(2, so_isect_fill(C, N, d->means2d, d->radii, d->depths, ts, tile_w, tile_h, d->isect_offsets, n_isects, cursor,
                        d->isect_capacity, d->key_buf, d->flatten_ids, nullptr, overflow, stream));
-  SO_STAGE(3, so_rasterize_fwd(C, N, 3, W, H, ts, d->means2d, d->conics, d->colors, d->opacities, d->backgrounds, nullptr,
-                          d->isect_offsets, d->flatten_ids, n_isects, 0, d->render_colors, d->render_alphas,
-                          d->last_ids, stream));
+  SO_STAGE(3, so_rasterize_fwd_packed(C, N, W, H, ts, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects,
+                                      0, d->render_colors, d->render_alphas, d->last_ids, stream));
   // loss = (1-l) * mean|.| + l * (1 - mean SSIM_valid)
   SO_STAGE(4, so_ssim_l1_fwd(C, H, W, 3, d->render_colors, d->pixels, 1, d->loss_sums, d->dmaps, stream));
   const float n_l1 = (float)C * H * W * 3.f, n_ss = (float)C * 3.f * (float)(H - 10) * (float)(W - 10);
   SO_STAGE(5, so_ssim_l1_bwd(C, H, W, 3, d->render_colors, d->pixels, d->dmaps, (1.f - d->ssim_lambda) / n_l1,
                         -d->ssim_lambda / n_ss, nullptr, d->v_render_colors, stream));
-  // gradients of the intermediates: v_means2d[CN,2] | v_conics[CN,3] | v_colors[CN,3] | v_opacities[CN] | abs[CN,2]
-  float *v_means2d = d->v_inter, *v_conics = v_means2d + 2 * CN, *v_colors = v_conics + 3 * CN,
-        *v_opac = v_colors + 3 * CN, *v_abs = d->absgrad ? v_opac + CN : nullptr;
-  so::zero_async(d->v_inter, CN * (d->absgrad ? 11 : 9), st);
-  SO_STAGE(6, so_rasterize_bwd(C, N, 3, W, H, ts, d->means2d, d->conics, d->colors, d->opacities, d->backgrounds, nullptr,
-                          d->isect_offsets, d->flatten_ids, n_isects, 0, d->render_alphas, d->last_ids,
-                          d->v_render_colors, d->zero_v_alphas, v_means2d, v_abs, v_conics, v_colors, v_opac, stream));
+  // gradients of the intermediates accumulate in the 64-byte records vrec[C*N] (zeroed by the
+  // forward preprocess kernel): one atomic request per (tile quadrant, Gaussian)
+  SO_STAGE(6, so_rasterize_bwd_packed(C, N, W, H, ts, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects,
+                                      0, d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
+                                      d->absgrad, stream));
   SO_STAGE(7, so_preprocess_bwd(C, N, K, d->sh_degree, d->means, d->log_scales, d->quats, d->logit_opacities, d->sh0, d->shN,
                            d->viewmats, d->Ks, W, H, d->eps2d, d->camera_model, d->antialiased, d->radii, d->opacities,
-                           d->colors, v_means2d, v_abs, nullptr, v_conics, v_colors, v_opac, d->opacity_reg,
+                           d->colors, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d->opacity_reg,
                            d->scale_reg, d->v_means, d->v_log_scales, d->v_quats, d->v_logit_opacities, d->v_sh0,
-                           d->v_shN, d->grad2d, d->count, stream));
+                           d->v_shN, d->grad2d, d->count, d->vrec, d->absgrad, stream));
 #undef SO_STAGE
 #undef SO_TRY
   return SO_OK;

@@ -83,7 +83,7 @@ class FusedEngine:
         w["dmaps"] = e(3, C, H, W, 3)
         w["v_render_colors"] = e(C, H, W, 3)
         w["zero_v_alphas"] = torch.zeros(C, H, W, device=dev)
-        w["v_inter"] = e((11 if self.cfg["absgrad"] else 9) * C * N)
+        w["rec"], w["vrec"] = e(C * N, 16), e(C * N, 16)     # 64-byte packed records (allocator aligns to 512 B)
         # gradients: static buffers bound to .grad so optimisers / reducers see them
         w["grads"] = {k: torch.zeros_like(self.splats[k]) for k in PARAM_ORDER}
         for k in PARAM_ORDER:
@@ -103,7 +103,7 @@ class FusedEngine:
         d.viewmats, d.Ks, d.pixels, d.backgrounds = p(w["viewmats"]), p(w["Ks"]), p(w["pixels"]), 0
         for k in ("radii", "means2d", "depths", "conics", "opacities", "colors", "tiles_per_gauss", "counters",
                   "isect_offsets", "key_buf", "flatten_ids", "render_colors", "render_alphas", "last_ids", "loss_sums",
-                  "dmaps", "v_render_colors", "zero_v_alphas", "v_inter"):
+                  "dmaps", "v_render_colors", "zero_v_alphas", "rec", "vrec"):
             setattr(d, k, p(w[k]))
         g = w["grads"]
         d.v_means, d.v_log_scales, d.v_quats, d.v_logit_opacities = p(g["means"]), p(g["scales"]), p(g["quats"]), p(g["opacities"])

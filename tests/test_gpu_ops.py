@@ -303,3 +303,18 @@ def test_photometric_loss(dev, B, H, W, CH):
         v_o.backward()
         assert abs(v_h.item() - v_o.item()) < 2e-6, padding
         assert rel_err(xh.grad, xo.grad) < 1e-4, padding
+
+
+def test_wave_reduction_primitives(dev):
+    """Transposing butterfly (8 sums in 26 instructions, slot s in lane with slot_of_lane==s) and the
+    two all-lane sums, against a float64 sum of exact small integers (bitwise in fp32)."""
+    from splat_one_amd import _lib
+    g = torch.Generator().manual_seed(0)
+    n = 37
+    x = torch.randint(-50, 50, (n * 64, 9), generator=g).float()
+    out = torch.zeros(n, 10, device=dev)
+    xd = x.to(dev)
+    _lib.call("so_debug_wave_reduce", n, _lib.ptr(xd), _lib.ptr(out), _lib.stream())
+    ref = x.reshape(n, 64, 9).double().sum(1)
+    assert torch.equal(out[:, :8].cpu().double(), ref[:, :8])
+    assert torch.equal(out[:, 8].cpu().double(), ref[:, 8]) and torch.equal(out[:, 9].cpu().double(), ref[:, 8])
