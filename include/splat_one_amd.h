@@ -48,6 +48,9 @@ int so_abi_version(void);
 const char *so_last_error(void);
 /* number of compute units / XCDs of the current device (launch sizing on the host side) */
 int so_device_cu_count(void);
+/* viewmats[C,4,4] = inverse(camtoworlds[C,4,4]) in one launch (replaces `torch.linalg.inv(camtoworlds)`,
+ * gsplat_trainer.py:483) */
+int so_camera_inverse(int C, const float *camtoworlds, float *viewmats, void *stream);
 /* test hook for the wave64 reduction primitives: in[n_waves*64,9] -> out[n_waves,10] */
 int so_debug_wave_reduce(int n_waves, const float *in, float *out, void *stream);
 
@@ -107,8 +110,10 @@ int so_sh_bwd(int C, int N, int K, int degrees_to_use, const float *dirs, const 
  *         isect_ids[capacity] i64 (= cam << (32+tile_bits) | tile << 32 | depth_bits).
  *         `capacity` is the size of the caller's buffers; if n_isects > capacity nothing beyond
  *         capacity is written and *overflow (device i32, nullable) is set to 1.
- *         tile_cursor[C*tile_h*tile_w] i32 must be zeroed by the caller.
- *         Lists longer than SO_TILE_SORT_LDS_MAX fall back to an in-kernel global-memory sort.
+ *         tile_cursor[C*tile_h*tile_w + 1] i32 must be zeroed by the caller (after the scatter the
+ *         array is reused as the work list of tiles whose list exceeds 1024 keys; the extra
+ *         element is its length).  Lists up to 16384 keys sort in 128 KiB of LDS, longer ones
+ *         fall back to the same network in global memory.
  * ---------------------------------------------------------------------------------------- */
 int so_isect_count(int C, int N, const float *means2d, const int32_t *radii, int tile_size, int tile_width,
                    int tile_height, int32_t *tiles_per_gauss, int32_t *tile_counts, int32_t *isect_offsets,
@@ -193,8 +198,9 @@ typedef struct so_adam_group {
 int so_adam_step(int n_groups, const so_adam_group *host_groups, double beta1, double beta2, double eps,
                  int zero_grad, void *stream);
 
-/* Device-scheduled variant for hipGraph replay: `step_counter` (device i32, number of optimiser
- * steps done so far) is read by the kernel, which evaluates lr = lr0[g] * lr_gamma[g]^step
+/* Device-scheduled variant for hipGraph replay: `step_counter` is a device int32[2 + 4*SO_ADAM_MAX_GROUPS]
+ * scratch whose element 0 is the number of optimiser steps done so far (the rest holds the per-group
+ * step sizes of the current step).  A one-block kernel evaluates lr = lr0[g] * lr_gamma[g]^step
  * (ExponentialLR, gsplat_trainer.py:512-516 and :741-742), the bias corrections for t = step+1, and
  * increments the counter afterwards.  Launch arguments are therefore constant across iterations. */
 int so_adam_step_dev(int n_groups, const so_adam_group *host_groups, const float *host_lr0,
@@ -238,8 +244,9 @@ int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float *means, co
 /* ------------------------------------------------------------------------------------------
  * One training iteration (gsplat_trainer.py:586-655: render -> loss -> backward) as ONE call on
  * caller-owned static buffers: memsets + 11 launches, no allocation, no host read-back, capturable
- * in a hipGraph.  Gradients of the raw parameters are overwritten; loss_sums[2] = (sum|x-y|,
- * sum SSIM_valid).  counters: int32[2*C*tiles + 2] (histogram | cursor | n_isects | overflow);
+ * in a hipGraph.  Gradients of the raw parameters are overwritten; loss_sums[5] = (sum|x-y|,
+ * sum SSIM_valid, loss, l1, 1-SSIM).  counters: int32[2*C*tiles + 3] (histogram | cursor | long-list length |
+ * n_isects | overflow);
  * zero_v_alphas: float[C*H*W] of zeros (the photometric loss does
  * not depend on alpha).  `abi_size` must be sizeof(so_step_desc).
  * ---------------------------------------------------------------------------------------- */
@@ -256,7 +263,7 @@ typedef struct so_step_desc {
   int32_t *flatten_ids;
   float *render_colors, *render_alphas;
   int32_t *last_ids;
-  float *loss_sums, *dmaps, *v_render_colors;
+  float *loss_sums /* [2] sums then [3] loss, l1, ssimloss */, *dmaps, *v_render_colors;
   const float *zero_v_alphas;
   float *rec, *vrec; /* [C*N][16] packed records, 64-byte aligned */
   /* gradients of the raw parameters */
@@ -288,12 +295,14 @@ void so_profile_stage_begin_end(int stage, int begin, void *stream);
  *   all pixels, or over the interior (5-pixel crop) when padding_valid != 0.
  *   dmaps[3,B,H,W,CH]: derivative maps saved for the backward (nullable when no gradient is needed).
  * Backward: v_img1 = v_loss * ( w_l1 * sign(img1-img2) + w_ssim * d(sum SSIM)/d img1 ), with
- *   v_loss a device scalar (nullable = 1).
+ *   v_loss a device scalar (nullable = 1); if loss_out[3] (nullable) is given together with the
+ *   forward's `sums`, it receives (w_l1*sums[0] + w_ssim*sums[1] + loss_const, mean|x-y|, 1-mean SSIM).
  * ---------------------------------------------------------------------------------------- */
 int so_ssim_l1_fwd(int B, int H, int W, int CH, const float *img1, const float *img2, int padding_valid,
                    float *sums, float *dmaps, void *stream);
 int so_ssim_l1_bwd(int B, int H, int W, int CH, const float *img1, const float *img2, const float *dmaps,
-                   float w_l1, float w_ssim, const float *v_loss, float *v_img1, void *stream);
+                   float w_l1, float w_ssim, const float *v_loss, float *v_img1, const float *sums,
+                   float *loss_out, int padding_valid, float loss_const, void *stream);
 
 #ifdef __cplusplus
 }

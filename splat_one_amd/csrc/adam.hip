@@ -64,26 +64,29 @@ k_adam(AdamGroups groups, AdamHyper h, int zero_grad) {
 
 // ---- device-scheduled variant: step counter, LR schedule and bias corrections live on the device,
 // so the launch arguments never change and the whole training step can be replayed as a hipGraph.
-struct AdamDevGroups {
-  so_adam_group g[SO_ADAM_MAX_GROUPS];
+struct AdamSched {
   float lr0[SO_ADAM_MAX_GROUPS];
   float lr_gamma[SO_ADAM_MAX_GROUPS];
 };
 
-__global__ void __launch_bounds__(256)
-k_adam_dev(AdamDevGroups groups, double beta1, double beta2, AdamHyper h, const int32_t *__restrict__ step_ptr,
-           int zero_grad) {
-  __shared__ float s_step_size, s_bc2_sqrt;
-  so_adam_group G = groups.g[blockIdx.y];
-  if (threadIdx.x == 0) {
-    const int step = *step_ptr;                 // optimiser steps completed so far
-    const double t = (double)(step + 1);
-    const double lr = (double)groups.lr0[blockIdx.y] * pow((double)groups.lr_gamma[blockIdx.y], (double)step);
-    s_step_size = (float)(lr / (1.0 - pow(beta1, t)));
-    s_bc2_sqrt = (float)sqrt(1.0 - pow(beta2, t));
+// one thread per group: evaluates the schedule for the current step, then advances the counter
+__global__ void k_adam_prep(AdamSched sch, int n_groups, double beta1, double beta2, int32_t *__restrict__ step_ptr,
+                            float2 *__restrict__ hyper) {
+  const int step = *step_ptr;                   // optimiser steps completed so far
+  const double t = (double)(step + 1);
+  if ((int)threadIdx.x < n_groups) {
+    const double lr = (double)sch.lr0[threadIdx.x] * pow((double)sch.lr_gamma[threadIdx.x], (double)step);
+    hyper[threadIdx.x] = make_float2((float)(lr / (1.0 - pow(beta1, t))), (float)sqrt(1.0 - pow(beta2, t)));
   }
   __syncthreads();
-  const float step_size = s_step_size, bc2_sqrt = s_bc2_sqrt;
+  if (threadIdx.x == 0) *step_ptr = step + 1;
+}
+
+__global__ void __launch_bounds__(256)
+k_adam_dev(AdamGroups groups, AdamHyper h, const float2 *__restrict__ hyper, int zero_grad) {
+  const so_adam_group G = groups.g[blockIdx.y];
+  const float2 hy = hyper[blockIdx.y];
+  const float step_size = hy.x, bc2_sqrt = hy.y;
   const int64_t n4 = G.numel / 4;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -108,8 +111,6 @@ k_adam_dev(AdamDevGroups groups, double beta1, double beta2, AdamHyper h, const 
   }
 }
 
-__global__ void k_step_inc(int32_t *step_ptr) { *step_ptr += 1; }
-
 }  // namespace so
 
 extern "C" int so_adam_step_dev(int n_groups, const so_adam_group *host_groups, const float *host_lr0,
@@ -119,7 +120,8 @@ extern "C" int so_adam_step_dev(int n_groups, const so_adam_group *host_groups, 
   SO_REQUIRE(step_counter, "so_adam_step_dev: null step counter");
   if (n_groups == 0) return SO_OK;
   SO_REQUIRE(host_groups && host_lr0 && host_lr_gamma, "so_adam_step_dev: null groups");
-  so::AdamDevGroups G;
+  so::AdamGroups G;
+  so::AdamSched S;
   int64_t max_numel = 0;
   for (int i = 0; i < n_groups; ++i) {
     const so_adam_group &g = host_groups[i];
@@ -128,22 +130,23 @@ extern "C" int so_adam_step_dev(int n_groups, const so_adam_group *host_groups, 
     SO_REQUIRE((((uintptr_t)g.param | (uintptr_t)g.grad | (uintptr_t)g.exp_avg | (uintptr_t)g.exp_avg_sq) & 15) == 0,
                "so_adam_step_dev: group %d buffers must be 16-byte aligned", i);
     G.g[i] = g;
-    G.lr0[i] = host_lr0[i];
-    G.lr_gamma[i] = host_lr_gamma[i];
+    S.lr0[i] = host_lr0[i];
+    S.lr_gamma[i] = host_lr_gamma[i];
     if (g.numel > max_numel) max_numel = g.numel;
   }
   hipStream_t st = so::as_stream(stream);
   so_profile_stage_begin_end(8, 1, stream);
+  // hyper[] lives right behind the step counter: step_counter[0] = step, [2..2+2*n) = (step_size, bc2_sqrt)
+  float2 *hyper = reinterpret_cast<float2 *>(step_counter + 2);
+  hipLaunchKernelGGL(so::k_adam_prep, dim3(1), dim3(SO_ADAM_MAX_GROUPS), 0, st, S, n_groups, beta1, beta2, step_counter, hyper);
   if (max_numel > 0) {
     int64_t gx = so::ceil_div(so::ceil_div(max_numel, 4), 256);
     if (gx > 2048) gx = 2048;
     if (gx < 1) gx = 1;
     const so::AdamHyper H{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps};
-    hipLaunchKernelGGL(so::k_adam_dev, dim3((unsigned)gx, (unsigned)n_groups), dim3(256), 0, st, G, beta1, beta2, H,
-                       step_counter, zero_grad);
+    hipLaunchKernelGGL(so::k_adam_dev, dim3((unsigned)gx, (unsigned)n_groups), dim3(256), 0, st, G, H, hyper, zero_grad);
   }
   so_profile_stage_begin_end(8, 0, stream);
-  hipLaunchKernelGGL(so::k_step_inc, dim3(1), dim3(1), 0, st, step_counter);
   return so::check_launch("so_adam_step_dev");
 }
 

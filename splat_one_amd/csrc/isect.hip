@@ -172,18 +172,24 @@ __device__ __forceinline__ void write_sorted(uint64_t key, int64_t pos, int64_t 
   }
 }
 
-// LDS sort for lists with MIN_LEN < L <= CAP (CAP keys of 8 B in LDS)
-template <int THREADS, int CAP, int MIN_LEN>
+// LDS sort for lists with L <= CAP (CAP keys of 8 B in LDS); longer lists are appended to the
+// work list (long_list[0..*long_count)) for k_tile_sort_long.
+template <int THREADS, int CAP>
 __global__ void __launch_bounds__(THREADS)
 k_tile_sort_lds(int64_t M, int n_tiles, int tile_bits, const int32_t *__restrict__ offsets,
                 const int32_t *__restrict__ n_isects, int64_t capacity, const uint64_t *__restrict__ key_buf,
-                int32_t *__restrict__ flatten_ids, int64_t *__restrict__ isect_ids) {
+                int32_t *__restrict__ flatten_ids, int64_t *__restrict__ isect_ids, int32_t *__restrict__ long_list,
+                int32_t *__restrict__ long_count) {
   extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
   for (int64_t t = blockIdx.x; t < M; t += gridDim.x) {
     int64_t lo, hi;
     tile_range(t, M, offsets, n_isects, capacity, lo, hi);
     const int64_t L = hi - lo;
-    if (L <= MIN_LEN || L > CAP) continue;
+    if (L > CAP) {
+      if (threadIdx.x == 0) long_list[atomicAdd(long_count, 1)] = (int32_t)t;
+      continue;
+    }
+    if (L <= 0) continue;
     for (int i = threadIdx.x; i < L; i += THREADS) s_keys[i] = key_buf[lo + i];
     __syncthreads();
     bitonic_sort_shared<THREADS>(s_keys, (int)L);
@@ -192,18 +198,30 @@ k_tile_sort_lds(int64_t M, int n_tiles, int tile_bits, const int32_t *__restrict
   }
 }
 
-// Fallback for lists longer than the LDS capacity: the same network on the global key buffer
-// (one workgroup per tile; rare: > CAP Gaussians overlapping one 16x16 tile).
+// Long lists (work list built by k_tile_sort_lds): a small fixed grid walks the list, so the launch
+// costs nothing when no tile is long.  <= CAP keys: the same network in 128 KiB of LDS; longer
+// (pathological: > 16384 Gaussians over one tile): the network runs on the global key buffer.
 template <int THREADS, int CAP>
 __global__ void __launch_bounds__(THREADS)
-k_tile_sort_global(int64_t M, int n_tiles, int tile_bits, const int32_t *__restrict__ offsets,
-                   const int32_t *__restrict__ n_isects, int64_t capacity, uint64_t *__restrict__ key_buf,
-                   int32_t *__restrict__ flatten_ids, int64_t *__restrict__ isect_ids) {
-  for (int64_t t = blockIdx.x; t < M; t += gridDim.x) {
+k_tile_sort_long(int64_t M, int n_tiles, int tile_bits, const int32_t *__restrict__ offsets,
+                 const int32_t *__restrict__ n_isects, int64_t capacity, uint64_t *__restrict__ key_buf,
+                 int32_t *__restrict__ flatten_ids, int64_t *__restrict__ isect_ids,
+                 const int32_t *__restrict__ long_list, const int32_t *__restrict__ long_count) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
+  const int n_long = *long_count;
+  for (int w = blockIdx.x; w < n_long; w += gridDim.x) {
+    const int64_t t = long_list[w];
     int64_t lo, hi;
     tile_range(t, M, offsets, n_isects, capacity, lo, hi);
     const int64_t n = hi - lo;
-    if (n <= CAP) continue;
+    if (n <= CAP) {
+      for (int i = threadIdx.x; i < n; i += THREADS) s_keys[i] = key_buf[lo + i];
+      __syncthreads();
+      bitonic_sort_shared<THREADS>(s_keys, (int)n);
+      for (int i = threadIdx.x; i < n; i += THREADS) write_sorted(s_keys[i], lo + i, t, n_tiles, tile_bits, flatten_ids, isect_ids);
+      __syncthreads();
+      continue;
+    }
     uint64_t *keys = key_buf + lo;
     int64_t np2 = 1;
     while (np2 < n) np2 <<= 1;
@@ -337,21 +355,21 @@ extern "C" int so_isect_fill(int C, int N, const float *means2d, const int32_t *
   const int gridM = (int)(M < 65535 * 8 ? M : 65535 * 8);
   static bool lds_attr_set = false;  // 128 KiB of dynamic LDS needs an explicit opt-in
   if (!lds_attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&so::k_tile_sort_lds<1024, 16384, 1024>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&so::k_tile_sort_long<1024, 16384>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8) != hipSuccess) {
       (void)hipGetLastError();
     }
     lds_attr_set = true;
   }
-  // small lists: 256 threads, up to 1024 keys (8 KiB LDS) -> many workgroups per CU
-  hipLaunchKernelGGL((so::k_tile_sort_lds<256, 1024, 0>), dim3(gridM), dim3(256), 1024 * 8, st, M, n_tiles, tb,
-                     isect_offsets, n_isects, capacity, key_buf, flatten_ids, isect_ids);
-  // long lists: 1024 threads, up to 16384 keys (128 KiB LDS)
-  hipLaunchKernelGGL((so::k_tile_sort_lds<1024, 16384, 1024>), dim3(gridM), dim3(1024), 16384 * 8, st, M, n_tiles,
-                     tb, isect_offsets, n_isects, capacity, key_buf, flatten_ids, isect_ids);
-  // pathological lists: global-memory network
-  hipLaunchKernelGGL((so::k_tile_sort_global<1024, 16384>), dim3(gridM), dim3(1024), 0, st, M, n_tiles, tb,
-                     isect_offsets, n_isects, capacity, key_buf, flatten_ids, isect_ids);
+  // after the scatter the cursor array is dead: it becomes the work list of long tiles, and the
+  // (caller-zeroed) element behind it is the list length
+  int32_t *long_list = tile_cursor, *long_count = tile_cursor + M;
+  // lists up to 1024 keys: 256 threads, 8 KiB LDS -> many workgroups per CU
+  hipLaunchKernelGGL((so::k_tile_sort_lds<256, 1024>), dim3(gridM), dim3(256), 1024 * 8, st, M, n_tiles, tb,
+                     isect_offsets, n_isects, capacity, key_buf, flatten_ids, isect_ids, long_list, long_count);
+  // longer lists: fixed small grid over the work list
+  hipLaunchKernelGGL((so::k_tile_sort_long<1024, 16384>), dim3(128), dim3(1024), 16384 * 8, st, M, n_tiles, tb,
+                     isect_offsets, n_isects, capacity, key_buf, flatten_ids, isect_ids, long_list, long_count);
   return so::check_launch("so_isect_fill");
 }
 

@@ -120,7 +120,8 @@ template <int CH>
 __global__ void __launch_bounds__(256)
 k_ssim_l1_bwd(int B, int H, int W, const float *__restrict__ img1, const float *__restrict__ img2,
               const float *__restrict__ dmaps, Window win, float w_l1, float w_ssim,
-              const float *__restrict__ v_loss, float *__restrict__ v_img1) {
+              const float *__restrict__ v_loss, float *__restrict__ v_img1, const float *__restrict__ sums,
+              float *__restrict__ loss_out, float a_l1, float b_ssim, float c_const) {
   __shared__ float sm[3][kHalo][kHalo + 1];
   __shared__ float hb[3][kHalo][kTile + 1];
   const int tid = threadIdx.x;
@@ -130,6 +131,13 @@ k_ssim_l1_bwd(int B, int H, int W, const float *__restrict__ img1, const float *
   const int64_t map_stride = (int64_t)B * plane;
   const float up = v_loss ? *v_loss : 1.f;
   const float wl1 = w_l1 * up, wss = w_ssim * up;
+  if (loss_out && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+    // the forward kernel has completed: finalise the scalars here instead of a separate launch
+    const float l1 = sums[0] * a_l1, ss = sums[1] * b_ssim;   // mean |x-y| , mean SSIM
+    loss_out[0] = w_l1 / a_l1 * l1 + w_ssim / b_ssim * ss + c_const;
+    loss_out[1] = l1;
+    loss_out[2] = 1.f - ss;
+  }
 #pragma unroll 1
   for (int ch = 0; ch < CH; ++ch) {
     for (int i = tid; i < kHalo * kHalo; i += 256) {
@@ -208,19 +216,24 @@ extern "C" int so_ssim_l1_fwd(int B, int H, int W, int CH, const float *img1, co
 
 /* v_img1[B,H,W,CH] = v_loss * ( w_l1 * sign(img1-img2) + w_ssim * d(sum of SSIM map)/d img1 ).
  * For loss = (1-l)*mean|.| + l*(1-mean SSIM): w_l1 = (1-l)/(B*H*W*CH), w_ssim = -l/n_counted.
- * v_loss: device scalar (nullable = 1). */
+ * v_loss: device scalar (nullable = 1).  If loss_out[3] is given (with the forward's `sums`), thread 0
+ * also writes (w_l1*sum|.| + w_ssim*sum SSIM + loss_const, mean|.|, 1 - mean SSIM). */
 extern "C" int so_ssim_l1_bwd(int B, int H, int W, int CH, const float *img1, const float *img2,
                               const float *dmaps, float w_l1, float w_ssim, const float *v_loss, float *v_img1,
+                              const float *sums, float *loss_out, int padding_valid, float loss_const,
                               void *stream) {
   SO_REQUIRE(B >= 0 && H > 0 && W > 0, "so_ssim_l1_bwd: bad sizes");
   SO_REQUIRE(CH == 1 || CH == 3 || CH == 4, "so_ssim_l1_bwd: CH=%d not in {1,3,4}", CH);
   if (B == 0) return SO_OK;
   SO_REQUIRE(img1 && img2 && dmaps && v_img1, "so_ssim_l1_bwd: null pointer");
+  SO_REQUIRE(loss_out == nullptr || sums != nullptr, "so_ssim_l1_bwd: loss_out needs sums");
+  const float a_l1 = 1.f / ((float)B * H * W * CH);
+  const float b_ss = 1.f / ((float)B * CH * (padding_valid ? (float)(H - 10) * (float)(W - 10) : (float)H * (float)W));
   const so::Window win = so::make_window();
   const dim3 grid((W + so::kTile - 1) / so::kTile, (H + so::kTile - 1) / so::kTile, B), block(256);
   hipStream_t st = so::as_stream(stream);
-  if (CH == 1) hipLaunchKernelGGL(so::k_ssim_l1_bwd<1>, grid, block, 0, st, B, H, W, img1, img2, dmaps, win, w_l1, w_ssim, v_loss, v_img1);
-  else if (CH == 3) hipLaunchKernelGGL(so::k_ssim_l1_bwd<3>, grid, block, 0, st, B, H, W, img1, img2, dmaps, win, w_l1, w_ssim, v_loss, v_img1);
-  else hipLaunchKernelGGL(so::k_ssim_l1_bwd<4>, grid, block, 0, st, B, H, W, img1, img2, dmaps, win, w_l1, w_ssim, v_loss, v_img1);
+  if (CH == 1) hipLaunchKernelGGL(so::k_ssim_l1_bwd<1>, grid, block, 0, st, B, H, W, img1, img2, dmaps, win, w_l1, w_ssim, v_loss, v_img1, sums, loss_out, a_l1, b_ss, loss_const);
+  else if (CH == 3) hipLaunchKernelGGL(so::k_ssim_l1_bwd<3>, grid, block, 0, st, B, H, W, img1, img2, dmaps, win, w_l1, w_ssim, v_loss, v_img1, sums, loss_out, a_l1, b_ss, loss_const);
+  else hipLaunchKernelGGL(so::k_ssim_l1_bwd<4>, grid, block, 0, st, B, H, W, img1, img2, dmaps, win, w_l1, w_ssim, v_loss, v_img1, sums, loss_out, a_l1, b_ss, loss_const);
   return so::check_launch("so_ssim_l1_bwd");
 }

@@ -95,11 +95,15 @@ extern "C" int so_train_step_fwd_bwd(const so_step_desc *d, void *stream) {
   const int64_t M = (int64_t)C * tile_w * tile_h;
   hipStream_t st = so::as_stream(stream);
   int rc;
-  // counters: tile_counts[M] | cursor[M] | n_isects | overflow        loss_sums: l1, ssim
-  int32_t *tile_counts = d->counters, *cursor = d->counters + M, *n_isects = d->counters + 2 * M,
-          *overflow = d->counters + 2 * M + 1;
-  so::zero_async(d->counters, 2 * M + 2, st);
-  so::zero_async(d->loss_sums, 2, st);
+  // counters: tile_counts[M] | cursor[M] | long-list length | n_isects | overflow     loss_sums: l1, ssim
+  int32_t *tile_counts = d->counters, *cursor = d->counters + M, *n_isects = d->counters + 2 * M + 1,
+          *overflow = d->counters + 2 * M + 2;
+  if (reinterpret_cast<int32_t *>(d->loss_sums) == d->counters + 2 * M + 3) {
+    so::zero_async(d->counters, 2 * M + 5, st);   // loss sums packed right behind the counters: one launch
+  } else {
+    so::zero_async(d->counters, 2 * M + 3, st);
+    so::zero_async(d->loss_sums, 2, st);
+  }
 #define SO_TRY(call) do { rc = (call); if (rc != SO_OK) return rc; } while (0)
 #define SO_STAGE(i, call) do { so::StageTimer _t(i, st); SO_TRY(call); } while (0)
   SO_STAGE(0, so_preprocess_fwd(C, N, K, d->sh_degree, d->means, d->log_scales, d->quats, d->logit_opacities, d->sh0, d->shN,
@@ -115,7 +119,8 @@ extern "C" int so_train_step_fwd_bwd(const so_step_desc *d, void *stream) {
   SO_STAGE(4, so_ssim_l1_fwd(C, H, W, 3, d->render_colors, d->pixels, 1, d->loss_sums, d->dmaps, stream));
   const float n_l1 = (float)C * H * W * 3.f, n_ss = (float)C * 3.f * (float)(H - 10) * (float)(W - 10);
   SO_STAGE(5, so_ssim_l1_bwd(C, H, W, 3, d->render_colors, d->pixels, d->dmaps, (1.f - d->ssim_lambda) / n_l1,
-                        -d->ssim_lambda / n_ss, nullptr, d->v_render_colors, stream));
+                        -d->ssim_lambda / n_ss, nullptr, d->v_render_colors, d->loss_sums, d->loss_sums + 2, 1,
+                        d->ssim_lambda, stream));
   // gradients of the intermediates accumulate in the 64-byte records vrec[C*N] (zeroed by the
   // forward preprocess kernel): one atomic request per (tile quadrant, Gaussian)
   SO_STAGE(6, so_rasterize_bwd_packed(C, N, W, H, ts, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects,

@@ -52,7 +52,7 @@ class FusedEngine:
         self._graph: Optional[torch.cuda.CUDAGraph] = None
         self._graph_key = None
         self.steps_done = 0
-        self._step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._step_dev = torch.zeros(2 + 4 * _lib.SO_ADAM_MAX_GROUPS, dtype=torch.int32, device=self.device)
         self._build_workspace()
 
     # ---------------------------------------------------------------------------------------------
@@ -73,13 +73,14 @@ class FusedEngine:
         w["radii"], w["tiles_per_gauss"] = e(C, N, dtype=i32), e(C, N, dtype=i32)
         w["means2d"], w["depths"], w["conics"] = e(C, N, 2), e(C, N), e(C, N, 3)
         w["opacities"], w["colors"] = e(C, N), e(C, N, 3)
-        w["counters"] = torch.zeros(2 * M + 2, dtype=i32, device=dev)
+        # counters (2M+3 ints) | loss sums (2 floats) | loss, l1, ssimloss (3 floats) in one allocation
+        w["counters"] = torch.zeros(2 * M + 8, dtype=i32, device=dev)
         w["isect_offsets"] = e(C, th, tw, dtype=i32)
         w["key_buf"] = e(cap, dtype=torch.int64)
         w["flatten_ids"] = e(cap, dtype=i32)
         w["render_colors"], w["render_alphas"] = e(C, H, W, 3), e(C, H, W, 1)
         w["last_ids"] = e(C, H, W, dtype=i32)
-        w["loss_sums"] = torch.zeros(2, device=dev)
+        w["loss_sums"] = w["counters"][2 * M + 3:2 * M + 8].view(torch.float32)
         w["dmaps"] = e(3, C, H, W, 3)
         w["v_render_colors"] = e(C, H, W, 3)
         w["zero_v_alphas"] = torch.zeros(C, H, W, device=dev)
@@ -153,9 +154,12 @@ class FusedEngine:
         camtoworlds[C,4,4] (rigid; inverted here), Ks[C,3,3], pixels[C,H,W,3] in 0..1."""
         assert camtoworlds.shape == (self.C, 4, 4) and Ks.shape == (self.C, 3, 3), (camtoworlds.shape, Ks.shape)
         assert pixels.shape == (self.C, self.H, self.W, 3), pixels.shape
-        vm = torch.linalg.inv(camtoworlds.detach().to("cpu", torch.float64)).to(torch.float32) \
-            if not camtoworlds.is_cuda else torch.linalg.inv(camtoworlds.detach())
-        self.ws["viewmats"].copy_(vm, non_blocking=True)
+        if camtoworlds.is_cuda:
+            c2w = camtoworlds.detach().to(torch.float32).contiguous()
+            _lib.call("so_camera_inverse", self.C, _lib.ptr(c2w), _lib.ptr(self.ws["viewmats"]), _lib.stream())
+        else:
+            vm = torch.linalg.inv(camtoworlds.detach().to(torch.float64)).to(torch.float32)
+            self.ws["viewmats"].copy_(vm, non_blocking=True)
         self.ws["Ks"].copy_(Ks, non_blocking=True)
         self.ws["pixels"].copy_(pixels, non_blocking=True)
 
@@ -227,17 +231,12 @@ class FusedEngine:
         self._build_workspace()
 
     def loss(self) -> Tensor:
-        """(loss, l1, ssimloss) of the last step as a device tensor [3] (no sync)."""
-        s = self.ws["loss_sums"]
-        n_l1 = float(self.C * self.H * self.W * 3)
-        n_ss = float(self.C * 3 * (self.H - 10) * (self.W - 10))
-        l1 = s[0] / n_l1
-        ss = 1.0 - s[1] / n_ss
-        lam = self.cfg["ssim_lambda"]
-        return torch.stack([l1 * (1 - lam) + ss * lam, l1, ss])
+        """(loss, l1, ssimloss) of the last step: a view of 3 device floats written by the step itself
+        (no extra launch, no sync; regularisers are not included in the scalar)."""
+        return self.ws["loss_sums"][2:5]
 
     def stats(self) -> dict:
         """Workload counters of the last step (synchronises)."""
         c = self.ws["counters"]
-        return {"n_isects": int(c[2 * self.M].item()), "overflow": int(c[2 * self.M + 1].item()),
+        return {"n_isects": int(c[2 * self.M + 1].item()), "overflow": int(c[2 * self.M + 2].item()),
                 "visible": int((self.ws["radii"] > 0).sum().item())}

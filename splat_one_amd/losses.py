@@ -40,7 +40,7 @@ class _L1SSIM(torch.autograd.Function):
         v_img1 = torch.empty_like(img1)
         v_loss = v_loss.contiguous().to(torch.float32)
         call("so_ssim_l1_bwd", B, H, W, CH, ptr(img1), ptr(img2), ptr(dmaps), ctx.w[0], ctx.w[1], ptr(v_loss),
-             ptr(v_img1), stream())
+             ptr(v_img1), 0, 0, 0, 0.0, stream())
         return v_img1, None, None, None, None, None
 
 

@@ -205,8 +205,9 @@ def isect_tiles(
     radii = radii.to(torch.int32).contiguous()
     M = C * tile_width * tile_height
     tiles_per_gauss = torch.empty(C, N, dtype=torch.int32, device=dev)
-    counters = torch.zeros(2 * M + 2, dtype=torch.int32, device=dev)  # counts | cursor | n | overflow
-    tile_counts, cursor, n_isects, overflow = counters[:M], counters[M:2 * M], counters[2 * M:2 * M + 1], counters[2 * M + 1:]
+    counters = torch.zeros(2 * M + 3, dtype=torch.int32, device=dev)  # counts | cursor (+1) | n | overflow
+    tile_counts, cursor = counters[:M], counters[M:2 * M + 1]
+    n_isects, overflow = counters[2 * M + 1:2 * M + 2], counters[2 * M + 2:]
     offsets = torch.empty(C, tile_height, tile_width, dtype=torch.int32, device=dev)
     call("so_isect_count", C, N, ptr(means2d), ptr(radii), tile_size, tile_width, tile_height,
          ptr(tiles_per_gauss), ptr(tile_counts), ptr(offsets), ptr(n_isects), stream())
@@ -246,14 +247,14 @@ def isect_tiles_static(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size
             ws[name] = t
         return t
     tiles_per_gauss = buf("tiles_per_gauss", (C, N), torch.int32)
-    counters = buf("counters", (2 * M + 2,), torch.int32)
+    counters = buf("counters", (2 * M + 3,), torch.int32)
     counters.zero_()
     offsets = buf("isect_offsets", (C, tile_height, tile_width), torch.int32)
     keys = buf("keys", (capacity,), torch.int64)
     flatten_ids = buf("flatten_ids", (capacity,), torch.int32)
     isect_ids = buf("isect_ids", (capacity,), torch.int64) if want_isect_ids else None
-    tile_counts, cursor = counters[:M], counters[M:2 * M]
-    n_isects, overflow = counters[2 * M:2 * M + 1], counters[2 * M + 1:]
+    tile_counts, cursor = counters[:M], counters[M:2 * M + 1]
+    n_isects, overflow = counters[2 * M + 1:2 * M + 2], counters[2 * M + 2:]
     means2d, depths = _f32(means2d), _f32(depths)
     call("so_isect_count", C, N, ptr(means2d), ptr(radii), tile_size, tile_width, tile_height,
          ptr(tiles_per_gauss), ptr(tile_counts), ptr(offsets), ptr(n_isects), stream())

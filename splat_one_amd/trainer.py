@@ -208,7 +208,7 @@ class Runner:
                 strategy_state=self.strategy_state, lr_gamma_means=self.lr_gamma,
                 isect_capacity=cfg.isect_capacity, use_graph=(self.world_size == 1))
             eng.steps_done = step
-            eng._step_dev.fill_(step)
+            eng._step_dev[0] = step
         eng.set_sh_degree(min(step // cfg.sh_degree_interval, cfg.sh_degree))
         # densification statistics are accumulated inside the backward kernel while refinement is active
         stats_on = step < s.refine_stop_iter
@@ -244,7 +244,7 @@ class Runner:
                 reset_opa(params=self.splats, optimizers=self.optimizers, state=self.strategy_state,
                           value=s.prune_opa * 2.0)
             eng.rebuild()
-        self.last_info = {"radii": eng.ws["radii"], "n_isects": eng.ws["counters"][2 * eng.M:2 * eng.M + 1],
+        self.last_info = {"radii": eng.ws["radii"], "n_isects": eng.ws["counters"][2 * eng.M + 1:2 * eng.M + 2],
                           "flatten_ids": eng.ws["flatten_ids"], "means2d": eng.ws["means2d"]}
         self.step += 1
         return eng.loss()[0]

@@ -318,3 +318,15 @@ def test_wave_reduction_primitives(dev):
     ref = x.reshape(n, 64, 9).double().sum(1)
     assert torch.equal(out[:, :8].cpu().double(), ref[:, :8])
     assert torch.equal(out[:, 8].cpu().double(), ref[:, 8]) and torch.equal(out[:, 9].cpu().double(), ref[:, 8])
+
+
+def test_camera_inverse(dev):
+    from splat_one_amd import _lib
+    from splat_one_amd.scene import ring_cameras
+    c2w = ring_cameras(8, 9.0, 0.7)
+    c2w[:, :3, :3] *= torch.linspace(0.5, 2.0, 8)[:, None, None]      # non-rigid (scaled) poses too
+    out = torch.empty(8, 4, 4, device=dev)
+    src = c2w.to(dev).contiguous()
+    _lib.call("so_camera_inverse", 8, _lib.ptr(src), _lib.ptr(out), _lib.stream())
+    ref = torch.linalg.inv(c2w.double())
+    assert torch.allclose(out.cpu().double(), ref, rtol=1e-6, atol=1e-6)
