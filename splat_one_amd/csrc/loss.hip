@@ -8,127 +8,230 @@
 // derivative maps).  HBM-bound: forward reads 2 images and writes 3 maps, backward reads 3 maps +
 // 2 images and writes 1 image; all window arithmetic runs out of LDS.
 //
-// One workgroup = one 32x32 output tile of one image, all channels: the (32+10)^2 halo of both
-// images is fetched once with row-contiguous (channel-interleaved) loads, then the horizontal and
-// vertical 11-tap passes run from LDS.
+// Row-streaming kernels: see the comment above kXT.
 #include "so_common.hpp"
 
 namespace so {
 
 constexpr int kWin = 11, kHalf = 5;
-constexpr int kTile = 32;
-constexpr int kHalo = kTile + 2 * kHalf;  // 42
 constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 
 struct Window {
   float w[kWin];
 };
 
-template <int CH>
-__global__ void __launch_bounds__(256)
-k_ssim_l1_fwd(int B, int H, int W, const float *__restrict__ img1, const float *__restrict__ img2, int valid, Window win,
-              float *__restrict__ sums, float *__restrict__ dmaps) {
-  __shared__ float s1[CH][kHalo][kHalo + 1];
-  __shared__ float s2[CH][kHalo][kHalo + 1];
-  __shared__ float hb[5][kHalo][kTile + 1];
-  __shared__ float red[2][4];
-  const int tid = threadIdx.x;
-  const int b = blockIdx.z;
-  const int x0 = blockIdx.x * kTile, y0 = blockIdx.y * kTile;
-  const int64_t plane = (int64_t)H * W * CH;
-  const float *p1 = img1 + b * plane, *p2 = img2 + b * plane;
-  // halo load: rows of kHalo pixels x CH channels are contiguous in memory
-  for (int i = tid; i < kHalo * kHalo * CH; i += 256) {
-    const int r = i / (kHalo * CH), rem = i - r * (kHalo * CH);
-    const int cx = rem / CH, ch = rem - cx * CH;
-    const int y = y0 + r - kHalf, x = x0 + cx - kHalf;
-    float a = 0.f, c = 0.f;
-    if (y >= 0 && y < H && x >= 0 && x < W) {
-      const int64_t o = ((int64_t)y * W + x) * CH + ch;
-      a = p1[o];
-      c = p2[o];
-    }
-    s1[ch][r][cx] = a;
-    s2[ch][r][cx] = c;
-  }
-  __syncthreads();
-  float l1_acc = 0.f, ssim_acc = 0.f;
-  const int64_t map_stride = (int64_t)B * plane;
-#pragma unroll 1
-  for (int ch = 0; ch < CH; ++ch) {
-    // horizontal pass: kHalo rows x kTile columns
-    for (int i = tid; i < kHalo * kTile; i += 256) {
-      const int r = i / kTile, cx = i - r * kTile;
-      float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+// ---------------------------------------------------------------------------------------------
+// Row-streaming formulation.  A workgroup owns a strip of kXT output columns x all CH channels
+// (thread = (column, channel), so global loads/stores of the channel-last image are contiguous
+// over the thread index) and walks kRows output rows top to bottom.  Per input row: the row
+// (+5 halo columns each side) is staged through a double-buffered LDS line, every thread does its
+// 11-tap horizontal sums and pushes them into an 11-deep ring of REGISTERS; the vertical 11-tap
+// sum for the row 5 above comes straight from that ring.  No 2-D intermediate ever exists in LDS
+// (2 x 1.8 KB per image instead of 71 KB), the next-but-one row is prefetched into registers while
+// the current one is computed, and each input element is read from HBM ~1.3x instead of 1.7-3x.
+// ---------------------------------------------------------------------------------------------
+constexpr int kXT = 64;     // output columns per workgroup
+constexpr int kRows = 32;   // output rows per workgroup
+
+template <int CH, int NIMG>
+struct RowStage {   // register staging of one input row of NIMG images: 2 elements per thread
+  float v[NIMG][2];
+};
+
+template <int CH, int NIMG>
+__device__ __forceinline__ void row_gload(RowStage<CH, NIMG> &st, const float *const (&img)[NIMG], int b, int H, int W,
+                                          int y, int x0, int tid) {
+  constexpr int T = kXT * CH, E = (kXT + 2 * kHalf) * CH;
 #pragma unroll
-      for (int k = 0; k < kWin; ++k) {
-        const float a = s1[ch][r][cx + k], c = s2[ch][r][cx + k], w = win.w[k];
-        m1 += w * a; m2 += w * c; e11 += w * a * a; e22 += w * c * c; e12 += w * a * c;
-      }
-      hb[0][r][cx] = m1; hb[1][r][cx] = m2; hb[2][r][cx] = e11; hb[3][r][cx] = e22; hb[4][r][cx] = e12;
-    }
-    __syncthreads();
-    // vertical pass + SSIM + derivative maps: kTile x kTile outputs, 4 per thread
-    for (int i = tid; i < kTile * kTile; i += 256) {
-      const int ry = i / kTile, cx = i - ry * kTile;
-      const int y = y0 + ry, x = x0 + cx;
-      if (y >= H || x >= W) continue;
-      float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+  for (int j = 0; j < 2; ++j) {
+    const int e = tid + j * T;
+    const int xx = x0 - kHalf + e / CH;
+    const bool ok = (e < E) && (y >= 0) && (y < H) && (xx >= 0) && (xx < W);
+    const int64_t off = (((int64_t)b * H + y) * W + xx) * CH + (e % CH);
 #pragma unroll
-      for (int k = 0; k < kWin; ++k) {
-        const float w = win.w[k];
-        mu1 += w * hb[0][ry + k][cx]; mu2 += w * hb[1][ry + k][cx]; e11 += w * hb[2][ry + k][cx];
-        e22 += w * hb[3][ry + k][cx]; e12 += w * hb[4][ry + k][cx];
-      }
-      const float sig1 = e11 - mu1 * mu1, sig2 = e22 - mu2 * mu2, sig12 = e12 - mu1 * mu2;
-      const float A = 2.f * mu1 * mu2 + kC1, Bv = 2.f * sig12 + kC2;
-      const float D = mu1 * mu1 + mu2 * mu2 + kC1, E = sig1 + sig2 + kC2;
-      const float rDE = 1.f / (D * E);
-      const float m = A * Bv * rDE;
-      const bool counted = !valid || (y >= kHalf && y < H - kHalf && x >= kHalf && x < W - kHalf);
-      const float xv = s1[ch][ry + kHalf][cx + kHalf], yv = s2[ch][ry + kHalf][cx + kHalf];
-      l1_acc += fabsf(xv - yv);
-      float g_mu = 0.f, g_e11 = 0.f, g_e12 = 0.f;
-      if (counted) {
-        ssim_acc += m;
-        const float dm_dA = Bv * rDE, dm_dB = A * rDE, dm_dD = -m / D, dm_dE = -m / E;
-        g_e11 = dm_dE;
-        g_e12 = 2.f * dm_dB;
-        g_mu = 2.f * mu2 * dm_dA + 2.f * mu1 * dm_dD - 2.f * mu1 * g_e11 - mu2 * g_e12;
-      }
-      if (dmaps) {
-        const int64_t o = b * plane + ((int64_t)y * W + x) * CH + ch;
-        dmaps[o] = g_mu;
-        dmaps[map_stride + o] = g_e11;
-        dmaps[2 * map_stride + o] = g_e12;
-      }
-    }
-    __syncthreads();
+    for (int i = 0; i < NIMG; ++i) st.v[i][j] = ok ? img[i][off] : 0.f;
   }
-  // block reduction of the two sums -> one atomic each
-  l1_acc = wave_reduce_sum(l1_acc);
-  ssim_acc = wave_reduce_sum(ssim_acc);
-  if ((tid & 63) == 0) { red[0][tid >> 6] = l1_acc; red[1][tid >> 6] = ssim_acc; }
-  __syncthreads();
-  if (tid == 0) {
-    atomicAdd(sums, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-    atomicAdd(sums + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+}
+
+template <int CH, int NIMG>
+__device__ __forceinline__ void row_lstore(const RowStage<CH, NIMG> &st, float (*rows)[(kXT + 2 * kHalf) * CH], int tid) {
+  constexpr int T = kXT * CH, E = (kXT + 2 * kHalf) * CH;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int e = tid + j * T;
+    if (e < E) {
+#pragma unroll
+      for (int i = 0; i < NIMG; ++i) rows[i][e] = st.v[i][j];
+    }
   }
 }
 
 template <int CH>
-__global__ void __launch_bounds__(256)
+struct SsimFwdState {
+  float ring[kWin][5];
+  float l1_acc, ss_acc;
+};
+
+template <int CH, int P>
+__device__ __forceinline__ void ssim_fwd_step(SsimFwdState<CH> &S, RowStage<CH, 2> &pre, float (*rows)[2][(kXT + 2 * kHalf) * CH],
+                                              const float *const (&img)[2], int it, int n_in, int n_out, int b, int H, int W,
+                                              int x0, int y0, int tid, int xl, int ch, int valid, const Window &win,
+                                              float *__restrict__ dmaps, int64_t map_stride) {
+  if (it >= n_in) return;   // uniform over the workgroup
+  __syncthreads();
+  if (it + 1 < n_in) row_lstore<CH, 2>(pre, rows[(it + 1) & 1], tid);
+  if (it + 2 < n_in) row_gload<CH, 2>(pre, img, b, H, W, y0 - kHalf + it + 2, x0, tid);
+  const float *A = rows[it & 1][0], *Bq = rows[it & 1][1];
+  float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+  for (int k = 0; k < kWin; ++k) {
+    const float a = A[(xl + k) * CH + ch], c = Bq[(xl + k) * CH + ch], w = win.w[k];
+    m1 += w * a; m2 += w * c; e11 += w * a * a; e22 += w * c * c; e12 += w * a * c;
+  }
+  S.ring[P][0] = m1; S.ring[P][1] = m2; S.ring[P][2] = e11; S.ring[P][3] = e22; S.ring[P][4] = e12;
+  const int x = x0 + xl;
+  const int y_in = y0 - kHalf + it;
+  if (y_in >= y0 && y_in < y0 + n_out && x < W) S.l1_acc += fabsf(A[(xl + kHalf) * CH + ch] - Bq[(xl + kHalf) * CH + ch]);
+  if (it >= 2 * kHalf) {
+    const int y = y_in - kHalf;   // output row
+    float mu1 = 0.f, mu2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+#pragma unroll
+    for (int k = 0; k < kWin; ++k) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int slot = (P + 1 + k) % kWin;   // oldest row first; compile-time after unrolling
+      const float w = win.w[k];
+      mu1 += w * S.ring[slot][0]; mu2 += w * S.ring[slot][1]; s11 += w * S.ring[slot][2];
+      s22 += w * S.ring[slot][3]; s12 += w * S.ring[slot][4];
+    }
+    const float sig1 = s11 - mu1 * mu1, sig2 = s22 - mu2 * mu2, sig12 = s12 - mu1 * mu2;
+    const float Av = 2.f * mu1 * mu2 + kC1, Bv = 2.f * sig12 + kC2;
+    const float D = mu1 * mu1 + mu2 * mu2 + kC1, E = sig1 + sig2 + kC2;
+    const float rDE = 1.f / (D * E);
+    const float m = Av * Bv * rDE;
+    const bool counted = !valid || (y >= kHalf && y < H - kHalf && x >= kHalf && x < W - kHalf);
+    float g_mu = 0.f, g_e11 = 0.f, g_e12 = 0.f;
+    if (counted && x < W) {
+      S.ss_acc += m;
+      const float dm_dA = Bv * rDE, dm_dB = Av * rDE, dm_dD = -m / D, dm_dE = -m / E;
+      g_e11 = dm_dE;
+      g_e12 = 2.f * dm_dB;
+      g_mu = 2.f * mu2 * dm_dA + 2.f * mu1 * dm_dD - 2.f * mu1 * g_e11 - mu2 * g_e12;
+    }
+    if (dmaps && x < W) {
+      const int64_t o = (((int64_t)b * H + y) * W + x) * CH + ch;
+      dmaps[o] = g_mu;
+      dmaps[map_stride + o] = g_e11;
+      dmaps[2 * map_stride + o] = g_e12;
+    }
+  }
+}
+
+template <int CH>
+__global__ void __launch_bounds__(kXT *CH)
+k_ssim_l1_fwd(int B, int H, int W, const float *__restrict__ img1, const float *__restrict__ img2, int valid, Window win,
+              float *__restrict__ sums, float *__restrict__ dmaps) {
+  constexpr int E = (kXT + 2 * kHalf) * CH;
+  __shared__ float rows[2][2][E];
+  __shared__ float red[2][CH];
+  const int tid = threadIdx.x, xl = tid / CH, ch = tid - xl * CH;
+  const int x0 = blockIdx.x * kXT, y0 = blockIdx.y * kRows, b = blockIdx.z;
+  const int n_out = (H - y0) < kRows ? (H - y0) : kRows;
+  const int n_in = n_out + 2 * kHalf;
+  const float *const img[2] = {img1, img2};
+  const int64_t map_stride = (int64_t)B * H * W * CH;
+  RowStage<CH, 2> pre;
+  row_gload<CH, 2>(pre, img, b, H, W, y0 - kHalf, x0, tid);
+  row_lstore<CH, 2>(pre, rows[0], tid);
+  row_gload<CH, 2>(pre, img, b, H, W, y0 - kHalf + 1, x0, tid);
+  SsimFwdState<CH> S;
+  S.l1_acc = S.ss_acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < kWin; ++i)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) S.ring[i][q] = 0.f;
+#define SO_STEP(P) ssim_fwd_step<CH, P>(S, pre, rows, img, base + P, n_in, n_out, b, H, W, x0, y0, tid, xl, ch, valid, win, dmaps, map_stride)
+#pragma unroll 1
+  for (int base = 0; base < n_in; base += kWin) {
+    SO_STEP(0); SO_STEP(1); SO_STEP(2); SO_STEP(3); SO_STEP(4); SO_STEP(5);
+    SO_STEP(6); SO_STEP(7); SO_STEP(8); SO_STEP(9); SO_STEP(10);
+  }
+#undef SO_STEP
+  const float l1 = wave_reduce_sum(S.l1_acc), ss = wave_reduce_sum(S.ss_acc);
+  if ((tid & 63) == 0) { red[0][tid >> 6] = l1; red[1][tid >> 6] = ss; }
+  __syncthreads();
+  if (tid == 0) {
+    float a = 0.f, c = 0.f;
+#pragma unroll
+    for (int w = 0; w < CH; ++w) { a += red[0][w]; c += red[1][w]; }
+    atomicAdd(sums, a);
+    atomicAdd(sums + 1, c);
+  }
+}
+
+template <int CH>
+struct SsimBwdState {
+  float ring[kWin][3];
+};
+
+template <int CH, int P>
+__device__ __forceinline__ void ssim_bwd_step(SsimBwdState<CH> &S, RowStage<CH, 3> &pre, float (*rows)[3][(kXT + 2 * kHalf) * CH],
+                                              const float *const (&maps)[3], const float *__restrict__ img1,
+                                              const float *__restrict__ img2, int it, int n_in, int b, int H, int W, int x0,
+                                              int y0, int tid, int xl, int ch, const Window &win, float wl1, float wss,
+                                              float *__restrict__ v_img1) {
+  if (it >= n_in) return;
+  __syncthreads();
+  if (it + 1 < n_in) row_lstore<CH, 3>(pre, rows[(it + 1) & 1], tid);
+  if (it + 2 < n_in) row_gload<CH, 3>(pre, maps, b, H, W, y0 - kHalf + it + 2, x0, tid);
+  const int x = x0 + xl;
+  const int y = y0 - 2 * kHalf + it;   // output row completed by this input row
+  float xv = 0.f, yv = 0.f;
+  const bool out = (it >= 2 * kHalf) && (x < W);
+  int64_t o = 0;
+  if (out) {   // issue the two pixel loads early; consumed after the vertical sums
+    o = (((int64_t)b * H + y) * W + x) * CH + ch;
+    xv = img1[o];
+    yv = img2[o];
+  }
+  const float *M0 = rows[it & 1][0], *M1 = rows[it & 1][1], *M2 = rows[it & 1][2];
+  float a = 0.f, c = 0.f, d = 0.f;
+#pragma unroll
+  for (int k = 0; k < kWin; ++k) {
+    const float w = win.w[k];
+    const int e = (xl + k) * CH + ch;
+    a += w * M0[e]; c += w * M1[e]; d += w * M2[e];
+  }
+  S.ring[P][0] = a; S.ring[P][1] = c; S.ring[P][2] = d;
+  if (it >= 2 * kHalf) {
+    float va = 0.f, vc = 0.f, vd = 0.f;
+#pragma unroll
+    for (int k = 0; k < kWin; ++k) {
+      const int slot = (P + 1 + k) % kWin;
+      const float w = win.w[k];
+      va += w * S.ring[slot][0]; vc += w * S.ring[slot][1]; vd += w * S.ring[slot][2];
+    }
+    if (out) {
+      const float diff = xv - yv;
+      const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+      v_img1[o] = wl1 * sgn + wss * (va + 2.f * xv * vc + yv * vd);
+    }
+  }
+}
+
+template <int CH>
+__global__ void __launch_bounds__(kXT *CH)
 k_ssim_l1_bwd(int B, int H, int W, const float *__restrict__ img1, const float *__restrict__ img2,
               const float *__restrict__ dmaps, Window win, float w_l1, float w_ssim,
               const float *__restrict__ v_loss, float *__restrict__ v_img1, const float *__restrict__ sums,
               float *__restrict__ loss_out, float a_l1, float b_ssim, float c_const) {
-  __shared__ float sm[3][kHalo][kHalo + 1];
-  __shared__ float hb[3][kHalo][kTile + 1];
-  const int tid = threadIdx.x;
-  const int b = blockIdx.z;
-  const int x0 = blockIdx.x * kTile, y0 = blockIdx.y * kTile;
-  const int64_t plane = (int64_t)H * W * CH;
-  const int64_t map_stride = (int64_t)B * plane;
+  constexpr int E = (kXT + 2 * kHalf) * CH;
+  __shared__ float rows[2][3][E];
+  const int tid = threadIdx.x, xl = tid / CH, ch = tid - xl * CH;
+  const int x0 = blockIdx.x * kXT, y0 = blockIdx.y * kRows, b = blockIdx.z;
+  const int n_out = (H - y0) < kRows ? (H - y0) : kRows;
+  const int n_in = n_out + 2 * kHalf;
+  const int64_t map_stride = (int64_t)B * H * W * CH;
   const float up = v_loss ? *v_loss : 1.f;
   const float wl1 = w_l1 * up, wss = w_ssim * up;
   if (loss_out && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
@@ -138,48 +241,21 @@ k_ssim_l1_bwd(int B, int H, int W, const float *__restrict__ img1, const float *
     loss_out[1] = l1;
     loss_out[2] = 1.f - ss;
   }
+  const float *const maps[3] = {dmaps, dmaps + map_stride, dmaps + 2 * map_stride};
+  RowStage<CH, 3> pre;
+  row_gload<CH, 3>(pre, maps, b, H, W, y0 - kHalf, x0, tid);
+  row_lstore<CH, 3>(pre, rows[0], tid);
+  row_gload<CH, 3>(pre, maps, b, H, W, y0 - kHalf + 1, x0, tid);
+  SsimBwdState<CH> S;
+#pragma unroll
+  for (int i = 0; i < kWin; ++i) S.ring[i][0] = S.ring[i][1] = S.ring[i][2] = 0.f;
+#define SO_STEP(P) ssim_bwd_step<CH, P>(S, pre, rows, maps, img1, img2, base + P, n_in, b, H, W, x0, y0, tid, xl, ch, win, wl1, wss, v_img1)
 #pragma unroll 1
-  for (int ch = 0; ch < CH; ++ch) {
-    for (int i = tid; i < kHalo * kHalo; i += 256) {
-      const int r = i / kHalo, cx = i - r * kHalo;
-      const int y = y0 + r - kHalf, x = x0 + cx - kHalf;
-      float a = 0.f, c = 0.f, d = 0.f;
-      if (y >= 0 && y < H && x >= 0 && x < W) {
-        const int64_t o = b * plane + ((int64_t)y * W + x) * CH + ch;
-        a = dmaps[o]; c = dmaps[map_stride + o]; d = dmaps[2 * map_stride + o];
-      }
-      sm[0][r][cx] = a; sm[1][r][cx] = c; sm[2][r][cx] = d;
-    }
-    __syncthreads();
-    for (int i = tid; i < kHalo * kTile; i += 256) {
-      const int r = i / kTile, cx = i - r * kTile;
-      float a = 0.f, c = 0.f, d = 0.f;
-#pragma unroll
-      for (int k = 0; k < kWin; ++k) {
-        const float w = win.w[k];
-        a += w * sm[0][r][cx + k]; c += w * sm[1][r][cx + k]; d += w * sm[2][r][cx + k];
-      }
-      hb[0][r][cx] = a; hb[1][r][cx] = c; hb[2][r][cx] = d;
-    }
-    __syncthreads();
-    for (int i = tid; i < kTile * kTile; i += 256) {
-      const int ry = i / kTile, cx = i - ry * kTile;
-      const int y = y0 + ry, x = x0 + cx;
-      if (y >= H || x >= W) continue;
-      float a = 0.f, c = 0.f, d = 0.f;
-#pragma unroll
-      for (int k = 0; k < kWin; ++k) {
-        const float w = win.w[k];
-        a += w * hb[0][ry + k][cx]; c += w * hb[1][ry + k][cx]; d += w * hb[2][ry + k][cx];
-      }
-      const int64_t o = b * plane + ((int64_t)y * W + x) * CH + ch;
-      const float xv = img1[o], yv = img2[o];
-      const float diff = xv - yv;
-      const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
-      v_img1[o] = wl1 * sgn + wss * (a + 2.f * xv * c + yv * d);
-    }
-    __syncthreads();
+  for (int base = 0; base < n_in; base += kWin) {
+    SO_STEP(0); SO_STEP(1); SO_STEP(2); SO_STEP(3); SO_STEP(4); SO_STEP(5);
+    SO_STEP(6); SO_STEP(7); SO_STEP(8); SO_STEP(9); SO_STEP(10);
   }
+#undef SO_STEP
 }
 
 static Window make_window() {
@@ -206,7 +282,7 @@ extern "C" int so_ssim_l1_fwd(int B, int H, int W, int CH, const float *img1, co
   if (B == 0) return SO_OK;
   SO_REQUIRE(img1 && img2 && sums, "so_ssim_l1_fwd: null pointer");
   const so::Window win = so::make_window();
-  const dim3 grid((W + so::kTile - 1) / so::kTile, (H + so::kTile - 1) / so::kTile, B), block(256);
+  const dim3 grid((W + so::kXT - 1) / so::kXT, (H + so::kRows - 1) / so::kRows, B), block(so::kXT * CH);
   hipStream_t st = so::as_stream(stream);
   if (CH == 1) hipLaunchKernelGGL(so::k_ssim_l1_fwd<1>, grid, block, 0, st, B, H, W, img1, img2, padding_valid, win, sums, dmaps);
   else if (CH == 3) hipLaunchKernelGGL(so::k_ssim_l1_fwd<3>, grid, block, 0, st, B, H, W, img1, img2, padding_valid, win, sums, dmaps);
@@ -230,7 +306,7 @@ extern "C" int so_ssim_l1_bwd(int B, int H, int W, int CH, const float *img1, co
   const float a_l1 = 1.f / ((float)B * H * W * CH);
   const float b_ss = 1.f / ((float)B * CH * (padding_valid ? (float)(H - 10) * (float)(W - 10) : (float)H * (float)W));
   const so::Window win = so::make_window();
-  const dim3 grid((W + so::kTile - 1) / so::kTile, (H + so::kTile - 1) / so::kTile, B), block(256);
+  const dim3 grid((W + so::kXT - 1) / so::kXT, (H + so::kRows - 1) / so::kRows, B), block(so::kXT * CH);
   hipStream_t st = so::as_stream(stream);
   if (CH == 1) hipLaunchKernelGGL(so::k_ssim_l1_bwd<1>, grid, block, 0, st, B, H, W, img1, img2, dmaps, win, w_l1, w_ssim, v_loss, v_img1, sums, loss_out, a_l1, b_ss, loss_const);
   else if (CH == 3) hipLaunchKernelGGL(so::k_ssim_l1_bwd<3>, grid, block, 0, st, B, H, W, img1, img2, dmaps, win, w_l1, w_ssim, v_loss, v_img1, sums, loss_out, a_l1, b_ss, loss_const);
