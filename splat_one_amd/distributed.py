@@ -96,7 +96,19 @@ class GradientReducer:
         if self._flat is None or self._flat.numel() != total or self._flat.device != ps[0].device:
             self._flat = torch.empty(total, dtype=ps[0].dtype, device=ps[0].device)
         flat = self._flat
-        torch.cat([p.grad.reshape(-1) for p in ps], out=flat)
+        # gradients that already live in the flat buffer (previous call re-pointed them) need no copy
+        off, in_place = 0, True
+        for p in ps:
+            g = p.grad
+            if not (g.is_contiguous() and g.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
+                    and g.storage_offset() == off):
+                in_place = False
+                break
+            off += p.numel()
+        if not in_place:
+            pieces = [p.grad.reshape(-1).clone() if p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
+                      else p.grad.reshape(-1) for p in ps]
+            torch.cat(pieces, out=flat)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         flat.mul_(1.0 / dist.get_world_size(self.group))
         off = 0
@@ -104,6 +116,15 @@ class GradientReducer:
             n = p.numel()
             p.grad = flat[off:off + n].view_as(p)
             off += n
+
+
+@torch.no_grad()
+def all_reduce_mean_(flat: torch.Tensor, group=None) -> None:
+    """In-place mean over ranks of one flat buffer (the engine's gradient SoA): ONE collective."""
+    if not is_initialized() or dist.get_world_size(group) == 1:
+        return
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.mul_(1.0 / dist.get_world_size(group))
 
 
 @torch.no_grad()

@@ -85,8 +85,16 @@ class FusedEngine:
         w["v_render_colors"] = e(C, H, W, 3)
         w["zero_v_alphas"] = torch.zeros(C, H, W, device=dev)
         w["rec"], w["vrec"] = e(C * N, 16), e(C * N, 16)     # 64-byte packed records (allocator aligns to 512 B)
-        # gradients: static buffers bound to .grad so optimisers / reducers see them
-        w["grads"] = {k: torch.zeros_like(self.splats[k]) for k in PARAM_ORDER}
+        # gradients: ONE flat static buffer (the data-parallel all-reduce runs on it directly, no
+        # flatten copy); per-tensor views are bound to .grad so optimisers / callers see them
+        pad = lambda n: (n + 63) // 64 * 64                  # 256-byte aligned segments (float4 access)
+        total = sum(pad(self.splats[k].numel()) for k in PARAM_ORDER)
+        w["grads_flat"] = torch.zeros(total, dtype=f32, device=dev)
+        w["grads"], off = {}, 0
+        for k in PARAM_ORDER:
+            n = self.splats[k].numel()
+            w["grads"][k] = w["grads_flat"][off:off + n].view_as(self.splats[k])
+            off += pad(n)
         for k in PARAM_ORDER:
             self.splats[k].grad = w["grads"][k]
         if self.strategy_state is not None:

@@ -220,9 +220,7 @@ class Runner:
             eng.step()
         else:
             eng.fwd_bwd()
-            self._reducer.reduce(self.splats.values())
-            for k, v in self.splats.items():      # the reducer repoints .grad at its flat buffer
-                eng.ws["grads"][k] = v.grad
+            sdist.all_reduce_mean_(eng.ws["grads_flat"])     # ONE collective on the flat gradient SoA
             eng.optimize()
         refine_now = (step < s.refine_stop_iter and step > s.refine_start_iter and step % s.refine_every == 0
                       and step % s.reset_every >= s.pause_refine_after_reset)
@@ -251,7 +249,8 @@ class Runner:
 
     def train_step(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor, masks: Optional[Tensor] = None) -> Tensor:
         """One iteration on an already-on-device batch (camtoworlds[B,4,4], Ks[B,3,3],
-        pixels[B,H,W,3] in 0..1).  Returns the loss tensor (no host sync)."""
+        pixels[B,H,W,3] in 0..1).  Returns the loss tensor (no host sync; on the fused path it is a
+        view of the engine's static loss buffer, valid until the next step -- clone it to keep it)."""
         if self._fused_ok(masks):
             return self._train_step_fused(camtoworlds, Ks, pixels)
         cfg, step = self.cfg, self.step
