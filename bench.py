@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--regime", default="mcmc", choices=["mcmc", "ref"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--raster-impl", type=int, default=0, help="0: LDS-tiled rasteriser, 1: wave-per-quadrant")
     ap.add_argument("--operator-path", action="store_true",
                     help="time the operator-level autograd path instead of the fused engine")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel times to stderr")
@@ -117,6 +118,7 @@ def main():
                  camera_model="pinhole", sh_degree_interval=1,    # SH degree 3 from step 3 on
                  fused=not args.operator_path)
     runner = Runner(local_rank, rank, world, cfg, scene_scale=1.0 / 1.1)   # effective scene_scale 1.0
+    runner.raster_impl = args.raster_impl
     cams = front_camera()[None] if world == 1 else ring_cameras(world)
     c2w = cams[rank:rank + 1].to(dev)
     Ks = pinhole_K(W, H)[None].to(dev)

@@ -171,6 +171,27 @@ int so_rasterize_bwd_packed(int C, int N, int width, int height, int tile_size, 
                             const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
                             float *vrec, int absgrad, void *stream);
 
+/* Wave-per-quadrant variants (tile 16, D = 3, packed records): every 8x8 pixel quadrant is an
+ * independent 64-lane workgroup, list entries are staged in registers and broadcast with
+ * v_readlane -- no LDS, no barriers.  Same results as the *_packed entry points. */
+int so_rasterize_fwd_wave(int C, int N, int width, int height, const float *rec, const float *backgrounds,
+                          const int32_t *isect_offsets, const int32_t *flatten_ids, const int32_t *n_isects_dev,
+                          int64_t n_isects_host, float *render_colors, float *render_alphas, int32_t *last_ids,
+                          void *stream);
+int so_rasterize_bwd_wave(int C, int N, int width, int height, const float *rec, const float *backgrounds,
+                          const int32_t *isect_offsets, const int32_t *flatten_ids, const int32_t *n_isects_dev,
+                          int64_t n_isects_host, const float *render_alphas, const int32_t *last_ids,
+                          const float *v_render_colors, const float *v_render_alphas, float *vrec, int absgrad,
+                          void *stream);
+
+/* diagnostic build of so_rasterize_bwd_wave with per-wave s_memtime stamps (profiling only) */
+int so_debug_rasterize_bwd_wave_stamps(int C, int N, int width, int height, const float *rec,
+                                       const int32_t *isect_offsets, const int32_t *flatten_ids,
+                                       const int32_t *n_isects_dev, const float *render_alphas,
+                                       const int32_t *last_ids, const float *v_render_colors,
+                                       const float *v_render_alphas, float *vrec, unsigned long long *stamps,
+                                       int variant, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Optimiser.  Replaces the six torch.optim.Adam steps + zero_grad of gsplat_trainer.py:726-731
  * (hyper-parameters per :266-280) with ONE launch over up to SO_ADAM_MAX_GROUPS tensors.
@@ -272,6 +293,7 @@ typedef struct so_step_desc {
   float *grad2d, *count;
   int64_t isect_capacity;
   int32_t abi_size, C, N, K, width, height, tile_size, sh_degree, camera_model, antialiased, absgrad;
+  int32_t raster_impl; /* 0: LDS-tiled kernels, 1: wave-per-quadrant kernels (tile 16 only) */
   float eps2d, near_plane, far_plane, radius_clip, ssim_lambda, opacity_reg, scale_reg;
 } so_step_desc;
 int so_train_step_fwd_bwd(const so_step_desc *desc, void *stream);

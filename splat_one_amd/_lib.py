@@ -38,7 +38,7 @@ class StepDesc(ctypes.Structure):
                               "grad2d", "count")]
         + [("isect_capacity", c_i64)]
         + [(n, ctypes.c_int32) for n in ("abi_size", "C", "N", "K", "width", "height", "tile_size", "sh_degree",
-                                         "camera_model", "antialiased", "absgrad")]
+                                         "camera_model", "antialiased", "absgrad", "raster_impl")]
         + [(n, c_f32) for n in ("eps2d", "near_plane", "far_plane", "radius_clip", "ssim_lambda", "opacity_reg",
                                 "scale_reg")])
 
@@ -63,6 +63,9 @@ _SIGS = {
     "so_preprocess_fwd": [c_int] * 4 + [c_ptr] * 8 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_int] + [c_ptr] * 11,
     "so_preprocess_bwd": [c_int] * 4 + [c_ptr] * 8 + [c_int, c_int, c_f32, c_int, c_int] + [c_ptr] * 9 + [c_f32, c_f32] + [c_ptr] * 9 + [c_int, c_ptr],
     "so_rasterize_fwd_packed": [c_int] * 5 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 4,
+    "so_rasterize_fwd_wave": [c_int] * 4 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 4,
+    "so_rasterize_bwd_wave": [c_int] * 4 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 5 + [c_int, c_ptr],
+    "so_debug_rasterize_bwd_wave_stamps": [c_int] * 4 + [c_ptr] * 10 + [c_int, c_ptr],
     "so_rasterize_bwd_packed": [c_int] * 5 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 5 + [c_int, c_ptr],
     "so_train_step_fwd_bwd": [ctypes.POINTER(StepDesc), c_ptr],
     "so_profile_enable": [c_int],

@@ -32,9 +32,10 @@ __global__ void __launch_bounds__(64) k_debug_wave_reduce(const float *__restric
   const float o = row_allreduce_sum(row[8]);
   const float c = wave_reduce_sum(row[8]);
   float *dst = out + (int64_t)blockIdx.x * 10;
-  // exactly the store pattern of the rasteriser backward: lanes (l&15) <= 8 of every row, one atomic
+  // exactly the store pattern of the rasteriser backward: rows combined, lanes 0..8 add once
   const int l15 = lane & 15;
-  if (l15 <= 8) atomicAdd(dst + (l15 < 8 ? slot_of_lane(lane) : 8), l15 < 8 ? e : o);
+  const float val = rows_combine(l15 < 8 ? e : o);
+  if (lane <= 8) atomicAdd(dst + (lane < 8 ? slot_of_lane(lane) : 8), val);
   if (lane == 17) dst[9] = c;
 }
 }  // namespace so

@@ -98,7 +98,6 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
     else if (slot == 8) { out_base = v_opacities; out_stride = 1; }
     else if (ABS && slot < 11) { out_base = v_means2d_abs + (slot - 9); out_stride = 2; }
   }
-  const bool out_lane = (D == 3) && (l15 <= (ABS ? 10 : 8));
 
   for (int64_t batch_end = block_last; batch_end >= lo; batch_end -= BLOCK) {
     __syncthreads();
@@ -136,6 +135,11 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
       if (cand < batch_size && batch_end - cand <= wave_last) {
         const float4 bx = s_box[cand];
         hit = !(bx.y < qx0 || bx.x > qx1 || bx.w < qy0 || bx.z > qy1);
+        if (hit) {   // bounding boxes overlap: settle it with the exact ellipse-rectangle test
+          const float4 a = s_xyoa[cand];
+          const float2 bc = s_bc[cand];
+          hit = ellipse_hits_rect(a.x, a.y, a.z, a.w, bc.x, bc.y, qx0, qx1, qy0, qy1);
+        }
       }
       unsigned long long mask = __ballot(hit);
       while (mask) {
@@ -156,7 +160,7 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
 #pragma unroll
         for (int k = 0; k < D; ++k) g_col[k] = 0.f;
         if (valid) {
-          const float ra = 1.f / (1.f - alpha);
+          const float ra = __builtin_amdgcn_rcpf(1.f - alpha);   // 1 ulp; alpha <= 0.999
           T *= ra;
           const float fac = alpha * T;
           float v_alpha = 0.f;
@@ -190,8 +194,10 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
             if (l15 == 9) val = r_ax;
             if (l15 == 10) val = r_ay;
           }
-          // one atomic instruction: <= 4 rows x 9(11) lanes, all inside one 64-byte record when PACKED
-          if (out_lane && val != 0.f) atomicAdd(out_base + (int64_t)s_id[tt] * out_stride, val);
+          // combine the four rows, then ONE atomic instruction with 9 (11) distinct addresses
+          // (one 64-byte record when PACKED)
+          val = rows_combine(val);
+          if (lane <= (ABS ? 10 : 8) && val != 0.f) atomicAdd(out_base + (int64_t)s_id[tt] * out_stride, val);
           continue;
         }
         // generic channel counts: wave sums land in lane 63

@@ -52,4 +52,41 @@ __device__ __forceinline__ float4 alpha_bound_box(float x, float y, float opac, 
   return make_float4(x - hx, x + hx, y - hy, y + hy);
 }
 
+// Exact test "can alpha reach 1/255 anywhere in the axis-aligned rectangle [x0,x1] x [y0,y1] of pixel
+// centres?" -- the minimum of sigma(p) = 1/2 (p-mu)^T Q (p-mu) over the rectangle against
+// tau = ln(255 opac), with the same conservative padding as alpha_bound_box.  Evaluated by ONE lane
+// per candidate Gaussian in the ballot phase (so its cost is amortised over 64 pixels); culls the
+// bounding-box corners the box test lets through.
+__device__ __forceinline__ bool ellipse_hits_rect(float mx, float my, float opac, float ca, float cb, float cc,
+                                                  float x0, float x1, float y0, float y1) {
+  if (!(opac * 255.f >= 0.999f)) return false;
+  const float det = ca * cc - cb * cb;
+  if (!(det > 0.f) || !(ca > 0.f) || !(cc > 0.f)) return true;   // degenerate conic: never cull
+  const float tau = fmaxf(__logf(opac * 255.f), 0.f) * 1.0001f + 1e-4f;
+  // translate so the Gaussian centre is the origin; pad the rectangle by 0.01 px
+  const float ax0 = x0 - mx - 0.01f, ax1 = x1 - mx + 0.01f, ay0 = y0 - my - 0.01f, ay1 = y1 - my + 0.01f;
+  if (ax0 <= 0.f && ax1 >= 0.f && ay0 <= 0.f && ay1 >= 0.f) return true;   // centre inside
+  // minimum over each edge of the convex quadratic: 1-D parabola, clamp the unconstrained minimiser
+  float best = __builtin_inff();
+  {  // edges x = ax0 / ax1:  sigma(y) = 1/2 (ca x^2 + cc y^2) + cb x y,  y* = -cb x / cc
+    const float xs[2] = {ax0, ax1};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float x = xs[i];
+      const float y = fminf(fmaxf(-cb * x / cc, ay0), ay1);
+      best = fminf(best, 0.5f * (ca * x * x + cc * y * y) + cb * x * y);
+    }
+  }
+  {  // edges y = ay0 / ay1
+    const float ys[2] = {ay0, ay1};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float y = ys[i];
+      const float x = fminf(fmaxf(-cb * y / ca, ax0), ax1);
+      best = fminf(best, 0.5f * (ca * x * x + cc * y * y) + cb * x * y);
+    }
+  }
+  return best <= tau * 1.0005f + 1e-3f;
+}
+
 }  // namespace so

@@ -108,6 +108,11 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
       if (cand < batch_size) {
         const float4 bx = s_box[cand];
         hit = !(bx.y < qx0 || bx.x > qx1 || bx.w < qy0 || bx.z > qy1);
+        if (hit) {   // bounding boxes overlap: settle it with the exact ellipse-rectangle test
+          const float4 a = s_xyoa[cand];
+          const float2 bc = s_bc[cand];
+          hit = ellipse_hits_rect(a.x, a.y, a.z, a.w, bc.x, bc.y, qx0, qx1, qy0, qy1);
+        }
       }
       unsigned long long mask = __ballot(hit);
       while (mask) {

@@ -77,11 +77,14 @@ __device__ __forceinline__ float wave_reduce_sum(float v) {
 // ---------------------------------------------------------------------------------------------
 // Transposing butterfly reduction over the 16 lanes of each DPP row: 8 per-lane values are summed
 // in 22 VALU instructions (vs 8 x 4 for eight independent row reductions) and the row total of
-// slot s ends in the lanes l of that row with slot_of_lane(l) == s.  The four rows of a wave are
-// NOT combined: the caller issues ONE atomic instruction in which lanes (l & 15) < 8 of every row
-// add their row total to slot_of_lane(l) -- 32 active lanes, one 32-byte segment, the memory-side
-// atomic unit sums the four rows.  (v_permlane16/32_swap would finish the sum in registers, but
-// hipcc 7.2 miscompiles `r[0] + r[1]` of that builtin.)  EXEC must be all ones.
+// slot s ends in the lanes l of that row with slot_of_lane(l) == s.  `rows_combine` then adds the four
+// rows (two ds_bpermute shuffles on the ONE remaining value per lane), after which lanes 0..8 of the
+// wave hold the nine totals and issue ONE atomic instruction with nine DISTINCT addresses inside one
+// 64-byte record.  Measured on MI355X (tools/dbg_stamps.py): letting the four rows add their partial
+// sums to the same addresses in one atomic instruction costs ~130 us per launch of the rasteriser
+// backward (same-address lanes serialise in the memory-side atomic unit); distinct addresses in
+// one line are almost free.  (v_permlane16/32_swap would do the row combine without LDS hardware,
+// but hipcc 7.2 miscompiles `r[0] + r[1]` of that builtin.)  EXEC must be all ones.
 //   xor1 / xor2 via quad_perm, rotate-4 / rotate-8 within the row via row_ror.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int slot_of_lane(int lane) {  // 4*b0 + 2*b1 + b2
@@ -106,6 +109,13 @@ __device__ __forceinline__ float row_reduce8_transposed(const float (&v)[8], int
   float e = keep + dpp_mov<0x124, 0xf, 0xf, true>(0.f, send);  // row_ror:4
   e += dpp_mov<0x128, 0xf, 0xf, true>(0.f, e);                 // row_ror:8
   return e;
+}
+
+// Adds the four DPP rows lane-wise: lanes 0..15 end with v[l] + v[l+16] + v[l+32] + v[l+48].
+__device__ __forceinline__ float rows_combine(float v) {
+  v += __shfl_down(v, 32, 64);
+  v += __shfl_down(v, 16, 64);
+  return v;
 }
 
 // Sum over the 16 lanes of each row, result in every lane of the row (4 VALU instructions).

@@ -113,8 +113,13 @@ extern "C" int so_train_step_fwd_bwd(const so_step_desc *d, void *stream) {
   SO_STAGE(1, so_isect_scan(C, tile_w, tile_h, tile_counts, d->isect_offsets, n_isects, stream));
   SO_STAGE(2, so_isect_fill(C, N, d->means2d, d->radii, d->depths, ts, tile_w, tile_h, d->isect_offsets, n_isects, cursor,
                        d->isect_capacity, d->key_buf, d->flatten_ids, nullptr, overflow, stream));
-  SO_STAGE(3, so_rasterize_fwd_packed(C, N, W, H, ts, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects,
-                                      0, d->render_colors, d->render_alphas, d->last_ids, stream));
+  const bool wave_impl = d->raster_impl == 1 && ts == 16;
+  if (wave_impl)
+    SO_STAGE(3, so_rasterize_fwd_wave(C, N, W, H, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects, 0,
+                                      d->render_colors, d->render_alphas, d->last_ids, stream));
+  else
+    SO_STAGE(3, so_rasterize_fwd_packed(C, N, W, H, ts, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects,
+                                        0, d->render_colors, d->render_alphas, d->last_ids, stream));
   // loss = (1-l) * mean|.| + l * (1 - mean SSIM_valid)
   SO_STAGE(4, so_ssim_l1_fwd(C, H, W, 3, d->render_colors, d->pixels, 1, d->loss_sums, d->dmaps, stream));
   const float n_l1 = (float)C * H * W * 3.f, n_ss = (float)C * 3.f * (float)(H - 10) * (float)(W - 10);
@@ -123,9 +128,14 @@ extern "C" int so_train_step_fwd_bwd(const so_step_desc *d, void *stream) {
                         d->ssim_lambda, stream));
   // gradients of the intermediates accumulate in the 64-byte records vrec[C*N] (zeroed by the
   // forward preprocess kernel): one atomic request per (tile quadrant, Gaussian)
-  SO_STAGE(6, so_rasterize_bwd_packed(C, N, W, H, ts, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects,
-                                      0, d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
+  if (wave_impl)
+    SO_STAGE(6, so_rasterize_bwd_wave(C, N, W, H, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects, 0,
+                                      d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
                                       d->absgrad, stream));
+  else
+    SO_STAGE(6, so_rasterize_bwd_packed(C, N, W, H, ts, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects,
+                                        0, d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
+                                        d->absgrad, stream));
   SO_STAGE(7, so_preprocess_bwd(C, N, K, d->sh_degree, d->means, d->log_scales, d->quats, d->logit_opacities, d->sh0, d->shN,
                            d->viewmats, d->Ks, W, H, d->eps2d, d->camera_model, d->antialiased, d->radii, d->opacities,
                            d->colors, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d->opacity_reg,

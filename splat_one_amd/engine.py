@@ -36,12 +36,13 @@ class FusedEngine:
                  antialiased: bool = False, absgrad: bool = False, ssim_lambda: float = 0.2,
                  opacity_reg: float = 0.0, scale_reg: float = 0.0, tile_size: int = 16,
                  strategy_state: Optional[dict] = None, lr_gamma_means: float = 1.0,
-                 isect_capacity: Optional[int] = None, use_graph: bool = True):
+                 isect_capacity: Optional[int] = None, use_graph: bool = True, raster_impl: int = 0):
         self.splats, self.optimizers = splats, optimizers
         self.W, self.H, self.C = int(width), int(height), int(n_views)
         self.cfg = dict(sh_degree=sh_degree, camera_model=camera_model, near_plane=near_plane, far_plane=far_plane,
                         radius_clip=radius_clip, eps2d=eps2d, antialiased=antialiased, absgrad=absgrad,
-                        ssim_lambda=ssim_lambda, opacity_reg=opacity_reg, scale_reg=scale_reg, tile_size=tile_size)
+                        ssim_lambda=ssim_lambda, opacity_reg=opacity_reg, scale_reg=scale_reg, tile_size=tile_size,
+                        raster_impl=raster_impl)
         self.strategy_state = strategy_state
         self.lr_gamma_means = lr_gamma_means
         self.use_graph = use_graph
@@ -125,6 +126,7 @@ class FusedEngine:
         d.C, d.N, d.K, d.width, d.height, d.tile_size = self.C, self.N, self.K, self.W, self.H, c["tile_size"]
         d.sh_degree, d.camera_model = c["sh_degree"], CAMERA_MODELS[c["camera_model"]]
         d.antialiased, d.absgrad = int(c["antialiased"]), int(c["absgrad"])
+        d.raster_impl = int(c["raster_impl"])
         d.eps2d, d.near_plane, d.far_plane, d.radius_clip = c["eps2d"], c["near_plane"], c["far_plane"], c["radius_clip"]
         d.ssim_lambda, d.opacity_reg, d.scale_reg = c["ssim_lambda"], c["opacity_reg"], c["scale_reg"]
         return d

@@ -206,7 +206,8 @@ class Runner:
                 near_plane=cfg.near_plane, far_plane=cfg.far_plane, antialiased=cfg.antialiased, absgrad=s.absgrad,
                 ssim_lambda=cfg.ssim_lambda, opacity_reg=cfg.opacity_reg, scale_reg=cfg.scale_reg,
                 strategy_state=self.strategy_state, lr_gamma_means=self.lr_gamma,
-                isect_capacity=cfg.isect_capacity, use_graph=(self.world_size == 1))
+                isect_capacity=cfg.isect_capacity, use_graph=(self.world_size == 1),
+                raster_impl=getattr(self, "raster_impl", 0))
             eng.steps_done = step
             eng._step_dev[0] = step
         eng.set_sh_degree(min(step // cfg.sh_degree_interval, cfg.sh_degree))
