@@ -144,16 +144,22 @@ def main():
         dominant = max(prof.items(), key=lambda kv: kv[1][0] * kv[1][1])[0]
         _lib.PROFILE = {dominant}
 
-    # forward-only rate (operator-level `rasterization` under no_grad: the viewer / eval path)
-    with torch.no_grad():
-        for _ in range(3):
-            runner.rasterize_splats(c2w, Ks, W, H, sh_degree=3, near_plane=cfg.near_plane, far_plane=cfg.far_plane)
-        barrier()
-        t0 = time.time()
-        for _ in range(20):
-            runner.rasterize_splats(c2w, Ks, W, H, sh_degree=3, near_plane=cfg.near_plane, far_plane=cfg.far_plane)
-        barrier()
-        fwd_s = (time.time() - t0) / 20
+    # forward-only rate: the eval / viewer render (projection + SH + binning + sort + rasterise)
+    if fused:
+        eng = runner._engine
+        fwd_call = eng.render
+    else:
+        def fwd_call():
+            with torch.no_grad():
+                runner.rasterize_splats(c2w, Ks, W, H, sh_degree=3, near_plane=cfg.near_plane, far_plane=cfg.far_plane)
+    for _ in range(5):
+        fwd_call()
+    barrier()
+    t0 = time.time()
+    for _ in range(50):
+        fwd_call()
+    barrier()
+    fwd_s = (time.time() - t0) / 50
     _lib.profile_summary()  # discard
 
     # timed region: EXACTLY --steps iterations between barriers

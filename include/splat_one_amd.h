@@ -297,6 +297,9 @@ typedef struct so_step_desc {
   float eps2d, near_plane, far_plane, radius_clip, ssim_lambda, opacity_reg, scale_reg;
 } so_step_desc;
 int so_train_step_fwd_bwd(const so_step_desc *desc, void *stream);
+/* the forward stages only (preprocess, binning, sort, rasterise) on the same descriptor: the eval /
+ * viewer render of gsplat_trainer.py:779-940; pixels, loss and gradient buffers are not touched */
+int so_render_forward(const so_step_desc *desc, void *stream);
 
 /* Per-stage HIP-event timing of so_train_step_fwd_bwd / so_adam_step_dev on their launch stream
  * (measurement only, not thread-safe; events cannot be recorded inside a hipGraph replay, so

@@ -68,6 +68,7 @@ _SIGS = {
     "so_debug_rasterize_bwd_wave_stamps": [c_int] * 4 + [c_ptr] * 10 + [c_int, c_ptr],
     "so_rasterize_bwd_packed": [c_int] * 5 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 5 + [c_int, c_ptr],
     "so_train_step_fwd_bwd": [ctypes.POINTER(StepDesc), c_ptr],
+    "so_render_forward": [ctypes.POINTER(StepDesc), c_ptr],
     "so_profile_enable": [c_int],
     "so_profile_read": [ctypes.POINTER(c_f32), ctypes.POINTER(c_int)],
     "so_adam_step_dev": [c_int, ctypes.POINTER(AdamGroup), ctypes.POINTER(c_f32), ctypes.POINTER(c_f32),

@@ -85,7 +85,15 @@ extern "C" void so_profile_stage_begin_end(int stage, int begin, void *stream) {
   else if (cur) { delete cur; cur = nullptr; }
 }
 
-extern "C" int so_train_step_fwd_bwd(const so_step_desc *d, void *stream) {
+static int step_impl(const so_step_desc *d, void *stream, bool forward_only);
+
+extern "C" int so_train_step_fwd_bwd(const so_step_desc *d, void *stream) { return step_impl(d, stream, false); }
+
+// Forward only (render_colors / render_alphas / last_ids of the current views): the eval / viewer
+// path of gsplat_trainer.py:779-940 on the same static buffers, also hipGraph-capturable.
+extern "C" int so_render_forward(const so_step_desc *d, void *stream) { return step_impl(d, stream, true); }
+
+static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
   SO_REQUIRE(d != nullptr, "so_train_step_fwd_bwd: null descriptor");
   SO_REQUIRE(d->abi_size == (int32_t)sizeof(so_step_desc), "so_train_step_fwd_bwd: descriptor size %d != %d (ABI mismatch)",
              d->abi_size, (int)sizeof(so_step_desc));
@@ -120,6 +128,7 @@ extern "C" int so_train_step_fwd_bwd(const so_step_desc *d, void *stream) {
   else
     SO_STAGE(3, so_rasterize_fwd_packed(C, N, W, H, ts, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects,
                                         0, d->render_colors, d->render_alphas, d->last_ids, stream));
+  if (forward_only) return SO_OK;
   // loss = (1-l) * mean|.| + l * (1 - mean SSIM_valid)
   SO_STAGE(4, so_ssim_l1_fwd(C, H, W, 3, d->render_colors, d->pixels, 1, d->loss_sums, d->dmaps, stream));
   const float n_l1 = (float)C * H * W * 3.f, n_ss = (float)C * 3.f * (float)(H - 10) * (float)(W - 10);

@@ -182,6 +182,24 @@ class FusedEngine:
         _lib.call("so_adam_step_dev", n, arr, lr0, gam, float(betas[0]), float(betas[1]), float(eps),
                   _lib.ptr(self._step_dev), 0, _lib.stream())
 
+    def set_cameras(self, camtoworlds: Tensor, Ks: Tensor) -> None:
+        """Cameras only (forward-only rendering needs no target image)."""
+        assert camtoworlds.shape == (self.C, 4, 4) and Ks.shape == (self.C, 3, 3), (camtoworlds.shape, Ks.shape)
+        if camtoworlds.is_cuda:
+            c2w = camtoworlds.detach().to(torch.float32).contiguous()
+            _lib.call("so_camera_inverse", self.C, _lib.ptr(c2w), _lib.ptr(self.ws["viewmats"]), _lib.stream())
+        else:
+            vm = torch.linalg.inv(camtoworlds.detach().to(torch.float64)).to(torch.float32)
+            self.ws["viewmats"].copy_(vm, non_blocking=True)
+        self.ws["Ks"].copy_(Ks, non_blocking=True)
+
+    def render(self):
+        """Forward only on the current cameras: returns (render_colors[C,H,W,3], render_alphas[C,H,W,1])
+        -- views of the static buffers, valid until the next call (the eval / viewer path)."""
+        d = self._desc()
+        _lib.call("so_render_forward", ctypes.byref(d), _lib.stream())
+        return self.ws["render_colors"], self.ws["render_alphas"]
+
     def fwd_bwd(self) -> None:
         """Render -> loss -> backward on the current static inputs; gradients land in `.grad`."""
         self._launch_fwd_bwd()

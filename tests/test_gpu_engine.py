@@ -121,3 +121,15 @@ def test_engine_training_steps_match_runner_and_graph_replay(dev):
         # graph replay is the same launches as the eager engine: equal up to atomic ordering
         assert rel_err(outs[2][k], outs[1][k]) < 1e-5, k
         assert rel_err(outs[1][k], outs[0][k]) < 1e-3, k
+
+
+def test_engine_render_forward_matches_operator_path(dev):
+    from splat_one_amd.engine import FusedEngine
+    N, W, H = 5000, 128, 96
+    r, c2w, Ks, pixels = _make(dev, N, W, H, "mcmc", C=2)
+    eng = FusedEngine(r.splats, r.optimizers, W, H, 2, sh_degree=3, use_graph=False)
+    eng.set_cameras(c2w, Ks)
+    rc, ra = eng.render()
+    with torch.no_grad():
+        rc2, ra2, _ = r.rasterize_splats(c2w, Ks, W, H, sh_degree=3, near_plane=0.01, far_plane=1e8)
+    assert (rc - rc2).abs().max().item() < 1e-5 and (ra - ra2).abs().max().item() < 1e-5
