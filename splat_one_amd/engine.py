@@ -52,6 +52,9 @@ class FusedEngine:
         self._capacity_hint = isect_capacity
         self._graph: Optional[torch.cuda.CUDAGraph] = None
         self._graph_key = None
+        self._graph_fb: Optional[torch.cuda.CUDAGraph] = None
+        self._graph_opt: Optional[torch.cuda.CUDAGraph] = None
+        self._graph_fb_key = None
         self.steps_done = 0
         self._step_dev = torch.zeros(2 + 4 * _lib.SO_ADAM_MAX_GROUPS, dtype=torch.int32, device=self.device)
         self._build_workspace()
@@ -103,6 +106,7 @@ class FusedEngine:
                 if self.strategy_state.get(k) is None or self.strategy_state[k].shape[0] != N:
                     self.strategy_state[k] = torch.zeros(N, device=dev)
         self._graph = None
+        self._graph_fb = self._graph_opt = None
 
     def _desc(self) -> _lib.StepDesc:
         w, s, c = self.ws, self.splats, self.cfg
@@ -201,12 +205,46 @@ class FusedEngine:
         return self.ws["render_colors"], self.ws["render_alphas"]
 
     def fwd_bwd(self) -> None:
-        """Render -> loss -> backward on the current static inputs; gradients land in `.grad`."""
-        self._launch_fwd_bwd()
+        """Render -> loss -> backward on the current static inputs; gradients land in `.grad`
+        (data-parallel runs all-reduce `ws["grads_flat"]` between this and `optimize`).  Replayed from
+        its own hipGraph when `use_graph`."""
+        if not self.use_graph:
+            self._launch_fwd_bwd()
+            return
+        key = (self.N, self.cfg["sh_degree"], id(self.ws), self.strategy_state is not None)
+        if self._graph_fb is None or self._graph_fb_key != key:
+            self._capture_split(key)
+        self._graph_fb.replay()
 
     def optimize(self) -> None:
-        self._launch_optimize()
+        if self.use_graph and self._graph_opt is not None:
+            self._graph_opt.replay()
+        else:
+            self._launch_optimize()
         self._advance_host_counters()
+
+    def _capture_split(self, key) -> None:
+        """Two graphs (fwd+bwd | Adam) so that a collective can run between them."""
+        self._adam_args()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            st = self.strategy_state
+            saved = [st[k].clone() for k in ("grad2d", "count")] if st is not None else None
+            self._launch_fwd_bwd()
+            if saved is not None:
+                st["grad2d"].copy_(saved[0])
+                st["count"].copy_(saved[1])
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            self._launch_fwd_bwd()
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            self._launch_optimize()
+        self._graph_fb, self._graph_opt, self._graph_fb_key = g1, g2, key
 
     def _advance_host_counters(self) -> None:
         self.steps_done += 1
@@ -253,6 +291,7 @@ class FusedEngine:
         if deg != self.cfg["sh_degree"]:
             self.cfg["sh_degree"] = deg
             self._graph = None
+            self._graph_fb = self._graph_opt = None
 
     def rebuild(self) -> None:
         """Call after the Gaussian set changed (densification rewrote params/optimiser state)."""

@@ -206,7 +206,7 @@ class Runner:
                 near_plane=cfg.near_plane, far_plane=cfg.far_plane, antialiased=cfg.antialiased, absgrad=s.absgrad,
                 ssim_lambda=cfg.ssim_lambda, opacity_reg=cfg.opacity_reg, scale_reg=cfg.scale_reg,
                 strategy_state=self.strategy_state, lr_gamma_means=self.lr_gamma,
-                isect_capacity=cfg.isect_capacity, use_graph=(self.world_size == 1),
+                isect_capacity=cfg.isect_capacity, use_graph=True,
                 raster_impl=getattr(self, "raster_impl", 0))
             eng.steps_done = step
             eng._step_dev[0] = step
@@ -216,6 +216,7 @@ class Runner:
         if stats_on != (eng.strategy_state is not None):
             eng.strategy_state = self.strategy_state if stats_on else None
             eng._graph = None
+            eng._graph_fb = eng._graph_opt = None
         eng.set_views(camtoworlds, Ks, pixels)
         if self.world_size == 1:
             eng.step()
