@@ -312,6 +312,19 @@ int so_profile_read(float *host_ms_sum, int *host_calls);
 void so_profile_stage_begin_end(int stage, int begin, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * MCMC densification strategy (the reference's `mcmc` preset, gsplat_trainer.py:975-983, :753-761).
+ * so_compute_relocation replaces gsplat `compute_relocation` (K13): for a Gaussian split `ratios[i]`
+ *   ways, new_opacity = 1-(1-o)^(1/n) and new_scale = s * o / sum_{i<=n} sum_{k<i} C(i-1,k)(-1)^k
+ *   new_opacity^(k+1)/sqrt(k+1); binoms[n_max,n_max] f32, ratios clamped to [1,n_max].
+ * so_inject_noise replaces `inject_noise_to_position`: means += Sigma (noise * sig(1-opacity) * scaler)
+ *   on the RAW parameters (log scales, logit opacities), sig(x) = 1/(1+exp(-100(x-0.995))).
+ * ---------------------------------------------------------------------------------------- */
+int so_compute_relocation(int64_t N, const float *opacities, const float *scales, const int32_t *ratios,
+                          const float *binoms, int n_max, float *new_opacities, float *new_scales, void *stream);
+int so_inject_noise(int64_t N, float *means, const float *log_scales, const float *quats,
+                    const float *logit_opacities, const float *noise, float scaler, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Photometric loss.  Replaces F.l1_loss + the CUDA-only `fused_ssim(..., padding="valid")` of
  * gsplat_trainer.py:624-628 with one forward and one backward kernel on the rasteriser's own
  * channel-last layout.  SSIM: 11x11 Gaussian window (sigma 1.5), C1=0.01^2, C2=0.03^2.

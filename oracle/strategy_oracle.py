@@ -44,3 +44,34 @@ def refine_masks(grad2d, count, log_scales, opac_logits, step, scene_scale, grow
         return torch.tensor(out)
 
     return torch.tensor(dup), torch.tensor(spl), prune
+
+
+# ------------------------------------------------------------------------------------------------
+# MCMC strategy (Kheradmand et al. 2024, "3D Gaussian Splatting as Markov Chain Monte Carlo", eq. 9;
+# reached through the reference's `mcmc` preset, gsplat_trainer.py:975-983 and :753-761)
+# ------------------------------------------------------------------------------------------------
+def compute_relocation(opacities, scales, ratios, n_max=51):
+    """Plain loops in float64: opacity and scale of a Gaussian split `ratio` ways."""
+    N = opacities.shape[0]
+    new_op = torch.zeros(N, dtype=torch.float64)
+    new_sc = torch.zeros(N, 3, dtype=torch.float64)
+    for i in range(N):
+        n = int(min(max(int(ratios[i]), 1), n_max))
+        o = float(opacities[i])
+        no = 1.0 - (1.0 - o) ** (1.0 / n)
+        denom = 0.0
+        for a in range(1, n + 1):
+            for k in range(a):
+                denom += math.comb(a - 1, k) * ((-1.0) ** k) / math.sqrt(k + 1) * no ** (k + 1)
+        new_op[i] = no
+        new_sc[i] = scales[i].double() * (o / denom)
+    return new_op, new_sc
+
+
+def inject_noise(means, log_scales, quats, logit_opac, noise, scaler):
+    """means + Sigma (noise * sigmoid_100((1-opacity) - 0.995) * scaler) in float64."""
+    from oracle.torch_oracle import quat_scale_to_covar
+    cov = quat_scale_to_covar(quats.double(), torch.exp(log_scales.double()))
+    op = torch.sigmoid(logit_opac.double())
+    g = 1.0 / (1.0 + torch.exp(-100.0 * ((1.0 - op) - 0.995)))
+    return means.double() + torch.einsum("bij,bj->bi", cov, noise.double() * g[:, None] * scaler)

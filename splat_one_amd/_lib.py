@@ -73,6 +73,8 @@ _SIGS = {
     "so_profile_read": [ctypes.POINTER(c_f32), ctypes.POINTER(c_int)],
     "so_adam_step_dev": [c_int, ctypes.POINTER(AdamGroup), ctypes.POINTER(c_f32), ctypes.POINTER(c_f32),
                          ctypes.c_double, ctypes.c_double, ctypes.c_double, c_ptr, c_int, c_ptr],
+    "so_compute_relocation": [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr],
+    "so_inject_noise": [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr],
     "so_adam_step": [c_int, ctypes.POINTER(AdamGroup), ctypes.c_double, ctypes.c_double, ctypes.c_double, c_int, c_ptr],
 }
 

@@ -142,6 +142,120 @@ def reset_opa(params, optimizers, state: Dict[str, Tensor], value: float) -> Non
 
 
 # ---------------------------------------------------------------------------------------------
+# MCMC operations (gsplat.strategy.ops: relocate / sample_add / inject_noise_to_position)
+# ---------------------------------------------------------------------------------------------
+def _multinomial_sample(weights: Tensor, n: int, replacement: bool = True,
+                        generator: Optional[torch.Generator] = None) -> Tensor:
+    num_elements = weights.size(0)
+    if num_elements <= 2 ** 24:
+        return torch.multinomial(weights, n, replacement=replacement, generator=generator)
+    weights = weights / weights.sum()          # torch.multinomial is limited to 2^24 categories
+    cdf = torch.cumsum(weights, dim=0)
+    u = torch.rand(n, device=weights.device, generator=generator)
+    return torch.searchsorted(cdf, u).clamp_max(num_elements - 1)
+
+
+@torch.no_grad()
+def compute_relocation(opacities: Tensor, scales: Tensor, ratios: Tensor, binoms: Tensor) -> Tuple[Tensor, Tensor]:
+    """Equation (9) of 3DGS-MCMC: opacities[N], scales[N,3], ratios[N] int, binoms[n_max,n_max] ->
+    (new_opacities[N], new_scales[N,3]).  HIP kernel `so_compute_relocation` (gsplat K13)."""
+    from . import _lib
+    N = opacities.shape[0]
+    n_max = binoms.shape[0]
+    assert scales.shape == (N, 3) and ratios.shape == (N,) and binoms.shape == (n_max, n_max)
+    opacities = opacities.contiguous().float()
+    scales = scales.contiguous().float()
+    ratios = ratios.clamp(min=1, max=n_max).int().contiguous()
+    binoms = binoms.contiguous().float()
+    new_opacities = torch.empty_like(opacities)
+    new_scales = torch.empty_like(scales)
+    _lib.call("so_compute_relocation", N, _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(ratios), _lib.ptr(binoms),
+              n_max, _lib.ptr(new_opacities), _lib.ptr(new_scales), _lib.stream())
+    return new_opacities, new_scales
+
+
+@torch.no_grad()
+def relocate(params, optimizers, state: Dict[str, Tensor], mask: Tensor, binoms: Tensor, min_opacity: float = 0.005,
+             generator: Optional[torch.Generator] = None) -> None:
+    """Teleport the dead Gaussians (mask) onto alive ones sampled proportionally to opacity."""
+    opacities = torch.sigmoid(params["opacities"])
+    dead_indices = mask.nonzero(as_tuple=True)[0]
+    alive_indices = (~mask).nonzero(as_tuple=True)[0]
+    n = len(dead_indices)
+    eps = torch.finfo(torch.float32).eps
+    probs = opacities[alive_indices].flatten()
+    sampled_idxs = alive_indices[_multinomial_sample(probs, n, replacement=True, generator=generator)]
+    new_opacities, new_scales = compute_relocation(
+        opacities=opacities[sampled_idxs], scales=torch.exp(params["scales"])[sampled_idxs],
+        ratios=torch.bincount(sampled_idxs)[sampled_idxs] + 1, binoms=binoms)
+    new_opacities = torch.clamp(new_opacities, max=1.0 - eps, min=min_opacity)
+
+    def param_fn(name: str, p: Tensor) -> Tensor:
+        p = p.detach().clone()
+        if name == "opacities":
+            p[sampled_idxs] = torch.logit(new_opacities)
+        elif name == "scales":
+            p[sampled_idxs] = torch.log(new_scales)
+        p[dead_indices] = p[sampled_idxs]
+        return torch.nn.Parameter(p)
+
+    def optimizer_fn(key: str, v: Tensor) -> Tensor:
+        v[sampled_idxs] = 0
+        return v
+
+    _update_param_with_optimizer(param_fn, optimizer_fn, params, optimizers)
+    for k, v in state.items():
+        if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == mask.shape[0]:
+            v[sampled_idxs] = 0
+
+
+@torch.no_grad()
+def sample_add(params, optimizers, state: Dict[str, Tensor], n: int, binoms: Tensor, min_opacity: float = 0.005,
+               generator: Optional[torch.Generator] = None) -> None:
+    """Add n Gaussians as copies of ones sampled proportionally to opacity (both get the relocated
+    opacity / scale)."""
+    opacities = torch.sigmoid(params["opacities"])
+    n_before = opacities.shape[0]
+    eps = torch.finfo(torch.float32).eps
+    probs = opacities.flatten()
+    sampled_idxs = _multinomial_sample(probs, n, replacement=True, generator=generator)
+    new_opacities, new_scales = compute_relocation(
+        opacities=opacities[sampled_idxs], scales=torch.exp(params["scales"])[sampled_idxs],
+        ratios=torch.bincount(sampled_idxs)[sampled_idxs] + 1, binoms=binoms)
+    new_opacities = torch.clamp(new_opacities, max=1.0 - eps, min=min_opacity)
+
+    def param_fn(name: str, p: Tensor) -> Tensor:
+        p = p.detach().clone()
+        if name == "opacities":
+            p[sampled_idxs] = torch.logit(new_opacities)
+        elif name == "scales":
+            p[sampled_idxs] = torch.log(new_scales)
+        return torch.nn.Parameter(torch.cat([p, p[sampled_idxs]]))
+
+    def optimizer_fn(key: str, v: Tensor) -> Tensor:
+        v_new = torch.zeros((len(sampled_idxs), *v.shape[1:]), device=v.device, dtype=v.dtype)
+        return torch.cat([v, v_new])
+
+    _update_param_with_optimizer(param_fn, optimizer_fn, params, optimizers)
+    for k, v in state.items():
+        if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == n_before:
+            v_new = torch.zeros((len(sampled_idxs), *v.shape[1:]), device=v.device, dtype=v.dtype)
+            state[k] = torch.cat((v, v_new))
+
+
+@torch.no_grad()
+def inject_noise_to_position(params, optimizers, state: Dict[str, Tensor], scaler: float,
+                             generator: Optional[torch.Generator] = None) -> None:
+    """means += Sigma (N(0,I) * sigmoid_100(0.005 - opacity) * scaler): one HIP kernel on the raw parameters."""
+    from . import _lib
+    means = params["means"]
+    noise = torch.randn(means.shape, device=means.device, dtype=means.dtype, generator=generator)
+    _lib.call("so_inject_noise", means.shape[0], _lib.ptr(means.data), _lib.ptr(params["scales"].data.contiguous()),
+              _lib.ptr(params["quats"].data.contiguous()), _lib.ptr(params["opacities"].data.flatten().contiguous()),
+              _lib.ptr(noise), float(scaler), _lib.stream())
+
+
+# ---------------------------------------------------------------------------------------------
 # strategies
 # ---------------------------------------------------------------------------------------------
 @dataclass
@@ -273,3 +387,66 @@ class DefaultStrategy(Strategy):
         if n_prune > 0:
             remove(params=params, optimizers=optimizers, state=state, mask=is_prune)
         return n_prune
+
+
+@dataclass
+class MCMCStrategy(Strategy):
+    """3D Gaussian Splatting as Markov Chain Monte Carlo (Kheradmand et al. 2024) with gsplat's
+    defaults -- the strategy of the reference's `mcmc` preset (gsplat_trainer.py:975-983), driven with
+    `lr=` the current means learning rate (:753-761).  Use with opacity_reg / scale_reg = 0.01."""
+    cap_max: int = 1_000_000
+    noise_lr: float = 5e5
+    refine_start_iter: int = 500
+    refine_stop_iter: int = 25_000
+    refine_every: int = 100
+    min_opacity: float = 0.005
+    verbose: bool = False
+
+    def initialize_state(self) -> Dict[str, Any]:
+        import math
+        n_max = 51
+        binoms = torch.zeros((n_max, n_max))
+        for n in range(n_max):
+            for k in range(n + 1):
+                binoms[n, k] = math.comb(n, k)
+        return {"binoms": binoms}
+
+    def check_sanity(self, params, optimizers) -> None:
+        super().check_sanity(params, optimizers)
+        for key in ["means", "scales", "quats", "opacities"]:
+            assert key in params, f"{key} is required in params but missing."
+
+    def step_post_backward(self, params, optimizers, state: Dict[str, Any], step: int, info: Dict[str, Any],
+                           lr: float, generator: Optional[torch.Generator] = None) -> Tuple[int, int]:
+        state["binoms"] = state["binoms"].to(params["means"].device)
+        binoms = state["binoms"]
+        n_relocated = n_new = 0
+        if step < self.refine_stop_iter and step > self.refine_start_iter and step % self.refine_every == 0:
+            n_relocated = self._relocate_gs(params, optimizers, binoms, generator)
+            n_new = self._add_new_gs(params, optimizers, binoms, generator)
+            if self.verbose:
+                print(f"Step {step}: Relocated {n_relocated} GSs. Added {n_new} GSs. "
+                      f"Now having {len(params['means'])} GSs.")
+        inject_noise_to_position(params=params, optimizers=optimizers, state={}, scaler=lr * self.noise_lr,
+                                 generator=generator)
+        return n_relocated, n_new
+
+    @torch.no_grad()
+    def _relocate_gs(self, params, optimizers, binoms: Tensor, generator=None) -> int:
+        opacities = torch.sigmoid(params["opacities"].flatten())
+        dead_mask = opacities <= self.min_opacity
+        n_gs = int(dead_mask.sum().item())
+        if n_gs > 0:
+            relocate(params=params, optimizers=optimizers, state={}, mask=dead_mask, binoms=binoms,
+                     min_opacity=self.min_opacity, generator=generator)
+        return n_gs
+
+    @torch.no_grad()
+    def _add_new_gs(self, params, optimizers, binoms: Tensor, generator=None) -> int:
+        current_n_points = len(params["means"])
+        n_target = min(self.cap_max, int(1.05 * current_n_points))
+        n_gs = max(0, n_target - current_n_points)
+        if n_gs > 0:
+            sample_add(params=params, optimizers=optimizers, state={}, n=n_gs, binoms=binoms,
+                       min_opacity=self.min_opacity, generator=generator)
+        return n_gs

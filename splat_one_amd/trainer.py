@@ -30,7 +30,7 @@ from .losses import photometric_loss
 from .optimizers import FusedAdam, SelectiveAdam, step_all
 from .rendering import rasterization
 from .scene import knn, rgb_to_sh, set_random_seed
-from .strategy import DefaultStrategy
+from .strategy import DefaultStrategy, MCMCStrategy
 
 
 @dataclass
@@ -49,7 +49,7 @@ class Config:
     ssim_lambda: float = 0.2
     near_plane: float = 0.01
     far_plane: float = 1e8
-    strategy: DefaultStrategy = field(default_factory=DefaultStrategy)
+    strategy: Union[DefaultStrategy, MCMCStrategy] = field(default_factory=DefaultStrategy)
     packed: bool = False
     sparse_grad: bool = False
     visible_adam: bool = False
@@ -73,6 +73,10 @@ class Config:
             s.refine_start_iter = int(s.refine_start_iter * factor)
             s.refine_stop_iter = int(s.refine_stop_iter * factor)
             s.reset_every = int(s.reset_every * factor)
+            s.refine_every = int(s.refine_every * factor)
+        elif isinstance(s, MCMCStrategy):
+            s.refine_start_iter = int(s.refine_start_iter * factor)
+            s.refine_stop_iter = int(s.refine_stop_iter * factor)
             s.refine_every = int(s.refine_every * factor)
 
 
@@ -152,7 +156,10 @@ class Runner:
             batch_size=cfg.batch_size, device=self.device, world_rank=world_rank, world_size=world_size,
             shN_init_std=cfg.shN_init_std)
         self.cfg.strategy.check_sanity(self.splats, self.optimizers)
-        self.strategy_state = self.cfg.strategy.initialize_state(scene_scale=self.scene_scale)
+        if isinstance(self.cfg.strategy, MCMCStrategy):
+            self.strategy_state = self.cfg.strategy.initialize_state()           # gsplat_trainer.py:351-352
+        else:
+            self.strategy_state = self.cfg.strategy.initialize_state(scene_scale=self.scene_scale)
         self.means_lr0 = self.optimizers["means"].param_groups[0]["lr"]
         self.lr_gamma = 0.01 ** (1.0 / cfg.max_steps)                     # ExponentialLR, :512-516
         self.step = 0
@@ -192,8 +199,11 @@ class Runner:
     # ------------------------------------------------------------------------------ fused fast path
     def _fused_ok(self, masks) -> bool:
         c = self.cfg
-        return (c.fused and masks is None and not c.random_bkgd and not c.visible_adam and not c.packed
-                and isinstance(c.strategy, DefaultStrategy) and c.strategy.refine_scale2d_stop_iter == 0)
+        if not (c.fused and masks is None and not c.random_bkgd and not c.visible_adam and not c.packed):
+            return False
+        if isinstance(c.strategy, DefaultStrategy):
+            return c.strategy.refine_scale2d_stop_iter == 0
+        return isinstance(c.strategy, MCMCStrategy)
 
     def _train_step_fused(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor) -> Tensor:
         from .engine import FusedEngine
@@ -203,16 +213,18 @@ class Runner:
         if eng is None or (eng.C, eng.H, eng.W) != (B, H, W):
             eng = self._engine = FusedEngine(
                 self.splats, self.optimizers, W, H, B, sh_degree=0, camera_model=cfg.camera_model,
-                near_plane=cfg.near_plane, far_plane=cfg.far_plane, antialiased=cfg.antialiased, absgrad=s.absgrad,
+                near_plane=cfg.near_plane, far_plane=cfg.far_plane, antialiased=cfg.antialiased,
+                absgrad=getattr(s, "absgrad", False),
                 ssim_lambda=cfg.ssim_lambda, opacity_reg=cfg.opacity_reg, scale_reg=cfg.scale_reg,
-                strategy_state=self.strategy_state, lr_gamma_means=self.lr_gamma,
+                strategy_state=(self.strategy_state if isinstance(s, DefaultStrategy) else None),
+                lr_gamma_means=self.lr_gamma,
                 isect_capacity=cfg.isect_capacity, use_graph=True,
                 raster_impl=getattr(self, "raster_impl", 0))
             eng.steps_done = step
             eng._step_dev[0] = step
         eng.set_sh_degree(min(step // cfg.sh_degree_interval, cfg.sh_degree))
         # densification statistics are accumulated inside the backward kernel while refinement is active
-        stats_on = step < s.refine_stop_iter
+        stats_on = isinstance(s, DefaultStrategy) and step < s.refine_stop_iter
         if stats_on != (eng.strategy_state is not None):
             eng.strategy_state = self.strategy_state if stats_on else None
             eng._graph = None
@@ -224,6 +236,19 @@ class Runner:
             eng.fwd_bwd()
             sdist.all_reduce_mean_(eng.ws["grads_flat"])     # ONE collective on the flat gradient SoA
             eng.optimize()
+        if isinstance(s, MCMCStrategy):
+            # lr = the means learning rate after this step's scheduler.step() (gsplat_trainer.py:753-761)
+            n_before = len(self.splats["means"])
+            n_rel, n_new = s.step_post_backward(params=self.splats, optimizers=self.optimizers,
+                                                state=self.strategy_state, step=step, info={},
+                                                lr=self.optimizers["means"].param_groups[0]["lr"],
+                                                generator=self._split_gen)
+            if n_rel or n_new:
+                eng.rebuild()
+            self.last_info = {"radii": eng.ws["radii"], "n_isects": eng.ws["counters"][2 * eng.M + 1:2 * eng.M + 2],
+                              "flatten_ids": eng.ws["flatten_ids"], "means2d": eng.ws["means2d"]}
+            self.step += 1
+            return eng.loss()[0]
         refine_now = (step < s.refine_stop_iter and step > s.refine_start_iter and step % s.refine_every == 0
                       and step % s.reset_every >= s.pause_refine_after_reset)
         reset_now = step < s.refine_stop_iter and step % s.reset_every == 0 and step > 0
@@ -296,6 +321,10 @@ class Runner:
             else:
                 s.step_post_backward(params=self.splats, optimizers=self.optimizers, state=self.strategy_state,
                                      step=step, info=info, packed=cfg.packed, generator=self._split_gen)
+        elif isinstance(s, MCMCStrategy):
+            s.step_post_backward(params=self.splats, optimizers=self.optimizers, state=self.strategy_state, step=step,
+                                 info=info, lr=self.optimizers["means"].param_groups[0]["lr"],
+                                 generator=self._split_gen)
         self.last_info = info
         self.step += 1
         return loss.detach()
