@@ -1,0 +1,13 @@
+"""Input side of the hot path: OpenSfM reconstruction parsing,
+world normalisation and render trajectories.  Host-side numpy; see the module docstrings for the
+reference lines each function follows."""
+from .normalize import (align_principle_axes, normalize, similarity_from_cameras, transform_cameras,
+                        transform_points)
+from .opensfm import Dataset, Parser, read_opensfm, read_opensfm_points3D
+from .traj import (generate_ellipse_path_y, generate_ellipse_path_z, generate_interpolated_path,
+                   generate_spiral_path, viewmatrix)
+
+__all__ = ["Parser", "Dataset", "read_opensfm", "read_opensfm_points3D", "normalize",
+           "similarity_from_cameras", "align_principle_axes", "transform_cameras", "transform_points",
+           "viewmatrix", "generate_ellipse_path_z", "generate_ellipse_path_y", "generate_interpolated_path",
+           "generate_spiral_path"]

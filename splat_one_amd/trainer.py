@@ -9,8 +9,14 @@
 
 Same names, argument meaning and step order, so `app/gsplat_manager.py` style callers
 (`Runner(local_rank, world_rank, world_size, cfg)`, `.train()`, `.rasterize_splats(...)`) read the
-same.  Out of scope here: dataset parsers, viewer, TensorBoard, eval,
-compression, pose/appearance/bilateral-grid modules.
+same.  The callers either side of the loop are here too:
+    Runner.from_data_dir          :308-324  Parser/Dataset wiring (splat_one_amd.datasets)
+    save / load checkpoints       :682-703, :950-957   ckpt_{step}_rank{r}.pt = {"step", "splats"}
+    Runner.eval                   :779-838  PSNR + SSIM over the val split (LPIPS needs downloaded weights)
+    Runner.render_traj            :841-901  interp / ellipse / spiral paths, RGB | normalised depth canvas
+    Runner._viewer_render_fn      :916-944  one frame for an interactive viewer
+Out of scope: the viewer itself, TensorBoard, compression,
+pose/appearance/bilateral-grid modules, video encoding (frames are returned / written as PNG).
 
 Multi-GPU: view-sharded data parallelism (splat_one_amd.distributed), not the reference's
 Gaussian sharding; the random init is therefore NOT strided over ranks (every rank holds all
@@ -59,6 +65,18 @@ class Config:
     scale_reg: float = 0.0
     global_scale: float = 1.0
     camera_model: str = "pinhole"   # reference default "spherical" is fork-only (no specification)
+    # data / results (gsplat_trainer.py:67-104): consumed by Runner.from_data_dir, eval, render_traj, checkpoints
+    ckpt: Optional[List[str]] = None
+    render_traj_path: str = "interp"
+    data_dir: str = "data_dir"
+    data_factor: int = 4
+    result_dir: str = "results/"
+    test_every: int = 8
+    patch_size: Optional[int] = None
+    normalize_world_space: bool = True
+    eval_steps: List[int] = field(default_factory=lambda: [7_000, 30_000])
+    save_steps: List[int] = field(default_factory=lambda: [7_000, 30_000])
+    depth_loss: bool = False        # accepted for the Dataset's placeholder depths; the loss term is out of scope
     # extensions of this build
     isect_capacity: Optional[int] = None   # preallocated intersections -> no host sync in the step
     fused: bool = False                    # FusedEngine: whole step in two C-ABI calls, hipGraph replay
@@ -66,6 +84,8 @@ class Config:
 
     def adjust_steps(self, factor: float):
         """gsplat_trainer.py:184-201"""
+        self.eval_steps = [int(i * factor) for i in self.eval_steps]
+        self.save_steps = [int(i * factor) for i in self.save_steps]
         self.max_steps = int(self.max_steps * factor)
         self.sh_degree_interval = int(self.sh_degree_interval * factor)
         s = self.strategy
@@ -147,7 +167,7 @@ class Runner:
         self.cfg = cfg
         self.world_rank, self.local_rank, self.world_size = world_rank, local_rank, world_size
         self.device = f"cuda:{local_rank}"
-        self.views = views or []
+        self.views = views if views is not None else []
         self.scene_scale = scene_scale * 1.1 * cfg.global_scale          # gsplat_trainer.py:322
         self.splats, self.optimizers = create_splats_with_optimizers(
             points, rgbs, init_type=cfg.init_type, init_num_pts=cfg.init_num_pts, init_extent=cfg.init_extent,
@@ -169,6 +189,195 @@ class Runner:
         self._split_gen = torch.Generator(device=self.device)
         self._split_gen.manual_seed(1234)                                 # same on every rank
         self.last_info: Optional[dict] = None
+
+    # ------------------------------------------------------------------------------ :308-324
+    @classmethod
+    def from_data_dir(cls, local_rank: int, world_rank: int, world_size: int, cfg: Config) -> "Runner":
+        """The reference's constructor path: parse cfg.data_dir, split train/val, take scene_scale and
+        (init_type "sfm") the point cloud from the parser."""
+        from .datasets import Dataset, Parser
+        parser = Parser(data_dir=cfg.data_dir, factor=cfg.data_factor, normalize=cfg.normalize_world_space,
+                        test_every=cfg.test_every)
+        types = {parser.camtype_dict[c] for c in parser.camera_ids}
+        if types != {"perspective"}:
+            raise NotImplementedError(f"camera types {sorted(types)}: only perspective shots can be rasterised "
+                                      "(the fork's spherical camera model has no specification)")
+        trainset = Dataset(parser, split="train", patch_size=cfg.patch_size, load_depths=cfg.depth_loss)
+        points = rgbs = None
+        if cfg.init_type == "sfm":
+            points = torch.from_numpy(parser.points).float()
+            rgbs = torch.from_numpy(parser.points_rgb / 255.0).float()
+        self = cls(local_rank, world_rank, world_size, cfg, views=trainset, scene_scale=parser.scene_scale,
+                   points=points, rgbs=rgbs)
+        self.parser = parser
+        self.trainset = trainset
+        self.valset = Dataset(parser, split="val")
+        self.allset = Dataset(parser, split="all")
+        return self
+
+    def _result_dirs(self):
+        import os
+        d = self.cfg.result_dir.rstrip("/")
+        out = {k: f"{d}/{k}" for k in ("ckpts", "stats", "renders", "videos")}
+        for v in out.values():
+            os.makedirs(v, exist_ok=True)
+        return out
+
+    # ------------------------------------------------------------------------------ :682-703
+    def save_checkpoint(self, step: Optional[int] = None) -> str:
+        """{result_dir}/ckpts/ckpt_{step}_rank{world_rank}.pt holding {"step", "splats"}; readable by the
+        reference's `main` (:950-957) and by `load_checkpoints`."""
+        step = self.step - 1 if step is None else step
+        path = f"{self._result_dirs()['ckpts']}/ckpt_{step}_rank{self.world_rank}.pt"
+        torch.save({"step": step, "splats": self.splats.state_dict()}, path)
+        return path
+
+    def load_checkpoints(self, files: List[str]) -> int:
+        """Concatenate the per-rank shards of a run (:950-957) into this runner's splats; optimiser state
+        is rebuilt empty, as the reference's evaluation-only path leaves it.  Returns the stored step."""
+        ckpts = [torch.load(f, map_location=self.device, weights_only=True) for f in files]
+        if not ckpts:
+            raise ValueError("no checkpoint files given")
+        keys = set(self.splats.keys())
+        for c in ckpts:
+            if set(c["splats"].keys()) != keys:
+                raise KeyError(f"checkpoint holds {sorted(c['splats'].keys())}, runner expects {sorted(keys)}")
+        for k in self.splats.keys():
+            new = torch.cat([c["splats"][k] for c in ckpts]).to(self.device).contiguous()
+            old = self.splats[k]
+            fresh = torch.nn.Parameter(new, requires_grad=True)
+            self.splats[k] = fresh
+            opt = self.optimizers[k]
+            opt.state.pop(old, None)
+            opt.param_groups[0]["params"] = [fresh]
+        self._engine = None
+        self.step = int(ckpts[0]["step"]) + 1
+        return int(ckpts[0]["step"])
+
+    # ------------------------------------------------------------------------------ :779-838
+    @torch.no_grad()
+    def eval(self, step: int, stage: str = "val", dataset=None, save_images: bool = True) -> dict:
+        """PSNR / SSIM of the val split (data_range 1, 11x11 sigma-1.5 window over the valid region --
+        the torchmetrics definitions the reference instantiates at :419-433).  LPIPS is not computed:
+        its network weights are a download.  Writes {stage}_step{step:04d}.json and the side-by-side
+        canvases like the reference; returns the stats dict."""
+        import json
+        import time
+        from .losses import fused_ssim
+        cfg, dev = self.cfg, self.device
+        dataset = dataset if dataset is not None else getattr(self, "valset", None)
+        if dataset is None or len(dataset) == 0:
+            raise ValueError("Runner.eval needs a validation set (Runner.from_data_dir or dataset=...)")
+        dirs = self._result_dirs()
+        psnr, ssim, elapsed = [], [], 0.0
+        for i in range(len(dataset)):
+            data = dataset[i]
+            c2w = data["camtoworld"][None].to(dev)
+            Ks = data["K"][None].to(dev)
+            pixels = data["image"][None].to(dev) / 255.0
+            h, w = pixels.shape[1:3]
+            torch.cuda.synchronize()
+            tic = time.time()
+            colors, _, _ = self.rasterize_splats(camtoworlds=c2w, Ks=Ks, width=w, height=h, sh_degree=cfg.sh_degree,
+                                                 near_plane=cfg.near_plane, far_plane=cfg.far_plane)
+            torch.cuda.synchronize()
+            elapsed += time.time() - tic
+            colors = torch.clamp(colors[..., :3], 0.0, 1.0)
+            if self.world_rank == 0:
+                if save_images:
+                    self._write_png(f"{dirs['renders']}/{stage}_step{step}_{i:04d}.png", torch.cat([pixels, colors], dim=2)[0])
+                mse = torch.mean((colors - pixels) ** 2)
+                psnr.append(10.0 * torch.log10(1.0 / mse))
+                ssim.append(fused_ssim(colors.permute(0, 3, 1, 2).contiguous(), pixels.permute(0, 3, 1, 2).contiguous(),
+                                       padding="valid", train=False))
+        stats = {}
+        if self.world_rank == 0:
+            stats = {"psnr": torch.stack(psnr).mean().item(), "ssim": torch.stack(ssim).mean().item(),
+                     "ellipse_time": elapsed / len(dataset), "num_GS": len(self.splats["means"])}
+            with open(f"{dirs['stats']}/{stage}_step{step:04d}.json", "w") as f:
+                json.dump(stats, f)
+        return stats
+
+    @staticmethod
+    def _write_png(path: str, canvas01: Tensor) -> None:
+        from PIL import Image as PILImage
+        PILImage.fromarray((canvas01.clamp(0, 1).cpu().numpy() * 255).astype("uint8")).save(path)
+
+    # ------------------------------------------------------------------------------ :841-901
+    def trajectory(self, camtoworlds=None):
+        """[n,4,4] float64 camera-to-world path of cfg.render_traj_path through the parser's cameras
+        (the reference drops the first and last five, :846)."""
+        import numpy as np
+        from .datasets import generate_ellipse_path_z, generate_interpolated_path, generate_spiral_path
+        cfg = self.cfg
+        if camtoworlds is None:
+            camtoworlds = self.parser.camtoworlds[5:-5]
+        c = np.asarray(camtoworlds, dtype=np.float64)
+        if len(c) < 2:
+            raise ValueError("a trajectory needs at least two key cameras (the reference trims 5 from each end)")
+        if cfg.render_traj_path == "interp":
+            path = generate_interpolated_path(c, 1)
+        elif cfg.render_traj_path == "ellipse":
+            path = generate_ellipse_path_z(c, height=c[:, 2, 3].mean())
+        elif cfg.render_traj_path == "spiral":
+            parser = getattr(self, "parser", None)
+            if parser is None or not hasattr(parser, "bounds"):
+                raise ValueError("spiral paths need parser.bounds / parser.extconf, which the OpenSfM parser "
+                                 "does not provide (the reference fails the same way, :856-860)")
+            path = generate_spiral_path(c, bounds=parser.bounds * self.scene_scale,
+                                        spiral_scale_r=parser.extconf["spiral_radius_scale"])
+        else:
+            raise ValueError(f"Render trajectory type not supported: {cfg.render_traj_path}")
+        bottom = np.tile(np.array([[[0.0, 0.0, 0.0, 1.0]]]), (len(path), 1, 1))
+        return np.concatenate([path[:, :3, :], bottom], axis=1)
+
+    @torch.no_grad()
+    def render_traj(self, step: int, camtoworlds=None, K: Optional[Tensor] = None,
+                    width: Optional[int] = None, height: Optional[int] = None, save: bool = True):
+        """Render the trajectory as [n, H, 2W, 3] uint8 canvases (colour | min-max normalised expected depth).
+        Frames go to {result_dir}/videos/traj_{step}/NNNN.png -- the mp4 muxing of the reference is left to
+        the caller (no encoder in the image)."""
+        cfg, dev = self.cfg, self.device
+        path = torch.from_numpy(self.trajectory(camtoworlds)).float().to(dev)
+        if K is None:
+            K = torch.from_numpy(list(self.parser.Ks_dict.values())[0]).float()
+            width, height = list(self.parser.imsize_dict.values())[0]
+        K = K.float().to(dev)
+        frames = []
+        for i in range(len(path)):
+            renders, _, _ = self.rasterize_splats(camtoworlds=path[i:i + 1], Ks=K[None], width=width, height=height,
+                                                  sh_degree=cfg.sh_degree, near_plane=cfg.near_plane,
+                                                  far_plane=cfg.far_plane, render_mode="RGB+ED")
+            colors = torch.clamp(renders[..., 0:3], 0.0, 1.0)
+            depths = renders[..., 3:4]
+            depths = (depths - depths.min()) / (depths.max() - depths.min())
+            canvas = torch.cat([colors, depths.repeat(1, 1, 1, 3)], dim=2)[0]
+            frames.append((canvas * 255).to(torch.uint8))
+        frames = torch.stack(frames).cpu().numpy()
+        if save and self.world_rank == 0:
+            import os
+            from PIL import Image as PILImage
+            d = f"{self._result_dirs()['videos']}/traj_{step}"
+            os.makedirs(d, exist_ok=True)
+            for i, fr in enumerate(frames):
+                PILImage.fromarray(fr).save(f"{d}/{i:04d}.png")
+        return frames
+
+    # ------------------------------------------------------------------------------ :916-944
+    @torch.no_grad()
+    def _viewer_render_fn(self, camera_state, img_wh: Tuple[int, int], camera_model: Optional[str] = None):
+        """One viewer frame: `camera_state` offers `.c2w` [4,4] and `.get_K(img_wh)` [3,3] (nerfview's
+        CameraState), or is a (c2w, K) pair.  Returns [H,W,3] float32 numpy in 0..1."""
+        W, H = img_wh
+        if isinstance(camera_state, (tuple, list)):
+            c2w, K = camera_state
+        else:
+            c2w, K = camera_state.c2w, camera_state.get_K(img_wh)
+        c2w = torch.as_tensor(c2w).float().to(self.device)
+        K = torch.as_tensor(K).float().to(self.device)
+        colors, _, _ = self.rasterize_splats(camtoworlds=c2w[None], Ks=K[None], width=W, height=H,
+                                             sh_degree=self.cfg.sh_degree, radius_clip=3.0, camera_model=camera_model)
+        return colors[0, ..., :3].cpu().numpy()
 
     # ------------------------------------------------------------------------------ :446-497
     def rasterize_splats(self, camtoworlds: Tensor, Ks: Tensor, width: int, height: int,
@@ -344,20 +553,43 @@ class Runner:
                       value=s.prune_opa * 2.0)
 
     def train(self, max_steps: Optional[int] = None) -> None:
-        """Loop over `views` (batch_size per step, rank-strided like a DistributedSampler)."""
-        assert self.views, "Runner.train needs views"
+        """Loop over `views` (batch_size per step, rank-strided like a DistributedSampler).
+        Decoded views stay resident in HBM after their first use (a 1080p float view is 25 MB; the
+        288 GB of an MI355X hold thousands), so steady-state steps do no host->device copies; random
+        patches (cfg.patch_size) are re-cut each time and bypass the cache.  Checkpoints and evaluation
+        fire at cfg.save_steps / cfg.eval_steps when the runner was built from a data directory."""
+        assert len(self.views) > 0, "Runner.train needs views"
         cfg = self.cfg
         n = max_steps if max_steps is not None else cfg.max_steps
         B = cfg.batch_size
         dev = self.device
         order = list(range(self.world_rank, len(self.views), self.world_size)) or [0]
         cursor = 0
+        resident: Dict[int, Tuple[Tensor, Tensor, Tensor]] = {}
+        cache = cfg.patch_size is None
+        has_data = hasattr(self, "parser")
+
+        def fetch(i: int):
+            if cache and i in resident:
+                return resident[i]
+            v = self.views[i]
+            t = (v["camtoworld"].to(dev), v["K"].to(dev), v["image"].to(dev) / 255.0)
+            if cache:
+                resident[i] = t
+            return t
+
         for _ in range(n):
             if self.stop_training:
                 break
-            batch = [self.views[order[(cursor + i) % len(order)]] for i in range(B)]
+            batch = [fetch(order[(cursor + i) % len(order)]) for i in range(B)]
             cursor += B
-            c2w = torch.stack([b["camtoworld"] for b in batch]).to(dev)
-            Ks = torch.stack([b["K"] for b in batch]).to(dev)
-            pixels = torch.stack([b["image"] for b in batch]).to(dev) / 255.0
+            c2w = torch.stack([b[0] for b in batch])
+            Ks = torch.stack([b[1] for b in batch])
+            pixels = torch.stack([b[2] for b in batch])
+            step = self.step
             self.train_step(c2w, Ks, pixels)
+            if has_data:
+                if step in [i - 1 for i in cfg.save_steps] or step == n - 1:
+                    self.save_checkpoint(step)
+                if step in [i - 1 for i in cfg.eval_steps] and len(self.valset) > 0:
+                    self.eval(step)

@@ -17,6 +17,10 @@ Fixtures (data only):
   g3_normalize.npz similarity_from_cameras/align_principle_axes  (utils/datasets/normalize.py)
   g4_traj.npz      viewmatrix / generate_ellipse_path_z          (utils/datasets/traj.py:16-142)
   g6_knn_sh.npz    knn, rgb_to_sh                                (utils.py:141-150)
+  g7_opensfm_math.npz angle_axis_to_quaternion / qvec2rotmat / rotmat2qvec, extracted like g1 (the
+                   module imports pyproj/cv2/imageio at top level)   (utils/datasets/opensfm.py:47-84)
+  g8_traj_paths.npz generate_ellipse_path_y / generate_interpolated_path / generate_spiral_path /
+                   focus_point_fn / average_pose                 (utils/datasets/traj.py:25-255)
 """
 import ast
 import math
@@ -156,6 +160,35 @@ def g6(U):
                         rgb=rgb.numpy(), sh=U.rgb_to_sh(rgb).numpy())
 
 
+def g7():
+    path = os.path.join(REF, "utils/datasets/opensfm.py")
+    ns = dict(np=np, math=math)
+    aa2q = _extract_function(path, "angle_axis_to_quaternion", ns)
+    q2r = _extract_function(path, "qvec2rotmat", ns)
+    r2q = _extract_function(path, "rotmat2qvec", ns)
+    rng = np.random.default_rng(7)
+    aa = rng.normal(size=(16, 3)) * np.array([0.01, 0.3, 1.0, 2.5] * 4)[:, None]
+    q = np.stack([aa2q(a) for a in aa])
+    R = np.stack([q2r(v) for v in q])
+    qb = np.stack([r2q(m) for m in R])
+    np.savez_compressed(os.path.join(HERE, "g7_opensfm_math.npz"), angle_axis=aa, qvec=q, R=R, qvec_back=qb)
+
+
+def g8(Tj):
+    rng = np.random.default_rng(8)
+    ring = ring_cameras(Tj, 10, 6.0, 0.4)
+    ring[:, :3, 3] += rng.normal(0, 0.3, (10, 3))
+    poses = ring[:, :3, :]
+    bounds = np.array([0.5, 30.0])
+    np.savez_compressed(
+        os.path.join(HERE, "g8_traj_paths.npz"), poses=poses, bounds=bounds,
+        focus=Tj.focus_point_fn(poses), avg=Tj.average_pose(poses),
+        ell_y=Tj.generate_ellipse_path_y(poses, n_frames=12, variation=0.3, phase=0.25, height=0.5),
+        ell_z=Tj.generate_ellipse_path_z(poses, n_frames=12, variation=0.2, phase=0.1, height=-0.3),
+        interp=Tj.generate_interpolated_path(poses, 3),
+        spiral=Tj.generate_spiral_path(poses, bounds, n_frames=16))
+
+
 if __name__ == "__main__":
     U, Nz, Tj = _load_reference()
     g1(U)
@@ -163,6 +196,8 @@ if __name__ == "__main__":
     g3(Nz, Tj)
     g4(Tj)
     g6(U)
+    g7()
+    g8(Tj)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))
