@@ -8,7 +8,7 @@
 // derivative maps).  HBM-bound: forward reads 2 images and writes 3 maps, backward reads 3 maps +
 // 2 images and writes 1 image; all window arithmetic runs out of LDS.
 //
-// Row-streaming kernels: see the comment above kXT.
+// Row-streaming kernels: see the comment above kT.
 #include "so_common.hpp"
 
 namespace so {
@@ -21,142 +21,266 @@ struct Window {
 };
 
 // ---------------------------------------------------------------------------------------------
-// Row-streaming formulation.  A workgroup owns a strip of kXT output columns x all CH channels
-// (thread = (column, channel), so global loads/stores of the channel-last image are contiguous
-// over the thread index) and walks kRows output rows top to bottom.  Per input row: the row
+// Row-streaming formulation.  A workgroup owns a strip of kT floats of the channel-last rows
+// (thread = one float = one (column, channel), so global loads/stores are contiguous over the
+// thread index) and walks kRows output rows top to bottom.  Per input row: the row
 // (+5 halo columns each side) is staged through a double-buffered LDS line, every thread does its
 // 11-tap horizontal sums and pushes them into an 11-deep ring of REGISTERS; the vertical 11-tap
-// sum for the row 5 above comes straight from that ring.  No 2-D intermediate ever exists in LDS
-// (2 x 1.8 KB per image instead of 71 KB), the next-but-one row is prefetched into registers while
-// the current one is computed, and each input element is read from HBM ~1.3x instead of 1.7-3x.
+// sum for the row 5 above comes straight from that ring.  No 2-D intermediate ever exists in LDS,
+// the next-but-one row is prefetched into registers while the current one is computed, and each
+// input element is read from HBM ~1.3x instead of 1.7-3x.
+//
+// The kernels are bound by instruction issue (measured on MI355X, tools/probes/valu_rate.hip: a
+// wave-instruction costs a SIMD ~1.2 ns for v_fma_f32, ~2.1 ns for v_pk_fma_f32 / 64-bit integer
+// ops, ~3.5 ns for v_rcp_f32 / a 4- or 8-byte LDS read, ~6.9 ns for a 16-byte LDS read, 13 ns for
+// ds_read2_b64, and scalar instructions are not free either), so the inner loop is written to
+// issue as little as possible:
+//   * staging is branch-free: row / column indices are clamped into the image and the loaded
+//     values multiplied by 0/1 masks; row pointers are wave-uniform, lane offsets 32-bit;
+//   * one LDS record per staged element holds everything a tap needs, as one 16-byte read:
+//     forward (x, y, x*x + y*y, x*y) -- the products are formed once per element, not once per
+//     tap -- backward (three derivative maps, pad);
+//   * window sums are two-wide (v_pk_fma_f32 on (mu1,mu2) and (E[x^2+y^2],E[xy]));
+//   * the SSIM map uses v_rcp_f32 (1 ulp) instead of three IEEE divisions;
+//   * the first ring fill (no output rows yet) is a separate instantiation, so the steady state
+//     carries no "is there an output row" test.
 // ---------------------------------------------------------------------------------------------
-constexpr int kXT = 64;     // output columns per workgroup
-constexpr int kRows = 32;   // output rows per workgroup
+#ifndef SO_SSIM_THREADS
+#define SO_SSIM_THREADS 256
+#endif
+#ifndef SO_SSIM_ROWS
+#define SO_SSIM_ROWS 36
+#endif
+// A workgroup is kT threads = kT consecutive FLOATS of a channel-last row (not a whole number of
+// pixels for CH = 3: the horizontal neighbours of a float are simply CH floats away), four waves,
+// one per SIMD, so workgroups pack a CU exactly.  kRows = 36: 23 x 30 = 690 workgroups for a
+// 1080p RGB frame, all resident at once at three waves per SIMD (<= 168 VGPRs).
+constexpr int kT = SO_SSIM_THREADS;   // floats of a row per workgroup
+constexpr int kRows = SO_SSIM_ROWS;   // output rows per workgroup
+#ifndef SO_SSIM_TAPGROUP
+#define SO_SSIM_TAPGROUP 4
+#endif
+constexpr int kTapGroup = SO_SSIM_TAPGROUP;
 
-template <int CH, int NIMG>
-struct RowStage {   // register staging of one input row of NIMG images: 2 elements per thread
-  float v[NIMG][2];
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v2f pk_fma(float w, v2f x, v2f acc) {
+  const v2f ww = {w, w};
+  return __builtin_elementwise_fma(ww, x, acc);
+}
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// Per-thread staging geometry: a staged line is the workgroup's kT floats plus kHalf*CH halo floats on
+// each side.  Every thread stages element `tid` of the line and (the first 2*kHalf*CH threads only)
+// element `tid + kT`; the others re-read their first element and park the copy in an LDS slot nobody
+// reads, so that no lane-dependent branch is needed.
+template <int CH>
+struct StageGeom {
+  unsigned off0, off1;   // offset inside an image row, clamped into it
+  float cm0, cm1;        // 1 if the float is inside the row
+  int slot1;             // LDS slot of the second element
+  __device__ __forceinline__ StageGeom(int tid, int f0, int W) {
+    constexpr int E = kT + 2 * kHalf * CH;
+    const int e1 = tid + kT;
+    const int ff0 = f0 - kHalf * CH + tid, ff1 = f0 - kHalf * CH + e1;
+    const bool ok0 = ff0 >= 0 && ff0 < W * CH, ok1 = e1 < E && ff1 >= 0 && ff1 < W * CH;
+    off0 = ok0 ? (unsigned)ff0 : 0u;
+    off1 = ok1 ? (unsigned)ff1 : off0;
+    cm0 = ok0 ? 1.f : 0.f;
+    cm1 = ok1 ? 1.f : 0.f;
+    slot1 = e1 < E ? e1 : E + tid;   // dummy slots start at E
+  }
+};
+template <int CH>
+constexpr int lds_line_slots() { return 2 * kT + 2 * kHalf * CH; }
+
+// wave-uniform pointer to row y (clamped into the image) of image b (rmask: 0/1 mask of that row)
+__device__ __forceinline__ const float *row_ptr(const float *img, int b, int H, int W, int CH, int y, float &rmask) {
+#ifdef SO_SSIM_DBG_SAMEROW
+  const int yc = (y < 0 ? 0 : (y >= H ? H - 1 : y)) & ~31;
+#else
+  const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
+#endif
+  rmask = (y == yc) ? 1.f : 0.f;
+  return img + ((int64_t)b * H + yc) * ((int64_t)W * CH);
+}
+
+// ------------------------------------------------------------------------------------ forward
+template <int CH>
+struct FwdStage {
+  v2f p0, p1;   // (img1, img2) of the two staged elements, as loaded (not yet masked)
 };
 
-template <int CH, int NIMG>
-__device__ __forceinline__ void row_gload(RowStage<CH, NIMG> &st, const float *const (&img)[NIMG], int b, int H, int W,
-                                          int y, int x0, int tid) {
-  constexpr int T = kXT * CH, E = (kXT + 2 * kHalf) * CH;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int e = tid + j * T;
-    const int xx = x0 - kHalf + e / CH;
-    const bool ok = (e < E) && (y >= 0) && (y < H) && (xx >= 0) && (xx < W);
-    const int64_t off = (((int64_t)b * H + y) * W + xx) * CH + (e % CH);
-#pragma unroll
-    for (int i = 0; i < NIMG; ++i) st.v[i][j] = ok ? img[i][off] : 0.f;
-  }
+template <int CH>
+__device__ __forceinline__ void fwd_gload(FwdStage<CH> &st, const StageGeom<CH> &g, const float *img1, const float *img2,
+                                          int b, int H, int W, int y) {
+  float rm;
+  const float *r1 = row_ptr(img1, b, H, W, CH, y, rm);
+  const float *r2 = row_ptr(img2, b, H, W, CH, y, rm);
+#ifdef SO_SSIM_DBG_NOGLOAD
+  st.p0 = v2f{(float)g.off0, rm};
+  st.p1 = v2f{(float)g.off1, (float)y};
+  (void)r1; (void)r2;
+#else
+  st.p0 = v2f{r1[g.off0], r2[g.off0]};
+  st.p1 = v2f{r1[g.off1], r2[g.off1]};
+#endif
 }
 
-template <int CH, int NIMG>
-__device__ __forceinline__ void row_lstore(const RowStage<CH, NIMG> &st, float (*rows)[(kXT + 2 * kHalf) * CH], int tid) {
-  constexpr int T = kXT * CH, E = (kXT + 2 * kHalf) * CH;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int e = tid + j * T;
-    if (e < E) {
-#pragma unroll
-      for (int i = 0; i < NIMG; ++i) rows[i][e] = st.v[i][j];
-    }
-  }
+__device__ __forceinline__ v4f fwd_record(v2f p, float mask) {   // (x, y, x*x + y*y, x*y), zero outside the image
+  p *= v2f{mask, mask};
+  return v4f{p.x, p.y, fmaf(p.x, p.x, p.y * p.y), p.x * p.y};
 }
 
-// SSIM needs sigma1^2 + sigma2^2 only as a sum, so the ring carries FOUR blurred quantities per row:
-// mu1, mu2, E[x^2 + y^2], E[xy]  (11 registers and 22 FMAs per row fewer than five).
+// The masks are applied here, when the row goes to LDS, not when it is loaded: touching a loaded value
+// is what makes the wave wait for it, and the loads are issued two steps before this point.
+template <int CH>
+__device__ __forceinline__ void fwd_lstore(const FwdStage<CH> &st, const StageGeom<CH> &g, v4f *line, int tid, int y, int H) {
+  const float rm = (y >= 0 && y < H) ? 1.f : 0.f;
+  line[tid] = fwd_record(st.p0, rm * g.cm0);
+  line[g.slot1] = fwd_record(st.p1, rm * g.cm1);
+}
+
 template <int CH>
 struct SsimFwdState {
-  float ring[kWin][4];
+  v2f ring[kWin][2];   // per input row: (blur_x mu1, mu2), (blur_x E[x^2+y^2], E[xy])
   float l1_acc, ss_acc;
 };
 
-template <int CH, int P>
-__device__ __forceinline__ void ssim_fwd_step(SsimFwdState<CH> &S, RowStage<CH, 2> &pre, float (*rows)[2][(kXT + 2 * kHalf) * CH],
-                                              const float *const (&img)[2], int it, int n_in, int n_out, int b, int H, int W,
-                                              int x0, int y0, int tid, int xl, int ch, int valid, const Window &win,
-                                              float *__restrict__ dmaps, int64_t map_stride) {
-  if (it >= n_in) return;   // uniform over the workgroup
+struct FwdOut {        // per-thread output geometry
+  unsigned off;        // x * CH + ch = the float's index in its row
+  bool in_image;       // inside the row
+  float cmask;         // x counted in the SSIM mean (valid crop)
+  float l1mask;        // x < W as float
+};
+
+// One input row.  P = ring slot (compile time), OUT = an output row is completed by this input row.
+template <int CH, int P, bool OUT>
+__device__ __forceinline__ void ssim_fwd_step(SsimFwdState<CH> &S, FwdStage<CH> &preA, FwdStage<CH> &preB,
+                                              v4f (*rows)[lds_line_slots<CH>()],
+                                              const StageGeom<CH> &g, const FwdOut &o, const float *img1, const float *img2,
+                                              int it, int n_out, int b, int H, int W, int y0, int tid, int valid,
+                                              const Window &win, float *__restrict__ dmaps, int64_t map_stride) {
+  __builtin_amdgcn_sched_barrier(0);   // keep the unrolled steps apart: overlapping them only costs registers
   __syncthreads();
-  if (it + 1 < n_in) row_lstore<CH, 2>(pre, rows[(it + 1) & 1], tid);
-  if (it + 2 < n_in) row_gload<CH, 2>(pre, img, b, H, W, y0 - kHalf + it + 2, x0, tid);
-  const float *A = rows[it & 1][0], *Bq = rows[it & 1][1];
-  float m1 = 0.f, m2 = 0.f, ess = 0.f, e12 = 0.f;
-#pragma unroll
-  for (int k = 0; k < kWin; ++k) {
-    const float a = A[(xl + k) * CH + ch], c = Bq[(xl + k) * CH + ch], w = win.w[k];
-    m1 += w * a; m2 += w * c; ess += w * (a * a + c * c); e12 += w * a * c;
+  {   // stage row it+1 (loaded two steps ago), fetch row it+3; both harmless past the end
+    fwd_lstore<CH>(preA, g, rows[(it + 1) & 1], tid, y0 - kHalf + it + 1, H);
+    preA = preB;
+    fwd_gload<CH>(preB, g, img1, img2, b, H, W, y0 - kHalf + it + 3);
   }
-  S.ring[P][0] = m1; S.ring[P][1] = m2; S.ring[P][2] = ess; S.ring[P][3] = e12;
-  const int x = x0 + xl;
-  const int y_in = y0 - kHalf + it;
-  if (y_in >= y0 && y_in < y0 + n_out && x < W) S.l1_acc += fabsf(A[(xl + kHalf) * CH + ch] - Bq[(xl + kHalf) * CH + ch]);
-  if (it >= 2 * kHalf) {
-    const int y = y_in - kHalf;   // output row
-    float mu1 = 0.f, mu2 = 0.f, sss = 0.f, s12 = 0.f;
+  const v4f *R = rows[it & 1] + tid;   // tap k of this thread's column/channel sits CH slots further per k
+  v2f m = {0.f, 0.f}, q = {0.f, 0.f};
+  float ctr_abs = 0.f;
+  // taps in groups of kTapGroup: at most that many 16-byte records are in flight, which bounds the
+  // registers the scheduler may spend on hoisted LDS reads
+#pragma unroll
+  for (int k0 = 0; k0 < kWin; k0 += kTapGroup) {
+    v4f t[kTapGroup];
+#pragma unroll
+    for (int j = 0; j < kTapGroup; ++j)
+#ifdef SO_SSIM_DBG_NOLDSREAD
+      if (k0 + j < kWin) t[j] = v4f{(float)tid, (float)it, (float)j, 1.f};
+#else
+      if (k0 + j < kWin) t[j] = R[(k0 + j) * CH];
+#endif
+#pragma unroll
+    for (int j = 0; j < kTapGroup; ++j)
+      if (k0 + j < kWin) {
+        m = pk_fma(win.w[k0 + j], v2f{t[j].x, t[j].y}, m);
+        q = pk_fma(win.w[k0 + j], v2f{t[j].z, t[j].w}, q);
+        if (k0 + j == kHalf) ctr_abs = fabsf(t[j].x - t[j].y);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  S.ring[P][0] = m; S.ring[P][1] = q;
+  // L1 term of the centre pixel of this input row, if the row belongs to this workgroup's outputs
+  const float l1m = (it >= kHalf && it < n_out + kHalf) ? o.l1mask : 0.f;
+  S.l1_acc = fmaf(ctr_abs, l1m, S.l1_acc);
+  if constexpr (OUT) {
+    const int y = y0 + it - 2 * kHalf;   // output row
+    v2f mu = {0.f, 0.f}, sq = {0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < kWin; ++k) {
       const int slot = (P + 1 + k) % kWin;   // oldest row first; compile-time after unrolling
-      const float w = win.w[k];
-      mu1 += w * S.ring[slot][0]; mu2 += w * S.ring[slot][1]; sss += w * S.ring[slot][2];
-      s12 += w * S.ring[slot][3];
+      mu = pk_fma(win.w[k], S.ring[slot][0], mu);
+      sq = pk_fma(win.w[k], S.ring[slot][1], sq);
     }
-    const float musq = mu1 * mu1 + mu2 * mu2;
-    const float sig12 = s12 - mu1 * mu2;
-    const float Av = 2.f * mu1 * mu2 + kC1, Bv = 2.f * sig12 + kC2;
-    const float D = musq + kC1, E = (sss - musq) + kC2;
-    const float rDE = 1.f / (D * E);
-    const float m = Av * Bv * rDE;
-    const bool counted = !valid || (y >= kHalf && y < H - kHalf && x >= kHalf && x < W - kHalf);
-    float g_mu = 0.f, g_e11 = 0.f, g_e12 = 0.f;
-    if (counted && x < W) {
-      S.ss_acc += m;
-      const float dm_dA = Bv * rDE, dm_dB = Av * rDE, dm_dD = -m / D, dm_dE = -m / E;
-      g_e11 = dm_dE;
-      g_e12 = 2.f * dm_dB;
-      g_mu = 2.f * mu2 * dm_dA + 2.f * mu1 * dm_dD - 2.f * mu1 * g_e11 - mu2 * g_e12;
-    }
-    if (dmaps && x < W) {
-      const int64_t o = (((int64_t)b * H + y) * W + x) * CH + ch;
-      dmaps[o] = g_mu;
-      dmaps[map_stride + o] = g_e11;
-      dmaps[2 * map_stride + o] = g_e12;
+    const float mu1 = mu.x, mu2 = mu.y;
+    const float musq = fmaf(mu1, mu1, mu2 * mu2), m12 = mu1 * mu2;
+    const float Av = fmaf(2.f, m12, kC1), Bv = fmaf(2.f, sq.y - m12, kC2);
+    const float D = musq + kC1, E = (sq.x - musq) + kC2;
+#ifdef SO_SSIM_DBG_NOEPI
+    const float rD = D, rE = E, rDE = rD * rE;
+#else
+    const float rD = fast_rcp(D), rE = fast_rcp(E), rDE = rD * rE;
+#endif
+    const float ssim = Av * Bv * rDE;
+    const float rowc = (!valid || (y >= kHalf && y < H - kHalf)) ? o.cmask : 0.f;
+    S.ss_acc = fmaf(ssim, rowc, S.ss_acc);
+    if (dmaps) {
+      const float dm_dA = Bv * rDE * rowc, dm_dB2 = 2.f * Av * rDE * rowc;
+      const float dm_dD = -ssim * rD * rowc, dm_dE = -ssim * rE * rowc;
+      const float g_mu = 2.f * (mu2 * dm_dA + mu1 * (dm_dD - dm_dE)) - mu2 * dm_dB2;
+#ifdef SO_SSIM_DBG_NOSTORE
+      if (o.in_image && g_mu == 123.f) {
+#else
+      if (o.in_image) {
+#endif
+        float *d = dmaps + ((int64_t)b * H + y) * ((int64_t)W * CH);
+        d[o.off] = g_mu;
+        d[map_stride + o.off] = dm_dE;
+        d[2 * map_stride + o.off] = dm_dB2;
+      }
     }
   }
 }
 
+#ifndef SO_SSIM_WAVES
+#define SO_SSIM_WAVES 3
+#endif
+// SO_SSIM_WAVES waves per SIMD = workgroups per CU: every workgroup of a 1080p frame must be resident
+// at once, or the launch runs in two rounds of half-empty CUs.
 template <int CH>
-__global__ void __launch_bounds__(kXT *CH)
+__global__ void __launch_bounds__(kT, SO_SSIM_WAVES)
 k_ssim_l1_fwd(int B, int H, int W, const float *__restrict__ img1, const float *__restrict__ img2, int valid, Window win,
               float *__restrict__ sums, float *__restrict__ dmaps) {
-  constexpr int E = (kXT + 2 * kHalf) * CH;
-  __shared__ float rows[2][2][E];
-  __shared__ float red[2][CH];
-  const int tid = threadIdx.x, xl = tid / CH, ch = tid - xl * CH;
-  const int x0 = blockIdx.x * kXT, y0 = blockIdx.y * kRows, b = blockIdx.z;
+  __shared__ v4f rows[2][lds_line_slots<CH>()];
+  __shared__ float red[2][kT / 64];
+  const int tid = threadIdx.x;
+  const int f0 = blockIdx.x * kT, y0 = blockIdx.y * kRows, b = blockIdx.z;
   const int n_out = (H - y0) < kRows ? (H - y0) : kRows;
   const int n_in = n_out + 2 * kHalf;
-  const float *const img[2] = {img1, img2};
   const int64_t map_stride = (int64_t)B * H * W * CH;
-  RowStage<CH, 2> pre;
-  row_gload<CH, 2>(pre, img, b, H, W, y0 - kHalf, x0, tid);
-  row_lstore<CH, 2>(pre, rows[0], tid);
-  row_gload<CH, 2>(pre, img, b, H, W, y0 - kHalf + 1, x0, tid);
+  const StageGeom<CH> g(tid, f0, W);
+  const int f = f0 + tid, x = f / CH;
+  FwdOut o;
+  o.in_image = f < W * CH;
+  o.off = o.in_image ? (unsigned)f : 0u;
+  o.l1mask = o.in_image ? 1.f : 0.f;
+  o.cmask = (o.in_image && (!valid || (x >= kHalf && x < W - kHalf))) ? 1.f : 0.f;
+  FwdStage<CH> preA, preB;
+  fwd_gload<CH>(preA, g, img1, img2, b, H, W, y0 - kHalf);
+  fwd_lstore<CH>(preA, g, rows[0], tid, y0 - kHalf, H);
+  fwd_gload<CH>(preA, g, img1, img2, b, H, W, y0 - kHalf + 1);
+  fwd_gload<CH>(preB, g, img1, img2, b, H, W, y0 - kHalf + 2);
   SsimFwdState<CH> S;
   S.l1_acc = S.ss_acc = 0.f;
 #pragma unroll
-  for (int i = 0; i < kWin; ++i)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) S.ring[i][q] = 0.f;
-#define SO_STEP(P) ssim_fwd_step<CH, P>(S, pre, rows, img, base + P, n_in, n_out, b, H, W, x0, y0, tid, xl, ch, valid, win, dmaps, map_stride)
-#pragma unroll 1
-  for (int base = 0; base < n_in; base += kWin) {
-    SO_STEP(0); SO_STEP(1); SO_STEP(2); SO_STEP(3); SO_STEP(4); SO_STEP(5);
-    SO_STEP(6); SO_STEP(7); SO_STEP(8); SO_STEP(9); SO_STEP(10);
+  for (int i = 0; i < kWin; ++i) S.ring[i][0] = S.ring[i][1] = v2f{0.f, 0.f};
+#define SO_STEP(P, OUT) ssim_fwd_step<CH, P, OUT>(S, preA, preB, rows, g, o, img1, img2, base + P, n_out, b, H, W, y0, tid, valid, win, dmaps, map_stride)
+  {   // ring fill: n_in >= 11 always, the first ten input rows complete no output row
+    const int base = 0;
+    SO_STEP(0, false); SO_STEP(1, false); SO_STEP(2, false); SO_STEP(3, false); SO_STEP(4, false);
+    SO_STEP(5, false); SO_STEP(6, false); SO_STEP(7, false); SO_STEP(8, false); SO_STEP(9, false);
+    SO_STEP(10, true);
   }
+#define SO_STEPC(P) if (base + P >= n_in) break; SO_STEP(P, true)
+#pragma unroll 1
+  for (int base = kWin; base < n_in; base += kWin) {
+    SO_STEPC(0); SO_STEPC(1); SO_STEPC(2); SO_STEPC(3); SO_STEPC(4); SO_STEPC(5);
+    SO_STEPC(6); SO_STEPC(7); SO_STEPC(8); SO_STEPC(9); SO_STEPC(10);
+  }
+#undef SO_STEPC
 #undef SO_STEP
   const float l1 = wave_reduce_sum(S.l1_acc), ss = wave_reduce_sum(S.ss_acc);
   if ((tid & 63) == 0) { red[0][tid >> 6] = l1; red[1][tid >> 6] = ss; }
@@ -164,72 +288,107 @@ k_ssim_l1_fwd(int B, int H, int W, const float *__restrict__ img1, const float *
   if (tid == 0) {
     float a = 0.f, c = 0.f;
 #pragma unroll
-    for (int w = 0; w < CH; ++w) { a += red[0][w]; c += red[1][w]; }
+    for (int w = 0; w < kT / 64; ++w) { a += red[0][w]; c += red[1][w]; }
     atomicAdd(sums, a);
     atomicAdd(sums + 1, c);
   }
 }
 
+// ------------------------------------------------------------------------------------ backward
 template <int CH>
-struct SsimBwdState {
-  float ring[kWin][3];
+struct BwdStage {
+  float a0, b0, c0, a1, b1, c1;   // the three maps at the two staged elements, as loaded
 };
 
-template <int CH, int P>
-__device__ __forceinline__ void ssim_bwd_step(SsimBwdState<CH> &S, RowStage<CH, 3> &pre, float (*rows)[3][(kXT + 2 * kHalf) * CH],
-                                              const float *const (&maps)[3], const float *__restrict__ img1,
-                                              const float *__restrict__ img2, int it, int n_in, int b, int H, int W, int x0,
-                                              int y0, int tid, int xl, int ch, const Window &win, float wl1, float wss,
+template <int CH>
+__device__ __forceinline__ void bwd_gload(BwdStage<CH> &st, const StageGeom<CH> &g, const float *dmaps, int64_t map_stride,
+                                          int b, int H, int W, int y) {
+  float rm;
+  const float *r0 = row_ptr(dmaps, b, H, W, CH, y, rm);
+  const float *r1 = r0 + map_stride, *r2 = r1 + map_stride;
+  st.a0 = r0[g.off0]; st.b0 = r1[g.off0]; st.c0 = r2[g.off0];
+  st.a1 = r0[g.off1]; st.b1 = r1[g.off1]; st.c1 = r2[g.off1];
+}
+
+template <int CH>
+__device__ __forceinline__ void bwd_lstore(const BwdStage<CH> &st, const StageGeom<CH> &g, v4f *line, int tid, int y, int H) {
+  const float rm = (y >= 0 && y < H) ? 1.f : 0.f;
+  const float m0 = rm * g.cm0, m1 = rm * g.cm1;
+  line[tid] = v4f{st.a0 * m0, st.b0 * m0, st.c0 * m0, 0.f};
+  line[g.slot1] = v4f{st.a1 * m1, st.b1 * m1, st.c1 * m1, 0.f};
+}
+
+template <int CH>
+struct SsimBwdState {
+  v2f ring01[kWin];
+  float ring2[kWin];
+};
+
+template <int CH, int P, bool OUT>
+__device__ __forceinline__ void ssim_bwd_step(SsimBwdState<CH> &S, BwdStage<CH> &preA, BwdStage<CH> &preB,
+                                              v4f (*rows)[lds_line_slots<CH>()],
+                                              const StageGeom<CH> &g, const FwdOut &o, const float *dmaps, int64_t map_stride,
+                                              const float *__restrict__ img1, const float *__restrict__ img2, int it, int b,
+                                              int H, int W, int y0, int tid, const Window &win, float wl1, float wss,
                                               float *__restrict__ v_img1) {
-  if (it >= n_in) return;
+  __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
-  if (it + 1 < n_in) row_lstore<CH, 3>(pre, rows[(it + 1) & 1], tid);
-  if (it + 2 < n_in) row_gload<CH, 3>(pre, maps, b, H, W, y0 - kHalf + it + 2, x0, tid);
-  const int x = x0 + xl;
-  const int y = y0 - 2 * kHalf + it;   // output row completed by this input row
+  {
+    bwd_lstore<CH>(preA, g, rows[(it + 1) & 1], tid, y0 - kHalf + it + 1, H);
+    preA = preB;
+    bwd_gload<CH>(preB, g, dmaps, map_stride, b, H, W, y0 - kHalf + it + 3);
+  }
   float xv = 0.f, yv = 0.f;
-  const bool out = (it >= 2 * kHalf) && (x < W);
-  int64_t o = 0;
-  if (out) {   // issue the two pixel loads early; consumed after the vertical sums
-    o = (((int64_t)b * H + y) * W + x) * CH + ch;
-    xv = img1[o];
-    yv = img2[o];
+  int64_t orow = 0;
+  if constexpr (OUT) {   // issue the two pixel loads early; consumed after the vertical sums
+    orow = ((int64_t)b * H + (y0 + it - 2 * kHalf)) * ((int64_t)W * CH);
+    xv = (img1 + orow)[o.off];
+    yv = (img2 + orow)[o.off];
   }
-  const float *M0 = rows[it & 1][0], *M1 = rows[it & 1][1], *M2 = rows[it & 1][2];
-  float a = 0.f, c = 0.f, d = 0.f;
+  const v4f *R = rows[it & 1] + tid;
+  v2f ac = {0.f, 0.f};
+  float d = 0.f;
 #pragma unroll
-  for (int k = 0; k < kWin; ++k) {
-    const float w = win.w[k];
-    const int e = (xl + k) * CH + ch;
-    a += w * M0[e]; c += w * M1[e]; d += w * M2[e];
+  for (int k0 = 0; k0 < kWin; k0 += kTapGroup) {
+    v4f t[kTapGroup];
+#pragma unroll
+    for (int j = 0; j < kTapGroup; ++j)
+      if (k0 + j < kWin) t[j] = R[(k0 + j) * CH];
+#pragma unroll
+    for (int j = 0; j < kTapGroup; ++j)
+      if (k0 + j < kWin) {
+        ac = pk_fma(win.w[k0 + j], v2f{t[j].x, t[j].y}, ac);
+        d = fmaf(win.w[k0 + j], t[j].z, d);
+      }
+    __builtin_amdgcn_sched_barrier(0);
   }
-  S.ring[P][0] = a; S.ring[P][1] = c; S.ring[P][2] = d;
-  if (it >= 2 * kHalf) {
-    float va = 0.f, vc = 0.f, vd = 0.f;
+  S.ring01[P] = ac; S.ring2[P] = d;
+  if constexpr (OUT) {
+    v2f vac = {0.f, 0.f};
+    float vd = 0.f;
 #pragma unroll
     for (int k = 0; k < kWin; ++k) {
       const int slot = (P + 1 + k) % kWin;
-      const float w = win.w[k];
-      va += w * S.ring[slot][0]; vc += w * S.ring[slot][1]; vd += w * S.ring[slot][2];
+      vac = pk_fma(win.w[k], S.ring01[slot], vac);
+      vd = fmaf(win.w[k], S.ring2[slot], vd);
     }
-    if (out) {
+    if (o.in_image) {
       const float diff = xv - yv;
       const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
-      v_img1[o] = wl1 * sgn + wss * (va + 2.f * xv * vc + yv * vd);
+      (v_img1 + orow)[o.off] = wl1 * sgn + wss * (vac.x + 2.f * xv * vac.y + yv * vd);
     }
   }
 }
 
 template <int CH>
-__global__ void __launch_bounds__(kXT *CH)
+__global__ void __launch_bounds__(kT, SO_SSIM_WAVES)
 k_ssim_l1_bwd(int B, int H, int W, const float *__restrict__ img1, const float *__restrict__ img2,
               const float *__restrict__ dmaps, Window win, float w_l1, float w_ssim,
               const float *__restrict__ v_loss, float *__restrict__ v_img1, const float *__restrict__ sums,
               float *__restrict__ loss_out, float a_l1, float b_ssim, float c_const) {
-  constexpr int E = (kXT + 2 * kHalf) * CH;
-  __shared__ float rows[2][3][E];
-  const int tid = threadIdx.x, xl = tid / CH, ch = tid - xl * CH;
-  const int x0 = blockIdx.x * kXT, y0 = blockIdx.y * kRows, b = blockIdx.z;
+  __shared__ v4f rows[2][lds_line_slots<CH>()];
+  const int tid = threadIdx.x;
+  const int f0 = blockIdx.x * kT, y0 = blockIdx.y * kRows, b = blockIdx.z;
   const int n_out = (H - y0) < kRows ? (H - y0) : kRows;
   const int n_in = n_out + 2 * kHalf;
   const int64_t map_stride = (int64_t)B * H * W * CH;
@@ -242,20 +401,34 @@ k_ssim_l1_bwd(int B, int H, int W, const float *__restrict__ img1, const float *
     loss_out[1] = l1;
     loss_out[2] = 1.f - ss;
   }
-  const float *const maps[3] = {dmaps, dmaps + map_stride, dmaps + 2 * map_stride};
-  RowStage<CH, 3> pre;
-  row_gload<CH, 3>(pre, maps, b, H, W, y0 - kHalf, x0, tid);
-  row_lstore<CH, 3>(pre, rows[0], tid);
-  row_gload<CH, 3>(pre, maps, b, H, W, y0 - kHalf + 1, x0, tid);
+  const StageGeom<CH> g(tid, f0, W);
+  const int f = f0 + tid;
+  FwdOut o;
+  o.in_image = f < W * CH;
+  o.off = o.in_image ? (unsigned)f : 0u;
+  o.l1mask = o.cmask = 0.f;
+  BwdStage<CH> preA, preB;
+  bwd_gload<CH>(preA, g, dmaps, map_stride, b, H, W, y0 - kHalf);
+  bwd_lstore<CH>(preA, g, rows[0], tid, y0 - kHalf, H);
+  bwd_gload<CH>(preA, g, dmaps, map_stride, b, H, W, y0 - kHalf + 1);
+  bwd_gload<CH>(preB, g, dmaps, map_stride, b, H, W, y0 - kHalf + 2);
   SsimBwdState<CH> S;
 #pragma unroll
-  for (int i = 0; i < kWin; ++i) S.ring[i][0] = S.ring[i][1] = S.ring[i][2] = 0.f;
-#define SO_STEP(P) ssim_bwd_step<CH, P>(S, pre, rows, maps, img1, img2, base + P, n_in, b, H, W, x0, y0, tid, xl, ch, win, wl1, wss, v_img1)
-#pragma unroll 1
-  for (int base = 0; base < n_in; base += kWin) {
-    SO_STEP(0); SO_STEP(1); SO_STEP(2); SO_STEP(3); SO_STEP(4); SO_STEP(5);
-    SO_STEP(6); SO_STEP(7); SO_STEP(8); SO_STEP(9); SO_STEP(10);
+  for (int i = 0; i < kWin; ++i) { S.ring01[i] = v2f{0.f, 0.f}; S.ring2[i] = 0.f; }
+#define SO_STEP(P, OUT) ssim_bwd_step<CH, P, OUT>(S, preA, preB, rows, g, o, dmaps, map_stride, img1, img2, base + P, b, H, W, y0, tid, win, wl1, wss, v_img1)
+  {
+    const int base = 0;
+    SO_STEP(0, false); SO_STEP(1, false); SO_STEP(2, false); SO_STEP(3, false); SO_STEP(4, false);
+    SO_STEP(5, false); SO_STEP(6, false); SO_STEP(7, false); SO_STEP(8, false); SO_STEP(9, false);
+    SO_STEP(10, true);
   }
+#define SO_STEPC(P) if (base + P >= n_in) break; SO_STEP(P, true)
+#pragma unroll 1
+  for (int base = kWin; base < n_in; base += kWin) {
+    SO_STEPC(0); SO_STEPC(1); SO_STEPC(2); SO_STEPC(3); SO_STEPC(4); SO_STEPC(5);
+    SO_STEPC(6); SO_STEPC(7); SO_STEPC(8); SO_STEPC(9); SO_STEPC(10);
+  }
+#undef SO_STEPC
 #undef SO_STEP
 }
 
@@ -283,7 +456,7 @@ extern "C" int so_ssim_l1_fwd(int B, int H, int W, int CH, const float *img1, co
   if (B == 0) return SO_OK;
   SO_REQUIRE(img1 && img2 && sums, "so_ssim_l1_fwd: null pointer");
   const so::Window win = so::make_window();
-  const dim3 grid((W + so::kXT - 1) / so::kXT, (H + so::kRows - 1) / so::kRows, B), block(so::kXT * CH);
+  const dim3 grid((W * CH + so::kT - 1) / so::kT, (H + so::kRows - 1) / so::kRows, B), block(so::kT);
   hipStream_t st = so::as_stream(stream);
   if (CH == 1) hipLaunchKernelGGL(so::k_ssim_l1_fwd<1>, grid, block, 0, st, B, H, W, img1, img2, padding_valid, win, sums, dmaps);
   else if (CH == 3) hipLaunchKernelGGL(so::k_ssim_l1_fwd<3>, grid, block, 0, st, B, H, W, img1, img2, padding_valid, win, sums, dmaps);
@@ -307,7 +480,7 @@ extern "C" int so_ssim_l1_bwd(int B, int H, int W, int CH, const float *img1, co
   const float a_l1 = 1.f / ((float)B * H * W * CH);
   const float b_ss = 1.f / ((float)B * CH * (padding_valid ? (float)(H - 10) * (float)(W - 10) : (float)H * (float)W));
   const so::Window win = so::make_window();
-  const dim3 grid((W + so::kXT - 1) / so::kXT, (H + so::kRows - 1) / so::kRows, B), block(so::kXT * CH);
+  const dim3 grid((W * CH + so::kT - 1) / so::kT, (H + so::kRows - 1) / so::kRows, B), block(so::kT);
   hipStream_t st = so::as_stream(stream);
   if (CH == 1) hipLaunchKernelGGL(so::k_ssim_l1_bwd<1>, grid, block, 0, st, B, H, W, img1, img2, dmaps, win, w_l1, w_ssim, v_loss, v_img1, sums, loss_out, a_l1, b_ss, loss_const);
   else if (CH == 3) hipLaunchKernelGGL(so::k_ssim_l1_bwd<3>, grid, block, 0, st, B, H, W, img1, img2, dmaps, win, w_l1, w_ssim, v_loss, v_img1, sums, loss_out, a_l1, b_ss, loss_const);
