@@ -26,17 +26,20 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
                 int64_t n_isects_host, float *__restrict__ render_colors, float *__restrict__ render_alphas,
                 int32_t *__restrict__ last_ids) {
   constexpr int BLOCK = TS * TS;
-  constexpr int NWAVE_CHUNK = (BLOCK + 63) / 64;
-  __shared__ float4 s_xyoa[BLOCK];  // x, y, opacity, conic a
-  __shared__ float2 s_bc[BLOCK];    // conic b, c
+  // staged per Gaussian: A = (x, y, conic a, conic b), B = (conic c, opacity [, r, g when D == 3]),
+  // remaining colour channels in s_col -- two 16-byte broadcast reads + one 4-byte read per pass for RGB
+  constexpr int DC = (D == 3) ? 1 : D;   // channels kept in s_col
+  __shared__ float4 s_A[BLOCK];
+  __shared__ float4 s_B[BLOCK];
   __shared__ float4 s_box[BLOCK];   // xmin, xmax, ymin, ymax of the alpha>=1/255 region
-  __shared__ float s_col[BLOCK * D];
+  __shared__ float s_col[BLOCK * DC];
 
+  // the host checked C * tile_w * tile_h < 2^31: 32-bit index arithmetic (a 64-bit division is ~100 instructions)
   const int n_tiles = tile_w * tile_h;
-  const int64_t M = (int64_t)C * n_tiles;
-  const int64_t ct = xcd_remap(blockIdx.x, M);
-  const int c = (int)(ct / n_tiles);
-  const int t = (int)(ct - (int64_t)c * n_tiles);
+  const int M = C * n_tiles;
+  const int ct = (int)xcd_remap(blockIdx.x, M);
+  const int c = ct / n_tiles;
+  const int t = ct - c * n_tiles;
   const int ty = t / tile_w, tx = t - ty * tile_w;
   const int tid = threadIdx.x;
   int lx, ly, wx0, wy0;
@@ -65,84 +68,92 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
   if (hi > n_isects) hi = n_isects;
   if (lo > hi) lo = hi;
 
-  float T = 1.f;
+  // Per-pixel state.  A finished pixel (outside the image, or transmittance exhausted) has T == 0, which
+  // makes every later contribution vanish arithmetically -- the pass body below has no branches.  T_out
+  // keeps the transmittance the pixel stopped at (exactly one of T, T_out is non-zero at the end).
+  float T = inside ? 1.f : 0.f, T_out = 0.f;
   float acc[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) acc[k] = 0.f;
   int32_t cur_idx = 0;
-  bool done = !inside;
   const int lane = tid & 63;
 
   for (int64_t batch_start = lo; batch_start < hi; batch_start += BLOCK) {
-    if (__syncthreads_and(done)) break;
+    if (__syncthreads_and(!(T > 0.f))) break;
     const int64_t idx = batch_start + tid;
     if (idx < hi) {
       const int32_t g = flatten_ids[idx];
       if (PACKED) {
         const float4 *r4 = reinterpret_cast<const float4 *>(colors) + 4 * (int64_t)g;
-        const float4 q0 = r4[0], q1 = r4[1];
-        const float bb = reinterpret_cast<const float *>(r4 + 2)[0];
-        s_xyoa[tid] = make_float4(q0.x, q0.y, q1.y, q0.z);
-        s_bc[tid] = make_float2(q0.w, q1.x);
+        const float4 q0 = r4[0], q1 = r4[1];   // x,y,ca,cb | cc,opac,r,g
+        s_A[tid] = q0;
+        s_B[tid] = q1;
         s_box[tid] = alpha_bound_box(q0.x, q0.y, q1.y, q0.z, q0.w, q1.x);
-        s_col[tid * D] = q1.z;
-        if (D > 1) s_col[tid * D + 1] = q1.w;
-        if (D > 2) s_col[tid * D + 2] = bb;
+        s_col[tid] = reinterpret_cast<const float *>(r4 + 2)[0];
       } else {
         const float2 xy = means2d[g];
         const float op = opacities[g];
         const float ca = conics[3 * (int64_t)g], cb = conics[3 * (int64_t)g + 1], cc = conics[3 * (int64_t)g + 2];
-        s_xyoa[tid] = make_float4(xy.x, xy.y, op, ca);
-        s_bc[tid] = make_float2(cb, cc);
+        s_A[tid] = make_float4(xy.x, xy.y, ca, cb);
         s_box[tid] = alpha_bound_box(xy.x, xy.y, op, ca, cb, cc);
+        if (D == 3) {
+          s_B[tid] = make_float4(cc, op, colors[(int64_t)g * D], colors[(int64_t)g * D + 1]);
+          s_col[tid] = colors[(int64_t)g * D + 2];
+        } else {
+          s_B[tid] = make_float4(cc, op, 0.f, 0.f);
 #pragma unroll
-        for (int k = 0; k < D; ++k) s_col[tid * D + k] = colors[(int64_t)g * D + k];
+          for (int k = 0; k < D; ++k) s_col[tid * DC + k] = colors[(int64_t)g * D + k];
+        }
       }
     }
     __syncthreads();
     const int batch_size = (int)((hi - batch_start) < BLOCK ? (hi - batch_start) : BLOCK);
+    const int32_t batch_base = (int32_t)batch_start;
 #pragma unroll 1
-    for (int chunk = 0; chunk < NWAVE_CHUNK; ++chunk) {
-      const int cand = chunk * 64 + lane;
+    for (int chunk0 = 0; chunk0 < batch_size; chunk0 += 64) {
+      const int cand = chunk0 + lane;
       bool hit = false;
       if (cand < batch_size) {
         const float4 bx = s_box[cand];
         hit = !(bx.y < qx0 || bx.x > qx1 || bx.w < qy0 || bx.z > qy1);
         if (hit) {   // bounding boxes overlap: settle it with the exact ellipse-rectangle test
-          const float4 a = s_xyoa[cand];
-          const float2 bc = s_bc[cand];
-          hit = ellipse_hits_rect(a.x, a.y, a.z, a.w, bc.x, bc.y, qx0, qx1, qy0, qy1);
+          const float4 a = s_A[cand];
+          const float4 bq = s_B[cand];
+          hit = ellipse_hits_rect(a.x, a.y, bq.y, a.z, a.w, bq.x, qx0, qx1, qy0, qy1);
         }
       }
       unsigned long long mask = __ballot(hit);
       while (mask) {
-        if (__ballot(!done) == 0ull) { mask = 0; break; }
+        if (__ballot(T > 0.f) == 0ull) break;
         const int bit = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
-        const int tt = chunk * 64 + bit;
-        if (!done) {
-          const float4 a = s_xyoa[tt];
-          const float2 bc = s_bc[tt];
-          const float dx = a.x - px, dy = a.y - py;
-          const float sigma = 0.5f * (a.w * dx * dx + bc.y * dy * dy) + bc.x * dx * dy;
-          const float alpha = fminf(kAlphaMax, a.z * __expf(-sigma));
-          if (!(sigma < 0.f || alpha < kAlphaMin)) {
-            const float next_T = T * (1.f - alpha);
-            if (next_T <= kTStop) {
-              done = true;
-            } else {
-              const float vis = alpha * T;
+        const int tt = chunk0 + bit;
+        const float4 a = s_A[tt];
+        const float4 bq = s_B[tt];
+        const float dx = a.x - px, dy = a.y - py;
+        const float sigma = 0.5f * (a.z * dx * dx + bq.x * dy * dy) + a.w * dx * dy;
+        float alpha = fminf(kAlphaMax, bq.y * __expf(-sigma));
+        alpha = (sigma < 0.f) ? 0.f : alpha;
+        alpha = (alpha < kAlphaMin) ? 0.f : alpha;          // skipped Gaussian == zero alpha
+        const float next_T = T * (1.f - alpha);
+        const bool stop = next_T <= kTStop;                 // also true for pixels already finished (T == 0)
+        T_out += stop ? T : 0.f;
+        const float vis = stop ? 0.f : alpha * T;
+        T = stop ? 0.f : next_T;
+        if constexpr (D == 3) {
+          acc[0] = fmaf(bq.z, vis, acc[0]);
+          acc[1] = fmaf(bq.w, vis, acc[1]);
+          acc[2] = fmaf(s_col[tt], vis, acc[2]);
+        } else {
 #pragma unroll
-              for (int k = 0; k < D; ++k) acc[k] += s_col[tt * D + k] * vis;
-              cur_idx = (int32_t)(batch_start + tt);
-              T = next_T;
-            }
-          }
+          for (int k = 0; k < D; ++k) acc[k] = fmaf(s_col[tt * DC + k], vis, acc[k]);
         }
+        cur_idx = (vis > 0.f) ? batch_base + tt : cur_idx;
       }
     }
   }
   if (inside) {
+    T += T_out;
     render_alphas[pix] = 1.f - T;
 #pragma unroll
     for (int k = 0; k < D; ++k) render_colors[pix * D + k] = backgrounds ? acc[k] + T * backgrounds[c * D + k] : acc[k];
@@ -181,6 +192,8 @@ extern "C" int so_rasterize_fwd(int C, int N, int D, int width, int height, int 
   SO_REQUIRE(N == 0 || (means2d && conics && colors && opacities), "so_rasterize_fwd: null pointer");
   SO_REQUIRE(n_isects_dev || n_isects_host == 0 || flatten_ids, "so_rasterize_fwd: null flatten_ids");
   const int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
+  SO_REQUIRE((int64_t)C * tile_w * tile_h < (int64_t)INT32_MAX, "so_rasterize_fwd: C*tiles = %lld does not fit 31 bits",
+             (long long)C * tile_w * tile_h);
   const dim3 grid((unsigned)((int64_t)C * tile_w * tile_h));
   hipStream_t st = so::as_stream(stream);
 #define SO_CASE(DD)                                                                                              \
@@ -208,6 +221,8 @@ extern "C" int so_rasterize_fwd_packed(int C, int N, int width, int height, int 
   SO_REQUIRE(isect_offsets && render_colors && render_alphas && last_ids && (N == 0 || rec), "so_rasterize_fwd_packed: null pointer");
   SO_REQUIRE((((uintptr_t)rec) & 63) == 0, "so_rasterize_fwd_packed: rec must be 64-byte aligned");
   const int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
+  SO_REQUIRE((int64_t)C * tile_w * tile_h < (int64_t)INT32_MAX, "so_rasterize_fwd_packed: C*tiles = %lld does not fit 31 bits",
+             (long long)C * tile_w * tile_h);
   const dim3 grid((unsigned)((int64_t)C * tile_w * tile_h));
   hipStream_t st = so::as_stream(stream);
   if (tile_size == 16)
