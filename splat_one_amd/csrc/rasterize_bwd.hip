@@ -29,19 +29,23 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
                 float *__restrict__ v_opacities) {
   constexpr int BLOCK = TS * TS;
   constexpr int NWAVES = (BLOCK + 63) / 64;
-  __shared__ float4 s_xyoa[BLOCK];
-  __shared__ float2 s_bc[BLOCK];
+  // staged per Gaussian (same records as the forward): A = (x, y, conic a, conic b),
+  // B = (conic c, opacity [, r, g when D == 3]), remaining colour channels in s_col
+  constexpr int DC = (D == 3) ? 1 : D;
+  __shared__ float4 s_A[BLOCK];
+  __shared__ float4 s_B[BLOCK];
   __shared__ float4 s_box[BLOCK];
-  __shared__ float s_col[BLOCK * D];
+  __shared__ float s_col[BLOCK * DC];
   __shared__ int32_t s_id[BLOCK];
   __shared__ int32_t s_wave_last[NWAVES];
 
+  // the host checked C * tile_w * tile_h < 2^31 (32-bit index arithmetic)
   const int n_tiles = tile_w * tile_h;
-  const int64_t M = (int64_t)C * n_tiles;
-  const int64_t ct = xcd_remap(blockIdx.x, M);
+  const int M = C * n_tiles;
+  const int ct = (int)xcd_remap(blockIdx.x, M);
   if (tile_masks && !tile_masks[ct]) return;
-  const int c = (int)(ct / n_tiles);
-  const int t = (int)(ct - (int64_t)c * n_tiles);
+  const int c = ct / n_tiles;
+  const int t = ct - c * n_tiles;
   const int ty = t / tile_w, tx = t - ty * tile_w;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   int lx, ly, wx0, wy0;
@@ -70,6 +74,7 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
     if (backgrounds) bg_dot += backgrounds[c * D + k] * v_c[k];
   }
   const float v_a = inside ? v_render_alphas[pix] : 0.f;
+  const float tf_bg = T_final * (v_a - bg_dot);
   // last contributor of this pixel; pixels that nothing reached keep lo-1 (no Gaussian valid)
   int32_t bin_final = (int32_t)lo - 1;
   if (inside && T_final < 1.f) bin_final = last_ids[pix];
@@ -107,83 +112,93 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
       s_id[tid] = g;
       if (PACKED) {
         const float4 *r4 = reinterpret_cast<const float4 *>(colors) + 4 * (int64_t)g;
-        const float4 q0 = r4[0], q1 = r4[1];
-        const float bb = reinterpret_cast<const float *>(r4 + 2)[0];
-        s_xyoa[tid] = make_float4(q0.x, q0.y, q1.y, q0.z);
-        s_bc[tid] = make_float2(q0.w, q1.x);
+        const float4 q0 = r4[0], q1 = r4[1];   // x,y,ca,cb | cc,opac,r,g
+        s_A[tid] = q0;
+        s_B[tid] = q1;
         s_box[tid] = alpha_bound_box(q0.x, q0.y, q1.y, q0.z, q0.w, q1.x);
-        s_col[tid * D] = q1.z;
-        if (D > 1) s_col[tid * D + 1] = q1.w;
-        if (D > 2) s_col[tid * D + 2] = bb;
+        s_col[tid] = reinterpret_cast<const float *>(r4 + 2)[0];
       } else {
         const float2 xy = means2d[g];
         const float op = opacities[g];
         const float ca = conics[3 * (int64_t)g], cb = conics[3 * (int64_t)g + 1], cc = conics[3 * (int64_t)g + 2];
-        s_xyoa[tid] = make_float4(xy.x, xy.y, op, ca);
-        s_bc[tid] = make_float2(cb, cc);
+        s_A[tid] = make_float4(xy.x, xy.y, ca, cb);
         s_box[tid] = alpha_bound_box(xy.x, xy.y, op, ca, cb, cc);
+        if (D == 3) {
+          s_B[tid] = make_float4(cc, op, colors[(int64_t)g * D], colors[(int64_t)g * D + 1]);
+          s_col[tid] = colors[(int64_t)g * D + 2];
+        } else {
+          s_B[tid] = make_float4(cc, op, 0.f, 0.f);
 #pragma unroll
-        for (int k = 0; k < D; ++k) s_col[tid * D + k] = colors[(int64_t)g * D + k];
+          for (int k = 0; k < D; ++k) s_col[tid * DC + k] = colors[(int64_t)g * D + k];
+        }
       }
     }
     __syncthreads();
     const int batch_size = (int)((batch_end + 1 - lo) < BLOCK ? (batch_end + 1 - lo) : BLOCK);
+    const int32_t rel_final = (int32_t)(batch_end - bin_final);   // candidate tt contributes to this pixel iff tt >= rel_final
+    const int32_t rel_wave = (int32_t)(batch_end - wave_last);
 #pragma unroll 1
-    for (int chunk = 0; chunk < NWAVES; ++chunk) {
-      const int cand = chunk * 64 + lane;
+    for (int chunk0 = 0; chunk0 < batch_size; chunk0 += 64) {
+      const int cand = chunk0 + lane;
       bool hit = false;
-      if (cand < batch_size && batch_end - cand <= wave_last) {
+      if (cand < batch_size && cand >= rel_wave) {
         const float4 bx = s_box[cand];
         hit = !(bx.y < qx0 || bx.x > qx1 || bx.w < qy0 || bx.z > qy1);
         if (hit) {   // bounding boxes overlap: settle it with the exact ellipse-rectangle test
-          const float4 a = s_xyoa[cand];
-          const float2 bc = s_bc[cand];
-          hit = ellipse_hits_rect(a.x, a.y, a.z, a.w, bc.x, bc.y, qx0, qx1, qy0, qy1);
+          const float4 a = s_A[cand];
+          const float4 bq = s_B[cand];
+          hit = ellipse_hits_rect(a.x, a.y, bq.y, a.z, a.w, bq.x, qx0, qx1, qy0, qy1);
         }
       }
       unsigned long long mask = __ballot(hit);
       while (mask) {
         const int bit = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
-        const int tt = chunk * 64 + bit;
-        const float4 a = s_xyoa[tt];
-        const float2 bc = s_bc[tt];
-        const float opac = a.z;
+        const int tt = chunk0 + bit;
+        const float4 a = s_A[tt];
+        const float4 bq = s_B[tt];
+        const float opac = bq.y;
         const float dx = a.x - px, dy = a.y - py;
-        const float sigma = 0.5f * (a.w * dx * dx + bc.y * dy * dy) + bc.x * dx * dy;
+        const float sigma = 0.5f * (a.z * dx * dx + bq.x * dy * dy) + a.w * dx * dy;
         const float vis = __expf(-sigma);
-        const float alpha = fminf(kAlphaMax, opac * vis);
-        const bool valid = inside && (batch_end - tt <= bin_final) && !(sigma < 0.f || alpha < kAlphaMin);
+        const float ov = opac * vis;
+        const float alpha = fminf(kAlphaMax, ov);
+        // pixels outside the image carry bin_final = lo - 1, i.e. rel_final > every tt
+        const bool valid = (tt >= rel_final) && !(sigma < 0.f || alpha < kAlphaMin);
         if (__ballot(valid) == 0ull) continue;
+        // Branch-free from here: a lane that does not take part uses alpha 0, which leaves T and the
+        // colour buffer untouched and makes its gradient terms vanish.
+        const float alpha_v = valid ? alpha : 0.f;
+        const float ra = __builtin_amdgcn_rcpf(1.f - alpha_v);   // 1 ulp; alpha <= 0.999
+        T *= ra;
+        const float fac = alpha_v * T;
         float g_col[D];
-        float g_cx = 0.f, g_cy = 0.f, g_cz = 0.f, g_x = 0.f, g_y = 0.f, g_ax = 0.f, g_ay = 0.f, g_op = 0.f;
+        float v_alpha = tf_bg * ra;   // T_final * ra * (v_a - bg . v_c)
+        if constexpr (D == 3) {
+          const float ck[3] = {bq.z, bq.w, s_col[tt]};
 #pragma unroll
-        for (int k = 0; k < D; ++k) g_col[k] = 0.f;
-        if (valid) {
-          const float ra = __builtin_amdgcn_rcpf(1.f - alpha);   // 1 ulp; alpha <= 0.999
-          T *= ra;
-          const float fac = alpha * T;
-          float v_alpha = 0.f;
+          for (int k = 0; k < 3; ++k) {
+            g_col[k] = fac * v_c[k];
+            v_alpha += (ck[k] * T - buffer[k] * ra) * v_c[k];
+            buffer[k] = fmaf(ck[k], fac, buffer[k]);
+          }
+        } else {
 #pragma unroll
           for (int k = 0; k < D; ++k) {
-            const float ck = s_col[tt * D + k];
+            const float ck = s_col[tt * DC + k];
             g_col[k] = fac * v_c[k];
             v_alpha += (ck * T - buffer[k] * ra) * v_c[k];
-            buffer[k] += ck * fac;
-          }
-          v_alpha += T_final * ra * v_a;
-          v_alpha -= T_final * ra * bg_dot;
-          if (opac * vis <= kAlphaMax) {
-            const float v_sigma = -opac * vis * v_alpha;
-            g_cx = 0.5f * v_sigma * dx * dx;
-            g_cy = v_sigma * dx * dy;
-            g_cz = 0.5f * v_sigma * dy * dy;
-            g_x = v_sigma * (a.w * dx + bc.x * dy);
-            g_y = v_sigma * (bc.x * dx + bc.y * dy);
-            if (ABS) { g_ax = fabsf(g_x); g_ay = fabsf(g_y); }
-            g_op = vis * v_alpha;
+            buffer[k] = fmaf(ck, fac, buffer[k]);
           }
         }
+        const bool grad_on = valid && (ov <= kAlphaMax);   // the clamp at 0.999 has zero slope
+        const float v_sigma = grad_on ? -ov * v_alpha : 0.f;
+        const float g_op = grad_on ? vis * v_alpha : 0.f;
+        const float t1 = v_sigma * dx, t2 = v_sigma * dy;
+        const float g_cx = 0.5f * (t1 * dx), g_cy = t1 * dy, g_cz = 0.5f * (t2 * dy);
+        const float g_x = fmaf(a.z, t1, a.w * t2), g_y = fmaf(a.w, t1, bq.x * t2);
+        float g_ax = 0.f, g_ay = 0.f;
+        if (ABS) { g_ax = fabsf(g_x); g_ay = fabsf(g_y); }
         if (D == 3) {
           const float v8[8] = {g_x, g_y, g_cx, g_cy, g_cz, g_col[0], g_col[1 % D], g_col[2 % D]};
           float val = row_reduce8_transposed(v8, lane);
@@ -203,27 +218,25 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         // generic channel counts: wave sums land in lane 63
 #pragma unroll
         for (int k = 0; k < D; ++k) g_col[k] = wave_reduce_sum_to_last(g_col[k]);
-        g_cx = wave_reduce_sum_to_last(g_cx);
-        g_cy = wave_reduce_sum_to_last(g_cy);
-        g_cz = wave_reduce_sum_to_last(g_cz);
-        g_x = wave_reduce_sum_to_last(g_x);
-        g_y = wave_reduce_sum_to_last(g_y);
+        const float w_cx = wave_reduce_sum_to_last(g_cx), w_cy = wave_reduce_sum_to_last(g_cy);
+        const float w_cz = wave_reduce_sum_to_last(g_cz);
+        const float w_x = wave_reduce_sum_to_last(g_x), w_y = wave_reduce_sum_to_last(g_y);
         if (ABS) { g_ax = wave_reduce_sum_to_last(g_ax); g_ay = wave_reduce_sum_to_last(g_ay); }
-        g_op = wave_reduce_sum_to_last(g_op);
+        const float w_op = wave_reduce_sum_to_last(g_op);
         if (lane == 63) {
           const int64_t g = s_id[tt];
 #pragma unroll
           for (int k = 0; k < D; ++k) atomicAdd(v_colors + g * D + k, g_col[k]);
-          atomicAdd(v_conics + 3 * g, g_cx);
-          atomicAdd(v_conics + 3 * g + 1, g_cy);
-          atomicAdd(v_conics + 3 * g + 2, g_cz);
-          atomicAdd(v_means2d + 2 * g, g_x);
-          atomicAdd(v_means2d + 2 * g + 1, g_y);
+          atomicAdd(v_conics + 3 * g, w_cx);
+          atomicAdd(v_conics + 3 * g + 1, w_cy);
+          atomicAdd(v_conics + 3 * g + 2, w_cz);
+          atomicAdd(v_means2d + 2 * g, w_x);
+          atomicAdd(v_means2d + 2 * g + 1, w_y);
           if (ABS) {
             atomicAdd(v_means2d_abs + 2 * g, g_ax);
             atomicAdd(v_means2d_abs + 2 * g + 1, g_ay);
           }
-          atomicAdd(v_opacities + g, g_op);
+          atomicAdd(v_opacities + g, w_op);
         }
       }
     }
@@ -266,6 +279,8 @@ extern "C" int so_rasterize_bwd(int C, int N, int D, int width, int height, int 
              "so_rasterize_bwd: null pointer");
   SO_REQUIRE(n_isects_dev || n_isects_host == 0 || flatten_ids, "so_rasterize_bwd: null flatten_ids");
   const int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
+  SO_REQUIRE((int64_t)C * tile_w * tile_h < (int64_t)INT32_MAX, "so_rasterize_bwd: C*tiles = %lld does not fit 31 bits",
+             (long long)C * tile_w * tile_h);
   const dim3 grid((unsigned)((int64_t)C * tile_w * tile_h));
   hipStream_t st = so::as_stream(stream);
 #define SO_CASE(DD)                                                                                             \
@@ -297,6 +312,8 @@ extern "C" int so_rasterize_bwd_packed(int C, int N, int width, int height, int 
              "so_rasterize_bwd_packed: null pointer");
   SO_REQUIRE(((((uintptr_t)rec) | ((uintptr_t)vrec)) & 63) == 0, "so_rasterize_bwd_packed: records must be 64-byte aligned");
   const int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
+  SO_REQUIRE((int64_t)C * tile_w * tile_h < (int64_t)INT32_MAX, "so_rasterize_bwd_packed: C*tiles = %lld does not fit 31 bits",
+             (long long)C * tile_w * tile_h);
   const dim3 grid((unsigned)((int64_t)C * tile_w * tile_h));
   hipStream_t st = so::as_stream(stream);
 #define SO_GO(TSV, ABSV)                                                                                          \

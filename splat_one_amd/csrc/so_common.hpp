@@ -111,11 +111,25 @@ __device__ __forceinline__ float row_reduce8_transposed(const float (&v)[8], int
   return e;
 }
 
-// Adds the four DPP rows lane-wise: lanes 0..15 end with v[l] + v[l+16] + v[l+32] + v[l+48].
+// Adds the four DPP rows lane-wise: every lane l ends with v[l%16] + v[l%16+16] + v[l%16+32] + v[l%16+48].
+// gfx950's v_permlane16_swap / v_permlane32_swap exchange the odd rows (upper half-wave) of one register
+// with the even rows (lower half-wave) of another; with both operands holding v, the two results are
+// (even rows duplicated) and (odd rows duplicated), whose sum is the pairwise row sum -- two VALU
+// instructions per level and no LDS hardware.  Written as inline asm: the builtin's struct return is
+// miscompiled by hipcc 7.2 when both members are added; the s_nop's are the wait states between a VALU
+// write and a cross-lane read of the same register (as for DPP), which the compiler does not insert around
+// inline asm -- without them the swap reads stale operands.  EXEC must be all ones.
 __device__ __forceinline__ float rows_combine(float v) {
-  v += __shfl_down(v, 32, 64);
-  v += __shfl_down(v, 16, 64);
+#if defined(__HIP_DEVICE_COMPILE__)
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  v = a + b;
+  a = v; b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
+#else
   return v;
+#endif
 }
 
 // Sum over the 16 lanes of each row, result in every lane of the row (4 VALU instructions).
