@@ -108,6 +108,8 @@ k_preprocess_fwd(int C, int N, int K, const float *__restrict__ means, const flo
   }
 }
 
+// (One wave per SIMD: 256 VGPRs + AGPRs.  Forcing two with __launch_bounds__(256, 2) spills 49 registers
+// and measured slower, 23.1 vs 20.5 us at 100k Gaussians.)
 template <int DEG>
 __global__ void __launch_bounds__(256)
 k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const float *__restrict__ log_scales,
