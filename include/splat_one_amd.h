@@ -226,7 +226,7 @@ int so_adam_step(int n_groups, const so_adam_group *host_groups, double beta1, d
  * increments the counter afterwards.  Launch arguments are therefore constant across iterations. */
 int so_adam_step_dev(int n_groups, const so_adam_group *host_groups, const float *host_lr0,
                      const float *host_lr_gamma, double beta1, double beta2, double eps, int32_t *step_counter,
-                     int zero_grad, void *stream);
+                     int zero_grad, int schedule_done, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused front end / back end on the RAW parameters (what `Runner.rasterize_splats` holds,
@@ -295,8 +295,26 @@ typedef struct so_step_desc {
   int32_t abi_size, C, N, K, width, height, tile_size, sh_degree, camera_model, antialiased, absgrad;
   int32_t raster_impl; /* 0: LDS-tiled kernels, 1: wave-per-quadrant kernels (tile 16 only) */
   float eps2d, near_plane, far_plane, radius_clip, ssim_lambda, opacity_reg, scale_reg;
+  /* Inputs staged by so_step_inputs (both optional, zero = off):
+   *   pixels_indirect  device slot holding the address of this iteration's target image [C,H,W,3]; when set it
+   *                    is read INSTEAD of `pixels`, so a resident dataset image is used in place, not copied;
+   *   inputs_staged    != 0: `counters` (and the loss sums behind them) are already zero, skip that launch. */
+  const float *const *pixels_indirect;
+  int32_t inputs_staged, reserved0;
 } so_step_desc;
 int so_train_step_fwd_bwd(const so_step_desc *desc, void *stream);
+/* Everything that changes from one iteration to the next, in ONE launch, so that a captured step needs
+ * neither copies nor re-capture (the reference does `inv(camtoworlds)`, `.to(device)` and the scheduler
+ * arithmetic on the host each iteration, gsplat_trainer.py:586-603, :483, :749-751):
+ *   viewmats[c] = inverse(camtoworlds[c]) (general 4x4, in double);  Ks_dst = Ks_src (nullable pair);
+ *   *pixels_slot = pixels (nullable pair; see so_step_desc.pixels_indirect);
+ *   counters[0 .. n_zero) = 0 (int32 words; nullable);
+ *   n_groups > 0: the Adam schedule of so_adam_step_dev for the step in step_counter[0] (hyper-parameters
+ *   written behind the counter, counter advanced) -- pass schedule_done = 1 to so_adam_step_dev then. */
+int so_step_inputs(int C, const float *camtoworlds, const float *Ks_src, float *viewmats, float *Ks_dst,
+                   const float *pixels, const float **pixels_slot, int32_t *counters, int64_t n_zero, int n_groups,
+                   const float *lr0, const float *lr_gamma, double beta1, double beta2, int32_t *step_counter,
+                   void *stream);
 /* the forward stages only (preprocess, binning, sort, rasterise) on the same descriptor: the eval /
  * viewer render of gsplat_trainer.py:779-940; pixels, loss and gradient buffers are not touched */
 int so_render_forward(const so_step_desc *desc, void *stream);

@@ -40,7 +40,8 @@ class StepDesc(ctypes.Structure):
         + [(n, ctypes.c_int32) for n in ("abi_size", "C", "N", "K", "width", "height", "tile_size", "sh_degree",
                                          "camera_model", "antialiased", "absgrad", "raster_impl")]
         + [(n, c_f32) for n in ("eps2d", "near_plane", "far_plane", "radius_clip", "ssim_lambda", "opacity_reg",
-                                "scale_reg")])
+                                "scale_reg")]
+        + [("pixels_indirect", c_ptr), ("inputs_staged", ctypes.c_int32), ("reserved0", ctypes.c_int32)])
 
 
 # name -> argtypes, exactly the prototypes of include/splat_one_amd.h
@@ -72,7 +73,9 @@ _SIGS = {
     "so_profile_enable": [c_int],
     "so_profile_read": [ctypes.POINTER(c_f32), ctypes.POINTER(c_int)],
     "so_adam_step_dev": [c_int, ctypes.POINTER(AdamGroup), ctypes.POINTER(c_f32), ctypes.POINTER(c_f32),
-                         ctypes.c_double, ctypes.c_double, ctypes.c_double, c_ptr, c_int, c_ptr],
+                         ctypes.c_double, ctypes.c_double, ctypes.c_double, c_ptr, c_int, c_int, c_ptr],
+    "so_step_inputs": [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, ctypes.POINTER(c_f32),
+                       ctypes.POINTER(c_f32), ctypes.c_double, ctypes.c_double, c_ptr, c_ptr],
     "so_compute_relocation": [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr],
     "so_inject_noise": [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr],
     "so_adam_step": [c_int, ctypes.POINTER(AdamGroup), ctypes.c_double, ctypes.c_double, ctypes.c_double, c_int, c_ptr],

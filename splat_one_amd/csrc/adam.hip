@@ -64,22 +64,12 @@ k_adam(AdamGroups groups, AdamHyper h, int zero_grad) {
 
 // ---- device-scheduled variant: step counter, LR schedule and bias corrections live on the device,
 // so the launch arguments never change and the whole training step can be replayed as a hipGraph.
-struct AdamSched {
-  float lr0[SO_ADAM_MAX_GROUPS];
-  float lr_gamma[SO_ADAM_MAX_GROUPS];
-};
+// (struct AdamSched and adam_schedule_block live in so_common.hpp: so_step_inputs runs the same schedule)
 
 // one thread per group: evaluates the schedule for the current step, then advances the counter
 __global__ void k_adam_prep(AdamSched sch, int n_groups, double beta1, double beta2, int32_t *__restrict__ step_ptr,
                             float2 *__restrict__ hyper) {
-  const int step = *step_ptr;                   // optimiser steps completed so far
-  const double t = (double)(step + 1);
-  if ((int)threadIdx.x < n_groups) {
-    const double lr = (double)sch.lr0[threadIdx.x] * pow((double)sch.lr_gamma[threadIdx.x], (double)step);
-    hyper[threadIdx.x] = make_float2((float)(lr / (1.0 - pow(beta1, t))), (float)sqrt(1.0 - pow(beta2, t)));
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) *step_ptr = step + 1;
+  adam_schedule_block(sch.lr0, sch.lr_gamma, n_groups, beta1, beta2, step_ptr, hyper);
 }
 
 __global__ void __launch_bounds__(256)
@@ -115,7 +105,7 @@ k_adam_dev(AdamGroups groups, AdamHyper h, const float2 *__restrict__ hyper, int
 
 extern "C" int so_adam_step_dev(int n_groups, const so_adam_group *host_groups, const float *host_lr0,
                                 const float *host_lr_gamma, double beta1, double beta2, double eps,
-                                int32_t *step_counter, int zero_grad, void *stream) {
+                                int32_t *step_counter, int zero_grad, int schedule_done, void *stream) {
   SO_REQUIRE(n_groups >= 0 && n_groups <= SO_ADAM_MAX_GROUPS, "so_adam_step_dev: n_groups %d not in [0,%d]", n_groups, SO_ADAM_MAX_GROUPS);
   SO_REQUIRE(step_counter, "so_adam_step_dev: null step counter");
   if (n_groups == 0) return SO_OK;
@@ -138,7 +128,8 @@ extern "C" int so_adam_step_dev(int n_groups, const so_adam_group *host_groups, 
   so_profile_stage_begin_end(8, 1, stream);
   // hyper[] lives right behind the step counter: step_counter[0] = step, [2..2+2*n) = (step_size, bc2_sqrt)
   float2 *hyper = reinterpret_cast<float2 *>(step_counter + 2);
-  hipLaunchKernelGGL(so::k_adam_prep, dim3(1), dim3(SO_ADAM_MAX_GROUPS), 0, st, S, n_groups, beta1, beta2, step_counter, hyper);
+  if (!schedule_done)   // otherwise so_step_inputs has evaluated this step's schedule already
+    hipLaunchKernelGGL(so::k_adam_prep, dim3(1), dim3(SO_ADAM_MAX_GROUPS), 0, st, S, n_groups, beta1, beta2, step_counter, hyper);
   if (max_numel > 0) {
     int64_t gx = so::ceil_div(so::ceil_div(max_numel, 4), 256);
     if (gx > 2048) gx = 2048;

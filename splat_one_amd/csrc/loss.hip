@@ -242,8 +242,10 @@ __device__ __forceinline__ void ssim_fwd_step(SsimFwdState<CH> &S, FwdStage<CH> 
 // at once, or the launch runs in two rounds of half-empty CUs.
 template <int CH>
 __global__ void __launch_bounds__(kT, SO_SSIM_WAVES)
-k_ssim_l1_fwd(int B, int H, int W, const float *__restrict__ img1, const float *__restrict__ img2, int valid, Window win,
-              float *__restrict__ sums, float *__restrict__ dmaps) {
+k_ssim_l1_fwd(int B, int H, int W, const float *__restrict__ img1, const float *__restrict__ img2_direct,
+              const float *const *__restrict__ img2_slot, int valid, Window win, float *__restrict__ sums,
+              float *__restrict__ dmaps) {
+  const float *__restrict__ img2 = img2_slot ? *img2_slot : img2_direct;   // target read in place (so_step_inputs)
   __shared__ v4f rows[2][lds_line_slots<CH>()];
   __shared__ float red[2][kT / 64];
   const int tid = threadIdx.x;
@@ -382,10 +384,11 @@ __device__ __forceinline__ void ssim_bwd_step(SsimBwdState<CH> &S, BwdStage<CH> 
 
 template <int CH>
 __global__ void __launch_bounds__(kT, SO_SSIM_WAVES)
-k_ssim_l1_bwd(int B, int H, int W, const float *__restrict__ img1, const float *__restrict__ img2,
-              const float *__restrict__ dmaps, Window win, float w_l1, float w_ssim,
+k_ssim_l1_bwd(int B, int H, int W, const float *__restrict__ img1, const float *__restrict__ img2_direct,
+              const float *const *__restrict__ img2_slot, const float *__restrict__ dmaps, Window win, float w_l1, float w_ssim,
               const float *__restrict__ v_loss, float *__restrict__ v_img1, const float *__restrict__ sums,
               float *__restrict__ loss_out, float a_l1, float b_ssim, float c_const) {
+  const float *__restrict__ img2 = img2_slot ? *img2_slot : img2_direct;
   __shared__ v4f rows[2][lds_line_slots<CH>()];
   const int tid = threadIdx.x;
   const int f0 = blockIdx.x * kT, y0 = blockIdx.y * kRows, b = blockIdx.z;
@@ -449,18 +452,29 @@ static Window make_window() {
 /* img1 (rendered, receives the gradient) / img2 (target): [B,H,W,CH] f32, CH in {1,3,4}.
  * sums[2] (device, zeroed by the caller): sums[0] += sum |img1-img2|, sums[1] += sum of the SSIM map
  * over the counted pixels (all, or the interior when padding_valid).  dmaps[3,B,H,W,CH] nullable. */
+namespace so {
+int ssim_l1_fwd_launch(int B, int H, int W, int CH, const float *img1, const float *img2, const float *const *img2_slot,
+                       int padding_valid, float *sums, float *dmaps, void *stream);
+int ssim_l1_bwd_launch(int B, int H, int W, int CH, const float *img1, const float *img2, const float *const *img2_slot,
+                       const float *dmaps, float w_l1, float w_ssim, const float *v_loss, float *v_img1, const float *sums,
+                       float *loss_out, int padding_valid, float loss_const, void *stream);
+}
 extern "C" int so_ssim_l1_fwd(int B, int H, int W, int CH, const float *img1, const float *img2,
                               int padding_valid, float *sums, float *dmaps, void *stream) {
+  return so::ssim_l1_fwd_launch(B, H, W, CH, img1, img2, nullptr, padding_valid, sums, dmaps, stream);
+}
+int so::ssim_l1_fwd_launch(int B, int H, int W, int CH, const float *img1, const float *img2, const float *const *img2_slot,
+                           int padding_valid, float *sums, float *dmaps, void *stream) {
   SO_REQUIRE(B >= 0 && H > 0 && W > 0, "so_ssim_l1_fwd: bad sizes");
   SO_REQUIRE(CH == 1 || CH == 3 || CH == 4, "so_ssim_l1_fwd: CH=%d not in {1,3,4}", CH);
   if (B == 0) return SO_OK;
-  SO_REQUIRE(img1 && img2 && sums, "so_ssim_l1_fwd: null pointer");
+  SO_REQUIRE(img1 && (img2 || img2_slot) && sums, "so_ssim_l1_fwd: null pointer");
   const so::Window win = so::make_window();
   const dim3 grid((W * CH + so::kT - 1) / so::kT, (H + so::kRows - 1) / so::kRows, B), block(so::kT);
   hipStream_t st = so::as_stream(stream);
-  if (CH == 1) hipLaunchKernelGGL(so::k_ssim_l1_fwd<1>, grid, block, 0, st, B, H, W, img1, img2, padding_valid, win, sums, dmaps);
-  else if (CH == 3) hipLaunchKernelGGL(so::k_ssim_l1_fwd<3>, grid, block, 0, st, B, H, W, img1, img2, padding_valid, win, sums, dmaps);
-  else hipLaunchKernelGGL(so::k_ssim_l1_fwd<4>, grid, block, 0, st, B, H, W, img1, img2, padding_valid, win, sums, dmaps);
+  if (CH == 1) hipLaunchKernelGGL(so::k_ssim_l1_fwd<1>, grid, block, 0, st, B, H, W, img1, img2, img2_slot, padding_valid, win, sums, dmaps);
+  else if (CH == 3) hipLaunchKernelGGL(so::k_ssim_l1_fwd<3>, grid, block, 0, st, B, H, W, img1, img2, img2_slot, padding_valid, win, sums, dmaps);
+  else hipLaunchKernelGGL(so::k_ssim_l1_fwd<4>, grid, block, 0, st, B, H, W, img1, img2, img2_slot, padding_valid, win, sums, dmaps);
   return so::check_launch("so_ssim_l1_fwd");
 }
 
@@ -472,18 +486,24 @@ extern "C" int so_ssim_l1_bwd(int B, int H, int W, int CH, const float *img1, co
                               const float *dmaps, float w_l1, float w_ssim, const float *v_loss, float *v_img1,
                               const float *sums, float *loss_out, int padding_valid, float loss_const,
                               void *stream) {
+  return so::ssim_l1_bwd_launch(B, H, W, CH, img1, img2, nullptr, dmaps, w_l1, w_ssim, v_loss, v_img1, sums, loss_out,
+                                padding_valid, loss_const, stream);
+}
+int so::ssim_l1_bwd_launch(int B, int H, int W, int CH, const float *img1, const float *img2, const float *const *img2_slot,
+                           const float *dmaps, float w_l1, float w_ssim, const float *v_loss, float *v_img1, const float *sums,
+                           float *loss_out, int padding_valid, float loss_const, void *stream) {
   SO_REQUIRE(B >= 0 && H > 0 && W > 0, "so_ssim_l1_bwd: bad sizes");
   SO_REQUIRE(CH == 1 || CH == 3 || CH == 4, "so_ssim_l1_bwd: CH=%d not in {1,3,4}", CH);
   if (B == 0) return SO_OK;
-  SO_REQUIRE(img1 && img2 && dmaps && v_img1, "so_ssim_l1_bwd: null pointer");
+  SO_REQUIRE(img1 && (img2 || img2_slot) && dmaps && v_img1, "so_ssim_l1_bwd: null pointer");
   SO_REQUIRE(loss_out == nullptr || sums != nullptr, "so_ssim_l1_bwd: loss_out needs sums");
   const float a_l1 = 1.f / ((float)B * H * W * CH);
   const float b_ss = 1.f / ((float)B * CH * (padding_valid ? (float)(H - 10) * (float)(W - 10) : (float)H * (float)W));
   const so::Window win = so::make_window();
   const dim3 grid((W * CH + so::kT - 1) / so::kT, (H + so::kRows - 1) / so::kRows, B), block(so::kT);
   hipStream_t st = so::as_stream(stream);
-  if (CH == 1) hipLaunchKernelGGL(so::k_ssim_l1_bwd<1>, grid, block, 0, st, B, H, W, img1, img2, dmaps, win, w_l1, w_ssim, v_loss, v_img1, sums, loss_out, a_l1, b_ss, loss_const);
-  else if (CH == 3) hipLaunchKernelGGL(so::k_ssim_l1_bwd<3>, grid, block, 0, st, B, H, W, img1, img2, dmaps, win, w_l1, w_ssim, v_loss, v_img1, sums, loss_out, a_l1, b_ss, loss_const);
-  else hipLaunchKernelGGL(so::k_ssim_l1_bwd<4>, grid, block, 0, st, B, H, W, img1, img2, dmaps, win, w_l1, w_ssim, v_loss, v_img1, sums, loss_out, a_l1, b_ss, loss_const);
+  if (CH == 1) hipLaunchKernelGGL(so::k_ssim_l1_bwd<1>, grid, block, 0, st, B, H, W, img1, img2, img2_slot, dmaps, win, w_l1, w_ssim, v_loss, v_img1, sums, loss_out, a_l1, b_ss, loss_const);
+  else if (CH == 3) hipLaunchKernelGGL(so::k_ssim_l1_bwd<3>, grid, block, 0, st, B, H, W, img1, img2, img2_slot, dmaps, win, w_l1, w_ssim, v_loss, v_img1, sums, loss_out, a_l1, b_ss, loss_const);
+  else hipLaunchKernelGGL(so::k_ssim_l1_bwd<4>, grid, block, 0, st, B, H, W, img1, img2, img2_slot, dmaps, win, w_l1, w_ssim, v_loss, v_img1, sums, loss_out, a_l1, b_ss, loss_const);
   return so::check_launch("so_ssim_l1_bwd");
 }

@@ -141,6 +141,49 @@ __device__ __forceinline__ float row_allreduce_sum(float x) {
   return x;
 }
 
+// General 4x4 inverse in double (adjugate / determinant) of one camera-to-world matrix.
+__device__ __forceinline__ void camera_inverse_one(const float *__restrict__ src, float *__restrict__ dst) {
+  double m[16], inv[16];
+  for (int i = 0; i < 16; ++i) m[i] = (double)src[i];
+  inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+  inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+  inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+  inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+  inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+  inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+  inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+  inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+  inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+  inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+  inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+  inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+  inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+  inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+  inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+  inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+  const double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+  const double rdet = 1.0 / det;
+  for (int i = 0; i < 16; ++i) dst[i] = (float)(inv[i] * rdet);
+}
+
+// Device-side Adam schedule (one thread per parameter group, a whole workgroup calls it): learning rate
+// lr0 * gamma^step, bias corrections for step+1, then the step counter advances.  hyper[g] = (step size, sqrt(bc2)).
+struct AdamSched {
+  float lr0[8];        // SO_ADAM_MAX_GROUPS
+  float lr_gamma[8];
+};
+__device__ __forceinline__ void adam_schedule_block(const float *lr0, const float *lr_gamma, int n_groups, double beta1,
+                                                    double beta2, int32_t *__restrict__ step_ptr, float2 *__restrict__ hyper) {
+  const int step = *step_ptr;                   // optimiser steps completed so far
+  const double t = (double)(step + 1);
+  if ((int)threadIdx.x < n_groups) {
+    const double lr = (double)lr0[threadIdx.x] * pow((double)lr_gamma[threadIdx.x], (double)step);
+    hyper[threadIdx.x] = make_float2((float)(lr / (1.0 - pow(beta1, t))), (float)sqrt(1.0 - pow(beta2, t)));
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *step_ptr = step + 1;
+}
+
 __device__ __forceinline__ int lane_id() {
 #if defined(__HIP_DEVICE_COMPILE__)
   return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));

@@ -45,6 +45,27 @@ namespace so {
 __global__ void __launch_bounds__(256) k_zero_u32(uint32_t *__restrict__ p, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0u;
 }
+int ssim_l1_fwd_launch(int B, int H, int W, int CH, const float *img1, const float *img2, const float *const *img2_slot,
+                       int padding_valid, float *sums, float *dmaps, void *stream);
+int ssim_l1_bwd_launch(int B, int H, int W, int CH, const float *img1, const float *img2, const float *const *img2_slot,
+                       const float *dmaps, float w_l1, float w_ssim, const float *v_loss, float *v_img1, const float *sums,
+                       float *loss_out, int padding_valid, float loss_const, void *stream);
+
+// Per-iteration inputs in one launch (see so_step_inputs in the header).  Workgroup 0 does the small serial
+// pieces (one lane per camera / per Ks entry / per Adam group); every workgroup zeroes its share of the counters.
+__global__ void __launch_bounds__(256)
+k_step_inputs(int C, const float *__restrict__ c2w, const float *__restrict__ Ks_src, float *__restrict__ w2c,
+              float *__restrict__ Ks_dst, const float *pixels, const float **pixels_slot, uint32_t *__restrict__ counters,
+              int64_t n_zero, AdamSched sch, int n_groups, double beta1, double beta2, int32_t *__restrict__ step_ptr) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += (int64_t)gridDim.x * blockDim.x) counters[i] = 0u;
+  if (blockIdx.x != 0) return;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) camera_inverse_one(c2w + 16 * c, w2c + 16 * c);
+  if (Ks_dst)
+    for (int i = threadIdx.x; i < 9 * C; i += blockDim.x) Ks_dst[i] = Ks_src[i];
+  if (pixels_slot && threadIdx.x == 0) *pixels_slot = pixels;
+  if (n_groups > 0) adam_schedule_block(sch.lr0, sch.lr_gamma, n_groups, beta1, beta2, step_ptr, reinterpret_cast<float2 *>(step_ptr + 2));
+}
+
 static inline void zero_async(void *p, int64_t n_words, hipStream_t st) {
   int64_t g = (n_words + 255) / 256;
   if (g > 1024) g = 1024;
@@ -89,6 +110,27 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only);
 
 extern "C" int so_train_step_fwd_bwd(const so_step_desc *d, void *stream) { return step_impl(d, stream, false); }
 
+extern "C" int so_step_inputs(int C, const float *camtoworlds, const float *Ks_src, float *viewmats, float *Ks_dst,
+                              const float *pixels, const float **pixels_slot, int32_t *counters, int64_t n_zero,
+                              int n_groups, const float *lr0, const float *lr_gamma, double beta1, double beta2,
+                              int32_t *step_counter, void *stream) {
+  SO_REQUIRE(C >= 0 && n_zero >= 0 && n_groups >= 0 && n_groups <= SO_ADAM_MAX_GROUPS, "so_step_inputs: bad sizes");
+  SO_REQUIRE(C == 0 || (camtoworlds && viewmats), "so_step_inputs: null camera pointers");
+  SO_REQUIRE((Ks_src == nullptr) == (Ks_dst == nullptr), "so_step_inputs: Ks_src and Ks_dst go together");
+  SO_REQUIRE(pixels_slot == nullptr || pixels != nullptr, "so_step_inputs: pixels_slot without pixels");
+  SO_REQUIRE(n_zero == 0 || counters, "so_step_inputs: null counters");
+  SO_REQUIRE(n_groups == 0 || (lr0 && lr_gamma && step_counter), "so_step_inputs: null schedule pointers");
+  so::AdamSched S{};
+  for (int i = 0; i < n_groups; ++i) { S.lr0[i] = lr0[i]; S.lr_gamma[i] = lr_gamma[i]; }
+  int64_t g = (n_zero + 1023) / 1024;
+  if (g < 1) g = 1;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(so::k_step_inputs, dim3((unsigned)g), dim3(256), 0, so::as_stream(stream), C, camtoworlds, Ks_src, viewmats,
+                     Ks_dst, pixels, pixels_slot, reinterpret_cast<uint32_t *>(counters), n_zero, S, n_groups, beta1, beta2,
+                     step_counter);
+  return so::check_launch("so_step_inputs");
+}
+
 // Forward only (render_colors / render_alphas / last_ids of the current views): the eval / viewer
 // path of gsplat_trainer.py:779-940 on the same static buffers, also hipGraph-capturable.
 extern "C" int so_render_forward(const so_step_desc *d, void *stream) { return step_impl(d, stream, true); }
@@ -106,7 +148,9 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
   // counters: tile_counts[M] | cursor[M] | long-list length | n_isects | overflow     loss_sums: l1, ssim
   int32_t *tile_counts = d->counters, *cursor = d->counters + M, *n_isects = d->counters + 2 * M + 1,
           *overflow = d->counters + 2 * M + 2;
-  if (reinterpret_cast<int32_t *>(d->loss_sums) == d->counters + 2 * M + 3) {
+  if (d->inputs_staged) {
+    // so_step_inputs zeroed the counters (and the loss sums behind them) for this iteration
+  } else if (reinterpret_cast<int32_t *>(d->loss_sums) == d->counters + 2 * M + 3) {
     so::zero_async(d->counters, 2 * M + 5, st);   // loss sums packed right behind the counters: one launch
   } else {
     so::zero_async(d->counters, 2 * M + 3, st);
@@ -130,9 +174,9 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
                                         0, d->render_colors, d->render_alphas, d->last_ids, stream));
   if (forward_only) return SO_OK;
   // loss = (1-l) * mean|.| + l * (1 - mean SSIM_valid)
-  SO_STAGE(4, so_ssim_l1_fwd(C, H, W, 3, d->render_colors, d->pixels, 1, d->loss_sums, d->dmaps, stream));
+  SO_STAGE(4, so::ssim_l1_fwd_launch(C, H, W, 3, d->render_colors, d->pixels, d->pixels_indirect, 1, d->loss_sums, d->dmaps, stream));
   const float n_l1 = (float)C * H * W * 3.f, n_ss = (float)C * 3.f * (float)(H - 10) * (float)(W - 10);
-  SO_STAGE(5, so_ssim_l1_bwd(C, H, W, 3, d->render_colors, d->pixels, d->dmaps, (1.f - d->ssim_lambda) / n_l1,
+  SO_STAGE(5, so::ssim_l1_bwd_launch(C, H, W, 3, d->render_colors, d->pixels, d->pixels_indirect, d->dmaps, (1.f - d->ssim_lambda) / n_l1,
                         -d->ssim_lambda / n_ss, nullptr, d->v_render_colors, d->loss_sums, d->loss_sums + 2, 1,
                         d->ssim_lambda, stream));
   // gradients of the intermediates accumulate in the 64-byte records vrec[C*N] (zeroed by the

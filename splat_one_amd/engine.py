@@ -73,7 +73,12 @@ class FusedEngine:
         e = lambda *shape, dtype=f32: torch.empty(*shape, dtype=dtype, device=dev)
         w = self.ws = {}
         w["viewmats"], w["Ks"] = e(C, 4, 4), e(C, 3, 3)
-        w["pixels"] = e(C, H, W, 3)
+        w["pixels"] = e(C, H, W, 3)                          # landing buffer for host-resident targets only
+        # device slot holding the address of this iteration's target image: a dataset image that is already
+        # resident in HBM is read in place (so_step_desc.pixels_indirect), not copied
+        w["pixels_slot"] = torch.tensor([w["pixels"].data_ptr()], dtype=torch.int64, device=dev)
+        self._pixels_ref = w["pixels"]
+        self._staged = self._sched_staged = False
         w["radii"], w["tiles_per_gauss"] = e(C, N, dtype=i32), e(C, N, dtype=i32)
         w["means2d"], w["depths"], w["conics"] = e(C, N, 2), e(C, N), e(C, N, 3)
         w["opacities"], w["colors"] = e(C, N), e(C, N, 3)
@@ -133,6 +138,7 @@ class FusedEngine:
         d.raster_impl = int(c["raster_impl"])
         d.eps2d, d.near_plane, d.far_plane, d.radius_clip = c["eps2d"], c["near_plane"], c["far_plane"], c["radius_clip"]
         d.ssim_lambda, d.opacity_reg, d.scale_reg = c["ssim_lambda"], c["opacity_reg"], c["scale_reg"]
+        d.pixels_indirect, d.inputs_staged = p(w["pixels_slot"]), 1     # every launch is preceded by _stage()
         return d
 
     def _adam_args(self):
@@ -163,43 +169,68 @@ class FusedEngine:
         return n, arr, lr0, gam, betas, eps
 
     # ---------------------------------------------------------------------------------------------
-    def set_views(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor) -> None:
-        """Copy this step's cameras and target images into the static input buffers.
-        camtoworlds[C,4,4] (rigid; inverted here), Ks[C,3,3], pixels[C,H,W,3] in 0..1."""
+    def _stage(self, c2w: Optional[Tensor], Ks: Optional[Tensor], pixels: Optional[Tensor], schedule: bool) -> None:
+        """ONE launch (so_step_inputs) for everything that changes per iteration: camera inverse, intrinsics,
+        the target-image slot, the zeroing of the binning counters / loss sums and, with `schedule`, the
+        Adam schedule of the optimiser step that follows.  c2w=None re-zeroes only (repeat launches on the
+        same inputs)."""
+        w, p, dev = self.ws, _lib.ptr, self.device
+        n_groups, lr0, gam, betas = 0, None, None, (0.0, 0.0)
+        if schedule:
+            n_groups, _arr, lr0, gam, betas, _eps = self._adam_args()
+        if c2w is not None:
+            c2w = c2w.detach().to(device=dev, dtype=torch.float32).contiguous()
+            Ks = Ks.detach().to(device=dev, dtype=torch.float32).contiguous()
+            self._keep = (c2w, Ks)                   # alive until the launch has run
+        px = None
+        if pixels is not None:
+            if pixels.is_cuda and pixels.dtype == torch.float32 and pixels.is_contiguous():
+                px = pixels.detach()
+            else:                                    # host / strided / other dtype: land it in the static buffer
+                w["pixels"].copy_(pixels, non_blocking=True)
+                px = w["pixels"]
+            self._pixels_ref = px                    # must stay alive and unchanged until the step has run
+        _lib.call("so_step_inputs", self.C if c2w is not None else 0, p(c2w), p(Ks), p(w["viewmats"]), p(w["Ks"]) if c2w is not None else 0,
+                  p(px), p(w["pixels_slot"]) if px is not None else 0, p(w["counters"]), 2 * self.M + 5, n_groups, lr0, gam,
+                  float(betas[0]), float(betas[1]), _lib.ptr(self._step_dev), _lib.stream())
+        self._staged = True
+        self._sched_staged = bool(schedule)
+
+    def set_views(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor, schedule: bool = False) -> None:
+        """Stage this step's cameras and target images.  camtoworlds[C,4,4] (inverted on the device),
+        Ks[C,3,3], pixels[C,H,W,3] in 0..1 -- a contiguous float32 HIP tensor is used IN PLACE (keep it
+        unchanged until the step has run).  schedule=True also evaluates the Adam schedule for the
+        `step()` / `optimize()` that follows (one launch fewer per iteration); leave it False when only
+        gradients are wanted."""
         assert camtoworlds.shape == (self.C, 4, 4) and Ks.shape == (self.C, 3, 3), (camtoworlds.shape, Ks.shape)
         assert pixels.shape == (self.C, self.H, self.W, 3), pixels.shape
-        if camtoworlds.is_cuda:
-            c2w = camtoworlds.detach().to(torch.float32).contiguous()
-            _lib.call("so_camera_inverse", self.C, _lib.ptr(c2w), _lib.ptr(self.ws["viewmats"]), _lib.stream())
-        else:
-            vm = torch.linalg.inv(camtoworlds.detach().to(torch.float64)).to(torch.float32)
-            self.ws["viewmats"].copy_(vm, non_blocking=True)
-        self.ws["Ks"].copy_(Ks, non_blocking=True)
-        self.ws["pixels"].copy_(pixels, non_blocking=True)
+        self._stage(camtoworlds, Ks, pixels, schedule)
 
     def _launch_fwd_bwd(self) -> None:
         d = self._desc()
         _lib.call("so_train_step_fwd_bwd", ctypes.byref(d), _lib.stream())
 
-    def _launch_optimize(self) -> None:
+    def _launch_optimize(self, schedule_done: bool = False) -> None:
         n, arr, lr0, gam, betas, eps = self._adam_args()
         _lib.call("so_adam_step_dev", n, arr, lr0, gam, float(betas[0]), float(betas[1]), float(eps),
-                  _lib.ptr(self._step_dev), 0, _lib.stream())
+                  _lib.ptr(self._step_dev), 0, int(schedule_done), _lib.stream())
 
     def set_cameras(self, camtoworlds: Tensor, Ks: Tensor) -> None:
         """Cameras only (forward-only rendering needs no target image)."""
         assert camtoworlds.shape == (self.C, 4, 4) and Ks.shape == (self.C, 3, 3), (camtoworlds.shape, Ks.shape)
-        if camtoworlds.is_cuda:
-            c2w = camtoworlds.detach().to(torch.float32).contiguous()
-            _lib.call("so_camera_inverse", self.C, _lib.ptr(c2w), _lib.ptr(self.ws["viewmats"]), _lib.stream())
-        else:
-            vm = torch.linalg.inv(camtoworlds.detach().to(torch.float64)).to(torch.float32)
-            self.ws["viewmats"].copy_(vm, non_blocking=True)
-        self.ws["Ks"].copy_(Ks, non_blocking=True)
+        self._stage(camtoworlds, Ks, None, False)
+
+    def _consume_staging(self) -> None:
+        """Every launch of the step needs zeroed counters: re-stage (zero only) when the caller repeats a
+        launch on the same inputs."""
+        if not self._staged:
+            self._stage(None, None, None, False)
+        self._staged = False
 
     def render(self):
         """Forward only on the current cameras: returns (render_colors[C,H,W,3], render_alphas[C,H,W,1])
         -- views of the static buffers, valid until the next call (the eval / viewer path)."""
+        self._consume_staging()
         d = self._desc()
         _lib.call("so_render_forward", ctypes.byref(d), _lib.stream())
         return self.ws["render_colors"], self.ws["render_alphas"]
@@ -209,42 +240,58 @@ class FusedEngine:
         (data-parallel runs all-reduce `ws["grads_flat"]` between this and `optimize`).  Replayed from
         its own hipGraph when `use_graph`."""
         if not self.use_graph:
+            self._consume_staging()
             self._launch_fwd_bwd()
             return
         key = (self.N, self.cfg["sh_degree"], id(self.ws), self.strategy_state is not None)
         if self._graph_fb is None or self._graph_fb_key != key:
             self._capture_split(key)
+        self._consume_staging()
         self._graph_fb.replay()
 
     def optimize(self) -> None:
+        sched, self._sched_staged = self._sched_staged, False
         if self.use_graph and self._graph_opt is not None:
-            self._graph_opt.replay()
+            self._graph_opt[sched].replay()
         else:
-            self._launch_optimize()
+            self._launch_optimize(sched)
         self._advance_host_counters()
 
-    def _capture_split(self, key) -> None:
-        """Two graphs (fwd+bwd | Adam) so that a collective can run between them."""
-        self._adam_args()
+    def _warm_fwd_bwd(self) -> None:
+        """Un-captured launch before a capture (module load, LDS attribute calls): gradients only, with the
+        densification statistics and the staging flags of the pending step left as they were."""
         torch.cuda.synchronize()
+        pending = (self._staged, self._sched_staged)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             st = self.strategy_state
             saved = [st[k].clone() for k in ("grad2d", "count")] if st is not None else None
             self._launch_fwd_bwd()
+            self._stage(None, None, None, False)     # leave the counters zero again for the real launch
             if saved is not None:
                 st["grad2d"].copy_(saved[0])
                 st["count"].copy_(saved[1])
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        self._staged, self._sched_staged = pending
+
+    def _capture_split(self, key) -> None:
+        """Graphs (fwd+bwd | Adam, with and without its own schedule launch) so that a collective can run
+        between them."""
+        self._adam_args()
+        if not self._staged:
+            self._stage(None, None, None, False)
+        self._warm_fwd_bwd()
         g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1):
             self._launch_fwd_bwd()
-        g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2):
-            self._launch_optimize()
-        self._graph_fb, self._graph_opt, self._graph_fb_key = g1, g2, key
+        opt = {}
+        for sched in (False, True):
+            opt[sched] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(opt[sched]):
+                self._launch_optimize(sched)
+        self._graph_fb, self._graph_opt, self._graph_fb_key = g1, opt, key
 
     def _advance_host_counters(self) -> None:
         self.steps_done += 1
@@ -255,36 +302,34 @@ class FusedEngine:
 
     def step(self) -> None:
         """One full iteration (fwd + loss + bwd + Adam); a hipGraph replay when `use_graph`."""
+        sched, self._sched_staged = self._sched_staged, False
         if not self.use_graph:
+            self._consume_staging()
             self._launch_fwd_bwd()
-            self._launch_optimize()
+            self._launch_optimize(sched)
         else:
             key = (self.N, self.cfg["sh_degree"], id(self.ws))
             if self._graph is None or self._graph_key != key:
+                self._sched_staged = sched
                 self._capture(key)
-            self._graph.replay()
+                self._sched_staged = False
+            self._consume_staging()
+            self._graph[sched].replay()
         self._advance_host_counters()
 
     def _capture(self, key) -> None:
         # make sure lazily-created optimiser state exists before capture
         self._adam_args()
-        torch.cuda.synchronize()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):        # warm-up outside capture (module load, LDS attribute calls)
-            st = self.strategy_state
-            saved = [st[k].clone() for k in ("grad2d", "count")] if st is not None else None
-            self._launch_fwd_bwd()               # gradients only: parameters and step counter untouched
-            if saved is not None:
-                st["grad2d"].copy_(saved[0])
-                st["count"].copy_(saved[1])
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._launch_fwd_bwd()
-            self._launch_optimize()
-        self._graph, self._graph_key = g, key
+        if not self._staged:
+            self._stage(None, None, None, False)
+        self._warm_fwd_bwd()
+        graphs = {}
+        for sched in (False, True):      # Adam with its own schedule launch / with the schedule staged by set_views
+            graphs[sched] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graphs[sched]):
+                self._launch_fwd_bwd()
+                self._launch_optimize(sched)
+        self._graph, self._graph_key = graphs, key
 
     # ---------------------------------------------------------------------------------------------
     def set_sh_degree(self, deg: int) -> None:

@@ -438,7 +438,7 @@ class Runner:
             eng.strategy_state = self.strategy_state if stats_on else None
             eng._graph = None
             eng._graph_fb = eng._graph_opt = None
-        eng.set_views(camtoworlds, Ks, pixels)
+        eng.set_views(camtoworlds, Ks, pixels, schedule=True)   # the step below always runs the optimiser
         if self.world_size == 1:
             eng.step()
         else:
