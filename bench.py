@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--operator-path", action="store_true",
                     help="time the operator-level autograd path instead of the fused engine")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel times to stderr")
+    ap.add_argument("--dp-mode", default="gaussian_sharded", choices=["gaussian_sharded", "allreduce"],
+                    help="multi-GPU scheme (ignored at --gpus 1): exchange projected Gaussians, or all-reduce gradients")
     args = ap.parse_args()
 
     from splat_one_amd import _lib, distributed as sdist
@@ -114,16 +116,33 @@ def main():
 
     W, H, N = args.width, args.height, args.n
     init_scale, init_opa = (1.0, 0.1) if args.regime == "ref" else (0.1, 0.5)
-    cfg = Config(init_num_pts=N, init_scale=init_scale, init_opa=init_opa, batch_size=1, shN_init_std=0.1,
-                 camera_model="pinhole", sh_degree_interval=1,    # SH degree 3 from step 3 on
-                 fused=not args.operator_path)
-    runner = Runner(local_rank, rank, world, cfg, scene_scale=1.0 / 1.1)   # effective scene_scale 1.0
-    runner.raster_impl = args.raster_impl
     cams = front_camera()[None] if world == 1 else ring_cameras(world)
-    c2w = cams[rank:rank + 1].to(dev)
-    Ks = pinhole_K(W, H)[None].to(dev)
     g = torch.Generator().manual_seed(100 + rank)
     pixels = torch.rand(1, H, W, 3, generator=g).to(dev)
+
+    def make_runner(dp_mode):
+        cfg = Config(init_num_pts=N, init_scale=init_scale, init_opa=init_opa, batch_size=1, shN_init_std=0.1,
+                     camera_model="pinhole", sh_degree_interval=1,    # SH degree 3 from step 3 on
+                     fused=not args.operator_path, dp_mode=dp_mode)
+        r = Runner(local_rank, rank, world, cfg, scene_scale=1.0 / 1.1)   # effective scene_scale 1.0
+        r.raster_impl = args.raster_impl
+        if r.sharded:      # the step takes the cameras of every rank (rank r renders camera r)
+            return cfg, r, cams.to(dev), pinhole_K(W, H)[None].repeat(world, 1, 1).to(dev)
+        return cfg, r, cams[rank:rank + 1].to(dev), pinhole_K(W, H)[None].to(dev)
+
+    cfg, runner, c2w, Ks = make_runner(args.dp_mode)
+    if runner.sharded:
+        # one guarded step: if the exchange path fails on any rank, every rank falls back to the gradient all-reduce
+        ok = torch.ones(1, device=dev)
+        try:
+            runner.train_step(c2w, Ks, pixels)
+            torch.cuda.synchronize()
+        except Exception as e:   # noqa: BLE001
+            print(f"[bench] gaussian_sharded step failed on rank {rank}: {e!r}; falling back to allreduce", file=sys.stderr)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() == 0:
+            cfg, runner, c2w, Ks = make_runner("allreduce")
 
     def barrier():
         if world > 1:
@@ -145,7 +164,9 @@ def main():
         _lib.PROFILE = {dominant}
 
     # forward-only rate: the eval / viewer render (projection + SH + binning + sort + rasterise)
-    if fused:
+    if runner.sharded:
+        fwd_call = lambda: None           # a render needs every shard on one rank: not a per-step quantity here
+    elif fused:
         eng = runner._engine
         fwd_call = eng.render
     else:
@@ -174,7 +195,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    if fused:
+    if runner.sharded:
+        # the sharded step is a sequence of C-ABI calls from Python: time each entry point with HIP events
+        _lib.PROFILE = "all"
+        _lib.profile_summary()
+        for _ in range(args.steps):
+            runner.train_step(c2w, Ks, pixels)
+        prof = {k.replace("_packed", ""): v for k, v in _lib.profile_summary().items()}
+        _lib.PROFILE = None
+        dominant = max(prof.items(), key=lambda kv: kv[1][0] * kv[1][1])[0]
+        dom_calls, dom_ms = prof[dominant]
+    elif fused:
         # Per-kernel durations with HIP events on the launch stream.  Events cannot be recorded
         # inside a hipGraph replay, so the same --steps iterations are re-run un-captured with the
         # library's stage timers on (same kernels, same inputs; parameters keep training).
@@ -228,12 +259,15 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "path": "fused engine (hipGraph replay)" if fused else "operator-level autograd path",
+        "path": ("sharded engine (C-ABI launches + 2 all-to-all)" if runner.sharded else
+                 "fused engine (hipGraph replay)" if fused else "operator-level autograd path"),
         "config": {"workload": f"c2: {N} Gaussians (reference random init, '{args.regime}' preset), "
                                f"{W}x{H}, SH degree 3, 1 view per GPU per step, pinhole",
                    "views_per_step": world, "visible_gaussians": V, "tile_intersections": I,
-                   "parallelism": f"view-sharded dp{world}"},
-        "forward_mpix_per_s": world * P / fwd_s / 1e6,
+                   "parallelism": (f"gaussian-sharded dp{world}: one view per GPU, N/{world} Gaussians per GPU, "
+                                   "projected Gaussians exchanged by all-to-all" if runner.sharded else
+                                   f"view-sharded dp{world}" + (", gradient all-reduce" if world > 1 else ""))},
+        "forward_mpix_per_s": None if runner.sharded else world * P / fwd_s / 1e6,
         "hbm_iter_fraction": b_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9),
         "algorithmic_bytes_per_iter": b_iter,
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,

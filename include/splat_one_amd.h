@@ -244,6 +244,11 @@ int so_adam_step_dev(int n_groups, const so_adam_group *host_groups, const float
  *   for the rasteriser's gathers) and zeroes vrec[C*N][16]; so_rasterize_bwd_packed accumulates
  *   {v_x, v_y, v_ca, v_cb, v_cc, v_r, v_g, v_b, v_opacity, abs_x, abs_y, 0...} there and the backward
  *   reads them from `vrec` instead of the five separate v_* arrays.
+ * cam_stride (0 = N): row stride between cameras of every per-view array and of rec / vrec -- lets a
+ *   rank whose shard is shorter than the exchange buffers use them in place.  tile_counts may be NULL
+ *   (no histogram: Gaussian-sharded runs bin after the exchange, on the records of all shards).
+ * so_rec_unpack: from rec[n][16] writes means2d[n,2], radii[n], depths[n] (the inputs of so_isect_count /
+ *   so_isect_fill) and zeroes vrec[n][16] (nullable).
  * ---------------------------------------------------------------------------------------- */
 int so_preprocess_fwd(int C, int N, int K, int sh_degree, const float *means, const float *log_scales,
                       const float *quats, const float *logit_opacities, const float *sh0, const float *shN,
@@ -251,7 +256,7 @@ int so_preprocess_fwd(int C, int N, int K, int sh_degree, const float *means, co
                       float near_plane, float far_plane, float radius_clip, int camera_model, int antialiased,
                       int tile_size, int32_t *radii, float *means2d, float *depths, float *conics,
                       float *opacities, float *colors, int32_t *tiles_per_gauss, int32_t *tile_counts,
-                      float *rec, float *vrec, void *stream);
+                      float *rec, float *vrec, int64_t cam_stride, void *stream);
 int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float *means, const float *log_scales,
                       const float *quats, const float *logit_opacities, const float *sh0, const float *shN,
                       const float *viewmats, const float *Ks, int width, int height, float eps2d,
@@ -260,7 +265,9 @@ int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float *means, co
                       const float *v_depths, const float *v_conics, const float *v_colors,
                       const float *v_opacities, float opacity_reg, float scale_reg, float *v_means,
                       float *v_log_scales, float *v_quats, float *v_logit_opacities, float *v_sh0, float *v_shN,
-                      float *grad2d, float *count, const float *vrec, int absgrad_stats, void *stream);
+                      float *grad2d, float *count, const float *vrec, int absgrad_stats, int64_t cam_stride, void *stream);
+int so_rec_unpack(int64_t n, const float *rec, float *means2d, int32_t *radii, float *depths, float *vrec,
+                  void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * One training iteration (gsplat_trainer.py:586-655: render -> loss -> backward) as ONE call on

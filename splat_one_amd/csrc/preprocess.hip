@@ -46,13 +46,14 @@ k_preprocess_fwd(int C, int N, int K, const float *__restrict__ means, const flo
                  int32_t *__restrict__ radii, float *__restrict__ means2d, float *__restrict__ depths,
                  float *__restrict__ conics, float *__restrict__ opacities, float *__restrict__ colors,
                  int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ tile_counts,
-                 float4 *__restrict__ rec, float4 *__restrict__ vrec) {
+                 float4 *__restrict__ rec, float4 *__restrict__ vrec, int64_t cam_stride) {
   const int64_t total = (int64_t)C * N;
   const int n_tiles = tile_w * tile_h;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(idx / N);
-    const int64_t n = idx - (int64_t)c * N;
+  for (int64_t lin = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; lin < total;
+       lin += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(lin / N);
+    const int64_t n = lin - (int64_t)c * N;
+    const int64_t idx = (int64_t)c * cam_stride + n;   // row of the per-view arrays (cam_stride >= N)
     const CamP cam = load_camp(viewmats, Ks, c);
     const float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
     const float4 qq = *reinterpret_cast<const float4 *>(quats + 4 * n);
@@ -89,9 +90,11 @@ k_preprocess_fwd(int C, int N, int K, const float *__restrict__ means, const flo
       const int y0 = (int)fminf(fmaxf(floorf(ty - tile_r), 0.f), (float)tile_h);
       const int y1 = (int)fminf(fmaxf(ceilf(ty + tile_r), 0.f), (float)tile_h);
       cnt = (x1 - x0) * (y1 - y0);
-      int32_t *row = tile_counts + (int64_t)c * n_tiles;
-      for (int y = y0; y < y1; ++y)
-        for (int x = x0; x < x1; ++x) atomicAdd(row + y * tile_w + x, 1);
+      if (tile_counts) {   // null: the caller bins later (Gaussian-sharded runs bin after the exchange)
+        int32_t *row = tile_counts + (int64_t)c * n_tiles;
+        for (int y = y0; y < y1; ++y)
+          for (int x = x0; x < x1; ++x) atomicAdd(row + y * tile_w + x, 1);
+      }
     }
     colors[3 * idx] = r; colors[3 * idx + 1] = g; colors[3 * idx + 2] = b;
     tiles_per_gauss[idx] = cnt;
@@ -124,7 +127,7 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
                  float *__restrict__ v_means, float *__restrict__ v_log_scales, float *__restrict__ v_quats,
                  float *__restrict__ v_logit_opac, float *__restrict__ v_sh0, float *__restrict__ v_shN,
                  float *__restrict__ grad2d, float *__restrict__ count, float stat_sx, float stat_sy,
-                 const float4 *__restrict__ vrec, int use_abs_stats) {
+                 const float4 *__restrict__ vrec, int use_abs_stats, int64_t cam_stride) {
   constexpr int NB = (DEG + 1) * (DEG + 1);
   for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
     const float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
@@ -139,7 +142,7 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
     for (int k = 0; k < NB; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.f;
     const bool use_abs = use_abs_stats != 0;
     for (int c = 0; c < C; ++c) {
-      const int64_t idx = (int64_t)c * N + n;
+      const int64_t idx = (int64_t)c * cam_stride + n;
       if (radii[idx] <= 0) continue;
       const CamP cam = load_camp(viewmats, Ks, c);
       float2 vm2;
@@ -212,6 +215,24 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
   }
 }
 
+// Gaussian-sharded data parallelism: after the all-to-all a rank holds the 64-byte records of ALL Gaussians
+// for its own camera.  Unpack what the binning kernels read (centre, radius, depth) and clear the gradient
+// records the rasteriser backward accumulates into.
+__global__ void __launch_bounds__(256)
+k_rec_unpack(int64_t n, const float4 *__restrict__ rec, float2 *__restrict__ means2d, int32_t *__restrict__ radii,
+             float *__restrict__ depths, float4 *__restrict__ vrec) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 q0 = rec[4 * i], q2 = rec[4 * i + 2];
+    means2d[i] = make_float2(q0.x, q0.y);
+    depths[i] = q2.y;
+    radii[i] = __float_as_int(q2.z);
+    if (vrec) {
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      vrec[4 * i] = z; vrec[4 * i + 1] = z; vrec[4 * i + 2] = z; vrec[4 * i + 3] = z;
+    }
+  }
+}
+
 static inline int pp_grid(int64_t total) {
   int64_t g = ceil_div(total, 256);
   return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -226,7 +247,7 @@ extern "C" int so_preprocess_fwd(int C, int N, int K, int sh_degree, const float
                                  int camera_model, int antialiased, int tile_size, int32_t *radii, float *means2d,
                                  float *depths, float *conics, float *opacities, float *colors,
                                  int32_t *tiles_per_gauss, int32_t *tile_counts, float *rec, float *vrec,
-                                 void *stream) {
+                                 int64_t cam_stride, void *stream) {
   SO_REQUIRE(C >= 0 && N >= 0 && K >= 1 && width > 0 && height > 0 && tile_size > 0, "so_preprocess_fwd: bad sizes");
   SO_REQUIRE(sh_degree >= 0 && sh_degree <= 4 && (sh_degree + 1) * (sh_degree + 1) <= K,
              "so_preprocess_fwd: sh_degree %d does not fit K=%d", sh_degree, K);
@@ -236,8 +257,10 @@ extern "C" int so_preprocess_fwd(int C, int N, int K, int sh_degree, const float
   }
   if ((int64_t)C * N == 0) return SO_OK;
   SO_REQUIRE(means && log_scales && quats && logit_opacities && sh0 && (shN || K == 1) && viewmats && Ks && radii &&
-                 means2d && depths && conics && opacities && colors && tiles_per_gauss && tile_counts,
+                 means2d && depths && conics && opacities && colors && tiles_per_gauss,
              "so_preprocess_fwd: null pointer");
+  if (cam_stride == 0) cam_stride = N;
+  SO_REQUIRE(cam_stride >= N, "so_preprocess_fwd: cam_stride %lld < N %d", (long long)cam_stride, N);
   const int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
   const dim3 grid(so::pp_grid((int64_t)C * N)), block(256);
   hipStream_t st = so::as_stream(stream);
@@ -246,7 +269,7 @@ extern "C" int so_preprocess_fwd(int C, int N, int K, int sh_degree, const float
                      logit_opacities, sh0, shN, viewmats, Ks, width, height, eps2d, near_plane, far_plane,         \
                      radius_clip, camera_model, antialiased, (float)tile_size, tile_w, tile_h, radii, means2d,     \
                      depths, conics, opacities, colors, tiles_per_gauss, tile_counts,                              \
-                     reinterpret_cast<float4 *>(rec), reinterpret_cast<float4 *>(vrec))
+                     reinterpret_cast<float4 *>(rec), reinterpret_cast<float4 *>(vrec), cam_stride)
   switch (sh_degree) {
     case 0: SO_LAUNCH(0); break;
     case 1: SO_LAUNCH(1); break;
@@ -267,7 +290,7 @@ extern "C" int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float
                                  const float *v_colors, const float *v_opacities, float opacity_reg,
                                  float scale_reg, float *v_means, float *v_log_scales, float *v_quats,
                                  float *v_logit_opacities, float *v_sh0, float *v_shN, float *grad2d, float *count,
-                                 const float *vrec, int absgrad_stats, void *stream) {
+                                 const float *vrec, int absgrad_stats, int64_t cam_stride, void *stream) {
   SO_REQUIRE(C >= 0 && N >= 0 && K >= 1 && width > 0 && height > 0, "so_preprocess_bwd: bad sizes");
   SO_REQUIRE(sh_degree >= 0 && sh_degree <= 4 && (sh_degree + 1) * (sh_degree + 1) <= K,
              "so_preprocess_bwd: sh_degree %d does not fit K=%d", sh_degree, K);
@@ -281,6 +304,8 @@ extern "C" int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float
                  v_log_scales && v_quats && v_logit_opacities && v_sh0 && (v_shN || K == 1),
              "so_preprocess_bwd: null pointer");
   SO_REQUIRE((((uintptr_t)vrec) & 63) == 0, "so_preprocess_bwd: vrec must be 64-byte aligned");
+  if (cam_stride == 0) cam_stride = N;
+  SO_REQUIRE(cam_stride >= N, "so_preprocess_bwd: cam_stride %lld < N %d", (long long)cam_stride, N);
   if (!vrec && v_means2d_abs) absgrad_stats = 1;
   SO_REQUIRE((grad2d == nullptr) == (count == nullptr), "so_preprocess_bwd: grad2d and count go together");
   const dim3 grid(so::pp_grid(N)), block(256);
@@ -291,7 +316,7 @@ extern "C" int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float
                      logit_opacities, sh0, shN, viewmats, Ks, width, height, eps2d, camera_model, antialiased,    \
                      radii, opacities, colors, v_means2d, v_means2d_abs, v_depths, v_conics, v_colors,            \
                      v_opacities, opacity_reg, scale_reg, v_means, v_log_scales, v_quats, v_logit_opacities,      \
-                     v_sh0, v_shN, grad2d, count, sx, sy, reinterpret_cast<const float4 *>(vrec), absgrad_stats)
+                     v_sh0, v_shN, grad2d, count, sx, sy, reinterpret_cast<const float4 *>(vrec), absgrad_stats, cam_stride)
   switch (sh_degree) {
     case 0: SO_LAUNCH(0); break;
     case 1: SO_LAUNCH(1); break;
@@ -301,4 +326,16 @@ extern "C" int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float
   }
 #undef SO_LAUNCH
   return so::check_launch("so_preprocess_bwd");
+}
+
+extern "C" int so_rec_unpack(int64_t n, const float *rec, float *means2d, int32_t *radii, float *depths, float *vrec,
+                             void *stream) {
+  SO_REQUIRE(n >= 0, "so_rec_unpack: bad size");
+  if (n == 0) return SO_OK;
+  SO_REQUIRE(rec && means2d && radii && depths, "so_rec_unpack: null pointer");
+  SO_REQUIRE(((((uintptr_t)rec) | ((uintptr_t)vrec)) & 63) == 0, "so_rec_unpack: records must be 64-byte aligned");
+  hipLaunchKernelGGL(so::k_rec_unpack, dim3(so::pp_grid(n)), dim3(256), 0, so::as_stream(stream), n,
+                     reinterpret_cast<const float4 *>(rec), reinterpret_cast<float2 *>(means2d), radii, depths,
+                     reinterpret_cast<float4 *>(vrec));
+  return so::check_launch("so_rec_unpack");
 }

@@ -39,10 +39,12 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:   # SPLAT_ONE_AMD_BACKEND=gloo: several ranks on one GPU (tests of the multi-GPU paths)
+            backend = os.environ.get("SPLAT_ONE_AMD_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
+        elif torch.cuda.is_available():
+            local_rank = local_rank % torch.cuda.device_count()
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return local_rank, rank, world
 

@@ -18,9 +18,10 @@ same.  The callers either side of the loop are 
 Out of scope: the viewer itself, TensorBoard, compression,
 pose/appearance/bilateral-grid modules, video encoding (frames are returned / written as PNG).
 
-Multi-GPU: view-sharded data parallelism (splat_one_amd.distributed), not the reference's
-Gaussian sharding; the random init is therefore NOT strided over ranks (every rank holds all
-Gaussians) unless `shard_gaussians=True` reproduces `points[world_rank::world_size]` (:236-238).
+Multi-GPU: every rank renders its own view.  `Config.dp_mode = "gaussian_sharded"` (default on the
+fused path) is the reference's scheme -- Gaussians strided over ranks as `points[world_rank::world_size]`
+(:236-238), projected Gaussians exchanged by all-to-all (splat_one_amd/sharded.py); "allreduce" keeps
+every Gaussian on every rank and all-reduces the gradients (splat_one_amd.distributed).
 """
 from __future__ import annotations
 
@@ -80,6 +81,11 @@ class Config:
     # extensions of this build
     isect_capacity: Optional[int] = None   # preallocated intersections -> no host sync in the step
     fused: bool = False                    # FusedEngine: whole step in two C-ABI calls, hipGraph replay
+    # multi-GPU scheme (world_size > 1, fused path, one view per rank per step):
+    #   "gaussian_sharded"  the reference's own: every rank owns N/world Gaussians, projected Gaussians are
+    #                       exchanged (two all-to-alls of ~64 B/Gaussian), per-rank densification / checkpoints;
+    #   "allreduce"         replicated Gaussians, one all-reduce of the 236 B/Gaussian gradient SoA
+    dp_mode: str = "gaussian_sharded"
     shN_init_std: float = 0.0              # >0: noise instead of zeros in the higher SH bands (bench scenes)
 
     def adjust_steps(self, factor: float):
@@ -169,12 +175,15 @@ class Runner:
         self.device = f"cuda:{local_rank}"
         self.views = views if views is not None else []
         self.scene_scale = scene_scale * 1.1 * cfg.global_scale          # gsplat_trainer.py:322
+        self.sharded = (world_size > 1 and cfg.fused and cfg.dp_mode == "gaussian_sharded" and cfg.batch_size == 1
+                        and sdist.is_initialized())
+        assert cfg.dp_mode in ("gaussian_sharded", "allreduce"), cfg.dp_mode
         self.splats, self.optimizers = create_splats_with_optimizers(
             points, rgbs, init_type=cfg.init_type, init_num_pts=cfg.init_num_pts, init_extent=cfg.init_extent,
             init_opacity=cfg.init_opa, init_scale=cfg.init_scale, scene_scale=self.scene_scale,
             sh_degree=cfg.sh_degree, sparse_grad=cfg.sparse_grad, visible_adam=cfg.visible_adam,
             batch_size=cfg.batch_size, device=self.device, world_rank=world_rank, world_size=world_size,
-            shN_init_std=cfg.shN_init_std)
+            shard_gaussians=self.sharded, shN_init_std=cfg.shN_init_std)
         self.cfg.strategy.check_sanity(self.splats, self.optimizers)
         if isinstance(self.cfg.strategy, MCMCStrategy):
             self.strategy_state = self.cfg.strategy.initialize_state()           # gsplat_trainer.py:351-352
@@ -379,18 +388,38 @@ class Runner:
                                              sh_degree=self.cfg.sh_degree, radius_clip=3.0, camera_model=camera_model)
         return colors[0, ..., :3].cpu().numpy()
 
+    @torch.no_grad()
+    def full_splats(self) -> Dict[str, Tensor]:
+        """All shards of a gaussian_sharded run concatenated in rank order (COLLECTIVE: every rank calls it);
+        the eval / viewer renders need every Gaussian on the rendering rank."""
+        import torch.distributed as dist
+        n_loc = torch.tensor([len(self.splats["means"])], device=self.device)
+        sizes = [torch.zeros_like(n_loc) for _ in range(self.world_size)]
+        dist.all_gather(sizes, n_loc)
+        sizes = [int(t.item()) for t in sizes]
+        cap = max(sizes)
+        out = {}
+        for k, v in self.splats.items():
+            buf = torch.zeros((cap,) + tuple(v.shape[1:]), dtype=v.dtype, device=self.device)
+            buf[:v.shape[0]] = v.detach()
+            parts = [torch.empty_like(buf) for _ in range(self.world_size)]
+            dist.all_gather(parts, buf)
+            out[k] = torch.cat([p[:m] for p, m in zip(parts, sizes)])
+        return out
+
     # ------------------------------------------------------------------------------ :446-497
     def rasterize_splats(self, camtoworlds: Tensor, Ks: Tensor, width: int, height: int,
                          masks: Optional[Tensor] = None, camera_model: Optional[str] = None,
                          **kwargs) -> Tuple[Tensor, Tensor, Dict]:
-        means = self.splats["means"]
-        quats = self.splats["quats"]
-        scales = torch.exp(self.splats["scales"])
-        opacities = torch.sigmoid(self.splats["opacities"])
+        sp = self.full_splats() if self.sharded else self.splats
+        means = sp["means"]
+        quats = sp["quats"]
+        scales = torch.exp(sp["scales"])
+        opacities = torch.sigmoid(sp["opacities"])
         if camera_model is None:
             camera_model = self.cfg.camera_model
         kwargs.pop("image_ids", None)
-        colors = torch.cat([self.splats["sh0"], self.splats["shN"]], 1)
+        colors = torch.cat([sp["sh0"], sp["shN"]], 1)
         rasterize_mode = "antialiased" if self.cfg.antialiased else "classic"
         render_colors, render_alphas, info = rasterization(
             means=means, quats=quats, scales=scales, opacities=opacities, colors=colors,
@@ -483,10 +512,67 @@ class Runner:
         self.step += 1
         return eng.loss()[0]
 
+    def _train_step_sharded(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor) -> Tensor:
+        """Gaussian-sharded step (splat_one_amd/sharded.py): camtoworlds / Ks hold the cameras of ALL ranks,
+        pixels the own view.  Densification runs on the own shard with its own statistics, like the
+        reference's per-rank strategy state."""
+        from .sharded import ShardedEngine
+        cfg, step, s = self.cfg, self.step, self.cfg.strategy
+        H, W = pixels.shape[1], pixels.shape[2]
+        eng = getattr(self, "_engine", None)
+        if eng is None or (eng.H, eng.W) != (H, W):
+            eng = self._engine = ShardedEngine(
+                self.splats, self.optimizers, W, H, self.world_rank, self.world_size, sh_degree=0,
+                camera_model=cfg.camera_model, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
+                antialiased=cfg.antialiased, absgrad=getattr(s, "absgrad", False), ssim_lambda=cfg.ssim_lambda,
+                opacity_reg=cfg.opacity_reg, scale_reg=cfg.scale_reg,
+                strategy_state=(self.strategy_state if isinstance(s, DefaultStrategy) else None),
+                lr_gamma_means=self.lr_gamma, isect_capacity=cfg.isect_capacity)
+            eng.steps_done = step
+            eng._step_dev[0] = step
+        eng.set_sh_degree(min(step // cfg.sh_degree_interval, cfg.sh_degree))
+        stats_on = isinstance(s, DefaultStrategy) and step < s.refine_stop_iter
+        eng.strategy_state = self.strategy_state if stats_on else None
+        eng.step(camtoworlds, Ks, pixels)
+        changed = False
+        if isinstance(s, MCMCStrategy):
+            n_rel, n_new = s.step_post_backward(params=self.splats, optimizers=self.optimizers,
+                                                state=self.strategy_state, step=step, info={},
+                                                lr=self.optimizers["means"].param_groups[0]["lr"],
+                                                generator=self._split_gen)
+            # ranks refine on the same steps, so the collective inside rebuild() is matched even when only
+            # some shards changed
+            changed = (step < s.refine_stop_iter and step > s.refine_start_iter and step % s.refine_every == 0)
+        else:
+            refine_now = (step < s.refine_stop_iter and step > s.refine_start_iter and step % s.refine_every == 0
+                          and step % s.reset_every >= s.pause_refine_after_reset)
+            reset_now = step < s.refine_stop_iter and step % s.reset_every == 0 and step > 0
+            if refine_now:
+                s._grow_gs(self.splats, self.optimizers, self.strategy_state, step, self._split_gen)
+                s._prune_gs(self.splats, self.optimizers, self.strategy_state, step)
+                self.strategy_state["grad2d"].zero_()
+                self.strategy_state["count"].zero_()
+            if reset_now:
+                from .strategy import reset_opa
+                reset_opa(params=self.splats, optimizers=self.optimizers, state=self.strategy_state,
+                          value=s.prune_opa * 2.0)
+            changed = refine_now or reset_now
+        if changed:
+            eng.rebuild()
+        self.last_info = {"radii": eng.ws["radii_full"], "n_isects": eng.ws["counters"][2 * eng.M + 1:2 * eng.M + 2],
+                          "flatten_ids": eng.ws["flatten_ids"], "means2d": eng.ws["means2d_full"]}
+        self.step += 1
+        return eng.loss()[0]
+
     def train_step(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor, masks: Optional[Tensor] = None) -> Tensor:
         """One iteration on an already-on-device batch (camtoworlds[B,4,4], Ks[B,3,3],
-        pixels[B,H,W,3] in 0..1).  Returns the loss tensor (no host sync; on the fused path it is a
+        pixels[B,H,W,3] in 0..1; in gaussian_sharded runs the cameras of ALL ranks and the own image).  Returns the loss tensor (no host sync; on the fused path it is a
         view of the engine's static loss buffer, valid until the next step -- clone it to keep it)."""
+        if self.sharded:
+            assert self._fused_ok(masks), "gaussian_sharded runs need the fused path (no masks / random background)"
+            assert camtoworlds.shape[0] == self.world_size and pixels.shape[0] == 1, \
+                "gaussian_sharded: pass the cameras of all ranks [world,4,4] / [world,3,3] and the own image [1,H,W,3]"
+            return self._train_step_sharded(camtoworlds, Ks, pixels)
         if self._fused_ok(masks):
             return self._train_step_fused(camtoworlds, Ks, pixels)
         cfg, step = self.cfg, self.step
@@ -578,13 +664,36 @@ class Runner:
                 resident[i] = t
             return t
 
+        def camera_of(i: int):
+            """Camera of view i without decoding its image (the other ranks' cameras of a sharded step)."""
+            if i in resident:
+                return resident[i][0], resident[i][1]
+            ps = getattr(self.views, "parser", None)
+            if ps is not None:
+                g = int(self.views.indices[i])
+                return (torch.from_numpy(ps.camtoworlds[g]).float().to(dev),
+                        torch.from_numpy(ps.Ks_dict[ps.camera_ids[g]]).float().to(dev))
+            v = self.views[i]
+            return v["camtoworld"].to(dev), v["K"].to(dev)
+
+        if self.sharded:
+            assert B == 1 and cfg.patch_size is None, "gaussian_sharded: one full view per rank per step"
         for _ in range(n):
             if self.stop_training:
                 break
             batch = [fetch(order[(cursor + i) % len(order)]) for i in range(B)]
+            if self.sharded:
+                # every rank derives the cameras of all ranks from the same sampling rule: no collective
+                cams = []
+                for j in range(self.world_size):
+                    oj = list(range(j, len(self.views), self.world_size)) or [0]
+                    cams.append(batch[0][:2] if j == self.world_rank else camera_of(oj[cursor % len(oj)]))
+                c2w = torch.stack([c[0] for c in cams])
+                Ks = torch.stack([c[1] for c in cams])
+            else:
+                c2w = torch.stack([b[0] for b in batch])
+                Ks = torch.stack([b[1] for b in batch])
             cursor += B
-            c2w = torch.stack([b[0] for b in batch])
-            Ks = torch.stack([b[1] for b in batch])
             pixels = torch.stack([b[2] for b in batch])
             step = self.step
             self.train_step(c2w, Ks, pixels)

@@ -1,6 +1,7 @@
 """N>1 path on CPU: world_size 2 over gloo.  Covers the launcher (`cli`), the single flattened
-gradient all-reduce of the view-sharded data parallelism and the densification-statistics
-all-reduce that keeps replicated Gaussians identical on every rank."""
+gradient all-reduce of the replicated data parallelism, the densification-statistics all-reduce that
+keeps replicated Gaussians identical on every rank, and the equal-split all-to-all of the
+Gaussian-sharded scheme (the full sharded step runs in tests/test_gpu_trainer.py)."""
 import os
 import socket
 
@@ -37,6 +38,14 @@ def _worker_fn(local_rank, world_rank, world_size, out_dir):
              "scene_scale": 1.0}
     sdist.all_reduce_strategy_state(state)
     assert torch.allclose(state["grad2d"], torch.full((10,), 3.0)) and torch.allclose(state["count"], torch.full((10,), 5.0))
+    # Gaussian-sharded exchange: block j of the send buffer lands on rank j, in source-rank order
+    from splat_one_amd.sharded import all_to_all_rows
+    cap = 3
+    send = torch.stack([torch.full((cap, 16), 10.0 * world_rank + j) for j in range(world_size)]).reshape(-1, 16)
+    recv = torch.empty_like(send)
+    all_to_all_rows(recv, send)
+    want = torch.stack([torch.full((cap, 16), 10.0 * j + world_rank) for j in range(world_size)]).reshape(-1, 16)
+    assert torch.equal(recv, want), (world_rank, recv[:, 0])
     torch.save({"ok": True, "rank": world_rank}, os.path.join(out_dir, f"rank{world_rank}.pt"))
 
 

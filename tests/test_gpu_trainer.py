@@ -65,7 +65,8 @@ def _dp_worker(local_rank, world_rank, world_size, out_dir):
     from splat_one_amd.trainer import Config, Runner
     dev = torch.device("cuda:0")                     # both ranks share the one GPU of the test box
     W, H, N = 128, 96, 3000
-    cfg = Config(init_num_pts=N, init_scale=0.3, init_opa=0.3, shN_init_std=0.05, sh_degree_interval=1, fused=True)
+    cfg = Config(init_num_pts=N, init_scale=0.3, init_opa=0.3, shN_init_std=0.05, sh_degree_interval=1, fused=True,
+                 dp_mode="allreduce")
     r = Runner(0, world_rank, world_size, cfg, scene_scale=1.0 / 1.1)
     with torch.no_grad():   # anisotropic scales: otherwise the quaternion gradient is pure rounding noise
         r.splats["scales"].add_((torch.randn(N, 3, generator=torch.Generator().manual_seed(7)) * 0.4).to(dev))
@@ -108,3 +109,79 @@ def test_view_sharded_dp_two_ranks_one_gpu(dev, tmp_path):
     for k in a:
         ref = r.splats[k].detach().cpu()
         assert ((a[k] - ref).norm() / ref.norm()).item() < 2e-4, k
+
+
+def _global_perturbation(N):
+    g = torch.Generator().manual_seed(7)
+    return torch.randn(N, 3, generator=g) * 0.4, torch.rand(N, 4, generator=g), torch.randn(N, 15, 3, generator=g) * 0.05
+
+
+def _sharded_worker(local_rank, world_rank, world_size, out_dir):
+    from splat_one_amd.trainer import Config, Runner
+    dev = torch.device("cuda:0")
+    W, H, N = 128, 96, 3001                           # odd: the shards differ in length (1501 / 1500)
+    cfg = Config(init_num_pts=N, init_scale=0.3, init_opa=0.3, sh_degree_interval=1, fused=True, opacity_reg=0.01,
+                 scale_reg=0.01, dp_mode="gaussian_sharded")
+    r = Runner(0, world_rank, world_size, cfg, scene_scale=1.0 / 1.1)
+    assert r.sharded and len(r.splats["means"]) == len(range(world_rank, N, world_size))
+    ds, q, sh = _global_perturbation(N)
+    with torch.no_grad():   # attributes drawn after the sharding in the reference: pin them to a global table
+        r.splats["scales"].add_(ds[world_rank::world_size].to(dev))
+        r.splats["quats"].copy_(q[world_rank::world_size].to(dev))
+        r.splats["shN"].copy_(sh[world_rank::world_size].to(dev))
+    c2w = ring_cameras(8)[:world_size].to(dev)         # the cameras of ALL ranks
+    Ks = pinhole_K(W, H)[None].repeat(world_size, 1, 1).to(dev)
+    pixels = torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(100 + world_rank)).to(dev)
+    losses = []
+    for _ in range(4):
+        losses.append(r.train_step(c2w, Ks, pixels).clone())
+    full = r.full_splats()
+    st = r._engine.stats()
+    torch.cuda.synchronize()
+    torch.save({"splats": {k: v.detach().cpu() for k, v in r.splats.items()}, "full": {k: v.cpu() for k, v in full.items()},
+                "loss": torch.stack(losses).cpu(), "stats": st}, os.path.join(out_dir, f"rank{world_rank}.pt"))
+
+
+def test_gaussian_sharded_dp_two_ranks_one_gpu(dev, tmp_path):
+    """world_size 2 over gloo with HIP tensors: the two shards, trained with the all-to-all exchange of
+    projected Gaussians, equal the corresponding rows of a single-process batch-of-2 run."""
+    from splat_one_amd import distributed as sdist
+    from splat_one_amd.trainer import Config, Runner
+    env_backup = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        sdist.cli(_sharded_worker, str(tmp_path), world_size=2, backend="gloo", port=_free_port())
+    finally:
+        for k, v in env_backup.items():
+            if v is not None:
+                os.environ[k] = v
+    out = [torch.load(os.path.join(tmp_path, f"rank{i}.pt")) for i in range(2)]
+    W, H, N = 128, 96, 3001
+    cfg = Config(init_num_pts=N, init_scale=0.3, init_opa=0.3, sh_degree_interval=1, fused=True, batch_size=2,
+                 opacity_reg=0.01, scale_reg=0.01)
+    r = Runner(0, 0, 1, cfg, scene_scale=1.0 / 1.1)
+    ds, q, sh = _global_perturbation(N)
+    with torch.no_grad():
+        r.splats["scales"].add_(ds.to(dev))
+        r.splats["quats"].copy_(q.to(dev))
+        r.splats["shN"].copy_(sh.to(dev))
+    c2w = ring_cameras(8)[0:2].to(dev)
+    Ks = pinhole_K(W, H)[None].repeat(2, 1, 1).to(dev)
+    pixels = torch.cat([torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(100 + i)) for i in range(2)]).to(dev)
+    ref_loss = []
+    for _ in range(4):
+        ref_loss.append(r.train_step(c2w, Ks, pixels).clone())
+    ref_loss = torch.stack(ref_loss).cpu()
+    for k in r.splats.keys():
+        ref = r.splats[k].detach().cpu()
+        for i in range(2):
+            a = out[i]["splats"][k]
+            assert a.shape == ref[i::2].shape, (k, a.shape)
+            assert ((a - ref[i::2]).norm() / ref[i::2].norm()).item() < 2e-4, (k, i)
+        # full_splats: rank-major concatenation, identical on both ranks
+        assert torch.equal(out[0]["full"][k], out[1]["full"][k])
+        assert torch.equal(out[0]["full"][k], torch.cat([out[0]["splats"][k], out[1]["splats"][k]]))
+    # the two per-rank losses carry weight 1/world: their sum is the batch-mean loss of the reference run
+    # (photometric part; the engine's scalar leaves the regularisers out in both)
+    tot = out[0]["loss"] + out[1]["loss"]
+    assert (tot - ref_loss).abs().max().item() < 2e-5, (tot, ref_loss)
+    assert out[0]["stats"]["overflow"] == 0 and out[0]["stats"]["n_isects"] > 0
