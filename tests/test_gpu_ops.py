@@ -330,3 +330,86 @@ def test_camera_inverse(dev):
     _lib.call("so_camera_inverse", 8, _lib.ptr(src), _lib.ptr(out), _lib.stream())
     ref = torch.linalg.inv(c2w.double())
     assert torch.allclose(out.cpu().double(), ref, rtol=1e-6, atol=1e-6)
+
+
+def test_step_inputs_one_launch(dev):
+    """so_step_inputs: camera inverse (vs float64 inverse), intrinsics copy, target-image slot, counter zeroing
+    and the Adam schedule (vs the closed form torch.optim.Adam + ExponentialLR use)."""
+    import ctypes
+    from splat_one_amd import _lib
+    C, nz, ng = 5, 3001, 3
+    g = torch.Generator().manual_seed(3)
+    c2w = torch.eye(4).repeat(C, 1, 1)
+    c2w[:, :3, :3] = torch.linalg.qr(torch.randn(C, 3, 3, generator=g))[0]
+    c2w[:, :3, 3] = torch.randn(C, 3, generator=g) * 4
+    c2w[0, :3, :3] *= 1.7                                        # not rigid: the inverse is the general one
+    Ks = torch.rand(C, 3, 3, generator=g)
+    c2w_d, Ks_d = c2w.to(dev), Ks.to(dev)
+    vm, Kd = torch.empty(C, 4, 4, device=dev), torch.empty(C, 3, 3, device=dev)
+    img = torch.rand(2, 3, device=dev)
+    slot = torch.zeros(1, dtype=torch.int64, device=dev)
+    counters = torch.full((nz + 7,), 77, dtype=torch.int32, device=dev)
+    step_dev = torch.zeros(2 + 4 * _lib.SO_ADAM_MAX_GROUPS, dtype=torch.int32, device=dev)
+    step_dev[0] = 41
+    lr0 = (ctypes.c_float * ng)(1.6e-4, 5e-3, 1e-3)
+    gam = (ctypes.c_float * ng)(0.99985, 1.0, 1.0)
+    b1, b2 = 0.9, 0.999
+    _lib.call("so_step_inputs", C, _lib.ptr(c2w_d), _lib.ptr(Ks_d), _lib.ptr(vm), _lib.ptr(Kd), _lib.ptr(img), _lib.ptr(slot),
+              _lib.ptr(counters), nz, ng, lr0, gam, b1, b2, _lib.ptr(step_dev), _lib.stream())
+    torch.cuda.synchronize()
+    want = torch.linalg.inv(c2w.double())
+    assert (vm.cpu().double() - want).abs().max().item() < 1e-6
+    assert torch.equal(Kd.cpu(), Ks)
+    assert slot.item() == img.data_ptr()
+    assert (counters[:nz] == 0).all() and (counters[nz:] == 77).all()
+    assert step_dev[0].item() == 42                               # schedule evaluated for step 41, counter advanced
+    hyper = step_dev[2:2 + 2 * ng].view(torch.float32).cpu().reshape(ng, 2)
+    for i in range(ng):
+        lr = lr0[i] * gam[i] ** 41
+        assert abs(hyper[i, 0].item() - lr / (1 - b1 ** 42)) <= 1e-6 * lr / (1 - b1 ** 42)
+        assert abs(hyper[i, 1].item() - math.sqrt(1 - b2 ** 42)) < 1e-6
+    # parts are optional: zero only
+    counters.fill_(5)
+    _lib.call("so_step_inputs", 0, 0, 0, 0, 0, 0, 0, _lib.ptr(counters), 10, 0, None, None, 0.0, 0.0, 0, _lib.stream())
+    torch.cuda.synchronize()
+    assert (counters[:10] == 0).all() and (counters[10:] == 5).all() and step_dev[0].item() == 42
+
+
+def test_rec_unpack_and_cam_stride(dev):
+    """so_rec_unpack reads (centre, depth, radius) out of the 64-byte records; so_preprocess_fwd with a camera
+    stride larger than N writes the same rows as the dense call, and a NULL histogram skips the binning pass."""
+    from splat_one_amd import _lib
+    from splat_one_amd.scene import make_scene
+    W, H, N, C, cap = 160, 120, 500, 2, 640
+    splats, c2w, Ks = make_scene(N, W, H, "ref", n_views=C)
+    s = {k: v.to(dev).contiguous() for k, v in splats.items()}
+    vm = torch.linalg.inv(c2w).to(dev).contiguous()
+    Kd = Ks.to(dev).contiguous()
+    K = 1 + s["shN"].shape[1]
+    p = _lib.ptr
+
+    def run(stride, hist):
+        n_rows = C * stride
+        o = dict(radii=torch.zeros(n_rows, dtype=torch.int32, device=dev), means2d=torch.zeros(n_rows, 2, device=dev),
+                 depths=torch.zeros(n_rows, device=dev), conics=torch.zeros(n_rows, 3, device=dev),
+                 opac=torch.zeros(n_rows, device=dev), colors=torch.zeros(n_rows, 3, device=dev),
+                 tpg=torch.zeros(n_rows, dtype=torch.int32, device=dev), rec=torch.zeros(n_rows, 16, device=dev),
+                 hist=torch.zeros(C * 8 * 10, dtype=torch.int32, device=dev))
+        _lib.call("so_preprocess_fwd", C, N, K, 3, p(s["means"]), p(s["scales"]), p(s["quats"]), p(s["opacities"]), p(s["sh0"]),
+                  p(s["shN"]), p(vm), p(Kd), W, H, 0.3, 0.01, 1e8, 0.0, 0, 0, 16, p(o["radii"]), p(o["means2d"]), p(o["depths"]),
+                  p(o["conics"]), p(o["opac"]), p(o["colors"]), p(o["tpg"]), p(o["hist"]) if hist else 0, p(o["rec"]), 0,
+                  stride, _lib.stream())
+        return o
+    dense, strided = run(N, True), run(cap, False)
+    assert dense["hist"].sum().item() == dense["tpg"].sum().item() > 0 and strided["hist"].sum().item() == 0
+    for k in ("radii", "means2d", "depths", "conics", "opac", "colors", "tpg", "rec"):
+        a = dense[k].reshape(C, N, -1)
+        b = strided[k].reshape(C, cap, -1)
+        assert torch.equal(a, b[:, :N]), k
+        assert (b[:, N:] == 0).all(), k                      # padding rows untouched
+    rec = strided["rec"]
+    m2, rad, dep = torch.empty(C * cap, 2, device=dev), torch.empty(C * cap, dtype=torch.int32, device=dev), torch.empty(C * cap, device=dev)
+    vrec = torch.ones(C * cap, 16, device=dev)
+    _lib.call("so_rec_unpack", C * cap, p(rec), p(m2), p(rad), p(dep), p(vrec), _lib.stream())
+    assert torch.equal(m2, strided["means2d"]) and torch.equal(rad, strided["radii"]) and torch.equal(dep, strided["depths"])
+    assert (vrec == 0).all()
