@@ -119,6 +119,8 @@ __device__ __forceinline__ float row_reduce8_transposed(const float (&v)[8], int
 // miscompiled by hipcc 7.2 when both members are added; the s_nop's are the wait states between a VALU
 // write and a cross-lane read of the same register (as for DPP), which the compiler does not insert around
 // inline asm -- without them the swap reads stale operands.  EXEC must be all ones.
+// (v_mfma_f32_16x16x4_f32 with A = 1 does the same sum in one instruction, but its 8 passes plus the 10 wait
+// states before the accumulator can be read measured slower: rasteriser backward 126 vs 112 us.)
 __device__ __forceinline__ float rows_combine(float v) {
 #if defined(__HIP_DEVICE_COMPILE__)
   float a = v, b = v;
