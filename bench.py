@@ -100,8 +100,10 @@ def main():
     ap.add_argument("--operator-path", action="store_true",
                     help="time the operator-level autograd path instead of the fused engine")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel times to stderr")
-    ap.add_argument("--dp-mode", default="gaussian_sharded", choices=["gaussian_sharded", "allreduce"],
-                    help="multi-GPU scheme (ignored at --gpus 1): exchange projected Gaussians, or all-reduce gradients")
+    ap.add_argument("--dp-mode", default="auto", choices=["auto", "gaussian_sharded", "allreduce"],
+                    help="multi-GPU scheme (ignored at --gpus 1): all-reduce of the Gaussian gradients (BASELINE.json's "
+                         "north_star), exchange of projected Gaussians (the reference's own scheme), or auto = time "
+                         "both for a few steps on this node and keep the faster")
     args = ap.parse_args()
 
     from splat_one_amd import _lib, distributed as sdist
@@ -130,19 +132,48 @@ def main():
             return cfg, r, cams.to(dev), pinhole_K(W, H)[None].repeat(world, 1, 1).to(dev)
         return cfg, r, cams[rank:rank + 1].to(dev), pinhole_K(W, H)[None].to(dev)
 
-    cfg, runner, c2w, Ks = make_runner(args.dp_mode)
-    if runner.sharded:
-        # one guarded step: if the exchange path fails on any rank, every rank falls back to the gradient all-reduce
+    def probe(mode, n_warm=8, n_timed=16):
+        """(seconds per step, runner tuple) of one scheme, max over ranks; (inf, None) if any rank failed."""
         ok = torch.ones(1, device=dev)
+        tup, dt = None, float("inf")
         try:
-            runner.train_step(c2w, Ks, pixels)
+            tup = make_runner(mode)
+            for _ in range(n_warm):
+                tup[1].train_step(tup[2], tup[3], pixels)
+            dist.barrier()
             torch.cuda.synchronize()
+            t0 = time.time()
+            for _ in range(n_timed):
+                tup[1].train_step(tup[2], tup[3], pixels)
+            torch.cuda.synchronize()
+            dt = (time.time() - t0) / n_timed
         except Exception as e:   # noqa: BLE001
-            print(f"[bench] gaussian_sharded step failed on rank {rank}: {e!r}; falling back to allreduce", file=sys.stderr)
+            print(f"[bench] dp_mode {mode} failed on rank {rank}: {e!r}", file=sys.stderr)
             ok.zero_()
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if ok.item() == 0:
-            cfg, runner, c2w, Ks = make_runner("allreduce")
+        t = torch.tensor([dt if ok.item() else 1e30], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return (float(t.item()), tup) if ok.item() else (float("inf"), None)
+
+    dp_probe = None
+    if world == 1:
+        cfg, runner, c2w, Ks = make_runner("allreduce")
+    elif args.dp_mode == "auto":
+        t_ar, tup_ar = probe("allreduce")
+        t_gs, tup_gs = probe("gaussian_sharded")
+        dp_probe = {"allreduce_ms": None if tup_ar is None else t_ar * 1e3,
+                    "gaussian_sharded_ms": None if tup_gs is None else t_gs * 1e3}
+        assert tup_ar is not None or tup_gs is not None, "both multi-GPU schemes failed"
+        cfg, runner, c2w, Ks = tup_gs if t_gs < t_ar else tup_ar
+        del tup_ar, tup_gs
+        torch.cuda.empty_cache()
+    else:
+        t_one, tup = probe(args.dp_mode)
+        if tup is None:      # the requested scheme failed on some rank: every rank falls back together
+            other = "allreduce" if args.dp_mode == "gaussian_sharded" else "gaussian_sharded"
+            t_one, tup = probe(other)
+        assert tup is not None, "both multi-GPU schemes failed"
+        cfg, runner, c2w, Ks = tup
 
     def barrier():
         if world > 1:
@@ -266,7 +297,8 @@ def main():
                    "views_per_step": world, "visible_gaussians": V, "tile_intersections": I,
                    "parallelism": (f"gaussian-sharded dp{world}: one view per GPU, N/{world} Gaussians per GPU, "
                                    "projected Gaussians exchanged by all-to-all" if runner.sharded else
-                                   f"view-sharded dp{world}" + (", gradient all-reduce" if world > 1 else ""))},
+                                   f"view-sharded dp{world}" + (", gradient all-reduce" if world > 1 else "")),
+                   "dp_mode_probe_ms_per_step": dp_probe},
         "forward_mpix_per_s": None if runner.sharded else world * P / fwd_s / 1e6,
         "hbm_iter_fraction": b_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9),
         "algorithmic_bytes_per_iter": b_iter,
