@@ -151,9 +151,6 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         }
       }
       unsigned long long mask = __ballot(hit);
-#ifdef SO_RASTER_DBG_NOWALK
-      if (mask != 0x1234567ull) mask = 0;
-#endif
       while (mask) {
         const int bit = __ffsll((long long)mask) - 1;
         mask &= mask - 1;

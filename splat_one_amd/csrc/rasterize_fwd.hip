@@ -123,9 +123,6 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         }
       }
       unsigned long long mask = __ballot(hit);
-#ifdef SO_RASTER_DBG_NOWALK
-      if (mask != 0x1234567ull) mask = 0;
-#endif
       while (mask) {
         if (__ballot(T > 0.f) == 0ull) break;
         const int bit = __ffsll((long long)mask) - 1;
