@@ -65,11 +65,13 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
 
   const float T_final = inside ? 1.f - render_alphas[pix] : 1.f;
   float T = T_final;
-  float buffer[D], v_c[D];
+  // The reference keeps a per-channel "colour behind this Gaussian" buffer and needs only its dot product
+  // with the pixel's upstream colour gradient: carry that scalar (buf_dot = sum_k buffer[k] * v_c[k]).
+  float v_c[D];
+  float buf_dot = 0.f;
   float bg_dot = 0.f;
 #pragma unroll
   for (int k = 0; k < D; ++k) {
-    buffer[k] = 0.f;
     v_c[k] = inside ? v_render_colors[pix * D + k] : 0.f;
     if (backgrounds) bg_dot += backgrounds[c * D + k] * v_c[k];
   }
@@ -173,24 +175,21 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         T *= ra;
         const float fac = alpha_v * T;
         float g_col[D];
-        float v_alpha = tf_bg * ra;   // T_final * ra * (v_a - bg . v_c)
+        float cv = 0.f;                          // sum_k colour[k] * v_c[k]
         if constexpr (D == 3) {
-          const float ck[3] = {bq.z, bq.w, s_col[tt]};
+          cv = fmaf(s_col[tt], v_c[2], fmaf(bq.w, v_c[1], bq.z * v_c[0]));
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            g_col[k] = fac * v_c[k];
-            v_alpha += (ck[k] * T - buffer[k] * ra) * v_c[k];
-            buffer[k] = fmaf(ck[k], fac, buffer[k]);
-          }
+          for (int k = 0; k < 3; ++k) g_col[k] = fac * v_c[k];
         } else {
 #pragma unroll
           for (int k = 0; k < D; ++k) {
-            const float ck = s_col[tt * DC + k];
+            cv = fmaf(s_col[tt * DC + k], v_c[k], cv);
             g_col[k] = fac * v_c[k];
-            v_alpha += (ck * T - buffer[k] * ra) * v_c[k];
-            buffer[k] = fmaf(ck, fac, buffer[k]);
           }
         }
+        // v_alpha = sum_k (c_k T - buffer_k ra) v_c[k] + T_final ra (v_a - bg . v_c)
+        const float v_alpha = fmaf(T, cv, ra * (tf_bg - buf_dot));
+        buf_dot = fmaf(fac, cv, buf_dot);
         const bool grad_on = valid && (ov <= kAlphaMax);   // the clamp at 0.999 has zero slope
         const float v_sigma = grad_on ? -ov * v_alpha : 0.f;
         const float g_op = grad_on ? vis * v_alpha : 0.f;
