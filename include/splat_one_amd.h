@@ -141,7 +141,8 @@ int so_isect_offset_encode(int64_t n_isects, const int64_t *isect_ids, int C, in
  *   means2d[C,N,2] conics[C,N,3] colors[C,N,D] opacities[C,N]; backgrounds[C,D] nullable;
  *   tile_masks[C,tile_h,tile_w] u8 nullable; isect_offsets[C,tile_h,tile_w]; flatten_ids[>=n_isects].
  *   n_isects is read from the device pointer `n_isects_dev` when it is non-NULL, else the host
- *   value `n_isects_host` is used.  D in {1,2,3,4,5,8,9,16,17,32,33}.  tile_size in {8,16}.
+ *   value `n_isects_host` is used; with both given (host value > 0) the smaller one counts -- pass the
+ *   capacity of `flatten_ids` there so that an overflowed binning pass is never walked past the buffer.  D in {1,2,3,4,5,8,9,16,17,32,33}.  tile_size in {8,16}.
  *   -> render_colors[C,H,W,D], render_alphas[C,H,W], last_ids[C,H,W] i32.
  * Backward: v_means2d[C,N,2], v_conics[C,N,3], v_colors[C,N,D], v_opacities[C,N] and the
  * nullable v_means2d_abs[C,N,2] (`absgrad`) must be zero-initialised; they are accumulated with
@@ -226,7 +227,8 @@ int so_adam_step(int n_groups, const so_adam_group *host_groups, double beta1, d
  * increments the counter afterwards.  Launch arguments are therefore constant across iterations. */
 int so_adam_step_dev(int n_groups, const so_adam_group *host_groups, const float *host_lr0,
                      const float *host_lr_gamma, double beta1, double beta2, double eps, int32_t *step_counter,
-                     int zero_grad, int schedule_done, void *stream);
+                     int zero_grad, int schedule_done, const int32_t *skip_if_nonzero_i32,
+                     const float *skip_if_nonzero_f32, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused front end / back end on the RAW parameters (what `Runner.rasterize_splats` holds,
@@ -265,7 +267,8 @@ int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float *means, co
                       const float *v_depths, const float *v_conics, const float *v_colors,
                       const float *v_opacities, float opacity_reg, float scale_reg, float *v_means,
                       float *v_log_scales, float *v_quats, float *v_logit_opacities, float *v_sh0, float *v_shN,
-                      float *grad2d, float *count, const float *vrec, int absgrad_stats, int64_t cam_stride, void *stream);
+                      float *grad2d, float *count, const float *vrec, int absgrad_stats, int64_t cam_stride, const int32_t *skip_if_nonzero,
+                      float *skip_flag_out, void *stream);
 int so_rec_unpack(int64_t n, const float *rec, float *means2d, int32_t *radii, float *depths, float *vrec,
                   void *stream);
 
@@ -308,6 +311,12 @@ typedef struct so_step_desc {
    *   inputs_staged    != 0: `counters` (and the loss sums behind them) are already zero, skip that launch. */
   const float *const *pixels_indirect;
   int32_t inputs_staged, reserved0;
+  /* A binning pass that does not fit `isect_capacity` raises counters[2M+2] (overflow).  The iteration is then
+   * VOID: lists are walked only up to the capacity (no out-of-bounds access), so_preprocess_bwd leaves the
+   * gradients and densification statistics untouched, and so_adam_step_dev skips when given that flag.
+   * overflow_flag_out (nullable): 1.0f / 0.0f copy of the flag, e.g. a spare slot behind the flat gradient
+   * buffer so that a gradient all-reduce carries "some rank overflowed" to every rank. */
+  float *overflow_flag_out;
 } so_step_desc;
 int so_train_step_fwd_bwd(const so_step_desc *desc, void *stream);
 /* Everything that changes from one iteration to the next, in ONE launch, so that a captured step needs
@@ -317,11 +326,14 @@ int so_train_step_fwd_bwd(const so_step_desc *desc, void *stream);
  *   *pixels_slot = pixels (nullable pair; see so_step_desc.pixels_indirect);
  *   counters[0 .. n_zero) = 0 (int32 words; nullable);
  *   n_groups > 0: the Adam schedule of so_adam_step_dev for the step in step_counter[0] (hyper-parameters
- *   written behind the counter, counter advanced) -- pass schedule_done = 1 to so_adam_step_dev then. */
+ *   written behind the counter, counter advanced) -- pass schedule_done = 1 to so_adam_step_dev then;
+ *   status_out (nullable, host-mapped int32[3]): before zeroing, counters[status_at] and [status_at+1]
+ *   (n_isects and overflow of the PREVIOUS iteration on these buffers) are published as
+ *   {n_isects, overflow, seq} -- the host learns of a void iteration one step late, without a device sync. */
 int so_step_inputs(int C, const float *camtoworlds, const float *Ks_src, float *viewmats, float *Ks_dst,
                    const float *pixels, const float **pixels_slot, int32_t *counters, int64_t n_zero, int n_groups,
                    const float *lr0, const float *lr_gamma, double beta1, double beta2, int32_t *step_counter,
-                   void *stream);
+                   int32_t *status_out, int64_t status_at, int32_t seq, void *stream);
 /* the forward stages only (preprocess, binning, sort, rasterise) on the same descriptor: the eval /
  * viewer render of gsplat_trainer.py:779-940; pixels, loss and gradient buffers are not touched */
 int so_render_forward(const so_step_desc *desc, void *stream);

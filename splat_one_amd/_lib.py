@@ -41,7 +41,8 @@ class StepDesc(ctypes.Structure):
                                          "camera_model", "antialiased", "absgrad", "raster_impl")]
         + [(n, c_f32) for n in ("eps2d", "near_plane", "far_plane", "radius_clip", "ssim_lambda", "opacity_reg",
                                 "scale_reg")]
-        + [("pixels_indirect", c_ptr), ("inputs_staged", ctypes.c_int32), ("reserved0", ctypes.c_int32)])
+        + [("pixels_indirect", c_ptr), ("inputs_staged", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+           ("overflow_flag_out", c_ptr)])
 
 
 # name -> argtypes, exactly the prototypes of include/splat_one_amd.h
@@ -63,7 +64,7 @@ _SIGS = {
     "so_isect_scan": [c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
     "so_preprocess_fwd": [c_int] * 4 + [c_ptr] * 8 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_int] + [c_ptr] * 10 + [c_i64, c_ptr],
     "so_rec_unpack": [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
-    "so_preprocess_bwd": [c_int] * 4 + [c_ptr] * 8 + [c_int, c_int, c_f32, c_int, c_int] + [c_ptr] * 9 + [c_f32, c_f32] + [c_ptr] * 9 + [c_int, c_i64, c_ptr],
+    "so_preprocess_bwd": [c_int] * 4 + [c_ptr] * 8 + [c_int, c_int, c_f32, c_int, c_int] + [c_ptr] * 9 + [c_f32, c_f32] + [c_ptr] * 9 + [c_int, c_i64, c_ptr, c_ptr, c_ptr],
     "so_rasterize_fwd_packed": [c_int] * 5 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 4,
     "so_rasterize_fwd_wave": [c_int] * 4 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 4,
     "so_rasterize_bwd_wave": [c_int] * 4 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 5 + [c_int, c_ptr],
@@ -74,9 +75,9 @@ _SIGS = {
     "so_profile_enable": [c_int],
     "so_profile_read": [ctypes.POINTER(c_f32), ctypes.POINTER(c_int)],
     "so_adam_step_dev": [c_int, ctypes.POINTER(AdamGroup), ctypes.POINTER(c_f32), ctypes.POINTER(c_f32),
-                         ctypes.c_double, ctypes.c_double, ctypes.c_double, c_ptr, c_int, c_int, c_ptr],
+                         ctypes.c_double, ctypes.c_double, ctypes.c_double, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr],
     "so_step_inputs": [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, ctypes.POINTER(c_f32),
-                       ctypes.POINTER(c_f32), ctypes.c_double, ctypes.c_double, c_ptr, c_ptr],
+                       ctypes.POINTER(c_f32), ctypes.c_double, ctypes.c_double, c_ptr, c_ptr, c_i64, c_int, c_ptr],
     "so_compute_relocation": [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr],
     "so_inject_noise": [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr],
     "so_adam_step": [c_int, ctypes.POINTER(AdamGroup), ctypes.c_double, ctypes.c_double, ctypes.c_double, c_int, c_ptr],

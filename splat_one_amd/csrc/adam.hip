@@ -73,7 +73,11 @@ __global__ void k_adam_prep(AdamSched sch, int n_groups, double beta1, double be
 }
 
 __global__ void __launch_bounds__(256)
-k_adam_dev(AdamGroups groups, AdamHyper h, const float2 *__restrict__ hyper, int zero_grad) {
+k_adam_dev(AdamGroups groups, AdamHyper h, const float2 *__restrict__ hyper, int zero_grad,
+           const int32_t *__restrict__ skip_i32, const float *__restrict__ skip_f32) {
+  // a void iteration (binning overflow on this or, summed through the all-reduce, on any rank) leaves the
+  // parameters and moments untouched
+  if ((skip_i32 && *skip_i32 != 0) || (skip_f32 && *skip_f32 != 0.f)) return;
   const so_adam_group G = groups.g[blockIdx.y];
   const float2 hy = hyper[blockIdx.y];
   const float step_size = hy.x, bc2_sqrt = hy.y;
@@ -105,7 +109,8 @@ k_adam_dev(AdamGroups groups, AdamHyper h, const float2 *__restrict__ hyper, int
 
 extern "C" int so_adam_step_dev(int n_groups, const so_adam_group *host_groups, const float *host_lr0,
                                 const float *host_lr_gamma, double beta1, double beta2, double eps,
-                                int32_t *step_counter, int zero_grad, int schedule_done, void *stream) {
+                                int32_t *step_counter, int zero_grad, int schedule_done, const int32_t *skip_i32,
+                                const float *skip_f32, void *stream) {
   SO_REQUIRE(n_groups >= 0 && n_groups <= SO_ADAM_MAX_GROUPS, "so_adam_step_dev: n_groups %d not in [0,%d]", n_groups, SO_ADAM_MAX_GROUPS);
   SO_REQUIRE(step_counter, "so_adam_step_dev: null step counter");
   if (n_groups == 0) return SO_OK;
@@ -135,7 +140,7 @@ extern "C" int so_adam_step_dev(int n_groups, const so_adam_group *host_groups, 
     if (gx > 2048) gx = 2048;
     if (gx < 1) gx = 1;
     const so::AdamHyper H{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps};
-    hipLaunchKernelGGL(so::k_adam_dev, dim3((unsigned)gx, (unsigned)n_groups), dim3(256), 0, st, G, H, hyper, zero_grad);
+    hipLaunchKernelGGL(so::k_adam_dev, dim3((unsigned)gx, (unsigned)n_groups), dim3(256), 0, st, G, H, hyper, zero_grad, skip_i32, skip_f32);
   }
   so_profile_stage_begin_end(8, 0, stream);
   return so::check_launch("so_adam_step_dev");

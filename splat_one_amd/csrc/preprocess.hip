@@ -127,8 +127,15 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
                  float *__restrict__ v_means, float *__restrict__ v_log_scales, float *__restrict__ v_quats,
                  float *__restrict__ v_logit_opac, float *__restrict__ v_sh0, float *__restrict__ v_shN,
                  float *__restrict__ grad2d, float *__restrict__ count, float stat_sx, float stat_sy,
-                 const float4 *__restrict__ vrec, int use_abs_stats, int64_t cam_stride) {
+                 const float4 *__restrict__ vrec, int use_abs_stats, int64_t cam_stride,
+                 const int32_t *__restrict__ skip_flag, float *__restrict__ skip_out) {
   constexpr int NB = (DEG + 1) * (DEG + 1);
+  // skip_flag (nullable): the binning pass overflowed its buffers -> this iteration is void: leave gradients and
+  // densification statistics alone (the optimiser step skips too); skip_out (nullable) publishes the flag as a
+  // float that a gradient all-reduce can sum across ranks
+  const bool skip = skip_flag && *skip_flag != 0;
+  if (skip_out && blockIdx.x == 0 && threadIdx.x == 0) *skip_out = skip ? 1.f : 0.f;
+  if (skip) return;
   for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
     const float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
     const float4 qq = *reinterpret_cast<const float4 *>(quats + 4 * n);
@@ -290,7 +297,8 @@ extern "C" int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float
                                  const float *v_colors, const float *v_opacities, float opacity_reg,
                                  float scale_reg, float *v_means, float *v_log_scales, float *v_quats,
                                  float *v_logit_opacities, float *v_sh0, float *v_shN, float *grad2d, float *count,
-                                 const float *vrec, int absgrad_stats, int64_t cam_stride, void *stream) {
+                                 const float *vrec, int absgrad_stats, int64_t cam_stride, const int32_t *skip_flag,
+                                 float *skip_out, void *stream) {
   SO_REQUIRE(C >= 0 && N >= 0 && K >= 1 && width > 0 && height > 0, "so_preprocess_bwd: bad sizes");
   SO_REQUIRE(sh_degree >= 0 && sh_degree <= 4 && (sh_degree + 1) * (sh_degree + 1) <= K,
              "so_preprocess_bwd: sh_degree %d does not fit K=%d", sh_degree, K);
@@ -316,7 +324,7 @@ extern "C" int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float
                      logit_opacities, sh0, shN, viewmats, Ks, width, height, eps2d, camera_model, antialiased,    \
                      radii, opacities, colors, v_means2d, v_means2d_abs, v_depths, v_conics, v_colors,            \
                      v_opacities, opacity_reg, scale_reg, v_means, v_log_scales, v_quats, v_logit_opacities,      \
-                     v_sh0, v_shN, grad2d, count, sx, sy, reinterpret_cast<const float4 *>(vrec), absgrad_stats, cam_stride)
+                     v_sh0, v_shN, grad2d, count, sx, sy, reinterpret_cast<const float4 *>(vrec), absgrad_stats, cam_stride, skip_flag, skip_out)
   switch (sh_degree) {
     case 0: SO_LAUNCH(0); break;
     case 1: SO_LAUNCH(1); break;

@@ -56,9 +56,22 @@ int ssim_l1_bwd_launch(int B, int H, int W, int CH, const float *img1, const flo
 __global__ void __launch_bounds__(256)
 k_step_inputs(int C, const float *__restrict__ c2w, const float *__restrict__ Ks_src, float *__restrict__ w2c,
               float *__restrict__ Ks_dst, const float *pixels, const float **pixels_slot, uint32_t *__restrict__ counters,
-              int64_t n_zero, AdamSched sch, int n_groups, double beta1, double beta2, int32_t *__restrict__ step_ptr) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += (int64_t)gridDim.x * blockDim.x) counters[i] = 0u;
+              int64_t n_zero, AdamSched sch, int n_groups, double beta1, double beta2, int32_t *__restrict__ step_ptr,
+              int32_t *status_out, int64_t status_at, int32_t seq) {
+  // status_out (host-mapped, nullable): what the PREVIOUS iteration left in counters[status_at], [status_at+1]
+  // (n_isects, overflow), read by one thread before that pair is zeroed, so no other workgroup races it
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += (int64_t)gridDim.x * blockDim.x)
+    if (!status_out || (i != status_at && i != status_at + 1)) counters[i] = 0u;
   if (blockIdx.x != 0) return;
+  if (status_out && threadIdx.x == 0) {
+    const int32_t n_prev = (int32_t)counters[status_at], ov_prev = (int32_t)counters[status_at + 1];
+    if (status_at < n_zero) counters[status_at] = 0u;
+    if (status_at + 1 < n_zero) counters[status_at + 1] = 0u;
+    status_out[0] = n_prev;
+    status_out[1] = ov_prev;
+    __threadfence_system();
+    status_out[2] = seq;      // written last: the host trusts [0], [1] once it sees its own sequence number here
+  }
   for (int c = threadIdx.x; c < C; c += blockDim.x) camera_inverse_one(c2w + 16 * c, w2c + 16 * c);
   if (Ks_dst)
     for (int i = threadIdx.x; i < 9 * C; i += blockDim.x) Ks_dst[i] = Ks_src[i];
@@ -113,13 +126,14 @@ extern "C" int so_train_step_fwd_bwd(const so_step_desc *d, void *stream) { retu
 extern "C" int so_step_inputs(int C, const float *camtoworlds, const float *Ks_src, float *viewmats, float *Ks_dst,
                               const float *pixels, const float **pixels_slot, int32_t *counters, int64_t n_zero,
                               int n_groups, const float *lr0, const float *lr_gamma, double beta1, double beta2,
-                              int32_t *step_counter, void *stream) {
+                              int32_t *step_counter, int32_t *status_out, int64_t status_at, int32_t seq, void *stream) {
   SO_REQUIRE(C >= 0 && n_zero >= 0 && n_groups >= 0 && n_groups <= SO_ADAM_MAX_GROUPS, "so_step_inputs: bad sizes");
   SO_REQUIRE(C == 0 || (camtoworlds && viewmats), "so_step_inputs: null camera pointers");
   SO_REQUIRE((Ks_src == nullptr) == (Ks_dst == nullptr), "so_step_inputs: Ks_src and Ks_dst go together");
   SO_REQUIRE(pixels_slot == nullptr || pixels != nullptr, "so_step_inputs: pixels_slot without pixels");
   SO_REQUIRE(n_zero == 0 || counters, "so_step_inputs: null counters");
   SO_REQUIRE(n_groups == 0 || (lr0 && lr_gamma && step_counter), "so_step_inputs: null schedule pointers");
+  SO_REQUIRE(status_out == nullptr || (counters && status_at >= 0), "so_step_inputs: status_out needs counters and status_at");
   so::AdamSched S{};
   for (int i = 0; i < n_groups; ++i) { S.lr0[i] = lr0[i]; S.lr_gamma[i] = lr_gamma[i]; }
   int64_t g = (n_zero + 1023) / 1024;
@@ -127,7 +141,7 @@ extern "C" int so_step_inputs(int C, const float *camtoworlds, const float *Ks_s
   if (g > 1024) g = 1024;
   hipLaunchKernelGGL(so::k_step_inputs, dim3((unsigned)g), dim3(256), 0, so::as_stream(stream), C, camtoworlds, Ks_src, viewmats,
                      Ks_dst, pixels, pixels_slot, reinterpret_cast<uint32_t *>(counters), n_zero, S, n_groups, beta1, beta2,
-                     step_counter);
+                     step_counter, status_out, status_at, seq);
   return so::check_launch("so_step_inputs");
 }
 
@@ -167,11 +181,11 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
                        d->isect_capacity, d->key_buf, d->flatten_ids, nullptr, overflow, stream));
   const bool wave_impl = d->raster_impl == 1 && ts == 16;
   if (wave_impl)
-    SO_STAGE(3, so_rasterize_fwd_wave(C, N, W, H, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects, 0,
+    SO_STAGE(3, so_rasterize_fwd_wave(C, N, W, H, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects, d->isect_capacity,
                                       d->render_colors, d->render_alphas, d->last_ids, stream));
   else
     SO_STAGE(3, so_rasterize_fwd_packed(C, N, W, H, ts, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects,
-                                        0, d->render_colors, d->render_alphas, d->last_ids, stream));
+                                        d->isect_capacity, d->render_colors, d->render_alphas, d->last_ids, stream));
   if (forward_only) return SO_OK;
   // loss = (1-l) * mean|.| + l * (1 - mean SSIM_valid)
   SO_STAGE(4, so::ssim_l1_fwd_launch(C, H, W, 3, d->render_colors, d->pixels, d->pixels_indirect, 1, d->loss_sums, d->dmaps, stream));
@@ -182,18 +196,18 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
   // gradients of the intermediates accumulate in the 64-byte records vrec[C*N] (zeroed by the
   // forward preprocess kernel): one atomic request per (tile quadrant, Gaussian)
   if (wave_impl)
-    SO_STAGE(6, so_rasterize_bwd_wave(C, N, W, H, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects, 0,
+    SO_STAGE(6, so_rasterize_bwd_wave(C, N, W, H, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects, d->isect_capacity,
                                       d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
                                       d->absgrad, stream));
   else
     SO_STAGE(6, so_rasterize_bwd_packed(C, N, W, H, ts, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects,
-                                        0, d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
+                                        d->isect_capacity, d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
                                         d->absgrad, stream));
   SO_STAGE(7, so_preprocess_bwd(C, N, K, d->sh_degree, d->means, d->log_scales, d->quats, d->logit_opacities, d->sh0, d->shN,
                            d->viewmats, d->Ks, W, H, d->eps2d, d->camera_model, d->antialiased, d->radii, d->opacities,
                            d->colors, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d->opacity_reg,
                            d->scale_reg, d->v_means, d->v_log_scales, d->v_quats, d->v_logit_opacities, d->v_sh0,
-                           d->v_shN, d->grad2d, d->count, d->vrec, d->absgrad, 0, stream));
+                           d->v_shN, d->grad2d, d->count, d->vrec, d->absgrad, 0, overflow, d->overflow_flag_out, stream));
 #undef SO_STAGE
 #undef SO_TRY
   return SO_OK;

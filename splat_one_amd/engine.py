@@ -57,6 +57,12 @@ class FusedEngine:
         self._graph_fb_key = None
         self.steps_done = 0
         self._step_dev = torch.zeros(2 + 4 * _lib.SO_ADAM_MAX_GROUPS, dtype=torch.int32, device=self.device)
+        # host-mapped status words {n_isects, overflow, seq} of the previous iteration (so_step_inputs)
+        self._status = torch.zeros(4, dtype=torch.int32).pin_memory()
+        self._seq = 0
+        self._status_event: Optional[torch.cuda.Event] = None
+        self.on_overflow = "grow"        # "grow": void iteration, larger buffers, continue;  "raise": RuntimeError
+        self.void_steps = 0              # iterations discarded because the binning pass overflowed
         self._build_workspace()
 
     # ---------------------------------------------------------------------------------------------
@@ -98,7 +104,10 @@ class FusedEngine:
         # flatten copy); per-tensor views are bound to .grad so optimisers / callers see them
         pad = lambda n: (n + 63) // 64 * 64                  # 256-byte aligned segments (float4 access)
         total = sum(pad(self.splats[k].numel()) for k in PARAM_ORDER)
-        w["grads_flat"] = torch.zeros(total, dtype=f32, device=dev)
+        # one spare slot behind the gradients carries "this iteration is void" through a gradient all-reduce
+        w["grads_flat"] = torch.zeros(total + 64, dtype=f32, device=dev)
+        w["ovf_f32"] = w["grads_flat"][total:total + 1]
+        self._probe_capacity = self._capacity_hint is None     # measure the first view's intersection count
         w["grads"], off = {}, 0
         for k in PARAM_ORDER:
             n = self.splats[k].numel()
@@ -139,6 +148,7 @@ class FusedEngine:
         d.eps2d, d.near_plane, d.far_plane, d.radius_clip = c["eps2d"], c["near_plane"], c["far_plane"], c["radius_clip"]
         d.ssim_lambda, d.opacity_reg, d.scale_reg = c["ssim_lambda"], c["opacity_reg"], c["scale_reg"]
         d.pixels_indirect, d.inputs_staged = p(w["pixels_slot"]), 1     # every launch is preceded by _stage()
+        d.overflow_flag_out = p(w["ovf_f32"])
         return d
 
     def _adam_args(self):
@@ -174,6 +184,8 @@ class FusedEngine:
         the target-image slot, the zeroing of the binning counters / loss sums and, with `schedule`, the
         Adam schedule of the optimiser step that follows.  c2w=None re-zeroes only (repeat launches on the
         same inputs)."""
+        if c2w is not None:
+            self._check_previous()                   # may rebuild the workspace: before anything is staged
         w, p, dev = self.ws, _lib.ptr, self.device
         n_groups, lr0, gam, betas = 0, None, None, (0.0, 0.0)
         if schedule:
@@ -190,11 +202,73 @@ class FusedEngine:
                 w["pixels"].copy_(pixels, non_blocking=True)
                 px = w["pixels"]
             self._pixels_ref = px                    # must stay alive and unchanged until the step has run
+        publish = c2w is not None                    # a new iteration: publish what the previous one left behind
+        if publish:
+            self._seq = (self._seq + 1) & 0x3FFFFFFF
         _lib.call("so_step_inputs", self.C if c2w is not None else 0, p(c2w), p(Ks), p(w["viewmats"]), p(w["Ks"]) if c2w is not None else 0,
                   p(px), p(w["pixels_slot"]) if px is not None else 0, p(w["counters"]), 2 * self.M + 5, n_groups, lr0, gam,
-                  float(betas[0]), float(betas[1]), _lib.ptr(self._step_dev), _lib.stream())
+                  float(betas[0]), float(betas[1]), _lib.ptr(self._step_dev),
+                  self._status.data_ptr() if publish else 0, 2 * self.M + 1, self._seq, _lib.stream())
+        if publish:
+            self._status_event = torch.cuda.Event()
+            self._status_event.record()
         self._staged = True
         self._sched_staged = bool(schedule)
+        if publish and self._probe_capacity:
+            self._probe_capacity = False
+            if self._measure_and_grow():             # buffers were too small for this view: stage again on the new ones
+                self._status_event = None            # (the previous iteration's status has been looked at already)
+                self._step_dev[0] = self.steps_done  # the schedule above advanced the device counter: undo
+                self._stage(c2w, Ks, pixels, schedule)
+            else:
+                self._stage(None, None, None, False)  # the measuring render used the counters: zero them again
+                self._sched_staged = bool(schedule)
+
+    # ------------------------------------------------------------------------------------------ capacity
+    def _grow(self, needed: int) -> None:
+        self._capacity_hint = int(1.5 * needed) + 4096
+        self._build_workspace()
+        self._probe_capacity = False
+
+    def _measure_and_grow(self) -> bool:
+        """Forward-only pass on the staged view, read its intersection count (one sync, once per workspace)."""
+        d = self._desc()
+        _lib.call("so_render_forward", ctypes.byref(d), _lib.stream())
+        n = int(self.ws["counters"][2 * self.M + 1].item())
+        if 1.25 * n > self.capacity:
+            self._grow(2 * n)
+            return True
+        return False
+
+    def _check_previous(self) -> None:
+        """One step late and without a device-wide sync: did the iteration before the last one overflow its
+        intersection buffers?  (The kernels stay in bounds and the optimiser skipped it; here the buffers grow
+        and the host-side step counters are rolled back for the void iterations.)"""
+        ev, self._status_event = self._status_event, None
+        if ev is None:
+            return
+        ev.synchronize()
+        n_prev, ov_prev, seq = (int(v) for v in self._status[:3])
+        if seq != self._seq or not ov_prev:
+            return
+        torch.cuda.synchronize()
+        c = self.ws["counters"]
+        n_last, ov_last = int(c[2 * self.M + 1].item()), int(c[2 * self.M + 2].item())
+        if self.on_overflow == "raise":
+            raise RuntimeError(f"tile-intersection buffers overflowed ({max(n_prev, n_last)} > capacity {self.capacity}); "
+                               "the affected iterations were skipped on the device -- raise Config.isect_capacity")
+        void = 1 + (1 if ov_last else 0)
+        self.void_steps += void
+        for _ in range(void):                        # undo _advance_host_counters for iterations that never happened
+            self.steps_done -= 1
+            for k in PARAM_ORDER:
+                self.optimizers[k].state[self.splats[k]]["step"] -= 1
+            self.optimizers["means"].param_groups[0]["lr"] /= self.lr_gamma_means
+        self._step_dev[0] = self.steps_done
+        import warnings
+        warnings.warn(f"splat_one_amd: {void} training iteration(s) skipped -- {max(n_prev, n_last)} tile intersections "
+                      f"exceeded the buffer capacity {self.capacity}; buffers enlarged", RuntimeWarning)
+        self._grow(max(n_prev, n_last))
 
     def set_views(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor, schedule: bool = False) -> None:
         """Stage this step's cameras and target images.  camtoworlds[C,4,4] (inverted on the device),
@@ -212,8 +286,9 @@ class FusedEngine:
 
     def _launch_optimize(self, schedule_done: bool = False) -> None:
         n, arr, lr0, gam, betas, eps = self._adam_args()
+        ovf = self.ws["counters"][2 * self.M + 2:]
         _lib.call("so_adam_step_dev", n, arr, lr0, gam, float(betas[0]), float(betas[1]), float(eps),
-                  _lib.ptr(self._step_dev), 0, int(schedule_done), _lib.stream())
+                  _lib.ptr(self._step_dev), 0, int(schedule_done), _lib.ptr(ovf), _lib.ptr(self.ws["ovf_f32"]), _lib.stream())
 
     def set_cameras(self, camtoworlds: Tensor, Ks: Tensor) -> None:
         """Cameras only (forward-only rendering needs no target image)."""

@@ -289,7 +289,7 @@ class _RasterizeToPixels(torch.autograd.Function):
         render_colors = torch.empty(C, height, width, D, dtype=torch.float32, device=dev)
         render_alphas = torch.empty(C, height, width, 1, dtype=torch.float32, device=dev)
         last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
-        n_host = 0 if n_isects_dev is not None else flatten_ids.numel()
+        n_host = flatten_ids.numel()      # exact count, or (static mode) the capacity that bounds the device count
         call("so_rasterize_fwd", C, N, D, width, height, tile_size, ptr(means2d), ptr(conics), ptr(colors),
              ptr(opacities), ptr(backgrounds), ptr(masks), ptr(isect_offsets), ptr(flatten_ids),
              ptr(n_isects_dev), n_host, ptr(render_colors), ptr(render_alphas), ptr(last_ids), stream())

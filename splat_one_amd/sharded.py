@@ -72,6 +72,9 @@ class ShardedEngine:
         self._capacity_hint = isect_capacity
         self.steps_done = 0
         self._step_dev = torch.zeros(2 + 4 * _lib.SO_ADAM_MAX_GROUPS, dtype=torch.int32, device=self.device)
+        self._status = torch.zeros(4, dtype=torch.int32).pin_memory()    # {n_isects, overflow, seq} of the previous step
+        self._seq = 0
+        self._status_event = None
         self._build_workspace()
 
     # ---------------------------------------------------------------------------------------------
@@ -91,6 +94,7 @@ class ShardedEngine:
         self.M = M = tw * th
         icap = self._capacity_hint or max(1 << 20, 8 * Nf)
         self.capacity = int(icap)
+        self._probe_capacity = self._capacity_hint is None
         f32, i32 = torch.float32, torch.int32
         e = lambda *shape, dtype=f32: torch.empty(*shape, dtype=dtype, device=dev)
         z = lambda *shape, dtype=f32: torch.zeros(*shape, dtype=dtype, device=dev)
@@ -180,11 +184,16 @@ class ShardedEngine:
         else:
             w["pixels"].copy_(pixels, non_blocking=True)
             px = w["pixels"]
+        self._check_previous()
         ng, lr0, gam, betas = 0, None, None, (0.0, 0.0)
         if schedule:
             ng, _arr, lr0, gam, betas, _eps = self._adam_args()
+        self._seq = (self._seq + 1) & 0x3FFFFFFF
         _lib.call("so_step_inputs", n, p(c2w), p(Ksd), p(w["viewmats"]), p(w["Ks"]), 0, 0, p(w["counters"]), 2 * M + 5, ng,
-                  lr0, gam, float(betas[0]), float(betas[1]), p(self._step_dev), st)
+                  lr0, gam, float(betas[0]), float(betas[1]), p(self._step_dev), self._status.data_ptr(), 2 * M + 1,
+                  self._seq, st)
+        self._status_event = torch.cuda.Event()
+        self._status_event.record()
         ts = c["tile_size"]
         tw, th = math.ceil(W / ts), math.ceil(H / ts)
         cam = CAMERA_MODELS[c["camera_model"]]
@@ -202,11 +211,21 @@ class ShardedEngine:
                   p(w["vrec_full"]), st)
         _lib.call("so_isect_count", 1, Nf, p(w["means2d_full"]), p(w["radii_full"]), ts, tw, th, p(w["tiles_full"]),
                   p(tile_counts), p(w["isect_offsets"]), p(n_isects), st)
+        if self._probe_capacity:     # once per workspace: the largest intersection count over the ranks decides the buffers
+            self._probe_capacity = False
+            cnt = n_isects[:1].to(torch.int64)
+            dist.all_reduce(cnt, op=dist.ReduceOp.MAX, group=self.group)
+            if 1.25 * int(cnt.item()) > self.capacity:
+                self._capacity_hint = 2 * int(cnt.item()) + 4096
+                self._status_event = None
+                self._step_dev[0] = self.steps_done
+                self._build_workspace()
+                return self.fwd_bwd(camtoworlds, Ks, pixels, schedule)
         _lib.call("so_isect_fill", 1, Nf, p(w["means2d_full"]), p(w["radii_full"]), p(w["depths_full"]), ts, tw, th,
                   p(w["isect_offsets"]), p(n_isects), p(cursor), self.capacity, p(w["key_buf"]), p(w["flatten_ids"]), 0,
                   p(overflow), st)
         _lib.call("so_rasterize_fwd_packed", 1, Nf, W, H, ts, p(w["rec_full"]), 0, p(w["isect_offsets"]), p(w["flatten_ids"]),
-                  p(n_isects), 0, p(w["render_colors"]), p(w["render_alphas"]), p(w["last_ids"]), st)
+                  p(n_isects), self.capacity, p(w["render_colors"]), p(w["render_alphas"]), p(w["last_ids"]), st)
         lam = float(c["ssim_lambda"])
         n_l1 = float(H * W * 3)
         n_ss = float((H - 10) * (W - 10) * 3)
@@ -215,7 +234,7 @@ class ShardedEngine:
         _lib.call("so_ssim_l1_bwd", 1, H, W, 3, p(w["render_colors"]), p(px), p(w["dmaps"]), (1.0 - lam) / n_l1 / n,
                   -lam / n_ss / n, 0, p(w["v_render_colors"]), p(w["loss_sums"]), p(w["loss_sums"][2:]), 1, lam / n, st)
         _lib.call("so_rasterize_bwd_packed", 1, Nf, W, H, ts, p(w["rec_full"]), 0, p(w["isect_offsets"]), p(w["flatten_ids"]),
-                  p(n_isects), 0, p(w["render_alphas"]), p(w["last_ids"]), p(w["v_render_colors"]), p(w["zero_v_alphas"]),
+                  p(n_isects), self.capacity, p(w["render_alphas"]), p(w["last_ids"]), p(w["v_render_colors"]), p(w["zero_v_alphas"]),
                   p(w["vrec_full"]), int(c["absgrad"]), st)
         all_to_all_rows(w["vrec_shard"], w["vrec_full"], self.group)
         if N > 0:
@@ -229,16 +248,31 @@ class ShardedEngine:
                       p(w["colors"]), 0, 0, 0, 0, 0, 0, c["opacity_reg"] * scale, c["scale_reg"] * scale, p(g["means"]),
                       p(g["scales"]), p(g["quats"]), p(g["opacities"]), p(g["sh0"]), p(g["shN"]),
                       p(sst["grad2d"]) if sst is not None else 0, p(sst["count"]) if sst is not None else 0,
-                      p(w["vrec_shard"]), int(c["absgrad"]), cap, st)
+                      p(w["vrec_shard"]), int(c["absgrad"]), cap, p(overflow), 0, st)
         self._keep = (c2w, Ksd, px)
         self._sched_staged = bool(schedule)
+
+    def _check_previous(self) -> None:
+        """One step late, without a device-wide sync: an overflow of the own intersection buffers.  The kernels
+        stayed in bounds and this rank's optimiser skipped, but the gradients it sent to the other shards were
+        incomplete, so the run stops here (the intersection count of the first view sizes the buffers with 2x
+        headroom; a later view exceeding that needs Config.isect_capacity)."""
+        ev, self._status_event = self._status_event, None
+        if ev is None:
+            return
+        ev.synchronize()
+        n_prev, ov_prev, seq = (int(v) for v in self._status[:3])
+        if seq == self._seq and ov_prev:
+            raise RuntimeError(f"rank {self.rank}: tile-intersection buffers overflowed ({n_prev} > capacity {self.capacity}); "
+                               "raise Config.isect_capacity")
 
     def optimize(self) -> None:
         n, arr, lr0, gam, betas, eps = self._adam_args()
         sched = getattr(self, "_sched_staged", False)
         self._sched_staged = False
+        ovf = self.ws["counters"][2 * self.M + 2:]
         _lib.call("so_adam_step_dev", n, arr, lr0, gam, float(betas[0]), float(betas[1]), float(eps),
-                  _lib.ptr(self._step_dev), 0, int(sched), _lib.stream())
+                  _lib.ptr(self._step_dev), 0, int(sched), _lib.ptr(ovf), 0, _lib.stream())
         self.steps_done += 1
         for k in PARAM_ORDER:
             self.optimizers[k].state[self.splats[k]]["step"] += 1

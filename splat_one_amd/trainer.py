@@ -460,6 +460,8 @@ class Runner:
                 raster_impl=getattr(self, "raster_impl", 0))
             eng.steps_done = step
             eng._step_dev[0] = step
+            if self.world_size > 1:
+                eng.on_overflow = "raise"        # replicas must not diverge: no silent per-rank buffer growth
         eng.set_sh_degree(min(step // cfg.sh_degree_interval, cfg.sh_degree))
         # densification statistics are accumulated inside the backward kernel while refinement is active
         stats_on = isinstance(s, DefaultStrategy) and step < s.refine_stop_iter

@@ -133,3 +133,61 @@ def test_engine_render_forward_matches_operator_path(dev):
     with torch.no_grad():
         rc2, ra2, _ = r.rasterize_splats(c2w, Ks, W, H, sh_degree=3, near_plane=0.01, far_plane=1e8)
     assert (rc - rc2).abs().max().item() < 1e-5 and (ra - ra2).abs().max().item() < 1e-5
+
+
+def test_engine_survives_intersection_overflow(dev):
+    """Buffers sized far too small: the overflowing iterations stay in bounds, change nothing (optimiser and
+    statistics skip on the device), are detected one step late without a device sync, the buffers grow, and the
+    run continues exactly like one that had enough room from the start, minus the void iterations."""
+    import warnings
+    from splat_one_amd.engine import FusedEngine
+    from splat_one_amd.scene import front_camera, pinhole_K
+    from splat_one_amd.trainer import Config, Runner
+    W, H, N, steps = 160, 120, 3000, 6
+
+    def make(capacity):
+        cfg = Config(init_num_pts=N, init_scale=0.6, init_opa=0.3, shN_init_std=0.05, sh_degree_interval=1, fused=True)
+        r = Runner(0, 0, 1, cfg, scene_scale=1.0 / 1.1)
+        with torch.no_grad():   # anisotropic: otherwise Adam amplifies a pure-rounding quaternion gradient
+            r.splats["scales"].add_((torch.randn(N, 3, generator=torch.Generator().manual_seed(7)) * 0.4).to(dev))
+        st = r.strategy_state
+        eng = FusedEngine(r.splats, r.optimizers, W, H, 1, sh_degree=3, strategy_state=st, lr_gamma_means=r.lr_gamma,
+                          isect_capacity=capacity, use_graph=True)
+        return r, eng
+    c2w = front_camera()[None].to(dev)
+    Ks = pinhole_K(W, H)[None].to(dev)
+    pixels = torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(5)).to(dev)
+
+    r_small, e_small = make(512)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        for _ in range(steps):
+            e_small.set_views(c2w, Ks, pixels, schedule=True)
+            e_small.step()
+        e_small.set_views(c2w, Ks, pixels)          # one more staging: publishes the last iteration's status
+        torch.cuda.synchronize()
+    assert e_small.void_steps >= 1 and any("skipped" in str(w.message) for w in rec)
+    assert e_small.capacity > 512 and e_small.stats()["overflow"] == 0
+    done = steps - e_small.void_steps
+    assert done >= 2 and e_small.steps_done == done
+    assert float(r_small.optimizers["means"].state[r_small.splats["means"]]["step"]) == float(done)
+
+    r_big, e_big = make(1 << 20)
+    for _ in range(done):
+        e_big.set_views(c2w, Ks, pixels, schedule=True)
+        e_big.step()
+    torch.cuda.synchronize()
+    assert e_big.void_steps == 0
+    for k in r_big.splats.keys():
+        assert rel_err(r_small.splats[k], r_big.splats[k]) < 2e-4, k      # atomic-order noise through Adam
+    assert rel_err(r_small.strategy_state["grad2d"], r_big.strategy_state["grad2d"]) < 1e-4
+    assert torch.equal(r_small.strategy_state["count"], r_big.strategy_state["count"])
+
+    # without an explicit capacity the first view is measured and the buffers sized from it: nothing is skipped
+    r_auto, e_auto = make(None)
+    e_auto.capacity = 1024          # pretend the default guess was far too small
+    for _ in range(2):
+        e_auto.set_views(c2w, Ks, pixels, schedule=True)
+        e_auto.step()
+    torch.cuda.synchronize()
+    assert e_auto.void_steps == 0 and e_auto.capacity > 1024

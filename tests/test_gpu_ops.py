@@ -355,7 +355,7 @@ def test_step_inputs_one_launch(dev):
     gam = (ctypes.c_float * ng)(0.99985, 1.0, 1.0)
     b1, b2 = 0.9, 0.999
     _lib.call("so_step_inputs", C, _lib.ptr(c2w_d), _lib.ptr(Ks_d), _lib.ptr(vm), _lib.ptr(Kd), _lib.ptr(img), _lib.ptr(slot),
-              _lib.ptr(counters), nz, ng, lr0, gam, b1, b2, _lib.ptr(step_dev), _lib.stream())
+              _lib.ptr(counters), nz, ng, lr0, gam, b1, b2, _lib.ptr(step_dev), 0, 0, 0, _lib.stream())
     torch.cuda.synchronize()
     want = torch.linalg.inv(c2w.double())
     assert (vm.cpu().double() - want).abs().max().item() < 1e-6
@@ -368,9 +368,17 @@ def test_step_inputs_one_launch(dev):
         lr = lr0[i] * gam[i] ** 41
         assert abs(hyper[i, 0].item() - lr / (1 - b1 ** 42)) <= 1e-6 * lr / (1 - b1 ** 42)
         assert abs(hyper[i, 1].item() - math.sqrt(1 - b2 ** 42)) < 1e-6
+    # status of the previous iteration: published to host-mapped memory before the pair is zeroed
+    status = torch.zeros(4, dtype=torch.int32).pin_memory()
+    counters.fill_(9)
+    counters[100], counters[101] = 123456, 1
+    _lib.call("so_step_inputs", 0, 0, 0, 0, 0, 0, 0, _lib.ptr(counters), nz, 0, None, None, 0.0, 0.0, 0,
+              status.data_ptr(), 100, 77, _lib.stream())
+    torch.cuda.synchronize()
+    assert status[:3].tolist() == [123456, 1, 77] and (counters[:nz] == 0).all()
     # parts are optional: zero only
     counters.fill_(5)
-    _lib.call("so_step_inputs", 0, 0, 0, 0, 0, 0, 0, _lib.ptr(counters), 10, 0, None, None, 0.0, 0.0, 0, _lib.stream())
+    _lib.call("so_step_inputs", 0, 0, 0, 0, 0, 0, 0, _lib.ptr(counters), 10, 0, None, None, 0.0, 0.0, 0, 0, 0, 0, _lib.stream())
     torch.cuda.synchronize()
     assert (counters[:10] == 0).all() and (counters[10:] == 5).all() and step_dev[0].item() == 42
 

@@ -26,7 +26,7 @@ def bwd():
     _lib.call("so_preprocess_bwd", 1, N, eng.K, 3, p(s["means"].data), p(s["scales"].data), p(s["quats"].data), p(s["opacities"].data),
               p(s["sh0"].data), p(s["shN"].data), p(w["viewmats"]), p(w["Ks"]), W, H, 0.3, 0, 0, p(w["radii"]), p(w["opacities"]),
               p(w["colors"]), 0, 0, 0, 0, 0, 0, 0.0, 0.0, p(g["means"]), p(g["scales"]), p(g["quats"]), p(g["opacities"]),
-              p(g["sh0"]), p(g["shN"]), 0, 0, p(w["vrec"]), 0, 0, _lib.stream())
+              p(g["sh0"]), p(g["shN"]), 0, 0, p(w["vrec"]), 0, 0, 0, 0, _lib.stream())
 for name, fn in (("preprocess_fwd", fwd), ("preprocess_bwd", bwd)):
     for reps in (1, 20):
         ts = []
