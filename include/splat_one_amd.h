@@ -111,7 +111,7 @@ int so_sh_bwd(int C, int N, int K, int degrees_to_use, const float *dirs, const 
  *         `capacity` is the size of the caller's buffers; if n_isects > capacity nothing beyond
  *         capacity is written and *overflow (device i32, nullable) is set to 1.
  *         tile_cursor[C*tile_h*tile_w + 1] i32 must be zeroed by the caller (after the scatter the
- *         array is reused as the work list of tiles whose list exceeds 1024 keys; the extra
+ *         array is reused as the work list of tiles whose list exceeds 2048 keys; the extra
  *         element is its length).  Lists up to 16384 keys sort in 128 KiB of LDS, longer ones
  *         fall back to the same network in global memory.
  * ---------------------------------------------------------------------------------------- */

@@ -424,11 +424,13 @@ extern "C" int so_isect_fill(int C, int N, const float *means2d, const int32_t *
   // after the scatter the cursor array is dead: it becomes the work list of long tiles, and the
   // (caller-zeroed) element behind it is the list length
   int32_t *long_list = tile_cursor, *long_count = tile_cursor + M;
-  // lists up to 1024 keys: 256 threads, 8 KiB LDS -> many workgroups per CU
-  hipLaunchKernelGGL((so::k_tile_sort_lds<256, 1024>), dim3(gridM), dim3(256), 1024 * 8, st, M, n_tiles, tb,
+  // lists up to 2048 keys: 256 threads, 16 KiB LDS (4096 keys / 32 KiB costs the sparse regime 14 us of occupancy; most lists of a trained scene take the
+  // one-wave register path anyway, and in the dense init regime -- ~800 keys per tile -- this kernel does the bulk)
+  hipLaunchKernelGGL((so::k_tile_sort_lds<256, 2048>), dim3(gridM), dim3(256), 2048 * 8, st, M, n_tiles, tb,
                      isect_offsets, n_isects, capacity, key_buf, flatten_ids, isect_ids, long_list, long_count);
-  // longer lists: fixed small grid over the work list
-  hipLaunchKernelGGL((so::k_tile_sort_long<1024, 16384>), dim3(128), dim3(1024), 16384 * 8, st, M, n_tiles, tb,
+  // longer lists: one workgroup per CU (128 KiB of LDS each) over the work list -- the grid is fixed at launch,
+  // the list length is only known on the device
+  hipLaunchKernelGGL((so::k_tile_sort_long<1024, 16384>), dim3(256), dim3(1024), 16384 * 8, st, M, n_tiles, tb,
                      isect_offsets, n_isects, capacity, key_buf, flatten_ids, isect_ids, long_list, long_count);
   return so::check_launch("so_isect_fill");
 }
