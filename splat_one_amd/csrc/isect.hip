@@ -42,19 +42,40 @@ k_isect_count(int C, int N, const float *__restrict__ means2d, const int32_t *__
               int tile_w, int tile_h, int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ tile_counts) {
   const int64_t total = (int64_t)C * N;
   const int n_tiles = tile_w * tile_h;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int r = radii[idx];
-    int cnt = 0;
-    if (r > 0) {
-      const float2 m = *reinterpret_cast<const float2 *>(means2d + 2 * idx);
-      const TileBox b = tile_box(m.x, m.y, (float)r, tile_size, tile_w, tile_h);
-      cnt = (b.x1 - b.x0) * (b.y1 - b.y0);
-      int32_t *row = tile_counts + (idx / N) * n_tiles;
+  // uniform trip count: the cooperative part needs every lane of a wave (same scheme as k_preprocess_fwd)
+  for (int64_t idx0 = (int64_t)blockIdx.x * blockDim.x; idx0 < total; idx0 += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t idx = idx0 + threadIdx.x;
+    int cnt = 0, c = 0;
+    TileBox b{0, 0, 0, 0};
+    if (idx < total) {
+      const int r = radii[idx];
+      if (r > 0) {
+        const float2 m = *reinterpret_cast<const float2 *>(means2d + 2 * idx);
+        b = tile_box(m.x, m.y, (float)r, tile_size, tile_w, tile_h);
+        cnt = (b.x1 - b.x0) * (b.y1 - b.y0);
+        c = (int)(idx / N);
+      }
+      tiles_per_gauss[idx] = cnt;
+    }
+    // small rectangles: the owning lane; large ones: the whole wave in 8x8 tile blocks
+    constexpr int kOwn = 12;
+    const bool big = cnt > kOwn;
+    if (cnt > 0 && !big) {
+      int32_t *row = tile_counts + (int64_t)c * n_tiles;
       for (int y = b.y0; y < b.y1; ++y)
         for (int x = b.x0; x < b.x1; ++x) atomicAdd(row + y * tile_w + x, 1);
     }
-    tiles_per_gauss[idx] = cnt;
+    unsigned long long todo = __ballot(big);
+    const int lane = lane_id();
+    while (todo) {
+      const int src = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const int sx0 = __builtin_amdgcn_readlane(b.x0, src), sx1 = __builtin_amdgcn_readlane(b.x1, src);
+      const int sy0 = __builtin_amdgcn_readlane(b.y0, src), sy1 = __builtin_amdgcn_readlane(b.y1, src);
+      int32_t *row = tile_counts + (int64_t)__builtin_amdgcn_readlane(c, src) * n_tiles;
+      for (int y = sy0 + (lane >> 3); y < sy1; y += 8)
+        for (int x = sx0 + (lane & 7); x < sx1; x += 8) atomicAdd(row + y * tile_w + x, 1);
+    }
   }
 }
 

@@ -49,9 +49,12 @@ k_preprocess_fwd(int C, int N, int K, const float *__restrict__ means, const flo
                  float4 *__restrict__ rec, float4 *__restrict__ vrec, int64_t cam_stride) {
   const int64_t total = (int64_t)C * N;
   const int n_tiles = tile_w * tile_h;
-  for (int64_t lin = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; lin < total;
-       lin += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(lin / N);
+  // the trip count is uniform over the workgroup: the histogram section below needs every lane of a wave
+  for (int64_t lin0 = (int64_t)blockIdx.x * blockDim.x; lin0 < total; lin0 += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t lin = lin0 + threadIdx.x;
+    int cnt = 0, bx0 = 0, bx1 = 0, by0 = 0, by1 = 0, c = 0;
+    if (lin < total) {
+    c = (int)(lin / N);
     const int64_t n = lin - (int64_t)c * N;
     const int64_t idx = (int64_t)c * cam_stride + n;   // row of the per-view arrays (cam_stride >= N)
     const CamP cam = load_camp(viewmats, Ks, c);
@@ -70,7 +73,6 @@ k_preprocess_fwd(int C, int N, int K, const float *__restrict__ means, const flo
     if (antialiased) op *= o.comp;
     opacities[idx] = op;
     float r = 0.f, g = 0.f, b = 0.f;
-    int cnt = 0;
     if (o.radius > 0) {
       float dx = mean[0] - cam.pos[0], dy = mean[1] - cam.pos[1], dz = mean[2] - cam.pos[2];
       const float inorm = rsqrtf(dx * dx + dy * dy + dz * dz);
@@ -90,11 +92,7 @@ k_preprocess_fwd(int C, int N, int K, const float *__restrict__ means, const flo
       const int y0 = (int)fminf(fmaxf(floorf(ty - tile_r), 0.f), (float)tile_h);
       const int y1 = (int)fminf(fmaxf(ceilf(ty + tile_r), 0.f), (float)tile_h);
       cnt = (x1 - x0) * (y1 - y0);
-      if (tile_counts) {   // null: the caller bins later (Gaussian-sharded runs bin after the exchange)
-        int32_t *row = tile_counts + (int64_t)c * n_tiles;
-        for (int y = y0; y < y1; ++y)
-          for (int x = x0; x < x1; ++x) atomicAdd(row + y * tile_w + x, 1);
-      }
+      bx0 = x0; bx1 = x1; by0 = y0; by1 = y1;
     }
     colors[3 * idx] = r; colors[3 * idx + 1] = g; colors[3 * idx + 2] = b;
     tiles_per_gauss[idx] = cnt;
@@ -107,6 +105,30 @@ k_preprocess_fwd(int C, int N, int K, const float *__restrict__ means, const flo
     if (vrec) {  // gradient record, accumulated atomically by the rasteriser backward
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       vrec[4 * idx] = z; vrec[4 * idx + 1] = z; vrec[4 * idx + 2] = z; vrec[4 * idx + 3] = z;
+    }
+    }   // lin < total
+    if (tile_counts) {   // null: the caller bins later (Gaussian-sharded runs bin after the exchange)
+      // Histogram of the first binning pass.  A lane walks a small rectangle itself; a large one (the dense
+      // init regime: ~70 tiles per Gaussian) is spread over the whole wave in 8x8 tile blocks, so the wave's
+      // trip count follows the total work, not its largest rectangle.
+      constexpr int kOwn = 12;
+      const bool big = cnt > kOwn;
+      if (cnt > 0 && !big) {
+        int32_t *row = tile_counts + (int64_t)c * n_tiles;
+        for (int y = by0; y < by1; ++y)
+          for (int x = bx0; x < bx1; ++x) atomicAdd(row + y * tile_w + x, 1);
+      }
+      unsigned long long todo = __ballot(big);
+      const int lane = lane_id();
+      while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int sx0 = __builtin_amdgcn_readlane(bx0, src), sx1 = __builtin_amdgcn_readlane(bx1, src);
+        const int sy0 = __builtin_amdgcn_readlane(by0, src), sy1 = __builtin_amdgcn_readlane(by1, src);
+        int32_t *row = tile_counts + (int64_t)__builtin_amdgcn_readlane(c, src) * n_tiles;
+        for (int y = sy0 + (lane >> 3); y < sy1; y += 8)
+          for (int x = sx0 + (lane & 7); x < sx1; x += 8) atomicAdd(row + y * tile_w + x, 1);
+      }
     }
   }
 }
