@@ -94,15 +94,16 @@ struct StageGeom {
 template <int CH>
 constexpr int lds_line_slots() { return 2 * kT + 2 * kHalf * CH; }
 
-// wave-uniform pointer to row y (clamped into the image) of image b (rmask: 0/1 mask of that row)
-__device__ __forceinline__ const float *row_ptr(const float *img, int b, int H, int W, int CH, int y, float &rmask) {
+// wave-uniform pointer to row y (clamped into the image) of ONE image (`img` already points at batch element b;
+// one image is < 2^31 floats, checked on the host, so the row offset is 32-bit scalar arithmetic); rmask: 0/1
+__device__ __forceinline__ const float *row_ptr(const float *img, int H, int stride, int y, float &rmask) {
 #ifdef SO_SSIM_DBG_SAMEROW
   const int yc = (y < 0 ? 0 : (y >= H ? H - 1 : y)) & ~31;
 #else
   const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
 #endif
   rmask = (y == yc) ? 1.f : 0.f;
-  return img + ((int64_t)b * H + yc) * ((int64_t)W * CH);
+  return img + (unsigned)(yc * stride);
 }
 
 // ------------------------------------------------------------------------------------ forward
@@ -113,10 +114,10 @@ struct FwdStage {
 
 template <int CH>
 __device__ __forceinline__ void fwd_gload(FwdStage<CH> &st, const StageGeom<CH> &g, const float *img1, const float *img2,
-                                          int b, int H, int W, int y) {
+                                          int H, int stride, int y) {
   float rm;
-  const float *r1 = row_ptr(img1, b, H, W, CH, y, rm);
-  const float *r2 = row_ptr(img2, b, H, W, CH, y, rm);
+  const float *r1 = row_ptr(img1, H, stride, y, rm);
+  const float *r2 = row_ptr(img2, H, stride, y, rm);
 #ifdef SO_SSIM_DBG_NOGLOAD
   st.p0 = v2f{(float)g.off0, rm};
   st.p1 = v2f{(float)g.off1, (float)y};
@@ -166,7 +167,7 @@ __device__ __forceinline__ void ssim_fwd_step(SsimFwdState<CH> &S, FwdStage<CH> 
   {   // stage row it+1 (loaded two steps ago), fetch row it+3; both harmless past the end
     fwd_lstore<CH>(preA, g, rows[(it + 1) & 1], tid, y0 - kHalf + it + 1, H);
     preA = preB;
-    fwd_gload<CH>(preB, g, img1, img2, b, H, W, y0 - kHalf + it + 3);
+    fwd_gload<CH>(preB, g, img1, img2, H, W * CH, y0 - kHalf + it + 3);
   }
   const v4f *R = rows[it & 1] + tid;   // tap k of this thread's column/channel sits CH slots further per k
   v2f m = {0.f, 0.f}, q = {0.f, 0.f};
@@ -226,7 +227,7 @@ __device__ __forceinline__ void ssim_fwd_step(SsimFwdState<CH> &S, FwdStage<CH> 
 #else
       if (o.in_image) {
 #endif
-        float *d = dmaps + ((int64_t)b * H + y) * ((int64_t)W * CH);
+        float *d = dmaps + (unsigned)(y * (W * CH));
         d[o.off] = g_mu;
         d[map_stride + o.off] = dm_dE;
         d[2 * map_stride + o.off] = dm_dB2;
@@ -260,11 +261,16 @@ k_ssim_l1_fwd(int B, int H, int W, const float *__restrict__ img1, const float *
   o.off = o.in_image ? (unsigned)f : 0u;
   o.l1mask = o.in_image ? 1.f : 0.f;
   o.cmask = (o.in_image && (!valid || (x >= kHalf && x < W - kHalf))) ? 1.f : 0.f;
+  {   // from here on every pointer addresses batch element b, rows are 32-bit offsets from it
+    const int64_t ob = (int64_t)b * H * ((int64_t)W * CH);
+    img1 += ob; img2 += ob;
+    if (dmaps) dmaps += ob;
+  }
   FwdStage<CH> preA, preB;
-  fwd_gload<CH>(preA, g, img1, img2, b, H, W, y0 - kHalf);
+  fwd_gload<CH>(preA, g, img1, img2, H, W * CH, y0 - kHalf);
   fwd_lstore<CH>(preA, g, rows[0], tid, y0 - kHalf, H);
-  fwd_gload<CH>(preA, g, img1, img2, b, H, W, y0 - kHalf + 1);
-  fwd_gload<CH>(preB, g, img1, img2, b, H, W, y0 - kHalf + 2);
+  fwd_gload<CH>(preA, g, img1, img2, H, W * CH, y0 - kHalf + 1);
+  fwd_gload<CH>(preB, g, img1, img2, H, W * CH, y0 - kHalf + 2);
   SsimFwdState<CH> S;
   S.l1_acc = S.ss_acc = 0.f;
 #pragma unroll
@@ -304,9 +310,9 @@ struct BwdStage {
 
 template <int CH>
 __device__ __forceinline__ void bwd_gload(BwdStage<CH> &st, const StageGeom<CH> &g, const float *dmaps, int64_t map_stride,
-                                          int b, int H, int W, int y) {
+                                          int H, int stride, int y) {
   float rm;
-  const float *r0 = row_ptr(dmaps, b, H, W, CH, y, rm);
+  const float *r0 = row_ptr(dmaps, H, stride, y, rm);
   const float *r1 = r0 + map_stride, *r2 = r1 + map_stride;
   st.a0 = r0[g.off0]; st.b0 = r1[g.off0]; st.c0 = r2[g.off0];
   st.a1 = r0[g.off1]; st.b1 = r1[g.off1]; st.c1 = r2[g.off1];
@@ -338,12 +344,12 @@ __device__ __forceinline__ void ssim_bwd_step(SsimBwdState<CH> &S, BwdStage<CH> 
   {
     bwd_lstore<CH>(preA, g, rows[(it + 1) & 1], tid, y0 - kHalf + it + 1, H);
     preA = preB;
-    bwd_gload<CH>(preB, g, dmaps, map_stride, b, H, W, y0 - kHalf + it + 3);
+    bwd_gload<CH>(preB, g, dmaps, map_stride, H, W * CH, y0 - kHalf + it + 3);
   }
   float xv = 0.f, yv = 0.f;
-  int64_t orow = 0;
+  unsigned orow = 0;
   if constexpr (OUT) {   // issue the two pixel loads early; consumed after the vertical sums
-    orow = ((int64_t)b * H + (y0 + it - 2 * kHalf)) * ((int64_t)W * CH);
+    orow = (unsigned)((y0 + it - 2 * kHalf) * (W * CH));
     xv = (img1 + orow)[o.off];
     yv = (img2 + orow)[o.off];
   }
@@ -410,11 +416,15 @@ k_ssim_l1_bwd(int B, int H, int W, const float *__restrict__ img1, const float *
   o.in_image = f < W * CH;
   o.off = o.in_image ? (unsigned)f : 0u;
   o.l1mask = o.cmask = 0.f;
+  {
+    const int64_t ob = (int64_t)b * H * ((int64_t)W * CH);
+    img1 += ob; img2 += ob; dmaps += ob; v_img1 += ob;
+  }
   BwdStage<CH> preA, preB;
-  bwd_gload<CH>(preA, g, dmaps, map_stride, b, H, W, y0 - kHalf);
+  bwd_gload<CH>(preA, g, dmaps, map_stride, H, W * CH, y0 - kHalf);
   bwd_lstore<CH>(preA, g, rows[0], tid, y0 - kHalf, H);
-  bwd_gload<CH>(preA, g, dmaps, map_stride, b, H, W, y0 - kHalf + 1);
-  bwd_gload<CH>(preB, g, dmaps, map_stride, b, H, W, y0 - kHalf + 2);
+  bwd_gload<CH>(preA, g, dmaps, map_stride, H, W * CH, y0 - kHalf + 1);
+  bwd_gload<CH>(preB, g, dmaps, map_stride, H, W * CH, y0 - kHalf + 2);
   SsimBwdState<CH> S;
 #pragma unroll
   for (int i = 0; i < kWin; ++i) { S.ring01[i] = v2f{0.f, 0.f}; S.ring2[i] = 0.f; }
@@ -469,6 +479,7 @@ int so::ssim_l1_fwd_launch(int B, int H, int W, int CH, const float *img1, const
   SO_REQUIRE(CH == 1 || CH == 3 || CH == 4, "so_ssim_l1_fwd: CH=%d not in {1,3,4}", CH);
   if (B == 0) return SO_OK;
   SO_REQUIRE(img1 && (img2 || img2_slot) && sums, "so_ssim_l1_fwd: null pointer");
+  SO_REQUIRE((int64_t)H * W * CH < (int64_t)INT32_MAX, "so_ssim_l1_fwd: one image must hold fewer than 2^31 values");
   const so::Window win = so::make_window();
   const dim3 grid((W * CH + so::kT - 1) / so::kT, (H + so::kRows - 1) / so::kRows, B), block(so::kT);
   hipStream_t st = so::as_stream(stream);
@@ -496,6 +507,7 @@ int so::ssim_l1_bwd_launch(int B, int H, int W, int CH, const float *img1, const
   SO_REQUIRE(CH == 1 || CH == 3 || CH == 4, "so_ssim_l1_bwd: CH=%d not in {1,3,4}", CH);
   if (B == 0) return SO_OK;
   SO_REQUIRE(img1 && (img2 || img2_slot) && dmaps && v_img1, "so_ssim_l1_bwd: null pointer");
+  SO_REQUIRE((int64_t)H * W * CH < (int64_t)INT32_MAX, "so_ssim_l1_bwd: one image must hold fewer than 2^31 values");
   SO_REQUIRE(loss_out == nullptr || sums != nullptr, "so_ssim_l1_bwd: loss_out needs sums");
   const float a_l1 = 1.f / ((float)B * H * W * CH);
   const float b_ss = 1.f / ((float)B * CH * (padding_valid ? (float)(H - 10) * (float)(W - 10) : (float)H * (float)W));
