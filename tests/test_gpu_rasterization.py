@@ -117,3 +117,32 @@ def test_permutation_invariance(dev):
                                   packed=False)
         outs.append(rc)
     assert (outs[0] - outs[1]).abs().max().item() < 1e-5
+
+
+def test_empty_and_all_culled_scenes(dev):
+    """No Gaussians at all, and Gaussians that are all behind the camera: the render is the background with zero
+    alpha, the backward gives zero gradients, nothing is launched out of bounds."""
+    from splat_one_amd import rasterization
+    W, H = 70, 45                                   # ragged: not a multiple of the tile size
+    viewmats = torch.eye(4, device=dev)[None]
+    Ks = torch.tensor([[[60.0, 0, W / 2], [0, 60.0, H / 2], [0, 0, 1]]], device=dev)
+    bg = torch.tensor([[0.2, 0.4, 0.6]], device=dev)
+    z = lambda *s: torch.zeros(*s, device=dev)
+    rc, ra, meta = rasterization(z(0, 3), z(0, 4), z(0, 3), z(0), z(0, 3), viewmats, Ks, W, H, backgrounds=bg, packed=False)
+    assert rc.shape == (1, H, W, 3) and ra.shape == (1, H, W, 1)
+    assert torch.equal(ra, torch.zeros_like(ra)) and torch.allclose(rc, bg.reshape(1, 1, 1, 3).expand_as(rc))
+    assert meta["flatten_ids"].numel() == 0
+    # behind the camera (z < near plane): culled in projection, radii 0, empty lists
+    N = 50
+    means = torch.randn(N, 3, device=dev)
+    means[:, 2] = -5.0 - means[:, 2].abs()
+    means.requires_grad_(True)
+    quats = torch.rand(N, 4, device=dev)
+    scales = torch.full((N, 3), 0.1, device=dev)
+    opac = torch.full((N,), 0.5, device=dev)
+    colors = torch.rand(N, 3, device=dev)
+    rc, ra, meta = rasterization(means, quats, scales, opac, colors, viewmats, Ks, W, H, packed=False)
+    assert (meta["radii"] <= 0).all() and meta["flatten_ids"].numel() == 0
+    assert torch.equal(rc, torch.zeros_like(rc)) and torch.equal(ra, torch.zeros_like(ra))
+    (rc.sum() + ra.sum()).backward()
+    assert torch.equal(means.grad, torch.zeros_like(means))
