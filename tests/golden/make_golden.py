@@ -19,6 +19,8 @@ Fixtures (data only):
   g6_knn_sh.npz    knn, rgb_to_sh                                (utils.py:141-150)
   g7_opensfm_math.npz angle_axis_to_quaternion / qvec2rotmat / rotmat2qvec, extracted like g1 (the
                    module imports pyproj/cv2/imageio at top level)   (utils/datasets/opensfm.py:47-84)
+  g9_camera_models.json CameraModelManager.load_camera_models (class extracted like g1: the module imports PyQt5)
+                   on the fixture data of the reference's own tests/test_camera_models.py:13-41 (app/camera_models.py:225-292)
   g8_traj_paths.npz generate_ellipse_path_y / generate_interpolated_path / generate_spiral_path /
                    focus_point_fn / average_pose                 (utils/datasets/traj.py:25-255)
 """
@@ -189,6 +191,41 @@ def g8(Tj):
         spiral=Tj.generate_spiral_path(poses, bounds, n_frames=16))
 
 
+def _extract_class(path: str, name: str, namespace: dict):
+    tree = ast.parse(open(path).read())
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == name:
+            exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), namespace)
+            return namespace[name]
+    raise KeyError(name)
+
+
+def g9():
+    import json
+    import tempfile
+    Manager = _extract_class(os.path.join(REF, "app/camera_models.py"), "CameraModelManager", dict(os=os, json=json))
+    base = {"Camera1": {"projection_type": "perspective", "width": 1920, "height": 1080, "focal_ratio": 1.2},
+            "Camera2": {"projection_type": "spherical", "width": 3840, "height": 2160, "focal_ratio": 1.0}}
+    cases = {"override_one_field": (base, {"Camera1": {"focal_ratio": 1.5}}),
+             "override_adds_camera": (base, {"Camera3": {"projection_type": "fisheye", "width": 640, "height": 480, "focal_ratio": 0.8}}),
+             "no_overrides": (base, None),
+             "missing_base_file": (None, {"Perspective": {"focal_ratio": 0.9}}),
+             "malformed_base_file": ("{not json", None)}
+    out = {}
+    for name, (b, o) in cases.items():
+        with tempfile.TemporaryDirectory() as d:
+            if isinstance(b, dict):
+                json.dump(b, open(os.path.join(d, "camera_models.json"), "w"))
+            elif isinstance(b, str):
+                open(os.path.join(d, "camera_models.json"), "w").write(b)
+            if o is not None:
+                json.dump(o, open(os.path.join(d, "camera_models_overrides.json"), "w"))
+            m = Manager(d)
+            written = json.load(open(os.path.join(d, "camera_models.json")))
+            out[name] = {"base": b, "overrides": o, "merged": m.get_camera_models(), "written_back": written}
+    json.dump(out, open(os.path.join(HERE, "g9_camera_models.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     U, Nz, Tj = _load_reference()
     g1(U)
@@ -198,6 +235,7 @@ if __name__ == "__main__":
     g6(U)
     g7()
     g8(Tj)
+    g9()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -259,3 +259,31 @@ def test_runner_refuses_spherical_scene(tmp_path):
     _write_scene(tmp_path, spherical=True, images=False, width=256, height=128)
     with pytest.raises(NotImplementedError, match="spherical"):
         Runner.from_data_dir(0, 0, 1, Config(data_dir=str(tmp_path), data_factor=1))
+
+
+# ------------------------------------------------------------------ camera_models.json (reference fixture)
+def test_camera_models_merge_matches_reference_golden(tmp_path):
+    """The reference's own CameraModelManager on the fixture of its tests/test_camera_models.py (overrides merged
+    key-wise, unknown cameras added, default model on a missing / malformed file, merged table written back)."""
+    cm = importlib.import_module("splat_one_amd.datasets.camera_models")
+    gold = json.load(open(os.path.join(GOLD, "g9_camera_models.json")))
+    for name, case in gold.items():
+        d = tmp_path / name
+        os.makedirs(d)
+        if isinstance(case["base"], dict):
+            json.dump(case["base"], open(d / "camera_models.json", "w"))
+        elif isinstance(case["base"], str):
+            (d / "camera_models.json").write_text(case["base"])
+        if case["overrides"] is not None:
+            json.dump(case["overrides"], open(d / "camera_models_overrides.json", "w"))
+        merged = cm.load_camera_models(str(d))
+        assert merged == case["merged"], name
+        assert json.load(open(d / "camera_models.json")) == case["written_back"], name
+    # the assertions of the reference's test_camera_model_manager_init, verbatim in meaning
+    m = gold["override_one_field"]["merged"]
+    assert m["Camera1"]["focal_ratio"] == 1.5 and m["Camera1"]["projection_type"] == "perspective"
+    assert m["Camera2"]["projection_type"] == "spherical"
+    K = cm.intrinsics(m["Camera1"])
+    np.testing.assert_allclose(K.numpy(), [[1.5 * 1920, 0, 960], [0, 1.5 * 1920, 540], [0, 0, 1]])
+    with pytest.raises(ValueError):
+        cm.intrinsics(m["Camera2"])
