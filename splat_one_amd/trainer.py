@@ -78,6 +78,11 @@ class Config:
     eval_steps: List[int] = field(default_factory=lambda: [7_000, 30_000])
     save_steps: List[int] = field(default_factory=lambda: [7_000, 30_000])
     depth_loss: bool = False        # accepted for the Dataset's placeholder depths; the loss term is out of scope
+    # camera pose refinement (gsplat_trainer.py:150-156): runs through the operator-level path (viewmat gradients)
+    pose_opt: bool = False
+    pose_opt_lr: float = 1e-5
+    pose_opt_reg: float = 1e-6
+    pose_noise: float = 0.0
     # extensions of this build
     isect_capacity: Optional[int] = None   # preallocated intersections -> no host sync in the step
     fused: bool = False                    # FusedEngine: whole step in two C-ABI calls, hipGraph replay
@@ -189,6 +194,21 @@ class Runner:
             self.strategy_state = self.cfg.strategy.initialize_state()           # gsplat_trainer.py:351-352
         else:
             self.strategy_state = self.cfg.strategy.initialize_state(scene_scale=self.scene_scale)
+        # pose refinement / perturbation (:363-381): one SE(3) delta per training view
+        self.pose_optimizers: List[torch.optim.Optimizer] = []
+        n_views_total = max(len(self.views), 1)
+        if cfg.pose_opt:
+            from .pose import CameraOptModule
+            self.pose_adjust = CameraOptModule(n_views_total).to(self.device)
+            self.pose_adjust.zero_init()
+            self.pose_optimizers = [torch.optim.Adam(self.pose_adjust.parameters(),
+                                                     lr=cfg.pose_opt_lr * math.sqrt(cfg.batch_size),
+                                                     weight_decay=cfg.pose_opt_reg)]
+            self.pose_lr0 = self.pose_optimizers[0].param_groups[0]["lr"]
+        if cfg.pose_noise > 0.0:
+            from .pose import CameraOptModule
+            self.pose_perturb = CameraOptModule(n_views_total).to(self.device)
+            self.pose_perturb.random_init(cfg.pose_noise)
         self.means_lr0 = self.optimizers["means"].param_groups[0]["lr"]
         self.lr_gamma = 0.01 ** (1.0 / cfg.max_steps)                     # ExponentialLR, :512-516
         self.step = 0
@@ -238,7 +258,10 @@ class Runner:
         reference's `main` (:950-957) and by `load_checkpoints`."""
         step = self.step - 1 if step is None else step
         path = f"{self._result_dirs()['ckpts']}/ckpt_{step}_rank{self.world_rank}.pt"
-        torch.save({"step": step, "splats": self.splats.state_dict()}, path)
+        data = {"step": step, "splats": self.splats.state_dict()}
+        if self.cfg.pose_opt:
+            data["pose_adjust"] = self.pose_adjust.state_dict()                # :693-697
+        torch.save(data, path)
         return path
 
     def load_checkpoints(self, files: List[str]) -> int:
@@ -437,7 +460,8 @@ class Runner:
     # ------------------------------------------------------------------------------ fused fast path
     def _fused_ok(self, masks) -> bool:
         c = self.cfg
-        if not (c.fused and masks is None and not c.random_bkgd and not c.visible_adam and not c.packed):
+        if not (c.fused and masks is None and not c.random_bkgd and not c.visible_adam and not c.packed
+                and not c.pose_opt and c.pose_noise <= 0.0):
             return False
         if isinstance(c.strategy, DefaultStrategy):
             return c.strategy.refine_scale2d_stop_iter == 0
@@ -566,7 +590,8 @@ class Runner:
         self.step += 1
         return eng.loss()[0]
 
-    def train_step(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor, masks: Optional[Tensor] = None) -> Tensor:
+    def train_step(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor, masks: Optional[Tensor] = None,
+                   image_ids: Optional[Tensor] = None) -> Tensor:
         """One iteration on an already-on-device batch (camtoworlds[B,4,4], Ks[B,3,3],
         pixels[B,H,W,3] in 0..1; in gaussian_sharded runs the cameras of ALL ranks and the own image).  Returns the loss tensor (no host sync; on the fused path it is a
         view of the engine's static loss buffer, valid until the next step -- clone it to keep it)."""
@@ -579,6 +604,13 @@ class Runner:
             return self._train_step_fused(camtoworlds, Ks, pixels)
         cfg, step = self.cfg, self.step
         height, width = pixels.shape[1:3]
+        if cfg.pose_noise > 0.0 or cfg.pose_opt:                               # :579-582
+            assert image_ids is not None, "pose_opt / pose_noise need image_ids (index of each view in the training set)"
+            ids = image_ids.to(self.device).long()
+            if cfg.pose_noise > 0.0:
+                camtoworlds = self.pose_perturb(camtoworlds, ids)
+            if cfg.pose_opt:
+                camtoworlds = self.pose_adjust(camtoworlds, ids)
         sh_degree_to_use = min(step // cfg.sh_degree_interval, cfg.sh_degree)
         renders, alphas, info = self.rasterize_splats(
             camtoworlds=camtoworlds, Ks=Ks, width=width, height=height, sh_degree=sh_degree_to_use,
@@ -603,6 +635,13 @@ class Runner:
         if cfg.visible_adam:
             vis = (info["radii"] > 0).any(0)
         step_all(self.optimizers.values(), set_to_none=True, visibility=vis)
+        for opt in self.pose_optimizers:                                       # :732-734, scheduler :517-522
+            if self.world_size > 1:
+                for prm in self.pose_adjust.parameters():
+                    sdist.all_reduce_mean_(prm.grad)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            opt.param_groups[0]["lr"] = self.pose_lr0 * self.lr_gamma ** (step + 1)
         # ExponentialLR on the means
         self.optimizers["means"].param_groups[0]["lr"] = self.means_lr0 * self.lr_gamma ** (step + 1)
         # densification
@@ -698,7 +737,8 @@ class Runner:
             cursor += B
             pixels = torch.stack([b[2] for b in batch])
             step = self.step
-            self.train_step(c2w, Ks, pixels)
+            ids = torch.tensor([order[(cursor - B + i) % len(order)] for i in range(B)])
+            self.train_step(c2w, Ks, pixels, image_ids=ids)
             if has_data:
                 if step in [i - 1 for i in cfg.save_steps] or step == n - 1:
                     self.save_checkpoint(step)

@@ -73,3 +73,19 @@ def test_g4_camera_ring_matches_reference_viewmatrix():
     for m in ring:
         pos, fwd = m[:3, 3], m[:3, 2]
         assert np.allclose(np.cross(fwd, -pos), 0, atol=1e-6) and np.dot(fwd, -pos) > 0
+
+
+def test_g2_pose_module_matches_reference():
+    """rotation_6d_to_matrix and CameraOptModule against outputs of the reference's own module."""
+    from splat_one_amd.pose import CameraOptModule, rotation_6d_to_matrix
+    g = np.load(os.path.join(GOLD, "g2_pose.npz"))
+    R = rotation_6d_to_matrix(torch.from_numpy(g["d6"]))
+    assert torch.allclose(R, torch.from_numpy(g["R"]), atol=1e-6)
+    assert torch.allclose(R @ R.transpose(-1, -2), torch.eye(3).expand(4, 3, 3), atol=1e-5)
+    m = CameraOptModule(g["embeds"].shape[0])
+    with torch.no_grad():
+        m.embeds.weight.copy_(torch.from_numpy(g["embeds"]))
+    out = m(torch.from_numpy(g["c2w"]), torch.from_numpy(g["ids"]).long())
+    assert torch.allclose(out, torch.from_numpy(g["out"]), atol=1e-5)
+    m.zero_init()       # zero deltas: the identity transform
+    assert torch.allclose(m(torch.from_numpy(g["c2w"]), torch.from_numpy(g["ids"]).long()), torch.from_numpy(g["c2w"]), atol=1e-6)

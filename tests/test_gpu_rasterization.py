@@ -146,3 +146,37 @@ def test_empty_and_all_culled_scenes(dev):
     assert torch.equal(rc, torch.zeros_like(rc)) and torch.equal(ra, torch.zeros_like(ra))
     (rc.sum() + ra.sum()).backward()
     assert torch.equal(means.grad, torch.zeros_like(means))
+
+
+def test_pose_refinement_gradients_match_oracle(dev):
+    """Config.pose_opt: the gradient of the per-view SE(3) deltas (through inv(camtoworld), the projection
+    backward's v_viewmats and the SH view directions) against float64 autograd through the oracle."""
+    from oracle import c_oracle as CO
+    from oracle import torch_oracle as O
+    from splat_one_amd import rasterization
+    from splat_one_amd.pose import CameraOptModule
+    from splat_one_amd.scene import make_scene
+    from tests.util import rel_err
+    W, H, N = 96, 64, 800
+    splats, c2w, Ks = make_scene(N, W, H, "ref", n_views=2)
+    gen = torch.Generator().manual_seed(3)
+    weights = torch.rand(2, H, W, 3, generator=gen)
+    embeds = torch.randn(5, 9, generator=gen) * 0.02
+    ids = torch.tensor([3, 1])
+
+    def run(fn, to, dtype, **kw):
+        m = CameraOptModule(5).to(to).to(dtype)
+        with torch.no_grad():
+            m.embeds.weight.copy_(embeds.to(to).to(dtype))
+        cam = m(c2w.to(to).to(dtype), ids.to(to))
+        p = {k: v.detach().to(to).to(dtype) for k, v in splats.items()}
+        colors = torch.cat([p["sh0"], p["shN"]], 1)
+        rc, ra, _ = fn(p["means"], p["quats"], torch.exp(p["scales"]), torch.sigmoid(p["opacities"]), colors,
+                       torch.linalg.inv(cam), Ks.to(to).to(dtype), W, H, sh_degree=3, **kw)
+        ((rc * weights.to(rc)).sum() + 0.1 * ra.sum()).backward()
+        return rc.detach().cpu().double(), m.embeds.weight.grad.detach().cpu().double()
+    rc_h, g_h = run(rasterization, dev, torch.float32, packed=False)
+    rc_o, g_o = run(O.rasterization, "cpu", torch.float64, raster_fn=CO.raster_fn())
+    assert (rc_h - rc_o).abs().mean().item() < 1e-4
+    assert g_o[[3, 1]].abs().min() > 0 and torch.equal(g_o[[0, 2, 4]], torch.zeros(3, 9, dtype=torch.float64))
+    assert rel_err(g_h, g_o) < 1e-3, rel_err(g_h, g_o)

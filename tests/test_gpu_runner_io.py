@@ -135,3 +135,21 @@ def test_render_traj_and_viewer_frame(dev, tmp_path):
         def get_K(wh):
             return d["K"].numpy()
     np.testing.assert_array_equal(r._viewer_render_fn(State(), (63, 47)), img)
+
+
+def test_pose_opt_training_and_checkpoint(dev, tmp_path):
+    """Config.pose_opt / pose_noise through Runner.train: the per-view deltas train (operator-level path), are
+    decayed by the same schedule as the means, and are saved under the reference's checkpoint key."""
+    from splat_one_amd.trainer import Runner
+    _scene(tmp_path)
+    cfg = _cfg(tmp_path, pose_opt=True, pose_noise=1e-3, pose_opt_lr=1e-3, fused=True, max_steps=6, save_steps=[6], eval_steps=[])
+    r = Runner.from_data_dir(0, 0, 1, cfg)
+    assert r.pose_adjust.embeds.weight.shape == (14, 9) and float(r.pose_adjust.embeds.weight.detach().abs().sum()) == 0.0
+    r.train()
+    w = r.pose_adjust.embeds.weight.detach()
+    assert torch.isfinite(w).all() and float(w.abs().max()) > 0            # every visited view moved
+    assert (w.abs().sum(1) > 0).sum().item() == 6                           # six steps, six distinct views
+    ck = torch.load(glob.glob(f"{cfg.result_dir}/ckpts/ckpt_5_rank0.pt")[0], weights_only=True)
+    assert "pose_adjust" in ck and torch.equal(ck["pose_adjust"]["embeds.weight"].to(w.device), w)
+    lr = r.pose_optimizers[0].param_groups[0]["lr"]
+    assert abs(lr - 1e-3 * (0.01 ** (6 / 6))) < 1e-9
