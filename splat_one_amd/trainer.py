@@ -719,6 +719,15 @@ class Runner:
 
         if self.sharded:
             assert B == 1 and cfg.patch_size is None, "gaussian_sharded: one full view per rank per step"
+        import json
+        import time
+        global_tic = time.time()
+        if has_data and self.world_rank == 0:           # the run's configuration next to its results (:505-507)
+            import yaml
+            d = self._result_dirs()
+            with open(f"{cfg.result_dir.rstrip('/')}/cfg.yml", "w") as f:
+                yaml.safe_dump({k: (v if isinstance(v, (int, float, str, bool, list, type(None))) else repr(v))
+                                for k, v in vars(cfg).items()}, f)
         for _ in range(n):
             if self.stop_training:
                 break
@@ -741,6 +750,10 @@ class Runner:
             self.train_step(c2w, Ks, pixels, image_ids=ids)
             if has_data:
                 if step in [i - 1 for i in cfg.save_steps] or step == n - 1:
+                    stats = {"mem": torch.cuda.max_memory_allocated() / 1024 ** 3, "ellipse_time": time.time() - global_tic,
+                             "num_GS": len(self.splats["means"])}                       # :683-691
+                    with open(f"{self._result_dirs()['stats']}/train_step{step:04d}_rank{self.world_rank}.json", "w") as f:
+                        json.dump(stats, f)
                     self.save_checkpoint(step)
                 if step in [i - 1 for i in cfg.eval_steps] and len(self.valset) > 0:
                     self.eval(step)

@@ -59,6 +59,11 @@ def test_runner_from_data_dir_trains_saves_evals(dev, tmp_path, fused):
     assert set(st) == {"psnr", "ssim", "ellipse_time", "num_GS"} and st["num_GS"] == 200
     assert np.isfinite(st["psnr"]) and -1.0 <= st["ssim"] <= 1.0
     assert len(glob.glob(f"{cfg.result_dir}/renders/val_step5_*.png")) == 3
+    tr = json.load(open(f"{cfg.result_dir}/stats/train_step0005_rank0.json"))
+    assert set(tr) == {"mem", "ellipse_time", "num_GS"} and tr["num_GS"] == 200 and tr["mem"] > 0
+    import yaml
+    dumped = yaml.safe_load(open(f"{cfg.result_dir}/cfg.yml"))
+    assert dumped["max_steps"] == 12 and dumped["data_factor"] == 1 and dumped["init_type"] == "sfm"
 
 
 def test_eval_metrics_match_oracle_and_checkpoint_roundtrip(dev, tmp_path):
