@@ -273,6 +273,7 @@ def main():
     ab["so_ssim_l1_bwd"] = 60 * P + 12 * P
     b_iter = sum(ab[k] for k in ("so_projection_fwd", "so_sh_fwd", "so_isect_count", "so_isect_fill", "so_rasterize_fwd",
                                  "so_rasterize_bwd", "so_sh_bwd", "so_projection_bwd", "so_adam_step"))
+    dominant = dominant.replace("_packed", "")          # the packed-record entry points share the byte model
     achieved = ab[dominant] / (dom_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
