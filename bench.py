@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--operator-path", action="store_true",
                     help="time the operator-level autograd path instead of the fused engine")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel times to stderr")
+    ap.add_argument("--attr-dtype", default="f32", choices=["f32", "f16"],
+                    help="f16: float16 attribute rows (BASELINE.json configs[4]); float32 arithmetic and masters")
     ap.add_argument("--dp-mode", default="auto", choices=["auto", "gaussian_sharded", "allreduce"],
                     help="multi-GPU scheme (ignored at --gpus 1): all-reduce of the Gaussian gradients (BASELINE.json's "
                          "north_star), exchange of projected Gaussians (the reference's own scheme), or auto = time "
@@ -125,7 +127,7 @@ def main():
     def make_runner(dp_mode):
         cfg = Config(init_num_pts=N, init_scale=init_scale, init_opa=init_opa, batch_size=1, shN_init_std=0.1,
                      camera_model="pinhole", sh_degree_interval=1,    # SH degree 3 from step 3 on
-                     fused=not args.operator_path, dp_mode=dp_mode)
+                     fused=not args.operator_path, dp_mode=dp_mode, attr_dtype=args.attr_dtype)
         r = Runner(local_rank, rank, world, cfg, scene_scale=1.0 / 1.1)   # effective scene_scale 1.0
         r.raster_impl = args.raster_impl
         if r.sharded:      # the step takes the cameras of every rank (rank r renders camera r)

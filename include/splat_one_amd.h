@@ -229,6 +229,22 @@ int so_adam_step_dev(int n_groups, const so_adam_group *host_groups, const float
                      const float *host_lr_gamma, double beta1, double beta2, double eps, int32_t *step_counter,
                      int zero_grad, int schedule_done, const int32_t *skip_if_nonzero_i32,
                      const float *skip_if_nonzero_f32, void *stream);
+/* The same step that also keeps the float16 attribute rows (so_attr_pack_f16 below) current: for a group g with
+ * offset_bytes[g] >= 0 every updated parameter is ALSO stored, rounded to nearest-even, as a half at
+ *   arec + (e / row_len[g]) * stride_bytes + offset_bytes[g] + 2 * (e % row_len[g])        (e = element index),
+ * so the float32 masters and their float16 copies never diverge and no separate repack launch is needed.
+ * `row_len` of such a group must be its true row length (3, 4, 3(K-1) ...) and numel < 2^31.  shadow == NULL (or
+ * shadow->arec == NULL) is so_adam_step_dev. */
+typedef struct so_attr_shadow {
+  void *arec;
+  int32_t stride_bytes;
+  int32_t offset_bytes[SO_ADAM_MAX_GROUPS]; /* < 0: no float16 copy of this group */
+} so_attr_shadow;
+int so_adam_step_dev_shadow(int n_groups, const so_adam_group *host_groups, const float *host_lr0,
+                            const float *host_lr_gamma, double beta1, double beta2, double eps,
+                            int32_t *step_counter, int zero_grad, int schedule_done,
+                            const int32_t *skip_if_nonzero_i32, const float *skip_if_nonzero_f32,
+                            const so_attr_shadow *shadow, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused front end / back end on the RAW parameters (what `Runner.rasterize_splats` holds,
@@ -271,6 +287,37 @@ int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float *means, co
                       float *skip_flag_out, void *stream);
 int so_rec_unpack(int64_t n, const float *rec, float *means2d, int32_t *radii, float *depths, float *vrec,
                   void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * float16 attribute storage (BASELINE.json configs[4]: "2M Gaussians ... fp16 attributes").  The 56 of the 59
+ * parameter floats per Gaussian that tolerate it are kept as halves in ONE 16-byte aligned row per Gaussian,
+ *   arec[N][stride]:  +0 f16 quat[4] | +8 f16 log_scale[3] | +14 f16 0 | +16 f16 sh[K][3] (sh0, then shN), zero pad
+ *   stride = so_attr_rec_stride(K) = 16 + roundup16(6 K) bytes   (K = 16: 112 B against 224 B in five arrays),
+ * read by so_preprocess_fwd_f16 / so_preprocess_bwd_f16 with 16-byte loads; positions and opacity logits stay
+ * float32 in their own arrays (a half resolves 2e-3 world units at |x| = 3, several pixels at 1080p).  All
+ * arithmetic is float32: the result equals so_preprocess_fwd / _bwd on the half-rounded attribute values.
+ * Gradients are float32 and go to the float32 masters, whose optimiser step refreshes the halves
+ * (so_adam_step_dev_shadow); so_attr_pack_f16 (re)builds all rows from the masters, e.g. after densification.
+ * The *_f16 entry points take the same arguments as their float32 counterparts with `arec` in place of
+ * log_scales / quats / sh0 / shN; the backward reads the rasteriser's gradients from `vrec` only.
+ * ---------------------------------------------------------------------------------------- */
+int64_t so_attr_rec_stride(int K);
+int so_attr_pack_f16(int64_t N, int K, const float *log_scales, const float *quats, const float *sh0,
+                     const float *shN, void *arec, void *stream);
+int so_preprocess_fwd_f16(int C, int N, int K, int sh_degree, const float *means, const float *logit_opacities,
+                          const void *arec, const float *viewmats, const float *Ks, int width, int height,
+                          float eps2d, float near_plane, float far_plane, float radius_clip, int camera_model,
+                          int antialiased, int tile_size, int32_t *radii, float *means2d, float *depths,
+                          float *conics, float *opacities, float *colors, int32_t *tiles_per_gauss,
+                          int32_t *tile_counts, float *rec, float *vrec, int64_t cam_stride, void *stream);
+int so_preprocess_bwd_f16(int C, int N, int K, int sh_degree, const float *means, const float *logit_opacities,
+                          const void *arec, const float *viewmats, const float *Ks, int width, int height,
+                          float eps2d, int camera_model, int antialiased, const int32_t *radii,
+                          const float *opacities, const float *colors, float opacity_reg, float scale_reg,
+                          float *v_means, float *v_log_scales, float *v_quats, float *v_logit_opacities,
+                          float *v_sh0, float *v_shN, float *grad2d, float *count, const float *vrec,
+                          int absgrad_stats, int64_t cam_stride, const int32_t *skip_if_nonzero,
+                          float *skip_flag_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * One training iteration (gsplat_trainer.py:586-655: render -> loss -> backward) as ONE call on
@@ -317,6 +364,9 @@ typedef struct so_step_desc {
    * overflow_flag_out (nullable): 1.0f / 0.0f copy of the flag, e.g. a spare slot behind the flat gradient
    * buffer so that a gradient all-reduce carries "some rank overflowed" to every rank. */
   float *overflow_flag_out;
+  /* float16 attribute rows (nullable; see so_attr_pack_f16): when set, quaternions, log-scales and SH coefficients
+   * are read from here instead of log_scales / quats / sh0 / shN (which may then be NULL). */
+  const void *attr_rows_f16;
 } so_step_desc;
 int so_train_step_fwd_bwd(const so_step_desc *desc, void *stream);
 /* Everything that changes from one iteration to the next, in ONE launch, so that a captured step needs

@@ -42,7 +42,12 @@ class StepDesc(ctypes.Structure):
         + [(n, c_f32) for n in ("eps2d", "near_plane", "far_plane", "radius_clip", "ssim_lambda", "opacity_reg",
                                 "scale_reg")]
         + [("pixels_indirect", c_ptr), ("inputs_staged", ctypes.c_int32), ("reserved0", ctypes.c_int32),
-           ("overflow_flag_out", c_ptr)])
+           ("overflow_flag_out", c_ptr), ("attr_rows_f16", c_ptr)])
+
+
+class AttrShadow(ctypes.Structure):
+    """Mirror of `so_attr_shadow`: where so_adam_step_dev_shadow keeps the float16 attribute rows current."""
+    _fields_ = [("arec", c_ptr), ("stride_bytes", ctypes.c_int32), ("offset_bytes", ctypes.c_int32 * SO_ADAM_MAX_GROUPS)]
 
 
 # name -> argtypes, exactly the prototypes of include/splat_one_amd.h
@@ -76,6 +81,12 @@ _SIGS = {
     "so_profile_read": [ctypes.POINTER(c_f32), ctypes.POINTER(c_int)],
     "so_adam_step_dev": [c_int, ctypes.POINTER(AdamGroup), ctypes.POINTER(c_f32), ctypes.POINTER(c_f32),
                          ctypes.c_double, ctypes.c_double, ctypes.c_double, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr],
+    "so_adam_step_dev_shadow": [c_int, ctypes.POINTER(AdamGroup), ctypes.POINTER(c_f32), ctypes.POINTER(c_f32),
+                                ctypes.c_double, ctypes.c_double, ctypes.c_double, c_ptr, c_int, c_int, c_ptr, c_ptr,
+                                ctypes.POINTER(AttrShadow), c_ptr],
+    "so_attr_pack_f16": [c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
+    "so_preprocess_fwd_f16": [c_int] * 4 + [c_ptr] * 5 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_int] + [c_ptr] * 10 + [c_i64, c_ptr],
+    "so_preprocess_bwd_f16": [c_int] * 4 + [c_ptr] * 5 + [c_int, c_int, c_f32, c_int, c_int] + [c_ptr] * 3 + [c_f32, c_f32] + [c_ptr] * 9 + [c_int, c_i64, c_ptr, c_ptr, c_ptr],
     "so_step_inputs": [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, ctypes.POINTER(c_f32),
                        ctypes.POINTER(c_f32), ctypes.c_double, ctypes.c_double, c_ptr, c_ptr, c_i64, c_int, c_ptr],
     "so_compute_relocation": [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr],
@@ -88,7 +99,7 @@ _lib: Optional[ctypes.CDLL] = None
 
 def exported_symbols():
     return ["so_abi_version", "so_last_error", "so_device_cu_count", "so_profile_num_stages",
-            "so_profile_stage_name", "so_profile_stage_begin_end"] + list(_SIGS)
+            "so_profile_stage_name", "so_profile_stage_begin_end", "so_attr_rec_stride"] + list(_SIGS)
 
 
 def load() -> ctypes.CDLL:
@@ -106,6 +117,8 @@ def load() -> ctypes.CDLL:
         lib.so_profile_num_stages.restype = c_int
         lib.so_profile_stage_name.restype = ctypes.c_char_p
         lib.so_profile_stage_name.argtypes = [c_int]
+        lib.so_attr_rec_stride.restype = c_i64
+        lib.so_attr_rec_stride.argtypes = [c_int]
         for name, argtypes in _SIGS.items():
             fn = getattr(lib, name)
             fn.argtypes = argtypes

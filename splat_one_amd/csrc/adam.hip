@@ -72,23 +72,33 @@ __global__ void k_adam_prep(AdamSched sch, int n_groups, double beta1, double be
   adam_schedule_block(sch.lr0, sch.lr_gamma, n_groups, beta1, beta2, step_ptr, hyper);
 }
 
-__global__ void __launch_bounds__(256)
-k_adam_dev(AdamGroups groups, AdamHyper h, const float2 *__restrict__ hyper, int zero_grad,
-           const int32_t *__restrict__ skip_i32, const float *__restrict__ skip_f32) {
-  // a void iteration (binning overflow on this or, summed through the all-reduce, on any rank) leaves the
-  // parameters and moments untouched
-  if ((skip_i32 && *skip_i32 != 0) || (skip_f32 && *skip_f32 != 0.f)) return;
-  const so_adam_group G = groups.g[blockIdx.y];
-  const float2 hy = hyper[blockIdx.y];
-  const float step_size = hy.x, bc2_sqrt = hy.y;
+// float16 shadow of a parameter group inside the attribute rows of attr_rec.hpp: element e of a group whose rows are
+// RL elements long lives at arec + (e / RL) * stride + off + 2 * (e % RL).  RL is a template parameter for the row
+// lengths of the six 3DGS tensors (division by a constant), 0 = run-time row length, -1 = no shadow.
+struct AttrShadowDev {
+  uint8_t *arec;
+  int32_t stride;
+  int32_t off[SO_ADAM_MAX_GROUPS];   // < 0: the group has no float16 copy
+};
+
+template <int RL>
+__device__ __forceinline__ void shadow_store(uint8_t *arec, int stride, int off, int rl, uint32_t e, float p) {
+  const uint32_t r = RL > 0 ? (uint32_t)RL : (uint32_t)rl;
+  const uint32_t n = e / r, j = e - n * r;
+  *reinterpret_cast<_Float16 *>(arec + (int64_t)n * stride + off + 2 * j) = (_Float16)p;
+}
+
+template <int RL>
+__device__ __forceinline__ void adam_dev_loop(const so_adam_group G, const AdamHyper h, float step_size, float bc2_sqrt,
+                                              int zero_grad, uint8_t *arec, int stride, int off) {
   const int64_t n4 = G.numel / 4;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   float4 *p4 = reinterpret_cast<float4 *>(G.param);
   float4 *g4 = reinterpret_cast<float4 *>(G.grad);
   float4 *m4 = reinterpret_cast<float4 *>(G.exp_avg);
   float4 *v4 = reinterpret_cast<float4 *>(G.exp_avg_sq);
-  for (int64_t i = t0; i < n4; i += stride) {
+  for (int64_t i = t0; i < n4; i += gstride) {
     float4 p = p4[i], g = g4[i], m = m4[i], v = v4[i];
     adam_one(p.x, g.x, m.x, v.x, h, step_size, bc2_sqrt);
     adam_one(p.y, g.y, m.y, v.y, h, step_size, bc2_sqrt);
@@ -96,21 +106,53 @@ k_adam_dev(AdamGroups groups, AdamHyper h, const float2 *__restrict__ hyper, int
     adam_one(p.w, g.w, m.w, v.w, h, step_size, bc2_sqrt);
     p4[i] = p; m4[i] = m; v4[i] = v;
     if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (RL >= 0) {
+      const uint32_t e = (uint32_t)i * 4u;
+      if (RL == 4) {   // one row per float4: a single 8-byte store
+        *reinterpret_cast<uint2 *>(arec + i * stride + off) =
+            make_uint2((uint32_t)__builtin_bit_cast(unsigned short, (_Float16)p.x) | ((uint32_t)__builtin_bit_cast(unsigned short, (_Float16)p.y) << 16),
+                       (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)p.z) | ((uint32_t)__builtin_bit_cast(unsigned short, (_Float16)p.w) << 16));
+      } else {
+        shadow_store<RL>(arec, stride, off, G.row_len, e, p.x);
+        shadow_store<RL>(arec, stride, off, G.row_len, e + 1, p.y);
+        shadow_store<RL>(arec, stride, off, G.row_len, e + 2, p.z);
+        shadow_store<RL>(arec, stride, off, G.row_len, e + 3, p.w);
+      }
+    }
   }
-  for (int64_t i = n4 * 4 + t0; i < G.numel; i += stride) {
+  for (int64_t i = n4 * 4 + t0; i < G.numel; i += gstride) {
     float p = G.param[i], m = G.exp_avg[i], v = G.exp_avg_sq[i];
     adam_one(p, G.grad[i], m, v, h, step_size, bc2_sqrt);
     G.param[i] = p; G.exp_avg[i] = m; G.exp_avg_sq[i] = v;
     if (zero_grad) G.grad[i] = 0.f;
+    if (RL >= 0) shadow_store<RL>(arec, stride, off, G.row_len, (uint32_t)i, p);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_adam_dev(AdamGroups groups, AdamHyper h, const float2 *__restrict__ hyper, int zero_grad,
+           const int32_t *__restrict__ skip_i32, const float *__restrict__ skip_f32, AttrShadowDev sh) {
+  // a void iteration (binning overflow on this or, summed through the all-reduce, on any rank) leaves the
+  // parameters and moments untouched
+  if ((skip_i32 && *skip_i32 != 0) || (skip_f32 && *skip_f32 != 0.f)) return;
+  const so_adam_group G = groups.g[blockIdx.y];
+  const float2 hy = hyper[blockIdx.y];
+  const int off = sh.arec ? sh.off[blockIdx.y] : -1;
+  if (off < 0) { adam_dev_loop<-1>(G, h, hy.x, hy.y, zero_grad, nullptr, 0, 0); return; }
+  switch (G.row_len) {   // uniform over the workgroup
+    case 3: adam_dev_loop<3>(G, h, hy.x, hy.y, zero_grad, sh.arec, sh.stride, off); break;
+    case 4: adam_dev_loop<4>(G, h, hy.x, hy.y, zero_grad, sh.arec, sh.stride, off); break;
+    case 45: adam_dev_loop<45>(G, h, hy.x, hy.y, zero_grad, sh.arec, sh.stride, off); break;
+    default: adam_dev_loop<0>(G, h, hy.x, hy.y, zero_grad, sh.arec, sh.stride, off); break;
   }
 }
 
 }  // namespace so
 
-extern "C" int so_adam_step_dev(int n_groups, const so_adam_group *host_groups, const float *host_lr0,
-                                const float *host_lr_gamma, double beta1, double beta2, double eps,
-                                int32_t *step_counter, int zero_grad, int schedule_done, const int32_t *skip_i32,
-                                const float *skip_f32, void *stream) {
+extern "C" int so_adam_step_dev_shadow(int n_groups, const so_adam_group *host_groups, const float *host_lr0,
+                                       const float *host_lr_gamma, double beta1, double beta2, double eps,
+                                       int32_t *step_counter, int zero_grad, int schedule_done, const int32_t *skip_i32,
+                                       const float *skip_f32, const so_attr_shadow *shadow, void *stream) {
   SO_REQUIRE(n_groups >= 0 && n_groups <= SO_ADAM_MAX_GROUPS, "so_adam_step_dev: n_groups %d not in [0,%d]", n_groups, SO_ADAM_MAX_GROUPS);
   SO_REQUIRE(step_counter, "so_adam_step_dev: null step counter");
   if (n_groups == 0) return SO_OK;
@@ -124,6 +166,12 @@ extern "C" int so_adam_step_dev(int n_groups, const so_adam_group *host_groups, 
     SO_REQUIRE(g.numel == 0 || (g.param && g.grad && g.exp_avg && g.exp_avg_sq), "so_adam_step_dev: group %d null pointer", i);
     SO_REQUIRE((((uintptr_t)g.param | (uintptr_t)g.grad | (uintptr_t)g.exp_avg | (uintptr_t)g.exp_avg_sq) & 15) == 0,
                "so_adam_step_dev: group %d buffers must be 16-byte aligned", i);
+    if (shadow && shadow->arec && shadow->offset_bytes[i] >= 0)
+      SO_REQUIRE(g.row_len >= 1 && g.numel % g.row_len == 0 && g.numel < ((int64_t)1 << 31) &&
+                     shadow->offset_bytes[i] + 2 * g.row_len <= shadow->stride_bytes &&
+                     shadow->offset_bytes[i] % (g.row_len == 4 ? 8 : 2) == 0,
+                 "so_adam_step_dev_shadow: group %d does not fit the float16 rows (row_len %d, offset %d, stride %d)", i,
+                 g.row_len, shadow->offset_bytes[i], shadow->stride_bytes);
     G.g[i] = g;
     S.lr0[i] = host_lr0[i];
     S.lr_gamma[i] = host_lr_gamma[i];
@@ -140,10 +188,26 @@ extern "C" int so_adam_step_dev(int n_groups, const so_adam_group *host_groups, 
     if (gx > 2048) gx = 2048;
     if (gx < 1) gx = 1;
     const so::AdamHyper H{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps};
-    hipLaunchKernelGGL(so::k_adam_dev, dim3((unsigned)gx, (unsigned)n_groups), dim3(256), 0, st, G, H, hyper, zero_grad, skip_i32, skip_f32);
+    so::AttrShadowDev SH{};
+    if (shadow && shadow->arec) {
+      SO_REQUIRE((((uintptr_t)shadow->arec) & 15) == 0 && shadow->stride_bytes > 0 && shadow->stride_bytes % 16 == 0,
+                 "so_adam_step_dev_shadow: arec must be 16-byte aligned with a stride that is a multiple of 16");
+      SH.arec = reinterpret_cast<uint8_t *>(shadow->arec);
+      SH.stride = shadow->stride_bytes;
+      for (int i = 0; i < SO_ADAM_MAX_GROUPS; ++i) SH.off[i] = i < n_groups ? shadow->offset_bytes[i] : -1;
+    }
+    hipLaunchKernelGGL(so::k_adam_dev, dim3((unsigned)gx, (unsigned)n_groups), dim3(256), 0, st, G, H, hyper, zero_grad, skip_i32, skip_f32, SH);
   }
   so_profile_stage_begin_end(8, 0, stream);
   return so::check_launch("so_adam_step_dev");
+}
+
+extern "C" int so_adam_step_dev(int n_groups, const so_adam_group *host_groups, const float *host_lr0,
+                                const float *host_lr_gamma, double beta1, double beta2, double eps,
+                                int32_t *step_counter, int zero_grad, int schedule_done, const int32_t *skip_i32,
+                                const float *skip_f32, void *stream) {
+  return so_adam_step_dev_shadow(n_groups, host_groups, host_lr0, host_lr_gamma, beta1, beta2, eps, step_counter,
+                                 zero_grad, schedule_done, skip_i32, skip_f32, nullptr, stream);
 }
 
 extern "C" int so_adam_step(int n_groups, const so_adam_group *host_groups, double beta1, double beta2, double eps,

@@ -11,6 +11,7 @@
 // Same math as projection.hip / sh.hip (splat_math.hpp); one lane per (camera, Gaussian) forward,
 // one lane per Gaussian backward (no atomics on parameter gradients).
 #include "so_common.hpp"
+#include "attr_rec.hpp"
 #include "splat_math.hpp"
 
 namespace so {
@@ -36,11 +37,10 @@ __device__ __forceinline__ CamP load_camp(const float *__restrict__ viewmats, co
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 
-template <int DEG>
+template <int DEG, class A>
 __global__ void __launch_bounds__(256)
-k_preprocess_fwd(int C, int N, int K, const float *__restrict__ means, const float *__restrict__ log_scales,
-                 const float *__restrict__ quats, const float *__restrict__ logit_opac,
-                 const float *__restrict__ sh0, const float *__restrict__ shN, const float *__restrict__ viewmats,
+k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__restrict__ logit_opac, const A attrs,
+                 const float *__restrict__ viewmats,
                  const float *__restrict__ Ks, int W, int H, float eps2d, float near_plane, float far_plane,
                  float radius_clip, int model, int antialiased, float tile_size, int tile_w, int tile_h,
                  int32_t *__restrict__ radii, float *__restrict__ means2d, float *__restrict__ depths,
@@ -59,9 +59,9 @@ k_preprocess_fwd(int C, int N, int K, const float *__restrict__ means, const flo
     const int64_t idx = (int64_t)c * cam_stride + n;   // row of the per-view arrays (cam_stride >= N)
     const CamP cam = load_camp(viewmats, Ks, c);
     const float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
-    const float4 qq = *reinterpret_cast<const float4 *>(quats + 4 * n);
-    const float q[4] = {qq.x, qq.y, qq.z, qq.w};
-    const float s[3] = {expf(log_scales[3 * n]), expf(log_scales[3 * n + 1]), expf(log_scales[3 * n + 2])};
+    float q[4], ls[3];
+    attrs.base(n, q, ls);
+    const float s[3] = {expf(ls[0]), expf(ls[1]), expf(ls[2])};
     ProjOut<float> o;
     project_fwd<float>(mean, nullptr, q, s, cam.Rw, cam.tw, cam.fx, cam.fy, cam.cx, cam.cy, W, H, eps2d, near_plane,
                        far_plane, radius_clip, model, o);
@@ -77,10 +77,10 @@ k_preprocess_fwd(int C, int N, int K, const float *__restrict__ means, const flo
       float dx = mean[0] - cam.pos[0], dy = mean[1] - cam.pos[1], dz = mean[2] - cam.pos[2];
       const float inorm = rsqrtf(dx * dx + dy * dy + dz * dz);
       dx *= inorm; dy *= inorm; dz *= inorm;
-      const float *c0 = sh0 + 3 * n;
-      const float *cN = shN + (int64_t)n * (K - 1) * 3;
+      const auto coef = attrs.template coefs<DEG>(n);
       sh_eval<float>(DEG, dx, dy, dz, [&](int k, float yk, float, float, float) {
-        const float *cf = (k == 0) ? c0 : cN + 3 * (k - 1);
+        float cf[3];
+        coef.get(k, cf);
         r += yk * cf[0]; g += yk * cf[1]; b += yk * cf[2];
       });
       r = fmaxf(r + 0.5f, 0.f); g = fmaxf(g + 0.5f, 0.f); b = fmaxf(b + 0.5f, 0.f);
@@ -135,11 +135,10 @@ k_preprocess_fwd(int C, int N, int K, const float *__restrict__ means, const flo
 
 // (One wave per SIMD: 256 VGPRs + AGPRs.  Forcing two with __launch_bounds__(256, 2) spills 49 registers
 // and measured slower, 23.1 vs 20.5 us at 100k Gaussians.)
-template <int DEG>
+template <int DEG, class A>
 __global__ void __launch_bounds__(256)
-k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const float *__restrict__ log_scales,
-                 const float *__restrict__ quats, const float *__restrict__ logit_opac,
-                 const float *__restrict__ sh0, const float *__restrict__ shN, const float *__restrict__ viewmats,
+k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const float *__restrict__ logit_opac,
+                 const A attrs, const float *__restrict__ viewmats,
                  const float *__restrict__ Ks, int W, int H, float eps2d, int model, int antialiased,
                  const int32_t *__restrict__ radii, const float *__restrict__ opacities,
                  const float *__restrict__ colors, const float *__restrict__ v_means2d,
@@ -160,10 +159,11 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
   if (skip) return;
   for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
     const float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
-    const float4 qq = *reinterpret_cast<const float4 *>(quats + 4 * n);
-    const float q[4] = {qq.x, qq.y, qq.z, qq.w};
-    const float s[3] = {expf(log_scales[3 * n]), expf(log_scales[3 * n + 1]), expf(log_scales[3 * n + 2])};
+    float q[4], ls[3];
+    attrs.base(n, q, ls);
+    const float s[3] = {expf(ls[0]), expf(ls[1]), expf(ls[2])};
     const float sig = sigmoidf(logit_opac[n]);
+    const auto coef = attrs.template coefs<DEG>(n);
     float vm[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f};
     float v_sig = 0.f, g2 = 0.f, cn = 0.f;
     float acc[NB][3];
@@ -206,12 +206,11 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
       const float ddx = mean[0] - cam.pos[0], ddy = mean[1] - cam.pos[1], ddz = mean[2] - cam.pos[2];
       const float inorm = rsqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
       const float x = ddx * inorm, y = ddy * inorm, z = ddz * inorm;
-      const float *c0 = sh0 + 3 * n;
-      const float *cN = shN + n * (int64_t)(K - 1) * 3;
       float vdn[3] = {0.f, 0.f, 0.f};
       sh_eval<float>(DEG, x, y, z, [&](int k, float yk, float gx, float gy, float gz) {
         acc[k][0] += yk * vr; acc[k][1] += yk * vg; acc[k][2] += yk * vb;
-        const float *cf = (k == 0) ? c0 : cN + 3 * (k - 1);
+        float cf[3];
+        coef.get(k, cf);
         const float w = cf[0] * vr + cf[1] * vg + cf[2] * vb;
         vdn[0] += gx * w; vdn[1] += gy * w; vdn[2] += gz * w;
       });
@@ -267,6 +266,118 @@ static inline int pp_grid(int64_t total) {
   return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
 
+// float32 SoA -> float16 attribute rows (attr_rec.hpp): one lane per 16-byte chunk, coalesced stores
+__global__ void __launch_bounds__(256)
+k_attr_pack_f16(int64_t N, int K, int stride16, const float *__restrict__ log_scales, const float *__restrict__ quats,
+                const float *__restrict__ sh0, const float *__restrict__ shN, uint4 *__restrict__ arec) {
+  const int64_t total = N * stride16;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / stride16;
+    const int t = (int)(i - n * stride16);
+    float v[8];
+    if (t == 0) {
+      const float4 q = *reinterpret_cast<const float4 *>(quats + 4 * n);
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+      v[4] = log_scales[3 * n]; v[5] = log_scales[3 * n + 1]; v[6] = log_scales[3 * n + 2]; v[7] = 0.f;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int h = 8 * (t - 1) + j;   // half index in the SH part: sh0 (3) then shN (3 (K-1))
+        v[j] = h < 3 ? sh0[3 * n + h] : (h < 3 * K ? shN[n * (int64_t)(3 * (K - 1)) + (h - 3)] : 0.f);
+      }
+    }
+    arec[i] = make_uint4(pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7]));
+  }
+}
+
+template <class A>
+static int preprocess_fwd_impl(const char *what, int C, int N, int K, int sh_degree, const float *means,
+                               const float *logit_opacities, const A &attrs, const float *viewmats, const float *Ks,
+                               int width, int height, float eps2d, float near_plane, float far_plane, float radius_clip,
+                               int camera_model, int antialiased, int tile_size, int32_t *radii, float *means2d,
+                               float *depths, float *conics, float *opacities, float *colors, int32_t *tiles_per_gauss,
+                               int32_t *tile_counts, float *rec, float *vrec, int64_t cam_stride, void *stream) {
+  SO_REQUIRE(C >= 0 && N >= 0 && K >= 1 && width > 0 && height > 0 && tile_size > 0, "%s: bad sizes", what);
+  SO_REQUIRE(sh_degree >= 0 && sh_degree <= 4 && (sh_degree + 1) * (sh_degree + 1) <= K,
+             "%s: sh_degree %d does not fit K=%d", what, sh_degree, K);
+  if (camera_model < 0 || camera_model > SO_CAM_FISHEYE) {
+    set_error("%s: unsupported camera_model %d", what, camera_model);
+    return SO_ERR_UNSUPPORTED;
+  }
+  if ((int64_t)C * N == 0) return SO_OK;
+  SO_REQUIRE(means && logit_opacities && viewmats && Ks && radii && means2d && depths && conics && opacities && colors &&
+                 tiles_per_gauss, "%s: null pointer", what);
+  if (cam_stride == 0) cam_stride = N;
+  SO_REQUIRE(cam_stride >= N, "%s: cam_stride %lld < N %d", what, (long long)cam_stride, N);
+  const int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
+  const dim3 grid(pp_grid((int64_t)C * N)), block(256);
+  hipStream_t st = as_stream(stream);
+#define SO_LAUNCH(D)                                                                                               \
+  hipLaunchKernelGGL((k_preprocess_fwd<D, A>), grid, block, 0, st, C, N, means, logit_opacities, attrs, viewmats,  \
+                     Ks, width, height, eps2d, near_plane, far_plane, radius_clip, camera_model, antialiased,      \
+                     (float)tile_size, tile_w, tile_h, radii, means2d, depths, conics, opacities, colors,          \
+                     tiles_per_gauss, tile_counts, reinterpret_cast<float4 *>(rec), reinterpret_cast<float4 *>(vrec), \
+                     cam_stride)
+  switch (sh_degree) {
+    case 0: SO_LAUNCH(0); break;
+    case 1: SO_LAUNCH(1); break;
+    case 2: SO_LAUNCH(2); break;
+    case 3: SO_LAUNCH(3); break;
+    default: SO_LAUNCH(4); break;
+  }
+#undef SO_LAUNCH
+  return check_launch(what);
+}
+
+template <class A>
+static int preprocess_bwd_impl(const char *what, int C, int N, int K, int sh_degree, const float *means,
+                               const float *logit_opacities, const A &attrs, const float *viewmats, const float *Ks,
+                               int width, int height, float eps2d, int camera_model, int antialiased,
+                               const int32_t *radii, const float *opacities, const float *colors,
+                               const float *v_means2d, const float *v_means2d_abs, const float *v_depths,
+                               const float *v_conics, const float *v_colors, const float *v_opacities,
+                               float opacity_reg, float scale_reg, float *v_means, float *v_log_scales, float *v_quats,
+                               float *v_logit_opacities, float *v_sh0, float *v_shN, float *grad2d, float *count,
+                               const float *vrec, int absgrad_stats, int64_t cam_stride, const int32_t *skip_flag,
+                               float *skip_out, void *stream) {
+  SO_REQUIRE(C >= 0 && N >= 0 && K >= 1 && width > 0 && height > 0, "%s: bad sizes", what);
+  SO_REQUIRE(sh_degree >= 0 && sh_degree <= 4 && (sh_degree + 1) * (sh_degree + 1) <= K,
+             "%s: sh_degree %d does not fit K=%d", what, sh_degree, K);
+  if (camera_model < 0 || camera_model > SO_CAM_FISHEYE) {
+    set_error("%s: unsupported camera_model %d", what, camera_model);
+    return SO_ERR_UNSUPPORTED;
+  }
+  if (N == 0) return SO_OK;
+  SO_REQUIRE(means && logit_opacities && viewmats && Ks && radii && opacities && colors &&
+                 (vrec || (v_means2d && v_conics && v_colors && v_opacities)) && v_means && v_log_scales && v_quats &&
+                 v_logit_opacities && v_sh0 && (v_shN || K == 1), "%s: null pointer", what);
+  SO_REQUIRE((((uintptr_t)vrec) & 63) == 0, "%s: vrec must be 64-byte aligned", what);
+  if (cam_stride == 0) cam_stride = N;
+  SO_REQUIRE(cam_stride >= N, "%s: cam_stride %lld < N %d", what, (long long)cam_stride, N);
+  if (!vrec && v_means2d_abs) absgrad_stats = 1;
+  SO_REQUIRE((grad2d == nullptr) == (count == nullptr), "%s: grad2d and count go together", what);
+  const dim3 grid(pp_grid(N)), block(256);
+  hipStream_t st = as_stream(stream);
+  const float sx = 0.5f * (float)width * (float)C, sy = 0.5f * (float)height * (float)C;
+#define SO_LAUNCH(D)                                                                                              \
+  hipLaunchKernelGGL((k_preprocess_bwd<D, A>), grid, block, 0, st, C, N, K, means, logit_opacities, attrs,        \
+                     viewmats, Ks, width, height, eps2d, camera_model, antialiased, radii, opacities, colors,     \
+                     v_means2d, v_means2d_abs, v_depths, v_conics, v_colors, v_opacities, opacity_reg, scale_reg, \
+                     v_means, v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN, grad2d, count, sx, sy,      \
+                     reinterpret_cast<const float4 *>(vrec), absgrad_stats, cam_stride, skip_flag, skip_out)
+  switch (sh_degree) {
+    case 0: SO_LAUNCH(0); break;
+    case 1: SO_LAUNCH(1); break;
+    case 2: SO_LAUNCH(2); break;
+    case 3: SO_LAUNCH(3); break;
+    default: SO_LAUNCH(4); break;
+  }
+#undef SO_LAUNCH
+  return check_launch(what);
+}
+
+static inline bool attr_rec_ok(const void *arec) { return arec && (((uintptr_t)arec) & 15) == 0; }
+
 }  // namespace so
 
 extern "C" int so_preprocess_fwd(int C, int N, int K, int sh_degree, const float *means, const float *log_scales,
@@ -277,37 +388,27 @@ extern "C" int so_preprocess_fwd(int C, int N, int K, int sh_degree, const float
                                  float *depths, float *conics, float *opacities, float *colors,
                                  int32_t *tiles_per_gauss, int32_t *tile_counts, float *rec, float *vrec,
                                  int64_t cam_stride, void *stream) {
-  SO_REQUIRE(C >= 0 && N >= 0 && K >= 1 && width > 0 && height > 0 && tile_size > 0, "so_preprocess_fwd: bad sizes");
-  SO_REQUIRE(sh_degree >= 0 && sh_degree <= 4 && (sh_degree + 1) * (sh_degree + 1) <= K,
-             "so_preprocess_fwd: sh_degree %d does not fit K=%d", sh_degree, K);
-  if (camera_model < 0 || camera_model > SO_CAM_FISHEYE) {
-    so::set_error("so_preprocess_fwd: unsupported camera_model %d", camera_model);
-    return SO_ERR_UNSUPPORTED;
-  }
-  if ((int64_t)C * N == 0) return SO_OK;
-  SO_REQUIRE(means && log_scales && quats && logit_opacities && sh0 && (shN || K == 1) && viewmats && Ks && radii &&
-                 means2d && depths && conics && opacities && colors && tiles_per_gauss,
-             "so_preprocess_fwd: null pointer");
-  if (cam_stride == 0) cam_stride = N;
-  SO_REQUIRE(cam_stride >= N, "so_preprocess_fwd: cam_stride %lld < N %d", (long long)cam_stride, N);
-  const int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
-  const dim3 grid(so::pp_grid((int64_t)C * N)), block(256);
-  hipStream_t st = so::as_stream(stream);
-#define SO_LAUNCH(D)                                                                                               \
-  hipLaunchKernelGGL(so::k_preprocess_fwd<D>, grid, block, 0, st, C, N, K, means, log_scales, quats,               \
-                     logit_opacities, sh0, shN, viewmats, Ks, width, height, eps2d, near_plane, far_plane,         \
-                     radius_clip, camera_model, antialiased, (float)tile_size, tile_w, tile_h, radii, means2d,     \
-                     depths, conics, opacities, colors, tiles_per_gauss, tile_counts,                              \
-                     reinterpret_cast<float4 *>(rec), reinterpret_cast<float4 *>(vrec), cam_stride)
-  switch (sh_degree) {
-    case 0: SO_LAUNCH(0); break;
-    case 1: SO_LAUNCH(1); break;
-    case 2: SO_LAUNCH(2); break;
-    case 3: SO_LAUNCH(3); break;
-    default: SO_LAUNCH(4); break;
-  }
-#undef SO_LAUNCH
-  return so::check_launch("so_preprocess_fwd");
+  SO_REQUIRE((int64_t)C * N == 0 || (log_scales && quats && sh0 && (shN || K == 1)), "so_preprocess_fwd: null pointer");
+  const so::AttrSoA attrs{log_scales, quats, sh0, shN, K};
+  return so::preprocess_fwd_impl("so_preprocess_fwd", C, N, K, sh_degree, means, logit_opacities, attrs, viewmats, Ks,
+                                 width, height, eps2d, near_plane, far_plane, radius_clip, camera_model, antialiased,
+                                 tile_size, radii, means2d, depths, conics, opacities, colors, tiles_per_gauss,
+                                 tile_counts, rec, vrec, cam_stride, stream);
+}
+
+extern "C" int so_preprocess_fwd_f16(int C, int N, int K, int sh_degree, const float *means,
+                                     const float *logit_opacities, const void *arec, const float *viewmats,
+                                     const float *Ks, int width, int height, float eps2d, float near_plane,
+                                     float far_plane, float radius_clip, int camera_model, int antialiased,
+                                     int tile_size, int32_t *radii, float *means2d, float *depths, float *conics,
+                                     float *opacities, float *colors, int32_t *tiles_per_gauss, int32_t *tile_counts,
+                                     float *rec, float *vrec, int64_t cam_stride, void *stream) {
+  SO_REQUIRE((int64_t)C * N == 0 || so::attr_rec_ok(arec), "so_preprocess_fwd_f16: arec must be non-null and 16-byte aligned");
+  const so::AttrRec attrs{reinterpret_cast<const uint4 *>(arec), so::attr_rec_stride_bytes(K < 1 ? 1 : K) / 16};
+  return so::preprocess_fwd_impl("so_preprocess_fwd_f16", C, N, K, sh_degree, means, logit_opacities, attrs, viewmats,
+                                 Ks, width, height, eps2d, near_plane, far_plane, radius_clip, camera_model,
+                                 antialiased, tile_size, radii, means2d, depths, conics, opacities, colors,
+                                 tiles_per_gauss, tile_counts, rec, vrec, cam_stride, stream);
 }
 
 extern "C" int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float *means, const float *log_scales,
@@ -321,41 +422,45 @@ extern "C" int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float
                                  float *v_logit_opacities, float *v_sh0, float *v_shN, float *grad2d, float *count,
                                  const float *vrec, int absgrad_stats, int64_t cam_stride, const int32_t *skip_flag,
                                  float *skip_out, void *stream) {
-  SO_REQUIRE(C >= 0 && N >= 0 && K >= 1 && width > 0 && height > 0, "so_preprocess_bwd: bad sizes");
-  SO_REQUIRE(sh_degree >= 0 && sh_degree <= 4 && (sh_degree + 1) * (sh_degree + 1) <= K,
-             "so_preprocess_bwd: sh_degree %d does not fit K=%d", sh_degree, K);
-  if (camera_model < 0 || camera_model > SO_CAM_FISHEYE) {
-    so::set_error("so_preprocess_bwd: unsupported camera_model %d", camera_model);
-    return SO_ERR_UNSUPPORTED;
-  }
+  SO_REQUIRE(N == 0 || (log_scales && quats && sh0 && (shN || K == 1)), "so_preprocess_bwd: null pointer");
+  const so::AttrSoA attrs{log_scales, quats, sh0, shN, K};
+  return so::preprocess_bwd_impl("so_preprocess_bwd", C, N, K, sh_degree, means, logit_opacities, attrs, viewmats, Ks,
+                                 width, height, eps2d, camera_model, antialiased, radii, opacities, colors, v_means2d,
+                                 v_means2d_abs, v_depths, v_conics, v_colors, v_opacities, opacity_reg, scale_reg,
+                                 v_means, v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN, grad2d, count, vrec,
+                                 absgrad_stats, cam_stride, skip_flag, skip_out, stream);
+}
+
+extern "C" int so_preprocess_bwd_f16(int C, int N, int K, int sh_degree, const float *means,
+                                     const float *logit_opacities, const void *arec, const float *viewmats,
+                                     const float *Ks, int width, int height, float eps2d, int camera_model,
+                                     int antialiased, const int32_t *radii, const float *opacities,
+                                     const float *colors, float opacity_reg, float scale_reg, float *v_means,
+                                     float *v_log_scales, float *v_quats, float *v_logit_opacities, float *v_sh0,
+                                     float *v_shN, float *grad2d, float *count, const float *vrec, int absgrad_stats,
+                                     int64_t cam_stride, const int32_t *skip_flag, float *skip_out, void *stream) {
+  SO_REQUIRE(N == 0 || so::attr_rec_ok(arec), "so_preprocess_bwd_f16: arec must be non-null and 16-byte aligned");
+  SO_REQUIRE(N == 0 || vrec, "so_preprocess_bwd_f16: the gradient records (vrec) are required");
+  const so::AttrRec attrs{reinterpret_cast<const uint4 *>(arec), so::attr_rec_stride_bytes(K < 1 ? 1 : K) / 16};
+  return so::preprocess_bwd_impl("so_preprocess_bwd_f16", C, N, K, sh_degree, means, logit_opacities, attrs, viewmats,
+                                 Ks, width, height, eps2d, camera_model, antialiased, radii, opacities, colors, nullptr,
+                                 nullptr, nullptr, nullptr, nullptr, nullptr, opacity_reg, scale_reg, v_means,
+                                 v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN, grad2d, count, vrec,
+                                 absgrad_stats, cam_stride, skip_flag, skip_out, stream);
+}
+
+extern "C" int64_t so_attr_rec_stride(int K) { return K >= 1 ? so::attr_rec_stride_bytes(K) : 0; }
+
+extern "C" int so_attr_pack_f16(int64_t N, int K, const float *log_scales, const float *quats, const float *sh0,
+                                const float *shN, void *arec, void *stream) {
+  SO_REQUIRE(N >= 0 && K >= 1, "so_attr_pack_f16: bad sizes");
   if (N == 0) return SO_OK;
-  SO_REQUIRE(means && log_scales && quats && logit_opacities && sh0 && (shN || K == 1) && viewmats && Ks && radii &&
-                 opacities && colors && (vrec || (v_means2d && v_conics && v_colors && v_opacities)) && v_means &&
-                 v_log_scales && v_quats && v_logit_opacities && v_sh0 && (v_shN || K == 1),
-             "so_preprocess_bwd: null pointer");
-  SO_REQUIRE((((uintptr_t)vrec) & 63) == 0, "so_preprocess_bwd: vrec must be 64-byte aligned");
-  if (cam_stride == 0) cam_stride = N;
-  SO_REQUIRE(cam_stride >= N, "so_preprocess_bwd: cam_stride %lld < N %d", (long long)cam_stride, N);
-  if (!vrec && v_means2d_abs) absgrad_stats = 1;
-  SO_REQUIRE((grad2d == nullptr) == (count == nullptr), "so_preprocess_bwd: grad2d and count go together");
-  const dim3 grid(so::pp_grid(N)), block(256);
-  hipStream_t st = so::as_stream(stream);
-  const float sx = 0.5f * (float)width * (float)C, sy = 0.5f * (float)height * (float)C;
-#define SO_LAUNCH(D)                                                                                              \
-  hipLaunchKernelGGL(so::k_preprocess_bwd<D>, grid, block, 0, st, C, N, K, means, log_scales, quats,              \
-                     logit_opacities, sh0, shN, viewmats, Ks, width, height, eps2d, camera_model, antialiased,    \
-                     radii, opacities, colors, v_means2d, v_means2d_abs, v_depths, v_conics, v_colors,            \
-                     v_opacities, opacity_reg, scale_reg, v_means, v_log_scales, v_quats, v_logit_opacities,      \
-                     v_sh0, v_shN, grad2d, count, sx, sy, reinterpret_cast<const float4 *>(vrec), absgrad_stats, cam_stride, skip_flag, skip_out)
-  switch (sh_degree) {
-    case 0: SO_LAUNCH(0); break;
-    case 1: SO_LAUNCH(1); break;
-    case 2: SO_LAUNCH(2); break;
-    case 3: SO_LAUNCH(3); break;
-    default: SO_LAUNCH(4); break;
-  }
-#undef SO_LAUNCH
-  return so::check_launch("so_preprocess_bwd");
+  SO_REQUIRE(log_scales && quats && sh0 && (shN || K == 1), "so_attr_pack_f16: null pointer");
+  SO_REQUIRE(so::attr_rec_ok(arec), "so_attr_pack_f16: arec must be non-null and 16-byte aligned");
+  const int stride16 = so::attr_rec_stride_bytes(K) / 16;
+  hipLaunchKernelGGL(so::k_attr_pack_f16, dim3(so::pp_grid(N * stride16)), dim3(256), 0, so::as_stream(stream), N, K,
+                     stride16, log_scales, quats, sh0, shN, reinterpret_cast<uint4 *>(arec));
+  return so::check_launch("so_attr_pack_f16");
 }
 
 extern "C" int so_rec_unpack(int64_t n, const float *rec, float *means2d, int32_t *radii, float *depths, float *vrec,

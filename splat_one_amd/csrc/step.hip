@@ -172,6 +172,12 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
   }
 #define SO_TRY(call) do { rc = (call); if (rc != SO_OK) return rc; } while (0)
 #define SO_STAGE(i, call) do { so::StageTimer _t(i, st); SO_TRY(call); } while (0)
+  if (d->attr_rows_f16)
+    SO_STAGE(0, so_preprocess_fwd_f16(C, N, K, d->sh_degree, d->means, d->logit_opacities, d->attr_rows_f16, d->viewmats, d->Ks,
+                                      W, H, d->eps2d, d->near_plane, d->far_plane, d->radius_clip, d->camera_model,
+                                      d->antialiased, ts, d->radii, d->means2d, d->depths, d->conics, d->opacities, d->colors,
+                                      d->tiles_per_gauss, tile_counts, d->rec, forward_only ? nullptr : d->vrec, 0, stream));
+  else
   SO_STAGE(0, so_preprocess_fwd(C, N, K, d->sh_degree, d->means, d->log_scales, d->quats, d->logit_opacities, d->sh0, d->shN,
                            d->viewmats, d->Ks, W, H, d->eps2d, d->near_plane, d->far_plane, d->radius_clip,
                            d->camera_model, d->antialiased, ts, d->radii, d->means2d, d->depths, d->conics,
@@ -203,6 +209,13 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
     SO_STAGE(6, so_rasterize_bwd_packed(C, N, W, H, ts, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects,
                                         d->isect_capacity, d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
                                         d->absgrad, stream));
+  if (d->attr_rows_f16)
+    SO_STAGE(7, so_preprocess_bwd_f16(C, N, K, d->sh_degree, d->means, d->logit_opacities, d->attr_rows_f16, d->viewmats, d->Ks,
+                                      W, H, d->eps2d, d->camera_model, d->antialiased, d->radii, d->opacities, d->colors,
+                                      d->opacity_reg, d->scale_reg, d->v_means, d->v_log_scales, d->v_quats,
+                                      d->v_logit_opacities, d->v_sh0, d->v_shN, d->grad2d, d->count, d->vrec, d->absgrad, 0,
+                                      overflow, d->overflow_flag_out, stream));
+  else
   SO_STAGE(7, so_preprocess_bwd(C, N, K, d->sh_degree, d->means, d->log_scales, d->quats, d->logit_opacities, d->sh0, d->shN,
                            d->viewmats, d->Ks, W, H, d->eps2d, d->camera_model, d->antialiased, d->radii, d->opacities,
                            d->colors, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d->opacity_reg,

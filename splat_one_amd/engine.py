@@ -36,7 +36,13 @@ class FusedEngine:
                  antialiased: bool = False, absgrad: bool = False, ssim_lambda: float = 0.2,
                  opacity_reg: float = 0.0, scale_reg: float = 0.0, tile_size: int = 16,
                  strategy_state: Optional[dict] = None, lr_gamma_means: float = 1.0,
-                 isect_capacity: Optional[int] = None, use_graph: bool = True, raster_impl: int = 0):
+                 isect_capacity: Optional[int] = None, use_graph: bool = True, raster_impl: int = 0,
+                 attr_dtype: str = "f32"):
+        """attr_dtype="f16": quaternions, log-scales and SH coefficients are READ from float16 attribute rows
+        (include/splat_one_amd.h, so_attr_pack_f16: 112 instead of 224 bytes per Gaussian at SH degree 3); the
+        float32 parameters stay the masters Adam updates, and the same Adam launch refreshes the halves."""
+        assert attr_dtype in ("f32", "f16"), attr_dtype
+        self.attr_dtype = attr_dtype
         self.splats, self.optimizers = splats, optimizers
         self.W, self.H, self.C = int(width), int(height), int(n_views)
         self.cfg = dict(sh_degree=sh_degree, camera_model=camera_model, near_plane=near_plane, far_plane=far_plane,
@@ -115,12 +121,33 @@ class FusedEngine:
             off += pad(n)
         for k in PARAM_ORDER:
             self.splats[k].grad = w["grads"][k]
+        if self.attr_dtype == "f16":
+            self.attr_stride = int(_lib.load().so_attr_rec_stride(K))
+            w["arec"] = torch.empty(N * self.attr_stride // 4, dtype=f32, device=dev)
+            self.refresh_attrs()
         if self.strategy_state is not None:
             for k in ("grad2d", "count"):
                 if self.strategy_state.get(k) is None or self.strategy_state[k].shape[0] != N:
                     self.strategy_state[k] = torch.zeros(N, device=dev)
         self._graph = None
         self._graph_fb = self._graph_opt = None
+
+    def refresh_attrs(self) -> None:
+        """Rebuild the float16 attribute rows from the float32 masters (after anything but the engine's own
+        optimiser step wrote quats / scales / sh0 / shN: densification, relocation, a loaded checkpoint)."""
+        if self.attr_dtype != "f16":
+            return
+        s, p = self.splats, _lib.ptr
+        _lib.call("so_attr_pack_f16", self.N, self.K, p(s["scales"].data), p(s["quats"].data), p(s["sh0"].data),
+                  p(s["shN"].data), p(self.ws["arec"]), _lib.stream())
+
+    def attr_rows(self) -> Dict[str, Tensor]:
+        """The float16 rows decoded to float32 tensors shaped like the parameters (tests, inspection)."""
+        assert self.attr_dtype == "f16"
+        h = self.ws["arec"].view(torch.float16).view(self.N, self.attr_stride // 2)
+        K = self.K
+        return {"quats": h[:, 0:4].float(), "scales": h[:, 4:7].float(), "sh0": h[:, 8:11].float().view(self.N, 1, 3),
+                "shN": h[:, 11:8 + 3 * K].float().reshape(self.N, K - 1, 3)}
 
     def _desc(self) -> _lib.StepDesc:
         w, s, c = self.ws, self.splats, self.cfg
@@ -149,6 +176,7 @@ class FusedEngine:
         d.ssim_lambda, d.opacity_reg, d.scale_reg = c["ssim_lambda"], c["opacity_reg"], c["scale_reg"]
         d.pixels_indirect, d.inputs_staged = p(w["pixels_slot"]), 1     # every launch is preceded by _stage()
         d.overflow_flag_out = p(w["ovf_f32"])
+        d.attr_rows_f16 = p(w["arec"]) if self.attr_dtype == "f16" else 0
         return d
 
     def _adam_args(self):
@@ -171,7 +199,7 @@ class FusedEngine:
         gam = (ctypes.c_float * n)()
         for i, (k, (prm, st, grp)) in enumerate(zip(PARAM_ORDER, items)):
             arr[i] = _lib.AdamGroup(_lib.ptr(prm.data), _lib.ptr(self.ws["grads"][k]), _lib.ptr(st["exp_avg"]),
-                                    _lib.ptr(st["exp_avg_sq"]), 0, prm.numel(), 1, 0.0, 0.0)
+                                    _lib.ptr(st["exp_avg_sq"]), 0, prm.numel(), max(1, prm[0].numel() if len(prm) else 1), 0.0, 0.0)
             # base LR of the schedule: the optimiser's current lr un-decayed to step 0
             g = self.lr_gamma_means if k == "means" else 1.0
             lr0[i] = grp["lr"] / (g ** self.steps_done)
@@ -287,8 +315,16 @@ class FusedEngine:
     def _launch_optimize(self, schedule_done: bool = False) -> None:
         n, arr, lr0, gam, betas, eps = self._adam_args()
         ovf = self.ws["counters"][2 * self.M + 2:]
-        _lib.call("so_adam_step_dev", n, arr, lr0, gam, float(betas[0]), float(betas[1]), float(eps),
-                  _lib.ptr(self._step_dev), 0, int(schedule_done), _lib.ptr(ovf), _lib.ptr(self.ws["ovf_f32"]), _lib.stream())
+        shadow = None
+        if self.attr_dtype == "f16":                 # the same launch keeps the float16 rows equal to the masters
+            where = {"scales": 8, "quats": 0, "sh0": 16, "shN": 22}
+            shadow = _lib.AttrShadow(_lib.ptr(self.ws["arec"]), self.attr_stride,
+                                     (ctypes.c_int32 * _lib.SO_ADAM_MAX_GROUPS)(*(
+                                         [where.get(k, -1) if self.splats[k].numel() else -1 for k in PARAM_ORDER]
+                                         + [-1] * (_lib.SO_ADAM_MAX_GROUPS - len(PARAM_ORDER)))))
+        _lib.call("so_adam_step_dev_shadow", n, arr, lr0, gam, float(betas[0]), float(betas[1]), float(eps),
+                  _lib.ptr(self._step_dev), 0, int(schedule_done), _lib.ptr(ovf), _lib.ptr(self.ws["ovf_f32"]),
+                  ctypes.byref(shadow) if shadow is not None else None, _lib.stream())
 
     def set_cameras(self, camtoworlds: Tensor, Ks: Tensor) -> None:
         """Cameras only (forward-only rendering needs no target image)."""

@@ -91,6 +91,10 @@ class Config:
     #                       exchanged (two all-to-alls of ~64 B/Gaussian), per-rank densification / checkpoints;
     #   "allreduce"         replicated Gaussians, one all-reduce of the 236 B/Gaussian gradient SoA
     dp_mode: str = "gaussian_sharded"
+    # "f16": the fused step reads quaternions, log-scales and SH coefficients from float16 attribute rows (112
+    # instead of 224 B per Gaussian; float32 masters + Adam state unchanged, checkpoints hold the masters) --
+    # BASELINE.json configs[4].  Single-GPU and dp_mode="allreduce" runs.
+    attr_dtype: str = "f32"
     shN_init_std: float = 0.0              # >0: noise instead of zeros in the higher SH bands (bench scenes)
 
     def adjust_steps(self, factor: float):
@@ -481,7 +485,7 @@ class Runner:
                 strategy_state=(self.strategy_state if isinstance(s, DefaultStrategy) else None),
                 lr_gamma_means=self.lr_gamma,
                 isect_capacity=cfg.isect_capacity, use_graph=True,
-                raster_impl=getattr(self, "raster_impl", 0))
+                raster_impl=getattr(self, "raster_impl", 0), attr_dtype=cfg.attr_dtype)
             eng.steps_done = step
             eng._step_dev[0] = step
             if self.world_size > 1:
