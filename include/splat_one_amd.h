@@ -43,6 +43,11 @@ enum so_status {
 };
 
 enum so_camera_model { SO_CAM_PINHOLE = 0, SO_CAM_ORTHO = 1, SO_CAM_FISHEYE = 2 };
+/* The fused entry points (so_preprocess_fwd / _bwd and their _f16 forms, so_step_desc.camera_model) also take one
+ * model PER VIEW -- BASELINE.json configs[4] mixes perspective and fisheye cameras (app/camera_models.py:230-237)
+ * in one batch:  SO_CAM_PER_VIEW | m_0 | m_1 << 2 | ... | m_{C-1} << 2 (C-1),  2 bits per view, C <= 15. */
+#define SO_CAM_PER_VIEW 0x40000000
+#define SO_CAM_PER_VIEW_MAX 15
 
 int so_abi_version(void);
 const char *so_last_error(void);

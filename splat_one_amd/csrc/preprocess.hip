@@ -35,6 +35,17 @@ __device__ __forceinline__ CamP load_camp(const float *__restrict__ viewmats, co
   return p;
 }
 
+// one model for all views, or SO_CAM_PER_VIEW with 2 bits per view
+__device__ __forceinline__ int cam_model_of(int cm, int c) { return (cm & SO_CAM_PER_VIEW) ? ((cm >> (2 * c)) & 3) : cm; }
+
+static bool camera_model_ok(int cm, int C) {
+  if (!(cm & SO_CAM_PER_VIEW)) return cm >= 0 && cm <= SO_CAM_FISHEYE;
+  if (C > SO_CAM_PER_VIEW_MAX) return false;
+  for (int c = 0; c < C; ++c)
+    if (((cm >> (2 * c)) & 3) > SO_CAM_FISHEYE) return false;
+  return true;
+}
+
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 
 template <int DEG, class A>
@@ -64,7 +75,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
     const float s[3] = {expf(ls[0]), expf(ls[1]), expf(ls[2])};
     ProjOut<float> o;
     project_fwd<float>(mean, nullptr, q, s, cam.Rw, cam.tw, cam.fx, cam.fy, cam.cx, cam.cy, W, H, eps2d, near_plane,
-                       far_plane, radius_clip, model, o);
+                       far_plane, radius_clip, cam_model_of(model, c), o);
     radii[idx] = o.radius;
     *reinterpret_cast<float2 *>(means2d + 2 * idx) = make_float2(o.m2d[0], o.m2d[1]);
     depths[idx] = o.depth;
@@ -197,7 +208,7 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
       } else {
         v_sig += v_op;
       }
-      project_bwd<float>(mean, nullptr, q, s, cam.Rw, cam.tw, cam.fx, cam.fy, cam.cx, cam.cy, W, H, eps2d, model,
+      project_bwd<float>(mean, nullptr, q, s, cam.Rw, cam.tw, cam.fx, cam.fy, cam.cx, cam.cy, W, H, eps2d, cam_model_of(model, c),
                          v_m2d, v_depths ? v_depths[idx] : 0.f, v_con, v_comp, vm, nullptr, vq, vs, nullptr, nullptr);
       // SH backward (through +0.5 / clamp: the saved colour is 0 exactly where the clamp cut)
       if (!(colors[3 * idx] > 0.f)) vr = 0.f;
@@ -300,8 +311,8 @@ static int preprocess_fwd_impl(const char *what, int C, int N, int K, int sh_deg
   SO_REQUIRE(C >= 0 && N >= 0 && K >= 1 && width > 0 && height > 0 && tile_size > 0, "%s: bad sizes", what);
   SO_REQUIRE(sh_degree >= 0 && sh_degree <= 4 && (sh_degree + 1) * (sh_degree + 1) <= K,
              "%s: sh_degree %d does not fit K=%d", what, sh_degree, K);
-  if (camera_model < 0 || camera_model > SO_CAM_FISHEYE) {
-    set_error("%s: unsupported camera_model %d", what, camera_model);
+  if (!camera_model_ok(camera_model, C)) {
+    set_error("%s: unsupported camera_model 0x%x for %d views", what, camera_model, C);
     return SO_ERR_UNSUPPORTED;
   }
   if ((int64_t)C * N == 0) return SO_OK;
@@ -343,8 +354,8 @@ static int preprocess_bwd_impl(const char *what, int C, int N, int K, int sh_deg
   SO_REQUIRE(C >= 0 && N >= 0 && K >= 1 && width > 0 && height > 0, "%s: bad sizes", what);
   SO_REQUIRE(sh_degree >= 0 && sh_degree <= 4 && (sh_degree + 1) * (sh_degree + 1) <= K,
              "%s: sh_degree %d does not fit K=%d", what, sh_degree, K);
-  if (camera_model < 0 || camera_model > SO_CAM_FISHEYE) {
-    set_error("%s: unsupported camera_model %d", what, camera_model);
+  if (!camera_model_ok(camera_model, C)) {
+    set_error("%s: unsupported camera_model 0x%x for %d views", what, camera_model, C);
     return SO_ERR_UNSUPPORTED;
   }
   if (N == 0) return SO_OK;

@@ -24,7 +24,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from .ops import CAMERA_MODELS
+from .ops import camera_model_code
 
 PARAM_ORDER = ("means", "scales", "quats", "opacities", "sh0", "shN")
 
@@ -54,7 +54,7 @@ class FusedEngine:
         self.use_graph = use_graph
         self.device = splats["means"].device
         assert self.device.type == "cuda", "FusedEngine needs HIP tensors (no CPU path exists)"
-        assert camera_model in CAMERA_MODELS, camera_model
+        camera_model_code(camera_model, self.C)      # a name, or one name per view (mixed batches)
         self._capacity_hint = isect_capacity
         self._graph: Optional[torch.cuda.CUDAGraph] = None
         self._graph_key = None
@@ -169,7 +169,7 @@ class FusedEngine:
         d.isect_capacity = self.capacity
         d.abi_size = ctypes.sizeof(_lib.StepDesc)
         d.C, d.N, d.K, d.width, d.height, d.tile_size = self.C, self.N, self.K, self.W, self.H, c["tile_size"]
-        d.sh_degree, d.camera_model = c["sh_degree"], CAMERA_MODELS[c["camera_model"]]
+        d.sh_degree, d.camera_model = c["sh_degree"], camera_model_code(c["camera_model"], self.C)
         d.antialiased, d.absgrad = int(c["antialiased"]), int(c["absgrad"])
         d.raster_impl = int(c["raster_impl"])
         d.eps2d, d.near_plane, d.far_plane, d.radius_clip = c["eps2d"], c["near_plane"], c["far_plane"], c["radius_clip"]

@@ -36,6 +36,25 @@ def _camera_model_id(camera_model: str) -> int:
     return CAMERA_MODELS[camera_model]
 
 
+SO_CAM_PER_VIEW, SO_CAM_PER_VIEW_MAX = 0x40000000, 15
+
+
+def camera_model_code(camera_model, n_views: int) -> int:
+    """`camera_model` argument of the fused entry points: one name for all views, or one name per view
+    (mixed perspective / fisheye batches; include/splat_one_amd.h SO_CAM_PER_VIEW)."""
+    if isinstance(camera_model, str):
+        return _camera_model_id(camera_model)
+    models = list(camera_model)
+    assert len(models) == n_views, f"{len(models)} camera models for {n_views} views"
+    if len(set(models)) == 1:
+        return _camera_model_id(models[0])
+    assert n_views <= SO_CAM_PER_VIEW_MAX, f"per-view camera models: at most {SO_CAM_PER_VIEW_MAX} views per step"
+    code = SO_CAM_PER_VIEW
+    for c, m in enumerate(models):
+        code |= _camera_model_id(m) << (2 * c)
+    return code
+
+
 # ---------------------------------------------------------------------------------------------
 # K1/K2 projection
 # ---------------------------------------------------------------------------------------------

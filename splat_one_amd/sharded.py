@@ -37,7 +37,7 @@ from torch import Tensor
 
 from . import _lib
 from .engine import PARAM_ORDER
-from .ops import CAMERA_MODELS
+from .ops import camera_model_code
 
 
 def all_to_all_rows(out: Tensor, inp: Tensor, group=None) -> None:
@@ -57,18 +57,21 @@ class ShardedEngine:
                  near_plane: float = 0.01, far_plane: float = 1e8, radius_clip: float = 0.0, eps2d: float = 0.3,
                  antialiased: bool = False, absgrad: bool = False, ssim_lambda: float = 0.2, opacity_reg: float = 0.0,
                  scale_reg: float = 0.0, tile_size: int = 16, strategy_state: Optional[dict] = None,
-                 lr_gamma_means: float = 1.0, isect_capacity: Optional[int] = None, group=None):
+                 lr_gamma_means: float = 1.0, isect_capacity: Optional[int] = None, group=None,
+                 attr_dtype: str = "f32"):
         assert dist.is_initialized() and dist.get_world_size(group) == world, "ShardedEngine needs the process group"
         self.splats, self.optimizers = splats, optimizers
         self.W, self.H, self.rank, self.world, self.group = int(width), int(height), int(rank), int(world), group
         self.cfg = dict(sh_degree=sh_degree, camera_model=camera_model, near_plane=near_plane, far_plane=far_plane,
                         radius_clip=radius_clip, eps2d=eps2d, antialiased=antialiased, absgrad=absgrad,
                         ssim_lambda=ssim_lambda, opacity_reg=opacity_reg, scale_reg=scale_reg, tile_size=tile_size)
+        assert attr_dtype in ("f32", "f16"), attr_dtype
+        self.attr_dtype = attr_dtype                  # "f16": float16 attribute rows of the own shard (see FusedEngine)
         self.strategy_state = strategy_state
         self.lr_gamma_means = lr_gamma_means
         self.device = splats["means"].device
         assert self.device.type == "cuda", "ShardedEngine needs HIP tensors (no CPU path exists)"
-        assert camera_model in CAMERA_MODELS, camera_model
+        camera_model_code(camera_model, world)       # a name, or the names of the cameras of ALL ranks in rank order
         self._capacity_hint = isect_capacity
         self.steps_done = 0
         self._step_dev = torch.zeros(2 + 4 * _lib.SO_ADAM_MAX_GROUPS, dtype=torch.int32, device=self.device)
@@ -130,6 +133,13 @@ class ShardedEngine:
             off += pad(m)
         for k in PARAM_ORDER:
             self.splats[k].grad = w["grads"][k]
+        if self.attr_dtype == "f16":
+            self.attr_stride = int(_lib.load().so_attr_rec_stride(K))
+            w["arec"] = e(max(N, 1) * self.attr_stride // 4)
+            if N > 0:
+                sp, p = self.splats, _lib.ptr
+                _lib.call("so_attr_pack_f16", N, K, p(sp["scales"].data), p(sp["quats"].data), p(sp["sh0"].data),
+                          p(sp["shN"].data), p(w["arec"]), _lib.stream())
         if self.strategy_state is not None:
             for k in ("grad2d", "count"):
                 if self.strategy_state.get(k) is None or self.strategy_state[k].shape[0] != N:
@@ -163,7 +173,7 @@ class ShardedEngine:
         gam = (ctypes.c_float * n)()
         for i, (k, (prm, st, grp)) in enumerate(zip(PARAM_ORDER, items)):
             arr[i] = _lib.AdamGroup(_lib.ptr(prm.data), _lib.ptr(self.ws["grads"][k]), _lib.ptr(st["exp_avg"]),
-                                    _lib.ptr(st["exp_avg_sq"]), 0, prm.numel(), 1, 0.0, 0.0)
+                                    _lib.ptr(st["exp_avg_sq"]), 0, prm.numel(), max(1, prm[0].numel() if len(prm) else 1), 0.0, 0.0)
             g = self.lr_gamma_means if k == "means" else 1.0
             lr0[i] = grp["lr"] / (g ** self.steps_done)
             gam[i] = g
@@ -196,8 +206,14 @@ class ShardedEngine:
         self._status_event.record()
         ts = c["tile_size"]
         tw, th = math.ceil(W / ts), math.ceil(H / ts)
-        cam = CAMERA_MODELS[c["camera_model"]]
-        if N > 0:
+        cam = camera_model_code(c["camera_model"], n)
+        f16 = self.attr_dtype == "f16"
+        if N > 0 and f16:
+            _lib.call("so_preprocess_fwd_f16", n, N, self.K, c["sh_degree"], p(s["means"].data), p(s["opacities"].data),
+                      p(w["arec"]), p(w["viewmats"]), p(w["Ks"]), W, H, c["eps2d"], c["near_plane"], c["far_plane"],
+                      c["radius_clip"], cam, int(c["antialiased"]), ts, p(w["radii"]), p(w["means2d"]), p(w["depths"]),
+                      p(w["conics"]), p(w["opacities"]), p(w["colors"]), p(w["tiles_per_gauss"]), 0, p(w["rec_shard"]), 0, cap, st)
+        elif N > 0:
             _lib.call("so_preprocess_fwd", n, N, self.K, c["sh_degree"], p(s["means"].data), p(s["scales"].data),
                       p(s["quats"].data), p(s["opacities"].data), p(s["sh0"].data), p(s["shN"].data), p(w["viewmats"]),
                       p(w["Ks"]), W, H, c["eps2d"], c["near_plane"], c["far_plane"], c["radius_clip"], cam,
@@ -242,13 +258,21 @@ class ShardedEngine:
             sst = self.strategy_state
             # the regularisers are means over ALL Gaussians: rescale the kernel's 1/N to 1/N_total
             scale = float(N) / float(max(self.N_total, 1))
-            _lib.call("so_preprocess_bwd", n, N, self.K, c["sh_degree"], p(s["means"].data), p(s["scales"].data),
-                      p(s["quats"].data), p(s["opacities"].data), p(s["sh0"].data), p(s["shN"].data), p(w["viewmats"]),
-                      p(w["Ks"]), W, H, c["eps2d"], cam, int(c["antialiased"]), p(w["radii"]), p(w["opacities"]),
-                      p(w["colors"]), 0, 0, 0, 0, 0, 0, c["opacity_reg"] * scale, c["scale_reg"] * scale, p(g["means"]),
-                      p(g["scales"]), p(g["quats"]), p(g["opacities"]), p(g["sh0"]), p(g["shN"]),
-                      p(sst["grad2d"]) if sst is not None else 0, p(sst["count"]) if sst is not None else 0,
-                      p(w["vrec_shard"]), int(c["absgrad"]), cap, p(overflow), 0, st)
+            if f16:
+                _lib.call("so_preprocess_bwd_f16", n, N, self.K, c["sh_degree"], p(s["means"].data), p(s["opacities"].data),
+                          p(w["arec"]), p(w["viewmats"]), p(w["Ks"]), W, H, c["eps2d"], cam, int(c["antialiased"]),
+                          p(w["radii"]), p(w["opacities"]), p(w["colors"]), c["opacity_reg"] * scale, c["scale_reg"] * scale,
+                          p(g["means"]), p(g["scales"]), p(g["quats"]), p(g["opacities"]), p(g["sh0"]), p(g["shN"]),
+                          p(sst["grad2d"]) if sst is not None else 0, p(sst["count"]) if sst is not None else 0,
+                          p(w["vrec_shard"]), int(c["absgrad"]), cap, p(overflow), 0, st)
+            else:
+                _lib.call("so_preprocess_bwd", n, N, self.K, c["sh_degree"], p(s["means"].data), p(s["scales"].data),
+                          p(s["quats"].data), p(s["opacities"].data), p(s["sh0"].data), p(s["shN"].data), p(w["viewmats"]),
+                          p(w["Ks"]), W, H, c["eps2d"], cam, int(c["antialiased"]), p(w["radii"]), p(w["opacities"]),
+                          p(w["colors"]), 0, 0, 0, 0, 0, 0, c["opacity_reg"] * scale, c["scale_reg"] * scale, p(g["means"]),
+                          p(g["scales"]), p(g["quats"]), p(g["opacities"]), p(g["sh0"]), p(g["shN"]),
+                          p(sst["grad2d"]) if sst is not None else 0, p(sst["count"]) if sst is not None else 0,
+                          p(w["vrec_shard"]), int(c["absgrad"]), cap, p(overflow), 0, st)
         self._keep = (c2w, Ksd, px)
         self._sched_staged = bool(schedule)
 
@@ -271,8 +295,16 @@ class ShardedEngine:
         sched = getattr(self, "_sched_staged", False)
         self._sched_staged = False
         ovf = self.ws["counters"][2 * self.M + 2:]
-        _lib.call("so_adam_step_dev", n, arr, lr0, gam, float(betas[0]), float(betas[1]), float(eps),
-                  _lib.ptr(self._step_dev), 0, int(sched), _lib.ptr(ovf), 0, _lib.stream())
+        shadow = None
+        if self.attr_dtype == "f16" and self.N > 0:
+            where = {"scales": 8, "quats": 0, "sh0": 16, "shN": 22}
+            shadow = _lib.AttrShadow(_lib.ptr(self.ws["arec"]), self.attr_stride,
+                                     (ctypes.c_int32 * _lib.SO_ADAM_MAX_GROUPS)(*(
+                                         [where.get(k, -1) if self.splats[k].numel() else -1 for k in PARAM_ORDER]
+                                         + [-1] * (_lib.SO_ADAM_MAX_GROUPS - len(PARAM_ORDER)))))
+        _lib.call("so_adam_step_dev_shadow", n, arr, lr0, gam, float(betas[0]), float(betas[1]), float(eps),
+                  _lib.ptr(self._step_dev), 0, int(sched), _lib.ptr(ovf), 0,
+                  ctypes.byref(shadow) if shadow is not None else None, _lib.stream())
         self.steps_done += 1
         for k in PARAM_ORDER:
             self.optimizers[k].state[self.splats[k]]["step"] += 1

@@ -65,7 +65,9 @@ class Config:
     opacity_reg: float = 0.0
     scale_reg: float = 0.0
     global_scale: float = 1.0
-    camera_model: str = "pinhole"   # reference default "spherical" is fork-only (no specification)
+    # reference default "spherical" is fork-only (no specification).  On the fused path also a list with one
+    # name per view of the batch (mixed perspective / fisheye batches)
+    camera_model: str = "pinhole"
     # data / results (gsplat_trainer.py:67-104): consumed by Runner.from_data_dir, eval, render_traj, checkpoints
     ckpt: Optional[List[str]] = None
     render_traj_path: str = "interp"
@@ -93,7 +95,7 @@ class Config:
     dp_mode: str = "gaussian_sharded"
     # "f16": the fused step reads quaternions, log-scales and SH coefficients from float16 attribute rows (112
     # instead of 224 B per Gaussian; float32 masters + Adam state unchanged, checkpoints hold the masters) --
-    # BASELINE.json configs[4].  Single-GPU and dp_mode="allreduce" runs.
+    # BASELINE.json configs[4].
     attr_dtype: str = "f32"
     shN_init_std: float = 0.0              # >0: noise instead of zeros in the higher SH bands (bench scenes)
 
@@ -187,6 +189,13 @@ class Runner:
         self.sharded = (world_size > 1 and cfg.fused and cfg.dp_mode == "gaussian_sharded" and cfg.batch_size == 1
                         and sdist.is_initialized())
         assert cfg.dp_mode in ("gaussian_sharded", "allreduce"), cfg.dp_mode
+        # Config.camera_model may differ between ranks (BASELINE.json configs[4]: even ranks perspective, odd ranks
+        # fisheye).  A gaussian_sharded step projects the own shard into the cameras of ALL ranks: learn their models.
+        self.camera_models_all = [cfg.camera_model]
+        if self.sharded:
+            import torch.distributed as dist
+            self.camera_models_all = [None] * world_size
+            dist.all_gather_object(self.camera_models_all, cfg.camera_model)
         self.splats, self.optimizers = create_splats_with_optimizers(
             points, rgbs, init_type=cfg.init_type, init_num_pts=cfg.init_num_pts, init_extent=cfg.init_extent,
             init_opacity=cfg.init_opa, init_scale=cfg.init_scale, scene_scale=self.scene_scale,
@@ -553,11 +562,11 @@ class Runner:
         if eng is None or (eng.H, eng.W) != (H, W):
             eng = self._engine = ShardedEngine(
                 self.splats, self.optimizers, W, H, self.world_rank, self.world_size, sh_degree=0,
-                camera_model=cfg.camera_model, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
+                camera_model=self.camera_models_all, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
                 antialiased=cfg.antialiased, absgrad=getattr(s, "absgrad", False), ssim_lambda=cfg.ssim_lambda,
                 opacity_reg=cfg.opacity_reg, scale_reg=cfg.scale_reg,
                 strategy_state=(self.strategy_state if isinstance(s, DefaultStrategy) else None),
-                lr_gamma_means=self.lr_gamma, isect_capacity=cfg.isect_capacity)
+                lr_gamma_means=self.lr_gamma, isect_capacity=cfg.isect_capacity, attr_dtype=cfg.attr_dtype)
             eng.steps_done = step
             eng._step_dev[0] = step
         eng.set_sh_degree(min(step // cfg.sh_degree_interval, cfg.sh_degree))

@@ -145,3 +145,38 @@ def test_c5_mixed_pinhole_fisheye_views(dev):
         assert (eng.ws["render_colors"].cpu().double() - rc_o).abs().mean().item() <= 1e-4, model
         assert abs(eng.loss()[0].item() - loss_o) < 1e-5
         _check_grads({k: v.grad for k, v in r.splats.items()}, g_o)
+
+
+def test_c5_mixed_batch_f16_attributes(dev):
+    """configs[4] in ONE step: a batch of a pinhole view and a fisheye view (per-view camera models,
+    SO_CAM_PER_VIEW) read from float16 attribute rows.  The oracle renders each view with its own model at the
+    half-rounded attribute values; the step's loss is the mean over the two views."""
+    from splat_one_amd.engine import FusedEngine
+    from splat_one_amd.trainer import Config, Runner
+    W, H, N = 640, 360, 200_000
+    models = ["pinhole", "fisheye"]
+    ring = ring_cameras(8)
+    Ks = pinhole_K(W, H)[None].repeat(2, 1, 1).to(dev)
+    r = Runner(0, 0, 1, Config(init_num_pts=N, init_scale=0.1, init_opa=0.5, shN_init_std=0.1, batch_size=2), scene_scale=1.0 / 1.1)
+    c2w = ring[0:2].to(dev)
+    pixels = torch.cat([torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(v)) for v in range(2)]).to(dev)
+    eng = FusedEngine(r.splats, r.optimizers, W, H, 2, sh_degree=3, camera_model=models, use_graph=False, attr_dtype="f16")
+    eng.set_views(c2w, Ks, pixels)
+    eng.fwd_bwd()
+    rounded = {k: (v.detach().half().float() if k in ("quats", "scales", "sh0", "shN") else v.detach()) for k, v in r.splats.items()}
+    g_sum, loss_sum = None, 0.0
+    for v, model in enumerate(models):
+        rc_o, g_o, _, (loss_o, _, _) = _oracle_step(rounded, c2w[v:v + 1], Ks[v:v + 1], W, H, pixels[v:v + 1], camera_model=model)
+        assert (eng.ws["render_colors"][v:v + 1].cpu().double() - rc_o).abs().mean().item() <= 1e-4, model
+        g_sum = g_o if g_sum is None else {k: g_sum[k] + g_o[k] for k in g_o}
+        loss_sum += loss_o
+    # the per-view L1 / SSIM terms are means over the batch: each view enters with weight 1/2
+    assert abs(eng.loss()[0].item() - loss_sum / 2) < 1e-5
+    _check_grads({k: v.grad for k, v in r.splats.items()}, {k: v / 2 for k, v in g_sum.items()})
+    # a uniform list is the plain model; a wrong length or an unknown name is refused before any launch
+    from splat_one_amd.ops import camera_model_code
+    assert camera_model_code(["fisheye", "fisheye"], 2) == 2 and camera_model_code("ortho", 7) == 1
+    with pytest.raises(AssertionError):
+        camera_model_code(["pinhole"], 2)
+    with pytest.raises(AssertionError):
+        camera_model_code(["pinhole", "spherical"], 2)

@@ -116,12 +116,17 @@ def _global_perturbation(N):
     return torch.randn(N, 3, generator=g) * 0.4, torch.rand(N, 4, generator=g), torch.randn(N, 15, 3, generator=g) * 0.05
 
 
-def _sharded_worker(local_rank, world_rank, world_size, out_dir):
+MIXED_MODELS = ["pinhole", "fisheye"]
+
+
+def _sharded_worker(local_rank, world_rank, world_size, args):
     from splat_one_amd.trainer import Config, Runner
+    out_dir, mixed = args
     dev = torch.device("cuda:0")
     W, H, N = 128, 96, 3001                           # odd: the shards differ in length (1501 / 1500)
     cfg = Config(init_num_pts=N, init_scale=0.3, init_opa=0.3, sh_degree_interval=1, fused=True, opacity_reg=0.01,
-                 scale_reg=0.01, dp_mode="gaussian_sharded")
+                 scale_reg=0.01, dp_mode="gaussian_sharded",
+                 camera_model=(MIXED_MODELS[world_rank] if mixed else "pinhole"), attr_dtype=("f16" if mixed else "f32"))
     r = Runner(0, world_rank, world_size, cfg, scene_scale=1.0 / 1.1)
     assert r.sharded and len(r.splats["means"]) == len(range(world_rank, N, world_size))
     ds, q, sh = _global_perturbation(N)
@@ -142,14 +147,17 @@ def _sharded_worker(local_rank, world_rank, world_size, out_dir):
                 "loss": torch.stack(losses).cpu(), "stats": st}, os.path.join(out_dir, f"rank{world_rank}.pt"))
 
 
-def test_gaussian_sharded_dp_two_ranks_one_gpu(dev, tmp_path):
+@pytest.mark.parametrize("mixed", [False, True])
+def test_gaussian_sharded_dp_two_ranks_one_gpu(dev, tmp_path, mixed):
     """world_size 2 over gloo with HIP tensors: the two shards, trained with the all-to-all exchange of
-    projected Gaussians, equal the corresponding rows of a single-process batch-of-2 run."""
+    projected Gaussians, equal the corresponding rows of a single-process batch-of-2 run.  mixed: rank 0 owns a
+    pinhole camera, rank 1 a fisheye camera, attributes are read from float16 rows (BASELINE.json configs[4]); every
+    rank projects its shard into both cameras."""
     from splat_one_amd import distributed as sdist
     from splat_one_amd.trainer import Config, Runner
     env_backup = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     try:
-        sdist.cli(_sharded_worker, str(tmp_path), world_size=2, backend="gloo", port=_free_port())
+        sdist.cli(_sharded_worker, (str(tmp_path), mixed), world_size=2, backend="gloo", port=_free_port())
     finally:
         for k, v in env_backup.items():
             if v is not None:
@@ -157,7 +165,8 @@ def test_gaussian_sharded_dp_two_ranks_one_gpu(dev, tmp_path):
     out = [torch.load(os.path.join(tmp_path, f"rank{i}.pt")) for i in range(2)]
     W, H, N = 128, 96, 3001
     cfg = Config(init_num_pts=N, init_scale=0.3, init_opa=0.3, sh_degree_interval=1, fused=True, batch_size=2,
-                 opacity_reg=0.01, scale_reg=0.01)
+                 opacity_reg=0.01, scale_reg=0.01, camera_model=(MIXED_MODELS if mixed else "pinhole"),
+                 attr_dtype=("f16" if mixed else "f32"))
     r = Runner(0, 0, 1, cfg, scene_scale=1.0 / 1.1)
     ds, q, sh = _global_perturbation(N)
     with torch.no_grad():
