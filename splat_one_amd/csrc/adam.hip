@@ -27,6 +27,15 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
   p = p - step_size * (m / denom);
 }
 
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_nt(const float4 *p) {
+  floatx4 v = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st_nt(float4 *p, float4 a) {
+  floatx4 v = {a.x, a.y, a.z, a.w};
+  __builtin_nontemporal_store(v, reinterpret_cast<floatx4 *>(p));
+}
 __global__ void __launch_bounds__(256)
 k_adam(AdamGroups groups, AdamHyper h, int zero_grad) {
   const so_adam_group G = groups.g[blockIdx.y];
@@ -42,12 +51,12 @@ k_adam(AdamGroups groups, AdamHyper h, int zero_grad) {
       if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       continue;
     }
-    float4 p = p4[i], g = g4[i], m = m4[i], v = v4[i];
+    float4 p = p4[i], g = ld_nt(g4 + i), m = ld_nt(m4 + i), v = ld_nt(v4 + i);
     adam_one(p.x, g.x, m.x, v.x, h, G.lr_step_size, G.bc2_sqrt);
     adam_one(p.y, g.y, m.y, v.y, h, G.lr_step_size, G.bc2_sqrt);
     adam_one(p.z, g.z, m.z, v.z, h, G.lr_step_size, G.bc2_sqrt);
     adam_one(p.w, g.w, m.w, v.w, h, G.lr_step_size, G.bc2_sqrt);
-    p4[i] = p; m4[i] = m; v4[i] = v;
+    p4[i] = p; st_nt(m4 + i, m); st_nt(v4 + i, v);
     if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   for (int64_t i = n4 * 4 + t0; i < G.numel; i += stride) {
@@ -98,13 +107,16 @@ __device__ __forceinline__ void adam_dev_loop(const so_adam_group G, const AdamH
   float4 *g4 = reinterpret_cast<float4 *>(G.grad);
   float4 *m4 = reinterpret_cast<float4 *>(G.exp_avg);
   float4 *v4 = reinterpret_cast<float4 *>(G.exp_avg_sq);
+  // gradient and moments are touched once per iteration: non-temporal loads / stores keep them from evicting
+  // what the next kernels re-read (measured 737 -> 639 us at 2M Gaussians, 35.5 -> 33.9 us at 100k); the
+  // parameters are stored normally, the next forward reads them
   for (int64_t i = t0; i < n4; i += gstride) {
-    float4 p = p4[i], g = g4[i], m = m4[i], v = v4[i];
+    float4 p = p4[i], g = ld_nt(g4 + i), m = ld_nt(m4 + i), v = ld_nt(v4 + i);
     adam_one(p.x, g.x, m.x, v.x, h, step_size, bc2_sqrt);
     adam_one(p.y, g.y, m.y, v.y, h, step_size, bc2_sqrt);
     adam_one(p.z, g.z, m.z, v.z, h, step_size, bc2_sqrt);
     adam_one(p.w, g.w, m.w, v.w, h, step_size, bc2_sqrt);
-    p4[i] = p; m4[i] = m; v4[i] = v;
+    p4[i] = p; st_nt(m4 + i, m); st_nt(v4 + i, v);
     if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (RL >= 0) {
       const uint32_t e = (uint32_t)i * 4u;
