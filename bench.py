@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--operator-path", action="store_true",
                     help="time the operator-level autograd path instead of the fused engine")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel times to stderr")
+    ap.add_argument("--densify", type=int, default=0, metavar="EVERY",
+                    help="BASELINE.json configs[3]: DefaultStrategy duplicates / splits / prunes every EVERY iterations "
+                         "(reference default 100) inside the timed region; 0 = the reference's first 500 iterations (off)")
     ap.add_argument("--attr-dtype", default="f32", choices=["f32", "f16"],
                     help="f16: float16 attribute rows (BASELINE.json configs[4]); float32 arithmetic and masters")
     ap.add_argument("--dp-mode", default="auto", choices=["auto", "gaussian_sharded", "allreduce"],
@@ -107,6 +110,8 @@ def main():
                          "north_star), exchange of projected Gaussians (the reference's own scheme), or auto = time "
                          "both for a few steps on this node and keep the faster")
     args = ap.parse_args()
+    if args.densify:      # the first refinement loads torch's einsum / index kernels (~1 s, once per process): warm it up
+        args.warmup = max(args.warmup, args.densify + 1)
 
     from splat_one_amd import _lib, distributed as sdist
     from splat_one_amd.scene import pinhole_K, ring_cameras, front_camera
@@ -128,6 +133,9 @@ def main():
         cfg = Config(init_num_pts=N, init_scale=init_scale, init_opa=init_opa, batch_size=1, shN_init_std=0.1,
                      camera_model="pinhole", sh_degree_interval=1,    # SH degree 3 from step 3 on
                      fused=not args.operator_path, dp_mode=dp_mode, attr_dtype=args.attr_dtype)
+        if args.densify:
+            from splat_one_amd.strategy import DefaultStrategy
+            cfg.strategy = DefaultStrategy(refine_start_iter=0, refine_every=args.densify, reset_every=3000, verbose=False)
         r = Runner(local_rank, rank, world, cfg, scene_scale=1.0 / 1.1)   # effective scene_scale 1.0
         r.raster_impl = args.raster_impl
         if r.sharded:      # the step takes the cameras of every rank (rank r renders camera r)
@@ -261,7 +269,12 @@ def main():
         for k, (n, ms) in sorted(prof.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
             print(f"  {k:24s} calls {n:5d}  mean {ms * 1e3:9.1f} us  share {n * ms / tot:5.1%}", file=sys.stderr)
 
+    if args.densify:      # a refinement rebuilt the workspace: read the workload counters after a plain iteration
+        runner.train_step(c2w, Ks, pixels)
+        while (runner.step - 1) % args.densify == 0:
+            runner.train_step(c2w, Ks, pixels)
     info = runner.last_info
+    N0, N = N, (N if runner.sharded else int(runner.splats["means"].shape[0]))     # densification changes N
     V = int((info["radii"] > 0).sum().item())
     I = int(info["flatten_ids"].numel()) if "n_isects" not in info else int(info["n_isects"].item())
     P = W * H
@@ -286,7 +299,8 @@ def main():
             traffic = None
 
     out = {
-        "metric": "training iters/sec (100k Gaussians, 1080p, fwd+loss+bwd+Adam)",
+        "metric": ("training iters/sec (100k Gaussians, 1080p, fwd+loss+bwd+Adam)" if (N0, W, H) == (100_000, 1920, 1080)
+                   else f"training iters/sec ({N0} Gaussians, {W}x{H}, fwd+loss+bwd+Adam)"),
         "value": world * args.steps / elapsed,
         "unit": "it/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -295,8 +309,11 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "path": ("sharded engine (C-ABI launches + 2 all-to-all)" if runner.sharded else
                  "fused engine (hipGraph replay)" if fused else "operator-level autograd path"),
-        "config": {"workload": f"c2: {N} Gaussians (reference random init, '{args.regime}' preset), "
-                               f"{W}x{H}, SH degree 3, 1 view per GPU per step, pinhole",
+        "config": {"workload": f"{'c2' if (N0, W, H, args.densify) == (100_000, 1920, 1080, 0) else 'custom'}: {N0} Gaussians "
+                               f"(reference random init, '{args.regime}' preset), "
+                               f"{W}x{H}, SH degree 3, 1 view per GPU per step, pinhole"
+                               + (f", DefaultStrategy refining every {args.densify} iterations ({N0} -> {N} Gaussians)" if args.densify else "")
+                               + (", float16 attribute rows" if args.attr_dtype == "f16" else ""),
                    "views_per_step": world, "visible_gaussians": V, "tile_intersections": I,
                    "parallelism": (f"gaussian-sharded dp{world}: one view per GPU, N/{world} Gaussians per GPU, "
                                    "projected Gaussians exchanged by all-to-all" if runner.sharded else
@@ -311,7 +328,7 @@ def main():
                      "launches_timed": dom_calls},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(N, W, H, args.regime)
+        out["cpu_baseline"] = cpu_baseline(N0, W, H, args.regime)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

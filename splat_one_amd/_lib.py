@@ -12,7 +12,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsplat_one_amd.so")
+# SPLAT_ONE_AMD_LIB: an alternative build of the same library (kernel experiments under tools/); never a fallback
+LIB_PATH = os.environ.get("SPLAT_ONE_AMD_LIB") or os.path.join(_HERE, "lib", "libsplat_one_amd.so")
 
 c_int, c_i64, c_f32, c_ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 

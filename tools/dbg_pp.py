@@ -8,7 +8,7 @@ from splat_one_amd.engine import FusedEngine
 from splat_one_amd.scene import pinhole_K, front_camera
 from splat_one_amd.trainer import Config, Runner
 dev = torch.device("cuda:0")
-N, W, H = 100000, 1920, 1080
+N, W, H = (int(a) for a in (sys.argv[1:4] or (100000, 1920, 1080)))
 cfg = Config(init_num_pts=N, init_scale=0.1, init_opa=0.5, shN_init_std=0.1, sh_degree_interval=1, fused=True)
 r = Runner(0, 0, 1, cfg, scene_scale=1 / 1.1)
 c2w = front_camera()[None].to(dev); Ks = pinhole_K(W, H)[None].to(dev)

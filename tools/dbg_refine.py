@@ -6,7 +6,7 @@ from splat_one_amd.scene import pinhole_K, front_camera
 from splat_one_amd.trainer import Config, Runner
 from splat_one_amd.strategy import DefaultStrategy
 dev = torch.device("cuda:0")
-N, W, H = 100000, 1920, 1080
+N, W, H = (int(a) for a in (sys.argv[1:4] or (100000, 1920, 1080)))
 cfg = Config(init_num_pts=N, init_scale=0.1, init_opa=0.5, shN_init_std=0.1, sh_degree_interval=1, fused=True,
              strategy=DefaultStrategy(refine_start_iter=20, refine_every=10))
 r = Runner(0, 0, 1, cfg, scene_scale=1 / 1.1)
@@ -22,7 +22,10 @@ for step in (30, 40):
     torch.cuda.synchronize()
     pr.disable()
     print(f"step {r.step - 1}: {1e3 * (time.time() - t0):.1f} ms, N = {len(r.splats['means'])}")
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(12)
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
     for i in range(9):
+        t0 = time.time()
         r.train_step(c2w, Ks, pixels)
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        if i < 3:
+            print(f"  step {r.step - 1} (after the refine): {1e3 * (time.time() - t0):.1f} ms")
