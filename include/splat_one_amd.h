@@ -124,12 +124,22 @@ int so_isect_count(int C, int N, const float *means2d, const int32_t *radii, int
                    int tile_height, int32_t *tiles_per_gauss, int32_t *tile_counts, int32_t *isect_offsets,
                    int32_t *n_isects, void *stream);
 /* the exclusive scan of step 1 alone (when the histogram was filled by so_preprocess_fwd) */
-int so_isect_scan(int C, int tile_width, int tile_height, const int32_t *tile_counts, int32_t *isect_offsets,
+int so_isect_scan(int C, int tile_width, int tile_height, const int32_t *tile_counts,
+                  const int32_t *tile_counts_big /* nullable: added element-wise (so_preprocess_fwd tile_slots) */, int32_t *isect_offsets,
                   int32_t *n_isects, void *stream);
 int so_isect_fill(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                   int tile_size, int tile_width, int tile_height, const int32_t *isect_offsets,
                   const int32_t *n_isects, int32_t *tile_cursor, int64_t capacity, uint64_t *key_buf,
-                  int32_t *flatten_ids, int64_t *isect_ids, int32_t *overflow, void *stream);
+                  int32_t *flatten_ids, int64_t *isect_ids, int32_t *overflow,
+                  const int32_t *tile_slots /* nullable, see below */, void *stream);
+/* Slotted binning (tile_slots, int32[C*N][SO_TILE_SLOTS], nullable everywhere): so_preprocess_fwd's histogram uses
+ * RETURNING atomics for rectangles of <= SO_TILE_SLOTS tiles and keeps what they return -- the Gaussian's slot in each
+ * tile's list -- in tile_slots (row-major over the rectangle); larger rectangles are counted apart, in the second half
+ * of a tile_counts[2*C*tiles] array.  so_isect_scan then takes both halves (tile_counts_big = tile_counts + C*tiles)
+ * and so_isect_fill, given the same tile_slots and tile_cursor = that second half, writes a slotted key to
+ * offsets[tile] + slot with no atomic at all and lets the large rectangles fill the tail of each list from the back
+ * (counting tile_cursor down to zero).  One round of atomics per iteration instead of two. */
+#define SO_TILE_SLOTS 12
 
 /* gsplat `isect_tiles(sort=False)`: Gaussian-major, row-major-tile emission order.
  * cum_tiles[C*N] i64 = inclusive prefix sum of tiles_per_gauss (caller-provided). */
@@ -279,7 +289,7 @@ int so_preprocess_fwd(int C, int N, int K, int sh_degree, const float *means, co
                       float near_plane, float far_plane, float radius_clip, int camera_model, int antialiased,
                       int tile_size, int32_t *radii, float *means2d, float *depths, float *conics,
                       float *opacities, float *colors, int32_t *tiles_per_gauss, int32_t *tile_counts,
-                      float *rec, float *vrec, int64_t cam_stride, void *stream);
+                      float *rec, float *vrec, int64_t cam_stride, int32_t *tile_slots, void *stream);
 int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float *means, const float *log_scales,
                       const float *quats, const float *logit_opacities, const float *sh0, const float *shN,
                       const float *viewmats, const float *Ks, int width, int height, float eps2d,
@@ -314,7 +324,8 @@ int so_preprocess_fwd_f16(int C, int N, int K, int sh_degree, const float *means
                           float eps2d, float near_plane, float far_plane, float radius_clip, int camera_model,
                           int antialiased, int tile_size, int32_t *radii, float *means2d, float *depths,
                           float *conics, float *opacities, float *colors, int32_t *tiles_per_gauss,
-                          int32_t *tile_counts, float *rec, float *vrec, int64_t cam_stride, void *stream);
+                          int32_t *tile_counts, float *rec, float *vrec, int64_t cam_stride, int32_t *tile_slots,
+                          void *stream);
 int so_preprocess_bwd_f16(int C, int N, int K, int sh_degree, const float *means, const float *logit_opacities,
                           const void *arec, const float *viewmats, const float *Ks, int width, int height,
                           float eps2d, int camera_model, int antialiased, const int32_t *radii,
@@ -372,6 +383,9 @@ typedef struct so_step_desc {
   /* float16 attribute rows (nullable; see so_attr_pack_f16): when set, quaternions, log-scales and SH coefficients
    * are read from here instead of log_scales / quats / sh0 / shN (which may then be NULL). */
   const void *attr_rows_f16;
+  /* int32[C*N][SO_TILE_SLOTS] scratch (nullable): the binning histogram keeps the slot each returning atomic handed
+   * out, so the scatter pass places those keys without a second round of atomics (see so_preprocess_fwd). */
+  int32_t *tile_slots;
 } so_step_desc;
 int so_train_step_fwd_bwd(const so_step_desc *desc, void *stream);
 /* Everything that changes from one iteration to the next, in ONE launch, so that a captured step needs

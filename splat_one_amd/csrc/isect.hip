@@ -81,7 +81,8 @@ k_isect_count(int C, int N, const float *__restrict__ means2d, const int32_t *__
 
 // single-workgroup exclusive scan over M = C*n_tiles counters (M is at most a few 100k)
 __global__ void __launch_bounds__(1024)
-k_scan_tiles(int64_t M, const int32_t *__restrict__ counts, int32_t *__restrict__ offsets, int32_t *__restrict__ total) {
+k_scan_tiles(int64_t M, const int32_t *__restrict__ counts, const int32_t *__restrict__ counts2,
+             int32_t *__restrict__ offsets, int32_t *__restrict__ total) {
   __shared__ int32_t wave_sums[16];
   __shared__ int32_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -92,7 +93,7 @@ k_scan_tiles(int64_t M, const int32_t *__restrict__ counts, int32_t *__restrict_
     const int64_t i0 = base + (int64_t)tid * 4;
     int32_t v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = (i0 + k < M) ? counts[i0 + k] : 0;
+    for (int k = 0; k < 4; ++k) v[k] = (i0 + k < M) ? counts[i0 + k] + (counts2 ? counts2[i0 + k] : 0) : 0;
     const int32_t mine = v[0] + v[1] + v[2] + v[3];
     // inclusive wave scan
     int32_t s = mine;
@@ -128,7 +129,8 @@ __global__ void __launch_bounds__(256)
 k_isect_scatter(int C, int N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
                 const float *__restrict__ depths, float tile_size, int tile_w, int tile_h,
                 const int32_t *__restrict__ offsets, int32_t *__restrict__ cursor, int64_t capacity,
-                uint64_t *__restrict__ key_buf, int32_t *__restrict__ overflow) {
+                uint64_t *__restrict__ key_buf, int32_t *__restrict__ overflow,
+                const int32_t *__restrict__ tile_slots, const int32_t *__restrict__ n_isects) {
   const int64_t total = (int64_t)C * N;
   const int n_tiles = tile_w * tile_h;
   const int sub = threadIdx.x & (kScatterLanes - 1);
@@ -141,10 +143,23 @@ k_isect_scatter(int C, int N, const float *__restrict__ means2d, const int32_t *
     const int nx = b.x1 - b.x0, cnt = nx * (b.y1 - b.y0);
     const uint64_t key = ((uint64_t)__float_as_uint(depths[idx]) << 32) | (uint64_t)(uint32_t)idx;
     const int64_t row = (idx / N) * n_tiles;
+    // tile_slots: the histogram pass (so_preprocess_fwd) kept the slot each of its returning atomics handed out for
+    // rectangles of <= SO_TILE_SLOTS tiles (row-major) -- those keys are placed without atomics.  It counted larger
+    // rectangles apart, in `cursor`; they fill the tail of the tile's list from the back, counting `cursor` down to 0.
+    const bool slotted = tile_slots != nullptr;
+    const bool have = slotted && cnt <= SO_TILE_SLOTS;
     for (int k = sub; k < cnt; k += kScatterLanes) {
       const int y = b.y0 + k / nx, x = b.x0 + k % nx;
       const int64_t t = row + y * tile_w + x;
-      const int64_t pos = (int64_t)offsets[t] + atomicAdd(cursor + t, 1);
+      int64_t pos;
+      if (have) {
+        pos = (int64_t)offsets[t] + tile_slots[idx * SO_TILE_SLOTS + k];
+      } else if (slotted) {
+        const int64_t end = (t == (int64_t)C * n_tiles - 1) ? (int64_t)*n_isects : (int64_t)offsets[t + 1];
+        pos = end - atomicSub(cursor + t, 1);
+      } else {
+        pos = (int64_t)offsets[t] + atomicAdd(cursor + t, 1);
+      }
       if (pos < capacity) key_buf[pos] = key;
       else if (overflow) *overflow = 1;
     }
@@ -404,23 +419,24 @@ extern "C" int so_isect_count(int C, int N, const float *means2d, const int32_t 
     hipLaunchKernelGGL(so::k_isect_count, dim3(so::grid_1d((int64_t)C * N, 256)), dim3(256), 0, st, C, N, means2d,
                        radii, (float)tile_size, tile_width, tile_height, tiles_per_gauss, tile_counts);
   }
-  hipLaunchKernelGGL(so::k_scan_tiles, dim3(1), dim3(1024), 0, st, M, tile_counts, isect_offsets, n_isects);
+  hipLaunchKernelGGL(so::k_scan_tiles, dim3(1), dim3(1024), 0, st, M, tile_counts, (const int32_t *)nullptr, isect_offsets, n_isects);
   return so::check_launch("so_isect_count");
 }
 
 extern "C" int so_isect_scan(int C, int tile_width, int tile_height, const int32_t *tile_counts,
-                             int32_t *isect_offsets, int32_t *n_isects, void *stream) {
+                             const int32_t *tile_counts_big, int32_t *isect_offsets, int32_t *n_isects, void *stream) {
   SO_REQUIRE(C >= 0 && tile_width > 0 && tile_height > 0, "so_isect_scan: bad sizes");
   SO_REQUIRE(tile_counts && isect_offsets && n_isects, "so_isect_scan: null pointer");
   hipLaunchKernelGGL(so::k_scan_tiles, dim3(1), dim3(1024), 0, so::as_stream(stream),
-                     (int64_t)C * tile_width * tile_height, tile_counts, isect_offsets, n_isects);
+                     (int64_t)C * tile_width * tile_height, tile_counts, tile_counts_big, isect_offsets, n_isects);
   return so::check_launch("so_isect_scan");
 }
 
 extern "C" int so_isect_fill(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                              int tile_size, int tile_width, int tile_height, const int32_t *isect_offsets,
                              const int32_t *n_isects, int32_t *tile_cursor, int64_t capacity, uint64_t *key_buf,
-                             int32_t *flatten_ids, int64_t *isect_ids, int32_t *overflow, void *stream) {
+                             int32_t *flatten_ids, int64_t *isect_ids, int32_t *overflow, const int32_t *tile_slots,
+                             void *stream) {
   SO_REQUIRE(C >= 0 && N >= 0 && tile_size > 0 && tile_width > 0 && tile_height > 0 && capacity >= 0,
              "so_isect_fill: bad sizes");
   if ((int64_t)C * N == 0 || capacity == 0) return SO_OK;
@@ -432,7 +448,7 @@ extern "C" int so_isect_fill(int C, int N, const float *means2d, const int32_t *
   const int tb = so::tile_bits_of(n_tiles);
   hipLaunchKernelGGL(so::k_isect_scatter, dim3(so::grid_1d((int64_t)C * N * so::kScatterLanes, 256, 16384)), dim3(256), 0, st, C, N, means2d,
                      radii, depths, (float)tile_size, tile_width, tile_height, isect_offsets, tile_cursor, capacity,
-                     key_buf, overflow);
+                     key_buf, overflow, tile_slots, n_isects);
   const int gridM = (int)(M < 65535 * 8 ? M : 65535 * 8);
   static bool lds_attr_set = false;  // 128 KiB of dynamic LDS needs an explicit opt-in
   if (!lds_attr_set) {

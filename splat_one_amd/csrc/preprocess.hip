@@ -57,7 +57,8 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
                  int32_t *__restrict__ radii, float *__restrict__ means2d, float *__restrict__ depths,
                  float *__restrict__ conics, float *__restrict__ opacities, float *__restrict__ colors,
                  int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ tile_counts,
-                 float4 *__restrict__ rec, float4 *__restrict__ vrec, int64_t cam_stride) {
+                 float4 *__restrict__ rec, float4 *__restrict__ vrec, int64_t cam_stride,
+                 int32_t *__restrict__ tile_slots) {
   const int64_t total = (int64_t)C * N;
   const int n_tiles = tile_w * tile_h;
   // the trip count is uniform over the workgroup: the histogram section below needs every lane of a wave
@@ -126,12 +127,31 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
       // Histogram of the first binning pass.  A lane walks a small rectangle itself; a large one (the dense
       // init regime: ~70 tiles per Gaussian) is spread over the whole wave in 8x8 tile blocks, so the wave's
       // trip count follows the total work, not its largest rectangle.
-      constexpr int kOwn = 12;
+      constexpr int kOwn = SO_TILE_SLOTS;
       const bool big = cnt > kOwn;
       if (cnt > 0 && !big) {
         int32_t *row = tile_counts + (int64_t)c * n_tiles;
-        for (int y = by0; y < by1; ++y)
-          for (int x = bx0; x < bx1; ++x) atomicAdd(row + y * tile_w + x, 1);
+        if (tile_slots) {
+          // the value an atomic returns IS this Gaussian's slot in that tile's list: keep it, and the scatter pass
+          // (k_isect_scatter) places the key at offsets[tile] + slot without a second round of atomics.  All
+          // requests are issued before the first result is consumed (one round trip, not cnt of them).
+          int32_t got[kOwn];
+          int x = bx0, y = by0;
+#pragma unroll
+          for (int i = 0; i < kOwn; ++i) {
+            if (i < cnt) {
+              got[i] = atomicAdd(row + y * tile_w + x, 1);
+              if (++x == bx1) { x = bx0; ++y; }
+            }
+          }
+          int32_t *mine = tile_slots + ((int64_t)c * cam_stride + (lin - (int64_t)c * N)) * kOwn;
+#pragma unroll
+          for (int i = 0; i < kOwn; ++i)
+            if (i < cnt) mine[i] = got[i];
+        } else {
+          for (int y = by0; y < by1; ++y)
+            for (int x = bx0; x < bx1; ++x) atomicAdd(row + y * tile_w + x, 1);
+        }
       }
       unsigned long long todo = __ballot(big);
       const int lane = lane_id();
@@ -140,7 +160,9 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
         todo &= todo - 1;
         const int sx0 = __builtin_amdgcn_readlane(bx0, src), sx1 = __builtin_amdgcn_readlane(bx1, src);
         const int sy0 = __builtin_amdgcn_readlane(by0, src), sy1 = __builtin_amdgcn_readlane(by1, src);
-        int32_t *row = tile_counts + (int64_t)__builtin_amdgcn_readlane(c, src) * n_tiles;
+        // with tile_slots the large rectangles are counted apart (second half of tile_counts): a tile's list is then
+        // [slotted small entries | large entries], and the scatter fills the second part from the back
+        int32_t *row = tile_counts + (int64_t)__builtin_amdgcn_readlane(c, src) * n_tiles + (tile_slots ? (int64_t)C * n_tiles : 0);
         for (int y = sy0 + (lane >> 3); y < sy1; y += 8)
           for (int x = sx0 + (lane & 7); x < sx1; x += 8) atomicAdd(row + y * tile_w + x, 1);
       }
@@ -345,8 +367,10 @@ static int preprocess_fwd_impl(const char *what, int C, int N, int K, int sh_deg
                                int width, int height, float eps2d, float near_plane, float far_plane, float radius_clip,
                                int camera_model, int antialiased, int tile_size, int32_t *radii, float *means2d,
                                float *depths, float *conics, float *opacities, float *colors, int32_t *tiles_per_gauss,
-                               int32_t *tile_counts, float *rec, float *vrec, int64_t cam_stride, void *stream) {
+                               int32_t *tile_counts, float *rec, float *vrec, int64_t cam_stride, int32_t *tile_slots,
+                               void *stream) {
   SO_REQUIRE(C >= 0 && N >= 0 && K >= 1 && width > 0 && height > 0 && tile_size > 0, "%s: bad sizes", what);
+  SO_REQUIRE(tile_slots == nullptr || tile_counts != nullptr, "%s: tile_slots need the histogram (tile_counts)", what);
   SO_REQUIRE(sh_degree >= 0 && sh_degree <= 4 && (sh_degree + 1) * (sh_degree + 1) <= K,
              "%s: sh_degree %d does not fit K=%d", what, sh_degree, K);
   if (!camera_model_ok(camera_model, C)) {
@@ -358,6 +382,7 @@ static int preprocess_fwd_impl(const char *what, int C, int N, int K, int sh_deg
                  tiles_per_gauss, "%s: null pointer", what);
   if (cam_stride == 0) cam_stride = N;
   SO_REQUIRE(cam_stride >= N, "%s: cam_stride %lld < N %d", what, (long long)cam_stride, N);
+  SO_REQUIRE(tile_slots == nullptr || cam_stride == N, "%s: tile_slots need densely packed views (cam_stride == N)", what);
   const int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
   const dim3 grid(pp_grid((int64_t)C * N)), block(256);
   hipStream_t st = as_stream(stream);
@@ -366,7 +391,7 @@ static int preprocess_fwd_impl(const char *what, int C, int N, int K, int sh_deg
                      Ks, width, height, eps2d, near_plane, far_plane, radius_clip, camera_model, antialiased,      \
                      (float)tile_size, tile_w, tile_h, radii, means2d, depths, conics, opacities, colors,          \
                      tiles_per_gauss, tile_counts, reinterpret_cast<float4 *>(rec), reinterpret_cast<float4 *>(vrec), \
-                     cam_stride)
+                     cam_stride, tile_slots)
   switch (sh_degree) {
     case 0: SO_LAUNCH(0); break;
     case 1: SO_LAUNCH(1); break;
@@ -446,13 +471,13 @@ extern "C" int so_preprocess_fwd(int C, int N, int K, int sh_degree, const float
                                  int camera_model, int antialiased, int tile_size, int32_t *radii, float *means2d,
                                  float *depths, float *conics, float *opacities, float *colors,
                                  int32_t *tiles_per_gauss, int32_t *tile_counts, float *rec, float *vrec,
-                                 int64_t cam_stride, void *stream) {
+                                 int64_t cam_stride, int32_t *tile_slots, void *stream) {
   SO_REQUIRE((int64_t)C * N == 0 || (log_scales && quats && sh0 && (shN || K == 1)), "so_preprocess_fwd: null pointer");
   const so::AttrSoA attrs{log_scales, quats, sh0, shN, K};
   return so::preprocess_fwd_impl("so_preprocess_fwd", C, N, K, sh_degree, means, logit_opacities, attrs, viewmats, Ks,
                                  width, height, eps2d, near_plane, far_plane, radius_clip, camera_model, antialiased,
                                  tile_size, radii, means2d, depths, conics, opacities, colors, tiles_per_gauss,
-                                 tile_counts, rec, vrec, cam_stride, stream);
+                                 tile_counts, rec, vrec, cam_stride, tile_slots, stream);
 }
 
 extern "C" int so_preprocess_fwd_f16(int C, int N, int K, int sh_degree, const float *means,
@@ -461,13 +486,13 @@ extern "C" int so_preprocess_fwd_f16(int C, int N, int K, int sh_degree, const f
                                      float far_plane, float radius_clip, int camera_model, int antialiased,
                                      int tile_size, int32_t *radii, float *means2d, float *depths, float *conics,
                                      float *opacities, float *colors, int32_t *tiles_per_gauss, int32_t *tile_counts,
-                                     float *rec, float *vrec, int64_t cam_stride, void *stream) {
+                                     float *rec, float *vrec, int64_t cam_stride, int32_t *tile_slots, void *stream) {
   SO_REQUIRE((int64_t)C * N == 0 || so::attr_rec_ok(arec), "so_preprocess_fwd_f16: arec must be non-null and 16-byte aligned");
   const so::AttrRec attrs{reinterpret_cast<const uint4 *>(arec), so::attr_rec_stride_bytes(K < 1 ? 1 : K) / 16};
   return so::preprocess_fwd_impl("so_preprocess_fwd_f16", C, N, K, sh_degree, means, logit_opacities, attrs, viewmats,
                                  Ks, width, height, eps2d, near_plane, far_plane, radius_clip, camera_model,
                                  antialiased, tile_size, radii, means2d, depths, conics, opacities, colors,
-                                 tiles_per_gauss, tile_counts, rec, vrec, cam_stride, stream);
+                                 tiles_per_gauss, tile_counts, rec, vrec, cam_stride, tile_slots, stream);
 }
 
 extern "C" int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float *means, const float *log_scales,

@@ -106,6 +106,8 @@ class FusedEngine:
         w["v_render_colors"] = e(C, H, W, 3)
         w["zero_v_alphas"] = torch.zeros(C, H, W, device=dev)
         w["rec"], w["vrec"] = e(C * N, 16), e(C * N, 16)     # 64-byte packed records (allocator aligns to 512 B)
+        # slots the binning histogram's returning atomics hand out (the scatter pass then needs no atomics)
+        w["tile_slots"] = e(C * N, _lib.SO_TILE_SLOTS, dtype=i32)
         # gradients: ONE flat static buffer (the data-parallel all-reduce runs on it directly, no
         # flatten copy); per-tensor views are bound to .grad so optimisers / callers see them
         pad = lambda n: (n + 63) // 64 * 64                  # 256-byte aligned segments (float4 access)
@@ -177,6 +179,7 @@ class FusedEngine:
         d.pixels_indirect, d.inputs_staged = p(w["pixels_slot"]), 1     # every launch is preceded by _stage()
         d.overflow_flag_out = p(w["ovf_f32"])
         d.attr_rows_f16 = p(w["arec"]) if self.attr_dtype == "f16" else 0
+        d.tile_slots = p(w["tile_slots"])
         return d
 
     def _adam_args(self):
