@@ -131,7 +131,8 @@ int so_isect_fill(int C, int N, const float *means2d, const int32_t *radii, cons
                   int tile_size, int tile_width, int tile_height, const int32_t *isect_offsets,
                   const int32_t *n_isects, int32_t *tile_cursor, int64_t capacity, uint64_t *key_buf,
                   int32_t *flatten_ids, int64_t *isect_ids, int32_t *overflow,
-                  const int32_t *tile_slots /* nullable, see below */, void *stream);
+                  const int32_t *tile_slots /* nullable, see below */,
+                  const float *cull_rec /* nullable, see below */, void *stream);
 /* Slotted binning (tile_slots, int32[C*N][SO_TILE_SLOTS], nullable everywhere): so_preprocess_fwd's histogram uses
  * RETURNING atomics for rectangles of <= SO_TILE_SLOTS tiles and keeps what they return -- the Gaussian's slot in each
  * tile's list -- in tile_slots (row-major over the rectangle); larger rectangles are counted apart, in the second half
@@ -140,6 +141,13 @@ int so_isect_fill(int C, int N, const float *means2d, const int32_t *radii, cons
  * offsets[tile] + slot with no atomic at all and lets the large rectangles fill the tail of each list from the back
  * (counting tile_cursor down to zero).  One round of atomics per iteration instead of two. */
 #define SO_TILE_SLOTS 12
+/* Exact tile culling (tile_cull of so_preprocess_fwd + cull_rec = its 64-byte records for so_isect_fill; both or
+ * neither): gsplat bins a Gaussian into every tile of the square of half-width ceil(3 sqrt(lambda_max)) around its
+ * centre, while the rasteriser drops every pair with alpha = opacity exp(-sigma) < 1/255.  A tile whose pixel-centre
+ * rectangle lies wholly outside the ellipse sigma <= ln(255 opacity) (+ margin) therefore changes no output and is left
+ * out of the lists: 15 % fewer intersections on isotropic trained-like scenes, 60 % on dense anisotropic low-opacity
+ * ones.  Images, losses and gradients are unchanged (tests/test_gpu_engine.py); the LISTS differ from gsplat's, so the
+ * operator-level isect_tiles never culls. */
 
 /* gsplat `isect_tiles(sort=False)`: Gaussian-major, row-major-tile emission order.
  * cum_tiles[C*N] i64 = inclusive prefix sum of tiles_per_gauss (caller-provided). */
@@ -289,7 +297,7 @@ int so_preprocess_fwd(int C, int N, int K, int sh_degree, const float *means, co
                       float near_plane, float far_plane, float radius_clip, int camera_model, int antialiased,
                       int tile_size, int32_t *radii, float *means2d, float *depths, float *conics,
                       float *opacities, float *colors, int32_t *tiles_per_gauss, int32_t *tile_counts,
-                      float *rec, float *vrec, int64_t cam_stride, int32_t *tile_slots, void *stream);
+                      float *rec, float *vrec, int64_t cam_stride, int32_t *tile_slots, int tile_cull, void *stream);
 int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float *means, const float *log_scales,
                       const float *quats, const float *logit_opacities, const float *sh0, const float *shN,
                       const float *viewmats, const float *Ks, int width, int height, float eps2d,
@@ -325,7 +333,7 @@ int so_preprocess_fwd_f16(int C, int N, int K, int sh_degree, const float *means
                           int antialiased, int tile_size, int32_t *radii, float *means2d, float *depths,
                           float *conics, float *opacities, float *colors, int32_t *tiles_per_gauss,
                           int32_t *tile_counts, float *rec, float *vrec, int64_t cam_stride, int32_t *tile_slots,
-                          void *stream);
+                          int tile_cull, void *stream);
 int so_preprocess_bwd_f16(int C, int N, int K, int sh_degree, const float *means, const float *logit_opacities,
                           const void *arec, const float *viewmats, const float *Ks, int width, int height,
                           float eps2d, int camera_model, int antialiased, const int32_t *radii,
@@ -373,7 +381,8 @@ typedef struct so_step_desc {
    *                    is read INSTEAD of `pixels`, so a resident dataset image is used in place, not copied;
    *   inputs_staged    != 0: `counters` (and the loss sums behind them) are already zero, skip that launch. */
   const float *const *pixels_indirect;
-  int32_t inputs_staged, reserved0;
+  int32_t inputs_staged;
+  int32_t tile_cull; /* != 0: exact tile culling in the binning passes (see so_isect_fill); needs rec */
   /* A binning pass that does not fit `isect_capacity` raises counters[2M+2] (overflow).  The iteration is then
    * VOID: lists are walked only up to the capacity (no out-of-bounds access), so_preprocess_bwd leaves the
    * gradients and densification statistics untouched, and so_adam_step_dev skips when given that flag.

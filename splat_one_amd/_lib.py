@@ -43,7 +43,7 @@ class StepDesc(ctypes.Structure):
                                          "camera_model", "antialiased", "absgrad", "raster_impl")]
         + [(n, c_f32) for n in ("eps2d", "near_plane", "far_plane", "radius_clip", "ssim_lambda", "opacity_reg",
                                 "scale_reg")]
-        + [("pixels_indirect", c_ptr), ("inputs_staged", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        + [("pixels_indirect", c_ptr), ("inputs_staged", ctypes.c_int32), ("tile_cull", ctypes.c_int32),
            ("overflow_flag_out", c_ptr), ("attr_rows_f16", c_ptr), ("tile_slots", c_ptr)])
 
 
@@ -59,7 +59,7 @@ _SIGS = {
     "so_sh_fwd": [c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr],
     "so_sh_bwd": [c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
     "so_isect_count": [c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_int] + [c_ptr] * 5,
-    "so_isect_fill": [c_int, c_int, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_i64] + [c_ptr] * 6,
+    "so_isect_fill": [c_int, c_int, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_i64] + [c_ptr] * 7,
     "so_isect_emit_unsorted": [c_int, c_int] + [c_ptr] * 4 + [c_int, c_int, c_int] + [c_ptr] * 3,
     "so_isect_offset_encode": [c_i64, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr],
     "so_rasterize_fwd": [c_int] * 6 + [c_ptr] * 9 + [c_i64] + [c_ptr] * 4,
@@ -69,7 +69,7 @@ _SIGS = {
     "so_camera_inverse": [c_int, c_ptr, c_ptr, c_ptr],
     "so_debug_wave_reduce": [c_int, c_ptr, c_ptr, c_ptr],
     "so_isect_scan": [c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
-    "so_preprocess_fwd": [c_int] * 4 + [c_ptr] * 8 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_int] + [c_ptr] * 10 + [c_i64, c_ptr, c_ptr],
+    "so_preprocess_fwd": [c_int] * 4 + [c_ptr] * 8 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_int] + [c_ptr] * 10 + [c_i64, c_ptr, c_int, c_ptr],
     "so_rec_unpack": [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
     "so_preprocess_bwd": [c_int] * 4 + [c_ptr] * 8 + [c_int, c_int, c_f32, c_int, c_int] + [c_ptr] * 9 + [c_f32, c_f32] + [c_ptr] * 9 + [c_int, c_i64, c_ptr, c_ptr, c_ptr],
     "so_rasterize_fwd_packed": [c_int] * 5 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 4,
@@ -87,7 +87,7 @@ _SIGS = {
                                 ctypes.c_double, ctypes.c_double, ctypes.c_double, c_ptr, c_int, c_int, c_ptr, c_ptr,
                                 ctypes.POINTER(AttrShadow), c_ptr],
     "so_attr_pack_f16": [c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
-    "so_preprocess_fwd_f16": [c_int] * 4 + [c_ptr] * 5 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_int] + [c_ptr] * 10 + [c_i64, c_ptr, c_ptr],
+    "so_preprocess_fwd_f16": [c_int] * 4 + [c_ptr] * 5 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_int] + [c_ptr] * 10 + [c_i64, c_ptr, c_int, c_ptr],
     "so_preprocess_bwd_f16": [c_int] * 4 + [c_ptr] * 5 + [c_int, c_int, c_f32, c_int, c_int] + [c_ptr] * 3 + [c_f32, c_f32] + [c_ptr] * 9 + [c_int, c_i64, c_ptr, c_ptr, c_ptr],
     "so_step_inputs": [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, ctypes.POINTER(c_f32),
                        ctypes.POINTER(c_f32), ctypes.c_double, ctypes.c_double, c_ptr, c_ptr, c_i64, c_int, c_ptr],

@@ -130,7 +130,8 @@ k_isect_scatter(int C, int N, const float *__restrict__ means2d, const int32_t *
                 const float *__restrict__ depths, float tile_size, int tile_w, int tile_h,
                 const int32_t *__restrict__ offsets, int32_t *__restrict__ cursor, int64_t capacity,
                 uint64_t *__restrict__ key_buf, int32_t *__restrict__ overflow,
-                const int32_t *__restrict__ tile_slots, const int32_t *__restrict__ n_isects) {
+                const int32_t *__restrict__ tile_slots, const int32_t *__restrict__ n_isects,
+                const float4 *__restrict__ cull_rec) {
   const int64_t total = (int64_t)C * N;
   const int n_tiles = tile_w * tile_h;
   const int sub = threadIdx.x & (kScatterLanes - 1);
@@ -148,8 +149,16 @@ k_isect_scatter(int C, int N, const float *__restrict__ means2d, const int32_t *
     // rectangles apart, in `cursor`; they fill the tail of the tile's list from the back, counting `cursor` down to 0.
     const bool slotted = tile_slots != nullptr;
     const bool have = slotted && cnt <= SO_TILE_SLOTS;
+    // exact tile culling (so_common.hpp tile_touches): the same test, on the same float32 values, as the histogram pass
+    float qa = 0.f, qb = 0.f, qc = 0.f, tau = 0.f;
+    if (cull_rec) {
+      const float4 q0 = cull_rec[4 * idx], q1 = cull_rec[4 * idx + 1];
+      qa = q0.z; qb = q0.w; qc = q1.x;
+      tau = cull_tau(q1.y);
+    }
     for (int k = sub; k < cnt; k += kScatterLanes) {
       const int y = b.y0 + k / nx, x = b.x0 + k % nx;
+      if (cull_rec && !tile_touches(m.x, m.y, qa, qb, qc, tau, x, y, tile_size)) continue;
       const int64_t t = row + y * tile_w + x;
       int64_t pos;
       if (have) {
@@ -436,7 +445,7 @@ extern "C" int so_isect_fill(int C, int N, const float *means2d, const int32_t *
                              int tile_size, int tile_width, int tile_height, const int32_t *isect_offsets,
                              const int32_t *n_isects, int32_t *tile_cursor, int64_t capacity, uint64_t *key_buf,
                              int32_t *flatten_ids, int64_t *isect_ids, int32_t *overflow, const int32_t *tile_slots,
-                             void *stream) {
+                             const float *cull_rec, void *stream) {
   SO_REQUIRE(C >= 0 && N >= 0 && tile_size > 0 && tile_width > 0 && tile_height > 0 && capacity >= 0,
              "so_isect_fill: bad sizes");
   if ((int64_t)C * N == 0 || capacity == 0) return SO_OK;
@@ -448,7 +457,7 @@ extern "C" int so_isect_fill(int C, int N, const float *means2d, const int32_t *
   const int tb = so::tile_bits_of(n_tiles);
   hipLaunchKernelGGL(so::k_isect_scatter, dim3(so::grid_1d((int64_t)C * N * so::kScatterLanes, 256, 16384)), dim3(256), 0, st, C, N, means2d,
                      radii, depths, (float)tile_size, tile_width, tile_height, isect_offsets, tile_cursor, capacity,
-                     key_buf, overflow, tile_slots, n_isects);
+                     key_buf, overflow, tile_slots, n_isects, reinterpret_cast<const float4 *>(cull_rec));
   const int gridM = (int)(M < 65535 * 8 ? M : 65535 * 8);
   static bool lds_attr_set = false;  // 128 KiB of dynamic LDS needs an explicit opt-in
   if (!lds_attr_set) {

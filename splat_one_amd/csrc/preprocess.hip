@@ -46,6 +46,10 @@ static bool camera_model_ok(int cm, int C) {
   return true;
 }
 
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 
 template <int DEG, class A>
@@ -58,13 +62,14 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
                  float *__restrict__ conics, float *__restrict__ opacities, float *__restrict__ colors,
                  int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ tile_counts,
                  float4 *__restrict__ rec, float4 *__restrict__ vrec, int64_t cam_stride,
-                 int32_t *__restrict__ tile_slots) {
+                 int32_t *__restrict__ tile_slots, int tile_cull) {
   const int64_t total = (int64_t)C * N;
   const int n_tiles = tile_w * tile_h;
   // the trip count is uniform over the workgroup: the histogram section below needs every lane of a wave
   for (int64_t lin0 = (int64_t)blockIdx.x * blockDim.x; lin0 < total; lin0 += (int64_t)gridDim.x * blockDim.x) {
     const int64_t lin = lin0 + threadIdx.x;
     int cnt = 0, bx0 = 0, bx1 = 0, by0 = 0, by1 = 0, c = 0;
+    float cmx = 0.f, cmy = 0.f, cqa = 0.f, cqb = 0.f, cqc = 0.f, ctau = 0.f;   // what the exact tile test needs
     if (lin < total) {
     c = (int)(lin / N);
     const int64_t n = lin - (int64_t)c * N;
@@ -105,6 +110,8 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
       const int y1 = (int)fminf(fmaxf(ceilf(ty + tile_r), 0.f), (float)tile_h);
       cnt = (x1 - x0) * (y1 - y0);
       bx0 = x0; bx1 = x1; by0 = y0; by1 = y1;
+      cmx = o.m2d[0]; cmy = o.m2d[1]; cqa = o.conic[0]; cqb = o.conic[1]; cqc = o.conic[2];
+      ctau = cull_tau(op);
     }
     colors[3 * idx] = r; colors[3 * idx + 1] = g; colors[3 * idx + 2] = b;
     tiles_per_gauss[idx] = cnt;
@@ -135,12 +142,12 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
           // the value an atomic returns IS this Gaussian's slot in that tile's list: keep it, and the scatter pass
           // (k_isect_scatter) places the key at offsets[tile] + slot without a second round of atomics.  All
           // requests are issued before the first result is consumed (one round trip, not cnt of them).
-          int32_t got[kOwn];
+          int32_t got[kOwn] = {};
           int x = bx0, y = by0;
 #pragma unroll
           for (int i = 0; i < kOwn; ++i) {
             if (i < cnt) {
-              got[i] = atomicAdd(row + y * tile_w + x, 1);
+              if (!tile_cull || tile_touches(cmx, cmy, cqa, cqb, cqc, ctau, x, y, tile_size)) got[i] = atomicAdd(row + y * tile_w + x, 1);
               if (++x == bx1) { x = bx0; ++y; }
             }
           }
@@ -150,7 +157,8 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
             if (i < cnt) mine[i] = got[i];
         } else {
           for (int y = by0; y < by1; ++y)
-            for (int x = bx0; x < bx1; ++x) atomicAdd(row + y * tile_w + x, 1);
+            for (int x = bx0; x < bx1; ++x)
+              if (!tile_cull || tile_touches(cmx, cmy, cqa, cqb, cqc, ctau, x, y, tile_size)) atomicAdd(row + y * tile_w + x, 1);
         }
       }
       unsigned long long todo = __ballot(big);
@@ -163,8 +171,11 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
         // with tile_slots the large rectangles are counted apart (second half of tile_counts): a tile's list is then
         // [slotted small entries | large entries], and the scatter fills the second part from the back
         int32_t *row = tile_counts + (int64_t)__builtin_amdgcn_readlane(c, src) * n_tiles + (tile_slots ? (int64_t)C * n_tiles : 0);
+        const float smx = readlane_f(cmx, src), smy = readlane_f(cmy, src), sqa = readlane_f(cqa, src),
+                    sqb = readlane_f(cqb, src), sqc = readlane_f(cqc, src), stau = readlane_f(ctau, src);
         for (int y = sy0 + (lane >> 3); y < sy1; y += 8)
-          for (int x = sx0 + (lane & 7); x < sx1; x += 8) atomicAdd(row + y * tile_w + x, 1);
+          for (int x = sx0 + (lane & 7); x < sx1; x += 8)
+            if (!tile_cull || tile_touches(smx, smy, sqa, sqb, sqc, stau, x, y, tile_size)) atomicAdd(row + y * tile_w + x, 1);
       }
     }
   }
@@ -368,7 +379,7 @@ static int preprocess_fwd_impl(const char *what, int C, int N, int K, int sh_deg
                                int camera_model, int antialiased, int tile_size, int32_t *radii, float *means2d,
                                float *depths, float *conics, float *opacities, float *colors, int32_t *tiles_per_gauss,
                                int32_t *tile_counts, float *rec, float *vrec, int64_t cam_stride, int32_t *tile_slots,
-                               void *stream) {
+                               int tile_cull, void *stream) {
   SO_REQUIRE(C >= 0 && N >= 0 && K >= 1 && width > 0 && height > 0 && tile_size > 0, "%s: bad sizes", what);
   SO_REQUIRE(tile_slots == nullptr || tile_counts != nullptr, "%s: tile_slots need the histogram (tile_counts)", what);
   SO_REQUIRE(sh_degree >= 0 && sh_degree <= 4 && (sh_degree + 1) * (sh_degree + 1) <= K,
@@ -391,7 +402,7 @@ static int preprocess_fwd_impl(const char *what, int C, int N, int K, int sh_deg
                      Ks, width, height, eps2d, near_plane, far_plane, radius_clip, camera_model, antialiased,      \
                      (float)tile_size, tile_w, tile_h, radii, means2d, depths, conics, opacities, colors,          \
                      tiles_per_gauss, tile_counts, reinterpret_cast<float4 *>(rec), reinterpret_cast<float4 *>(vrec), \
-                     cam_stride, tile_slots)
+                     cam_stride, tile_slots, tile_cull)
   switch (sh_degree) {
     case 0: SO_LAUNCH(0); break;
     case 1: SO_LAUNCH(1); break;
@@ -471,13 +482,13 @@ extern "C" int so_preprocess_fwd(int C, int N, int K, int sh_degree, const float
                                  int camera_model, int antialiased, int tile_size, int32_t *radii, float *means2d,
                                  float *depths, float *conics, float *opacities, float *colors,
                                  int32_t *tiles_per_gauss, int32_t *tile_counts, float *rec, float *vrec,
-                                 int64_t cam_stride, int32_t *tile_slots, void *stream) {
+                                 int64_t cam_stride, int32_t *tile_slots, int tile_cull, void *stream) {
   SO_REQUIRE((int64_t)C * N == 0 || (log_scales && quats && sh0 && (shN || K == 1)), "so_preprocess_fwd: null pointer");
   const so::AttrSoA attrs{log_scales, quats, sh0, shN, K};
   return so::preprocess_fwd_impl("so_preprocess_fwd", C, N, K, sh_degree, means, logit_opacities, attrs, viewmats, Ks,
                                  width, height, eps2d, near_plane, far_plane, radius_clip, camera_model, antialiased,
                                  tile_size, radii, means2d, depths, conics, opacities, colors, tiles_per_gauss,
-                                 tile_counts, rec, vrec, cam_stride, tile_slots, stream);
+                                 tile_counts, rec, vrec, cam_stride, tile_slots, tile_cull, stream);
 }
 
 extern "C" int so_preprocess_fwd_f16(int C, int N, int K, int sh_degree, const float *means,
@@ -486,13 +497,13 @@ extern "C" int so_preprocess_fwd_f16(int C, int N, int K, int sh_degree, const f
                                      float far_plane, float radius_clip, int camera_model, int antialiased,
                                      int tile_size, int32_t *radii, float *means2d, float *depths, float *conics,
                                      float *opacities, float *colors, int32_t *tiles_per_gauss, int32_t *tile_counts,
-                                     float *rec, float *vrec, int64_t cam_stride, int32_t *tile_slots, void *stream) {
+                                     float *rec, float *vrec, int64_t cam_stride, int32_t *tile_slots, int tile_cull, void *stream) {
   SO_REQUIRE((int64_t)C * N == 0 || so::attr_rec_ok(arec), "so_preprocess_fwd_f16: arec must be non-null and 16-byte aligned");
   const so::AttrRec attrs{reinterpret_cast<const uint4 *>(arec), so::attr_rec_stride_bytes(K < 1 ? 1 : K) / 16};
   return so::preprocess_fwd_impl("so_preprocess_fwd_f16", C, N, K, sh_degree, means, logit_opacities, attrs, viewmats,
                                  Ks, width, height, eps2d, near_plane, far_plane, radius_clip, camera_model,
                                  antialiased, tile_size, radii, means2d, depths, conics, opacities, colors,
-                                 tiles_per_gauss, tile_counts, rec, vrec, cam_stride, tile_slots, stream);
+                                 tiles_per_gauss, tile_counts, rec, vrec, cam_stride, tile_slots, tile_cull, stream);
 }
 
 extern "C" int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float *means, const float *log_scales,

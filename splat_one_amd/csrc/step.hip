@@ -176,15 +176,15 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
     SO_STAGE(0, so_preprocess_fwd_f16(C, N, K, d->sh_degree, d->means, d->logit_opacities, d->attr_rows_f16, d->viewmats, d->Ks,
                                       W, H, d->eps2d, d->near_plane, d->far_plane, d->radius_clip, d->camera_model,
                                       d->antialiased, ts, d->radii, d->means2d, d->depths, d->conics, d->opacities, d->colors,
-                                      d->tiles_per_gauss, tile_counts, d->rec, forward_only ? nullptr : d->vrec, 0, d->tile_slots, stream));
+                                      d->tiles_per_gauss, tile_counts, d->rec, forward_only ? nullptr : d->vrec, 0, d->tile_slots, d->tile_cull, stream));
   else
   SO_STAGE(0, so_preprocess_fwd(C, N, K, d->sh_degree, d->means, d->log_scales, d->quats, d->logit_opacities, d->sh0, d->shN,
                            d->viewmats, d->Ks, W, H, d->eps2d, d->near_plane, d->far_plane, d->radius_clip,
                            d->camera_model, d->antialiased, ts, d->radii, d->means2d, d->depths, d->conics,
-                           d->opacities, d->colors, d->tiles_per_gauss, tile_counts, d->rec, forward_only ? nullptr : d->vrec, 0, d->tile_slots, stream));
+                           d->opacities, d->colors, d->tiles_per_gauss, tile_counts, d->rec, forward_only ? nullptr : d->vrec, 0, d->tile_slots, d->tile_cull, stream));
   SO_STAGE(1, so_isect_scan(C, tile_w, tile_h, tile_counts, d->tile_slots ? cursor : nullptr, d->isect_offsets, n_isects, stream));
   SO_STAGE(2, so_isect_fill(C, N, d->means2d, d->radii, d->depths, ts, tile_w, tile_h, d->isect_offsets, n_isects, cursor,
-                       d->isect_capacity, d->key_buf, d->flatten_ids, nullptr, overflow, d->tile_slots, stream));
+                       d->isect_capacity, d->key_buf, d->flatten_ids, nullptr, overflow, d->tile_slots, d->tile_cull ? d->rec : nullptr, stream));
   const bool wave_impl = d->raster_impl == 1 && ts == 16;
   if (wave_impl)
     SO_STAGE(3, so_rasterize_fwd_wave(C, N, W, H, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects, d->isect_capacity,

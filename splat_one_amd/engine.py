@@ -37,12 +37,15 @@ class FusedEngine:
                  opacity_reg: float = 0.0, scale_reg: float = 0.0, tile_size: int = 16,
                  strategy_state: Optional[dict] = None, lr_gamma_means: float = 1.0,
                  isect_capacity: Optional[int] = None, use_graph: bool = True, raster_impl: int = 0,
-                 attr_dtype: str = "f32"):
+                 attr_dtype: str = "f32", tile_cull: bool = True):
         """attr_dtype="f16": quaternions, log-scales and SH coefficients are READ from float16 attribute rows
         (include/splat_one_amd.h, so_attr_pack_f16: 112 instead of 224 bytes per Gaussian at SH degree 3); the
         float32 parameters stay the masters Adam updates, and the same Adam launch refreshes the halves."""
         assert attr_dtype in ("f32", "f16"), attr_dtype
         self.attr_dtype = attr_dtype
+        # exact tile culling (include/splat_one_amd.h): tiles no pixel of which can reach alpha = 1/255 are left out
+        # of the lists -- outputs unchanged, lists shorter than gsplat's
+        self.tile_cull = bool(tile_cull)
         self.splats, self.optimizers = splats, optimizers
         self.W, self.H, self.C = int(width), int(height), int(n_views)
         self.cfg = dict(sh_degree=sh_degree, camera_model=camera_model, near_plane=near_plane, far_plane=far_plane,
@@ -180,6 +183,7 @@ class FusedEngine:
         d.overflow_flag_out = p(w["ovf_f32"])
         d.attr_rows_f16 = p(w["arec"]) if self.attr_dtype == "f16" else 0
         d.tile_slots = p(w["tile_slots"])
+        d.tile_cull = int(self.tile_cull)
         return d
 
     def _adam_args(self):

@@ -238,7 +238,7 @@ def isect_tiles(
             keys = torch.empty(total, dtype=torch.int64, device=dev)
             call("so_isect_fill", C, N, ptr(means2d), ptr(radii), ptr(depths), tile_size, tile_width,
                  tile_height, ptr(offsets), ptr(n_isects), ptr(cursor), total, ptr(keys), ptr(flatten_ids),
-                 ptr(isect_ids), ptr(overflow), 0, stream())
+                 ptr(isect_ids), ptr(overflow), 0, 0, stream())
         else:
             cum = torch.cumsum(tiles_per_gauss.reshape(-1).to(torch.int64), 0).contiguous()
             call("so_isect_emit_unsorted", C, N, ptr(means2d), ptr(radii), ptr(depths), ptr(cum), tile_size,
@@ -279,7 +279,7 @@ def isect_tiles_static(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size
          ptr(tiles_per_gauss), ptr(tile_counts), ptr(offsets), ptr(n_isects), stream())
     call("so_isect_fill", C, N, ptr(means2d), ptr(radii), ptr(depths), tile_size, tile_width, tile_height,
          ptr(offsets), ptr(n_isects), ptr(cursor), capacity, ptr(keys), ptr(flatten_ids), ptr(isect_ids),
-         ptr(overflow), 0, stream())
+         ptr(overflow), 0, 0, stream())
     return dict(tiles_per_gauss=tiles_per_gauss, isect_offsets=offsets, flatten_ids=flatten_ids,
                 isect_ids=isect_ids, n_isects=n_isects, overflow=overflow)
 

@@ -212,13 +212,13 @@ class ShardedEngine:
             _lib.call("so_preprocess_fwd_f16", n, N, self.K, c["sh_degree"], p(s["means"].data), p(s["opacities"].data),
                       p(w["arec"]), p(w["viewmats"]), p(w["Ks"]), W, H, c["eps2d"], c["near_plane"], c["far_plane"],
                       c["radius_clip"], cam, int(c["antialiased"]), ts, p(w["radii"]), p(w["means2d"]), p(w["depths"]),
-                      p(w["conics"]), p(w["opacities"]), p(w["colors"]), p(w["tiles_per_gauss"]), 0, p(w["rec_shard"]), 0, cap, 0, st)
+                      p(w["conics"]), p(w["opacities"]), p(w["colors"]), p(w["tiles_per_gauss"]), 0, p(w["rec_shard"]), 0, cap, 0, 0, st)
         elif N > 0:
             _lib.call("so_preprocess_fwd", n, N, self.K, c["sh_degree"], p(s["means"].data), p(s["scales"].data),
                       p(s["quats"].data), p(s["opacities"].data), p(s["sh0"].data), p(s["shN"].data), p(w["viewmats"]),
                       p(w["Ks"]), W, H, c["eps2d"], c["near_plane"], c["far_plane"], c["radius_clip"], cam,
                       int(c["antialiased"]), ts, p(w["radii"]), p(w["means2d"]), p(w["depths"]), p(w["conics"]),
-                      p(w["opacities"]), p(w["colors"]), p(w["tiles_per_gauss"]), 0, p(w["rec_shard"]), 0, cap, 0, st)
+                      p(w["opacities"]), p(w["colors"]), p(w["tiles_per_gauss"]), 0, p(w["rec_shard"]), 0, cap, 0, 0, st)
         all_to_all_rows(w["rec_full"], w["rec_shard"], self.group)
         counters = w["counters"]
         tile_counts, cursor = counters, counters[M:]
@@ -239,7 +239,7 @@ class ShardedEngine:
                 return self.fwd_bwd(camtoworlds, Ks, pixels, schedule)
         _lib.call("so_isect_fill", 1, Nf, p(w["means2d_full"]), p(w["radii_full"]), p(w["depths_full"]), ts, tw, th,
                   p(w["isect_offsets"]), p(n_isects), p(cursor), self.capacity, p(w["key_buf"]), p(w["flatten_ids"]), 0,
-                  p(overflow), 0, st)
+                  p(overflow), 0, 0, st)
         _lib.call("so_rasterize_fwd_packed", 1, Nf, W, H, ts, p(w["rec_full"]), 0, p(w["isect_offsets"]), p(w["flatten_ids"]),
                   p(n_isects), self.capacity, p(w["render_colors"]), p(w["render_alphas"]), p(w["last_ids"]), st)
         lam = float(c["ssim_lambda"])

@@ -97,6 +97,9 @@ class Config:
     # instead of 224 B per Gaussian; float32 masters + Adam state unchanged, checkpoints hold the masters) --
     # BASELINE.json configs[4].
     attr_dtype: str = "f32"
+    # fused path: tiles no pixel of which can reach alpha >= 1/255 are left out of the per-tile lists (exact: images,
+    # losses and gradients are unchanged; only the internal lists are shorter than gsplat's)
+    tile_cull: bool = True
     shN_init_std: float = 0.0              # >0: noise instead of zeros in the higher SH bands (bench scenes)
 
     def adjust_steps(self, factor: float):
@@ -494,7 +497,7 @@ class Runner:
                 strategy_state=(self.strategy_state if isinstance(s, DefaultStrategy) else None),
                 lr_gamma_means=self.lr_gamma,
                 isect_capacity=cfg.isect_capacity, use_graph=True,
-                raster_impl=getattr(self, "raster_impl", 0), attr_dtype=cfg.attr_dtype)
+                raster_impl=getattr(self, "raster_impl", 0), attr_dtype=cfg.attr_dtype, tile_cull=cfg.tile_cull)
             eng.steps_done = step
             eng._step_dev[0] = step
             if self.world_size > 1:

@@ -84,8 +84,9 @@ def test_engine_gradients_match_oracle_and_operator_path(dev, regime, C, kw, ras
     if kw.get("scale_reg", 0) > 0:
         loss_p = loss_p + kw["scale_reg"] * torch.exp(r.splats["scales"]).abs().mean()
     loss_p.backward()
-    assert torch.equal(info["flatten_ids"], eng.ws["flatten_ids"][:stats["n_isects"]])
-    # identical lists and arithmetic; a 1-ulp opacity difference (fused sigmoid*comp) may flip one
+    # the engine's lists are gsplat's minus the tiles its exact culling proves empty (test_engine_tile_cull_is_exact)
+    assert stats["n_isects"] <= info["flatten_ids"].numel()
+    # identical arithmetic; a 1-ulp opacity difference (fused sigmoid*comp) may flip one
     # alpha>=1/255 decision at a pixel, hence mean/max rather than bitwise
     assert (renders - eng.ws["render_colors"]).abs().mean().item() < 1e-6
     assert (renders - eng.ws["render_colors"]).abs().max().item() < 5e-3
@@ -191,3 +192,49 @@ def test_engine_survives_intersection_overflow(dev):
         e_auto.step()
     torch.cuda.synchronize()
     assert e_auto.void_steps == 0 and e_auto.capacity > 1024
+
+
+@pytest.mark.parametrize("regime,C,aa", [("ref", 1, False), ("mcmc", 2, True)])
+def test_engine_tile_cull_is_exact(dev, regime, C, aa):
+    """Exact tile culling drops (Gaussian, tile) pairs that cannot reach alpha = 1/255 at any pixel of the tile:
+    fewer intersections, the SAME image bit for bit, the same gradients up to the order of the atomic sums; the
+    surviving lists are subsequences of gsplat's lists (which the engine reproduces exactly with culling off)."""
+    from splat_one_amd.engine import FusedEngine
+    from splat_one_amd.rendering import rasterization
+    N, W, H = 8000, 200, 136
+    res = {}
+    for cull in (False, True):
+        r, c2w, Ks, pixels = _make(dev, N, W, H, regime, C, antialiased=aa)
+        with torch.no_grad():                    # some Gaussians that can never reach 1/255, some barely
+            r.splats["opacities"][:500] = -6.0
+            r.splats["opacities"][500:1000] = -5.0
+        eng = FusedEngine(r.splats, r.optimizers, W, H, C, sh_degree=3, use_graph=False, tile_cull=cull, antialiased=aa)
+        eng.set_views(c2w, Ks, pixels)
+        eng.fwd_bwd()
+        st = eng.stats()
+        assert st["overflow"] == 0
+        M = eng.M
+        offs = eng.ws["isect_offsets"].reshape(-1).cpu().tolist() + [st["n_isects"]]
+        ids = eng.ws["flatten_ids"][:st["n_isects"]].cpu()
+        res[cull] = dict(img=eng.ws["render_colors"].clone(), alpha=eng.ws["render_alphas"].clone(), n=st["n_isects"],
+                         grads={k: v.grad.detach().clone() for k, v in r.splats.items()}, offs=offs, ids=ids,
+                         loss=eng.loss().clone(), radii=eng.ws["radii"].clone())
+        if not cull:       # culling off == the operator-level lists (gsplat semantics), bit for bit
+            sp = r.splats
+            _, _, info = rasterization(sp["means"], sp["quats"], torch.exp(sp["scales"]), torch.sigmoid(sp["opacities"]),
+                                       torch.cat([sp["sh0"], sp["shN"]], 1), torch.linalg.inv(c2w), Ks, W, H, sh_degree=3,
+                                       near_plane=0.01, far_plane=1e8, rasterize_mode="antialiased" if aa else "classic")
+            assert torch.equal(info["flatten_ids"].cpu(), ids)
+    a, b = res[False], res[True]
+    assert b["n"] < 0.9 * a["n"], (a["n"], b["n"])
+    assert torch.equal(a["img"], b["img"]) and torch.equal(a["alpha"], b["alpha"])
+    assert (a["loss"] - b["loss"]).abs().max().item() < 1e-6         # same image; the loss sums are atomic (order varies)
+    assert torch.equal(a["radii"], b["radii"])                       # visibility (densification) is not touched
+    for k in a["grads"]:
+        d = (a["grads"][k] - b["grads"][k]).norm().item()
+        assert d <= 1e-5 * a["grads"][k].norm().item() + 1e-12, (k, d)
+    for t in range(len(a["offs"]) - 1):                              # per tile: an order-preserving subsequence
+        full = a["ids"][a["offs"][t]:a["offs"][t + 1]].tolist()
+        kept = b["ids"][b["offs"][t]:b["offs"][t + 1]].tolist()
+        it = iter(full)
+        assert all(any(g == f for f in it) for g in kept), t

@@ -406,7 +406,7 @@ def test_rec_unpack_and_cam_stride(dev):
         _lib.call("so_preprocess_fwd", C, N, K, 3, p(s["means"]), p(s["scales"]), p(s["quats"]), p(s["opacities"]), p(s["sh0"]),
                   p(s["shN"]), p(vm), p(Kd), W, H, 0.3, 0.01, 1e8, 0.0, 0, 0, 16, p(o["radii"]), p(o["means2d"]), p(o["depths"]),
                   p(o["conics"]), p(o["opac"]), p(o["colors"]), p(o["tpg"]), p(o["hist"]) if hist else 0, p(o["rec"]), 0,
-                  stride, 0, _lib.stream())
+                  stride, 0, 0, _lib.stream())
         return o
     dense, strided = run(N, True), run(cap, False)
     assert dense["hist"].sum().item() == dense["tpg"].sum().item() > 0 and strided["hist"].sum().item() == 0
