@@ -122,7 +122,8 @@ int so_sh_bwd(int C, int N, int K, int degrees_to_use, const float *dirs, const 
  * ---------------------------------------------------------------------------------------- */
 int so_isect_count(int C, int N, const float *means2d, const int32_t *radii, int tile_size, int tile_width,
                    int tile_height, int32_t *tiles_per_gauss, int32_t *tile_counts, int32_t *isect_offsets,
-                   int32_t *n_isects, void *stream);
+                   int32_t *n_isects, const float *cull_rec /* nullable: exact tile culling, see so_isect_fill */,
+                   void *stream);
 /* the exclusive scan of step 1 alone (when the histogram was filled by so_preprocess_fwd) */
 int so_isect_scan(int C, int tile_width, int tile_height, const int32_t *tile_counts,
                   const int32_t *tile_counts_big /* nullable: added element-wise (so_preprocess_fwd tile_slots) */, int32_t *isect_offsets,

@@ -58,7 +58,7 @@ _SIGS = {
     "so_projection_bwd": [c_int, c_int] + [c_ptr] * 6 + [c_int, c_int, c_f32, c_int] + [c_ptr] * 11,
     "so_sh_fwd": [c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr],
     "so_sh_bwd": [c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
-    "so_isect_count": [c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_int] + [c_ptr] * 5,
+    "so_isect_count": [c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_int] + [c_ptr] * 6,
     "so_isect_fill": [c_int, c_int, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_i64] + [c_ptr] * 7,
     "so_isect_emit_unsorted": [c_int, c_int] + [c_ptr] * 4 + [c_int, c_int, c_int] + [c_ptr] * 3,
     "so_isect_offset_encode": [c_i64, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr],

@@ -39,7 +39,8 @@ __device__ __forceinline__ TileBox tile_box(float mx, float my, float radius, fl
 
 __global__ void __launch_bounds__(256)
 k_isect_count(int C, int N, const float *__restrict__ means2d, const int32_t *__restrict__ radii, float tile_size,
-              int tile_w, int tile_h, int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ tile_counts) {
+              int tile_w, int tile_h, int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ tile_counts,
+              const float4 *__restrict__ cull_rec) {
   const int64_t total = (int64_t)C * N;
   const int n_tiles = tile_w * tile_h;
   // uniform trip count: the cooperative part needs every lane of a wave (same scheme as k_preprocess_fwd)
@@ -47,6 +48,7 @@ k_isect_count(int C, int N, const float *__restrict__ means2d, const int32_t *__
     const int64_t idx = idx0 + threadIdx.x;
     int cnt = 0, c = 0;
     TileBox b{0, 0, 0, 0};
+    float mx = 0.f, my = 0.f, qa = 0.f, qb = 0.f, qc = 0.f, tau = 0.f;   // exact tile culling (cull_rec: see so_isect_fill)
     if (idx < total) {
       const int r = radii[idx];
       if (r > 0) {
@@ -54,6 +56,12 @@ k_isect_count(int C, int N, const float *__restrict__ means2d, const int32_t *__
         b = tile_box(m.x, m.y, (float)r, tile_size, tile_w, tile_h);
         cnt = (b.x1 - b.x0) * (b.y1 - b.y0);
         c = (int)(idx / N);
+        mx = m.x; my = m.y;
+        if (cull_rec) {
+          const float4 q0 = cull_rec[4 * idx], q1 = cull_rec[4 * idx + 1];
+          qa = q0.z; qb = q0.w; qc = q1.x;
+          tau = cull_tau(q1.y);
+        }
       }
       tiles_per_gauss[idx] = cnt;
     }
@@ -63,18 +71,22 @@ k_isect_count(int C, int N, const float *__restrict__ means2d, const int32_t *__
     if (cnt > 0 && !big) {
       int32_t *row = tile_counts + (int64_t)c * n_tiles;
       for (int y = b.y0; y < b.y1; ++y)
-        for (int x = b.x0; x < b.x1; ++x) atomicAdd(row + y * tile_w + x, 1);
+        for (int x = b.x0; x < b.x1; ++x)
+          if (!cull_rec || tile_touches(mx, my, qa, qb, qc, tau, x, y, tile_size)) atomicAdd(row + y * tile_w + x, 1);
     }
     unsigned long long todo = __ballot(big);
     const int lane = lane_id();
+    auto rl = [](float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
     while (todo) {
       const int src = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
       const int sx0 = __builtin_amdgcn_readlane(b.x0, src), sx1 = __builtin_amdgcn_readlane(b.x1, src);
       const int sy0 = __builtin_amdgcn_readlane(b.y0, src), sy1 = __builtin_amdgcn_readlane(b.y1, src);
+      const float smx = rl(mx, src), smy = rl(my, src), sqa = rl(qa, src), sqb = rl(qb, src), sqc = rl(qc, src), stau = rl(tau, src);
       int32_t *row = tile_counts + (int64_t)__builtin_amdgcn_readlane(c, src) * n_tiles;
       for (int y = sy0 + (lane >> 3); y < sy1; y += 8)
-        for (int x = sx0 + (lane & 7); x < sx1; x += 8) atomicAdd(row + y * tile_w + x, 1);
+        for (int x = sx0 + (lane & 7); x < sx1; x += 8)
+          if (!cull_rec || tile_touches(smx, smy, sqa, sqb, sqc, stau, x, y, tile_size)) atomicAdd(row + y * tile_w + x, 1);
     }
   }
 }
@@ -417,7 +429,7 @@ static inline int grid_1d(int64_t total, int block, int cap = 4096) {
 
 extern "C" int so_isect_count(int C, int N, const float *means2d, const int32_t *radii, int tile_size,
                               int tile_width, int tile_height, int32_t *tiles_per_gauss, int32_t *tile_counts,
-                              int32_t *isect_offsets, int32_t *n_isects, void *stream) {
+                              int32_t *isect_offsets, int32_t *n_isects, const float *cull_rec, void *stream) {
   SO_REQUIRE(C >= 0 && N >= 0 && tile_size > 0 && tile_width > 0 && tile_height > 0, "so_isect_count: bad sizes");
   SO_REQUIRE(tile_counts && isect_offsets && n_isects, "so_isect_count: null pointer");
   SO_REQUIRE((int64_t)C * N < ((int64_t)1 << 31), "so_isect_count: C*N must fit int32 flatten ids");
@@ -426,7 +438,8 @@ extern "C" int so_isect_count(int C, int N, const float *means2d, const int32_t 
   if ((int64_t)C * N > 0) {
     SO_REQUIRE(means2d && radii && tiles_per_gauss, "so_isect_count: null pointer");
     hipLaunchKernelGGL(so::k_isect_count, dim3(so::grid_1d((int64_t)C * N, 256)), dim3(256), 0, st, C, N, means2d,
-                       radii, (float)tile_size, tile_width, tile_height, tiles_per_gauss, tile_counts);
+                       radii, (float)tile_size, tile_width, tile_height, tiles_per_gauss, tile_counts,
+                       reinterpret_cast<const float4 *>(cull_rec));
   }
   hipLaunchKernelGGL(so::k_scan_tiles, dim3(1), dim3(1024), 0, st, M, tile_counts, (const int32_t *)nullptr, isect_offsets, n_isects);
   return so::check_launch("so_isect_count");

@@ -229,7 +229,7 @@ def isect_tiles(
     n_isects, overflow = counters[2 * M + 1:2 * M + 2], counters[2 * M + 2:]
     offsets = torch.empty(C, tile_height, tile_width, dtype=torch.int32, device=dev)
     call("so_isect_count", C, N, ptr(means2d), ptr(radii), tile_size, tile_width, tile_height,
-         ptr(tiles_per_gauss), ptr(tile_counts), ptr(offsets), ptr(n_isects), stream())
+         ptr(tiles_per_gauss), ptr(tile_counts), ptr(offsets), ptr(n_isects), 0, stream())
     total = int(n_isects.item())
     isect_ids = torch.empty(total, dtype=torch.int64, device=dev)
     flatten_ids = torch.empty(total, dtype=torch.int32, device=dev)
@@ -276,7 +276,7 @@ def isect_tiles_static(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size
     n_isects, overflow = counters[2 * M + 1:2 * M + 2], counters[2 * M + 2:]
     means2d, depths = _f32(means2d), _f32(depths)
     call("so_isect_count", C, N, ptr(means2d), ptr(radii), tile_size, tile_width, tile_height,
-         ptr(tiles_per_gauss), ptr(tile_counts), ptr(offsets), ptr(n_isects), stream())
+         ptr(tiles_per_gauss), ptr(tile_counts), ptr(offsets), ptr(n_isects), 0, stream())
     call("so_isect_fill", C, N, ptr(means2d), ptr(radii), ptr(depths), tile_size, tile_width, tile_height,
          ptr(offsets), ptr(n_isects), ptr(cursor), capacity, ptr(keys), ptr(flatten_ids), ptr(isect_ids),
          ptr(overflow), 0, 0, stream())

@@ -58,7 +58,7 @@ class ShardedEngine:
                  antialiased: bool = False, absgrad: bool = False, ssim_lambda: float = 0.2, opacity_reg: float = 0.0,
                  scale_reg: float = 0.0, tile_size: int = 16, strategy_state: Optional[dict] = None,
                  lr_gamma_means: float = 1.0, isect_capacity: Optional[int] = None, group=None,
-                 attr_dtype: str = "f32"):
+                 attr_dtype: str = "f32", tile_cull: bool = True):
         assert dist.is_initialized() and dist.get_world_size(group) == world, "ShardedEngine needs the process group"
         self.splats, self.optimizers = splats, optimizers
         self.W, self.H, self.rank, self.world, self.group = int(width), int(height), int(rank), int(world), group
@@ -66,6 +66,7 @@ class ShardedEngine:
                         radius_clip=radius_clip, eps2d=eps2d, antialiased=antialiased, absgrad=absgrad,
                         ssim_lambda=ssim_lambda, opacity_reg=opacity_reg, scale_reg=scale_reg, tile_size=tile_size)
         assert attr_dtype in ("f32", "f16"), attr_dtype
+        self.tile_cull = bool(tile_cull)              # exact tile culling of the binning passes (see FusedEngine)
         self.attr_dtype = attr_dtype                  # "f16": float16 attribute rows of the own shard (see FusedEngine)
         self.strategy_state = strategy_state
         self.lr_gamma_means = lr_gamma_means
@@ -226,7 +227,7 @@ class ShardedEngine:
         _lib.call("so_rec_unpack", Nf, p(w["rec_full"]), p(w["means2d_full"]), p(w["radii_full"]), p(w["depths_full"]),
                   p(w["vrec_full"]), st)
         _lib.call("so_isect_count", 1, Nf, p(w["means2d_full"]), p(w["radii_full"]), ts, tw, th, p(w["tiles_full"]),
-                  p(tile_counts), p(w["isect_offsets"]), p(n_isects), st)
+                  p(tile_counts), p(w["isect_offsets"]), p(n_isects), p(w["rec_full"]) if self.tile_cull else 0, st)
         if self._probe_capacity:     # once per workspace: the largest intersection count over the ranks decides the buffers
             self._probe_capacity = False
             cnt = n_isects[:1].to(torch.int64)
@@ -239,7 +240,7 @@ class ShardedEngine:
                 return self.fwd_bwd(camtoworlds, Ks, pixels, schedule)
         _lib.call("so_isect_fill", 1, Nf, p(w["means2d_full"]), p(w["radii_full"]), p(w["depths_full"]), ts, tw, th,
                   p(w["isect_offsets"]), p(n_isects), p(cursor), self.capacity, p(w["key_buf"]), p(w["flatten_ids"]), 0,
-                  p(overflow), 0, 0, st)
+                  p(overflow), 0, p(w["rec_full"]) if self.tile_cull else 0, st)
         _lib.call("so_rasterize_fwd_packed", 1, Nf, W, H, ts, p(w["rec_full"]), 0, p(w["isect_offsets"]), p(w["flatten_ids"]),
                   p(n_isects), self.capacity, p(w["render_colors"]), p(w["render_alphas"]), p(w["last_ids"]), st)
         lam = float(c["ssim_lambda"])

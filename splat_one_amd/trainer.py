@@ -569,7 +569,7 @@ class Runner:
                 antialiased=cfg.antialiased, absgrad=getattr(s, "absgrad", False), ssim_lambda=cfg.ssim_lambda,
                 opacity_reg=cfg.opacity_reg, scale_reg=cfg.scale_reg,
                 strategy_state=(self.strategy_state if isinstance(s, DefaultStrategy) else None),
-                lr_gamma_means=self.lr_gamma, isect_capacity=cfg.isect_capacity, attr_dtype=cfg.attr_dtype)
+                lr_gamma_means=self.lr_gamma, isect_capacity=cfg.isect_capacity, attr_dtype=cfg.attr_dtype, tile_cull=cfg.tile_cull)
             eng.steps_done = step
             eng._step_dev[0] = step
         eng.set_sh_degree(min(step // cfg.sh_degree_interval, cfg.sh_degree))
