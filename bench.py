@@ -315,6 +315,7 @@ def main():
                                + (f", DefaultStrategy refining every {args.densify} iterations ({N0} -> {N} Gaussians)" if args.densify else "")
                                + (", float16 attribute rows" if args.attr_dtype == "f16" else ""),
                    "views_per_step": world, "visible_gaussians": V, "tile_intersections": I,
+                   "tile_cull": bool(cfg.tile_cull and fused),   # I counts what is left after exact tile culling
                    "parallelism": (f"gaussian-sharded dp{world}: one view per GPU, N/{world} Gaussians per GPU, "
                                    "projected Gaussians exchanged by all-to-all" if runner.sharded else
                                    f"view-sharded dp{world}" + (", gradient all-reduce" if world > 1 else "")),
