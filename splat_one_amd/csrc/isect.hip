@@ -264,42 +264,61 @@ __device__ __forceinline__ void write_sorted(uint64_t key, int64_t pos, int64_t 
   }
 }
 
-// Register sort of up to 128 keys by ONE wave: lane l holds elements l and l+64 (UINT64_MAX pads the
+// Register sort of up to 256 keys by ONE wave: lane l holds elements l, l+64, ... (UINT64_MAX pads the
 // tail), the classic xor-partner bitonic network runs on ds_bpermute shuffles -- no LDS array, no
-// barrier.  Short lists dominate trained-like scenes (mean ~50 keys per tile on the c2 workload).
+// barrier.  Short lists dominate trained-like scenes (mean ~40 keys per tile on the c2 workload, ~150 at
+// 1M Gaussians / 1440p).
 __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
   const uint32_t lo = __shfl_xor((uint32_t)v, m, 64), hi = __shfl_xor((uint32_t)(v >> 32), m, 64);
   return ((uint64_t)hi << 32) | lo;
 }
 
-template <bool TWO>
-__device__ __forceinline__ void wave_bitonic_sort(uint64_t &a, uint64_t &b, int lane) {
-  constexpr int NE = TWO ? 128 : 64;
+// E elements per lane (element index = lane + 64 e): up to 64 E keys sorted by ONE wave in registers.  Steps with
+// j >= 64 pair two registers of the same lane (no shuffle); the sort direction of an element depends on lane bits
+// only for k < 64, so everything else folds at compile time.
+template <int E>
+__device__ __forceinline__ void wave_bitonic_sort(uint64_t (&v)[E], int lane) {
+  constexpr int NE = 64 * E;
 #pragma unroll
   for (int k = 2; k <= NE; k <<= 1) {
 #pragma unroll
     for (int j = k >> 1; j >= 1; j >>= 1) {
-      if (j == 64) {   // partner is the lane's own second element (only when TWO, k == 128: ascending)
-        const uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
-        a = lo; b = hi;
+      if (j >= 64) {
+        const int je = j >> 6;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          if ((e & je) == 0) {
+            const bool asc = (((64 * e) & k) == 0);            // k >= 128 here: the lane bits do not reach bit k
+            const uint64_t x = v[e], y = v[e | je];
+            const uint64_t lo = x < y ? x : y, hi = x < y ? y : x;
+            v[e] = asc ? lo : hi;
+            v[e | je] = asc ? hi : lo;
+          }
+        }
       } else {
         const bool upper = (lane & j) != 0;
-        {
-          const bool asc = TWO ? ((lane & k) == 0 || k == 128) : ((lane & k) == 0 || k == 64);
-          const uint64_t o = shfl_xor_u64(a, j);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const bool asc = (((lane + 64 * e) & k) == 0);
+          const uint64_t o = shfl_xor_u64(v[e], j);
           const bool take_min = (asc != upper);
-          a = take_min ? (a < o ? a : o) : (a < o ? o : a);
-        }
-        if (TWO) {
-          // element index of b is lane + 64: bit 6 set, so for k == 64 the direction flips (descending)
-          const bool asc = (k == 128) ? true : (k == 64 ? false : ((lane & k) == 0));
-          const uint64_t o = shfl_xor_u64(b, j);
-          const bool take_min = (asc != upper);
-          b = take_min ? (b < o ? b : o) : (b < o ? o : b);
+          v[e] = take_min ? (v[e] < o ? v[e] : o) : (v[e] < o ? o : v[e]);
         }
       }
     }
   }
+}
+
+template <int E>
+__device__ __forceinline__ void wave_sort_list(const uint64_t *__restrict__ key_buf, int64_t lo, int L, int lane, int64_t t,
+                                               int n_tiles, int tile_bits, int32_t *flatten_ids, int64_t *isect_ids) {
+  uint64_t v[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) v[e] = (lane + 64 * e < L) ? key_buf[lo + lane + 64 * e] : ~0ull;
+  wave_bitonic_sort<E>(v, lane);
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+    if (lane + 64 * e < L) write_sorted(v[e], lo + lane + 64 * e, t, n_tiles, tile_bits, flatten_ids, isect_ids);
 }
 
 // LDS sort for lists with L <= CAP (CAP keys of 8 B in LDS); longer lists are appended to the
@@ -320,19 +339,13 @@ k_tile_sort_lds(int64_t M, int n_tiles, int tile_bits, const int32_t *__restrict
       continue;
     }
     if (L <= 0) continue;
-    if (L <= 128) {   // one wave, registers only, no barrier; the other waves of the block move on
+    if (L <= 256) {   // one wave, registers only, no barrier; the other waves of the block move on (8 keys per lane,
+                      // 512-key lists, measured no faster than the LDS network)
       if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
-        uint64_t a = lane < L ? key_buf[lo + lane] : ~0ull;
-        uint64_t b = ~0ull;
-        if (L <= 64) {
-          wave_bitonic_sort<false>(a, b, lane);
-        } else {
-          if (lane + 64 < L) b = key_buf[lo + 64 + lane];
-          wave_bitonic_sort<true>(a, b, lane);
-        }
-        if (lane < L) write_sorted(a, lo + lane, t, n_tiles, tile_bits, flatten_ids, isect_ids);
-        if (lane + 64 < L) write_sorted(b, lo + 64 + lane, t, n_tiles, tile_bits, flatten_ids, isect_ids);
+        if (L <= 64) wave_sort_list<1>(key_buf, lo, (int)L, lane, t, n_tiles, tile_bits, flatten_ids, isect_ids);
+        else if (L <= 128) wave_sort_list<2>(key_buf, lo, (int)L, lane, t, n_tiles, tile_bits, flatten_ids, isect_ids);
+        else wave_sort_list<4>(key_buf, lo, (int)L, lane, t, n_tiles, tile_bits, flatten_ids, isect_ids);
       }
       continue;
     }

@@ -152,6 +152,22 @@ def test_isect_empty_and_ties(dev):
     assert torch.equal(flat_h.cpu(), flat_o) and torch.equal(ids_h.cpu(), ids_o)
 
 
+def test_isect_every_sort_path_boundary(dev):
+    """One tile, list lengths around every switch of the per-tile sort (1 / 2 / 4 keys per lane in registers,
+    LDS network, long-list kernel), with ties: bit-exact against the oracle's global sort."""
+    from splat_one_amd.ops import isect_tiles
+    g = torch.Generator().manual_seed(1)
+    for N in (1, 2, 63, 64, 65, 127, 128, 129, 191, 255, 256, 257, 300, 511, 512, 513, 2047, 2048, 2049):
+        m2 = torch.rand(1, N, 2, generator=g) * 8 + 4
+        radii = torch.ones(1, N, dtype=torch.int32)
+        dep = torch.rand(1, N, generator=g) + 0.5
+        dep[0, ::5] = 0.75
+        _, ids_o, flat_o = O.isect_tiles(m2, radii, dep, 16, 1, 1)
+        _, ids_h, flat_h = isect_tiles(m2.to(dev), radii.to(dev), dep.to(dev), 16, 1, 1)
+        assert torch.equal(flat_h.cpu(), flat_o), N
+        assert torch.equal(ids_h.cpu(), ids_o), N
+
+
 def test_isect_long_lists(dev):
     """Lists longer than the small (1024) and the large (16384) LDS sort capacities."""
     from splat_one_amd.ops import isect_tiles
