@@ -165,7 +165,9 @@ static inline void launch_scan(int64_t M, const int32_t *counts, const int32_t *
 // 16 lanes cooperate on one (camera, Gaussian): lane s takes tiles s, s+16, ... of its AABB, so the
 // returning atomics of one Gaussian are in flight together instead of one after the other
 // (the per-Gaussian loop was latency-bound: ~7 dependent atomic round trips per lane).
-constexpr int kScatterLanes = 16;
+// With tile_slots most keys need no atomic at all and at large N 16 lanes per Gaussian only multiply the thread count
+// (16M threads at 1M Gaussians): so_isect_fill picks 2..16 lanes from C*N.
+template <int kScatterLanes>
 __global__ void __launch_bounds__(256)
 k_isect_scatter(int C, int N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
                 const float *__restrict__ depths, float tile_size, int tile_w, int tile_h,
@@ -509,9 +511,19 @@ extern "C" int so_isect_fill(int C, int N, const float *means2d, const int32_t *
   const int n_tiles = tile_width * tile_height;
   const int64_t M = (int64_t)C * n_tiles;
   const int tb = so::tile_bits_of(n_tiles);
-  hipLaunchKernelGGL(so::k_isect_scatter, dim3(so::grid_1d((int64_t)C * N * so::kScatterLanes, 256, 16384)), dim3(256), 0, st, C, N, means2d,
-                     radii, depths, (float)tile_size, tile_width, tile_height, isect_offsets, tile_cursor, capacity,
-                     key_buf, overflow, tile_slots, n_isects, reinterpret_cast<const float4 *>(cull_rec));
+  // lanes per Gaussian of the slotted scatter: few Gaussians want many lanes (parallelism: 100k Gaussians 32 us with
+  // 16 lanes, 46 with 4), many Gaussians want few (thread count: 1M Gaussians 98 us with 4 lanes, 154 with 16)
+  const int64_t CN = (int64_t)C * N;
+  const int slotted_lanes = CN <= 300000 ? 16 : (CN <= 600000 ? 8 : (CN <= 1500000 ? 4 : 2));
+#define SO_SCATTER(L)                                                                                                         \
+    hipLaunchKernelGGL(so::k_isect_scatter<L>, dim3(so::grid_1d((int64_t)C * N * L, 256, 16384)), dim3(256), 0, st, C, N, means2d, \
+                       radii, depths, (float)tile_size, tile_width, tile_height, isect_offsets, tile_cursor, capacity,        \
+                       key_buf, overflow, tile_slots, n_isects, reinterpret_cast<const float4 *>(cull_rec))
+  if (tile_slots && slotted_lanes == 2) SO_SCATTER(2);
+  else if (tile_slots && slotted_lanes == 4) SO_SCATTER(4);
+  else if (tile_slots && slotted_lanes == 8) SO_SCATTER(8);
+  else SO_SCATTER(16);
+#undef SO_SCATTER
   const int gridM = (int)(M < 65535 * 8 ? M : 65535 * 8);
   static bool lds_attr_set = false;  // 128 KiB of dynamic LDS needs an explicit opt-in
   if (!lds_attr_set) {
