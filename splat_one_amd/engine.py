@@ -100,7 +100,8 @@ class FusedEngine:
         # counters (2M+3 ints) | loss sums (2 floats) | loss, l1, ssimloss (3 floats) in one allocation
         w["counters"] = torch.zeros(2 * M + 8, dtype=i32, device=dev)
         w["isect_offsets"] = e(C, th, tw, dtype=i32)
-        w["key_buf"] = e(cap, dtype=torch.int64)
+        # zero-filled once: whatever a list slot holds before its key is written is a valid Gaussian index
+        w["key_buf"] = torch.zeros(cap, dtype=torch.int64, device=dev)
         w["flatten_ids"] = e(cap, dtype=i32)
         w["render_colors"], w["render_alphas"] = e(C, H, W, 3), e(C, H, W, 1)
         w["last_ids"] = e(C, H, W, dtype=i32)

@@ -115,7 +115,7 @@ class ShardedEngine:
         w["tiles_full"] = e(Nf, dtype=i32)
         w["counters"] = z(2 * M + 8, dtype=i32)
         w["isect_offsets"] = e(th, tw, dtype=i32)
-        w["key_buf"] = e(icap, dtype=torch.int64)
+        w["key_buf"] = z(icap, dtype=torch.int64)
         w["flatten_ids"] = e(icap, dtype=i32)
         w["render_colors"], w["render_alphas"] = e(1, H, W, 3), e(1, H, W, 1)
         w["last_ids"] = e(1, H, W, dtype=i32)
