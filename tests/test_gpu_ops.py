@@ -437,3 +437,74 @@ def test_rec_unpack_and_cam_stride(dev):
     _lib.call("so_rec_unpack", C * cap, p(rec), p(m2), p(rad), p(dep), p(vrec), _lib.stream())
     assert torch.equal(m2, strided["means2d"]) and torch.equal(rad, strided["radii"]) and torch.equal(dep, strided["depths"])
     assert (vrec == 0).all()
+
+
+@pytest.mark.parametrize("cull", [0, 1])
+def test_slotted_binning_and_exact_tile_cull_c_abi(dev, cull):
+    """so_preprocess_fwd(tile_slots[, tile_cull]) -> so_isect_scan(both histogram halves) -> so_isect_fill(tile_slots
+    [, cull_rec]) through the C ABI.  Without culling every tile's list equals, as a sorted sequence, the list of the
+    plain path (so_isect_count / so_isect_fill).  With culling every list is a subsequence of it, and every pair that
+    was dropped has alpha < 1/255 at ALL 256 pixel centres of its tile (float64 brute force): the cull is exact."""
+    from splat_one_amd import _lib
+    from splat_one_amd.scene import make_scene
+    W, H, N, C = 320, 208, 3000, 2
+    splats, c2w, Ks = make_scene(N, W, H, "ref", n_views=C)
+    g = torch.Generator().manual_seed(11)
+    splats["scales"] = splats["scales"] + torch.randn(N, 3, generator=g) * 0.7       # needles, blobs, > 12-tile rectangles
+    splats["scales"][:200] -= 2.0                                                     # sub-pixel ones
+    splats["opacities"] = torch.randn(N, generator=g) * 3.0 - 2.0                     # many near / below 1/255
+    s = {k: v.to(dev).contiguous() for k, v in splats.items()}
+    vm, Kd = torch.linalg.inv(c2w).to(dev).contiguous(), Ks.to(dev).contiguous()
+    K, ts = 1 + s["shN"].shape[1], 16
+    tw, th = (W + ts - 1) // ts, (H + ts - 1) // ts
+    M = C * tw * th
+    p, st = _lib.ptr, _lib.stream()
+    z = lambda *sh, dt=torch.float32: torch.zeros(*sh, dtype=dt, device=dev)
+    o = dict(radii=z(C * N, dt=torch.int32), means2d=z(C * N, 2), depths=z(C * N), conics=z(C * N, 3), opac=z(C * N),
+             colors=z(C * N, 3), tpg=z(C * N, dt=torch.int32), rec=z(C * N, 16), slots=z(C * N, _lib.SO_TILE_SLOTS, dt=torch.int32))
+    counters = z(2 * M + 4, dt=torch.int32)                   # small histogram | large-rectangle histogram | long-list length, n_isects, overflow
+    offsets, n_is, ovf = z(M, dt=torch.int32), counters[2 * M + 1:], counters[2 * M + 2:]
+    _lib.call("so_preprocess_fwd", C, N, K, 3, p(s["means"]), p(s["scales"]), p(s["quats"]), p(s["opacities"]), p(s["sh0"]), p(s["shN"]),
+              p(vm), p(Kd), W, H, 0.3, 0.01, 1e8, 0.0, 0, 0, ts, p(o["radii"]), p(o["means2d"]), p(o["depths"]), p(o["conics"]),
+              p(o["opac"]), p(o["colors"]), p(o["tpg"]), p(counters), p(o["rec"]), 0, 0, p(o["slots"]), cull, st)
+    assert counters[M:2 * M].sum().item() > 0 and counters[:M].sum().item() > 0           # both kinds of rectangle occur
+    _lib.call("so_isect_scan", C, tw, th, p(counters), p(counters[M:]), p(offsets), p(n_is), st)
+    n = int(n_is[0].item())
+    cap = n + 16
+    keys, flat = z(cap, dt=torch.int64), torch.full((cap,), -1, dtype=torch.int32, device=dev)
+    _lib.call("so_isect_fill", C, N, p(o["means2d"]), p(o["radii"]), p(o["depths"]), ts, tw, th, p(offsets), p(n_is),
+              p(counters[M:]), cap, p(keys), p(flat), 0, p(ovf), p(o["slots"]), p(o["rec"]) if cull else 0, st)
+    assert int(ovf[0].item()) == 0 and (flat[:n] >= 0).all() and (flat[:n] < C * N).all()
+    # the plain path on the same projected Gaussians
+    from splat_one_amd.ops import isect_offset_encode, isect_tiles
+    _, ids_ref, flat_ref = isect_tiles(o["means2d"].view(C, N, 2), o["radii"].view(C, N), o["depths"].view(C, N), ts, tw, th)
+    offs_ref = isect_offset_encode(ids_ref, C, tw, th).reshape(-1).cpu().tolist() + [flat_ref.numel()]
+    offs = offsets.cpu().tolist() + [n]
+    flat, flat_ref = flat.cpu(), flat_ref.cpu()
+    if not cull:
+        assert n == flat_ref.numel() and offs == offs_ref and torch.equal(flat[:n], flat_ref)
+        return
+    assert 0.2 * flat_ref.numel() < n < 0.8 * flat_ref.numel(), (n, flat_ref.numel())
+    m2, con, op = o["means2d"].cpu().double(), o["conics"].cpu().double(), o["opac"].cpu().double()
+    py, px = torch.meshgrid(torch.arange(ts, dtype=torch.float64) + 0.5, torch.arange(ts, dtype=torch.float64) + 0.5, indexing="ij")
+    n_dropped, worst = 0, 0.0
+    for t in range(M):
+        full = flat_ref[offs_ref[t]:offs_ref[t + 1]].tolist()
+        kept = flat[offs[t]:offs[t + 1]].tolist()
+        it = iter(full)
+        assert all(any(k == f for f in it) for k in kept), t            # an order-preserving subsequence
+        dropped = sorted(set(full) - set(kept))
+        if not dropped:
+            continue
+        tile = t % (tw * th)
+        x0, y0 = (tile % tw) * ts, (tile // tw) * ts
+        d = torch.tensor(dropped)
+        dx = (x0 + px)[None] - m2[d, 0, None, None]
+        dy = (y0 + py)[None] - m2[d, 1, None, None]
+        sigma = 0.5 * (con[d, 0, None, None] * dx * dx + con[d, 2, None, None] * dy * dy) + con[d, 1, None, None] * dx * dy
+        alpha = op[d, None, None] * torch.exp(-sigma)
+        alpha = torch.where(sigma < 0, torch.zeros_like(alpha), alpha)
+        worst = max(worst, alpha.max().item())
+        n_dropped += len(dropped)
+    assert n_dropped == flat_ref.numel() - n
+    assert worst < 1.0 / 255.0, worst
