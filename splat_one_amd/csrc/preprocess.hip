@@ -216,6 +216,9 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
     const int64_t n = n0 + threadIdx.x;
     const bool active = n < N;
     float acc[NB][3];
+    // staged: the 3 (NB - 1) gradient sums of shN live in this lane's LDS row from the start (45 registers fewer)
+    float *const my_row = s_stage + ((size_t)(threadIdx.x >> 6) * 64 + (threadIdx.x & 63)) * R;
+    bool first = true;
     if (active) {
     const float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
     float q[4], ls[3];
@@ -266,12 +269,20 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
       const float x = ddx * inorm, y = ddy * inorm, z = ddz * inorm;
       float vdn[3] = {0.f, 0.f, 0.f};
       sh_eval<float>(DEG, x, y, z, [&](int k, float yk, float gx, float gy, float gz) {
-        acc[k][0] += yk * vr; acc[k][1] += yk * vg; acc[k][2] += yk * vb;
+        if (STAGE && k > 0) {
+          float *rp = my_row + 3 * (k - 1);
+          rp[0] = first ? yk * vr : rp[0] + yk * vr;
+          rp[1] = first ? yk * vg : rp[1] + yk * vg;
+          rp[2] = first ? yk * vb : rp[2] + yk * vb;
+        } else {
+          acc[k][0] += yk * vr; acc[k][1] += yk * vg; acc[k][2] += yk * vb;
+        }
         float cf[3];
         coef.get(k, cf);
         const float w = cf[0] * vr + cf[1] * vg + cf[2] * vb;
         vdn[0] += gx * w; vdn[1] += gy * w; vdn[2] += gz * w;
       });
+      first = false;
       const float dot = vdn[0] * x + vdn[1] * y + vdn[2] * z;
       vm[0] += (vdn[0] - dot * x) * inorm;
       vm[1] += (vdn[1] - dot * y) * inorm;
@@ -305,10 +316,9 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
       const int lane = lane_id(), wv = threadIdx.x >> 6;
       float *mine = s_stage + (size_t)wv * 64 * R;        // this wave's 64 rows, row stride R (odd for K = 16: no bank conflicts)
       if (active) {
-        float *row = mine + lane * R;
-#pragma unroll
-        for (int k = 1; k < NB; ++k) { row[3 * (k - 1)] = acc[k][0]; row[3 * (k - 1) + 1] = acc[k][1]; row[3 * (k - 1) + 2] = acc[k][2]; }
-        for (int k = 3 * (NB - 1); k < R; ++k) row[k] = 0.f;
+        if (first)                                        // seen by no camera: the sums were never started
+          for (int k = 0; k < 3 * (NB - 1); ++k) my_row[k] = 0.f;
+        for (int k = 3 * (NB - 1); k < R; ++k) my_row[k] = 0.f;
       }
       __syncthreads();
       const int64_t w0 = n0 + (int64_t)wv * 64;            // first Gaussian of this wave: a multiple of 64 -> 16-byte aligned run
