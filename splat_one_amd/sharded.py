@@ -84,6 +84,7 @@ class ShardedEngine:
     # ---------------------------------------------------------------------------------------------
     def _build_workspace(self) -> None:
         dev, W, H, n = self.device, self.W, self.H, self.world
+        self._ptr_cache, self._adam_cache = {}, None         # everything below is reallocated
         N = self.splats["means"].shape[0]
         K = 1 + self.splats["shN"].shape[1]
         sizes = torch.tensor([N, -N], dtype=torch.int64, device=dev)         # max and (negated) min in one collective
@@ -150,11 +151,31 @@ class ShardedEngine:
         """Call on EVERY rank after a densification step (the shard sizes are re-agreed collectively)."""
         self._build_workspace()
 
+    def _P(self, key: str) -> int:
+        """Cached device pointer: "w.<workspace tensor>", "s.<parameter>", "g.<gradient>", "c.<slot of the counters>"."""
+        v = self._ptr_cache.get(key)
+        if v is None:
+            kind, _, name = key.partition(".")
+            M = self.M
+            if kind == "w":
+                t = self.ws[name]
+            elif kind == "s":
+                t = self.splats[name].data
+            elif kind == "g":
+                t = self.ws["grads"][name]
+            else:
+                t = {"cursor": self.ws["counters"][M:], "n_isects": self.ws["counters"][2 * M + 1:],
+                     "overflow": self.ws["counters"][2 * M + 2:], "loss_out": self.ws["loss_sums"][2:]}[name]
+            v = self._ptr_cache[key] = _lib.ptr(t)
+        return v
+
     def set_sh_degree(self, deg: int) -> None:
         self.cfg["sh_degree"] = deg
 
     # same schedule bookkeeping as FusedEngine
     def _adam_args(self):
+        if self._adam_cache is not None:        # parameter / moment tensors only change with rebuild()
+            return self._adam_cache
         items = []
         for k in PARAM_ORDER:
             opt = self.optimizers[k]
@@ -178,7 +199,8 @@ class ShardedEngine:
             g = self.lr_gamma_means if k == "means" else 1.0
             lr0[i] = grp["lr"] / (g ** self.steps_done)
             gam[i] = g
-        return n, arr, lr0, gam, betas, eps
+        self._adam_cache = (n, arr, lr0, gam, betas, eps)
+        return self._adam_cache
 
     # ---------------------------------------------------------------------------------------------
     def fwd_bwd(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor, schedule: bool = False) -> None:
@@ -188,6 +210,8 @@ class ShardedEngine:
         assert camtoworlds.shape == (n, 4, 4) and Ks.shape == (n, 3, 3), (camtoworlds.shape, Ks.shape)
         assert pixels.shape == (1, H, W, 3), pixels.shape
         w, s, c, p, st, dev = self.ws, self.splats, self.cfg, _lib.ptr, _lib.stream(), self.device
+        P = self._P          # device pointers of the static buffers, looked up once per workspace (the step is a
+                             # sequence of ~20 C-ABI calls from Python: their argument marshalling is its host cost)
         c2w = camtoworlds.detach().to(device=dev, dtype=torch.float32).contiguous()
         Ksd = Ks.detach().to(device=dev, dtype=torch.float32).contiguous()
         if pixels.is_cuda and pixels.dtype == torch.float32 and pixels.is_contiguous():
@@ -200,7 +224,7 @@ class ShardedEngine:
         if schedule:
             ng, _arr, lr0, gam, betas, _eps = self._adam_args()
         self._seq = (self._seq + 1) & 0x3FFFFFFF
-        _lib.call("so_step_inputs", n, p(c2w), p(Ksd), p(w["viewmats"]), p(w["Ks"]), 0, 0, p(w["counters"]), 2 * M + 5, ng,
+        _lib.call("so_step_inputs", n, p(c2w), p(Ksd), P("w.viewmats"), P("w.Ks"), 0, 0, P("w.counters"), 2 * M + 5, ng,
                   lr0, gam, float(betas[0]), float(betas[1]), p(self._step_dev), self._status.data_ptr(), 2 * M + 1,
                   self._seq, st)
         self._status_event = torch.cuda.Event()
@@ -210,27 +234,24 @@ class ShardedEngine:
         cam = camera_model_code(c["camera_model"], n)
         f16 = self.attr_dtype == "f16"
         if N > 0 and f16:
-            _lib.call("so_preprocess_fwd_f16", n, N, self.K, c["sh_degree"], p(s["means"].data), p(s["opacities"].data),
-                      p(w["arec"]), p(w["viewmats"]), p(w["Ks"]), W, H, c["eps2d"], c["near_plane"], c["far_plane"],
-                      c["radius_clip"], cam, int(c["antialiased"]), ts, p(w["radii"]), p(w["means2d"]), p(w["depths"]),
-                      p(w["conics"]), p(w["opacities"]), p(w["colors"]), p(w["tiles_per_gauss"]), 0, p(w["rec_shard"]), 0, cap, 0, 0, st)
+            _lib.call("so_preprocess_fwd_f16", n, N, self.K, c["sh_degree"], P("s.means"), P("s.opacities"),
+                      P("w.arec"), P("w.viewmats"), P("w.Ks"), W, H, c["eps2d"], c["near_plane"], c["far_plane"],
+                      c["radius_clip"], cam, int(c["antialiased"]), ts, P("w.radii"), P("w.means2d"), P("w.depths"),
+                      P("w.conics"), P("w.opacities"), P("w.colors"), P("w.tiles_per_gauss"), 0, P("w.rec_shard"), 0, cap, 0, 0, st)
         elif N > 0:
-            _lib.call("so_preprocess_fwd", n, N, self.K, c["sh_degree"], p(s["means"].data), p(s["scales"].data),
-                      p(s["quats"].data), p(s["opacities"].data), p(s["sh0"].data), p(s["shN"].data), p(w["viewmats"]),
-                      p(w["Ks"]), W, H, c["eps2d"], c["near_plane"], c["far_plane"], c["radius_clip"], cam,
-                      int(c["antialiased"]), ts, p(w["radii"]), p(w["means2d"]), p(w["depths"]), p(w["conics"]),
-                      p(w["opacities"]), p(w["colors"]), p(w["tiles_per_gauss"]), 0, p(w["rec_shard"]), 0, cap, 0, 0, st)
+            _lib.call("so_preprocess_fwd", n, N, self.K, c["sh_degree"], P("s.means"), P("s.scales"),
+                      P("s.quats"), P("s.opacities"), P("s.sh0"), P("s.shN"), P("w.viewmats"),
+                      P("w.Ks"), W, H, c["eps2d"], c["near_plane"], c["far_plane"], c["radius_clip"], cam,
+                      int(c["antialiased"]), ts, P("w.radii"), P("w.means2d"), P("w.depths"), P("w.conics"),
+                      P("w.opacities"), P("w.colors"), P("w.tiles_per_gauss"), 0, P("w.rec_shard"), 0, cap, 0, 0, st)
         all_to_all_rows(w["rec_full"], w["rec_shard"], self.group)
-        counters = w["counters"]
-        tile_counts, cursor = counters, counters[M:]
-        n_isects, overflow = counters[2 * M + 1:], counters[2 * M + 2:]
-        _lib.call("so_rec_unpack", Nf, p(w["rec_full"]), p(w["means2d_full"]), p(w["radii_full"]), p(w["depths_full"]),
-                  p(w["vrec_full"]), st)
-        _lib.call("so_isect_count", 1, Nf, p(w["means2d_full"]), p(w["radii_full"]), ts, tw, th, p(w["tiles_full"]),
-                  p(tile_counts), p(w["isect_offsets"]), p(n_isects), p(w["rec_full"]) if self.tile_cull else 0, st)
+        _lib.call("so_rec_unpack", Nf, P("w.rec_full"), P("w.means2d_full"), P("w.radii_full"), P("w.depths_full"),
+                  P("w.vrec_full"), st)
+        _lib.call("so_isect_count", 1, Nf, P("w.means2d_full"), P("w.radii_full"), ts, tw, th, P("w.tiles_full"),
+                  P("w.counters"), P("w.isect_offsets"), P("c.n_isects"), P("w.rec_full") if self.tile_cull else 0, st)
         if self._probe_capacity:     # once per workspace: the largest intersection count over the ranks decides the buffers
             self._probe_capacity = False
-            cnt = n_isects[:1].to(torch.int64)
+            cnt = w["counters"][2 * M + 1:2 * M + 2].to(torch.int64)
             dist.all_reduce(cnt, op=dist.ReduceOp.MAX, group=self.group)
             if 1.25 * int(cnt.item()) > self.capacity:
                 self._capacity_hint = 2 * int(cnt.item()) + 4096
@@ -238,42 +259,41 @@ class ShardedEngine:
                 self._step_dev[0] = self.steps_done
                 self._build_workspace()
                 return self.fwd_bwd(camtoworlds, Ks, pixels, schedule)
-        _lib.call("so_isect_fill", 1, Nf, p(w["means2d_full"]), p(w["radii_full"]), p(w["depths_full"]), ts, tw, th,
-                  p(w["isect_offsets"]), p(n_isects), p(cursor), self.capacity, p(w["key_buf"]), p(w["flatten_ids"]), 0,
-                  p(overflow), 0, p(w["rec_full"]) if self.tile_cull else 0, st)
-        _lib.call("so_rasterize_fwd_packed", 1, Nf, W, H, ts, p(w["rec_full"]), 0, p(w["isect_offsets"]), p(w["flatten_ids"]),
-                  p(n_isects), self.capacity, p(w["render_colors"]), p(w["render_alphas"]), p(w["last_ids"]), st)
+        _lib.call("so_isect_fill", 1, Nf, P("w.means2d_full"), P("w.radii_full"), P("w.depths_full"), ts, tw, th,
+                  P("w.isect_offsets"), P("c.n_isects"), P("c.cursor"), self.capacity, P("w.key_buf"), P("w.flatten_ids"), 0,
+                  P("c.overflow"), 0, P("w.rec_full") if self.tile_cull else 0, st)
+        _lib.call("so_rasterize_fwd_packed", 1, Nf, W, H, ts, P("w.rec_full"), 0, P("w.isect_offsets"), P("w.flatten_ids"),
+                  P("c.n_isects"), self.capacity, P("w.render_colors"), P("w.render_alphas"), P("w.last_ids"), st)
         lam = float(c["ssim_lambda"])
         n_l1 = float(H * W * 3)
         n_ss = float((H - 10) * (W - 10) * 3)
-        _lib.call("so_ssim_l1_fwd", 1, H, W, 3, p(w["render_colors"]), p(px), 1, p(w["loss_sums"]), p(w["dmaps"]), st)
+        _lib.call("so_ssim_l1_fwd", 1, H, W, 3, P("w.render_colors"), p(px), 1, P("w.loss_sums"), P("w.dmaps"), st)
         # weight 1/world: the step's loss is the mean over the global batch of views
-        _lib.call("so_ssim_l1_bwd", 1, H, W, 3, p(w["render_colors"]), p(px), p(w["dmaps"]), (1.0 - lam) / n_l1 / n,
-                  -lam / n_ss / n, 0, p(w["v_render_colors"]), p(w["loss_sums"]), p(w["loss_sums"][2:]), 1, lam / n, st)
-        _lib.call("so_rasterize_bwd_packed", 1, Nf, W, H, ts, p(w["rec_full"]), 0, p(w["isect_offsets"]), p(w["flatten_ids"]),
-                  p(n_isects), self.capacity, p(w["render_alphas"]), p(w["last_ids"]), p(w["v_render_colors"]), p(w["zero_v_alphas"]),
-                  p(w["vrec_full"]), int(c["absgrad"]), st)
+        _lib.call("so_ssim_l1_bwd", 1, H, W, 3, P("w.render_colors"), p(px), P("w.dmaps"), (1.0 - lam) / n_l1 / n,
+                  -lam / n_ss / n, 0, P("w.v_render_colors"), P("w.loss_sums"), P("c.loss_out"), 1, lam / n, st)
+        _lib.call("so_rasterize_bwd_packed", 1, Nf, W, H, ts, P("w.rec_full"), 0, P("w.isect_offsets"), P("w.flatten_ids"),
+                  P("c.n_isects"), self.capacity, P("w.render_alphas"), P("w.last_ids"), P("w.v_render_colors"), P("w.zero_v_alphas"),
+                  P("w.vrec_full"), int(c["absgrad"]), st)
         all_to_all_rows(w["vrec_shard"], w["vrec_full"], self.group)
         if N > 0:
-            g = w["grads"]
             sst = self.strategy_state
             # the regularisers are means over ALL Gaussians: rescale the kernel's 1/N to 1/N_total
             scale = float(N) / float(max(self.N_total, 1))
             if f16:
-                _lib.call("so_preprocess_bwd_f16", n, N, self.K, c["sh_degree"], p(s["means"].data), p(s["opacities"].data),
-                          p(w["arec"]), p(w["viewmats"]), p(w["Ks"]), W, H, c["eps2d"], cam, int(c["antialiased"]),
-                          p(w["radii"]), p(w["opacities"]), p(w["colors"]), c["opacity_reg"] * scale, c["scale_reg"] * scale,
-                          p(g["means"]), p(g["scales"]), p(g["quats"]), p(g["opacities"]), p(g["sh0"]), p(g["shN"]),
+                _lib.call("so_preprocess_bwd_f16", n, N, self.K, c["sh_degree"], P("s.means"), P("s.opacities"),
+                          P("w.arec"), P("w.viewmats"), P("w.Ks"), W, H, c["eps2d"], cam, int(c["antialiased"]),
+                          P("w.radii"), P("w.opacities"), P("w.colors"), c["opacity_reg"] * scale, c["scale_reg"] * scale,
+                          P("g.means"), P("g.scales"), P("g.quats"), P("g.opacities"), P("g.sh0"), P("g.shN"),
                           p(sst["grad2d"]) if sst is not None else 0, p(sst["count"]) if sst is not None else 0,
-                          p(w["vrec_shard"]), int(c["absgrad"]), cap, p(overflow), 0, st)
+                          P("w.vrec_shard"), int(c["absgrad"]), cap, P("c.overflow"), 0, st)
             else:
-                _lib.call("so_preprocess_bwd", n, N, self.K, c["sh_degree"], p(s["means"].data), p(s["scales"].data),
-                          p(s["quats"].data), p(s["opacities"].data), p(s["sh0"].data), p(s["shN"].data), p(w["viewmats"]),
-                          p(w["Ks"]), W, H, c["eps2d"], cam, int(c["antialiased"]), p(w["radii"]), p(w["opacities"]),
-                          p(w["colors"]), 0, 0, 0, 0, 0, 0, c["opacity_reg"] * scale, c["scale_reg"] * scale, p(g["means"]),
-                          p(g["scales"]), p(g["quats"]), p(g["opacities"]), p(g["sh0"]), p(g["shN"]),
+                _lib.call("so_preprocess_bwd", n, N, self.K, c["sh_degree"], P("s.means"), P("s.scales"),
+                          P("s.quats"), P("s.opacities"), P("s.sh0"), P("s.shN"), P("w.viewmats"),
+                          P("w.Ks"), W, H, c["eps2d"], cam, int(c["antialiased"]), P("w.radii"), P("w.opacities"),
+                          P("w.colors"), 0, 0, 0, 0, 0, 0, c["opacity_reg"] * scale, c["scale_reg"] * scale, P("g.means"),
+                          P("g.scales"), P("g.quats"), P("g.opacities"), P("g.sh0"), P("g.shN"),
                           p(sst["grad2d"]) if sst is not None else 0, p(sst["count"]) if sst is not None else 0,
-                          p(w["vrec_shard"]), int(c["absgrad"]), cap, p(overflow), 0, st)
+                          P("w.vrec_shard"), int(c["absgrad"]), cap, P("c.overflow"), 0, st)
         self._keep = (c2w, Ksd, px)
         self._sched_staged = bool(schedule)
 
@@ -295,7 +315,6 @@ class ShardedEngine:
         n, arr, lr0, gam, betas, eps = self._adam_args()
         sched = getattr(self, "_sched_staged", False)
         self._sched_staged = False
-        ovf = self.ws["counters"][2 * self.M + 2:]
         shadow = None
         if self.attr_dtype == "f16" and self.N > 0:
             where = {"scales": 8, "quats": 0, "sh0": 16, "shN": 22}
@@ -304,7 +323,7 @@ class ShardedEngine:
                                          [where.get(k, -1) if self.splats[k].numel() else -1 for k in PARAM_ORDER]
                                          + [-1] * (_lib.SO_ADAM_MAX_GROUPS - len(PARAM_ORDER)))))
         _lib.call("so_adam_step_dev_shadow", n, arr, lr0, gam, float(betas[0]), float(betas[1]), float(eps),
-                  _lib.ptr(self._step_dev), 0, int(sched), _lib.ptr(ovf), 0,
+                  _lib.ptr(self._step_dev), 0, int(sched), self._P("c.overflow"), 0,
                   ctypes.byref(shadow) if shadow is not None else None, _lib.stream())
         self.steps_done += 1
         for k in PARAM_ORDER:

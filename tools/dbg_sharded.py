@@ -19,7 +19,7 @@ pixels = torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(1)).to(d
 for _ in range(20):
     r.train_step(c2w, Ks, pixels)
 torch.cuda.synchronize()
-for trial in range(3):
+for trial in range(2):
     t0 = time.time()
     for _ in range(200):
         r.train_step(c2w, Ks, pixels)
