@@ -63,3 +63,57 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "oracle/" not in txt or f.endswith((".md",)), f
+
+
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """sizeof / offsetof of so_step_desc, so_adam_group and so_attr_shadow as gcc sees the header == the ctypes mirrors
+    (a silent mismatch would hand the kernels shifted pointers)."""
+    import subprocess
+    fields = {"so_step_desc": ["means", "viewmats", "radii", "key_buf", "rec", "v_means", "grad2d", "isect_capacity", "abi_size",
+                               "raster_impl", "eps2d", "scale_reg", "pixels_indirect", "inputs_staged", "tile_cull",
+                               "overflow_flag_out", "attr_rows_f16", "tile_slots"],
+              "so_adam_group": ["param", "visibility", "numel", "row_len", "lr_step_size", "bc2_sqrt"],
+              "so_attr_shadow": ["arec", "stride_bytes", "offset_bytes"]}
+    src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
+    for st, fs in fields.items():
+        src.append(f'  printf("{st} %zu\\n", sizeof({st}));')
+        for f in fs:
+            src.append(f'  printf("{st}.{f} %zu\\n", offsetof({st}, {f}));')
+    src += ['  printf("SO_TILE_SLOTS %d\\nSO_ADAM_MAX_GROUPS %d\\nSO_CAM_PER_VIEW %d\\n", SO_TILE_SLOTS, SO_ADAM_MAX_GROUPS, SO_CAM_PER_VIEW);',
+            "  return 0;", "}"]
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-o", str(exe), str(c)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    mirrors = {"so_step_desc": _lib.StepDesc, "so_adam_group": _lib.AdamGroup, "so_attr_shadow": _lib.AttrShadow}
+    for st, fs in fields.items():
+        assert int(out[st]) == ctypes.sizeof(mirrors[st]), st
+        for f in fs:
+            assert int(out[f"{st}.{f}"]) == getattr(mirrors[st], f).offset, (st, f)
+    from splat_one_amd import ops
+    assert int(out["SO_TILE_SLOTS"]) == _lib.SO_TILE_SLOTS and int(out["SO_ADAM_MAX_GROUPS"]) == _lib.SO_ADAM_MAX_GROUPS
+    assert int(out["SO_CAM_PER_VIEW"]) == ops.SO_CAM_PER_VIEW
+
+
+def test_per_view_camera_models_and_f16_rows_validate_without_a_gpu():
+    from splat_one_amd.ops import SO_CAM_PER_VIEW, camera_model_code
+    assert camera_model_code("pinhole", 3) == 0 and camera_model_code(["fisheye"] * 4, 4) == 2
+    assert camera_model_code(["pinhole", "fisheye", "ortho"], 3) == SO_CAM_PER_VIEW | (0 << 0) | (2 << 2) | (1 << 4)
+    for bad, nv in ((["pinhole"], 2), (["pinhole", "spherical"], 2), (["pinhole", "fisheye"] * 8, 16)):
+        with pytest.raises(AssertionError):
+            camera_model_code(bad, nv)
+    lib = _lib.load()
+    assert [lib.so_attr_rec_stride(k) for k in (0, 1, 4, 9, 16, 25)] == [0, 32, 48, 80, 112, 176]
+    # a per-view code with a model id that does not exist, and more views than the code can carry: refused
+    with pytest.raises(RuntimeError, match="camera_model"):
+        _lib.call("so_preprocess_fwd", 2, 4, 16, 3, *([1] * 8), 16, 16, 0.3, 0.01, 1e8, 0.0, SO_CAM_PER_VIEW | (3 << 2), 0, 16,
+                  *([1] * 7), 0, 0, 0, 0, 0, 0, 0)
+    with pytest.raises(RuntimeError, match="camera_model"):
+        _lib.call("so_preprocess_fwd", 16, 4, 16, 3, *([1] * 8), 16, 16, 0.3, 0.01, 1e8, 0.0, SO_CAM_PER_VIEW, 0, 16,
+                  *([1] * 7), 0, 0, 0, 0, 0, 0, 0)
+    with pytest.raises(RuntimeError, match="16-byte aligned"):
+        _lib.call("so_preprocess_bwd_f16", 1, 4, 16, 3, 1, 1, 8, 1, 1, 16, 16, 0.3, 0, 0, 1, 1, 1, 0.0, 0.0, *([1] * 6), 0, 0, 64, 0, 0, 0, 0, 0)
+    with pytest.raises(RuntimeError, match="tile_slots"):
+        _lib.call("so_preprocess_fwd", 1, 4, 16, 3, *([1] * 8), 16, 16, 0.3, 0.01, 1e8, 0.0, 0, 0, 16,
+                  *([1] * 7), 0, 0, 0, 0, 1, 0, 0)
