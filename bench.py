@@ -276,7 +276,10 @@ def main():
     info = runner.last_info
     N0, N = N, (N if runner.sharded else int(runner.splats["means"].shape[0]))     # densification changes N
     V = int((info["radii"] > 0).sum().item())
-    I = int(info["flatten_ids"].numel()) if "n_isects" not in info else int(info["n_isects"].item())
+    if "engine" in info:
+        I = info["engine"].stats()["n_isects"]
+    else:
+        I = int(info["flatten_ids"].numel()) if "n_isects" not in info else int(info["n_isects"].item())
     P = W * H
     K = (cfg.sh_degree + 1) ** 2
     ab = algorithmic_bytes(N, V, I, P, K)
@@ -316,6 +319,7 @@ def main():
                                + (", float16 attribute rows" if args.attr_dtype == "f16" else ""),
                    "views_per_step": world, "visible_gaussians": V, "tile_intersections": I,
                    "tile_cull": bool(cfg.tile_cull and fused),   # I counts what is left after exact tile culling
+                   "binned_lists": bool(fused and not runner.sharded and runner._engine.binned),
                    "parallelism": (f"gaussian-sharded dp{world}: one view per GPU, N/{world} Gaussians per GPU, "
                                    "projected Gaussians exchanged by all-to-all" if runner.sharded else
                                    f"view-sharded dp{world}" + (", gradient all-reduce" if world > 1 else "")),

@@ -142,6 +142,15 @@ int so_isect_fill(int C, int N, const float *means2d, const int32_t *radii, cons
  * offsets[tile] + slot with no atomic at all and lets the large rectangles fill the tail of each list from the back
  * (counting tile_cursor down to zero).  One round of atomics per iteration instead of two. */
 #define SO_TILE_SLOTS 12
+/* Binned lists -- the third way to build the per-tile lists, and the fused engine's: so_preprocess_fwd(bin_keys,
+ * bin_cap, bin_overflow) gives every (camera, tile) bin_cap key slots; the returning atomic on tile_counts[t] is the slot
+ * and the key {depth bits, flatten id} is stored at bin_keys[t * bin_cap + slot] at once (slot >= bin_cap raises
+ * *bin_overflow instead).  so_isect_sort_bins then sorts each bin's min(tile_counts[t], bin_cap) keys in place and
+ * writes flatten_ids[t * bin_cap + i]; long_list is int32[C*tiles + 1] scratch whose last element is zero on entry.
+ * The rasteriser's packed entry points take this layout as isect_offsets = tile_counts, n_isects_dev = NULL,
+ * n_isects_host = -bin_cap. */
+int so_isect_sort_bins(int C, int tile_width, int tile_height, const int32_t *tile_counts, int64_t bin_cap,
+                       uint64_t *bin_keys, int32_t *flatten_ids, int32_t *long_list, void *stream);
 /* Exact tile culling (tile_cull of so_preprocess_fwd + cull_rec = its 64-byte records for so_isect_fill; both or
  * neither): gsplat bins a Gaussian into every tile of the square of half-width ceil(3 sqrt(lambda_max)) around its
  * centre, while the rasteriser drops every pair with alpha = opacity exp(-sigma) < 1/255.  A tile whose pixel-centre
@@ -298,7 +307,9 @@ int so_preprocess_fwd(int C, int N, int K, int sh_degree, const float *means, co
                       float near_plane, float far_plane, float radius_clip, int camera_model, int antialiased,
                       int tile_size, int32_t *radii, float *means2d, float *depths, float *conics,
                       float *opacities, float *colors, int32_t *tiles_per_gauss, int32_t *tile_counts,
-                      float *rec, float *vrec, int64_t cam_stride, int32_t *tile_slots, int tile_cull, void *stream);
+                      float *rec, float *vrec, int64_t cam_stride, int32_t *tile_slots, int tile_cull,
+                      uint64_t *bin_keys /* nullable, see so_isect_sort_bins */, int64_t bin_cap, int32_t *bin_overflow,
+                      void *stream);
 int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float *means, const float *log_scales,
                       const float *quats, const float *logit_opacities, const float *sh0, const float *shN,
                       const float *viewmats, const float *Ks, int width, int height, float eps2d,
@@ -334,7 +345,7 @@ int so_preprocess_fwd_f16(int C, int N, int K, int sh_degree, const float *means
                           int antialiased, int tile_size, int32_t *radii, float *means2d, float *depths,
                           float *conics, float *opacities, float *colors, int32_t *tiles_per_gauss,
                           int32_t *tile_counts, float *rec, float *vrec, int64_t cam_stride, int32_t *tile_slots,
-                          int tile_cull, void *stream);
+                          int tile_cull, uint64_t *bin_keys, int64_t bin_cap, int32_t *bin_overflow, void *stream);
 int so_preprocess_bwd_f16(int C, int N, int K, int sh_degree, const float *means, const float *logit_opacities,
                           const void *arec, const float *viewmats, const float *Ks, int width, int height,
                           float eps2d, int camera_model, int antialiased, const int32_t *radii,
@@ -396,6 +407,12 @@ typedef struct so_step_desc {
   /* int32[C*N][SO_TILE_SLOTS] scratch (nullable): the binning histogram keeps the slot each returning atomic handed
    * out, so the scatter pass places those keys without a second round of atomics (see so_preprocess_fwd). */
   int32_t *tile_slots;
+  /* Binned lists (0 = off): every (camera, tile) owns bin_capacity slots of key_buf / flatten_ids (both then hold
+   * C*tiles*bin_capacity entries; isect_offsets / isect_capacity / tile_slots are unused).  The forward kernel's
+   * returning histogram atomic IS the slot, so the key goes straight to its place: no scan, no scatter pass.  A tile
+   * that receives more than bin_capacity Gaussians raises the overflow flag (void iteration, as above); the caller
+   * then enlarges the bins -- at 288 GB of HBM, 8160 tiles x 4096 slots x 12 B = 400 MB is not a constraint. */
+  int64_t bin_capacity;
 } so_step_desc;
 int so_train_step_fwd_bwd(const so_step_desc *desc, void *stream);
 /* Everything that changes from one iteration to the next, in ONE launch, so that a captured step needs

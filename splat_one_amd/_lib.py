@@ -44,7 +44,7 @@ class StepDesc(ctypes.Structure):
         + [(n, c_f32) for n in ("eps2d", "near_plane", "far_plane", "radius_clip", "ssim_lambda", "opacity_reg",
                                 "scale_reg")]
         + [("pixels_indirect", c_ptr), ("inputs_staged", ctypes.c_int32), ("tile_cull", ctypes.c_int32),
-           ("overflow_flag_out", c_ptr), ("attr_rows_f16", c_ptr), ("tile_slots", c_ptr)])
+           ("overflow_flag_out", c_ptr), ("attr_rows_f16", c_ptr), ("tile_slots", c_ptr), ("bin_capacity", c_i64)])
 
 
 class AttrShadow(ctypes.Structure):
@@ -69,7 +69,8 @@ _SIGS = {
     "so_camera_inverse": [c_int, c_ptr, c_ptr, c_ptr],
     "so_debug_wave_reduce": [c_int, c_ptr, c_ptr, c_ptr],
     "so_isect_scan": [c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
-    "so_preprocess_fwd": [c_int] * 4 + [c_ptr] * 8 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_int] + [c_ptr] * 10 + [c_i64, c_ptr, c_int, c_ptr],
+    "so_preprocess_fwd": [c_int] * 4 + [c_ptr] * 8 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_int] + [c_ptr] * 10 + [c_i64, c_ptr, c_int, c_ptr, c_i64, c_ptr, c_ptr],
+    "so_isect_sort_bins": [c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr],
     "so_rec_unpack": [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
     "so_preprocess_bwd": [c_int] * 4 + [c_ptr] * 8 + [c_int, c_int, c_f32, c_int, c_int] + [c_ptr] * 9 + [c_f32, c_f32] + [c_ptr] * 9 + [c_int, c_i64, c_ptr, c_ptr, c_ptr],
     "so_rasterize_fwd_packed": [c_int] * 5 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 4,
@@ -87,7 +88,7 @@ _SIGS = {
                                 ctypes.c_double, ctypes.c_double, ctypes.c_double, c_ptr, c_int, c_int, c_ptr, c_ptr,
                                 ctypes.POINTER(AttrShadow), c_ptr],
     "so_attr_pack_f16": [c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
-    "so_preprocess_fwd_f16": [c_int] * 4 + [c_ptr] * 5 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_int] + [c_ptr] * 10 + [c_i64, c_ptr, c_int, c_ptr],
+    "so_preprocess_fwd_f16": [c_int] * 4 + [c_ptr] * 5 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_int] + [c_ptr] * 10 + [c_i64, c_ptr, c_int, c_ptr, c_i64, c_ptr, c_ptr],
     "so_preprocess_bwd_f16": [c_int] * 4 + [c_ptr] * 5 + [c_int, c_int, c_f32, c_int, c_int] + [c_ptr] * 3 + [c_f32, c_f32] + [c_ptr] * 9 + [c_int, c_i64, c_ptr, c_ptr, c_ptr],
     "so_step_inputs": [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, ctypes.POINTER(c_f32),
                        ctypes.POINTER(c_f32), ctypes.c_double, ctypes.c_double, c_ptr, c_ptr, c_i64, c_int, c_ptr],

@@ -251,6 +251,12 @@ __device__ __forceinline__ void bitonic_sort_shared(uint64_t *keys, int n) {
 
 __device__ __forceinline__ void tile_range(int64_t t, int64_t M, const int32_t *offsets, const int32_t *n_isects,
                                            int64_t capacity, int64_t &lo, int64_t &hi) {
+  if (!n_isects && capacity < 0) {   // binned lists: cap = -capacity slots per tile, `offsets` holds the per-tile counts
+    const int64_t cap = -capacity, cnt = offsets[t];
+    lo = t * cap;
+    hi = lo + (cnt < cap ? cnt : cap);
+    return;
+  }
   lo = offsets[t];
   hi = (t == M - 1) ? (int64_t)*n_isects : (int64_t)offsets[t + 1];
   if (hi > capacity) hi = capacity;
@@ -471,6 +477,32 @@ static inline int grid_1d(int64_t total, int block, int cap = 4096) {
 
 }  // namespace so
 
+namespace so {
+// the per-tile sorts over lists given either compactly (offsets / n_isects / capacity) or binned (n_isects NULL,
+// capacity = -slots per tile, offsets = per-tile counts): see tile_range
+static void launch_tile_sorts(int64_t M, int n_tiles, int tb, const int32_t *isect_offsets, const int32_t *n_isects,
+                              int64_t capacity, uint64_t *key_buf, int32_t *flatten_ids, int64_t *isect_ids,
+                              int32_t *long_list, int32_t *long_count, hipStream_t st) {
+  const int gridM = (int)(M < 65535 * 8 ? M : 65535 * 8);
+  static bool lds_attr_set = false;  // 128 KiB of dynamic LDS needs an explicit opt-in
+  if (!lds_attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sort_long<1024, 16384>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8) != hipSuccess) {
+      (void)hipGetLastError();
+    }
+    lds_attr_set = true;
+  }
+  // lists up to 2048 keys: 256 threads, 16 KiB LDS (4096 keys / 32 KiB costs the sparse regime 14 us of occupancy; most lists of a trained scene take the
+  // one-wave register path anyway, and in the dense init regime -- ~800 keys per tile -- this kernel does the bulk)
+  hipLaunchKernelGGL((k_tile_sort_lds<256, 2048>), dim3(gridM), dim3(256), 2048 * 8, st, M, n_tiles, tb,
+                     isect_offsets, n_isects, capacity, key_buf, flatten_ids, isect_ids, long_list, long_count);
+  // longer lists: one workgroup per CU (128 KiB of LDS each) over the work list -- the grid is fixed at launch,
+  // the list length is only known on the device
+  hipLaunchKernelGGL((k_tile_sort_long<1024, 16384>), dim3(256), dim3(1024), 16384 * 8, st, M, n_tiles, tb,
+                     isect_offsets, n_isects, capacity, key_buf, flatten_ids, isect_ids, long_list, long_count);
+}
+}  // namespace so
+
 extern "C" int so_isect_count(int C, int N, const float *means2d, const int32_t *radii, int tile_size,
                               int tile_width, int tile_height, int32_t *tiles_per_gauss, int32_t *tile_counts,
                               int32_t *isect_offsets, int32_t *n_isects, const float *cull_rec, void *stream) {
@@ -524,26 +556,9 @@ extern "C" int so_isect_fill(int C, int N, const float *means2d, const int32_t *
   else if (tile_slots && slotted_lanes == 8) SO_SCATTER(8);
   else SO_SCATTER(16);
 #undef SO_SCATTER
-  const int gridM = (int)(M < 65535 * 8 ? M : 65535 * 8);
-  static bool lds_attr_set = false;  // 128 KiB of dynamic LDS needs an explicit opt-in
-  if (!lds_attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&so::k_tile_sort_long<1024, 16384>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8) != hipSuccess) {
-      (void)hipGetLastError();
-    }
-    lds_attr_set = true;
-  }
   // after the scatter the cursor array is dead: it becomes the work list of long tiles, and the
   // (caller-zeroed) element behind it is the list length
-  int32_t *long_list = tile_cursor, *long_count = tile_cursor + M;
-  // lists up to 2048 keys: 256 threads, 16 KiB LDS (4096 keys / 32 KiB costs the sparse regime 14 us of occupancy; most lists of a trained scene take the
-  // one-wave register path anyway, and in the dense init regime -- ~800 keys per tile -- this kernel does the bulk)
-  hipLaunchKernelGGL((so::k_tile_sort_lds<256, 2048>), dim3(gridM), dim3(256), 2048 * 8, st, M, n_tiles, tb,
-                     isect_offsets, n_isects, capacity, key_buf, flatten_ids, isect_ids, long_list, long_count);
-  // longer lists: one workgroup per CU (128 KiB of LDS each) over the work list -- the grid is fixed at launch,
-  // the list length is only known on the device
-  hipLaunchKernelGGL((so::k_tile_sort_long<1024, 16384>), dim3(256), dim3(1024), 16384 * 8, st, M, n_tiles, tb,
-                     isect_offsets, n_isects, capacity, key_buf, flatten_ids, isect_ids, long_list, long_count);
+  so::launch_tile_sorts(M, n_tiles, tb, isect_offsets, n_isects, capacity, key_buf, flatten_ids, isect_ids, tile_cursor, tile_cursor + M, st);
   return so::check_launch("so_isect_fill");
 }
 
@@ -570,4 +585,19 @@ extern "C" int so_isect_offset_encode(int64_t n_isects, const int64_t *isect_ids
   hipLaunchKernelGGL(so::k_isect_offset_encode, dim3(so::grid_1d((int64_t)C * n_tiles, 256)), dim3(256), 0,
                      so::as_stream(stream), n_isects, isect_ids, C, n_tiles, so::tile_bits_of(n_tiles), isect_offsets);
   return so::check_launch("so_isect_offset_encode");
+}
+
+// Binned lists (so_preprocess_fwd bin_keys): sorts every tile's min(tile_counts[t], bin_cap) keys in place and writes
+// flatten_ids[t * bin_cap + i].  long_list: int32[M + 1] scratch whose LAST element is zero on entry.
+extern "C" int so_isect_sort_bins(int C, int tile_width, int tile_height, const int32_t *tile_counts, int64_t bin_cap,
+                                  uint64_t *bin_keys, int32_t *flatten_ids, int32_t *long_list, void *stream) {
+  SO_REQUIRE(C >= 0 && tile_width > 0 && tile_height > 0 && bin_cap > 0, "so_isect_sort_bins: bad sizes");
+  if (C == 0) return SO_OK;
+  SO_REQUIRE(tile_counts && bin_keys && flatten_ids && long_list, "so_isect_sort_bins: null pointer");
+  const int n_tiles = tile_width * tile_height;
+  const int64_t M = (int64_t)C * n_tiles;
+  SO_REQUIRE(M * bin_cap < ((int64_t)1 << 31), "so_isect_sort_bins: C*tiles*bin_cap = %lld does not fit 31 bits", (long long)(M * bin_cap));
+  so::launch_tile_sorts(M, n_tiles, so::tile_bits_of(n_tiles), tile_counts, nullptr, -bin_cap, bin_keys, flatten_ids, nullptr,
+                        long_list, long_list + M, so::as_stream(stream));
+  return so::check_launch("so_isect_sort_bins");
 }

@@ -62,7 +62,8 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
                  float *__restrict__ conics, float *__restrict__ opacities, float *__restrict__ colors,
                  int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ tile_counts,
                  float4 *__restrict__ rec, float4 *__restrict__ vrec, int64_t cam_stride,
-                 int32_t *__restrict__ tile_slots, int tile_cull) {
+                 int32_t *__restrict__ tile_slots, int tile_cull, uint64_t *__restrict__ bin_keys, int64_t bin_cap,
+                 int32_t *__restrict__ bin_overflow) {
   const int64_t total = (int64_t)C * N;
   const int n_tiles = tile_w * tile_h;
   // the trip count is uniform over the workgroup: the histogram section below needs every lane of a wave
@@ -70,6 +71,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
     const int64_t lin = lin0 + threadIdx.x;
     int cnt = 0, bx0 = 0, bx1 = 0, by0 = 0, by1 = 0, c = 0;
     float cmx = 0.f, cmy = 0.f, cqa = 0.f, cqb = 0.f, cqc = 0.f, ctau = 0.f;   // what the exact tile test needs
+    float cdepth = 0.f;
     if (lin < total) {
     c = (int)(lin / N);
     const int64_t n = lin - (int64_t)c * N;
@@ -112,6 +114,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
       bx0 = x0; bx1 = x1; by0 = y0; by1 = y1;
       cmx = o.m2d[0]; cmy = o.m2d[1]; cqa = o.conic[0]; cqb = o.conic[1]; cqc = o.conic[2];
       ctau = cull_tau(op);
+      cdepth = o.depth;
     }
     colors[3 * idx] = r; colors[3 * idx + 1] = g; colors[3 * idx + 2] = b;
     tiles_per_gauss[idx] = cnt;
@@ -138,7 +141,24 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
       const bool big = cnt > kOwn;
       if (cnt > 0 && !big) {
         int32_t *row = tile_counts + (int64_t)c * n_tiles;
-        if (tile_slots) {
+        if (bin_keys) {
+          // binned lists (so_step_desc.bin_capacity): every tile owns bin_cap key slots, the returning atomic IS the
+          // slot -- the key goes straight to its place and neither a scan nor a scatter pass exists
+          const uint64_t key = ((uint64_t)__float_as_uint(cdepth) << 32) | (uint64_t)(uint32_t)lin;
+          int x = bx0, y = by0;
+#pragma unroll
+          for (int i = 0; i < kOwn; ++i) {
+            if (i < cnt) {
+              if (!tile_cull || tile_touches(cmx, cmy, cqa, cqb, cqc, ctau, x, y, tile_size)) {
+                const int64_t t = (int64_t)c * n_tiles + y * tile_w + x;
+                const int32_t s = atomicAdd(tile_counts + t, 1);
+                if (s < bin_cap) bin_keys[t * bin_cap + s] = key;
+                else *bin_overflow = 1;
+              }
+              if (++x == bx1) { x = bx0; ++y; }
+            }
+          }
+        } else if (tile_slots) {
           // the value an atomic returns IS this Gaussian's slot in that tile's list: keep it, and the scatter pass
           // (k_isect_scatter) places the key at offsets[tile] + slot without a second round of atomics.  All
           // requests are issued before the first result is consumed (one round trip, not cnt of them).
@@ -173,9 +193,20 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
         int32_t *row = tile_counts + (int64_t)__builtin_amdgcn_readlane(c, src) * n_tiles + (tile_slots ? (int64_t)C * n_tiles : 0);
         const float smx = readlane_f(cmx, src), smy = readlane_f(cmy, src), sqa = readlane_f(cqa, src),
                     sqb = readlane_f(cqb, src), sqc = readlane_f(cqc, src), stau = readlane_f(ctau, src);
+        const uint64_t skey = ((uint64_t)__float_as_uint(readlane_f(cdepth, src)) << 32) | (uint64_t)(uint32_t)(lin0 + (threadIdx.x & ~63) + src);
+        const int64_t srow = (int64_t)__builtin_amdgcn_readlane(c, src) * n_tiles;
         for (int y = sy0 + (lane >> 3); y < sy1; y += 8)
           for (int x = sx0 + (lane & 7); x < sx1; x += 8)
-            if (!tile_cull || tile_touches(smx, smy, sqa, sqb, sqc, stau, x, y, tile_size)) atomicAdd(row + y * tile_w + x, 1);
+            if (!tile_cull || tile_touches(smx, smy, sqa, sqb, sqc, stau, x, y, tile_size)) {
+              if (bin_keys) {
+                const int64_t t = srow + y * tile_w + x;
+                const int32_t s = atomicAdd(tile_counts + t, 1);
+                if (s < bin_cap) bin_keys[t * bin_cap + s] = skey;
+                else *bin_overflow = 1;
+              } else {
+                atomicAdd(row + y * tile_w + x, 1);
+              }
+            }
       }
     }
   }
@@ -389,7 +420,7 @@ static int preprocess_fwd_impl(const char *what, int C, int N, int K, int sh_deg
                                int camera_model, int antialiased, int tile_size, int32_t *radii, float *means2d,
                                float *depths, float *conics, float *opacities, float *colors, int32_t *tiles_per_gauss,
                                int32_t *tile_counts, float *rec, float *vrec, int64_t cam_stride, int32_t *tile_slots,
-                               int tile_cull, void *stream) {
+                               int tile_cull, uint64_t *bin_keys, int64_t bin_cap, int32_t *bin_overflow, void *stream) {
   SO_REQUIRE(C >= 0 && N >= 0 && K >= 1 && width > 0 && height > 0 && tile_size > 0, "%s: bad sizes", what);
   SO_REQUIRE(tile_slots == nullptr || tile_counts != nullptr, "%s: tile_slots need the histogram (tile_counts)", what);
   SO_REQUIRE(sh_degree >= 0 && sh_degree <= 4 && (sh_degree + 1) * (sh_degree + 1) <= K,
@@ -404,6 +435,9 @@ static int preprocess_fwd_impl(const char *what, int C, int N, int K, int sh_deg
   if (cam_stride == 0) cam_stride = N;
   SO_REQUIRE(cam_stride >= N, "%s: cam_stride %lld < N %d", what, (long long)cam_stride, N);
   SO_REQUIRE(tile_slots == nullptr || cam_stride == N, "%s: tile_slots need densely packed views (cam_stride == N)", what);
+  SO_REQUIRE(bin_keys == nullptr || (tile_counts && bin_overflow && bin_cap > 0 && cam_stride == N && tile_slots == nullptr &&
+                                     (int64_t)C * N < ((int64_t)1 << 31)),
+             "%s: bin_keys need tile_counts, bin_overflow, bin_cap > 0, densely packed views and no tile_slots", what);
   const int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
   const dim3 grid(pp_grid((int64_t)C * N)), block(256);
   hipStream_t st = as_stream(stream);
@@ -412,7 +446,7 @@ static int preprocess_fwd_impl(const char *what, int C, int N, int K, int sh_deg
                      Ks, width, height, eps2d, near_plane, far_plane, radius_clip, camera_model, antialiased,      \
                      (float)tile_size, tile_w, tile_h, radii, means2d, depths, conics, opacities, colors,          \
                      tiles_per_gauss, tile_counts, reinterpret_cast<float4 *>(rec), reinterpret_cast<float4 *>(vrec), \
-                     cam_stride, tile_slots, tile_cull)
+                     cam_stride, tile_slots, tile_cull, bin_keys, bin_cap, bin_overflow)
   switch (sh_degree) {
     case 0: SO_LAUNCH(0); break;
     case 1: SO_LAUNCH(1); break;
@@ -492,13 +526,14 @@ extern "C" int so_preprocess_fwd(int C, int N, int K, int sh_degree, const float
                                  int camera_model, int antialiased, int tile_size, int32_t *radii, float *means2d,
                                  float *depths, float *conics, float *opacities, float *colors,
                                  int32_t *tiles_per_gauss, int32_t *tile_counts, float *rec, float *vrec,
-                                 int64_t cam_stride, int32_t *tile_slots, int tile_cull, void *stream) {
+                                 int64_t cam_stride, int32_t *tile_slots, int tile_cull, uint64_t *bin_keys, int64_t bin_cap,
+                                 int32_t *bin_overflow, void *stream) {
   SO_REQUIRE((int64_t)C * N == 0 || (log_scales && quats && sh0 && (shN || K == 1)), "so_preprocess_fwd: null pointer");
   const so::AttrSoA attrs{log_scales, quats, sh0, shN, K};
   return so::preprocess_fwd_impl("so_preprocess_fwd", C, N, K, sh_degree, means, logit_opacities, attrs, viewmats, Ks,
                                  width, height, eps2d, near_plane, far_plane, radius_clip, camera_model, antialiased,
                                  tile_size, radii, means2d, depths, conics, opacities, colors, tiles_per_gauss,
-                                 tile_counts, rec, vrec, cam_stride, tile_slots, tile_cull, stream);
+                                 tile_counts, rec, vrec, cam_stride, tile_slots, tile_cull, bin_keys, bin_cap, bin_overflow, stream);
 }
 
 extern "C" int so_preprocess_fwd_f16(int C, int N, int K, int sh_degree, const float *means,
@@ -507,13 +542,14 @@ extern "C" int so_preprocess_fwd_f16(int C, int N, int K, int sh_degree, const f
                                      float far_plane, float radius_clip, int camera_model, int antialiased,
                                      int tile_size, int32_t *radii, float *means2d, float *depths, float *conics,
                                      float *opacities, float *colors, int32_t *tiles_per_gauss, int32_t *tile_counts,
-                                     float *rec, float *vrec, int64_t cam_stride, int32_t *tile_slots, int tile_cull, void *stream) {
+                                     float *rec, float *vrec, int64_t cam_stride, int32_t *tile_slots, int tile_cull, uint64_t *bin_keys, int64_t bin_cap,
+                                 int32_t *bin_overflow, void *stream) {
   SO_REQUIRE((int64_t)C * N == 0 || so::attr_rec_ok(arec), "so_preprocess_fwd_f16: arec must be non-null and 16-byte aligned");
   const so::AttrRec attrs{reinterpret_cast<const uint4 *>(arec), so::attr_rec_stride_bytes(K < 1 ? 1 : K) / 16};
   return so::preprocess_fwd_impl("so_preprocess_fwd_f16", C, N, K, sh_degree, means, logit_opacities, attrs, viewmats,
                                  Ks, width, height, eps2d, near_plane, far_plane, radius_clip, camera_model,
                                  antialiased, tile_size, radii, means2d, depths, conics, opacities, colors,
-                                 tiles_per_gauss, tile_counts, rec, vrec, cam_stride, tile_slots, tile_cull, stream);
+                                 tiles_per_gauss, tile_counts, rec, vrec, cam_stride, tile_slots, tile_cull, bin_keys, bin_cap, bin_overflow, stream);
 }
 
 extern "C" int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float *means, const float *log_scales,

@@ -57,13 +57,8 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
   const float qx0 = (float)(tx * TS + wx0) + 0.5f, qx1 = qx0 + 7.f;
   const float qy0 = (float)(ty * TS + wy0) + 0.5f, qy1 = qy0 + 7.f;
 
-  // device count, bounded by the host value when both are given (the capacity of flatten_ids: a list that
-  // overflowed its buffer must not be walked past the end)
-  int64_t n_isects = n_isects_dev ? (int64_t)*n_isects_dev : n_isects_host;
-  if (n_isects_dev && n_isects_host > 0 && n_isects > n_isects_host) n_isects = n_isects_host;
-  int64_t lo = offsets[ct];
-  int64_t hi = (ct == M - 1) ? n_isects : (int64_t)offsets[ct + 1];
-  if (hi > n_isects) hi = n_isects;
+  int64_t lo, hi;
+  tile_list_range(ct, M, offsets, n_isects_dev, n_isects_host, lo, hi);
   if (hi <= lo) return;  // uniform over the block
 
   const float T_final = inside ? 1.f - render_alphas[pix] : 1.f;

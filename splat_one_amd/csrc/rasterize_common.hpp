@@ -37,6 +37,28 @@ template <> struct PixelMap<8> {
   }
 };
 
+// A tile's slice of flatten_ids.  Two layouts:
+//   compact (gsplat): [offsets[t], offsets[t+1]) with the total n_isects on the device and/or the host -- the device
+//     count bounded by the host value when both are given (the capacity of flatten_ids: a list that overflowed its
+//     buffer must not be walked past the end);
+//   binned (n_dev == NULL, n_host = -cap < 0): every tile owns cap slots, [t cap, t cap + min(offsets[t], cap)), where
+//     `offsets` holds the per-tile COUNTS -- no scan, no scatter pass (so_step_desc.bin_capacity).
+__device__ __forceinline__ void tile_list_range(int64_t ct, int64_t M, const int32_t *__restrict__ offsets,
+                                                const int32_t *__restrict__ n_dev, int64_t n_host, int64_t &lo, int64_t &hi) {
+  if (!n_dev && n_host < 0) {
+    const int64_t cap = -n_host, cnt = offsets[ct];
+    lo = ct * cap;
+    hi = lo + (cnt < cap ? cnt : cap);
+    return;
+  }
+  int64_t n_isects = n_dev ? (int64_t)*n_dev : n_host;
+  if (n_dev && n_host > 0 && n_isects > n_host) n_isects = n_host;
+  lo = offsets[ct];
+  hi = (ct == M - 1) ? n_isects : (int64_t)offsets[ct + 1];
+  if (hi > n_isects) hi = n_isects;
+  if (lo > hi) lo = hi;
+}
+
 // Axis-aligned bound of {p : opac * exp(-sigma(p)) >= 1/255}, padded for float rounding.  A pixel
 // centre outside it provably fails the alpha threshold, so skipping it cannot change any result.
 // Degenerate conics (det <= 0) and opacities that can never pass are handled conservatively.

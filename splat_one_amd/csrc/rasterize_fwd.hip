@@ -62,14 +62,8 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
     return;
   }
 
-  // device count, bounded by the host value when both are given (the capacity of flatten_ids: a list that
-  // overflowed its buffer must not be walked past the end)
-  int64_t n_isects = n_isects_dev ? (int64_t)*n_isects_dev : n_isects_host;
-  if (n_isects_dev && n_isects_host > 0 && n_isects > n_isects_host) n_isects = n_isects_host;
-  int64_t lo = offsets[ct];
-  int64_t hi = (ct == M - 1) ? n_isects : (int64_t)offsets[ct + 1];
-  if (hi > n_isects) hi = n_isects;
-  if (lo > hi) lo = hi;
+  int64_t lo, hi;
+  tile_list_range(ct, M, offsets, n_isects_dev, n_isects_host, lo, hi);
 
   // Per-pixel state.  A finished pixel (outside the image, or transmittance exhausted) has T == 0, which
   // makes every later contribution vanish arithmetically -- the pass body below has no branches.  T_out

@@ -172,26 +172,41 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
   }
 #define SO_TRY(call) do { rc = (call); if (rc != SO_OK) return rc; } while (0)
 #define SO_STAGE(i, call) do { so::StageTimer _t(i, st); SO_TRY(call); } while (0)
+  // binned lists: every tile owns bin_capacity slots of key_buf / flatten_ids; the forward kernel's returning atomics
+  // place the keys, so the scan and the scatter pass do not exist (tile_counts doubles as the per-tile list length)
+  const int64_t bins = d->bin_capacity;
+  SO_REQUIRE(bins >= 0 && (bins == 0 || d->raster_impl != 1), "so_train_step_fwd_bwd: bin_capacity needs raster_impl 0");
+  SO_REQUIRE(bins == 0 || M * bins < ((int64_t)1 << 31), "so_train_step_fwd_bwd: C*tiles*bin_capacity does not fit 31 bits");
+  int32_t *slots = bins ? nullptr : d->tile_slots;
+  uint64_t *bin_keys = bins ? d->key_buf : nullptr;
   if (d->attr_rows_f16)
     SO_STAGE(0, so_preprocess_fwd_f16(C, N, K, d->sh_degree, d->means, d->logit_opacities, d->attr_rows_f16, d->viewmats, d->Ks,
                                       W, H, d->eps2d, d->near_plane, d->far_plane, d->radius_clip, d->camera_model,
                                       d->antialiased, ts, d->radii, d->means2d, d->depths, d->conics, d->opacities, d->colors,
-                                      d->tiles_per_gauss, tile_counts, d->rec, forward_only ? nullptr : d->vrec, 0, d->tile_slots, d->tile_cull, stream));
+                                      d->tiles_per_gauss, tile_counts, d->rec, forward_only ? nullptr : d->vrec, 0, slots, d->tile_cull, bin_keys, bins, overflow, stream));
   else
   SO_STAGE(0, so_preprocess_fwd(C, N, K, d->sh_degree, d->means, d->log_scales, d->quats, d->logit_opacities, d->sh0, d->shN,
                            d->viewmats, d->Ks, W, H, d->eps2d, d->near_plane, d->far_plane, d->radius_clip,
                            d->camera_model, d->antialiased, ts, d->radii, d->means2d, d->depths, d->conics,
-                           d->opacities, d->colors, d->tiles_per_gauss, tile_counts, d->rec, forward_only ? nullptr : d->vrec, 0, d->tile_slots, d->tile_cull, stream));
-  SO_STAGE(1, so_isect_scan(C, tile_w, tile_h, tile_counts, d->tile_slots ? cursor : nullptr, d->isect_offsets, n_isects, stream));
-  SO_STAGE(2, so_isect_fill(C, N, d->means2d, d->radii, d->depths, ts, tile_w, tile_h, d->isect_offsets, n_isects, cursor,
-                       d->isect_capacity, d->key_buf, d->flatten_ids, nullptr, overflow, d->tile_slots, d->tile_cull ? d->rec : nullptr, stream));
+                           d->opacities, d->colors, d->tiles_per_gauss, tile_counts, d->rec, forward_only ? nullptr : d->vrec, 0, slots, d->tile_cull, bin_keys, bins, overflow, stream));
+  if (bins) {
+    SO_STAGE(2, so_isect_sort_bins(C, tile_w, tile_h, tile_counts, bins, d->key_buf, d->flatten_ids, cursor, stream));
+  } else {
+    SO_STAGE(1, so_isect_scan(C, tile_w, tile_h, tile_counts, slots ? cursor : nullptr, d->isect_offsets, n_isects, stream));
+    SO_STAGE(2, so_isect_fill(C, N, d->means2d, d->radii, d->depths, ts, tile_w, tile_h, d->isect_offsets, n_isects, cursor,
+                         d->isect_capacity, d->key_buf, d->flatten_ids, nullptr, overflow, slots, d->tile_cull ? d->rec : nullptr, stream));
+  }
+  // list layout handed to the rasteriser: compact (offsets, device count, capacity) or binned (counts, NULL, -slots)
+  const int32_t *list_off = bins ? tile_counts : d->isect_offsets;
+  const int32_t *list_n = bins ? nullptr : n_isects;
+  const int64_t list_cap = bins ? -bins : d->isect_capacity;
   const bool wave_impl = d->raster_impl == 1 && ts == 16;
   if (wave_impl)
     SO_STAGE(3, so_rasterize_fwd_wave(C, N, W, H, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects, d->isect_capacity,
                                       d->render_colors, d->render_alphas, d->last_ids, stream));
   else
-    SO_STAGE(3, so_rasterize_fwd_packed(C, N, W, H, ts, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects,
-                                        d->isect_capacity, d->render_colors, d->render_alphas, d->last_ids, stream));
+    SO_STAGE(3, so_rasterize_fwd_packed(C, N, W, H, ts, d->rec, d->backgrounds, list_off, d->flatten_ids, list_n,
+                                        list_cap, d->render_colors, d->render_alphas, d->last_ids, stream));
   if (forward_only) return SO_OK;
   // loss = (1-l) * mean|.| + l * (1 - mean SSIM_valid)
   SO_STAGE(4, so::ssim_l1_fwd_launch(C, H, W, 3, d->render_colors, d->pixels, d->pixels_indirect, 1, d->loss_sums, d->dmaps, stream));
@@ -206,8 +221,8 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
                                       d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
                                       d->absgrad, stream));
   else
-    SO_STAGE(6, so_rasterize_bwd_packed(C, N, W, H, ts, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects,
-                                        d->isect_capacity, d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
+    SO_STAGE(6, so_rasterize_bwd_packed(C, N, W, H, ts, d->rec, d->backgrounds, list_off, d->flatten_ids, list_n,
+                                        list_cap, d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
                                         d->absgrad, stream));
   if (d->attr_rows_f16)
     SO_STAGE(7, so_preprocess_bwd_f16(C, N, K, d->sh_degree, d->means, d->logit_opacities, d->attr_rows_f16, d->viewmats, d->Ks,

@@ -37,7 +37,8 @@ class FusedEngine:
                  opacity_reg: float = 0.0, scale_reg: float = 0.0, tile_size: int = 16,
                  strategy_state: Optional[dict] = None, lr_gamma_means: float = 1.0,
                  isect_capacity: Optional[int] = None, use_graph: bool = True, raster_impl: int = 0,
-                 attr_dtype: str = "f32", tile_cull: bool = True):
+                 attr_dtype: str = "f32", tile_cull: bool = True, binned: bool = True,
+                 bin_capacity: Optional[int] = None):
         """attr_dtype="f16": quaternions, log-scales and SH coefficients are READ from float16 attribute rows
         (include/splat_one_amd.h, so_attr_pack_f16: 112 instead of 224 bytes per Gaussian at SH degree 3); the
         float32 parameters stay the masters Adam updates, and the same Adam launch refreshes the halves."""
@@ -46,6 +47,11 @@ class FusedEngine:
         # exact tile culling (include/splat_one_amd.h): tiles no pixel of which can reach alpha = 1/255 are left out
         # of the lists -- outputs unchanged, lists shorter than gsplat's
         self.tile_cull = bool(tile_cull)
+        # binned lists (so_step_desc.bin_capacity): every tile owns `bin_capacity` key slots, the forward kernel's
+        # histogram atomic places the key -- no scan, no scatter pass.  Sized from the first view (8x its fullest
+        # tile, at least 1024 slots), enlarged after an overflow like the compact buffers.
+        self.binned = bool(binned) and raster_impl != 1
+        self._bin_hint = bin_capacity
         self.splats, self.optimizers = splats, optimizers
         self.W, self.H, self.C = int(width), int(height), int(n_views)
         self.cfg = dict(sh_degree=sh_degree, camera_model=camera_model, near_plane=near_plane, far_plane=far_plane,
@@ -82,7 +88,15 @@ class FusedEngine:
         ts = self.cfg["tile_size"]
         tw, th = math.ceil(W / ts), math.ceil(H / ts)
         M = C * tw * th
-        cap = self._capacity_hint or max(1 << 20, 8 * C * N)
+        if self.binned:
+            # generous by default: the step time does not depend on the capacity (256 ... 16384 slots measured alike),
+            # only memory does -- 12 bytes per slot, bounded here to 8 GB of the 288
+            limit = min((2 ** 31 - 1) // M, int(8e9) // (12 * M))
+            self.bin_capacity = int(max(16, min(self._bin_hint or 1024, limit)))
+            cap = M * self.bin_capacity
+        else:
+            self.bin_capacity = 0
+            cap = self._capacity_hint or max(1 << 20, 8 * C * N)
         self.N, self.K, self.M, self.capacity = N, K, M, int(cap)
         f32, i32 = torch.float32, torch.int32
         e = lambda *shape, dtype=f32: torch.empty(*shape, dtype=dtype, device=dev)
@@ -111,7 +125,7 @@ class FusedEngine:
         w["zero_v_alphas"] = torch.zeros(C, H, W, device=dev)
         w["rec"], w["vrec"] = e(C * N, 16), e(C * N, 16)     # 64-byte packed records (allocator aligns to 512 B)
         # slots the binning histogram's returning atomics hand out (the scatter pass then needs no atomics)
-        w["tile_slots"] = e(C * N, _lib.SO_TILE_SLOTS, dtype=i32)
+        w["tile_slots"] = None if self.binned else e(C * N, _lib.SO_TILE_SLOTS, dtype=i32)
         # gradients: ONE flat static buffer (the data-parallel all-reduce runs on it directly, no
         # flatten copy); per-tensor views are bound to .grad so optimisers / callers see them
         pad = lambda n: (n + 63) // 64 * 64                  # 256-byte aligned segments (float4 access)
@@ -119,7 +133,8 @@ class FusedEngine:
         # one spare slot behind the gradients carries "this iteration is void" through a gradient all-reduce
         w["grads_flat"] = torch.zeros(total + 64, dtype=f32, device=dev)
         w["ovf_f32"] = w["grads_flat"][total:total + 1]
-        self._probe_capacity = self._capacity_hint is None     # measure the first view's intersection count
+        # measure the first view's intersection count (fullest tile) unless the caller fixed the size
+        self._probe_capacity = self._bin_hint is None if self.binned else self._capacity_hint is None
         w["grads"], off = {}, 0
         for k in PARAM_ORDER:
             n = self.splats[k].numel()
@@ -185,6 +200,7 @@ class FusedEngine:
         d.attr_rows_f16 = p(w["arec"]) if self.attr_dtype == "f16" else 0
         d.tile_slots = p(w["tile_slots"])
         d.tile_cull = int(self.tile_cull)
+        d.bin_capacity = self.bin_capacity
         return d
 
     def _adam_args(self):
@@ -261,8 +277,15 @@ class FusedEngine:
                 self._sched_staged = bool(schedule)
 
     # ------------------------------------------------------------------------------------------ capacity
+    def _fullest_tile(self) -> int:
+        """Largest per-tile count of the last binning pass (binned lists: the atomics count past the capacity)."""
+        return int(self.ws["counters"][:self.M].max().item())
+
     def _grow(self, needed: int) -> None:
-        self._capacity_hint = int(1.5 * needed) + 4096
+        if self.binned:                              # `needed`: Gaussians over the fullest tile
+            self._bin_hint = -(-int(2 * needed + 16) // 256) * 256
+        else:
+            self._capacity_hint = int(1.5 * needed) + 4096
         self._build_workspace()
         self._probe_capacity = False
 
@@ -270,6 +293,14 @@ class FusedEngine:
         """Forward-only pass on the staged view, read its intersection count (one sync, once per workspace)."""
         d = self._desc()
         _lib.call("so_render_forward", ctypes.byref(d), _lib.stream())
+        if self.binned:
+            mx = self._fullest_tile()
+            if 8 * mx > self.bin_capacity:           # other views / later iterations may fill a tile far more than this one
+                self._bin_hint = -(-8 * mx // 256) * 256
+                self._build_workspace()
+                self._probe_capacity = False
+                return True
+            return False
         n = int(self.ws["counters"][2 * self.M + 1].item())
         if 1.25 * n > self.capacity:
             self._grow(2 * n)
@@ -290,6 +321,8 @@ class FusedEngine:
         torch.cuda.synchronize()
         c = self.ws["counters"]
         n_last, ov_last = int(c[2 * self.M + 1].item()), int(c[2 * self.M + 2].item())
+        if self.binned:                              # what overflowed is one tile's bin: size by the fullest tile
+            n_prev = n_last = self._fullest_tile()
         if self.on_overflow == "raise":
             raise RuntimeError(f"tile-intersection buffers overflowed ({max(n_prev, n_last)} > capacity {self.capacity}); "
                                "the affected iterations were skipped on the device -- raise Config.isect_capacity")
@@ -469,5 +502,18 @@ class FusedEngine:
     def stats(self) -> dict:
         """Workload counters of the last step (synchronises)."""
         c = self.ws["counters"]
-        return {"n_isects": int(c[2 * self.M + 1].item()), "overflow": int(c[2 * self.M + 2].item()),
-                "visible": int((self.ws["radii"] > 0).sum().item())}
+        n = int(c[:self.M].clamp(max=self.bin_capacity).sum().item()) if self.binned else int(c[2 * self.M + 1].item())
+        return {"n_isects": n, "overflow": int(c[2 * self.M + 2].item()), "visible": int((self.ws["radii"] > 0).sum().item())}
+
+    def tile_lists(self):
+        """(offsets, flatten_ids) of the last step in the compact layout -- offsets[C*tiles + 1] as a Python list, ids
+        as one int32 tensor -- whichever layout the engine keeps on the device (tests, inspection; synchronises)."""
+        c, M = self.ws["counters"], self.M
+        if not self.binned:
+            n = int(c[2 * M + 1].item())
+            return self.ws["isect_offsets"].reshape(-1).cpu().tolist() + [n], self.ws["flatten_ids"][:n].clone()
+        cnt = c[:M].clamp(max=self.bin_capacity).to(torch.int64)
+        offs = [0] + torch.cumsum(cnt, 0).cpu().tolist()
+        ids = self.ws["flatten_ids"].view(M, self.bin_capacity)
+        keep = torch.arange(self.bin_capacity, device=self.device)[None, :] < cnt[:, None]
+        return offs, ids[keep]

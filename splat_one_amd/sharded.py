@@ -237,13 +237,13 @@ class ShardedEngine:
             _lib.call("so_preprocess_fwd_f16", n, N, self.K, c["sh_degree"], P("s.means"), P("s.opacities"),
                       P("w.arec"), P("w.viewmats"), P("w.Ks"), W, H, c["eps2d"], c["near_plane"], c["far_plane"],
                       c["radius_clip"], cam, int(c["antialiased"]), ts, P("w.radii"), P("w.means2d"), P("w.depths"),
-                      P("w.conics"), P("w.opacities"), P("w.colors"), P("w.tiles_per_gauss"), 0, P("w.rec_shard"), 0, cap, 0, 0, st)
+                      P("w.conics"), P("w.opacities"), P("w.colors"), P("w.tiles_per_gauss"), 0, P("w.rec_shard"), 0, cap, 0, 0, 0, 0, 0, st)
         elif N > 0:
             _lib.call("so_preprocess_fwd", n, N, self.K, c["sh_degree"], P("s.means"), P("s.scales"),
                       P("s.quats"), P("s.opacities"), P("s.sh0"), P("s.shN"), P("w.viewmats"),
                       P("w.Ks"), W, H, c["eps2d"], c["near_plane"], c["far_plane"], c["radius_clip"], cam,
                       int(c["antialiased"]), ts, P("w.radii"), P("w.means2d"), P("w.depths"), P("w.conics"),
-                      P("w.opacities"), P("w.colors"), P("w.tiles_per_gauss"), 0, P("w.rec_shard"), 0, cap, 0, 0, st)
+                      P("w.opacities"), P("w.colors"), P("w.tiles_per_gauss"), 0, P("w.rec_shard"), 0, cap, 0, 0, 0, 0, 0, st)
         all_to_all_rows(w["rec_full"], w["rec_shard"], self.group)
         _lib.call("so_rec_unpack", Nf, P("w.rec_full"), P("w.means2d_full"), P("w.radii_full"), P("w.depths_full"),
                   P("w.vrec_full"), st)

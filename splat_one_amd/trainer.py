@@ -100,6 +100,10 @@ class Config:
     # fused path: tiles no pixel of which can reach alpha >= 1/255 are left out of the per-tile lists (exact: images,
     # losses and gradients are unchanged; only the internal lists are shorter than gsplat's)
     tile_cull: bool = True
+    # fused path: per-tile lists in fixed-capacity bins (no scan / scatter pass; sized from the first view, enlarged on
+    # overflow).  False: gsplat's compact layout (one buffer of Config.isect_capacity entries)
+    binned: bool = True
+    bin_capacity: Optional[int] = None     # slots per tile; None: 8x the fullest tile of the first view, >= 1024
     shN_init_std: float = 0.0              # >0: noise instead of zeros in the higher SH bands (bench scenes)
 
     def adjust_steps(self, factor: float):
@@ -497,7 +501,9 @@ class Runner:
                 strategy_state=(self.strategy_state if isinstance(s, DefaultStrategy) else None),
                 lr_gamma_means=self.lr_gamma,
                 isect_capacity=cfg.isect_capacity, use_graph=True,
-                raster_impl=getattr(self, "raster_impl", 0), attr_dtype=cfg.attr_dtype, tile_cull=cfg.tile_cull)
+                raster_impl=getattr(self, "raster_impl", 0), attr_dtype=cfg.attr_dtype, tile_cull=cfg.tile_cull,
+                binned=(cfg.binned and self.world_size == 1),   # replicas keep the compact layout: one global
+                bin_capacity=cfg.bin_capacity)                  # slack instead of a per-tile one, and no per-rank growth
             eng.steps_done = step
             eng._step_dev[0] = step
             if self.world_size > 1:
@@ -525,7 +531,7 @@ class Runner:
                                                 generator=self._split_gen)
             if n_rel or n_new:
                 eng.rebuild()
-            self.last_info = {"radii": eng.ws["radii"], "n_isects": eng.ws["counters"][2 * eng.M + 1:2 * eng.M + 2],
+            self.last_info = {"radii": eng.ws["radii"], "engine": eng,   # eng.stats() / eng.tile_lists(): counts and lists
                               "flatten_ids": eng.ws["flatten_ids"], "means2d": eng.ws["means2d"]}
             self.step += 1
             return eng.loss()[0]
@@ -549,7 +555,7 @@ class Runner:
                 reset_opa(params=self.splats, optimizers=self.optimizers, state=self.strategy_state,
                           value=s.prune_opa * 2.0)
             eng.rebuild()
-        self.last_info = {"radii": eng.ws["radii"], "n_isects": eng.ws["counters"][2 * eng.M + 1:2 * eng.M + 2],
+        self.last_info = {"radii": eng.ws["radii"], "engine": eng,   # eng.stats() / eng.tile_lists(): counts and lists
                           "flatten_ids": eng.ws["flatten_ids"], "means2d": eng.ws["means2d"]}
         self.step += 1
         return eng.loss()[0]

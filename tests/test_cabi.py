@@ -108,12 +108,12 @@ def test_per_view_camera_models_and_f16_rows_validate_without_a_gpu():
     # a per-view code with a model id that does not exist, and more views than the code can carry: refused
     with pytest.raises(RuntimeError, match="camera_model"):
         _lib.call("so_preprocess_fwd", 2, 4, 16, 3, *([1] * 8), 16, 16, 0.3, 0.01, 1e8, 0.0, SO_CAM_PER_VIEW | (3 << 2), 0, 16,
-                  *([1] * 7), 0, 0, 0, 0, 0, 0, 0)
+                  *([1] * 7), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
     with pytest.raises(RuntimeError, match="camera_model"):
         _lib.call("so_preprocess_fwd", 16, 4, 16, 3, *([1] * 8), 16, 16, 0.3, 0.01, 1e8, 0.0, SO_CAM_PER_VIEW, 0, 16,
-                  *([1] * 7), 0, 0, 0, 0, 0, 0, 0)
+                  *([1] * 7), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
     with pytest.raises(RuntimeError, match="16-byte aligned"):
         _lib.call("so_preprocess_bwd_f16", 1, 4, 16, 3, 1, 1, 8, 1, 1, 16, 16, 0.3, 0, 0, 1, 1, 1, 0.0, 0.0, *([1] * 6), 0, 0, 64, 0, 0, 0, 0, 0)
     with pytest.raises(RuntimeError, match="tile_slots"):
         _lib.call("so_preprocess_fwd", 1, 4, 16, 3, *([1] * 8), 16, 16, 0.3, 0.01, 1e8, 0.0, 0, 0, 16,
-                  *([1] * 7), 0, 0, 0, 0, 1, 0, 0)
+                  *([1] * 7), 0, 0, 0, 0, 1, 0, 0, 0, 0, 0)

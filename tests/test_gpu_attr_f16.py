@@ -163,4 +163,4 @@ def test_f16_entry_points_reject_bad_rows(dev):
         _lib.call("so_attr_pack_f16", 1, 16, _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), z.data_ptr() + 4, _lib.stream())
     with pytest.raises(RuntimeError, match="arec"):
         _lib.call("so_preprocess_fwd_f16", 1, 1, 16, 3, _lib.ptr(z), _lib.ptr(z), 0, _lib.ptr(z), _lib.ptr(z), 16, 16,
-                  0.3, 0.01, 100.0, 0.0, 0, 0, 16, *([_lib.ptr(z)] * 7), 0, 0, 0, 0, 0, 0, _lib.stream())
+                  0.3, 0.01, 100.0, 0.0, 0, 0, 16, *([_lib.ptr(z)] * 7), 0, 0, 0, 0, 0, 0, 0, 0, 0, _lib.stream())

@@ -77,8 +77,7 @@ def test_c2_100k_1080p_both_paths(dev, regime):
     I_o = meta_o["flatten_ids"].numel()
     assert abs(info["flatten_ids"].numel() - I_o) <= max(8, 2e-4 * I_o)
     # (2) fused engine (the path bench.py times)
-    eng = FusedEngine(r.splats, r.optimizers, W, H, 1, sh_degree=3, use_graph=False,
-                      isect_capacity=int(I_o * 1.2) + 1024)
+    eng = FusedEngine(r.splats, r.optimizers, W, H, 1, sh_degree=3, use_graph=False)
     eng.set_views(c2w, Ks, pixels)
     eng.fwd_bwd()
     st = eng.stats()

@@ -136,7 +136,8 @@ def test_engine_render_forward_matches_operator_path(dev):
     assert (rc - rc2).abs().max().item() < 1e-5 and (ra - ra2).abs().max().item() < 1e-5
 
 
-def test_engine_survives_intersection_overflow(dev):
+@pytest.mark.parametrize("binned", [True, False])
+def test_engine_survives_intersection_overflow(dev, binned):
     """Buffers sized far too small: the overflowing iterations stay in bounds, change nothing (optimiser and
     statistics skip on the device), are detected one step late without a device sync, the buffers grow, and the
     run continues exactly like one that had enough room from the start, minus the void iterations."""
@@ -146,14 +147,15 @@ def test_engine_survives_intersection_overflow(dev):
     from splat_one_amd.trainer import Config, Runner
     W, H, N, steps = 160, 120, 3000, 6
 
-    def make(capacity):
+    def make(capacity):     # a total for the compact layout, turned into slots per tile for the binned one
+        per_tile = None if capacity is None else max(16, capacity // 80)
         cfg = Config(init_num_pts=N, init_scale=0.6, init_opa=0.3, shN_init_std=0.05, sh_degree_interval=1, fused=True)
         r = Runner(0, 0, 1, cfg, scene_scale=1.0 / 1.1)
         with torch.no_grad():   # anisotropic: otherwise Adam amplifies a pure-rounding quaternion gradient
             r.splats["scales"].add_((torch.randn(N, 3, generator=torch.Generator().manual_seed(7)) * 0.4).to(dev))
         st = r.strategy_state
         eng = FusedEngine(r.splats, r.optimizers, W, H, 1, sh_degree=3, strategy_state=st, lr_gamma_means=r.lr_gamma,
-                          isect_capacity=capacity, use_graph=True)
+                          isect_capacity=capacity, use_graph=True, binned=binned, bin_capacity=per_tile)
         return r, eng
     c2w = front_camera()[None].to(dev)
     Ks = pinhole_K(W, H)[None].to(dev)
@@ -186,16 +188,19 @@ def test_engine_survives_intersection_overflow(dev):
 
     # without an explicit capacity the first view is measured and the buffers sized from it: nothing is skipped
     r_auto, e_auto = make(None)
-    e_auto.capacity = 1024          # pretend the default guess was far too small
+    if binned:                      # pretend the default guess was far too small
+        e_auto.bin_capacity = 16
+    else:
+        e_auto.capacity = 1024
     for _ in range(2):
         e_auto.set_views(c2w, Ks, pixels, schedule=True)
         e_auto.step()
     torch.cuda.synchronize()
-    assert e_auto.void_steps == 0 and e_auto.capacity > 1024
+    assert e_auto.void_steps == 0 and (e_auto.bin_capacity > 16 if binned else e_auto.capacity > 1024)
 
 
-@pytest.mark.parametrize("regime,C,aa", [("ref", 1, False), ("mcmc", 2, True)])
-def test_engine_tile_cull_is_exact(dev, regime, C, aa):
+@pytest.mark.parametrize("regime,C,aa,binned", [("ref", 1, False, True), ("mcmc", 2, True, True), ("ref", 1, False, False)])
+def test_engine_tile_cull_is_exact(dev, regime, C, aa, binned):
     """Exact tile culling drops (Gaussian, tile) pairs that cannot reach alpha = 1/255 at any pixel of the tile:
     fewer intersections, the SAME image bit for bit, the same gradients up to the order of the atomic sums; the
     surviving lists are subsequences of gsplat's lists (which the engine reproduces exactly with culling off)."""
@@ -208,14 +213,16 @@ def test_engine_tile_cull_is_exact(dev, regime, C, aa):
         with torch.no_grad():                    # some Gaussians that can never reach 1/255, some barely
             r.splats["opacities"][:500] = -6.0
             r.splats["opacities"][500:1000] = -5.0
-        eng = FusedEngine(r.splats, r.optimizers, W, H, C, sh_degree=3, use_graph=False, tile_cull=cull, antialiased=aa)
+        eng = FusedEngine(r.splats, r.optimizers, W, H, C, sh_degree=3, use_graph=False, tile_cull=cull, antialiased=aa,
+                          binned=binned)
         eng.set_views(c2w, Ks, pixels)
         eng.fwd_bwd()
         st = eng.stats()
         assert st["overflow"] == 0
         M = eng.M
-        offs = eng.ws["isect_offsets"].reshape(-1).cpu().tolist() + [st["n_isects"]]
-        ids = eng.ws["flatten_ids"][:st["n_isects"]].cpu()
+        offs, ids = eng.tile_lists()
+        ids = ids.cpu()
+        assert offs[-1] == st["n_isects"] == ids.numel()
         res[cull] = dict(img=eng.ws["render_colors"].clone(), alpha=eng.ws["render_alphas"].clone(), n=st["n_isects"],
                          grads={k: v.grad.detach().clone() for k, v in r.splats.items()}, offs=offs, ids=ids,
                          loss=eng.loss().clone(), radii=eng.ws["radii"].clone())

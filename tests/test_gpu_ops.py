@@ -422,7 +422,7 @@ def test_rec_unpack_and_cam_stride(dev):
         _lib.call("so_preprocess_fwd", C, N, K, 3, p(s["means"]), p(s["scales"]), p(s["quats"]), p(s["opacities"]), p(s["sh0"]),
                   p(s["shN"]), p(vm), p(Kd), W, H, 0.3, 0.01, 1e8, 0.0, 0, 0, 16, p(o["radii"]), p(o["means2d"]), p(o["depths"]),
                   p(o["conics"]), p(o["opac"]), p(o["colors"]), p(o["tpg"]), p(o["hist"]) if hist else 0, p(o["rec"]), 0,
-                  stride, 0, 0, _lib.stream())
+                  stride, 0, 0, 0, 0, 0, _lib.stream())
         return o
     dense, strided = run(N, True), run(cap, False)
     assert dense["hist"].sum().item() == dense["tpg"].sum().item() > 0 and strided["hist"].sum().item() == 0
@@ -466,7 +466,7 @@ def test_slotted_binning_and_exact_tile_cull_c_abi(dev, cull):
     offsets, n_is, ovf = z(M, dt=torch.int32), counters[2 * M + 1:], counters[2 * M + 2:]
     _lib.call("so_preprocess_fwd", C, N, K, 3, p(s["means"]), p(s["scales"]), p(s["quats"]), p(s["opacities"]), p(s["sh0"]), p(s["shN"]),
               p(vm), p(Kd), W, H, 0.3, 0.01, 1e8, 0.0, 0, 0, ts, p(o["radii"]), p(o["means2d"]), p(o["depths"]), p(o["conics"]),
-              p(o["opac"]), p(o["colors"]), p(o["tpg"]), p(counters), p(o["rec"]), 0, 0, p(o["slots"]), cull, st)
+              p(o["opac"]), p(o["colors"]), p(o["tpg"]), p(counters), p(o["rec"]), 0, 0, p(o["slots"]), cull, 0, 0, 0, st)
     assert counters[M:2 * M].sum().item() > 0 and counters[:M].sum().item() > 0           # both kinds of rectangle occur
     _lib.call("so_isect_scan", C, tw, th, p(counters), p(counters[M:]), p(offsets), p(n_is), st)
     n = int(n_is[0].item())

@@ -21,7 +21,7 @@ def fwd():
     _lib.call("so_preprocess_fwd", 1, N, eng.K, 3, p(s["means"].data), p(s["scales"].data), p(s["quats"].data), p(s["opacities"].data),
               p(s["sh0"].data), p(s["shN"].data), p(w["viewmats"]), p(w["Ks"]), W, H, 0.3, 0.01, 1e8, 0.0, 0, 0, 16,
               p(w["radii"]), p(w["means2d"]), p(w["depths"]), p(w["conics"]), p(w["opacities"]), p(w["colors"]),
-              p(w["tiles_per_gauss"]), p(w["counters"]), p(w["rec"]), p(w["vrec"]), 0, p(w["tile_slots"]), 1, _lib.stream())
+              p(w["tiles_per_gauss"]), p(w["counters"]), p(w["rec"]), p(w["vrec"]), 0, 0, 1, p(w["key_buf"]), eng.bin_capacity, p(w["counters"][2 * eng.M + 2:]), _lib.stream())
 def bwd():
     _lib.call("so_preprocess_bwd", 1, N, eng.K, 3, p(s["means"].data), p(s["scales"].data), p(s["quats"].data), p(s["opacities"].data),
               p(s["sh0"].data), p(s["shN"].data), p(w["viewmats"]), p(w["Ks"]), W, H, 0.3, 0, 0, p(w["radii"]), p(w["opacities"]),
