@@ -498,6 +498,8 @@ static void launch_tile_sorts(int64_t M, int n_tiles, int tb, const int32_t *ise
                      isect_offsets, n_isects, capacity, key_buf, flatten_ids, isect_ids, long_list, long_count);
   // longer lists: one workgroup per CU (128 KiB of LDS each) over the work list -- the grid is fixed at launch,
   // the list length is only known on the device
+  // (binned lists whose bins hold no more than the first kernel sorts cannot have a long tile: nothing to launch)
+  if (!n_isects && capacity < 0 && -capacity <= 2048) return;
   hipLaunchKernelGGL((k_tile_sort_long<1024, 16384>), dim3(256), dim3(1024), 16384 * 8, st, M, n_tiles, tb,
                      isect_offsets, n_isects, capacity, key_buf, flatten_ids, isect_ids, long_list, long_count);
 }
