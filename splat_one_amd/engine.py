@@ -76,6 +76,7 @@ class FusedEngine:
         self._status = torch.zeros(4, dtype=torch.int32).pin_memory()
         self._seq = 0
         self._status_event: Optional[torch.cuda.Event] = None
+        self._last_launch = self._status_kind = None   # "train" | "render": what last ran on the counters
         self.on_overflow = "grow"        # "grow": void iteration, larger buffers, continue;  "raise": RuntimeError
         self.void_steps = 0              # iterations discarded because the binning pass overflowed
         self._build_workspace()
@@ -100,9 +101,13 @@ class FusedEngine:
         self.N, self.K, self.M, self.capacity = N, K, M, int(cap)
         f32, i32 = torch.float32, torch.int32
         e = lambda *shape, dtype=f32: torch.empty(*shape, dtype=dtype, device=dev)
+        old = getattr(self, "ws", None) or {}
         w = self.ws = {}
-        w["viewmats"], w["Ks"] = e(C, 4, 4), e(C, 3, 3)
-        w["pixels"] = e(C, H, W, 3)                          # landing buffer for host-resident targets only
+        # cameras and the landing buffer survive a rebuild (C, W, H are fixed for an engine): a render right after
+        # densification sees the cameras that were staged last, not uninitialised memory
+        w["viewmats"] = old["viewmats"] if "viewmats" in old else torch.eye(4, device=dev).repeat(C, 1, 1)
+        w["Ks"] = old["Ks"] if "Ks" in old else torch.eye(3, device=dev).repeat(C, 1, 1)
+        w["pixels"] = old["pixels"] if "pixels" in old else e(C, H, W, 3)   # landing buffer for host-resident targets only
         # device slot holding the address of this iteration's target image: a dataset image that is already
         # resident in HBM is read in place (so_step_desc.pixels_indirect), not copied
         w["pixels_slot"] = torch.tensor([w["pixels"].data_ptr()], dtype=torch.int64, device=dev)
@@ -256,6 +261,7 @@ class FusedEngine:
             self._pixels_ref = px                    # must stay alive and unchanged until the step has run
         publish = c2w is not None                    # a new iteration: publish what the previous one left behind
         if publish:
+            self._status_kind = self._last_launch    # ... which was a training iteration or a forward-only render
             self._seq = (self._seq + 1) & 0x3FFFFFFF
         _lib.call("so_step_inputs", self.C if c2w is not None else 0, p(c2w), p(Ks), p(w["viewmats"]), p(w["Ks"]) if c2w is not None else 0,
                   p(px), p(w["pixels_slot"]) if px is not None else 0, p(w["counters"]), 2 * self.M + 5, n_groups, lr0, gam,
@@ -323,6 +329,9 @@ class FusedEngine:
         n_last, ov_last = int(c[2 * self.M + 1].item()), int(c[2 * self.M + 2].item())
         if self.binned:                              # what overflowed is one tile's bin: size by the fullest tile
             n_prev = n_last = self._fullest_tile()
+        if self._status_kind != "train":             # a forward-only render overflowed: no iteration to take back
+            self._grow(max(n_prev, n_last))
+            return
         if self.on_overflow == "raise":
             raise RuntimeError(f"tile-intersection buffers overflowed ({max(n_prev, n_last)} > capacity {self.capacity}); "
                                "the affected iterations were skipped on the device -- raise Config.isect_capacity")
@@ -385,12 +394,14 @@ class FusedEngine:
         self._consume_staging()
         d = self._desc()
         _lib.call("so_render_forward", ctypes.byref(d), _lib.stream())
+        self._last_launch = "render"
         return self.ws["render_colors"], self.ws["render_alphas"]
 
     def fwd_bwd(self) -> None:
         """Render -> loss -> backward on the current static inputs; gradients land in `.grad`
         (data-parallel runs all-reduce `ws["grads_flat"]` between this and `optimize`).  Replayed from
         its own hipGraph when `use_graph`."""
+        self._last_launch = "train"
         if not self.use_graph:
             self._consume_staging()
             self._launch_fwd_bwd()
@@ -455,6 +466,7 @@ class FusedEngine:
     def step(self) -> None:
         """One full iteration (fwd + loss + bwd + Adam); a hipGraph replay when `use_graph`."""
         sched, self._sched_staged = self._sched_staged, False
+        self._last_launch = "train"
         if not self.use_graph:
             self._consume_staging()
             self._launch_fwd_bwd()

@@ -245,3 +245,29 @@ def test_engine_tile_cull_is_exact(dev, regime, C, aa, binned):
         kept = b["ids"][b["offs"][t]:b["offs"][t + 1]].tolist()
         it = iter(full)
         assert all(any(g == f for f in it) for g in kept), t
+
+
+def test_engine_render_after_rebuild_keeps_cameras_and_counts_no_void_step(dev):
+    """A rebuild (densification) reallocates the workspace: the staged cameras survive it, so a forward-only render
+    right after shows the same view; and a render that overflows its bins enlarges them without taking a training
+    iteration back."""
+    from splat_one_amd.engine import FusedEngine
+    N, W, H = 4000, 160, 96
+    r, c2w, Ks, pixels = _make(dev, N, W, H, "ref")
+    eng = FusedEngine(r.splats, r.optimizers, W, H, 1, sh_degree=3, lr_gamma_means=r.lr_gamma)
+    eng.set_views(c2w, Ks, pixels, schedule=True)
+    eng.step()
+    img0 = eng.render()[0].clone()
+    eng.rebuild()
+    img1 = eng.render()[0].clone()
+    assert torch.equal(img0, img1) and img0.abs().sum().item() > 0
+    # a render on bins that are far too small, then training goes on: buffers grow, nothing is rolled back
+    eng.bin_capacity = 16
+    eng.render()
+    assert eng.stats()["overflow"] == 1
+    for _ in range(3):
+        eng.set_views(c2w, Ks, pixels, schedule=True)
+        eng.step()
+    torch.cuda.synchronize()
+    assert eng.void_steps == 0 and eng.steps_done == 4 and eng.bin_capacity > 16 and eng.stats()["overflow"] == 0
+    assert float(r.optimizers["means"].state[r.splats["means"]]["step"]) == 4.0
