@@ -413,7 +413,17 @@ typedef struct so_step_desc {
    * that receives more than bin_capacity Gaussians raises the overflow flag (void iteration, as above); the caller
    * then enlarges the bins -- at 288 GB of HBM, 8160 tiles x 4096 slots x 12 B = 400 MB is not a constraint. */
   int64_t bin_capacity;
+  /* Optimiser fused into the backward (nullable): the last kernel of the step applies Adam to the six parameter
+   * tensors itself -- the 236 B/Gaussian of gradient never travel to HBM and back and so_adam_step_dev is not called.
+   * The v_* gradient outputs are then NOT written.  Single-GPU steps only (a data-parallel step needs the gradients
+   * for its all-reduce); the schedule of this step must have been evaluated by so_step_inputs (n_groups = 6). */
+  const struct so_adam_fuse *fuse_adam;
 } so_step_desc;
+typedef struct so_adam_fuse {
+  so_adam_group groups[6]; /* means, log_scales, quats, logit_opacities, sh0, shN: param / exp_avg / exp_avg_sq (grad unused) */
+  double beta1, beta2, eps;
+  int32_t *step_counter;   /* the device scratch of so_adam_step_dev */
+} so_adam_fuse;
 int so_train_step_fwd_bwd(const so_step_desc *desc, void *stream);
 /* Everything that changes from one iteration to the next, in ONE launch, so that a captured step needs
  * neither copies nor re-capture (the reference does `inv(camtoworlds)`, `.to(device)` and the scheduler

@@ -44,7 +44,13 @@ class StepDesc(ctypes.Structure):
         + [(n, c_f32) for n in ("eps2d", "near_plane", "far_plane", "radius_clip", "ssim_lambda", "opacity_reg",
                                 "scale_reg")]
         + [("pixels_indirect", c_ptr), ("inputs_staged", ctypes.c_int32), ("tile_cull", ctypes.c_int32),
-           ("overflow_flag_out", c_ptr), ("attr_rows_f16", c_ptr), ("tile_slots", c_ptr), ("bin_capacity", c_i64)])
+           ("overflow_flag_out", c_ptr), ("attr_rows_f16", c_ptr), ("tile_slots", c_ptr), ("bin_capacity", c_i64), ("fuse_adam", c_ptr)])
+
+
+class AdamFuse(ctypes.Structure):
+    """Mirror of `so_adam_fuse` (the optimiser fused into the backward kernel)."""
+    _fields_ = [("groups", AdamGroup * 6), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double),
+                ("step_counter", c_ptr)]
 
 
 class AttrShadow(ctypes.Structure):

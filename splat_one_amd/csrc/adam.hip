@@ -14,28 +14,6 @@ struct AdamGroups {
   so_adam_group g[SO_ADAM_MAX_GROUPS];
 };
 
-struct AdamHyper {
-  float omb1, b2, omb2, eps;  // (1-beta1), beta2, (1-beta2) rounded to f32 once on the host
-};
-
-__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, const AdamHyper h,
-                                         float step_size, float bc2_sqrt) {
-  const float eps = h.eps;
-  m = m + (g - m) * h.omb1;
-  v = v * h.b2 + h.omb2 * g * g;
-  const float denom = sqrtf(v) / bc2_sqrt + eps;
-  p = p - step_size * (m / denom);
-}
-
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 ld_nt(const float4 *p) {
-  floatx4 v = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(p));
-  return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ void st_nt(float4 *p, float4 a) {
-  floatx4 v = {a.x, a.y, a.z, a.w};
-  __builtin_nontemporal_store(v, reinterpret_cast<floatx4 *>(p));
-}
 __global__ void __launch_bounds__(256)
 k_adam(AdamGroups groups, AdamHyper h, int zero_grad) {
   const so_adam_group G = groups.g[blockIdx.y];

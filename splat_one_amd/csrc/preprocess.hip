@@ -214,7 +214,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
 
 // (One wave per SIMD: 256 VGPRs + AGPRs.  Forcing two with __launch_bounds__(256, 2) spills 49 registers
 // and measured slower, 23.1 vs 20.5 us at 100k Gaussians.)
-template <int DEG, class A, bool STAGE>
+template <int DEG, class A, bool STAGE, bool ADAM>
 __global__ void __launch_bounds__(256)
 k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const float *__restrict__ logit_opac,
                  const A attrs, const float *__restrict__ viewmats,
@@ -228,8 +228,9 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
                  float *__restrict__ v_logit_opac, float *__restrict__ v_sh0, float *__restrict__ v_shN,
                  float *__restrict__ grad2d, float *__restrict__ count, float stat_sx, float stat_sy,
                  const float4 *__restrict__ vrec, int use_abs_stats, int64_t cam_stride,
-                 const int32_t *__restrict__ skip_flag, float *__restrict__ skip_out) {
+                 const int32_t *__restrict__ skip_flag, float *__restrict__ skip_out, const AdamFuse af) {
   constexpr int NB = (DEG + 1) * (DEG + 1);
+  static_assert(!ADAM || STAGE, "the fused optimiser works on the staged shN rows");
   // skip_flag (nullable): the binning pass overflowed its buffers -> this iteration is void: leave gradients and
   // densification statistics alone (the optimiser step skips too); skip_out (nullable) publishes the flag as a
   // float that a gradient all-reduce can sum across ranks
@@ -326,15 +327,37 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
         cn += 1.f;
       }
     }
-    v_means[3 * n] = vm[0]; v_means[3 * n + 1] = vm[1]; v_means[3 * n + 2] = vm[2];
-    *reinterpret_cast<float4 *>(v_quats + 4 * n) = make_float4(vq[0], vq[1], vq[2], vq[3]);
     // d/d log s = s * d/ds ; scale regulariser: scale_reg * mean|exp(s)| over 3N entries
     const float sreg = scale_reg / (3.f * (float)N);
-    v_log_scales[3 * n] = (vs[0] + sreg) * s[0];
-    v_log_scales[3 * n + 1] = (vs[1] + sreg) * s[1];
-    v_log_scales[3 * n + 2] = (vs[2] + sreg) * s[2];
-    v_logit_opac[n] = (v_sig + opacity_reg / (float)N) * sig * (1.f - sig);
-    v_sh0[3 * n] = acc[0][0]; v_sh0[3 * n + 1] = acc[0][1]; v_sh0[3 * n + 2] = acc[0][2];
+    const float gs[3] = {(vs[0] + sreg) * s[0], (vs[1] + sreg) * s[1], (vs[2] + sreg) * s[2]};
+    const float go = (v_sig + opacity_reg / (float)N) * sig * (1.f - sig);
+    if (ADAM) {
+      // Fused optimiser (so_step_desc.fuse_adam): the gradient of this Gaussian is in registers (and, for shN, in
+      // its LDS row) -- apply Adam here instead of writing 236 B of gradient for the Adam kernel to read back.
+      // Same arithmetic as adam.hip (adam_one); hyper[g] = (step size, sqrt(bias correction 2)) of group g.
+      auto upd = [&](int grp, int64_t at, int len, const float *grad) {
+        const float2 hy = af.hyper[grp];
+        float *P = af.p[grp] + at, *Mo = af.m[grp] + at, *Vo = af.v[grp] + at;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < len) {
+            float pj = P[j], mj = Mo[j], vj = Vo[j];
+            adam_one(pj, grad[j], mj, vj, af.h, hy.x, hy.y);
+            P[j] = pj; Mo[j] = mj; Vo[j] = vj;
+          }
+      };
+      upd(0, 3 * n, 3, vm);
+      upd(1, 3 * n, 3, gs);
+      upd(2, 4 * n, 4, vq);
+      upd(3, n, 1, &go);
+      upd(4, 3 * n, 3, acc[0]);
+    } else {
+      v_means[3 * n] = vm[0]; v_means[3 * n + 1] = vm[1]; v_means[3 * n + 2] = vm[2];
+      *reinterpret_cast<float4 *>(v_quats + 4 * n) = make_float4(vq[0], vq[1], vq[2], vq[3]);
+      v_log_scales[3 * n] = gs[0]; v_log_scales[3 * n + 1] = gs[1]; v_log_scales[3 * n + 2] = gs[2];
+      v_logit_opac[n] = go;
+      v_sh0[3 * n] = acc[0][0]; v_sh0[3 * n + 1] = acc[0][1]; v_sh0[3 * n + 2] = acc[0][2];
+    }
     if (grad2d) { grad2d[n] += g2; count[n] += cn; }
     if (!STAGE) {
       float *o = v_shN + n * (int64_t)R;
@@ -356,10 +379,30 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
       const int64_t rows = N - w0 < 64 ? N - w0 : 64;
       if (rows > 0) {
         const int total = (int)rows * R;
-        float4 *dst4 = reinterpret_cast<float4 *>(v_shN + w0 * R);
         const float4 *src4 = reinterpret_cast<const float4 *>(mine);
-        for (int i = lane; i < total / 4; i += 64) dst4[i] = src4[i];
-        for (int i = (total & ~3) + lane; i < total; i += 64) v_shN[w0 * R + i] = mine[i];
+        if (ADAM) {   // the wave's 64 rows of shN, its moments and (in LDS) its gradient: one coalesced sweep
+          const float2 hy = af.hyper[5];
+          float4 *p4 = reinterpret_cast<float4 *>(af.p[5] + w0 * R), *m4 = reinterpret_cast<float4 *>(af.m[5] + w0 * R),
+                 *v4 = reinterpret_cast<float4 *>(af.v[5] + w0 * R);
+          for (int i = lane; i < total / 4; i += 64) {
+            float4 pp = p4[i], mm = ld_nt(m4 + i), vv = ld_nt(v4 + i);
+            const float4 g = src4[i];
+            adam_one(pp.x, g.x, mm.x, vv.x, af.h, hy.x, hy.y);
+            adam_one(pp.y, g.y, mm.y, vv.y, af.h, hy.x, hy.y);
+            adam_one(pp.z, g.z, mm.z, vv.z, af.h, hy.x, hy.y);
+            adam_one(pp.w, g.w, mm.w, vv.w, af.h, hy.x, hy.y);
+            p4[i] = pp; st_nt(m4 + i, mm); st_nt(v4 + i, vv);
+          }
+          for (int i = (total & ~3) + lane; i < total; i += 64) {
+            float pj = af.p[5][w0 * R + i], mj = af.m[5][w0 * R + i], vj = af.v[5][w0 * R + i];
+            adam_one(pj, mine[i], mj, vj, af.h, hy.x, hy.y);
+            af.p[5][w0 * R + i] = pj; af.m[5][w0 * R + i] = mj; af.v[5][w0 * R + i] = vj;
+          }
+        } else {
+          float4 *dst4 = reinterpret_cast<float4 *>(v_shN + w0 * R);
+          for (int i = lane; i < total / 4; i += 64) dst4[i] = src4[i];
+          for (int i = (total & ~3) + lane; i < total; i += 64) v_shN[w0 * R + i] = mine[i];
+        }
       }
       __syncthreads();
     }
@@ -468,7 +511,7 @@ static int preprocess_bwd_impl(const char *what, int C, int N, int K, int sh_deg
                                float opacity_reg, float scale_reg, float *v_means, float *v_log_scales, float *v_quats,
                                float *v_logit_opacities, float *v_sh0, float *v_shN, float *grad2d, float *count,
                                const float *vrec, int absgrad_stats, int64_t cam_stride, const int32_t *skip_flag,
-                               float *skip_out, void *stream) {
+                               float *skip_out, void *stream, const AdamFuse *fuse = nullptr) {
   SO_REQUIRE(C >= 0 && N >= 0 && K >= 1 && width > 0 && height > 0, "%s: bad sizes", what);
   SO_REQUIRE(sh_degree >= 0 && sh_degree <= 4 && (sh_degree + 1) * (sh_degree + 1) <= K,
              "%s: sh_degree %d does not fit K=%d", what, sh_degree, K);
@@ -491,19 +534,34 @@ static int preprocess_bwd_impl(const char *what, int C, int N, int K, int sh_deg
   // v_shN rows go through LDS when a workgroup's 256 rows fit the default 64 KB (K <= 22) and the run is 16-byte aligned
   const size_t stage_bytes = (size_t)256 * 3 * (K - 1) * sizeof(float);
   const bool stage = K > 1 && stage_bytes <= 64 * 1024 && (((uintptr_t)v_shN) & 15) == 0;
+  if (fuse) {   // the fused optimiser sweeps the staged rows: same conditions, on the parameter / moment tensors
+    SO_REQUIRE(K > 1 && stage_bytes <= 64 * 1024 && cam_stride == N, "%s: fused Adam needs 2 <= K <= 22 and densely packed views", what);
+    uintptr_t bits = 0;
+    for (int g = 0; g < 6; ++g) {
+      SO_REQUIRE(fuse->p[g] && fuse->m[g] && fuse->v[g], "%s: fused Adam: null parameter / moment pointer (group %d)", what, g);
+      bits |= (uintptr_t)fuse->p[g] | (uintptr_t)fuse->m[g] | (uintptr_t)fuse->v[g];
+    }
+    SO_REQUIRE((bits & 15) == 0 && fuse->hyper, "%s: fused Adam: tensors must be 16-byte aligned, hyper non-null", what);
+  }
 #define SO_LAUNCH(D)                                                                                              \
-  if (stage)                                                                                                      \
-    hipLaunchKernelGGL((k_preprocess_bwd<D, A, true>), grid, block, stage_bytes, st, C, N, K, means, logit_opacities, attrs, \
+  if (fuse)                                                                                                       \
+    hipLaunchKernelGGL((k_preprocess_bwd<D, A, true, true>), grid, block, stage_bytes, st, C, N, K, means, logit_opacities, attrs, \
                      viewmats, Ks, width, height, eps2d, camera_model, antialiased, radii, opacities, colors,     \
                      v_means2d, v_means2d_abs, v_depths, v_conics, v_colors, v_opacities, opacity_reg, scale_reg, \
                      v_means, v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN, grad2d, count, sx, sy,      \
-                     reinterpret_cast<const float4 *>(vrec), absgrad_stats, cam_stride, skip_flag, skip_out);     \
+                     reinterpret_cast<const float4 *>(vrec), absgrad_stats, cam_stride, skip_flag, skip_out, *fuse); \
+  else if (stage)                                                                                                 \
+    hipLaunchKernelGGL((k_preprocess_bwd<D, A, true, false>), grid, block, stage_bytes, st, C, N, K, means, logit_opacities, attrs, \
+                     viewmats, Ks, width, height, eps2d, camera_model, antialiased, radii, opacities, colors,     \
+                     v_means2d, v_means2d_abs, v_depths, v_conics, v_colors, v_opacities, opacity_reg, scale_reg, \
+                     v_means, v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN, grad2d, count, sx, sy,      \
+                     reinterpret_cast<const float4 *>(vrec), absgrad_stats, cam_stride, skip_flag, skip_out, AdamFuse{}); \
   else                                                                                                            \
-  hipLaunchKernelGGL((k_preprocess_bwd<D, A, false>), grid, block, 0, st, C, N, K, means, logit_opacities, attrs, \
+  hipLaunchKernelGGL((k_preprocess_bwd<D, A, false, false>), grid, block, 0, st, C, N, K, means, logit_opacities, attrs, \
                      viewmats, Ks, width, height, eps2d, camera_model, antialiased, radii, opacities, colors,     \
                      v_means2d, v_means2d_abs, v_depths, v_conics, v_colors, v_opacities, opacity_reg, scale_reg, \
                      v_means, v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN, grad2d, count, sx, sy,      \
-                     reinterpret_cast<const float4 *>(vrec), absgrad_stats, cam_stride, skip_flag, skip_out)
+                     reinterpret_cast<const float4 *>(vrec), absgrad_stats, cam_stride, skip_flag, skip_out, AdamFuse{})
   switch (sh_degree) {
     case 0: SO_LAUNCH(0); break;
     case 1: SO_LAUNCH(1); break;
@@ -589,6 +647,23 @@ extern "C" int so_preprocess_bwd_f16(int C, int N, int K, int sh_degree, const f
                                  v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN, grad2d, count, vrec,
                                  absgrad_stats, cam_stride, skip_flag, skip_out, stream);
 }
+
+// internal (step.hip): the float32-attribute backward with the optimiser fused in
+namespace so {
+int preprocess_bwd_fused_adam(int C, int N, int K, int sh_degree, const float *means, const float *log_scales, const float *quats,
+                              const float *logit_opacities, const float *sh0, const float *shN, const float *viewmats,
+                              const float *Ks, int width, int height, float eps2d, int camera_model, int antialiased,
+                              const int32_t *radii, const float *opacities, const float *colors, float opacity_reg,
+                              float scale_reg, float *grad2d, float *count, const float *vrec, int absgrad_stats,
+                              const int32_t *skip_flag, float *skip_out, const AdamFuse &fuse, void *stream) {
+  const AttrSoA attrs{log_scales, quats, sh0, shN, K};
+  float *dummy = fuse.p[0];   // the gradient outputs are not written in this mode; any non-null pointer passes the checks
+  return preprocess_bwd_impl("so_train_step_fwd_bwd (fused Adam)", C, N, K, sh_degree, means, logit_opacities, attrs, viewmats, Ks,
+                             width, height, eps2d, camera_model, antialiased, radii, opacities, colors, nullptr, nullptr,
+                             nullptr, nullptr, nullptr, nullptr, opacity_reg, scale_reg, dummy, dummy, dummy, dummy, dummy,
+                             fuse.p[5], grad2d, count, vrec, absgrad_stats, 0, skip_flag, skip_out, stream, &fuse);
+}
+}  // namespace so
 
 extern "C" int64_t so_attr_rec_stride(int K) { return K >= 1 ? so::attr_rec_stride_bytes(K) : 0; }
 

@@ -186,6 +186,39 @@ __device__ __forceinline__ void adam_schedule_block(const float *lr0, const floa
   if (threadIdx.x == 0) *step_ptr = step + 1;
 }
 
+// ---- Adam arithmetic shared by adam.hip and the fused tail of k_preprocess_bwd (identical rounding in both)
+struct AdamHyper {
+  float omb1, b2, omb2, eps;  // (1-beta1), beta2, (1-beta2) rounded to f32 once on the host
+};
+
+__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, const AdamHyper h,
+                                         float step_size, float bc2_sqrt) {
+  const float eps = h.eps;
+  m = m + (g - m) * h.omb1;
+  v = v * h.b2 + h.omb2 * g * g;
+  const float denom = sqrtf(v) / bc2_sqrt + eps;
+  p = p - step_size * (m / denom);
+}
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_nt(const float4 *p) {
+  floatx4 v = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st_nt(float4 *p, float4 a) {
+  floatx4 v = {a.x, a.y, a.z, a.w};
+  __builtin_nontemporal_store(v, reinterpret_cast<floatx4 *>(p));
+}
+
+// What k_preprocess_bwd needs to apply the optimiser itself (so_step_desc.fuse_adam): the six parameter tensors of
+// the 3DGS model in the order means, log-scales, quats, opacity logits, sh0, shN with their moments, the per-group
+// (step size, sqrt(bias correction 2)) evaluated by so_step_inputs, and the rounded betas / eps.
+struct AdamFuse {
+  float *p[6], *m[6], *v[6];
+  const float2 *hyper;
+  AdamHyper h;
+};
+
 __device__ __forceinline__ int lane_id() {
 #if defined(__HIP_DEVICE_COMPILE__)
   return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));

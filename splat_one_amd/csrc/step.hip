@@ -51,6 +51,13 @@ int ssim_l1_bwd_launch(int B, int H, int W, int CH, const float *img1, const flo
                        const float *dmaps, float w_l1, float w_ssim, const float *v_loss, float *v_img1, const float *sums,
                        float *loss_out, int padding_valid, float loss_const, void *stream);
 
+int preprocess_bwd_fused_adam(int C, int N, int K, int sh_degree, const float *means, const float *log_scales, const float *quats,
+                              const float *logit_opacities, const float *sh0, const float *shN, const float *viewmats,
+                              const float *Ks, int width, int height, float eps2d, int camera_model, int antialiased,
+                              const int32_t *radii, const float *opacities, const float *colors, float opacity_reg,
+                              float scale_reg, float *grad2d, float *count, const float *vrec, int absgrad_stats,
+                              const int32_t *skip_flag, float *skip_out, const AdamFuse &fuse, void *stream);
+
 // Per-iteration inputs in one launch (see so_step_inputs in the header).  Workgroup 0 does the small serial
 // pieces (one lane per camera / per Ks entry / per Adam group); every workgroup zeroes its share of the counters.
 __global__ void __launch_bounds__(256)
@@ -224,7 +231,22 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
     SO_STAGE(6, so_rasterize_bwd_packed(C, N, W, H, ts, d->rec, d->backgrounds, list_off, d->flatten_ids, list_n,
                                         list_cap, d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
                                         d->absgrad, stream));
-  if (d->attr_rows_f16)
+  if (d->fuse_adam) {
+    // the optimiser runs inside the backward kernel (gradients never reach HBM); its schedule for this step was
+    // evaluated by so_step_inputs into the scratch behind the step counter
+    const so_adam_fuse *f = d->fuse_adam;
+    SO_REQUIRE(!d->attr_rows_f16 && f->step_counter, "so_train_step_fwd_bwd: fuse_adam needs float32 attributes and the step counter");
+    so::AdamFuse F{};
+    for (int g = 0; g < 6; ++g) { F.p[g] = f->groups[g].param; F.m[g] = f->groups[g].exp_avg; F.v[g] = f->groups[g].exp_avg_sq; }
+    SO_REQUIRE(F.p[0] == d->means && F.p[1] == d->log_scales && F.p[2] == d->quats && F.p[3] == d->logit_opacities &&
+                   F.p[4] == d->sh0 && F.p[5] == d->shN, "so_train_step_fwd_bwd: fuse_adam groups must be the descriptor's six parameter tensors, in order");
+    F.hyper = reinterpret_cast<const float2 *>(f->step_counter + 2);
+    F.h = so::AdamHyper{(float)(1.0 - f->beta1), (float)f->beta2, (float)(1.0 - f->beta2), (float)f->eps};
+    SO_STAGE(7, so::preprocess_bwd_fused_adam(C, N, K, d->sh_degree, d->means, d->log_scales, d->quats, d->logit_opacities, d->sh0,
+                                              d->shN, d->viewmats, d->Ks, W, H, d->eps2d, d->camera_model, d->antialiased, d->radii,
+                                              d->opacities, d->colors, d->opacity_reg, d->scale_reg, d->grad2d, d->count, d->vrec,
+                                              d->absgrad, overflow, d->overflow_flag_out, F, stream));
+  } else if (d->attr_rows_f16)
     SO_STAGE(7, so_preprocess_bwd_f16(C, N, K, d->sh_degree, d->means, d->logit_opacities, d->attr_rows_f16, d->viewmats, d->Ks,
                                       W, H, d->eps2d, d->camera_model, d->antialiased, d->radii, d->opacities, d->colors,
                                       d->opacity_reg, d->scale_reg, d->v_means, d->v_log_scales, d->v_quats,

@@ -38,7 +38,7 @@ class FusedEngine:
                  strategy_state: Optional[dict] = None, lr_gamma_means: float = 1.0,
                  isect_capacity: Optional[int] = None, use_graph: bool = True, raster_impl: int = 0,
                  attr_dtype: str = "f32", tile_cull: bool = True, binned: bool = True,
-                 bin_capacity: Optional[int] = None):
+                 bin_capacity: Optional[int] = None, fuse_adam: bool = True):
         """attr_dtype="f16": quaternions, log-scales and SH coefficients are READ from float16 attribute rows
         (include/splat_one_amd.h, so_attr_pack_f16: 112 instead of 224 bytes per Gaussian at SH degree 3); the
         float32 parameters stay the masters Adam updates, and the same Adam launch refreshes the halves."""
@@ -50,6 +50,9 @@ class FusedEngine:
         # binned lists (so_step_desc.bin_capacity): every tile owns `bin_capacity` key slots, the forward kernel's
         # histogram atomic places the key -- no scan, no scatter pass.  Sized from the first view (8x its fullest
         # tile, at least 1024 slots), enlarged after an overflow like the compact buffers.
+        # step(): Adam runs inside the backward kernel (so_step_desc.fuse_adam) -- the gradients of a single-GPU step
+        # never reach HBM.  fwd_bwd() + optimize() (data-parallel steps, gradient inspection) keep the two kernels.
+        self.fuse_adam = bool(fuse_adam) and attr_dtype == "f32"
         self.binned = bool(binned) and raster_impl != 1
         self._bin_hint = bin_capacity
         self.splats, self.optimizers = splats, optimizers
@@ -358,8 +361,20 @@ class FusedEngine:
         assert pixels.shape == (self.C, self.H, self.W, 3), pixels.shape
         self._stage(camtoworlds, Ks, pixels, schedule)
 
-    def _launch_fwd_bwd(self) -> None:
+    def _fusable(self, sched: bool) -> bool:
+        """The fused optimiser needs this step's schedule staged (set_views(schedule=True)), SH coefficients beyond
+        degree 0 (its sweep works on the staged shN rows) and rows that fit the 64 KB stage."""
+        return self.fuse_adam and sched and 2 <= self.K <= 22
+
+    def _launch_fwd_bwd(self, fused_adam: bool = False) -> None:
         d = self._desc()
+        if fused_adam:
+            n, arr, _lr0, _gam, betas, eps = self._adam_args()
+            f = self._fuse_struct = _lib.AdamFuse()           # must outlive the call only (copied into the launch)
+            for i in range(6):
+                f.groups[i] = arr[i]
+            f.beta1, f.beta2, f.eps, f.step_counter = float(betas[0]), float(betas[1]), float(eps), _lib.ptr(self._step_dev)
+            d.fuse_adam = ctypes.addressof(f)
         _lib.call("so_train_step_fwd_bwd", ctypes.byref(d), _lib.stream())
 
     def _launch_optimize(self, schedule_done: bool = False) -> None:
@@ -469,8 +484,11 @@ class FusedEngine:
         self._last_launch = "train"
         if not self.use_graph:
             self._consume_staging()
-            self._launch_fwd_bwd()
-            self._launch_optimize(sched)
+            if self._fusable(sched):
+                self._launch_fwd_bwd(fused_adam=True)
+            else:
+                self._launch_fwd_bwd()
+                self._launch_optimize(sched)
         else:
             key = (self.N, self.cfg["sh_degree"], id(self.ws))
             if self._graph is None or self._graph_key != key:
@@ -491,8 +509,11 @@ class FusedEngine:
         for sched in (False, True):      # Adam with its own schedule launch / with the schedule staged by set_views
             graphs[sched] = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graphs[sched]):
-                self._launch_fwd_bwd()
-                self._launch_optimize(sched)
+                if self._fusable(sched):
+                    self._launch_fwd_bwd(fused_adam=True)
+                else:
+                    self._launch_fwd_bwd()
+                    self._launch_optimize(sched)
         self._graph, self._graph_key = graphs, key
 
     # ---------------------------------------------------------------------------------------------

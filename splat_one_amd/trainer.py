@@ -103,6 +103,7 @@ class Config:
     # fused path: per-tile lists in fixed-capacity bins (no scan / scatter pass; sized from the first view, enlarged on
     # overflow).  False: gsplat's compact layout (one buffer of Config.isect_capacity entries)
     binned: bool = True
+    fuse_adam: bool = True                 # single-GPU fused step: Adam inside the backward kernel (no gradient round trip)
     bin_capacity: Optional[int] = None     # slots per tile; None: 8x the fullest tile of the first view, >= 1024
     shN_init_std: float = 0.0              # >0: noise instead of zeros in the higher SH bands (bench scenes)
 
@@ -503,7 +504,8 @@ class Runner:
                 isect_capacity=cfg.isect_capacity, use_graph=True,
                 raster_impl=getattr(self, "raster_impl", 0), attr_dtype=cfg.attr_dtype, tile_cull=cfg.tile_cull,
                 binned=(cfg.binned and self.world_size == 1),   # replicas keep the compact layout: one global
-                bin_capacity=cfg.bin_capacity)                  # slack instead of a per-tile one, and no per-rank growth
+                bin_capacity=cfg.bin_capacity,                  # slack instead of a per-tile one, and no per-rank growth
+                fuse_adam=cfg.fuse_adam)
             eng.steps_done = step
             eng._step_dev[0] = step
             if self.world_size > 1:
