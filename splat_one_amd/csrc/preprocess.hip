@@ -384,7 +384,7 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
           const float2 hy = af.hyper[5];
           float4 *p4 = reinterpret_cast<float4 *>(af.p[5] + w0 * R), *m4 = reinterpret_cast<float4 *>(af.m[5] + w0 * R),
                  *v4 = reinterpret_cast<float4 *>(af.v[5] + w0 * R);
-          for (int i = lane; i < total / 4; i += 64) {
+          for (int i = lane; i < total / 4; i += 64) {   // (unrolling by 4 measured slower: 50 -> 52 us)
             float4 pp = p4[i], mm = ld_nt(m4 + i), vv = ld_nt(v4 + i);
             const float4 g = src4[i];
             adam_one(pp.x, g.x, mm.x, vv.x, af.h, hy.x, hy.y);
