@@ -365,6 +365,52 @@ k_tile_sort_lds(int64_t M, int n_tiles, int tile_bits, const int32_t *__restrict
   }
 }
 
+// The same with one tile per WAVE (sparse scenes: nearly every list fits the register sort, so no wave idles) -- 
+// LDS sort for lists with L <= CAP (CAP keys of 8 B in LDS); longer lists are appended to the
+// work list (long_list[0..*long_count)) for k_tile_sort_long.
+template <int THREADS, int CAP>
+__global__ void __launch_bounds__(THREADS)
+k_tile_sort_waves(int64_t M, int n_tiles, int tile_bits, const int32_t *__restrict__ offsets,
+                const int32_t *__restrict__ n_isects, int64_t capacity, const uint64_t *__restrict__ key_buf,
+                int32_t *__restrict__ flatten_ids, int64_t *__restrict__ isect_ids, int32_t *__restrict__ long_list,
+                int32_t *__restrict__ long_count) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
+  constexpr int WAVES = THREADS / 64;
+  __shared__ int s_mid[WAVES];   // tiles of this group that need the whole workgroup (256 < L <= CAP), -1 = none
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // A workgroup takes WAVES consecutive tiles at a time: every wave sorts its own tile in registers (the common case:
+  // no LDS array, no barrier, no idle wave), then the workgroup does the few medium lists of the group together.
+  for (int64_t base = (int64_t)blockIdx.x * WAVES; base < M; base += (int64_t)gridDim.x * WAVES) {
+    const int64_t t = base + wave;
+    int64_t lo = 0, hi = 0;
+    if (t < M) tile_range(t, M, offsets, n_isects, capacity, lo, hi);
+    const int64_t L = hi - lo;
+    if (lane == 0) s_mid[wave] = (L > 256 && L <= CAP) ? 1 : 0;
+    if (L > CAP) {
+      if (lane == 0) long_list[atomicAdd(long_count, 1)] = (int32_t)t;
+    } else if (L > 0 && L <= 256) {
+      if (L <= 64) wave_sort_list<1>(key_buf, lo, (int)L, lane, t, n_tiles, tile_bits, flatten_ids, isect_ids);
+      else if (L <= 128) wave_sort_list<2>(key_buf, lo, (int)L, lane, t, n_tiles, tile_bits, flatten_ids, isect_ids);
+      else wave_sort_list<4>(key_buf, lo, (int)L, lane, t, n_tiles, tile_bits, flatten_ids, isect_ids);   // (8 keys per lane,
+                                                  // 512-key lists, measured no faster than the LDS network)
+    }
+    __syncthreads();
+    for (int w = 0; w < WAVES; ++w) {
+      if (!s_mid[w]) continue;                    // uniform over the workgroup
+      const int64_t tm = base + w;
+      int64_t mlo, mhi;
+      tile_range(tm, M, offsets, n_isects, capacity, mlo, mhi);
+      const int64_t ML = mhi - mlo;
+      for (int i = threadIdx.x; i < ML; i += THREADS) s_keys[i] = key_buf[mlo + i];
+      __syncthreads();
+      bitonic_sort_shared<THREADS>(s_keys, (int)ML);
+      for (int i = threadIdx.x; i < ML; i += THREADS) write_sorted(s_keys[i], mlo + i, tm, n_tiles, tile_bits, flatten_ids, isect_ids);
+      __syncthreads();
+    }
+    __syncthreads();                              // s_mid is rewritten by the next group
+  }
+}
+
 // Long lists (work list built by k_tile_sort_lds): a small fixed grid walks the list, so the launch
 // costs nothing when no tile is long.  <= CAP keys: the same network in 128 KiB of LDS; longer
 // (pathological: > 16384 Gaussians over one tile): the network runs on the global key buffer.
@@ -484,6 +530,13 @@ static void launch_tile_sorts(int64_t M, int n_tiles, int tb, const int32_t *ise
                               int64_t capacity, uint64_t *key_buf, int32_t *flatten_ids, int64_t *isect_ids,
                               int32_t *long_list, int32_t *long_count, hipStream_t st) {
   const int gridM = (int)(M < 65535 * 8 ? M : 65535 * 8);
+  // sparse scenes (few slots per tile on average): one tile per wave; dense ones (most lists 257..2048 keys): one tile
+  // per workgroup -- measured 14.7 -> 11.7 us on c2 and 137 -> 176 us on the dense init regime with the former
+  // (all the host knows is the capacity: bins hold ~8x the fullest tile, a compact buffer ~1-2x the total)
+  const bool binned = !n_isects && capacity < 0;
+  const bool per_wave = binned ? -capacity <= 4096 : (M > 0 && capacity / M <= 192);
+  const int64_t groups = (M + 3) / 4;
+  const int gridW = (int)(groups < 65535 * 8 ? groups : 65535 * 8);
   static bool lds_attr_set = false;  // 128 KiB of dynamic LDS needs an explicit opt-in
   if (!lds_attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sort_long<1024, 16384>),
@@ -494,8 +547,12 @@ static void launch_tile_sorts(int64_t M, int n_tiles, int tb, const int32_t *ise
   }
   // lists up to 2048 keys: 256 threads, 16 KiB LDS (4096 keys / 32 KiB costs the sparse regime 14 us of occupancy; most lists of a trained scene take the
   // one-wave register path anyway, and in the dense init regime -- ~800 keys per tile -- this kernel does the bulk)
-  hipLaunchKernelGGL((k_tile_sort_lds<256, 2048>), dim3(gridM), dim3(256), 2048 * 8, st, M, n_tiles, tb,
-                     isect_offsets, n_isects, capacity, key_buf, flatten_ids, isect_ids, long_list, long_count);
+  if (per_wave)
+    hipLaunchKernelGGL((k_tile_sort_waves<256, 2048>), dim3(gridW), dim3(256), 2048 * 8, st, M, n_tiles, tb,
+                       isect_offsets, n_isects, capacity, key_buf, flatten_ids, isect_ids, long_list, long_count);
+  else
+    hipLaunchKernelGGL((k_tile_sort_lds<256, 2048>), dim3(gridM), dim3(256), 2048 * 8, st, M, n_tiles, tb,
+                       isect_offsets, n_isects, capacity, key_buf, flatten_ids, isect_ids, long_list, long_count);
   // longer lists: one workgroup per CU (128 KiB of LDS each) over the work list -- the grid is fixed at launch,
   // the list length is only known on the device
   // (binned lists whose bins hold no more than the first kernel sorts cannot have a long tile: nothing to launch)
