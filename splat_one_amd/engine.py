@@ -97,6 +97,7 @@ class FusedEngine:
             # only memory does -- 12 bytes per slot, bounded here to 8 GB of the 288
             limit = min((2 ** 31 - 1) // M, int(8e9) // (12 * M))
             self.bin_capacity = int(max(16, min(self._bin_hint or 1024, limit)))
+            self._bin_limit = int(limit)
             cap = M * self.bin_capacity
         else:
             self.bin_capacity = 0
@@ -332,6 +333,9 @@ class FusedEngine:
         n_last, ov_last = int(c[2 * self.M + 1].item()), int(c[2 * self.M + 2].item())
         if self.binned:                              # what overflowed is one tile's bin: size by the fullest tile
             n_prev = n_last = self._fullest_tile()
+            if self.bin_capacity >= self._bin_limit:
+                raise RuntimeError(f"{n_last} Gaussians over one tile exceed the largest bin this view size allows "
+                                   f"({self._bin_limit} slots): use FusedEngine(binned=False) / Config.binned = False")
         if self._status_kind != "train":             # a forward-only render overflowed: no iteration to take back
             self._grow(max(n_prev, n_last))
             return
