@@ -301,6 +301,24 @@ def main():
         except Exception:
             traffic = None
 
+    # every timed stage against the HBM roofline (the table of DESIGN.md section 4): which kernels stream at the
+    # roofline and which are bound by instruction issue
+    by_kernel = {}
+    fused_adam = fused and not runner.sharded and "so_adam_step_dev" not in prof and world == 1
+    for k, (n_calls, ms) in prof.items():
+        kk = k.replace("_packed", "")
+        nbytes = ab.get(kk)
+        if kk == "so_preprocess_bwd" and fused_adam:      # Adam runs inside: + its traffic, - the gradient round trip
+            nbytes = ab["so_preprocess_bwd"] + ab["so_adam_step"] - 8 * N * (11 + 3 * K)
+        if kk == "so_preprocess_fwd" and fused and not runner.sharded and runner._engine.binned:
+            nbytes = ab["so_preprocess_fwd"] + 8 * I     # the keys are written here (no scatter pass)
+        if kk == "so_isect_fill" and fused and not runner.sharded and runner._engine.binned:
+            nbytes = 12 * I                                # sort only: 8 B key read + 4 B id written
+        if nbytes and ms > 0:
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            by_kernel[kk] = {"us": round(ms * 1e3, 1), "algorithmic_bytes": int(nbytes), "GB/s": round(gbs, 1),
+                             "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
     out = {
         "metric": ("training iters/sec (100k Gaussians, 1080p, fwd+loss+bwd+Adam)" if (N0, W, H) == (100_000, 1920, 1080)
                    else f"training iters/sec ({N0} Gaussians, {W}x{H}, fwd+loss+bwd+Adam)"),
@@ -331,6 +349,7 @@ def main():
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": ab[dominant], "mean_launch_us": dom_ms * 1e3,
                      "launches_timed": dom_calls},
+        "roofline_by_kernel": by_kernel,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N0, W, H, args.regime)

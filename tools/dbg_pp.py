@@ -18,6 +18,7 @@ for _ in range(10):
 eng = r._engine; w = eng.ws; s = eng.splats; p = _lib.ptr; g = w["grads"]
 M = eng.M
 def fwd():
+    w["counters"][:2 * M + 5].zero_()          # the binning counters (a launch of its own: ~3 us, the same for every variant)
     _lib.call("so_preprocess_fwd", 1, N, eng.K, 3, p(s["means"].data), p(s["scales"].data), p(s["quats"].data), p(s["opacities"].data),
               p(s["sh0"].data), p(s["shN"].data), p(w["viewmats"]), p(w["Ks"]), W, H, 0.3, 0.01, 1e8, 0.0, 0, 0, 16,
               p(w["radii"]), p(w["means2d"]), p(w["depths"]), p(w["conics"]), p(w["opacities"]), p(w["colors"]),
