@@ -17,12 +17,16 @@ for _ in range(10):
     r.train_step(c2w, Ks, pixels)
 eng = r._engine; w = eng.ws; s = eng.splats; p = _lib.ptr; g = w["grads"]
 M = eng.M
+VARIANT = sys.argv[4] if len(sys.argv) > 4 else ""      # "" | nohist | nocull | deg0 | norec
 def fwd():
     w["counters"][:2 * M + 5].zero_()          # the binning counters (a launch of its own: ~3 us, the same for every variant)
-    _lib.call("so_preprocess_fwd", 1, N, eng.K, 3, p(s["means"].data), p(s["scales"].data), p(s["quats"].data), p(s["opacities"].data),
+    hist = VARIANT != "nohist"
+    _lib.call("so_preprocess_fwd", 1, N, eng.K, 0 if VARIANT == "deg0" else 3, p(s["means"].data), p(s["scales"].data), p(s["quats"].data), p(s["opacities"].data),
               p(s["sh0"].data), p(s["shN"].data), p(w["viewmats"]), p(w["Ks"]), W, H, 0.3, 0.01, 1e8, 0.0, 0, 0, 16,
               p(w["radii"]), p(w["means2d"]), p(w["depths"]), p(w["conics"]), p(w["opacities"]), p(w["colors"]),
-              p(w["tiles_per_gauss"]), p(w["counters"]), p(w["rec"]), p(w["vrec"]), 0, 0, 1, p(w["key_buf"]), eng.bin_capacity, p(w["counters"][2 * eng.M + 2:]), _lib.stream())
+              p(w["tiles_per_gauss"]), p(w["counters"]) if hist else 0, 0 if VARIANT == "norec" else p(w["rec"]), 0 if VARIANT == "norec" else p(w["vrec"]), 0, 0,
+              0 if VARIANT == "nocull" else 1, p(w["key_buf"]) if hist else 0, eng.bin_capacity if hist else 0,
+              p(w["counters"][2 * eng.M + 2:]) if hist else 0, _lib.stream())
 def bwd():
     _lib.call("so_preprocess_bwd", 1, N, eng.K, 3, p(s["means"].data), p(s["scales"].data), p(s["quats"].data), p(s["opacities"].data),
               p(s["sh0"].data), p(s["shN"].data), p(w["viewmats"]), p(w["Ks"]), W, H, 0.3, 0, 0, p(w["radii"]), p(w["opacities"]),
