@@ -19,6 +19,8 @@ pixels = torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(1)).to(d
 for _ in range(20):
     r.train_step(c2w, Ks, pixels)
 torch.cuda.synchronize()
+if len(sys.argv) > 1:      # "free": let the host run ahead of the GPU (no wait on the previous step's status event)
+    r._engine._check_previous = lambda: None
 for trial in range(2):
     t0 = time.time()
     for _ in range(200):
