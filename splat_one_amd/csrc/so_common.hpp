@@ -193,11 +193,15 @@ struct AdamHyper {
 
 __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, const AdamHyper h,
                                          float step_size, float bc2_sqrt) {
+  // sqrt and the two divisions as single hardware instructions (v_sqrt_f32 / v_rcp_f32, 1 ulp each) instead of the
+  // correctly rounded sequences (~30 instructions per element): the update differs from torch's by < 4e-7 of its own
+  // size (tests/test_gpu_ops.py::test_adam_matches_torch allows 1e-6 lr), and inside the fused backward kernel the
+  // arithmetic is on the critical path (6.8M -> 3.6M VALU instructions per launch at 100k Gaussians)
   const float eps = h.eps;
   m = m + (g - m) * h.omb1;
   v = v * h.b2 + h.omb2 * g * g;
-  const float denom = sqrtf(v) / bc2_sqrt + eps;
-  p = p - step_size * (m / denom);
+  const float denom = __builtin_amdgcn_sqrtf(v) * __builtin_amdgcn_rcpf(bc2_sqrt) + eps;
+  p = p - step_size * (m * __builtin_amdgcn_rcpf(denom));
 }
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
