@@ -35,7 +35,8 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
   __shared__ float4 s_A[BLOCK];
   __shared__ float4 s_B[BLOCK];
   __shared__ float4 s_box[BLOCK];
-  __shared__ float s_col[BLOCK * DC];
+  __shared__ float s_col[(D == 3) ? 1 : BLOCK * DC];
+  __shared__ float4 s_C[(D == 3) ? BLOCK : 1];   // RGB: blue, 16-byte strided like s_A / s_B (one address register per pass)
   __shared__ int32_t s_id[BLOCK];
   __shared__ int32_t s_wave_last[NWAVES];
 
@@ -116,7 +117,7 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         s_A[tid] = q0;
         s_B[tid] = q1;
         s_box[tid] = alpha_bound_box(q0.x, q0.y, q1.y, q0.z, q0.w, q1.x);
-        s_col[tid] = reinterpret_cast<const float *>(r4 + 2)[0];
+        s_C[tid].x = reinterpret_cast<const float *>(r4 + 2)[0];
       } else {
         const float2 xy = means2d[g];
         const float op = opacities[g];
@@ -125,7 +126,7 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         s_box[tid] = alpha_bound_box(xy.x, xy.y, op, ca, cb, cc);
         if (D == 3) {
           s_B[tid] = make_float4(cc, op, colors[(int64_t)g * D], colors[(int64_t)g * D + 1]);
-          s_col[tid] = colors[(int64_t)g * D + 2];
+          s_C[tid].x = colors[(int64_t)g * D + 2];
         } else {
           s_B[tid] = make_float4(cc, op, 0.f, 0.f);
 #pragma unroll
@@ -153,7 +154,7 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
       unsigned long long mask = __ballot(hit);
       while (mask) {
         const int bit = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
+        mask = clear_bit(mask, bit);
         const int tt = chunk0 + bit;
         const float4 a = s_A[tt];
         const float4 bq = s_B[tt];
@@ -175,7 +176,7 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         float g_col[D];
         float cv = 0.f;                          // sum_k colour[k] * v_c[k]
         if constexpr (D == 3) {
-          cv = fmaf(s_col[tt], v_c[2], fmaf(bq.w, v_c[1], bq.z * v_c[0]));
+          cv = fmaf(s_C[tt].x, v_c[2], fmaf(bq.w, v_c[1], bq.z * v_c[0]));
 #pragma unroll
           for (int k = 0; k < 3; ++k) g_col[k] = fac * v_c[k];
         } else {

@@ -37,6 +37,12 @@ template <> struct PixelMap<8> {
   }
 };
 
+// mask with bit `bit` (uniform, known to be set) cleared: s_bitset0_b64
+__device__ __forceinline__ unsigned long long clear_bit(unsigned long long mask, int bit) {
+  asm("s_bitset0_b64 %0, %1" : "+s"(mask) : "s"(bit));
+  return mask;
+}
+
 // A tile's slice of flatten_ids.  Two layouts:
 //   compact (gsplat): [offsets[t], offsets[t+1]) with the total n_isects on the device and/or the host -- the device
 //     count bounded by the host value when both are given (the capacity of flatten_ids: a list that overflowed its

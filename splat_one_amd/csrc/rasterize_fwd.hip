@@ -32,7 +32,9 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
   __shared__ float4 s_A[BLOCK];
   __shared__ float4 s_B[BLOCK];
   __shared__ float4 s_box[BLOCK];   // xmin, xmax, ymin, ymax of the alpha>=1/255 region
-  __shared__ float s_col[BLOCK * DC];
+  __shared__ float s_col[(D == 3) ? 1 : BLOCK * DC];
+  // RGB: blue sits in a third 16-byte-strided array, so one address register (tt * 16) serves all three reads of a pass
+  __shared__ float4 s_C[(D == 3) ? BLOCK : 1];
 
   // the host checked C * tile_w * tile_h < 2^31: 32-bit index arithmetic (a 64-bit division is ~100 instructions)
   const int n_tiles = tile_w * tile_h;
@@ -86,7 +88,7 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         s_A[tid] = q0;
         s_B[tid] = q1;
         s_box[tid] = alpha_bound_box(q0.x, q0.y, q1.y, q0.z, q0.w, q1.x);
-        s_col[tid] = reinterpret_cast<const float *>(r4 + 2)[0];
+        s_C[tid].x = reinterpret_cast<const float *>(r4 + 2)[0];
       } else {
         const float2 xy = means2d[g];
         const float op = opacities[g];
@@ -95,7 +97,7 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         s_box[tid] = alpha_bound_box(xy.x, xy.y, op, ca, cb, cc);
         if (D == 3) {
           s_B[tid] = make_float4(cc, op, colors[(int64_t)g * D], colors[(int64_t)g * D + 1]);
-          s_col[tid] = colors[(int64_t)g * D + 2];
+          s_C[tid].x = colors[(int64_t)g * D + 2];
         } else {
           s_B[tid] = make_float4(cc, op, 0.f, 0.f);
 #pragma unroll
@@ -123,10 +125,12 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
       while (mask) {
         if (__ballot(T > 0.f) == 0ull) break;
         const int bit = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
+        mask = clear_bit(mask, bit);                // one scalar instruction (mask &= mask - 1 is three)
         const int tt = chunk0 + bit;
         const float4 a = s_A[tt];
         const float4 bq = s_B[tt];
+        float blue = 0.f;
+        if constexpr (D == 3) blue = s_C[tt].x;     // issued with the other two reads, not at its use
         const float dx = a.x - px, dy = a.y - py;
         const float sigma = 0.5f * (a.z * dx * dx + bq.x * dy * dy) + a.w * dx * dy;
         float alpha = fminf(kAlphaMax, bq.y * __expf(-sigma));
@@ -140,7 +144,7 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         if constexpr (D == 3) {
           acc[0] = fmaf(bq.z, vis, acc[0]);
           acc[1] = fmaf(bq.w, vis, acc[1]);
-          acc[2] = fmaf(s_col[tt], vis, acc[2]);
+          acc[2] = fmaf(blue, vis, acc[2]);
         } else {
 #pragma unroll
           for (int k = 0; k < D; ++k) acc[k] = fmaf(s_col[tt * DC + k], vis, acc[k]);
