@@ -56,6 +56,33 @@ def camera_model_code(camera_model, n_views: int) -> int:
 
 
 # ---------------------------------------------------------------------------------------------
+# inverse(camtoworlds) without torch.linalg.inv's device synchronisation (its singularity check reads back)
+# ---------------------------------------------------------------------------------------------
+class _CameraInverse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, camtoworlds: Tensor) -> Tensor:
+        c2w = _f32(camtoworlds)
+        out = torch.empty_like(c2w)
+        call("so_camera_inverse", c2w.shape[0], ptr(c2w), ptr(out), stream())
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, v_out: Tensor):
+        (inv,) = ctx.saved_tensors                       # d(A^-1) = -A^-1 dA A^-1  ->  v_A = -A^-T v_out A^-T
+        it = inv.transpose(-1, -2)
+        return -(it @ v_out @ it)
+
+
+def camera_inverse(camtoworlds: Tensor) -> Tensor:
+    """viewmats[C,4,4] = inverse(camtoworlds[C,4,4]) (general 4x4, computed in double on the device; differentiable --
+    pose optimisation reaches the camera deltas through it).  gsplat_trainer.py:483 uses torch.linalg.inv, which
+    synchronises the device to report singular inputs."""
+    assert camtoworlds.shape[-2:] == (4, 4) and camtoworlds.dim() == 3, camtoworlds.shape
+    return _CameraInverse.apply(camtoworlds)
+
+
+# ---------------------------------------------------------------------------------------------
 # K1/K2 projection
 # ---------------------------------------------------------------------------------------------
 def _covars_to_6(covars: Tensor) -> Tensor:

@@ -36,6 +36,7 @@ from . import distributed as sdist
 from .losses import photometric_loss
 from .optimizers import FusedAdam, SelectiveAdam, step_all
 from .rendering import rasterization
+from .ops import camera_inverse
 from .scene import knn, rgb_to_sh, set_random_seed
 from .strategy import DefaultStrategy, MCMCStrategy
 
@@ -467,7 +468,7 @@ class Runner:
         rasterize_mode = "antialiased" if self.cfg.antialiased else "classic"
         render_colors, render_alphas, info = rasterization(
             means=means, quats=quats, scales=scales, opacities=opacities, colors=colors,
-            viewmats=torch.linalg.inv(camtoworlds), Ks=Ks, width=width, height=height,
+            viewmats=camera_inverse(camtoworlds), Ks=Ks, width=width, height=height,
             packed=self.cfg.packed,
             absgrad=(self.cfg.strategy.absgrad if isinstance(self.cfg.strategy, DefaultStrategy) else False),
             sparse_grad=self.cfg.sparse_grad, rasterize_mode=rasterize_mode, distributed=False,

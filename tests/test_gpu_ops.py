@@ -508,3 +508,19 @@ def test_slotted_binning_and_exact_tile_cull_c_abi(dev, cull):
         n_dropped += len(dropped)
     assert n_dropped == flat_ref.numel() - n
     assert worst < 1.0 / 255.0, worst
+
+
+def test_camera_inverse_matches_torch_and_is_differentiable(dev):
+    """ops.camera_inverse == torch.linalg.inv on rigid and on general 4x4 matrices, with the analytic gradient
+    (-A^-T v A^-T) that pose optimisation relies on -- and no device synchronisation."""
+    from splat_one_amd.ops import camera_inverse
+    from splat_one_amd.scene import ring_cameras
+    g = torch.Generator().manual_seed(3)
+    A = torch.cat([ring_cameras(5), torch.eye(4)[None] + 0.3 * torch.randn(3, 4, 4, generator=g)]).to(dev).requires_grad_(True)
+    B = A.detach().clone().requires_grad_(True)
+    w = torch.randn(8, 4, 4, generator=g).to(dev)
+    inv_h, inv_t = camera_inverse(A), torch.linalg.inv(B.double()).float()
+    assert (inv_h - inv_t).abs().max().item() < 1e-5
+    (inv_h * w).sum().backward()
+    (torch.linalg.inv(B) * w).sum().backward()
+    assert rel_err(A.grad, B.grad) < 1e-4
