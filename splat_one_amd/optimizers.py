@@ -100,5 +100,7 @@ def step_all(optimizers: Iterable[FusedAdam], set_to_none: bool = True, zero_gra
         items.extend(opt._collect(visibility))
     _launch(items, zero_grad_in_place)
     if set_to_none and not zero_grad_in_place:
-        for opt in opts:
-            opt.zero_grad(set_to_none=True)
+        for opt in opts:       # == opt.zero_grad(set_to_none=True) without torch's per-call profiler / dynamo wrappers
+            for group in opt.param_groups:     # (20 us each: 0.12 ms per step for the six 3DGS tensors)
+                for p in group["params"]:
+                    p.grad = None
