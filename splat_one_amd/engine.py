@@ -94,8 +94,8 @@ class FusedEngine:
         M = C * tw * th
         if self.binned:
             # generous by default: the step time does not depend on the capacity (256 ... 16384 slots measured alike),
-            # only memory does -- 12 bytes per slot, bounded here to 8 GB of the 288
-            limit = min((2 ** 31 - 1) // M, int(8e9) // (12 * M))
+            # only memory does -- 12 bytes per slot, bounded here to 32 GB of the 288
+            limit = min((2 ** 31 - 1) // M, int(32e9) // (12 * M))
             self.bin_capacity = int(max(16, min(self._bin_hint or 1024, limit)))
             self._bin_limit = int(limit)
             cap = M * self.bin_capacity
