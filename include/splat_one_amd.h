@@ -300,6 +300,12 @@ int so_adam_step_dev_shadow(int n_groups, const so_adam_group *host_groups, cons
  *   (no histogram: Gaussian-sharded runs bin after the exchange, on the records of all shards).
  * so_rec_unpack: from rec[n][16] writes means2d[n,2], radii[n], depths[n] (the inputs of so_isect_count /
  *   so_isect_fill) and zeroes vrec[n][16] (nullable).
+ * so_shard_flag_put / so_shard_flag_get: a Gaussian-sharded step (the reference's `distributed=True` scheme,
+ *   gsplat_trainer.py:236-238, 477-494) sends block j of vrec_full[world][cap][16] to rank j.  put writes
+ *   (*overflow != 0) as 1.0f / 0.0f into slot 15 of the first record of every block before that exchange (after
+ *   so_rasterize_bwd_packed; slots 11..15 carry no gradient); get, on the received vrec_shard[world][cap][16],
+ *   SETS *overflow when any sender's flag is set (it never clears it).  Every rank then skips the same iteration
+ *   (so_preprocess_bwd / so_adam_step_dev skip_if_nonzero) without a collective of its own.  world <= 64.
  * ---------------------------------------------------------------------------------------- */
 int so_preprocess_fwd(int C, int N, int K, int sh_degree, const float *means, const float *log_scales,
                       const float *quats, const float *logit_opacities, const float *sh0, const float *shN,
@@ -322,6 +328,8 @@ int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float *means, co
                       float *skip_flag_out, void *stream);
 int so_rec_unpack(int64_t n, const float *rec, float *means2d, int32_t *radii, float *depths, float *vrec,
                   void *stream);
+int so_shard_flag_put(int world, int64_t cap, const int32_t *overflow, float *vrec_full, void *stream);
+int so_shard_flag_get(int world, int64_t cap, const float *vrec_shard, int32_t *overflow, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * float16 attribute storage (BASELINE.json configs[4]: "2M Gaussians ... fp16 attributes").  The 56 of the 59

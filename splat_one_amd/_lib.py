@@ -78,6 +78,8 @@ _SIGS = {
     "so_preprocess_fwd": [c_int] * 4 + [c_ptr] * 8 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_int] + [c_ptr] * 10 + [c_i64, c_ptr, c_int, c_ptr, c_i64, c_ptr, c_ptr],
     "so_isect_sort_bins": [c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr],
     "so_rec_unpack": [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
+    "so_shard_flag_put": [c_int, c_i64, c_ptr, c_ptr, c_ptr],
+    "so_shard_flag_get": [c_int, c_i64, c_ptr, c_ptr, c_ptr],
     "so_preprocess_bwd": [c_int] * 4 + [c_ptr] * 8 + [c_int, c_int, c_f32, c_int, c_int] + [c_ptr] * 9 + [c_f32, c_f32] + [c_ptr] * 9 + [c_int, c_i64, c_ptr, c_ptr, c_ptr],
     "so_rasterize_fwd_packed": [c_int] * 5 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 4,
     "so_rasterize_fwd_wave": [c_int] * 4 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 4,

@@ -427,6 +427,22 @@ k_rec_unpack(int64_t n, const float4 *__restrict__ rec, float2 *__restrict__ mea
   }
 }
 
+// Gaussian-sharded steps: "the binning pass of my view overflowed" has to reach every rank before any optimiser
+// runs (the gradients that view sent to the other shards are incomplete).  It travels with the gradient records:
+// slot 15 of the first record of every block of vrec_full (the rasteriser's backward accumulates into slots 0..10
+// and so_preprocess_bwd reads 0..11), so no collective is added to the step.  One wave; world <= 64.
+__global__ void __launch_bounds__(64)
+k_shard_flag(int world, int64_t cap, float *__restrict__ vrec, int32_t *__restrict__ flag, int put) {
+  const int j = threadIdx.x;
+  const int64_t at = (int64_t)j * cap * 16 + 15;
+  if (put) {
+    if (j < world) vrec[at] = (*flag != 0) ? 1.f : 0.f;
+    return;
+  }
+  const bool any = (j < world) && vrec[at] != 0.f;
+  if (__ballot(any) != 0ull && j == 0) *flag = 1;
+}
+
 static inline int pp_grid(int64_t total) {
   int64_t g = ceil_div(total, 256);
   return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -689,4 +705,22 @@ extern "C" int so_rec_unpack(int64_t n, const float *rec, float *means2d, int32_
                      reinterpret_cast<const float4 *>(rec), reinterpret_cast<float2 *>(means2d), radii, depths,
                      reinterpret_cast<float4 *>(vrec));
   return so::check_launch("so_rec_unpack");
+}
+
+extern "C" int so_shard_flag_put(int world, int64_t cap, const int32_t *overflow, float *vrec_full, void *stream) {
+  SO_REQUIRE(world >= 1 && world <= 64 && cap >= 0, "so_shard_flag_put: world %d not in 1..64 or cap < 0", world);
+  if (cap == 0) return SO_OK;
+  SO_REQUIRE(overflow && vrec_full, "so_shard_flag_put: null pointer");
+  hipLaunchKernelGGL(so::k_shard_flag, dim3(1), dim3(64), 0, so::as_stream(stream), world, cap, vrec_full,
+                     const_cast<int32_t *>(overflow), 1);
+  return so::check_launch("so_shard_flag_put");
+}
+
+extern "C" int so_shard_flag_get(int world, int64_t cap, const float *vrec_shard, int32_t *overflow, void *stream) {
+  SO_REQUIRE(world >= 1 && world <= 64 && cap >= 0, "so_shard_flag_get: world %d not in 1..64 or cap < 0", world);
+  if (cap == 0) return SO_OK;
+  SO_REQUIRE(overflow && vrec_shard, "so_shard_flag_get: null pointer");
+  hipLaunchKernelGGL(so::k_shard_flag, dim3(1), dim3(64), 0, so::as_stream(stream), world, cap,
+                     const_cast<float *>(vrec_shard), overflow, 0);
+  return so::check_launch("so_shard_flag_get");
 }

@@ -11,7 +11,9 @@ Built here from the same C-ABI kernels as the single-GPU engine:
     all_to_all            block c of rec_shard -> rank c          (world-1)/world x 64 B x N per rank
     so_rec_unpack, so_isect_count/fill, so_rasterize_fwd_packed, so_ssim_l1_fwd/bwd,
     so_rasterize_bwd_packed  on the records of ALL Gaussians for the own view -> vrec_full
+    so_shard_flag_put     "my binning pass overflowed" into a spare slot of every block of vrec_full
     all_to_all            block j of vrec_full -> rank j          same volume back
+    so_shard_flag_get     any sender overflowed -> the own skip flag (every rank voids the same iteration)
     so_preprocess_bwd     own shard x C=world cameras (sums the cameras) -> parameter gradients
     so_adam_step_dev      own shard
 
@@ -24,6 +26,11 @@ replicated-parameter gradient all-reduce moves (the all-reduce path stays availa
 Shards may differ in length after densification: buffers are sized for `cap` = the largest shard
 (agreed with one all-reduce(MAX) whenever a workspace is built) and `cam_stride = cap` lets the
 preprocess kernels use them in place; padding rows keep radius 0 and are culled by the binning.
+
+A view whose tile intersections outgrow the buffers of its rank voids the iteration on EVERY rank (the flag rides
+on the gradient exchange, so no optimiser applies the incomplete gradients); one step later all ranks find it in
+their host-mapped status words, roll their step counters back, agree on a larger capacity and carry on
+(`on_overflow = "grow"`, like FusedEngine; "raise" stops instead).
 """
 from __future__ import annotations
 
@@ -79,6 +86,8 @@ class ShardedEngine:
         self._status = torch.zeros(4, dtype=torch.int32).pin_memory()    # {n_isects, overflow, seq} of the previous step
         self._seq = 0
         self._status_event = None
+        self.on_overflow = "grow"        # "grow": void iteration on every rank, larger buffers, continue;  "raise"
+        self.void_steps = 0              # iterations discarded because some rank's binning pass overflowed
         self._build_workspace()
 
     # ---------------------------------------------------------------------------------------------
@@ -97,7 +106,9 @@ class ShardedEngine:
         ts = self.cfg["tile_size"]
         tw, th = math.ceil(W / ts), math.ceil(H / ts)
         self.M = M = tw * th
-        icap = self._capacity_hint or max(1 << 20, 8 * Nf)
+        icap_t = torch.tensor([self._capacity_hint or max(1 << 20, 8 * Nf)], dtype=torch.int64, device=dev)
+        dist.all_reduce(icap_t, op=dist.ReduceOp.MAX, group=self.group)     # one capacity on every rank
+        icap = int(icap_t.item())
         self.capacity = int(icap)
         self._probe_capacity = self._capacity_hint is None
         f32, i32 = torch.float32, torch.int32
@@ -206,6 +217,7 @@ class ShardedEngine:
     def fwd_bwd(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor, schedule: bool = False) -> None:
         """camtoworlds[world,4,4] / Ks[world,3,3]: the cameras of ALL ranks for this step (rank r renders
         camera r); pixels[1,H,W,3]: the own target image.  Leaves the shard's gradients in `.grad`."""
+        self._check_previous()       # may rebuild the workspace (buffers grown after an overflow): before any of it is used
         n, N, cap, Nf, M, W, H = self.world, self.N, self.cap, self.Nf, self.M, self.W, self.H
         assert camtoworlds.shape == (n, 4, 4) and Ks.shape == (n, 3, 3), (camtoworlds.shape, Ks.shape)
         assert pixels.shape == (1, H, W, 3), pixels.shape
@@ -219,7 +231,6 @@ class ShardedEngine:
         else:
             w["pixels"].copy_(pixels, non_blocking=True)
             px = w["pixels"]
-        self._check_previous()
         ng, lr0, gam, betas = 0, None, None, (0.0, 0.0)
         if schedule:
             ng, _arr, lr0, gam, betas, _eps = self._adam_args()
@@ -274,7 +285,9 @@ class ShardedEngine:
         _lib.call("so_rasterize_bwd_packed", 1, Nf, W, H, ts, P("w.rec_full"), 0, P("w.isect_offsets"), P("w.flatten_ids"),
                   P("c.n_isects"), self.capacity, P("w.render_alphas"), P("w.last_ids"), P("w.v_render_colors"), P("w.zero_v_alphas"),
                   P("w.vrec_full"), int(c["absgrad"]), st)
+        _lib.call("so_shard_flag_put", n, cap, P("c.overflow"), P("w.vrec_full"), st)
         all_to_all_rows(w["vrec_shard"], w["vrec_full"], self.group)
+        _lib.call("so_shard_flag_get", n, cap, P("w.vrec_shard"), P("c.overflow"), st)
         if N > 0:
             sst = self.strategy_state
             # the regularisers are means over ALL Gaussians: rescale the kernel's 1/N to 1/N_total
@@ -298,18 +311,41 @@ class ShardedEngine:
         self._sched_staged = bool(schedule)
 
     def _check_previous(self) -> None:
-        """One step late, without a device-wide sync: an overflow of the own intersection buffers.  The kernels
-        stayed in bounds and this rank's optimiser skipped, but the gradients it sent to the other shards were
-        incomplete, so the run stops here (the intersection count of the first view sizes the buffers with 2x
-        headroom; a later view exceeding that needs Config.isect_capacity)."""
+        """One step late, without a device-wide sync: did the binning pass of ANY rank overflow its buffers in the
+        iteration before the last one?  The flag every rank reads here is the OR over the ranks
+        (so_shard_flag_put / _get around the gradient exchange), so all ranks take this branch on the same step:
+        the kernels stayed in bounds, every optimiser skipped; here the host-side step counters are rolled back and
+        the buffers grow to a capacity agreed in `_build_workspace` (a collective: every rank is in it)."""
         ev, self._status_event = self._status_event, None
         if ev is None:
             return
         ev.synchronize()
         n_prev, ov_prev, seq = (int(v) for v in self._status[:3])
-        if seq == self._seq and ov_prev:
-            raise RuntimeError(f"rank {self.rank}: tile-intersection buffers overflowed ({n_prev} > capacity {self.capacity}); "
+        if seq != self._seq or not ov_prev:
+            return
+        torch.cuda.synchronize()
+        cnt = self.ws["counters"]
+        n_last, ov_last = int(cnt[2 * self.M + 1].item()), int(cnt[2 * self.M + 2].item())
+        need = max(n_prev, n_last)
+        if self.on_overflow == "raise":
+            raise RuntimeError(f"rank {self.rank}: tile-intersection buffers overflowed on some rank (own count {need}, "
+                               f"capacity {self.capacity}); the affected iterations were skipped on every rank -- "
                                "raise Config.isect_capacity")
+        void = 1 + (1 if ov_last else 0)
+        self.void_steps += void
+        for _ in range(void):                        # undo optimize()'s bookkeeping for iterations that never happened
+            self.steps_done -= 1
+            for k in PARAM_ORDER:
+                self.optimizers[k].state[self.splats[k]]["step"] -= 1
+            self.optimizers["means"].param_groups[0]["lr"] /= self.lr_gamma_means
+        self._step_dev[0] = self.steps_done
+        import warnings
+        warnings.warn(f"splat_one_amd: rank {self.rank}: {void} training iteration(s) skipped on every rank -- the tile "
+                      f"intersections of some view exceeded the buffer capacity {self.capacity}; buffers enlarged",
+                      RuntimeWarning)
+        self._capacity_hint = max(2 * self.capacity, int(1.5 * need) + 4096)
+        self._probe_capacity = False
+        self._build_workspace()
 
     def optimize(self) -> None:
         n, arr, lr0, gam, betas, eps = self._adam_args()

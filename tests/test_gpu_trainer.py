@@ -195,3 +195,73 @@ def test_gaussian_sharded_dp_two_ranks_one_gpu(dev, tmp_path, mixed):
     tot = out[0]["loss"] + out[1]["loss"]
     assert (tot - ref_loss).abs().max().item() < 2e-5, (tot, ref_loss)
     assert out[0]["stats"]["overflow"] == 0 and out[0]["stats"]["n_isects"] > 0
+
+
+def _sharded_overflow_worker(local_rank, world_rank, world_size, out_dir):
+    import warnings
+    import torch.distributed as dist
+    from splat_one_amd.trainer import Config, Runner
+    dev = torch.device("cuda:0")
+    W, H, N = 128, 96, 3001
+
+    def make(isect_capacity):
+        cfg = Config(init_num_pts=N, init_scale=0.3, init_opa=0.3, fused=True, dp_mode="gaussian_sharded",
+                     isect_capacity=isect_capacity)             # SH degree 0 throughout (interval 1000)
+        r = Runner(0, world_rank, world_size, cfg, scene_scale=1.0 / 1.1)
+        ds, q, _ = _global_perturbation(N)
+        with torch.no_grad():
+            r.splats["scales"].add_(ds[world_rank::world_size].to(dev))
+            r.splats["quats"].copy_(q[world_rank::world_size].to(dev))
+        return r
+
+    c2w = ring_cameras(8)[:world_size].to(dev)
+    Ks = pinhole_K(W, H)[None].repeat(world_size, 1, 1).to(dev)
+    pixels = torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(100 + world_rank)).to(dev)
+    a = make(None)                                   # ample buffers: the run to reproduce
+    a.train_step(c2w, Ks, pixels)
+    counts = [None] * world_size
+    dist.all_gather_object(counts, a._engine.stats()["n_isects"])
+    for _ in range(3):
+        a.train_step(c2w, Ks, pixels)
+    lo, hi = min(counts), max(counts)
+    tight = (lo + hi) // 2 if hi - lo >= 16 else lo - 8      # between the two views' counts when they differ enough
+    b = make(tight)
+    calls = 0
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        while getattr(b, "_engine", None) is None or b._engine.steps_done < 4:
+            b.train_step(c2w, Ks, pixels)
+            calls += 1
+            assert calls < 16, "the sharded engine does not recover from the overflow"
+    st = b._engine.stats()
+    torch.cuda.synchronize()
+    rel = {k: ((b.splats[k] - a.splats[k]).norm() / a.splats[k].norm().clamp_min(1e-12)).item() for k in a.splats.keys()}
+    torch.save({"counts": counts, "tight": tight, "calls": calls, "void": b._engine.void_steps,
+                "capacity": b._engine.capacity, "overflow_now": st["overflow"], "rel": rel,
+                "warned": sum(1 for w in caught if "skipped on every rank" in str(w.message)),
+                "opt_step": float(b.optimizers["means"].state[b.splats["means"]]["step"]),
+                "lr": (a.optimizers["means"].param_groups[0]["lr"], b.optimizers["means"].param_groups[0]["lr"])},
+               os.path.join(out_dir, f"ovf{world_rank}.pt"))
+
+
+def test_gaussian_sharded_overflow_voids_and_grows_on_every_rank(dev, tmp_path):
+    """Buffers sized between the two views' intersection counts: the view that does not fit voids the iteration on
+    BOTH ranks (the flag rides on the gradient exchange: so_shard_flag_put / _get), both roll back, agree on a larger
+    capacity and then reproduce the run with ample buffers."""
+    from splat_one_amd import distributed as sdist
+    env_backup = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        sdist.cli(_sharded_overflow_worker, str(tmp_path), world_size=2, backend="gloo", port=_free_port())
+    finally:
+        for k, v in env_backup.items():
+            if v is not None:
+                os.environ[k] = v
+    out = [torch.load(os.path.join(tmp_path, f"ovf{i}.pt")) for i in range(2)]
+    assert max(out[0]["counts"]) > out[0]["tight"], out[0]
+    for o in out:
+        assert o["void"] == 2 and o["calls"] == 6 and o["warned"] == 1, o      # found one step late: two void iterations
+        assert o["capacity"] == out[0]["capacity"] and o["capacity"] >= 2 * o["tight"], o
+        assert o["overflow_now"] == 0 and o["opt_step"] == 4.0, o
+        assert abs(o["lr"][0] - o["lr"][1]) <= 1e-12 * abs(o["lr"][0]), o
+        for k, v in o["rel"].items():
+            assert v < 2e-4, (k, v, o)
