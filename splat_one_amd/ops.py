@@ -139,6 +139,81 @@ class _FullyFusedProjection(torch.autograd.Function):
         return (v_means, v_covars6, v_quats, v_scales, v_viewmats) + (None,) * 9
 
 
+def _sparse_rows(dense: Optional[Tensor], rows: Tensor) -> Optional[Tensor]:
+    """Row-sparse COO view of a per-Gaussian gradient: the rows `rows` (unique, sorted) of `dense`."""
+    if dense is None:
+        return None
+    return torch.sparse_coo_tensor(rows[None], dense[rows], size=dense.shape, is_coalesced=True)
+
+
+class _PackedProjection(torch.autograd.Function):
+    """Packed layout of gsplat's `fully_fused_projection(packed=True)`: one row per (camera, Gaussian) pair with a
+    positive radius, camera-major.  The projection kernel works on the [C,N] grid; what is returned and what is kept for
+    the backward are the nnz packed rows (the [C,N] scratch is released when forward returns)."""
+
+    @staticmethod
+    def forward(ctx, means, covars6, quats, scales, viewmats, Ks, width, height, eps2d, near_plane,
+                far_plane, radius_clip, calc_compensations, camera_model, sparse_grad):
+        C, N = viewmats.shape[0], means.shape[0]
+        dev = means.device
+        radii = torch.empty(C, N, dtype=torch.int32, device=dev)
+        means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
+        depths = torch.empty(C, N, dtype=torch.float32, device=dev)
+        conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
+        comps = torch.empty(C, N, dtype=torch.float32, device=dev) if calc_compensations else None
+        call("so_projection_fwd", C, N, ptr(means), ptr(covars6), ptr(quats), ptr(scales), ptr(viewmats),
+             ptr(Ks), width, height, eps2d, near_plane, far_plane, radius_clip, camera_model, ptr(radii),
+             ptr(means2d), ptr(depths), ptr(conics), ptr(comps), stream())
+        sel = torch.nonzero(radii.reshape(-1) > 0).squeeze(1)        # [nnz] row-major = camera-major (one host read: nnz)
+        camera_ids = torch.div(sel, max(N, 1), rounding_mode="floor")
+        gaussian_ids = sel - camera_ids * N
+        radii_p = radii.reshape(-1)[sel]
+        means2d_p = means2d.reshape(-1, 2)[sel]
+        depths_p = depths.reshape(-1)[sel]
+        conics_p = conics.reshape(-1, 3)[sel]
+        comps_p = comps.reshape(-1)[sel] if comps is not None else None
+        ctx.save_for_backward(means, covars6, quats, scales, viewmats, Ks, sel, gaussian_ids, radii_p, conics_p, comps_p)
+        ctx.cfg = (width, height, eps2d, camera_model, sparse_grad)
+        ctx.mark_non_differentiable(camera_ids, gaussian_ids, radii_p)
+        if comps_p is None:
+            return camera_ids, gaussian_ids, radii_p, means2d_p, depths_p, conics_p
+        return camera_ids, gaussian_ids, radii_p, means2d_p, depths_p, conics_p, comps_p
+
+    @staticmethod
+    def backward(ctx, _v_cid, _v_gid, _v_radii, v_means2d, v_depths, v_conics, v_comps=None):
+        means, covars6, quats, scales, viewmats, Ks, sel, gaussian_ids, radii_p, conics_p, comps_p = ctx.saved_tensors
+        width, height, eps2d, camera_model, sparse_grad = ctx.cfg
+        C, N = viewmats.shape[0], means.shape[0]
+        dev = means.device
+
+        def dense(rows, shape, dtype=torch.float32):     # packed rows back onto the [C,N] grid (zeros elsewhere)
+            out = torch.zeros(shape, dtype=dtype, device=dev)
+            if rows is not None:
+                out.view(C * N, *shape[2:])[sel] = rows.to(dtype)
+            return out
+        radii = dense(radii_p, (C, N), torch.int32)
+        conics = dense(conics_p, (C, N, 3))
+        comps = None if comps_p is None else dense(comps_p, (C, N))
+        v_means2d = dense(v_means2d, (C, N, 2))
+        v_depths = dense(v_depths, (C, N))
+        v_conics = dense(v_conics, (C, N, 3))
+        v_comps = None if comps_p is None else dense(v_comps, (C, N))
+        v_means = torch.empty_like(means)
+        v_covars6 = torch.empty_like(covars6) if covars6 is not None else None
+        v_quats = torch.empty_like(quats) if covars6 is None else None
+        v_scales = torch.empty_like(scales) if covars6 is None else None
+        v_viewmats = torch.zeros_like(viewmats) if ctx.needs_input_grad[4] else None
+        call("so_projection_bwd", C, N, ptr(means), ptr(covars6), ptr(quats), ptr(scales), ptr(viewmats),
+             ptr(Ks), width, height, eps2d, camera_model, ptr(radii), ptr(v_means2d), ptr(v_depths),
+             ptr(v_conics), ptr(v_comps), ptr(v_means), ptr(v_covars6), ptr(v_quats), ptr(v_scales),
+             ptr(v_viewmats), stream())
+        if sparse_grad:      # rows of Gaussians no camera sees are exactly zero: hand back only the visible rows
+            rows = gaussian_ids if C == 1 else torch.unique(gaussian_ids)
+            v_means, v_covars6 = _sparse_rows(v_means, rows), _sparse_rows(v_covars6, rows)
+            v_quats, v_scales = _sparse_rows(v_quats, rows), _sparse_rows(v_scales, rows)
+        return (v_means, v_covars6, v_quats, v_scales, v_viewmats) + (None,) * 10
+
+
 def fully_fused_projection(
     means: Tensor, covars: Optional[Tensor], quats: Optional[Tensor], scales: Optional[Tensor],
     viewmats: Tensor, Ks: Tensor, width: int, height: int, eps2d: float = 0.3,
@@ -146,13 +221,16 @@ def fully_fused_projection(
     sparse_grad: bool = False, calc_compensations: bool = False, camera_model: str = "pinhole",
 ) -> Tuple[Tensor, Tensor, Tensor, Tensor, Optional[Tensor]]:
     """means[N,3], covars[N,6]|[N,3,3]|None, quats[N,4], scales[N,3], viewmats[C,4,4], Ks[C,3,3] ->
-    (radii[C,N] i32, means2d[C,N,2], depths[C,N], conics[C,N,3], compensations[C,N]|None)."""
+    (radii[C,N] i32, means2d[C,N,2], depths[C,N], conics[C,N,3], compensations[C,N]|None);
+    packed=True (gsplat_trainer.py:487 `packed=self.cfg.packed`) -> (camera_ids[nnz] i64, gaussian_ids[nnz] i64,
+    radii[nnz], means2d[nnz,2], depths[nnz], conics[nnz,3], compensations[nnz]|None) for the pairs with radius > 0,
+    camera-major; sparse_grad=True (packed only) returns the gradients of means / quats / scales (covars) as
+    row-sparse COO tensors over the visible Gaussians."""
     C, N = viewmats.shape[0], means.shape[0]
     assert means.shape == (N, 3), means.shape
     assert viewmats.shape == (C, 4, 4), viewmats.shape
     assert Ks.shape == (C, 3, 3), Ks.shape
-    assert not packed, "packed projection is not implemented yet (reference default: packed=False, gsplat_trainer.py:133)"
-    assert not sparse_grad, "sparse_grad requires packed=True"
+    assert packed or not sparse_grad, "sparse_grad requires packed=True"
     if covars is not None:
         covars6 = _f32(_covars_to_6(covars))
         assert covars6.shape == (N, 6), covars6.shape
@@ -163,6 +241,12 @@ def fully_fused_projection(
         assert quats.shape == (N, 4), quats.shape
         assert scales.shape == (N, 3), scales.shape
         quats, scales = _f32(quats), _f32(scales)
+    if packed:
+        out = _PackedProjection.apply(
+            _f32(means), covars6, quats, scales, _f32(viewmats), _f32(Ks), int(width), int(height),
+            float(eps2d), float(near_plane), float(far_plane), float(radius_clip), bool(calc_compensations),
+            _camera_model_id(camera_model), bool(sparse_grad))
+        return out + (None,) if len(out) == 6 else out
     out = _FullyFusedProjection.apply(
         _f32(means), covars6, quats, scales, _f32(viewmats), _f32(Ks), int(width), int(height),
         float(eps2d), float(near_plane), float(far_plane), float(radius_clip), bool(calc_compensations),
@@ -241,8 +325,12 @@ def isect_tiles(
 ):
     """means2d[C,N,2], radii[C,N] i32, depths[C,N] -> (tiles_per_gauss[C,N] i32, isect_ids[I] i64,
     flatten_ids[I] i32).  Exact-size outputs need I on the host: this entry point performs ONE
-    device->host read (the sync-free path with preallocated capacity is `isect_tiles_static`)."""
-    assert not packed, "packed mode is not implemented yet"
+    device->host read (the sync-free path with preallocated capacity is `isect_tiles_static`).
+    packed=True: means2d[nnz,2], radii[nnz], depths[nnz] with n_cameras and camera_ids[nnz] (gaussian_ids is accepted
+    and not needed); flatten_ids then index the packed rows."""
+    if packed:
+        return _isect_tiles_packed(means2d, radii, depths, tile_size, tile_width, tile_height, sort, n_cameras,
+                                   camera_ids, return_offsets)
     C, N = radii.shape
     assert means2d.shape == (C, N, 2), means2d.shape
     assert depths.shape == (C, N), depths.shape
@@ -273,6 +361,34 @@ def isect_tiles(
     if return_offsets:
         return tiles_per_gauss, isect_ids, flatten_ids, offsets
     return tiles_per_gauss, isect_ids, flatten_ids
+
+
+def _isect_tiles_packed(means2d, radii, depths, tile_size, tile_width, tile_height, sort, n_cameras, camera_ids,
+                        return_offsets):
+    nnz = radii.shape[0]
+    assert means2d.shape == (nnz, 2) and depths.shape == (nnz,), (means2d.shape, depths.shape)
+    assert n_cameras is not None and camera_ids is not None and camera_ids.shape == (nnz,), "packed: n_cameras / camera_ids"
+    C = int(n_cameras)
+    if C == 1:          # one camera: the packed rows ARE a dense [1, nnz] problem
+        out = isect_tiles(means2d[None], radii[None], depths[None], tile_size, tile_width, tile_height, sort=sort,
+                          return_offsets=return_offsets)
+        return (out[0][0],) + tuple(out[1:])
+    # several cameras: the binning kernels take the camera of a row from its position in a [C, n] grid -- give every
+    # camera a row of nnz slots and put packed row r into slot (camera_ids[r], r); empty slots have radius 0
+    dev = means2d.device
+    rows = torch.arange(nnz, device=dev)
+    slot = camera_ids.to(torch.int64) * nnz + rows
+    g_radii = torch.zeros(C * nnz, dtype=torch.int32, device=dev)
+    g_means2d = torch.zeros(C * nnz, 2, dtype=torch.float32, device=dev)
+    g_depths = torch.zeros(C * nnz, dtype=torch.float32, device=dev)
+    g_radii[slot] = radii.to(torch.int32)
+    g_means2d[slot] = means2d.to(torch.float32)
+    g_depths[slot] = depths.to(torch.float32)
+    out = isect_tiles(g_means2d.view(C, nnz, 2), g_radii.view(C, nnz), g_depths.view(C, nnz), tile_size, tile_width,
+                      tile_height, sort=sort, return_offsets=return_offsets)
+    tiles_per_gauss = out[0].reshape(-1)[slot]
+    flatten_ids = out[2] % max(nnz, 1)                 # slot index -> packed row
+    return (tiles_per_gauss, out[1], flatten_ids) + tuple(out[3:])
 
 
 @torch.no_grad()
@@ -329,7 +445,7 @@ class _RasterizeToPixels(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, masks, width, height, tile_size,
                 isect_offsets, flatten_ids, n_isects_dev, absgrad):
-        C, N = opacities.shape
+        C, N = isect_offsets.shape[0], opacities.shape[-1]   # rows are addressed through flatten_ids: [C,N] or packed [nnz]
         D = colors.shape[-1]
         dev = means2d.device
         render_colors = torch.empty(C, height, width, D, dtype=torch.float32, device=dev)
@@ -349,7 +465,7 @@ class _RasterizeToPixels(torch.autograd.Function):
         (means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids, n_isects_dev,
          render_alphas, last_ids) = ctx.saved_tensors
         width, height, tile_size, absgrad, n_host = ctx.cfg
-        C, N = opacities.shape
+        C, N = isect_offsets.shape[0], opacities.shape[-1]
         D = colors.shape[-1]
         v_render_colors = v_render_colors.contiguous()
         v_render_alphas = v_render_alphas.contiguous()
@@ -379,12 +495,18 @@ def rasterize_to_pixels(
 ) -> Tuple[Tensor, Tensor]:
     """means2d[C,N,2] conics[C,N,3] colors[C,N,D] opacities[C,N] -> (render_colors[C,H,W,D],
     render_alphas[C,H,W,1]).  `n_isects` (device i32[1]) switches to the static-capacity mode of
-    `isect_tiles_static`.  Channel counts outside the compiled set are zero-padded (as gsplat does)."""
-    assert not packed, "packed mode is not implemented yet"
-    C, N = opacities.shape
-    assert means2d.shape == (C, N, 2), means2d.shape
-    assert conics.shape == (C, N, 3), conics.shape
-    assert colors.shape[:2] == (C, N), colors.shape
+    `isect_tiles_static`.  Channel counts outside the compiled set are zero-padded (as gsplat does).
+    packed=True: means2d[nnz,2] conics[nnz,3] colors[nnz,D] opacities[nnz], flatten_ids indexing those rows (the
+    kernels address Gaussians through flatten_ids only, so both layouts run the same code)."""
+    C = isect_offsets.shape[0]
+    lead = tuple(opacities.shape)
+    if packed:
+        assert len(lead) == 1, opacities.shape
+    else:
+        assert len(lead) == 2 and lead[0] == C, opacities.shape
+    assert means2d.shape == lead + (2,), means2d.shape
+    assert conics.shape == lead + (3,), conics.shape
+    assert colors.shape[:-1] == lead, colors.shape
     assert tile_size in (8, 16), f"tile_size {tile_size} not supported (8 or 16)"
     th, tw = isect_offsets.shape[1:]
     assert isect_offsets.shape[0] == C
@@ -401,7 +523,7 @@ def rasterize_to_pixels(
         assert D <= SUPPORTED_CHANNELS[-1], f"too many channels: {D} (chunk them, as `rasterization` does)"
         Dp = min(d for d in SUPPORTED_CHANNELS if d >= D)
         pad = Dp - D
-        colors = torch.cat([colors, torch.zeros(C, N, pad, dtype=colors.dtype, device=colors.device)], -1)
+        colors = torch.cat([colors, torch.zeros(lead + (pad,), dtype=colors.dtype, device=colors.device)], -1)
         if backgrounds is not None:
             backgrounds = torch.cat([backgrounds, torch.zeros(C, pad, dtype=torch.float32, device=colors.device)], -1)
     rc, ra = _RasterizeToPixels.apply(

@@ -51,9 +51,12 @@ def rasterization(
     """Rasterise N Gaussians to C cameras.  Returns (render_colors[C,H,W,X], render_alphas[C,H,W,1], meta).
 
     Differences from the gsplat call, all explicit:
-      * `packed=True` (gsplat's default) is accepted and executed in the dense [C,N] layout -- the
-        reference passes packed=False (`Config.packed`, gsplat_trainer.py:133); results are identical,
-        `meta` has the non-packed layout.
+      * `packed=True` (gsplat's default; the reference passes `Config.packed` = False, gsplat_trainer.py:133, 487):
+        every per-Gaussian intermediate and `meta` entry has one row per (camera, Gaussian) pair with a positive
+        radius, camera-major, with `meta["camera_ids"]` / `meta["gaussian_ids"]` naming the pair; the rasteriser
+        kernels address rows through `flatten_ids`, so both layouts run the same kernels and give the same images.
+        `sparse_grad=True` (packed only) returns row-sparse COO gradients for means / quats / scales.
+        `isect_capacity` (the sync-free binning) does not apply to packed calls: nnz is read on the host anyway.
       * `distributed=True` is refused here: multi-GPU runs of this build are view-sharded
         (splat_one_amd.distributed), not Gaussian-sharded.
       * `isect_capacity` / `workspace` (extensions): preallocated intersection buffers make the call
@@ -77,7 +80,7 @@ def rasterization(
     assert rasterize_mode in ("classic", "antialiased"), rasterize_mode
     assert not distributed, ("Gaussian-sharded `distributed=True` is not provided; use "
                              "splat_one_amd.distributed (view-sharded data parallelism)")
-    assert not sparse_grad, "sparse_grad needs packed mode, which is not implemented yet"
+    assert packed or not sparse_grad, "sparse_grad requires packed=True"
 
     if sh_degree is None:
         # treat colors as post-activation values, [N, D] or [C, N, D]
@@ -89,28 +92,41 @@ def rasterization(
         assert (sh_degree + 1) ** 2 <= colors.shape[-2], colors.shape
 
     # K1 projection
-    radii, means2d, depths, conics, compensations = fully_fused_projection(
-        means, covars, quats, scales, viewmats, Ks, width, height, eps2d=eps2d, packed=False,
-        near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip, sparse_grad=False,
+    proj = fully_fused_projection(
+        means, covars, quats, scales, viewmats, Ks, width, height, eps2d=eps2d, packed=packed,
+        near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip, sparse_grad=sparse_grad,
         calc_compensations=(rasterize_mode == "antialiased"), camera_model=camera_model)
-    opacities = opacities[None, :].expand(C, N)
+    if packed:
+        camera_ids, gaussian_ids, radii, means2d, depths, conics, compensations = proj
+        opacities = opacities[gaussian_ids]                      # [nnz]
+        isect_capacity = None
+    else:
+        camera_ids = gaussian_ids = None
+        radii, means2d, depths, conics, compensations = proj
+        opacities = opacities[None, :].expand(C, N)
     if compensations is not None:
         opacities = opacities * compensations
     opacities = opacities.contiguous()
 
-    meta.update({"camera_ids": None, "gaussian_ids": None, "radii": radii, "means2d": means2d,
+    meta.update({"camera_ids": camera_ids, "gaussian_ids": gaussian_ids, "radii": radii, "means2d": means2d,
                  "depths": depths, "conics": conics, "opacities": opacities})
 
     # K4 colours
     if sh_degree is None:
-        if colors.dim() == 2:
+        if packed:
+            colors = colors[gaussian_ids] if colors.dim() == 2 else colors[camera_ids, gaussian_ids]    # [nnz, D]
+        elif colors.dim() == 2:
             colors = colors[None].expand(C, -1, -1)
     else:
         camtoworlds = torch.inverse(viewmats)
-        dirs = means[None, :, :] - camtoworlds[:, None, :3, 3]  # [C, N, 3]
+        if packed:
+            dirs = means[gaussian_ids] - camtoworlds[camera_ids, :3, 3]  # [nnz, 3]
+            shs = colors[gaussian_ids] if colors.dim() == 3 else colors[camera_ids, gaussian_ids]     # [nnz, K, 3]
+        else:
+            dirs = means[None, :, :] - camtoworlds[:, None, :3, 3]  # [C, N, 3]
+            shs = colors[None].expand(C, -1, -1, -1) if colors.dim() == 3 else colors
         masks = radii > 0
-        shs = colors[None].expand(C, -1, -1, -1) if colors.dim() == 3 else colors
-        colors = spherical_harmonics(sh_degree, dirs, shs, masks=masks)  # [C, N, 3]
+        colors = spherical_harmonics(sh_degree, dirs, shs, masks=masks)  # [C, N, 3] | [nnz, 3]
         colors = torch.clamp_min(colors + 0.5, 0.0)
 
     if render_mode in ("RGB+D", "RGB+ED"):
@@ -128,8 +144,8 @@ def rasterization(
     n_isects_dev = None
     if isect_capacity is None:
         tiles_per_gauss, isect_ids, flatten_ids, isect_offsets = isect_tiles(
-            means2d, radii, depths, tile_size, tile_width, tile_height, packed=False, n_cameras=C,
-            return_offsets=True)
+            means2d, radii, depths, tile_size, tile_width, tile_height, packed=packed, n_cameras=C,
+            camera_ids=camera_ids, gaussian_ids=gaussian_ids, return_offsets=True)
     else:
         st = isect_tiles_static(means2d, radii, depths, tile_size, tile_width, tile_height, int(isect_capacity),
                                 workspace=workspace, want_isect_ids=False)
@@ -151,7 +167,7 @@ def rasterization(
             colors_chunk = colors[..., i * channel_chunk:(i + 1) * channel_chunk].contiguous()
             bg_chunk = backgrounds[..., i * channel_chunk:(i + 1) * channel_chunk] if backgrounds is not None else None
             rc, ra = rasterize_to_pixels(means2d, conics, colors_chunk, opacities, width, height, tile_size,
-                                         isect_offsets, flatten_ids, backgrounds=bg_chunk, packed=False,
+                                         isect_offsets, flatten_ids, backgrounds=bg_chunk, packed=packed,
                                          absgrad=absgrad, n_isects=n_isects_dev)
             render_colors.append(rc)
             render_alphas.append(ra)
@@ -160,7 +176,7 @@ def rasterization(
     else:
         render_colors, render_alphas = rasterize_to_pixels(
             means2d, conics, colors, opacities, width, height, tile_size, isect_offsets, flatten_ids,
-            backgrounds=backgrounds, packed=False, absgrad=absgrad, n_isects=n_isects_dev)
+            backgrounds=backgrounds, packed=packed, absgrad=absgrad, n_isects=n_isects_dev)
     if render_mode in ("ED", "RGB+ED"):
         # normalise the accumulated depth to get the expected depth
         render_colors = torch.cat(

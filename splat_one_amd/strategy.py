@@ -333,9 +333,8 @@ class DefaultStrategy(Strategy):
     def _update_state(self, params, state: Dict[str, Any], info: Dict[str, Any], packed: bool = False):
         for key in ["width", "height", "n_cameras", "radii", self.key_for_gradient]:
             assert key in info, f"{key} is required but missing."
-        assert not packed, "packed mode is not implemented yet"
         m2 = info[self.key_for_gradient]
-        grads = m2.absgrad if self.absgrad else m2.grad                     # [C, N, 2]
+        grads = m2.absgrad if self.absgrad else m2.grad                     # [C, N, 2] | packed [nnz, 2]
         n_gaussian = len(list(params.values())[0])
         if state["grad2d"] is None:
             state["grad2d"] = torch.zeros(n_gaussian, device=grads.device)
@@ -345,8 +344,16 @@ class DefaultStrategy(Strategy):
             state["radii"] = torch.zeros(n_gaussian, device=grads.device)
         sx = info["width"] / 2.0 * info["n_cameras"]
         sy = info["height"] / 2.0 * info["n_cameras"]
-        sel = info["radii"] > 0                                            # [C, N]
         norms = torch.sqrt((grads[..., 0] * sx) ** 2 + (grads[..., 1] * sy) ** 2)
+        if packed:       # one row per visible (camera, Gaussian) pair, named by info["gaussian_ids"] (radii > 0 on all of them)
+            gs_ids = info["gaussian_ids"]
+            state["grad2d"].index_add_(0, gs_ids, norms)
+            state["count"].index_add_(0, gs_ids, torch.ones_like(norms))
+            if self.refine_scale2d_stop_iter > 0:
+                r = info["radii"].to(torch.float32) / float(max(info["width"], info["height"]))
+                state["radii"].scatter_reduce_(0, gs_ids, r, reduce="amax", include_self=True)
+            return
+        sel = info["radii"] > 0                                            # [C, N]
         # dense masked sums == index_add_ over the visible ids, without torch.where's host sync
         state["grad2d"] += (norms * sel).sum(dim=0)
         state["count"] += sel.sum(dim=0).to(torch.float32)

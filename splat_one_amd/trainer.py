@@ -170,8 +170,8 @@ def create_splats_with_optimizers(
     lrs = dict(PARAM_LRS)
     lrs["means"] = lrs["means"] * scene_scale
     splats = torch.nn.ParameterDict({n: torch.nn.Parameter(v) for n, v in values.items()}).to(device)
-    assert not sparse_grad, "sparse_grad needs packed mode, which is not implemented yet"
-    opt_cls = SelectiveAdam if visible_adam else FusedAdam
+    # gsplat_trainer.py:267-272: SparseAdam for row-sparse gradients (packed mode), SelectiveAdam, else Adam
+    opt_cls = torch.optim.SparseAdam if sparse_grad else (SelectiveAdam if visible_adam else FusedAdam)
     optimizers = {}
     for name in values:
         lr, eps, betas = adam_hyperparameters(lrs[name], batch_size, world_size)
@@ -654,12 +654,35 @@ class Runner:
         loss.backward()
         # view-sharded data parallelism: one all-reduce of the flattened gradient SoA
         if self.world_size > 1:
+            if cfg.sparse_grad:                     # the flat all-reduce takes dense gradients
+                for prm in self.splats.values():
+                    if prm.grad is not None and prm.grad.is_sparse:
+                        prm.grad = prm.grad.to_dense()
             self._reducer.reduce(self.splats.values())
+        if cfg.sparse_grad:                                                    # :705-717
+            assert cfg.packed, "Sparse gradients only work with packed mode."
+            gaussian_ids = info["gaussian_ids"]
+            rows = gaussian_ids if len(Ks) == 1 else torch.unique(gaussian_ids)    # one index per visible Gaussian
+            for prm in self.splats.values():
+                grad = prm.grad
+                if grad is None or grad.is_sparse:
+                    continue
+                prm.grad = torch.sparse_coo_tensor(indices=rows[None], values=grad[rows], size=prm.size(),
+                                                   is_coalesced=True)
         # optimisers (one fused launch) + zero_grad(set_to_none=True)
         vis = None
-        if cfg.visible_adam:
-            vis = (info["radii"] > 0).any(0)
-        step_all(self.optimizers.values(), set_to_none=True, visibility=vis)
+        if cfg.visible_adam:                                                   # :719-724
+            if cfg.packed:
+                vis = torch.zeros_like(self.splats["opacities"], dtype=torch.bool)
+                vis.scatter_(0, info["gaussian_ids"], True)
+            else:
+                vis = (info["radii"] > 0).any(0)
+        if cfg.sparse_grad:
+            for opt in self.optimizers.values():                               # torch.optim.SparseAdam
+                opt.step()
+                opt.zero_grad(set_to_none=True)
+        else:
+            step_all(self.optimizers.values(), set_to_none=True, visibility=vis)
         for opt in self.pose_optimizers:                                       # :732-734, scheduler :517-522
             if self.world_size > 1:
                 for prm in self.pose_adjust.parameters():

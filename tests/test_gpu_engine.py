@@ -230,7 +230,8 @@ def test_engine_tile_cull_is_exact(dev, regime, C, aa, binned):
             sp = r.splats
             _, _, info = rasterization(sp["means"], sp["quats"], torch.exp(sp["scales"]), torch.sigmoid(sp["opacities"]),
                                        torch.cat([sp["sh0"], sp["shN"]], 1), torch.linalg.inv(c2w), Ks, W, H, sh_degree=3,
-                                       near_plane=0.01, far_plane=1e8, rasterize_mode="antialiased" if aa else "classic")
+                                       near_plane=0.01, far_plane=1e8, rasterize_mode="antialiased" if aa else "classic",
+                                       packed=False)
             assert torch.equal(info["flatten_ids"].cpu(), ids)
     a, b = res[False], res[True]
     assert b["n"] < 0.9 * a["n"], (a["n"], b["n"])
