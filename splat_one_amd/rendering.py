@@ -11,12 +11,62 @@ import math
 from typing import Dict, Optional, Tuple
 
 import torch
+import torch.distributed as dist
 from torch import Tensor
 
 from .ops import (fully_fused_projection, isect_offset_encode, isect_tiles, isect_tiles_static,
                   rasterize_to_pixels, spherical_harmonics)
 
 RENDER_MODES = ("RGB", "D", "ED", "RGB+D", "RGB+ED")
+
+
+def _all_to_all_rows(inp: Tensor, send: list, recv: list) -> Tensor:
+    """Variable-split all-to-all along dim 0.  RCCL directly; the gloo backend (tests with several ranks on one GPU)
+    stages through host memory."""
+    out = torch.empty((sum(recv),) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
+    if dist.get_backend() == "nccl":
+        dist.all_to_all_single(out, inp.contiguous(), output_split_sizes=recv, input_split_sizes=send)
+    else:
+        o = torch.empty(out.shape, dtype=inp.dtype)
+        dist.all_to_all_single(o, inp.detach().cpu().contiguous(), output_split_sizes=recv, input_split_sizes=send)
+        out.copy_(o)
+    return out
+
+
+class _AllToAllRows(torch.autograd.Function):
+    """Differentiable all-to-all: the gradient of what a rank received travels back to the rank that sent it."""
+
+    @staticmethod
+    def forward(ctx, inp, send, recv):
+        ctx.splits = (list(send), list(recv))
+        return _all_to_all_rows(inp, list(send), list(recv))
+
+    @staticmethod
+    def backward(ctx, v_out):
+        send, recv = ctx.splits
+        return _all_to_all_rows(v_out.contiguous(), recv, send), None, None
+
+
+@torch.no_grad()
+def _gather_cameras(N: int, viewmats: Tensor, Ks: Tensor):
+    """(Gaussians per rank, viewmats of all ranks [C_world,4,4], Ks of all ranks) -- every rank brings the same number
+    of cameras (as gsplat requires)."""
+    assert dist.is_available() and dist.is_initialized(), "distributed=True needs an initialised process group"
+    world = dist.get_world_size()
+    dev = viewmats.device
+    gloo = dist.get_backend() != "nccl"
+    mine = torch.cat([torch.tensor([float(N)], dtype=torch.float64), viewmats.detach().double().reshape(-1).cpu(),
+                      Ks.detach().double().reshape(-1).cpu()])
+    mine = mine if gloo else mine.to(dev)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    C = viewmats.shape[0]
+    parts = [p.cpu() for p in parts]
+    assert all(p.numel() == mine.numel() for p in parts), "every rank must bring the same number of cameras"
+    N_world = [int(p[0].item()) for p in parts]
+    vm = torch.cat([p[1:1 + 16 * C].reshape(C, 4, 4) for p in parts]).to(device=dev, dtype=torch.float32)
+    ks = torch.cat([p[1 + 16 * C:].reshape(C, 3, 3) for p in parts]).to(device=dev, dtype=torch.float32)
+    return N_world, vm, ks
 
 
 def rasterization(
@@ -57,8 +107,13 @@ def rasterization(
         kernels address rows through `flatten_ids`, so both layouts run the same kernels and give the same images.
         `sparse_grad=True` (packed only) returns row-sparse COO gradients for means / quats / scales.
         `isect_capacity` (the sync-free binning) does not apply to packed calls: nnz is read on the host anyway.
-      * `distributed=True` is refused here: multi-GPU runs of this build are view-sharded
-        (splat_one_amd.distributed), not Gaussian-sharded.
+      * `distributed=True` (the reference passes `distributed=self.world_size > 1`, gsplat_trainer.py:490): every rank
+        holds a shard of the Gaussians and the same number of cameras; the cameras are all-gathered, the shard is
+        projected into ALL of them, and ONE differentiable all-to-all of the projected rows {radius, centre, depth, conic,
+        opacity, colour} (RCCL; its backward is the reverse all-to-all) gives every rank all Gaussians for its own
+        cameras.  `meta` keeps the shard-local pre-exchange tensors ([C_world, N_local], what a per-rank strategy needs),
+        `meta["n_cameras"]` the local count.  Not combined with `packed` here; viewmats / Ks are gathered without a
+        gradient path.  (`splat_one_amd.sharded.ShardedEngine` is the fused form of the same scheme.)
       * `isect_capacity` / `workspace` (extensions): preallocated intersection buffers make the call
         free of host synchronisation (hipGraph-capturable); `meta["n_isects"]` then lives on the device.
     """
@@ -78,8 +133,11 @@ def rasterization(
     assert Ks.shape == (C, 3, 3), Ks.shape
     assert render_mode in RENDER_MODES, render_mode
     assert rasterize_mode in ("classic", "antialiased"), rasterize_mode
-    assert not distributed, ("Gaussian-sharded `distributed=True` is not provided; use "
-                             "splat_one_amd.distributed (view-sharded data parallelism)")
+    if distributed:
+        assert not packed, "distributed=True with packed=True is not provided: pass packed=False (the reference's default)"
+        assert isect_capacity is None, "distributed=True: the exchange sizes are read on the host anyway"
+        N_world, viewmats, Ks = _gather_cameras(N, viewmats, Ks)
+        C_local, C = C, viewmats.shape[0]
     assert packed or not sparse_grad, "sparse_grad requires packed=True"
 
     if sh_degree is None:
@@ -132,11 +190,24 @@ def rasterization(
     if render_mode in ("RGB+D", "RGB+ED"):
         colors = torch.cat((colors, depths[..., None]), dim=-1)
         if backgrounds is not None:
-            backgrounds = torch.cat([backgrounds, torch.zeros(C, 1, device=device)], dim=-1)
+            backgrounds = torch.cat([backgrounds, torch.zeros(backgrounds.shape[0], 1, device=device)], dim=-1)
     elif render_mode in ("D", "ED"):
         colors = depths[..., None]
         if backgrounds is not None:
-            backgrounds = torch.zeros(C, 1, device=device)
+            backgrounds = torch.zeros(backgrounds.shape[0], 1, device=device)
+
+    if distributed:
+        # one all-to-all of the projected rows: block c of the shard's [C_world, N_local] grid goes to the rank owning camera c
+        F = 8 + colors.shape[-1]
+        rec = torch.cat([radii.view(torch.float32)[..., None], means2d, depths[..., None], conics, opacities[..., None],
+                         colors], dim=-1).reshape(C * N, F)
+        world = len(N_world)
+        got = _AllToAllRows.apply(rec, [C_local * N] * world, [C_local * n for n in N_world])
+        rows = torch.cat([b.view(C_local, n, F) for b, n in zip(got.split([C_local * n for n in N_world]), N_world)], dim=1)
+        C, N = C_local, sum(N_world)
+        radii = rows[..., 0].contiguous().view(torch.int32)
+        means2d, depths, conics = rows[..., 1:3].contiguous(), rows[..., 3].contiguous(), rows[..., 4:7].contiguous()
+        opacities, colors = rows[..., 7].contiguous(), rows[..., 8:]
 
     # K6-K8 binning + sort + offsets
     tile_width = math.ceil(width / float(tile_size))

@@ -46,6 +46,24 @@ def _worker_fn(local_rank, world_rank, world_size, out_dir):
     all_to_all_rows(recv, send)
     want = torch.stack([torch.full((cap, 16), 10.0 * j + world_rank) for j in range(world_size)]).reshape(-1, 16)
     assert torch.equal(recv, want), (world_rank, recv[:, 0])
+    # rasterization(distributed=True): the differentiable variable-split all-to-all of the projected rows
+    # (rank r owns 2 + r rows per camera block) and the camera gather
+    from splat_one_amd.rendering import _AllToAllRows, _gather_cameras
+    n_mine, n_all = 2 + world_rank, [2, 3]
+    inp = (100.0 * world_rank + torch.arange(2 * n_mine * 4, dtype=torch.float32).reshape(2 * n_mine, 4)).requires_grad_(True)
+    got = _AllToAllRows.apply(inp, [n_mine] * 2, n_all)
+    assert got.shape == (5, 4)
+    for j, blk in enumerate(got.split(n_all)):      # block j came from rank j: its rows [world_rank*n_j, (world_rank+1)*n_j)
+        want = 100.0 * j + torch.arange(2 * n_all[j] * 4, dtype=torch.float32).reshape(2 * n_all[j], 4)
+        assert torch.equal(blk, want[world_rank * n_all[j]:(world_rank + 1) * n_all[j]]), (world_rank, j)
+    (got * (world_rank + 1.0)).sum().backward()     # the gradient of what rank j received returns to the sender
+    want_grad = torch.cat([torch.full((n_mine, 4), j + 1.0) for j in range(2)])
+    assert torch.equal(inp.grad, want_grad), (world_rank, inp.grad)
+    vm = torch.eye(4)[None] * (world_rank + 1.0)
+    ks = torch.eye(3)[None] * (world_rank + 5.0)
+    N_world, vms, kss = _gather_cameras(7 + world_rank, vm, ks)
+    assert N_world == [7, 8] and vms.shape == (2, 4, 4) and kss.shape == (2, 3, 3)
+    assert torch.equal(vms[1], torch.eye(4) * 2.0) and torch.equal(kss[0], torch.eye(3) * 5.0)
     torch.save({"ok": True, "rank": world_rank}, os.path.join(out_dir, f"rank{world_rank}.pt"))
 
 
