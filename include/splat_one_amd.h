@@ -42,7 +42,11 @@ enum so_status {
   SO_ERR_LAUNCH = 4       /* HIP reported an error at launch                       */
 };
 
-enum so_camera_model { SO_CAM_PINHOLE = 0, SO_CAM_ORTHO = 1, SO_CAM_FISHEYE = 2 };
+enum so_camera_model { SO_CAM_PINHOLE = 0, SO_CAM_ORTHO = 1, SO_CAM_FISHEYE = 2, SO_CAM_SPHERICAL = 3 };
+/* SO_CAM_SPHERICAL: the 360-degree (equirectangular) cameras of the reference's data sets (utils/datasets/opensfm.py:
+ * 176-193, 430-436).  The fork's own kernel for it is absent from the reference tree: the model is defined by this
+ * library (csrc/splat_math.hpp: u = W (atan2(x,z)/2pi + 1/2), v = H (atan2(y,|xz|)/pi + 1/2), depth = range, K unused)
+ * -- parity unpinned. */
 /* The fused entry points (so_preprocess_fwd / _bwd and their _f16 forms, so_step_desc.camera_model) also take one
  * model PER VIEW -- BASELINE.json configs[4] mixes perspective and fisheye cameras (app/camera_models.py:230-237)
  * in one batch:  SO_CAM_PER_VIEW | m_0 | m_1 << 2 | ... | m_{C-1} << 2 (C-1),  2 bits per view, C <= 15. */

@@ -42,7 +42,7 @@ ALPHA_MIN = 1.0 / 255.0    # contribution threshold
 T_STOP = 1e-4              # transmittance early stop
 FISHEYE_EPS = 1e-7
 
-CAMERA_MODELS = ("pinhole", "ortho", "fisheye")
+CAMERA_MODELS = ("pinhole", "ortho", "fisheye", "spherical")
 
 
 # ----------------------------------------------------------------------------------------
@@ -121,7 +121,27 @@ def _ortho_proj(mc: Tensor, cc: Tensor, fx, fy, cx, cy, W: int, H: int):
     return mean2d, cov2d
 
 
-_PROJ = {"pinhole": _persp_proj, "fisheye": _fisheye_proj, "ortho": _ortho_proj}
+def _spherical_proj(mc: Tensor, cc: Tensor, fx, fy, cx, cy, W: int, H: int):
+    """360-degree equirectangular camera (the reference's `spherical` / `equirectangular` data sets,
+    utils/datasets/opensfm.py:176-193, 430-436).  The fork's kernel for it is absent from the reference tree, so this is
+    the BUILD'S definition (parity unpinned): lon = atan2(x, z), lat = atan2(y, |xz|), u = W (lon/2pi + 1/2),
+    v = H (lat/pi + 1/2); K is not used; EWA covariance with J = d(u,v)/d(x,y,z) written out (autograd differentiates
+    its entries w.r.t. the mean, as for the other models)."""
+    x, y, z = mc.unbind(-1)
+    fxs, fys = W / (2.0 * math.pi), H / math.pi
+    p2 = x * x + z * z + 1e-12
+    p = torch.sqrt(p2)
+    r2 = p2 + y * y
+    mean2d = torch.stack([fxs * torch.atan2(x, z) + 0.5 * W, fys * torch.atan2(y, p) + 0.5 * H], dim=-1)
+    k = fys / (r2 * p)
+    O = torch.zeros_like(z)
+    J = torch.stack([fxs * z / p2, O, -fxs * x / p2,
+                     -k * x * y, fys * p / r2, -k * z * y], dim=-1).reshape(z.shape + (2, 3))
+    cov2d = J @ cc @ J.transpose(-1, -2)
+    return mean2d, cov2d
+
+
+_PROJ = {"pinhole": _persp_proj, "fisheye": _fisheye_proj, "ortho": _ortho_proj, "spherical": _spherical_proj}
 
 
 def fully_fused_projection(
@@ -148,7 +168,9 @@ def fully_fused_projection(
     Rm = viewmats[:, :3, :3]                                   # [C,3,3]
     tv = viewmats[:, :3, 3]                                    # [C,3]
     mc_all = torch.einsum("cij,nj->cni", Rm, means) + tv[:, None, :]      # [C,N,3]
-    z_all = mc_all[..., 2].detach()
+    # what near / far apply to and what the tile sort orders by: camera-space z; the range for the spherical model
+    depth_all = mc_all.norm(dim=-1) if camera_model == "spherical" else mc_all[..., 2]
+    z_all = depth_all.detach()
     ok = (z_all >= near_plane) & (z_all <= far_plane)          # [C,N]
     ci, ni = torch.where(ok)
     mc = mc_all[ci, ni]                                        # [M,3]
@@ -177,7 +199,7 @@ def fully_fused_projection(
     radii = torch.zeros(C, N, dtype=torch.int32)
     radii[ci, ni] = radius[gi].to(torch.int32)
     means2d = torch.zeros(C, N, 2, dtype=dtype).index_put((ci, ni), mean2d[gi])
-    depths = torch.zeros(C, N, dtype=dtype).index_put((ci, ni), mc[gi, 2])
+    depths = torch.zeros(C, N, dtype=dtype).index_put((ci, ni), depth_all[ci, ni])
     conics = torch.zeros(C, N, 3, dtype=dtype).index_put((ci, ni), conic[gi])
     comps = None
     if calc_compensations:

@@ -39,10 +39,10 @@ __device__ __forceinline__ CamP load_camp(const float *__restrict__ viewmats, co
 __device__ __forceinline__ int cam_model_of(int cm, int c) { return (cm & SO_CAM_PER_VIEW) ? ((cm >> (2 * c)) & 3) : cm; }
 
 static bool camera_model_ok(int cm, int C) {
-  if (!(cm & SO_CAM_PER_VIEW)) return cm >= 0 && cm <= SO_CAM_FISHEYE;
+  if (!(cm & SO_CAM_PER_VIEW)) return cm >= 0 && cm <= SO_CAM_SPHERICAL;
   if (C > SO_CAM_PER_VIEW_MAX) return false;
   for (int c = 0; c < C; ++c)
-    if (((cm >> (2 * c)) & 3) > SO_CAM_FISHEYE) return false;
+    if (((cm >> (2 * c)) & 3) > SO_CAM_SPHERICAL) return false;
   return true;
 }
 

@@ -147,7 +147,7 @@ extern "C" int so_projection_fwd(int C, int N, const float *means, const float *
                                  int camera_model, int32_t *radii, float *means2d, float *depths, float *conics,
                                  float *compensations, void *stream) {
   SO_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, "so_projection_fwd: bad sizes C=%d N=%d %dx%d", C, N, width, height);
-  if (camera_model < 0 || camera_model > SO_CAM_FISHEYE) {
+  if (camera_model < 0 || camera_model > SO_CAM_SPHERICAL) {
     so::set_error("so_projection_fwd: unsupported camera_model %d", camera_model);
     return SO_ERR_UNSUPPORTED;
   }
@@ -168,7 +168,7 @@ extern "C" int so_projection_bwd(int C, int N, const float *means, const float *
                                  const float *v_compensations, float *v_means, float *v_covars6, float *v_quats,
                                  float *v_scales, float *v_viewmats, void *stream) {
   SO_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, "so_projection_bwd: bad sizes");
-  if (camera_model < 0 || camera_model > SO_CAM_FISHEYE) {
+  if (camera_model < 0 || camera_model > SO_CAM_SPHERICAL) {
     so::set_error("so_projection_bwd: unsupported camera_model %d", camera_model);
     return SO_ERR_UNSUPPORTED;
   }

@@ -21,7 +21,14 @@
 
 namespace so {
 
-enum CameraModel : int { CAM_PINHOLE = 0, CAM_ORTHO = 1, CAM_FISHEYE = 2 };
+enum CameraModel : int { CAM_PINHOLE = 0, CAM_ORTHO = 1, CAM_FISHEYE = 2, CAM_SPHERICAL = 3 };
+// CAM_SPHERICAL -- the 360-degree (equirectangular) cameras of the reference's data sets
+// (utils/datasets/opensfm.py:176-193, 430-436 `spherical` / `equirectangular`; app/camera_models.py).  The fork's
+// kernel for it is not part of the reference tree, so this model is DEFINED HERE (parity unpinned):
+//   lon = atan2(x, z), lat = atan2(y, sqrt(x^2 + z^2))   (OpenCV axes: +z forward, +y down)
+//   u = W (lon / 2pi + 1/2),  v = H (lat / pi + 1/2)       -- K is not used (the reference's spherical "K" is not an
+//   intrinsic matrix); depth = |mean_c| (the range: z is negative for half of the sphere), near/far apply to it;
+//   the 2D covariance is the EWA one, J = d(u,v)/d(x,y,z); a splat is not wrapped across the +-pi seam.
 
 constexpr double kShC0 = 0.28209479177387814;
 constexpr double kShC1 = 0.4886025119029199;
@@ -113,6 +120,14 @@ SO_HD void camera_project(int model, const T *mc, T fx, T fy, T cx, T cy, int W,
     J[0] = fx; J[1] = 0; J[2] = 0; J[3] = 0; J[4] = fy; J[5] = 0;
     m2d[0] = fx * x + cx;
     m2d[1] = fy * y + cy;
+  } else if (model == CAM_SPHERICAL) {
+    const T fxs = T(W) * T(0.15915494309189535), fys = T(H) * T(0.3183098861837907);   // W / 2pi, H / pi
+    const T p2 = x * x + z * z + T(1e-12), p = std::sqrt(p2), r2 = p2 + y * y;
+    const T ip2 = T(1) / p2, ir2 = T(1) / r2, k = fys * ir2 / p;
+    m2d[0] = fxs * std::atan2(x, z) + T(0.5) * T(W);
+    m2d[1] = fys * std::atan2(y, p) + T(0.5) * T(H);
+    J[0] = fxs * z * ip2; J[1] = 0; J[2] = -fxs * x * ip2;
+    J[3] = -k * x * y; J[4] = fys * p * ir2; J[5] = -k * z * y;
   } else {  // equidistant fisheye
     const T eps = T(1e-7);
     const T xy_len = std::sqrt(x * x + y * y) + eps;
@@ -140,6 +155,11 @@ template <typename T> SO_HD void project_cov(const T *J, const T *cc, T &a, T &b
   d = JC[3] * J[3] + JC[4] * J[4] + JC[5] * J[5];
 }
 
+// what near / far apply to and what the tile sort orders by: camera-space z, or the range for the spherical model
+template <typename T> SO_HD T camera_depth(int model, const T *mc) {
+  return model == CAM_SPHERICAL ? std::sqrt(mc[0] * mc[0] + mc[1] * mc[1] + mc[2] * mc[2]) : mc[2];
+}
+
 template <typename T> struct ProjOut {
   T m2d[2];
   T depth;
@@ -159,7 +179,8 @@ SO_HD void project_fwd(const T *mean, const T *covar6, const T *quat, const T *s
   T mc[3];
   SO_UNROLL
   for (int i = 0; i < 3; ++i) mc[i] = Rw[3 * i] * mean[0] + Rw[3 * i + 1] * mean[1] + Rw[3 * i + 2] * mean[2] + tw[i];
-  if (mc[2] < near_plane || mc[2] > far_plane) return;
+  const T depth = camera_depth(model, mc);
+  if (depth < near_plane || depth > far_plane) return;
   T cov[9];
   if (covar6) {
     cov[0] = covar6[0]; cov[1] = covar6[1]; cov[2] = covar6[2];
@@ -191,7 +212,7 @@ SO_HD void project_fwd(const T *mean, const T *covar6, const T *quat, const T *s
   const T rdet = T(1) / det;
   o.radius = (int)radius;
   o.m2d[0] = m2d[0]; o.m2d[1] = m2d[1];
-  o.depth = mc[2];
+  o.depth = depth;
   o.conic[0] = d * rdet; o.conic[1] = -b * rdet; o.conic[2] = a * rdet;
   o.comp = comp;
 }
@@ -266,7 +287,7 @@ SO_HD void project_bwd(const T *mean, const T *covar6, const T *quat, const T *s
     for (int j = 0; j < 3; ++j)
       v_J[3 * i + j] = 2 * (VJ[3 * i] * cc[j] + VJ[3 * i + 1] * cc[3 + j] + VJ[3 * i + 2] * cc[6 + j]);
   // camera model VJP -> v_mc
-  T v_mc[3] = {0, 0, v_depth};
+  T v_mc[3] = {0, 0, model == CAM_SPHERICAL ? T(0) : v_depth};
   const T x = mc[0], y = mc[1], z = mc[2];
   if (model == CAM_PINHOLE) {
     const T rz = T(1) / z, rz2 = rz * rz, rz3 = rz2 * rz;
@@ -279,6 +300,34 @@ SO_HD void project_bwd(const T *mean, const T *covar6, const T *quat, const T *s
   } else if (model == CAM_ORTHO) {
     v_mc[0] += fx * v_m2d[0];
     v_mc[1] += fy * v_m2d[1];
+  } else if (model == CAM_SPHERICAL) {
+    // reverse-mode through the spherical forward sequence of camera_project() (+ depth = sqrt(r2))
+    const T fxs = T(W) * T(0.15915494309189535), fys = T(H) * T(0.3183098861837907);
+    const T p2 = x * x + z * z + T(1e-12), p = std::sqrt(p2), r2 = p2 + y * y;
+    const T ip2 = T(1) / p2, ir2 = T(1) / r2, ip = T(1) / p, k = fys * ir2 * ip;
+    T vx = 0, vy = 0, vz = 0, v_ip2 = 0, v_ir2 = 0, v_ip = 0, v_p = 0, v_r2 = 0;
+    // J0 = fxs z ip2 ; J2 = -fxs x ip2
+    vz += fxs * ip2 * v_J[0]; v_ip2 += fxs * z * v_J[0];
+    vx += -fxs * ip2 * v_J[2]; v_ip2 += -fxs * x * v_J[2];
+    // J3 = -k x y ; J5 = -k z y ; J4 = fys p ir2
+    const T v_k = -x * y * v_J[3] - z * y * v_J[5];
+    vx += -k * y * v_J[3]; vy += -k * (x * v_J[3] + z * v_J[5]); vz += -k * y * v_J[5];
+    v_p += fys * ir2 * v_J[4]; v_ir2 += fys * p * v_J[4];
+    // k = fys ir2 ip
+    v_ir2 += fys * ip * v_k; v_ip += fys * ir2 * v_k;
+    // u = fxs atan2(x, z) ; v = fys atan2(y, p)
+    const T v_lon = fxs * v_m2d[0], v_lat = fys * v_m2d[1];
+    vx += z * ip2 * v_lon; vz += -x * ip2 * v_lon;
+    vy += p * ir2 * v_lat; v_p += -y * ir2 * v_lat;
+    // depth = sqrt(r2)
+    v_r2 += T(0.5) * v_depth / std::sqrt(r2);
+    // ip = 1/p ; ir2 = 1/r2 ; ip2 = 1/p2 ; p = sqrt(p2) ; r2 = p2 + y^2 ; p2 = x^2 + z^2
+    v_p += -ip * ip * v_ip;
+    v_r2 += -ir2 * ir2 * v_ir2;
+    T v_p2 = -ip2 * ip2 * v_ip2 + T(0.5) * ip * v_p;
+    v_p2 += v_r2; vy += 2 * y * v_r2;
+    vx += 2 * x * v_p2; vz += 2 * z * v_p2;
+    v_mc[0] += vx; v_mc[1] += vy; v_mc[2] += vz;
   } else {
     // reverse-mode through the fisheye forward sequence of camera_project()
     const T eps = T(1e-7);

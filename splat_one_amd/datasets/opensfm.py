@@ -26,8 +26,8 @@ blindly"):
     it at :486-487); the false northing cancels in the differences either way;
   * the undistortion branch is chosen per camera, not by the model of the last parsed shot (:239);
   * unsupported projection types raise instead of silently mapping to camera id 0.
-The spherical camera keeps the reference's K layout (:188) for callers that inspect it, but the
-rasteriser has no spherical model (fork-only, unspecified), so training on it raises.
+The spherical camera keeps the reference's K layout (:188) for callers that inspect it; the rasteriser's
+`spherical` model (csrc/splat_math.hpp, defined by this build) takes width and height only and ignores that K.
 """
 from __future__ import annotations
 

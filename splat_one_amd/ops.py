@@ -20,7 +20,7 @@ from torch import Tensor
 from . import _lib
 from ._lib import call, ptr, stream
 
-CAMERA_MODELS = {"pinhole": 0, "ortho": 1, "fisheye": 2}
+CAMERA_MODELS = {"pinhole": 0, "ortho": 1, "fisheye": 2, "spherical": 3}    # spherical: defined by this build, see splat_math.hpp
 SUPPORTED_CHANNELS = (1, 2, 3, 4, 5, 8, 9, 16, 17, 32, 33)
 
 
@@ -31,8 +31,7 @@ def _f32(t: Tensor) -> Tensor:
 
 def _camera_model_id(camera_model: str) -> int:
     assert camera_model in CAMERA_MODELS, (
-        f"camera_model must be one of {list(CAMERA_MODELS)}, got {camera_model!r} "
-        "(the gsplat fork's 'spherical' model has no published specification)")
+        f"camera_model must be one of {list(CAMERA_MODELS)}, got {camera_model!r}")
     return CAMERA_MODELS[camera_model]
 
 

@@ -66,8 +66,9 @@ class Config:
     opacity_reg: float = 0.0
     scale_reg: float = 0.0
     global_scale: float = 1.0
-    # reference default "spherical" is fork-only (no specification).  On the fused path also a list with one
-    # name per view of the batch (mixed perspective / fisheye batches)
+    # "pinhole" | "ortho" | "fisheye" | "spherical" (the reference's default, :89: 360-degree equirectangular shots; the
+    # fork's kernel is not in the reference tree, so that model is the one csrc/splat_math.hpp defines -- parity
+    # unpinned).  On the fused path also a list with one name per view of the batch (mixed batches)
     camera_model: str = "pinhole"
     # data / results (gsplat_trainer.py:67-104): consumed by Runner.from_data_dir, eval, render_traj, checkpoints
     ckpt: Optional[List[str]] = None
@@ -249,10 +250,16 @@ class Runner:
         from .datasets import Dataset, Parser
         parser = Parser(data_dir=cfg.data_dir, factor=cfg.data_factor, normalize=cfg.normalize_world_space,
                         test_every=cfg.test_every)
+        # the reference renders every training view with Config.camera_model (:89, default "spherical": its data sets
+        # are 360-degree captures); here the shots' own projection type has to agree with it
         types = {parser.camtype_dict[c] for c in parser.camera_ids}
-        if types != {"perspective"}:
-            raise NotImplementedError(f"camera types {sorted(types)}: only perspective shots can be rasterised "
-                                      "(the fork's spherical camera model has no specification)")
+        if len(types) != 1:
+            raise NotImplementedError(f"camera types {sorted(types)} in one data set: train the perspective and the "
+                                      "spherical shots as separate runs (one camera model per Runner)")
+        want = {"perspective": ("pinhole", "fisheye", "ortho"), "spherical": ("spherical",)}[types.pop()]
+        if cfg.camera_model not in want:
+            raise ValueError(f"Config.camera_model = {cfg.camera_model!r}, but the shots of {cfg.data_dir!r} need one of "
+                             f"{want} (the reference's default is 'spherical', gsplat_trainer.py:89)")
         trainset = Dataset(parser, split="train", patch_size=cfg.patch_size, load_depths=cfg.depth_loss)
         points = rgbs = None
         if cfg.init_type == "sfm":

@@ -254,11 +254,13 @@ def test_remap_and_resize():
     assert flat.shape == (4, 3) and (flat == 9).all()
 
 
-def test_runner_refuses_spherical_scene(tmp_path):
+def test_runner_wants_the_camera_model_of_the_shots(tmp_path):
+    """360-degree shots train with Config.camera_model = "spherical" (the reference's default, gsplat_trainer.py:89);
+    a perspective model on them is refused before anything touches the GPU."""
     from splat_one_amd.trainer import Config, Runner
     _write_scene(tmp_path, spherical=True, images=False, width=256, height=128)
-    with pytest.raises(NotImplementedError, match="spherical"):
-        Runner.from_data_dir(0, 0, 1, Config(data_dir=str(tmp_path), data_factor=1))
+    with pytest.raises(ValueError, match="spherical"):
+        Runner.from_data_dir(0, 0, 1, Config(data_dir=str(tmp_path), data_factor=1, camera_model="pinhole"))
 
 
 # ------------------------------------------------------------------ camera_models.json (reference fixture)

@@ -179,4 +179,35 @@ def test_c5_mixed_batch_f16_attributes(dev):
     with pytest.raises(AssertionError):
         camera_model_code(["pinhole"], 2)
     with pytest.raises(AssertionError):
-        camera_model_code(["pinhole", "spherical"], 2)
+        camera_model_code(["pinhole", "cylindrical"], 2)
+
+
+def test_spherical_views_fused_engine(dev):
+    """The reference's default camera model (gsplat_trainer.py:89): 360-degree equirectangular views, here one from
+    inside the point cloud (Gaussians all around, behind the camera included; depth = range) and one perspective view in
+    the same batch (per-view camera models).  Model defined by this build (csrc/splat_math.hpp) -- checked against the
+    float64 oracle's statement of the same definition."""
+    from splat_one_amd.engine import FusedEngine
+    from splat_one_amd.trainer import Config, Runner
+    W, H, N = 512, 256, 20_000
+    models = ["spherical", "pinhole"]
+    Ks = pinhole_K(W, H)[None].repeat(2, 1, 1).to(dev)
+    r = Runner(0, 0, 1, Config(init_num_pts=N, init_scale=0.1, init_opa=0.5, shN_init_std=0.1, batch_size=2), scene_scale=1.0 / 1.1)
+    with torch.no_grad():
+        r.splats["scales"].add_((torch.randn(N, 3, generator=torch.Generator().manual_seed(9)) * 0.3).to(dev))
+    inside = torch.eye(4)
+    inside[:3, 3] = torch.tensor([0.3, -0.2, 0.1])
+    c2w = torch.stack([inside, front_camera()]).to(dev)
+    pixels = torch.cat([torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(v)) for v in range(2)]).to(dev)
+    eng = FusedEngine(r.splats, r.optimizers, W, H, 2, sh_degree=3, camera_model=models, use_graph=False)
+    eng.set_views(c2w, Ks, pixels)
+    eng.fwd_bwd()
+    assert int((eng.ws["radii"][0] > 0).sum()) > 0.9 * N          # the panorama sees (nearly) everything
+    g_sum, loss_sum = None, 0.0
+    for v, model in enumerate(models):
+        rc_o, g_o, _, (loss_o, _, _) = _oracle_step(r.splats, c2w[v:v + 1], Ks[v:v + 1], W, H, pixels[v:v + 1], camera_model=model)
+        assert (eng.ws["render_colors"][v:v + 1].cpu().double() - rc_o).abs().mean().item() <= 1e-4, model
+        g_sum = g_o if g_sum is None else {k: g_sum[k] + g_o[k] for k in g_o}
+        loss_sum += loss_o
+    assert abs(eng.loss()[0].item() - loss_sum / 2) < 1e-5
+    _check_grads({k: v.grad for k, v in r.splats.items()}, {k: v / 2 for k, v in g_sum.items()})

@@ -16,7 +16,7 @@ FWD_TOL = 1e-4
 GRAD_TOL = 1e-3
 
 
-@pytest.mark.parametrize("camera_model", ["pinhole", "ortho", "fisheye"])
+@pytest.mark.parametrize("camera_model", ["pinhole", "ortho", "fisheye", "spherical"])
 @pytest.mark.parametrize("use_covars", [False, True])
 def test_projection_fwd_bwd(dev, camera_model, use_covars):
     from splat_one_amd.ops import fully_fused_projection

@@ -74,12 +74,16 @@ def test_render_modes(dev, render_mode, X):
              backgrounds=None if bg is None else bg)
 
 
-@pytest.mark.parametrize("camera_model", ["fisheye", "ortho"])
+@pytest.mark.parametrize("camera_model", ["fisheye", "ortho", "spherical"])
 def test_camera_models(dev, camera_model):
     splats, c2w, Ks = make_scene(4000, 128, 96, regime="ref")
     if camera_model == "ortho":
         Ks = Ks.clone()
         Ks[:, 0, 0] = Ks[:, 1, 1] = 14.0
+    if camera_model == "spherical":      # 360 degrees: a second camera INSIDE the cloud (Gaussians behind it, depth = range)
+        inside = torch.eye(4)
+        inside[:3, 3] = torch.tensor([0.3, -0.2, 0.1])
+        c2w, Ks = torch.cat([c2w, inside[None]]), Ks.repeat(2, 1, 1)
     _compare(splats, c2w, Ks, 128, 96, sh_degree=3, camera_model=camera_model)
 
 

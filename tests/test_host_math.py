@@ -23,7 +23,7 @@ def hh():
     return ctypes.CDLL(build())
 
 
-@pytest.mark.parametrize("model_i,model", [(0, "pinhole"), (1, "ortho"), (2, "fisheye")])
+@pytest.mark.parametrize("model_i,model", [(0, "pinhole"), (1, "ortho"), (2, "fisheye"), (3, "spherical")])
 @pytest.mark.parametrize("use_cov", [False, True])
 def test_projection_math_f64(hh, model_i, model, use_cov):
     W, H, N = 96, 64, 600
