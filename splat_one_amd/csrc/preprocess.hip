@@ -38,6 +38,14 @@ __device__ __forceinline__ CamP load_camp(const float *__restrict__ viewmats, co
 // one model for all views, or SO_CAM_PER_VIEW with 2 bits per view
 __device__ __forceinline__ int cam_model_of(int cm, int c) { return (cm & SO_CAM_PER_VIEW) ? ((cm >> (2 * c)) & 3) : cm; }
 
+// does any view use the spherical model?  (the kernels are built with and without it: splat_math.hpp SPH)
+static bool camera_model_has_spherical(int cm, int C) {
+  if (!(cm & SO_CAM_PER_VIEW)) return cm == SO_CAM_SPHERICAL;
+  for (int c = 0; c < C; ++c)
+    if (((cm >> (2 * c)) & 3) == SO_CAM_SPHERICAL) return true;
+  return false;
+}
+
 static bool camera_model_ok(int cm, int C) {
   if (!(cm & SO_CAM_PER_VIEW)) return cm >= 0 && cm <= SO_CAM_SPHERICAL;
   if (C > SO_CAM_PER_VIEW_MAX) return false;
@@ -52,7 +60,7 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 
-template <int DEG, class A>
+template <int DEG, class A, bool SPH>
 __global__ void __launch_bounds__(256)
 k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__restrict__ logit_opac, const A attrs,
                  const float *__restrict__ viewmats,
@@ -82,7 +90,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
     attrs.base(n, q, ls);
     const float s[3] = {expf(ls[0]), expf(ls[1]), expf(ls[2])};
     ProjOut<float> o;
-    project_fwd<float>(mean, nullptr, q, s, cam.Rw, cam.tw, cam.fx, cam.fy, cam.cx, cam.cy, W, H, eps2d, near_plane,
+    project_fwd<float, SPH>(mean, nullptr, q, s, cam.Rw, cam.tw, cam.fx, cam.fy, cam.cx, cam.cy, W, H, eps2d, near_plane,
                        far_plane, radius_clip, cam_model_of(model, c), o);
     radii[idx] = o.radius;
     *reinterpret_cast<float2 *>(means2d + 2 * idx) = make_float2(o.m2d[0], o.m2d[1]);
@@ -214,7 +222,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
 
 // (One wave per SIMD: 256 VGPRs + AGPRs.  Forcing two with __launch_bounds__(256, 2) spills 49 registers
 // and measured slower, 23.1 vs 20.5 us at 100k Gaussians.)
-template <int DEG, class A, bool STAGE, bool ADAM>
+template <int DEG, class A, bool STAGE, bool ADAM, bool SPH>
 __global__ void __launch_bounds__(256)
 k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const float *__restrict__ logit_opac,
                  const A attrs, const float *__restrict__ viewmats,
@@ -290,7 +298,7 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
       } else {
         v_sig += v_op;
       }
-      project_bwd<float>(mean, nullptr, q, s, cam.Rw, cam.tw, cam.fx, cam.fy, cam.cx, cam.cy, W, H, eps2d, cam_model_of(model, c),
+      project_bwd<float, SPH>(mean, nullptr, q, s, cam.Rw, cam.tw, cam.fx, cam.fy, cam.cx, cam.cy, W, H, eps2d, cam_model_of(model, c),
                          v_m2d, v_depths ? v_depths[idx] : 0.f, v_con, v_comp, vm, nullptr, vq, vs, nullptr, nullptr);
       // SH backward (through +0.5 / clamp: the saved colour is 0 exactly where the clamp cut)
       if (!(colors[3 * idx] > 0.f)) vr = 0.f;
@@ -500,8 +508,11 @@ static int preprocess_fwd_impl(const char *what, int C, int N, int K, int sh_deg
   const int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
   const dim3 grid(pp_grid((int64_t)C * N)), block(256);
   hipStream_t st = as_stream(stream);
+  const bool sph = camera_model_has_spherical(camera_model, C);
 #define SO_LAUNCH(D)                                                                                               \
-  hipLaunchKernelGGL((k_preprocess_fwd<D, A>), grid, block, 0, st, C, N, means, logit_opacities, attrs, viewmats,  \
+  if (sph) SO_LAUNCH_(D, true); else SO_LAUNCH_(D, false)
+#define SO_LAUNCH_(D, S)                                                                                           \
+  hipLaunchKernelGGL((k_preprocess_fwd<D, A, S>), grid, block, 0, st, C, N, means, logit_opacities, attrs, viewmats,  \
                      Ks, width, height, eps2d, near_plane, far_plane, radius_clip, camera_model, antialiased,      \
                      (float)tile_size, tile_w, tile_h, radii, means2d, depths, conics, opacities, colors,          \
                      tiles_per_gauss, tile_counts, reinterpret_cast<float4 *>(rec), reinterpret_cast<float4 *>(vrec), \
@@ -514,6 +525,7 @@ static int preprocess_fwd_impl(const char *what, int C, int N, int K, int sh_deg
     default: SO_LAUNCH(4); break;
   }
 #undef SO_LAUNCH
+#undef SO_LAUNCH_
   return check_launch(what);
 }
 
@@ -559,21 +571,24 @@ static int preprocess_bwd_impl(const char *what, int C, int N, int K, int sh_deg
     }
     SO_REQUIRE((bits & 15) == 0 && fuse->hyper, "%s: fused Adam: tensors must be 16-byte aligned, hyper non-null", what);
   }
+  const bool sph = camera_model_has_spherical(camera_model, C);
 #define SO_LAUNCH(D)                                                                                              \
+  if (sph) { SO_LAUNCH_(D, true); } else { SO_LAUNCH_(D, false); }
+#define SO_LAUNCH_(D, S)                                                                                          \
   if (fuse)                                                                                                       \
-    hipLaunchKernelGGL((k_preprocess_bwd<D, A, true, true>), grid, block, stage_bytes, st, C, N, K, means, logit_opacities, attrs, \
+    hipLaunchKernelGGL((k_preprocess_bwd<D, A, true, true, S>), grid, block, stage_bytes, st, C, N, K, means, logit_opacities, attrs, \
                      viewmats, Ks, width, height, eps2d, camera_model, antialiased, radii, opacities, colors,     \
                      v_means2d, v_means2d_abs, v_depths, v_conics, v_colors, v_opacities, opacity_reg, scale_reg, \
                      v_means, v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN, grad2d, count, sx, sy,      \
                      reinterpret_cast<const float4 *>(vrec), absgrad_stats, cam_stride, skip_flag, skip_out, *fuse); \
   else if (stage)                                                                                                 \
-    hipLaunchKernelGGL((k_preprocess_bwd<D, A, true, false>), grid, block, stage_bytes, st, C, N, K, means, logit_opacities, attrs, \
+    hipLaunchKernelGGL((k_preprocess_bwd<D, A, true, false, S>), grid, block, stage_bytes, st, C, N, K, means, logit_opacities, attrs, \
                      viewmats, Ks, width, height, eps2d, camera_model, antialiased, radii, opacities, colors,     \
                      v_means2d, v_means2d_abs, v_depths, v_conics, v_colors, v_opacities, opacity_reg, scale_reg, \
                      v_means, v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN, grad2d, count, sx, sy,      \
                      reinterpret_cast<const float4 *>(vrec), absgrad_stats, cam_stride, skip_flag, skip_out, AdamFuse{}); \
   else                                                                                                            \
-  hipLaunchKernelGGL((k_preprocess_bwd<D, A, false, false>), grid, block, 0, st, C, N, K, means, logit_opacities, attrs, \
+  hipLaunchKernelGGL((k_preprocess_bwd<D, A, false, false, S>), grid, block, 0, st, C, N, K, means, logit_opacities, attrs, \
                      viewmats, Ks, width, height, eps2d, camera_model, antialiased, radii, opacities, colors,     \
                      v_means2d, v_means2d_abs, v_depths, v_conics, v_colors, v_opacities, opacity_reg, scale_reg, \
                      v_means, v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN, grad2d, count, sx, sy,      \
@@ -586,6 +601,7 @@ static int preprocess_bwd_impl(const char *what, int C, int N, int K, int sh_deg
     default: SO_LAUNCH(4); break;
   }
 #undef SO_LAUNCH
+#undef SO_LAUNCH_
   return check_launch(what);
 }
 

@@ -96,7 +96,9 @@ template <typename T> struct CamAux {   // what the backward needs again
   bool clamp_x, clamp_y;
 };
 
-template <typename T>
+// SPH = false compiles the spherical model out (its reverse mode costs the fused backward kernel registers: the
+// launchers pick that variant when no view of the step is spherical).
+template <typename T, bool SPH = true>
 SO_HD void camera_project(int model, const T *mc, T fx, T fy, T cx, T cy, int W, int H, T *m2d, CamAux<T> &aux) {
   const T x = mc[0], y = mc[1], z = mc[2];
   T *J = aux.J;
@@ -120,7 +122,7 @@ SO_HD void camera_project(int model, const T *mc, T fx, T fy, T cx, T cy, int W,
     J[0] = fx; J[1] = 0; J[2] = 0; J[3] = 0; J[4] = fy; J[5] = 0;
     m2d[0] = fx * x + cx;
     m2d[1] = fy * y + cy;
-  } else if (model == CAM_SPHERICAL) {
+  } else if (SPH && model == CAM_SPHERICAL) {
     const T fxs = T(W) * T(0.15915494309189535), fys = T(H) * T(0.3183098861837907);   // W / 2pi, H / pi
     const T p2 = x * x + z * z + T(1e-12), p = std::sqrt(p2), r2 = p2 + y * y;
     const T ip2 = T(1) / p2, ir2 = T(1) / r2, k = fys * ir2 / p;
@@ -156,8 +158,8 @@ template <typename T> SO_HD void project_cov(const T *J, const T *cc, T &a, T &b
 }
 
 // what near / far apply to and what the tile sort orders by: camera-space z, or the range for the spherical model
-template <typename T> SO_HD T camera_depth(int model, const T *mc) {
-  return model == CAM_SPHERICAL ? std::sqrt(mc[0] * mc[0] + mc[1] * mc[1] + mc[2] * mc[2]) : mc[2];
+template <typename T, bool SPH = true> SO_HD T camera_depth(int model, const T *mc) {
+  return (SPH && model == CAM_SPHERICAL) ? std::sqrt(mc[0] * mc[0] + mc[1] * mc[1] + mc[2] * mc[2]) : mc[2];
 }
 
 template <typename T> struct ProjOut {
@@ -170,7 +172,7 @@ template <typename T> struct ProjOut {
 
 // Full forward for one (camera, Gaussian).  Rw/tw: rotation (row-major 3x3) and translation of
 // the world->camera matrix.  `covar6` (xx,xy,xz,yy,yz,zz) is used when non-null, else quat/scale.
-template <typename T>
+template <typename T, bool SPH = true>
 SO_HD void project_fwd(const T *mean, const T *covar6, const T *quat, const T *scale, const T *Rw, const T *tw,
                        T fx, T fy, T cx, T cy, int W, int H, T eps2d, T near_plane, T far_plane,
                        T radius_clip, int model, ProjOut<T> &o) {
@@ -179,7 +181,7 @@ SO_HD void project_fwd(const T *mean, const T *covar6, const T *quat, const T *s
   T mc[3];
   SO_UNROLL
   for (int i = 0; i < 3; ++i) mc[i] = Rw[3 * i] * mean[0] + Rw[3 * i + 1] * mean[1] + Rw[3 * i + 2] * mean[2] + tw[i];
-  const T depth = camera_depth(model, mc);
+  const T depth = camera_depth<T, SPH>(model, mc);
   if (depth < near_plane || depth > far_plane) return;
   T cov[9];
   if (covar6) {
@@ -195,7 +197,7 @@ SO_HD void project_fwd(const T *mean, const T *covar6, const T *quat, const T *s
   mat3_mul_bt(tmp, Rw, cc);
   CamAux<T> aux;
   T m2d[2];
-  camera_project(model, mc, fx, fy, cx, cy, W, H, m2d, aux);
+  camera_project<T, SPH>(model, mc, fx, fy, cx, cy, W, H, m2d, aux);
   T a, b, d;
   project_cov(aux.J, cc, a, b, d);
   const T det_orig = a * d - b * b;
@@ -221,7 +223,7 @@ SO_HD void project_fwd(const T *mean, const T *covar6, const T *quat, const T *s
 // Inputs v_m2d[2], v_depth, v_conic[3], v_comp (0 if unused).  Accumulates (+=) into
 // v_mean[3], and either v_covar6[6] (covar6 != null) or v_quat[4], v_scale[3]; optionally into
 // v_Rw[9], v_tw[3] (world->camera rotation / translation) when v_Rw != null.
-template <typename T>
+template <typename T, bool SPH = true>
 SO_HD void project_bwd(const T *mean, const T *covar6, const T *quat, const T *scale, const T *Rw, const T *tw,
                        T fx, T fy, T cx, T cy, int W, int H, T eps2d, int model,
                        const T *v_m2d, T v_depth, const T *v_conic, T v_comp,
@@ -242,7 +244,7 @@ SO_HD void project_bwd(const T *mean, const T *covar6, const T *quat, const T *s
   mat3_mul_bt(tmp, Rw, cc);
   CamAux<T> aux;
   T m2d[2];
-  camera_project(model, mc, fx, fy, cx, cy, W, H, m2d, aux);
+  camera_project<T, SPH>(model, mc, fx, fy, cx, cy, W, H, m2d, aux);
   const T *J = aux.J;
   T a0, b, d0;
   project_cov(J, cc, a0, b, d0);
@@ -287,7 +289,7 @@ SO_HD void project_bwd(const T *mean, const T *covar6, const T *quat, const T *s
     for (int j = 0; j < 3; ++j)
       v_J[3 * i + j] = 2 * (VJ[3 * i] * cc[j] + VJ[3 * i + 1] * cc[3 + j] + VJ[3 * i + 2] * cc[6 + j]);
   // camera model VJP -> v_mc
-  T v_mc[3] = {0, 0, model == CAM_SPHERICAL ? T(0) : v_depth};
+  T v_mc[3] = {0, 0, (SPH && model == CAM_SPHERICAL) ? T(0) : v_depth};
   const T x = mc[0], y = mc[1], z = mc[2];
   if (model == CAM_PINHOLE) {
     const T rz = T(1) / z, rz2 = rz * rz, rz3 = rz2 * rz;
@@ -300,7 +302,7 @@ SO_HD void project_bwd(const T *mean, const T *covar6, const T *quat, const T *s
   } else if (model == CAM_ORTHO) {
     v_mc[0] += fx * v_m2d[0];
     v_mc[1] += fy * v_m2d[1];
-  } else if (model == CAM_SPHERICAL) {
+  } else if (SPH && model == CAM_SPHERICAL) {
     // reverse-mode through the spherical forward sequence of camera_project() (+ depth = sqrt(r2))
     const T fxs = T(W) * T(0.15915494309189535), fys = T(H) * T(0.3183098861837907);
     const T p2 = x * x + z * z + T(1e-12), p = std::sqrt(p2), r2 = p2 + y * y;

@@ -100,14 +100,16 @@ def test_per_view_camera_models_and_f16_rows_validate_without_a_gpu():
     from splat_one_amd.ops import SO_CAM_PER_VIEW, camera_model_code
     assert camera_model_code("pinhole", 3) == 0 and camera_model_code(["fisheye"] * 4, 4) == 2
     assert camera_model_code(["pinhole", "fisheye", "ortho"], 3) == SO_CAM_PER_VIEW | (0 << 0) | (2 << 2) | (1 << 4)
-    for bad, nv in ((["pinhole"], 2), (["pinhole", "spherical"], 2), (["pinhole", "fisheye"] * 8, 16)):
+    assert camera_model_code("spherical", 1) == 3 and camera_model_code(["spherical", "pinhole"], 2) == SO_CAM_PER_VIEW | 3
+    for bad, nv in ((["pinhole"], 2), (["pinhole", "cylindrical"], 2), (["pinhole", "fisheye"] * 8, 16)):
         with pytest.raises(AssertionError):
             camera_model_code(bad, nv)
     lib = _lib.load()
     assert [lib.so_attr_rec_stride(k) for k in (0, 1, 4, 9, 16, 25)] == [0, 32, 48, 80, 112, 176]
-    # a per-view code with a model id that does not exist, and more views than the code can carry: refused
+    # a model id that does not exist (the four 2-bit per-view values are all taken), and more views than the code can
+    # carry: refused
     with pytest.raises(RuntimeError, match="camera_model"):
-        _lib.call("so_preprocess_fwd", 2, 4, 16, 3, *([1] * 8), 16, 16, 0.3, 0.01, 1e8, 0.0, SO_CAM_PER_VIEW | (3 << 2), 0, 16,
+        _lib.call("so_preprocess_fwd", 2, 4, 16, 3, *([1] * 8), 16, 16, 0.3, 0.01, 1e8, 0.0, 4, 0, 16,
                   *([1] * 7), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
     with pytest.raises(RuntimeError, match="camera_model"):
         _lib.call("so_preprocess_fwd", 16, 4, 16, 3, *([1] * 8), 16, 16, 0.3, 0.01, 1e8, 0.0, SO_CAM_PER_VIEW, 0, 16,
