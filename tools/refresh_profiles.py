@@ -17,7 +17,8 @@ for a, b in pairs:
 d = json.load(open(os.path.join(dst, f"{tag}_engine_pmc_traffic.json")))
 names = {"so_rasterize_bwd": "void so::k_rasterize_bwd<3, 16, false, true>", "so_rasterize_fwd": "void so::k_rasterize_fwd<3, 16, true>",
          "so_adam_step_dev": "so::k_adam_dev", "so_ssim_l1_fwd": "void so::k_ssim_l1_fwd<3>", "so_ssim_l1_bwd": "void so::k_ssim_l1_bwd<3>",
-         "so_preprocess_fwd": "void so::k_preprocess_fwd<3, so::AttrSoA>", "so_preprocess_bwd": "void so::k_preprocess_bwd<3, so::AttrSoA, true, true>"}
+         "so_preprocess_fwd": "void so::k_preprocess_fwd<3, so::AttrSoA, false>",
+         "so_preprocess_bwd": "void so::k_preprocess_bwd<3, so::AttrSoA, true, true, false>"}
 out = {k: d[v]["hbm_bytes_per_launch_corrected"] for k, v in names.items() if v in d}
 out["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_pmc.sh), KB -> bytes, FETCH_SIZE doubled as "
                 "MI355X_MICROARCH.md prescribes for gfx950; source profiles/%s_engine_pmc_traffic.json" % tag)
