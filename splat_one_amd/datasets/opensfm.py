@@ -441,7 +441,7 @@ class Dataset:
         data = {
             "K": torch.from_numpy(K).float(),
             "camtoworld": torch.from_numpy(p.camtoworlds[g]).float(),
-            "image": torch.from_numpy(np.ascontiguousarray(image)).float(),
+            "image": torch.from_numpy(np.require(image, requirements=["C", "W"])).float(),   # copies only a read-only decode
             "image_id": item,
             "image_name": img.name,
         }

@@ -158,3 +158,35 @@ def test_pose_opt_training_and_checkpoint(dev, tmp_path):
     assert "pose_adjust" in ck and torch.equal(ck["pose_adjust"]["embeds.weight"].to(w.device), w)
     lr = r.pose_optimizers[0].param_groups[0]["lr"]
     assert abs(lr - 1e-3 * (0.01 ** (6 / 6))) < 1e-9
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_runner_trains_a_spherical_data_set(dev, tmp_path, fused):
+    """The reference's default: 360-degree shots (`projection_type: spherical`, opensfm.py:176-193) rendered with
+    Config.camera_model = "spherical" (gsplat_trainer.py:89).  Parser -> Dataset (no undistortion, the fork's K layout) ->
+    training step -> eval, through both step implementations; the panorama sees the whole point cloud."""
+    from splat_one_amd.trainer import Runner
+    d = tmp_path / "scene"
+    os.makedirs(d, exist_ok=True)
+    Wp, Hp = 128, 64
+    yy, xx = np.meshgrid(np.linspace(0, 1, Hp), np.linspace(0, 1, Wp), indexing="ij")
+
+    def image_fn(name):
+        k = int(name.split("_")[1].split(".")[0])
+        return (np.stack([xx, yy, 0.5 + 0.5 * np.sin(6 * xx + 0.3 * k)], -1) * 255).astype(np.uint8)
+
+    write_opensfm_scene(d, image_fn=image_fn, spherical=True, width=Wp, height=Hp)
+    cfg = _cfg(tmp_path, fused=fused, camera_model="spherical")
+    r = Runner.from_data_dir(0, 0, 1, cfg)
+    assert {r.parser.camtype_dict[c] for c in r.parser.camera_ids} == {"spherical"}
+    r.train()
+    assert r.step == 12
+    info = r.last_info
+    radii = info["radii"] if "radii" in info else info["engine"].ws["radii"]
+    assert int((radii > 0).sum()) >= 190                      # 200 SfM points all around the camera: (nearly) all visible
+    st = json.load(open(f"{cfg.result_dir}/stats/val_step0005.json"))
+    assert np.isfinite(st["psnr"]) and st["num_GS"] == 200
+    frame = r._viewer_render_fn((r.parser.camtoworlds[0], np.eye(3)), (Wp, Hp), camera_model="spherical")
+    assert frame.shape == (Hp, Wp, 3) and np.isfinite(frame).all() and frame.max() > 0
+    with pytest.raises(ValueError, match="spherical"):
+        Runner.from_data_dir(0, 0, 1, _cfg(tmp_path, camera_model="pinhole"))
