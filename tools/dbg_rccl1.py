@@ -1,0 +1,77 @@
+"""The RCCL (backend "nccl") branches of the multi-GPU code with a process group of ONE rank on the one GPU of the box:
+every collective degenerates to a copy, but the calls, dtypes, split arguments and stream ordering are the ones the
+8-GPU runs issue (the two-rank tests use gloo, whose branches stage through the host)."""
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29533")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+dev = torch.device("cuda:0")
+print("backend", dist.get_backend(), flush=True)
+
+from splat_one_amd import distributed as sdist, rasterization                       # noqa: E402
+from splat_one_amd.rendering import _AllToAllRows, _gather_cameras                   # noqa: E402
+from splat_one_amd.scene import make_scene, pinhole_K, ring_cameras                  # noqa: E402
+from splat_one_amd.sharded import ShardedEngine, all_to_all_rows                     # noqa: E402
+from splat_one_amd.trainer import Config, Runner                                     # noqa: E402
+
+# collectives of the helpers
+x = torch.arange(48, dtype=torch.float32, device=dev).reshape(3, 16)
+y = torch.empty_like(x)
+all_to_all_rows(y, x)
+assert torch.equal(x, y)
+inp = torch.randn(5, 4, device=dev, requires_grad=True)
+got = _AllToAllRows.apply(inp, [5], [5])
+(got * 2).sum().backward()
+assert torch.equal(got, inp.detach()) and torch.equal(inp.grad, torch.full_like(inp, 2.0))
+N_world, vm, ks = _gather_cameras(7, torch.eye(4, device=dev)[None], torch.eye(3, device=dev)[None])
+assert N_world == [7] and vm.shape == (1, 4, 4) and ks.shape == (1, 3, 3)
+ps = [torch.nn.Parameter(torch.zeros(4, 3, device=dev)), torch.nn.Parameter(torch.zeros(4, device=dev))]
+for p in ps:
+    p.grad = torch.ones_like(p)
+red = sdist.GradientReducer()
+red._flat = None
+# world 1: reduce() returns early; call the collective itself
+flat = torch.ones(16, device=dev)
+dist.all_reduce(flat)
+sdist.all_reduce_strategy_state({"grad2d": torch.ones(4, device=dev), "count": torch.ones(4, device=dev)})
+print("helpers ok", flush=True)
+
+# rasterization(distributed=True) == the plain call when the group has one rank
+W, H, N = 128, 96, 1500
+splats, c2w, Ks = make_scene(N, W, H, "ref", n_views=2)
+args = [splats["means"], splats["quats"], splats["scales"].exp(), splats["opacities"].sigmoid(),
+        torch.cat([splats["sh0"], splats["shN"]], 1)]
+args = [a.to(dev) for a in args] + [torch.linalg.inv(c2w).to(dev), Ks.to(dev), W, H]
+rc0, ra0, _ = rasterization(*args, sh_degree=3, packed=False)
+rc1, ra1, m1 = rasterization(*args, sh_degree=3, packed=False, distributed=True)
+assert torch.equal(rc0, rc1) and torch.equal(ra0, ra1) and m1["n_cameras"] == 2
+print("distributed operator ok", flush=True)
+
+# the sharded engine over RCCL (its all-to-alls, capacity probe, flag kernels, workspace collectives)
+cfg = Config(init_num_pts=20000, init_scale=0.1, init_opa=0.5, shN_init_std=0.1, sh_degree_interval=1, fused=True)
+r = Runner(0, 0, 1, cfg, scene_scale=1.0 / 1.1)
+Wb, Hb = 640, 360
+eng = ShardedEngine(r.splats, r.optimizers, Wb, Hb, 0, 1, sh_degree=3)
+cam = ring_cameras(8)[:1].to(dev)
+K1 = pinhole_K(Wb, Hb)[None].to(dev)
+px = torch.rand(1, Hb, Wb, 3, device=dev)
+before = r.splats["means"].detach().clone()
+t0 = time.time()
+for _ in range(20):
+    eng.step(cam, K1, px)
+torch.cuda.synchronize()
+st = eng.stats()
+assert st["overflow"] == 0 and st["n_isects"] > 0 and not torch.equal(before, r.splats["means"].detach())
+assert torch.isfinite(eng.loss()).all()
+print(f"sharded engine over RCCL ok: {st}, {(time.time() - t0) / 20 * 1e3:.3f} ms/step", flush=True)
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL-1 OK")
