@@ -68,8 +68,10 @@ class Config:
     global_scale: float = 1.0
     # "pinhole" | "ortho" | "fisheye" | "spherical" (the reference's default, :89: 360-degree equirectangular shots; the
     # fork's kernel is not in the reference tree, so that model is the one csrc/splat_math.hpp defines -- parity
-    # unpinned).  On the fused path also a list with one name per view of the batch (mixed batches)
-    camera_model: str = "pinhole"
+    # unpinned).  On the fused path also a list with one name per view of the batch (mixed batches).
+    # None (default): what the shots of Config.data_dir are -- "spherical" for 360-degree shots (= the reference's
+    # default on its own data sets), "pinhole" for perspective shots and for synthetic views
+    camera_model: Optional[str] = None
     # data / results (gsplat_trainer.py:67-104): consumed by Runner.from_data_dir, eval, render_traj, checkpoints
     ckpt: Optional[List[str]] = None
     render_traj_path: str = "interp"
@@ -87,6 +89,22 @@ class Config:
     pose_opt_lr: float = 1e-5
     pose_opt_reg: float = 1e-6
     pose_noise: float = 0.0
+    # accepted so that the reference's Config(...) calls keep working (app/gsplat_manager.py:43-48 passes
+    # disable_viewer=True): the viewer server, TensorBoard and LPIPS are outside this path and ignored; the appearance /
+    # bilateral-grid / compression branches are refused by Runner when switched on (gsplat_trainer.py:106-112, 157-182)
+    disable_viewer: bool = False
+    port: int = 8080
+    compression: Optional[str] = None
+    app_opt: bool = False
+    app_embed_dim: int = 16
+    app_opt_lr: float = 1e-3
+    app_opt_reg: float = 1e-6
+    use_bilateral_grid: bool = False
+    bilateral_grid_shape: Tuple[int, int, int] = (16, 16, 8)
+    depth_lambda: float = 1e-2
+    tb_every: int = 100
+    tb_save_image: bool = False
+    lpips_net: str = "alex"
     # extensions of this build
     isect_capacity: Optional[int] = None   # preallocated intersections -> no host sync in the step
     fused: bool = False                    # FusedEngine: whole step in two C-ABI calls, hipGraph replay
@@ -194,6 +212,21 @@ class Runner:
         self.cfg = cfg
         self.world_rank, self.local_rank, self.world_size = world_rank, local_rank, world_size
         self.device = f"cuda:{local_rank}"
+        for name in ("app_opt", "use_bilateral_grid", "compression"):
+            if getattr(cfg, name):
+                raise NotImplementedError(f"Config.{name}: the appearance / bilateral-grid / compression branches of the "
+                                          "reference trainer are outside the rasterisation path this package replaces")
+        # Runner(local_rank, world_rank, world_size, cfg) on a data directory, as the reference's constructor (:308-324)
+        # and app/gsplat_manager.py:49 call it: parse cfg.data_dir, split train / val, scene scale and SfM points
+        import os
+        if views is None and points is None and os.path.isfile(os.path.join(cfg.data_dir, "reconstruction.json")):
+            self.parser, self.trainset, points, rgbs = self._load_data_dir(cfg)
+            from .datasets import Dataset
+            self.valset = Dataset(self.parser, split="val")
+            self.allset = Dataset(self.parser, split="all")
+            views, scene_scale = self.trainset, self.parser.scene_scale
+        if cfg.camera_model is None:
+            cfg.camera_model = "pinhole"
         self.views = views if views is not None else []
         self.scene_scale = scene_scale * 1.1 * cfg.global_scale          # gsplat_trainer.py:322
         self.sharded = (world_size > 1 and cfg.fused and cfg.dp_mode == "gaussian_sharded" and cfg.batch_size == 1
@@ -243,10 +276,9 @@ class Runner:
         self.last_info: Optional[dict] = None
 
     # ------------------------------------------------------------------------------ :308-324
-    @classmethod
-    def from_data_dir(cls, local_rank: int, world_rank: int, world_size: int, cfg: Config) -> "Runner":
-        """The reference's constructor path: parse cfg.data_dir, split train/val, take scene_scale and
-        (init_type "sfm") the point cloud from the parser."""
+    @staticmethod
+    def _load_data_dir(cfg: Config):
+        """(parser, trainset, points, rgbs) of cfg.data_dir; resolves / checks Config.camera_model against the shots."""
         from .datasets import Dataset, Parser
         parser = Parser(data_dir=cfg.data_dir, factor=cfg.data_factor, normalize=cfg.normalize_world_space,
                         test_every=cfg.test_every)
@@ -257,6 +289,8 @@ class Runner:
             raise NotImplementedError(f"camera types {sorted(types)} in one data set: train the perspective and the "
                                       "spherical shots as separate runs (one camera model per Runner)")
         want = {"perspective": ("pinhole", "fisheye", "ortho"), "spherical": ("spherical",)}[types.pop()]
+        if cfg.camera_model is None:
+            cfg.camera_model = want[0]
         if cfg.camera_model not in want:
             raise ValueError(f"Config.camera_model = {cfg.camera_model!r}, but the shots of {cfg.data_dir!r} need one of "
                              f"{want} (the reference's default is 'spherical', gsplat_trainer.py:89)")
@@ -265,13 +299,17 @@ class Runner:
         if cfg.init_type == "sfm":
             points = torch.from_numpy(parser.points).float()
             rgbs = torch.from_numpy(parser.points_rgb / 255.0).float()
-        self = cls(local_rank, world_rank, world_size, cfg, views=trainset, scene_scale=parser.scene_scale,
-                   points=points, rgbs=rgbs)
-        self.parser = parser
-        self.trainset = trainset
-        self.valset = Dataset(parser, split="val")
-        self.allset = Dataset(parser, split="all")
-        return self
+        return parser, trainset, points, rgbs
+
+    @classmethod
+    def from_data_dir(cls, local_rank: int, world_rank: int, world_size: int, cfg: Config) -> "Runner":
+        """The reference's constructor path (:308-324) under an explicit name: parse cfg.data_dir, split train/val, take
+        scene_scale and (init_type "sfm") the point cloud from the parser.  `Runner(local_rank, world_rank, world_size,
+        cfg)` does the same whenever cfg.data_dir holds a reconstruction.json."""
+        import os
+        if not os.path.isfile(os.path.join(cfg.data_dir, "reconstruction.json")):
+            raise FileNotFoundError(f"{cfg.data_dir!r} holds no reconstruction.json")
+        return cls(local_rank, world_rank, world_size, cfg)
 
     def _result_dirs(self):
         import os

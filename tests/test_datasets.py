@@ -261,6 +261,19 @@ def test_runner_wants_the_camera_model_of_the_shots(tmp_path):
     _write_scene(tmp_path, spherical=True, images=False, width=256, height=128)
     with pytest.raises(ValueError, match="spherical"):
         Runner.from_data_dir(0, 0, 1, Config(data_dir=str(tmp_path), data_factor=1, camera_model="pinhole"))
+    with pytest.raises(ValueError, match="spherical"):          # the reference's own constructor call (:308-324)
+        Runner(local_rank=0, world_rank=0, world_size=1, cfg=Config(data_dir=str(tmp_path), data_factor=1, camera_model="fisheye"))
+    with pytest.raises(FileNotFoundError):
+        Runner.from_data_dir(0, 0, 1, Config(data_dir=str(tmp_path / "nowhere")))
+    # the Config surface of the reference (app/gsplat_manager.py:43-48 passes disable_viewer); branches outside the
+    # rasterisation path are refused when switched on, before anything touches the GPU
+    cfg = Config(data_dir=str(tmp_path), result_dir=str(tmp_path / "results"), disable_viewer=True, max_steps=30000)
+    assert cfg.camera_model is None and cfg.port == 8080 and cfg.lpips_net == "alex" and cfg.depth_lambda == 1e-2
+    for name in ("app_opt", "use_bilateral_grid"):
+        with pytest.raises(NotImplementedError, match=name):
+            Runner(0, 0, 1, Config(**{name: True}))
+    with pytest.raises(NotImplementedError, match="compression"):
+        Runner(0, 0, 1, Config(compression="png"))
 
 
 # ------------------------------------------------------------------ camera_models.json (reference fixture)

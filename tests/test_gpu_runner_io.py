@@ -176,9 +176,10 @@ def test_runner_trains_a_spherical_data_set(dev, tmp_path, fused):
         return (np.stack([xx, yy, 0.5 + 0.5 * np.sin(6 * xx + 0.3 * k)], -1) * 255).astype(np.uint8)
 
     write_opensfm_scene(d, image_fn=image_fn, spherical=True, width=Wp, height=Hp)
-    cfg = _cfg(tmp_path, fused=fused, camera_model="spherical")
-    r = Runner.from_data_dir(0, 0, 1, cfg)
-    assert {r.parser.camtype_dict[c] for c in r.parser.camera_ids} == {"spherical"}
+    cfg = _cfg(tmp_path, fused=fused, disable_viewer=True)         # camera_model left at its default, as the GUI does
+    r = Runner(local_rank=0, world_rank=0, world_size=1, cfg=cfg)  # app/gsplat_manager.py:43-49
+    assert cfg.camera_model == "spherical" and {r.parser.camtype_dict[c] for c in r.parser.camera_ids} == {"spherical"}
+    assert r.allset.get_data_by_image_name("img_003.png")["image"].shape == (Hp, Wp, 3)
     r.train()
     assert r.step == 12
     info = r.last_info
