@@ -312,6 +312,37 @@ def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor, masks
     return out.reshape(lead + (3,))
 
 
+def _eval_sh_bases_fast(basis_dim: int, dirs: Tensor) -> Tensor:
+    """Real SH basis values Y_k(dir) for the first `basis_dim` in {1, 4, 9, 16, 25} functions, 3DGS sign convention,
+    for UNIT `dirs[..., 3]` -> [..., basis_dim].  Drop-in for `gsplat.cuda._torch_impl._eval_sh_bases_fast`, which the
+    reference's appearance module imports (/root/reference/utils/gsplat_utils/utils.py:91, 107).  Elementwise torch
+    arithmetic on whatever device `dirs` lives on, differentiable by autograd like the function it replaces (the colour
+    path proper evaluates the basis inside so_sh_fwd / so_preprocess_fwd)."""
+    assert basis_dim in (1, 4, 9, 16, 25), f"basis_dim {basis_dim}: (degree + 1)^2 for degree 0..4 expected"
+    assert dirs.shape[-1] == 3, dirs.shape
+    x, y, z = dirs.unbind(-1)
+    out = [torch.full_like(x, 0.2820947917738781)]
+    if basis_dim > 1:
+        c1 = 0.48860251190292
+        out += [-c1 * y, c1 * z, -c1 * x]
+    if basis_dim > 4:
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        out += [1.092548430592079 * xy, -1.092548430592079 * yz, 0.9461746957575601 * zz - 0.3153915652525201,
+                -1.092548430592079 * xz, 0.5462742152960395 * (xx - yy)]
+    if basis_dim > 9:
+        out += [-0.5900435899266435 * y * (3 * xx - yy), 2.890611442640554 * xy * z,
+                -0.4570457994644658 * y * (5 * zz - 1), 0.3731763325901154 * z * (5 * zz - 3),
+                -0.4570457994644658 * x * (5 * zz - 1), 1.445305721320277 * z * (xx - yy),
+                -0.5900435899266435 * x * (xx - 3 * yy)]
+    if basis_dim > 16:
+        out += [2.5033429417967046 * xy * (xx - yy), -1.7701307697799304 * yz * (3 * xx - yy),
+                0.9461746957575601 * xy * (7 * zz - 1), -0.6690465435572892 * yz * (7 * zz - 3),
+                0.10578554691520431 * (zz * (35 * zz - 30) + 3), -0.6690465435572892 * xz * (7 * zz - 3),
+                0.47308734787878004 * (xx - yy) * (7 * zz - 1), -1.7701307697799304 * xz * (xx - 3 * yy),
+                0.6258357354491761 * (xx * (xx - 3 * yy) - yy * (3 * xx - yy))]
+    return torch.stack(out, dim=-1)
+
+
 # ---------------------------------------------------------------------------------------------
 # K6-K8 tile binning / sort / offsets  (non-differentiable)
 # ---------------------------------------------------------------------------------------------

@@ -104,3 +104,27 @@ def test_sh_bases_and_derivatives(hh, deg):
     Yo = O.eval_sh_bases(deg, dd)
     J = torch.stack([torch.autograd.grad(Yo[:, k].sum() + 0 * dd.sum(), dd, retain_graph=True)[0] for k in range(nb)], 1)
     assert (Y - Yo).abs().max() < 1e-14 and (dY - J).abs().max() < 1e-13
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3, 4])
+def test_eval_sh_bases_fast_matches_the_oracle_basis(deg):
+    """`_eval_sh_bases_fast` (the import of the reference's appearance module, utils.py:91, 107): the same real SH basis
+    as the oracle's on unit directions, differentiable."""
+    from splat_one_amd.ops import _eval_sh_bases_fast
+    g = torch.Generator().manual_seed(deg)
+    d = torch.randn(500, 3, generator=g, dtype=torch.float64)
+    d = (d / d.norm(dim=-1, keepdim=True)).requires_grad_()
+    got = _eval_sh_bases_fast((deg + 1) ** 2, d)
+    want = O.eval_sh_bases(deg, d.detach())
+    assert got.shape == (500, (deg + 1) ** 2) and (got.detach() - want).abs().max() < 1e-14
+    with pytest.raises(AssertionError):
+        _eval_sh_bases_fast(5, d)
+    if deg == 0:
+        return                                   # a constant: nothing to differentiate
+    w = torch.randn(got.shape, generator=g, dtype=torch.float64)
+    d2 = d.detach().clone().requires_grad_()
+    (got * w).sum().backward()
+    (O.eval_sh_bases(deg, d2) * w).sum().backward()
+    # the two polynomial forms agree on the unit sphere; their gradients agree along it (tangential part)
+    tang = lambda v, n: v - (v * n).sum(-1, keepdim=True) * n
+    assert (tang(d.grad, d.detach()) - tang(d2.grad, d.detach())).abs().max() < 1e-12
