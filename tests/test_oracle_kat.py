@@ -240,3 +240,49 @@ def test_kat9_permutation_invariance_and_kat10_absgrad():
     (rc * torch.rand(rc.shape, generator=g, dtype=dt)).sum().backward()
     ab = O.collect_absgrad(probe, N).reshape(1, N, 2)
     assert (ab + 1e-15 >= meta["means2d"].grad.abs()).all() and ab.sum() > 0
+
+
+def test_kat11_spherical_mapping_and_gradcheck():
+    """The 360-degree model as this build defines it (oracle/torch_oracle.py::_spherical_proj; the fork's kernel is absent
+    from the reference): longitude / latitude of the camera-space direction map linearly onto the W x H panorama, depth
+    is the range, Gaussians behind the camera are seen; the whole float64 path passes gradcheck with Gaussians all around."""
+    W, H = 400, 200
+    viewmats, Ks = _cam(W, H, 50.0)                       # K is not used by this model
+    means = torch.tensor([[0.0, 0.0, 2.0], [2.0, 0.0, 0.0], [-2.0, 0.0, 0.0], [0.0, 2.0, 2.0], [1.0, 1.0, -1.0]], dtype=dt)
+    quats = torch.tensor([[1.0, 0, 0, 0]] * 5, dtype=dt)
+    radii, m2, dep, _, _ = O.fully_fused_projection(means, None, quats, torch.full((5, 3), 0.05, dtype=dt), viewmats, Ks,
+                                                    W, H, camera_model="spherical")
+    assert (radii > 0).all()
+    want = torch.tensor([[200.0, 100.0], [300.0, 100.0], [100.0, 100.0], [200.0, 150.0],
+                         [200.0 + 400.0 * 135.0 / 360.0, 100.0 + 200.0 * math.degrees(math.atan2(1.0, math.sqrt(2.0))) / 180.0]],
+                        dtype=dt)
+    assert (m2[0] - want).abs().max() < 1e-4
+    assert (dep[0] - means.norm(dim=-1)).abs().max() < 1e-12
+    # near / far apply to the range: a Gaussian behind the camera at range 1.7 survives near = 1.5 and not near = 1.8
+    for near, seen in ((1.5, True), (1.8, False)):
+        r, *_ = O.fully_fused_projection(means[4:], None, quats[4:], torch.full((1, 3), 0.05, dtype=dt), viewmats, Ks, W, H,
+                                         near_plane=near, camera_model="spherical")
+        assert bool(r[0, 0] > 0) == seen
+    Wg, Hg = 32, 16
+    g = torch.Generator().manual_seed(6)
+    N = 6
+    d = torch.randn(N, 3, generator=g, dtype=dt)
+    d[:, 1] *= 0.4                                        # away from the poles
+    means = d / d.norm(dim=-1, keepdim=True) * (1.5 + torch.rand(N, 1, generator=g, dtype=dt))
+    qs = torch.randn(N, 4, generator=g, dtype=dt)
+    scales = torch.rand(N, 3, generator=g, dtype=dt) * 0.4 + 0.3
+    opac = torch.rand(N, generator=g, dtype=dt) * 0.5 + 0.3
+    sh = torch.randn(N, 4, 3, generator=g, dtype=dt) * 0.3
+    vm, Kg = _cam(Wg, Hg, 14.0)
+    vm = vm.clone()
+    vm[0, :3, 3] = torch.tensor([0.1, -0.05, 0.2], dtype=dt)
+    ins = [t.requires_grad_() for t in (means, qs, scales, opac, sh, vm)]
+
+    def f(means, qs, scales, opac, sh, vm):
+        rc, ra, meta = O.rasterization(means, qs, scales, opac, sh, vm, Kg, Wg, Hg, sh_degree=1,
+                                       camera_model="spherical", render_mode="RGB+D")
+        return rc, ra
+
+    rc, ra, meta = O.rasterization(*[t.detach() for t in ins], Kg, Wg, Hg, sh_degree=1, camera_model="spherical")
+    assert (meta["radii"] > 0).all() and float(ra.max()) > 0.2
+    assert torch.autograd.gradcheck(f, ins, eps=1e-6, atol=1e-5, rtol=1e-3, nondet_tol=0)
