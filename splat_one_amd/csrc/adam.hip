@@ -75,6 +75,33 @@ __device__ __forceinline__ void shadow_store(uint8_t *arec, int stride, int off,
   *reinterpret_cast<_Float16 *>(arec + (int64_t)n * stride + off + 2 * j) = (_Float16)p;
 }
 
+// four consecutive elements of one lane: inside one row they are 8 contiguous bytes of the float16 attribute row, written
+// as two dwords, or (row offset 2 mod 4) as half | dword | half -- 2 or 3 store instructions instead of 4 two-byte ones
+// (rows are 16-byte aligned: attr_rec.hpp); a group that straddles a row boundary keeps the element-wise stores
+template <int RL>
+__device__ __forceinline__ void shadow_store4(uint8_t *arec, int stride, int off, int rl, uint32_t e, const float4 p) {
+  const uint32_t r = RL > 0 ? (uint32_t)RL : (uint32_t)rl;
+  const uint32_t n = e / r, j = e - n * r;
+  if (j + 4 <= r) {
+    const uint32_t h0 = __builtin_bit_cast(unsigned short, (_Float16)p.x), h1 = __builtin_bit_cast(unsigned short, (_Float16)p.y);
+    const uint32_t h2 = __builtin_bit_cast(unsigned short, (_Float16)p.z), h3 = __builtin_bit_cast(unsigned short, (_Float16)p.w);
+    uint8_t *a = arec + (int64_t)n * stride + off + 2 * j;
+    if (((uint32_t)(off >> 1) + j) & 1u) {
+      *reinterpret_cast<unsigned short *>(a) = (unsigned short)h0;
+      *reinterpret_cast<uint32_t *>(a + 2) = h1 | (h2 << 16);
+      *reinterpret_cast<unsigned short *>(a + 6) = (unsigned short)h3;
+    } else {
+      *reinterpret_cast<uint32_t *>(a) = h0 | (h1 << 16);
+      *reinterpret_cast<uint32_t *>(a + 4) = h2 | (h3 << 16);
+    }
+    return;
+  }
+  shadow_store<RL>(arec, stride, off, rl, e, p.x);
+  shadow_store<RL>(arec, stride, off, rl, e + 1, p.y);
+  shadow_store<RL>(arec, stride, off, rl, e + 2, p.z);
+  shadow_store<RL>(arec, stride, off, rl, e + 3, p.w);
+}
+
 template <int RL>
 __device__ __forceinline__ void adam_dev_loop(const so_adam_group G, const AdamHyper h, float step_size, float bc2_sqrt,
                                               int zero_grad, uint8_t *arec, int stride, int off) {
@@ -103,10 +130,7 @@ __device__ __forceinline__ void adam_dev_loop(const so_adam_group G, const AdamH
             make_uint2((uint32_t)__builtin_bit_cast(unsigned short, (_Float16)p.x) | ((uint32_t)__builtin_bit_cast(unsigned short, (_Float16)p.y) << 16),
                        (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)p.z) | ((uint32_t)__builtin_bit_cast(unsigned short, (_Float16)p.w) << 16));
       } else {
-        shadow_store<RL>(arec, stride, off, G.row_len, e, p.x);
-        shadow_store<RL>(arec, stride, off, G.row_len, e + 1, p.y);
-        shadow_store<RL>(arec, stride, off, G.row_len, e + 2, p.z);
-        shadow_store<RL>(arec, stride, off, G.row_len, e + 3, p.w);
+        shadow_store4<RL>(arec, stride, off, G.row_len, e, p);
       }
     }
   }
