@@ -385,7 +385,11 @@ class FusedEngine:
         n, arr, lr0, gam, betas, eps = self._adam_args()
         ovf = self.ws["counters"][2 * self.M + 2:]
         shadow = None
-        if self.attr_dtype == "f16":                 # the same launch keeps the float16 rows equal to the masters
+        # float16 rows after the step: either the Adam launch scatters every updated value into its row (`shadow`: 90-byte
+        # runs at a 112-byte stride = partial-line writes, ~350 us at 2M Gaussians), or -- default -- a second, fully
+        # coalesced pass re-packs the rows from the masters (so_attr_pack_f16; same rounding, so both give the same rows)
+        repack = self.attr_dtype == "f16" and getattr(self, "f16_repack", True)
+        if self.attr_dtype == "f16" and not repack:
             where = {"scales": 8, "quats": 0, "sh0": 16, "shN": 22}
             shadow = _lib.AttrShadow(_lib.ptr(self.ws["arec"]), self.attr_stride,
                                      (ctypes.c_int32 * _lib.SO_ADAM_MAX_GROUPS)(*(
@@ -394,6 +398,8 @@ class FusedEngine:
         _lib.call("so_adam_step_dev_shadow", n, arr, lr0, gam, float(betas[0]), float(betas[1]), float(eps),
                   _lib.ptr(self._step_dev), 0, int(schedule_done), _lib.ptr(ovf), _lib.ptr(self.ws["ovf_f32"]),
                   ctypes.byref(shadow) if shadow is not None else None, _lib.stream())
+        if repack:
+            self.refresh_attrs()
 
     def set_cameras(self, camtoworlds: Tensor, Ks: Tensor) -> None:
         """Cameras only (forward-only rendering needs no target image)."""

@@ -352,7 +352,8 @@ class ShardedEngine:
         sched = getattr(self, "_sched_staged", False)
         self._sched_staged = False
         shadow = None
-        if self.attr_dtype == "f16" and self.N > 0:
+        repack = self.attr_dtype == "f16" and self.N > 0 and getattr(self, "f16_repack", True)    # see FusedEngine._launch_optimize
+        if self.attr_dtype == "f16" and self.N > 0 and not repack:
             where = {"scales": 8, "quats": 0, "sh0": 16, "shN": 22}
             shadow = _lib.AttrShadow(_lib.ptr(self.ws["arec"]), self.attr_stride,
                                      (ctypes.c_int32 * _lib.SO_ADAM_MAX_GROUPS)(*(
@@ -361,6 +362,10 @@ class ShardedEngine:
         _lib.call("so_adam_step_dev_shadow", n, arr, lr0, gam, float(betas[0]), float(betas[1]), float(eps),
                   _lib.ptr(self._step_dev), 0, int(sched), self._P("c.overflow"), 0,
                   ctypes.byref(shadow) if shadow is not None else None, _lib.stream())
+        if repack:
+            sp, p = self.splats, _lib.ptr
+            _lib.call("so_attr_pack_f16", self.N, self.K, p(sp["scales"].data), p(sp["quats"].data), p(sp["sh0"].data),
+                      p(sp["shN"].data), self._P("w.arec"), _lib.stream())
         self.steps_done += 1
         for k in PARAM_ORDER:
             self.optimizers[k].state[self.splats[k]]["step"] += 1

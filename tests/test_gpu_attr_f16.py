@@ -99,16 +99,18 @@ def test_engine_f16_attributes_match_oracle_at_rounded_values(dev, C, kw):
         assert (v.grad.cpu().double() - g_eng[k]).norm().item() <= 1e-5 * g_eng[k].norm().item() + 1e-12, k
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_engine_f16_rows_follow_the_optimiser(dev, use_graph):
-    """Adam updates the float32 masters exactly as in float32 storage given the same gradients, and the same
-    launch leaves rows == masters.half() bit for bit; training makes progress; a rebuild repacks."""
+@pytest.mark.parametrize("use_graph,repack", [(False, True), (True, True), (True, False)])
+def test_engine_f16_rows_follow_the_optimiser(dev, use_graph, repack):
+    """Adam updates the float32 masters exactly as in float32 storage given the same gradients, and the step leaves
+    rows == masters.half() bit for bit -- through the coalesced re-pack that follows the Adam launch (default) and
+    through the scatter inside it (f16_repack = False); training makes progress; a rebuild repacks."""
     from splat_one_amd.engine import FusedEngine
     N, W, H = 5000, 128, 96
     r, c2w, Ks, pixels = _make(dev, N, W, H, "mcmc")
     r.step = 10
     eng = FusedEngine(r.splats, r.optimizers, W, H, 1, sh_degree=3, lr_gamma_means=r.lr_gamma, use_graph=use_graph,
                       attr_dtype="f16")
+    eng.f16_repack = repack
     losses = []
     for _ in range(12):
         eng.set_views(c2w, Ks, pixels, schedule=True)
