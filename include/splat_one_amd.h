@@ -17,8 +17,9 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *   - return value: SO_OK or an SO_ERR_* code; so_last_error() gives a thread-local message.
  *   - (C, N): cameras x Gaussians.  Flattened (camera, Gaussian) index g = c*N + n.
- *   - camera_model: SO_CAM_PINHOLE / SO_CAM_ORTHO / SO_CAM_FISHEYE (trainer Config.camera_model,
- *     gsplat_trainer.py:89; "spherical" is fork-only and unspecified -> SO_ERR_UNSUPPORTED).
+ *   - camera_model: SO_CAM_PINHOLE / SO_CAM_ORTHO / SO_CAM_FISHEYE / SO_CAM_SPHERICAL (trainer
+ *     Config.camera_model, gsplat_trainer.py:89; "spherical" is fork-only: the model is the one this
+ *     library defines, see enum so_camera_model below); any other value -> SO_ERR_UNSUPPORTED.
  *
  * Reference-side bindings (ctypes / torch autograd.Function) are shown in INTEGRATION.md.
  */
@@ -430,6 +431,11 @@ typedef struct so_step_desc {
    * The v_* gradient outputs are then NOT written.  Single-GPU steps only (a data-parallel step needs the gradients
    * for its all-reduce); the schedule of this step must have been evaluated by so_step_inputs (n_groups = 6). */
   const struct so_adam_fuse *fuse_adam;
+  /* Device-resident Gaussian count (nullable): when set, `N` above is the CAPACITY of every per-Gaussian buffer (the
+   * parameters, their moments, the per-view arrays with row stride N, rec / vrec, grad2d / count) and the number of
+   * live Gaussians is read from *n_dev by the kernels themselves -- so_refine_default changes it on the device and a
+   * captured step follows without re-capture or host read-back.  float32 attributes only. */
+  const int32_t *n_dev;
 } so_step_desc;
 typedef struct so_adam_fuse {
   so_adam_group groups[6]; /* means, log_scales, quats, logit_opacities, sh0, shN: param / exp_avg / exp_avg_sq (grad unused) */
@@ -465,6 +471,58 @@ int so_profile_num_stages(void);
 const char *so_profile_stage_name(int stage);
 int so_profile_read(float *host_ms_sum, int *host_calls);
 void so_profile_stage_begin_end(int stage, int begin, void *stream);
+
+/* so_adam_step_dev with the ROW count of every group in device memory (so_step_desc.n_dev): numel[g] is then
+ * capacity * row_len[g] and only the first *n_rows_dev rows are stepped. */
+int so_adam_step_dev_n(int n_groups, const so_adam_group *host_groups, const float *host_lr0,
+                       const float *host_lr_gamma, double beta1, double beta2, double eps, int32_t *step_counter,
+                       int zero_grad, int schedule_done, const int32_t *skip_if_nonzero_i32,
+                       const float *skip_if_nonzero_f32, const int32_t *n_rows_dev, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Device-side densification.   Replaces gsplat `DefaultStrategy._grow_gs` / `_prune_gs` / `reset_opa`
+ * (duplicate, split, remove on the parameters AND the Adam moments), which the reference drives from
+ * gsplat_trainer.py:744-763 every `refine_every` steps (hooks :616-622; defaults SURVEY.md section 8 a11 / B.3).
+ * gsplat reads three counts back to the host per refinement to size its torch.cat's; here the refinement is a
+ * stream compaction from one capacity-preallocated model set into another, with N in device memory:
+ *   avg = grad2d / max(count, 1);  high = avg > grow_grad2d;  small = max_k exp(log_scale_k) <= grow_scale3d
+ *   duplicate = high & small (copy appended, moments zero);  split = high & !small (replaced by two samples
+ *   mean + R diag(s) z, z ~ N(0, I), scales / 1.6, moments zero; opacity 1 - sqrt(1 - o) when revised_opacity);
+ *   prune (evaluated on the grown set) = sigmoid(logit) < prune_opa, or, when prune_big, max scale > prune_scale3d.
+ * Output rows, in gsplat's order: [kept originals | kept duplicates | first children | second children], each in
+ * source order.  z is a counter-based function of (seed, step, source row, child, component) -- Philox4x32-10 +
+ * Box-Muller, csrc/so_rng.hpp -- so no host generator is involved and replicas agree without communication.
+ *   src / dst: two DISJOINT model sets of `capacity` rows each (tensor order: means[.,3], log_scales[.,3], quats[.,4],
+ *     logit_opacities[.], sh0[.,3], shN[.,3(K-1)]; p = parameter, m = exp_avg, v = exp_avg_sq);
+ *   n_src_dev / n_dst_dev: device int32 (distinct): live rows of src (read), of dst (written);
+ *   grad2d / count [capacity]: the densification statistics, zeroed on exit;
+ *   scratch: int32[so_refine_scratch_words(capacity)];
+ *   report_dev int32[8] (zero-initialised once by the caller): {duplicated, split, pruned, new N, overflow, old N,
+ *     refinements so far, 0}.  overflow = the grown set did not fit `capacity`: the rows past it were dropped (the tail
+ *     of the output order) -- the caller enlarges its buffers when it next looks.
+ * so_reset_opacity: gsplat `reset_opa` -- logits clamped to max_logit, their moments zeroed; n_dev nullable.
+ * No entry point here synchronises or reads back; all are hipGraph-capturable.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct so_model_set {
+  float *p[6], *m[6], *v[6];
+} so_model_set;
+typedef struct so_refine_params {
+  float grow_grad2d;
+  float grow_scale3d;  /* already multiplied by scene_scale */
+  float prune_opa;
+  float prune_scale3d; /* already multiplied by scene_scale */
+  int32_t prune_big;   /* step > reset_every */
+  int32_t revised_opacity;
+  uint64_t seed;
+  int32_t step;
+  int32_t reserved;
+} so_refine_params;
+int64_t so_refine_scratch_words(int64_t capacity);
+int so_refine_default(int64_t capacity, int K, const so_model_set *src, const int32_t *n_src_dev,
+                      const so_model_set *dst, int32_t *n_dst_dev, float *grad2d, float *count,
+                      const so_refine_params *prm, int32_t *scratch, int32_t *report_dev, void *stream);
+int so_reset_opacity(int64_t capacity, const int32_t *n_dev, float *logit_opacities, float *exp_avg, float *exp_avg_sq,
+                     float max_logit, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * MCMC densification strategy (the reference's `mcmc` preset, gsplat_trainer.py:975-983, :753-761).

@@ -432,11 +432,19 @@ def rasterization(
     backgrounds: Optional[Tensor] = None, render_mode: str = "RGB",
     rasterize_mode: str = "classic", camera_model: str = "pinhole",
     covars: Optional[Tensor] = None, absgrad_probe: Optional[List] = None,
-    dtype: torch.dtype = torch.float64, raster_fn=None,
+    dtype: torch.dtype = torch.float64, raster_fn=None, sort_depths: Optional[Tensor] = None,
 ):
     """means[N,3] quats[N,4] scales[N,3] opacities[N] colors[N,K,3]|[N,D]|[C,N,D] ->
     (render_colors[C,H,W,X], render_alphas[C,H,W,1], meta).  Activations (exp / sigmoid) are
-    the caller's job, as at gsplat_trainer.py:456-459."""
+    the caller's job, as at gsplat_trainer.py:456-459.
+
+    sort_depths [C,N] (optional): float32 depths to build the tile-sort keys from INSTEAD of this function's own
+    depths rounded to float32.  The sort key is a discrete input of the algorithm (fp32 depth bits, SURVEY.md B.1
+    step 6): two overlapping Gaussians whose depths differ by less than one float32 ulp are ordered by whatever the
+    float32 depth computation rounds to, and a float64 restatement rounds differently on a handful of pairs per
+    100k Gaussians.  A parity test that hands the device's own float32 depths in here (after checking that they
+    are within 2 ulp of the float64 values, `depth_key_report`) compares the arithmetic on identical blending
+    orders; everything differentiable still uses this function's own float64 depths."""
     assert render_mode in ("RGB", "D", "ED", "RGB+D", "RGB+ED"), render_mode
     assert rasterize_mode in ("classic", "antialiased"), rasterize_mode
     C, N = viewmats.shape[0], means.shape[0]
@@ -470,8 +478,12 @@ def rasterization(
             bg = torch.zeros(C, 1, dtype=dtype)
     tile_width = math.ceil(width / float(tile_size))
     tile_height = math.ceil(height / float(tile_size))
+    key_depths = depths
+    if sort_depths is not None:
+        assert sort_depths.shape == depths.shape, (sort_depths.shape, depths.shape)
+        key_depths = sort_depths.detach().to("cpu", torch.float32)
     tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(
-        means2d, radii, depths, tile_size, tile_width, tile_height)
+        means2d, radii, key_depths, tile_size, tile_width, tile_height)
     isect_offsets = isect_offset_encode(isect_ids, C, tile_width, tile_height)
     meta = dict(radii=radii, means2d=means2d, depths=depths, conics=conics, opacities=opac,
                 tile_width=tile_width, tile_height=tile_height, tiles_per_gauss=tiles_per_gauss,
@@ -488,3 +500,25 @@ def rasterization(
         render_colors = torch.cat([render_colors[..., :-1],
                                    render_colors[..., -1:] / render_alphas.clamp(min=1e-10)], dim=-1)
     return render_colors, render_alphas, meta
+
+
+def depth_key_report(depths_oracle: Tensor, depths_device: Tensor, radii: Tensor) -> dict:
+    """How far the device's float32 depths are from this oracle's (float64) depths, in float32 ulps, over the
+    visible (camera, Gaussian) pairs; and how many ORDERED pairs of the per-camera depth ranking the two disagree on
+    (counted over adjacent entries of the device's ranking -- a lower bound of the blending-order flips)."""
+    vis = radii > 0
+    d64 = depths_oracle.detach().double()[vis]
+    d32 = depths_device.detach().cpu().float()[vis]
+    ulp = torch.abs(torch.nextafter(d32, torch.full_like(d32, float("inf"))) - d32).double()
+    err_ulp = (d32.double() - d64).abs() / ulp
+    r32 = d64.float()
+    flips = 0
+    for c in range(radii.shape[0]):
+        v = vis[c]
+        a = depths_device[c].detach().cpu().float()[v]
+        b = depths_oracle[c].detach().double()[v]
+        order = torch.argsort(a, stable=True)
+        flips += int((b[order][1:] < b[order][:-1]).sum())
+    return {"max_ulp": float(err_ulp.max()) if err_ulp.numel() else 0.0,
+            "keys_differ": int((r32.view(torch.int32) != d32.view(torch.int32)).sum()),
+            "adjacent_rank_flips": flips, "visible": int(vis.sum())}

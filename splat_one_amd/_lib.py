@@ -44,13 +44,26 @@ class StepDesc(ctypes.Structure):
         + [(n, c_f32) for n in ("eps2d", "near_plane", "far_plane", "radius_clip", "ssim_lambda", "opacity_reg",
                                 "scale_reg")]
         + [("pixels_indirect", c_ptr), ("inputs_staged", ctypes.c_int32), ("tile_cull", ctypes.c_int32),
-           ("overflow_flag_out", c_ptr), ("attr_rows_f16", c_ptr), ("tile_slots", c_ptr), ("bin_capacity", c_i64), ("fuse_adam", c_ptr)])
+           ("overflow_flag_out", c_ptr), ("attr_rows_f16", c_ptr), ("tile_slots", c_ptr), ("bin_capacity", c_i64), ("fuse_adam", c_ptr),
+           ("n_dev", c_ptr)])
 
 
 class AdamFuse(ctypes.Structure):
     """Mirror of `so_adam_fuse` (the optimiser fused into the backward kernel)."""
     _fields_ = [("groups", AdamGroup * 6), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double),
                 ("step_counter", c_ptr)]
+
+
+class ModelSet(ctypes.Structure):
+    """Mirror of `so_model_set`: parameters, exp_avg, exp_avg_sq of the six tensors (capacity rows each)."""
+    _fields_ = [("p", c_ptr * 6), ("m", c_ptr * 6), ("v", c_ptr * 6)]
+
+
+class RefineParams(ctypes.Structure):
+    """Mirror of `so_refine_params` (device-side DefaultStrategy refinement)."""
+    _fields_ = [("grow_grad2d", c_f32), ("grow_scale3d", c_f32), ("prune_opa", c_f32), ("prune_scale3d", c_f32),
+                ("prune_big", ctypes.c_int32), ("revised_opacity", ctypes.c_int32), ("seed", ctypes.c_uint64),
+                ("step", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class AttrShadow(ctypes.Structure):
@@ -95,6 +108,11 @@ _SIGS = {
     "so_adam_step_dev_shadow": [c_int, ctypes.POINTER(AdamGroup), ctypes.POINTER(c_f32), ctypes.POINTER(c_f32),
                                 ctypes.c_double, ctypes.c_double, ctypes.c_double, c_ptr, c_int, c_int, c_ptr, c_ptr,
                                 ctypes.POINTER(AttrShadow), c_ptr],
+    "so_adam_step_dev_n": [c_int, ctypes.POINTER(AdamGroup), ctypes.POINTER(c_f32), ctypes.POINTER(c_f32),
+                           ctypes.c_double, ctypes.c_double, ctypes.c_double, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr],
+    "so_refine_default": [c_i64, c_int, ctypes.POINTER(ModelSet), c_ptr, ctypes.POINTER(ModelSet), c_ptr, c_ptr, c_ptr,
+                          ctypes.POINTER(RefineParams), c_ptr, c_ptr, c_ptr],
+    "so_reset_opacity": [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr],
     "so_attr_pack_f16": [c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
     "so_preprocess_fwd_f16": [c_int] * 4 + [c_ptr] * 5 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_int] + [c_ptr] * 10 + [c_i64, c_ptr, c_int, c_ptr, c_i64, c_ptr, c_ptr],
     "so_preprocess_bwd_f16": [c_int] * 4 + [c_ptr] * 5 + [c_int, c_int, c_f32, c_int, c_int] + [c_ptr] * 3 + [c_f32, c_f32] + [c_ptr] * 9 + [c_int, c_i64, c_ptr, c_ptr, c_ptr],
@@ -110,7 +128,7 @@ _lib: Optional[ctypes.CDLL] = None
 
 def exported_symbols():
     return ["so_abi_version", "so_last_error", "so_device_cu_count", "so_profile_num_stages",
-            "so_profile_stage_name", "so_profile_stage_begin_end", "so_attr_rec_stride"] + list(_SIGS)
+            "so_profile_stage_name", "so_profile_stage_begin_end", "so_attr_rec_stride", "so_refine_scratch_words"] + list(_SIGS)
 
 
 def load() -> ctypes.CDLL:
@@ -130,6 +148,8 @@ def load() -> ctypes.CDLL:
         lib.so_profile_stage_name.argtypes = [c_int]
         lib.so_attr_rec_stride.restype = c_i64
         lib.so_attr_rec_stride.argtypes = [c_int]
+        lib.so_refine_scratch_words.restype = c_i64
+        lib.so_refine_scratch_words.argtypes = [c_i64]
         for name, argtypes in _SIGS.items():
             fn = getattr(lib, name)
             fn.argtypes = argtypes

@@ -145,11 +145,16 @@ __device__ __forceinline__ void adam_dev_loop(const so_adam_group G, const AdamH
 
 __global__ void __launch_bounds__(256)
 k_adam_dev(AdamGroups groups, AdamHyper h, const float2 *__restrict__ hyper, int zero_grad,
-           const int32_t *__restrict__ skip_i32, const float *__restrict__ skip_f32, AttrShadowDev sh) {
+           const int32_t *__restrict__ skip_i32, const float *__restrict__ skip_f32, AttrShadowDev sh,
+           const int32_t *__restrict__ n_rows_dev) {
   // a void iteration (binning overflow on this or, summed through the all-reduce, on any rank) leaves the
   // parameters and moments untouched
   if ((skip_i32 && *skip_i32 != 0) || (skip_f32 && *skip_f32 != 0.f)) return;
-  const so_adam_group G = groups.g[blockIdx.y];
+  so_adam_group G = groups.g[blockIdx.y];
+  if (n_rows_dev) {   // the row count lives on the device (so_refine_default): numel is the capacity
+    const int64_t live = (int64_t)*n_rows_dev * G.row_len;
+    if (live < G.numel) G.numel = live;
+  }
   const float2 hy = hyper[blockIdx.y];
   const int off = sh.arec ? sh.off[blockIdx.y] : -1;
   if (off < 0) { adam_dev_loop<-1>(G, h, hy.x, hy.y, zero_grad, nullptr, 0, 0); return; }
@@ -163,10 +168,10 @@ k_adam_dev(AdamGroups groups, AdamHyper h, const float2 *__restrict__ hyper, int
 
 }  // namespace so
 
-extern "C" int so_adam_step_dev_shadow(int n_groups, const so_adam_group *host_groups, const float *host_lr0,
-                                       const float *host_lr_gamma, double beta1, double beta2, double eps,
-                                       int32_t *step_counter, int zero_grad, int schedule_done, const int32_t *skip_i32,
-                                       const float *skip_f32, const so_attr_shadow *shadow, void *stream) {
+static int adam_step_dev_impl(int n_groups, const so_adam_group *host_groups, const float *host_lr0,
+                              const float *host_lr_gamma, double beta1, double beta2, double eps,
+                              int32_t *step_counter, int zero_grad, int schedule_done, const int32_t *skip_i32,
+                              const float *skip_f32, const so_attr_shadow *shadow, const int32_t *n_rows_dev, void *stream) {
   SO_REQUIRE(n_groups >= 0 && n_groups <= SO_ADAM_MAX_GROUPS, "so_adam_step_dev: n_groups %d not in [0,%d]", n_groups, SO_ADAM_MAX_GROUPS);
   SO_REQUIRE(step_counter, "so_adam_step_dev: null step counter");
   if (n_groups == 0) return SO_OK;
@@ -210,10 +215,29 @@ extern "C" int so_adam_step_dev_shadow(int n_groups, const so_adam_group *host_g
       SH.stride = shadow->stride_bytes;
       for (int i = 0; i < SO_ADAM_MAX_GROUPS; ++i) SH.off[i] = i < n_groups ? shadow->offset_bytes[i] : -1;
     }
-    hipLaunchKernelGGL(so::k_adam_dev, dim3((unsigned)gx, (unsigned)n_groups), dim3(256), 0, st, G, H, hyper, zero_grad, skip_i32, skip_f32, SH);
+    hipLaunchKernelGGL(so::k_adam_dev, dim3((unsigned)gx, (unsigned)n_groups), dim3(256), 0, st, G, H, hyper, zero_grad, skip_i32, skip_f32, SH, n_rows_dev);
   }
   so_profile_stage_begin_end(8, 0, stream);
   return so::check_launch("so_adam_step_dev");
+}
+
+extern "C" int so_adam_step_dev_shadow(int n_groups, const so_adam_group *host_groups, const float *host_lr0,
+                                       const float *host_lr_gamma, double beta1, double beta2, double eps,
+                                       int32_t *step_counter, int zero_grad, int schedule_done, const int32_t *skip_i32,
+                                       const float *skip_f32, const so_attr_shadow *shadow, void *stream) {
+  return adam_step_dev_impl(n_groups, host_groups, host_lr0, host_lr_gamma, beta1, beta2, eps, step_counter, zero_grad,
+                            schedule_done, skip_i32, skip_f32, shadow, nullptr, stream);
+}
+
+extern "C" int so_adam_step_dev_n(int n_groups, const so_adam_group *host_groups, const float *host_lr0,
+                                  const float *host_lr_gamma, double beta1, double beta2, double eps,
+                                  int32_t *step_counter, int zero_grad, int schedule_done, const int32_t *skip_i32,
+                                  const float *skip_f32, const int32_t *n_rows_dev, void *stream) {
+  for (int i = 0; n_rows_dev && i < n_groups && host_groups; ++i)
+    SO_REQUIRE(host_groups[i].row_len >= 1 && host_groups[i].numel % host_groups[i].row_len == 0,
+               "so_adam_step_dev_n: group %d: numel must be capacity x row_len", i);
+  return adam_step_dev_impl(n_groups, host_groups, host_lr0, host_lr_gamma, beta1, beta2, eps, step_counter, zero_grad,
+                            schedule_done, skip_i32, skip_f32, nullptr, n_rows_dev, stream);
 }
 
 extern "C" int so_adam_step_dev(int n_groups, const so_adam_group *host_groups, const float *host_lr0,

@@ -71,7 +71,10 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
                  int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ tile_counts,
                  float4 *__restrict__ rec, float4 *__restrict__ vrec, int64_t cam_stride,
                  int32_t *__restrict__ tile_slots, int tile_cull, uint64_t *__restrict__ bin_keys, int64_t bin_cap,
-                 int32_t *__restrict__ bin_overflow) {
+                 int32_t *__restrict__ bin_overflow, const int32_t *__restrict__ n_dev) {
+  // n_dev (nullable): the number of Gaussians lives in device memory (device-side densification, so_refine_default):
+  // N is then the CAPACITY of the buffers, rows n >= *n_dev are idle -- a captured launch follows N without re-capture
+  const int n_live = n_dev ? min(*n_dev, N) : N;
   const int64_t total = (int64_t)C * N;
   const int n_tiles = tile_w * tile_h;
   // the trip count is uniform over the workgroup: the histogram section below needs every lane of a wave
@@ -80,10 +83,11 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
     int cnt = 0, bx0 = 0, bx1 = 0, by0 = 0, by1 = 0, c = 0;
     float cmx = 0.f, cmy = 0.f, cqa = 0.f, cqb = 0.f, cqc = 0.f, ctau = 0.f;   // what the exact tile test needs
     float cdepth = 0.f;
-    if (lin < total) {
+    int64_t idx = 0;
+    if (lin < total && (lin - (lin / N) * N) < n_live) {
     c = (int)(lin / N);
     const int64_t n = lin - (int64_t)c * N;
-    const int64_t idx = (int64_t)c * cam_stride + n;   // row of the per-view arrays (cam_stride >= N)
+    idx = (int64_t)c * cam_stride + n;   // row of the per-view arrays (cam_stride >= N) = the flatten id of the lists
     const CamP cam = load_camp(viewmats, Ks, c);
     const float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
     float q[4], ls[3];
@@ -140,7 +144,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       vrec[4 * idx] = z; vrec[4 * idx + 1] = z; vrec[4 * idx + 2] = z; vrec[4 * idx + 3] = z;
     }
-    }   // lin < total
+    }   // lin < total, n < n_live
     if (tile_counts) {   // null: the caller bins later (Gaussian-sharded runs bin after the exchange)
       // Histogram of the first binning pass.  A lane walks a small rectangle itself; a large one (the dense
       // init regime: ~70 tiles per Gaussian) is spread over the whole wave in 8x8 tile blocks, so the wave's
@@ -152,7 +156,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
         if (bin_keys) {
           // binned lists (so_step_desc.bin_capacity): every tile owns bin_cap key slots, the returning atomic IS the
           // slot -- the key goes straight to its place and neither a scan nor a scatter pass exists
-          const uint64_t key = ((uint64_t)__float_as_uint(cdepth) << 32) | (uint64_t)(uint32_t)lin;
+          const uint64_t key = ((uint64_t)__float_as_uint(cdepth) << 32) | (uint64_t)(uint32_t)idx;
           int x = bx0, y = by0;
 #pragma unroll
           for (int i = 0; i < kOwn; ++i) {
@@ -179,7 +183,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
               if (++x == bx1) { x = bx0; ++y; }
             }
           }
-          int32_t *mine = tile_slots + ((int64_t)c * cam_stride + (lin - (int64_t)c * N)) * kOwn;
+          int32_t *mine = tile_slots + idx * kOwn;
 #pragma unroll
           for (int i = 0; i < kOwn; ++i)
             if (i < cnt) mine[i] = got[i];
@@ -201,7 +205,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
         int32_t *row = tile_counts + (int64_t)__builtin_amdgcn_readlane(c, src) * n_tiles + (tile_slots ? (int64_t)C * n_tiles : 0);
         const float smx = readlane_f(cmx, src), smy = readlane_f(cmy, src), sqa = readlane_f(cqa, src),
                     sqb = readlane_f(cqb, src), sqc = readlane_f(cqc, src), stau = readlane_f(ctau, src);
-        const uint64_t skey = ((uint64_t)__float_as_uint(readlane_f(cdepth, src)) << 32) | (uint64_t)(uint32_t)(lin0 + (threadIdx.x & ~63) + src);
+        const uint64_t skey = ((uint64_t)__float_as_uint(readlane_f(cdepth, src)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)idx, src);
         const int64_t srow = (int64_t)__builtin_amdgcn_readlane(c, src) * n_tiles;
         for (int y = sy0 + (lane >> 3); y < sy1; y += 8)
           for (int x = sx0 + (lane & 7); x < sx1; x += 8)
@@ -236,8 +240,10 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
                  float *__restrict__ v_logit_opac, float *__restrict__ v_sh0, float *__restrict__ v_shN,
                  float *__restrict__ grad2d, float *__restrict__ count, float stat_sx, float stat_sy,
                  const float4 *__restrict__ vrec, int use_abs_stats, int64_t cam_stride,
-                 const int32_t *__restrict__ skip_flag, float *__restrict__ skip_out, const AdamFuse af) {
+                 const int32_t *__restrict__ skip_flag, float *__restrict__ skip_out, const AdamFuse af,
+                 const int32_t *__restrict__ n_dev) {
   constexpr int NB = (DEG + 1) * (DEG + 1);
+  if (n_dev) N = min(*n_dev, N);   // device-resident Gaussian count (see k_preprocess_fwd); the grid covers the capacity
   static_assert(!ADAM || STAGE, "the fused optimiser works on the staged shN rows");
   // skip_flag (nullable): the binning pass overflowed its buffers -> this iteration is void: leave gradients and
   // densification statistics alone (the optimiser step skips too); skip_out (nullable) publishes the flag as a
@@ -487,7 +493,8 @@ static int preprocess_fwd_impl(const char *what, int C, int N, int K, int sh_deg
                                int camera_model, int antialiased, int tile_size, int32_t *radii, float *means2d,
                                float *depths, float *conics, float *opacities, float *colors, int32_t *tiles_per_gauss,
                                int32_t *tile_counts, float *rec, float *vrec, int64_t cam_stride, int32_t *tile_slots,
-                               int tile_cull, uint64_t *bin_keys, int64_t bin_cap, int32_t *bin_overflow, void *stream) {
+                               int tile_cull, uint64_t *bin_keys, int64_t bin_cap, int32_t *bin_overflow, void *stream,
+                               const int32_t *n_dev = nullptr) {
   SO_REQUIRE(C >= 0 && N >= 0 && K >= 1 && width > 0 && height > 0 && tile_size > 0, "%s: bad sizes", what);
   SO_REQUIRE(tile_slots == nullptr || tile_counts != nullptr, "%s: tile_slots need the histogram (tile_counts)", what);
   SO_REQUIRE(sh_degree >= 0 && sh_degree <= 4 && (sh_degree + 1) * (sh_degree + 1) <= K,
@@ -502,9 +509,9 @@ static int preprocess_fwd_impl(const char *what, int C, int N, int K, int sh_deg
   if (cam_stride == 0) cam_stride = N;
   SO_REQUIRE(cam_stride >= N, "%s: cam_stride %lld < N %d", what, (long long)cam_stride, N);
   SO_REQUIRE(tile_slots == nullptr || cam_stride == N, "%s: tile_slots need densely packed views (cam_stride == N)", what);
-  SO_REQUIRE(bin_keys == nullptr || (tile_counts && bin_overflow && bin_cap > 0 && cam_stride == N && tile_slots == nullptr &&
-                                     (int64_t)C * N < ((int64_t)1 << 31)),
-             "%s: bin_keys need tile_counts, bin_overflow, bin_cap > 0, densely packed views and no tile_slots", what);
+  SO_REQUIRE(bin_keys == nullptr || (tile_counts && bin_overflow && bin_cap > 0 && tile_slots == nullptr &&
+                                     (int64_t)C * cam_stride < ((int64_t)1 << 31)),
+             "%s: bin_keys need tile_counts, bin_overflow, bin_cap > 0, C * cam_stride < 2^31 and no tile_slots", what);
   const int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
   const dim3 grid(pp_grid((int64_t)C * N)), block(256);
   hipStream_t st = as_stream(stream);
@@ -516,7 +523,7 @@ static int preprocess_fwd_impl(const char *what, int C, int N, int K, int sh_deg
                      Ks, width, height, eps2d, near_plane, far_plane, radius_clip, camera_model, antialiased,      \
                      (float)tile_size, tile_w, tile_h, radii, means2d, depths, conics, opacities, colors,          \
                      tiles_per_gauss, tile_counts, reinterpret_cast<float4 *>(rec), reinterpret_cast<float4 *>(vrec), \
-                     cam_stride, tile_slots, tile_cull, bin_keys, bin_cap, bin_overflow)
+                     cam_stride, tile_slots, tile_cull, bin_keys, bin_cap, bin_overflow, n_dev)
   switch (sh_degree) {
     case 0: SO_LAUNCH(0); break;
     case 1: SO_LAUNCH(1); break;
@@ -539,7 +546,7 @@ static int preprocess_bwd_impl(const char *what, int C, int N, int K, int sh_deg
                                float opacity_reg, float scale_reg, float *v_means, float *v_log_scales, float *v_quats,
                                float *v_logit_opacities, float *v_sh0, float *v_shN, float *grad2d, float *count,
                                const float *vrec, int absgrad_stats, int64_t cam_stride, const int32_t *skip_flag,
-                               float *skip_out, void *stream, const AdamFuse *fuse = nullptr) {
+                               float *skip_out, void *stream, const AdamFuse *fuse = nullptr, const int32_t *n_dev = nullptr) {
   SO_REQUIRE(C >= 0 && N >= 0 && K >= 1 && width > 0 && height > 0, "%s: bad sizes", what);
   SO_REQUIRE(sh_degree >= 0 && sh_degree <= 4 && (sh_degree + 1) * (sh_degree + 1) <= K,
              "%s: sh_degree %d does not fit K=%d", what, sh_degree, K);
@@ -563,7 +570,7 @@ static int preprocess_bwd_impl(const char *what, int C, int N, int K, int sh_deg
   const size_t stage_bytes = (size_t)256 * 3 * (K - 1) * sizeof(float);
   const bool stage = K > 1 && stage_bytes <= 64 * 1024 && (((uintptr_t)v_shN) & 15) == 0;
   if (fuse) {   // the fused optimiser sweeps the staged rows: same conditions, on the parameter / moment tensors
-    SO_REQUIRE(K > 1 && stage_bytes <= 64 * 1024 && cam_stride == N, "%s: fused Adam needs 2 <= K <= 22 and densely packed views", what);
+    SO_REQUIRE(K > 1 && stage_bytes <= 64 * 1024, "%s: fused Adam needs 2 <= K <= 22", what);
     uintptr_t bits = 0;
     for (int g = 0; g < 6; ++g) {
       SO_REQUIRE(fuse->p[g] && fuse->m[g] && fuse->v[g], "%s: fused Adam: null parameter / moment pointer (group %d)", what, g);
@@ -580,19 +587,19 @@ static int preprocess_bwd_impl(const char *what, int C, int N, int K, int sh_deg
                      viewmats, Ks, width, height, eps2d, camera_model, antialiased, radii, opacities, colors,     \
                      v_means2d, v_means2d_abs, v_depths, v_conics, v_colors, v_opacities, opacity_reg, scale_reg, \
                      v_means, v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN, grad2d, count, sx, sy,      \
-                     reinterpret_cast<const float4 *>(vrec), absgrad_stats, cam_stride, skip_flag, skip_out, *fuse); \
+                     reinterpret_cast<const float4 *>(vrec), absgrad_stats, cam_stride, skip_flag, skip_out, *fuse, n_dev); \
   else if (stage)                                                                                                 \
     hipLaunchKernelGGL((k_preprocess_bwd<D, A, true, false, S>), grid, block, stage_bytes, st, C, N, K, means, logit_opacities, attrs, \
                      viewmats, Ks, width, height, eps2d, camera_model, antialiased, radii, opacities, colors,     \
                      v_means2d, v_means2d_abs, v_depths, v_conics, v_colors, v_opacities, opacity_reg, scale_reg, \
                      v_means, v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN, grad2d, count, sx, sy,      \
-                     reinterpret_cast<const float4 *>(vrec), absgrad_stats, cam_stride, skip_flag, skip_out, AdamFuse{}); \
+                     reinterpret_cast<const float4 *>(vrec), absgrad_stats, cam_stride, skip_flag, skip_out, AdamFuse{}, n_dev); \
   else                                                                                                            \
   hipLaunchKernelGGL((k_preprocess_bwd<D, A, false, false, S>), grid, block, 0, st, C, N, K, means, logit_opacities, attrs, \
                      viewmats, Ks, width, height, eps2d, camera_model, antialiased, radii, opacities, colors,     \
                      v_means2d, v_means2d_abs, v_depths, v_conics, v_colors, v_opacities, opacity_reg, scale_reg, \
                      v_means, v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN, grad2d, count, sx, sy,      \
-                     reinterpret_cast<const float4 *>(vrec), absgrad_stats, cam_stride, skip_flag, skip_out, AdamFuse{})
+                     reinterpret_cast<const float4 *>(vrec), absgrad_stats, cam_stride, skip_flag, skip_out, AdamFuse{}, n_dev)
   switch (sh_degree) {
     case 0: SO_LAUNCH(0); break;
     case 1: SO_LAUNCH(1); break;
@@ -687,13 +694,44 @@ int preprocess_bwd_fused_adam(int C, int N, int K, int sh_degree, const float *m
                               const float *Ks, int width, int height, float eps2d, int camera_model, int antialiased,
                               const int32_t *radii, const float *opacities, const float *colors, float opacity_reg,
                               float scale_reg, float *grad2d, float *count, const float *vrec, int absgrad_stats,
-                              const int32_t *skip_flag, float *skip_out, const AdamFuse &fuse, void *stream) {
+                              const int32_t *skip_flag, float *skip_out, const AdamFuse &fuse, void *stream,
+                              const int32_t *n_dev) {
   const AttrSoA attrs{log_scales, quats, sh0, shN, K};
   float *dummy = fuse.p[0];   // the gradient outputs are not written in this mode; any non-null pointer passes the checks
   return preprocess_bwd_impl("so_train_step_fwd_bwd (fused Adam)", C, N, K, sh_degree, means, logit_opacities, attrs, viewmats, Ks,
                              width, height, eps2d, camera_model, antialiased, radii, opacities, colors, nullptr, nullptr,
                              nullptr, nullptr, nullptr, nullptr, opacity_reg, scale_reg, dummy, dummy, dummy, dummy, dummy,
-                             fuse.p[5], grad2d, count, vrec, absgrad_stats, 0, skip_flag, skip_out, stream, &fuse);
+                             fuse.p[5], grad2d, count, vrec, absgrad_stats, 0, skip_flag, skip_out, stream, &fuse, n_dev);
+}
+
+// internal (step.hip): so_preprocess_fwd / so_preprocess_bwd with the Gaussian count in device memory (n_dev; N = capacity)
+int preprocess_fwd_n(int C, int N, int K, int sh_degree, const float *means, const float *log_scales, const float *quats,
+                     const float *logit_opacities, const float *sh0, const float *shN, const float *viewmats, const float *Ks,
+                     int width, int height, float eps2d, float near_plane, float far_plane, float radius_clip, int camera_model,
+                     int antialiased, int tile_size, int32_t *radii, float *means2d, float *depths, float *conics,
+                     float *opacities, float *colors, int32_t *tiles_per_gauss, int32_t *tile_counts, float *rec, float *vrec,
+                     int32_t *tile_slots, int tile_cull, uint64_t *bin_keys, int64_t bin_cap, int32_t *bin_overflow,
+                     const int32_t *n_dev, void *stream) {
+  SO_REQUIRE((int64_t)C * N == 0 || (log_scales && quats && sh0 && (shN || K == 1)), "so_preprocess_fwd: null pointer");
+  const AttrSoA attrs{log_scales, quats, sh0, shN, K};
+  return preprocess_fwd_impl("so_preprocess_fwd", C, N, K, sh_degree, means, logit_opacities, attrs, viewmats, Ks, width, height,
+                             eps2d, near_plane, far_plane, radius_clip, camera_model, antialiased, tile_size, radii, means2d,
+                             depths, conics, opacities, colors, tiles_per_gauss, tile_counts, rec, vrec, 0, tile_slots, tile_cull,
+                             bin_keys, bin_cap, bin_overflow, stream, n_dev);
+}
+int preprocess_bwd_n(int C, int N, int K, int sh_degree, const float *means, const float *log_scales, const float *quats,
+                     const float *logit_opacities, const float *sh0, const float *shN, const float *viewmats, const float *Ks,
+                     int width, int height, float eps2d, int camera_model, int antialiased, const int32_t *radii,
+                     const float *opacities, const float *colors, float opacity_reg, float scale_reg, float *v_means,
+                     float *v_log_scales, float *v_quats, float *v_logit_opacities, float *v_sh0, float *v_shN, float *grad2d,
+                     float *count, const float *vrec, int absgrad_stats, const int32_t *skip_flag, float *skip_out,
+                     const int32_t *n_dev, void *stream) {
+  SO_REQUIRE(N == 0 || (log_scales && quats && sh0 && (shN || K == 1)), "so_preprocess_bwd: null pointer");
+  const AttrSoA attrs{log_scales, quats, sh0, shN, K};
+  return preprocess_bwd_impl("so_preprocess_bwd", C, N, K, sh_degree, means, logit_opacities, attrs, viewmats, Ks, width, height,
+                             eps2d, camera_model, antialiased, radii, opacities, colors, nullptr, nullptr, nullptr, nullptr, nullptr,
+                             nullptr, opacity_reg, scale_reg, v_means, v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN,
+                             grad2d, count, vrec, absgrad_stats, 0, skip_flag, skip_out, stream, nullptr, n_dev);
 }
 }  // namespace so
 

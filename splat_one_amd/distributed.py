@@ -129,6 +129,13 @@ def all_reduce_mean_(flat: torch.Tensor, group=None) -> None:
     flat.mul_(1.0 / dist.get_world_size(group))
 
 
+def all_reduce_max_(t: torch.Tensor, group=None) -> None:
+    """In-place element-wise maximum over ranks (visibility masks, overflow flags)."""
+    if not is_initialized() or dist.get_world_size(group) == 1:
+        return
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+
+
 @torch.no_grad()
 def all_reduce_strategy_state(state: Dict, group=None) -> None:
     """Sum `grad2d` / `count` over ranks (one packed all-reduce) before a refine step."""

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import threading
 from typing import Dict, Optional
 
 import torch
@@ -27,6 +28,11 @@ from . import _lib
 from .ops import camera_model_code
 
 PARAM_ORDER = ("means", "scales", "quats", "opacities", "sh0", "shN")
+
+# A hipGraph capture must not see work from another thread on the default stream (the reference's GUI thread renders
+# while the training thread steps, app/gsplat_manager.py:185 vs :204-206): captures hold this lock, and so does every
+# render issued through Runner.rasterize_splats while an engine exists.
+CAPTURE_LOCK = threading.RLock()
 
 
 class FusedEngine:
@@ -38,12 +44,23 @@ class FusedEngine:
                  strategy_state: Optional[dict] = None, lr_gamma_means: float = 1.0,
                  isect_capacity: Optional[int] = None, use_graph: bool = True, raster_impl: int = 0,
                  attr_dtype: str = "f32", tile_cull: bool = True, binned: bool = True,
-                 bin_capacity: Optional[int] = None, fuse_adam: bool = True):
+                 bin_capacity: Optional[int] = None, fuse_adam: bool = True, device_refine: bool = False,
+                 capacity: Optional[int] = None):
         """attr_dtype="f16": quaternions, log-scales and SH coefficients are READ from float16 attribute rows
         (include/splat_one_amd.h, so_attr_pack_f16: 112 instead of 224 bytes per Gaussian at SH degree 3); the
         float32 parameters stay the masters Adam updates, and the same Adam launch refreshes the halves."""
         assert attr_dtype in ("f32", "f16"), attr_dtype
         self.attr_dtype = attr_dtype
+        # device_refine: the model lives in two capacity-preallocated sets of (parameters, exp_avg, exp_avg_sq) and
+        # the Gaussian count in device memory; `refine()` / `reset_opacity()` run DefaultStrategy's densification as
+        # a stream compaction from the active set into the other one (so_refine_default) -- no host read-back, no
+        # torch.cat, no workspace rebuild, no graph re-capture (one graph per set).  The torch-side handles
+        # (ParameterDict, optimiser state, statistics) are re-pointed lazily by `sync_host()`.
+        self.device_refine = bool(device_refine)
+        assert not (self.device_refine and attr_dtype != "f32"), "device_refine needs float32 attributes"
+        self._capacity_request = capacity
+        self._host_stale = False
+        self._lock = threading.RLock()
         # exact tile culling (include/splat_one_amd.h): tiles no pixel of which can reach alpha = 1/255 are left out
         # of the lists -- outputs unchanged, lists shorter than gsplat's
         self.tile_cull = bool(tile_cull)
@@ -70,6 +87,7 @@ class FusedEngine:
         self._capacity_hint = isect_capacity
         self._graph: Optional[torch.cuda.CUDAGraph] = None
         self._graph_key = None
+        self._graphs, self._graphs_fb = {}, {}       # captured steps by (N, SH degree, workspace, statistics on, model set)
         self._graph_fb: Optional[torch.cuda.CUDAGraph] = None
         self._graph_opt: Optional[torch.cuda.CUDAGraph] = None
         self._graph_fb_key = None
@@ -82,12 +100,140 @@ class FusedEngine:
         self._last_launch = self._status_kind = None   # "train" | "render": what last ran on the counters
         self.on_overflow = "grow"        # "grow": void iteration, larger buffers, continue;  "raise": RuntimeError
         self.void_steps = 0              # iterations discarded because the binning pass overflowed
+        if self.device_refine:
+            self._build_model_sets(int(capacity) if capacity else max(2 * splats["means"].shape[0], 1 << 20))
         self._build_workspace()
+
+    # --------------------------------------------------------------------------------------------- device-resident model
+    def _build_model_sets(self, cap: int) -> None:
+        """Two sets of capacity-sized buffers {p, m, v}[tensor]; the current Gaussians move into set 0 (or keep their
+        place when the capacity grows) and the torch-side handles become views of it."""
+        dev = self.device
+        n = self.splats["means"].shape[0]
+        cap = max(int(cap), n)
+        assert cap < (1 << 30), cap
+        old = getattr(self, "sets", None)
+        self._adam_args_host()                   # lazily-created optimiser state must exist before it is moved
+        sets = []
+        for _ in range(2):
+            sets.append({kind: {k: torch.zeros((cap,) + tuple(self.splats[k].shape[1:]), dtype=torch.float32, device=dev)
+                                for k in PARAM_ORDER} for kind in ("p", "m", "v")})
+        with torch.no_grad():
+            for k in PARAM_ORDER:
+                st = self.optimizers[k].state[self.splats[k]]
+                sets[0]["p"][k][:n].copy_(self.splats[k].detach())
+                sets[0]["m"][k][:n].copy_(st["exp_avg"])
+                sets[0]["v"][k][:n].copy_(st["exp_avg_sq"])
+        stats = {q: torch.zeros(cap, dtype=torch.float32, device=dev) for q in ("grad2d", "count")}
+        if old is not None:
+            for q in stats:
+                stats[q][:n].copy_(self.stats[q][:n])
+        elif self.strategy_state is not None:
+            for q in stats:
+                if isinstance(self.strategy_state.get(q), torch.Tensor) and self.strategy_state[q].shape[0] == n:
+                    stats[q][:n].copy_(self.strategy_state[q])
+        self.sets, self.stats, self.active, self.cap = sets, stats, 0, cap
+        self._n_dev = torch.tensor([n, 0], dtype=torch.int32, device=dev)
+        self._report = torch.zeros(8, dtype=torch.int32, device=dev)
+        words = int(_lib.load().so_refine_scratch_words(cap))
+        self._refine_scratch = torch.empty(words, dtype=torch.int32, device=dev)
+        self._ms = []
+        for sset in sets:
+            ms = _lib.ModelSet()
+            for i, k in enumerate(PARAM_ORDER):
+                ms.p[i], ms.m[i], ms.v[i] = sset["p"][k].data_ptr(), sset["m"][k].data_ptr(), sset["v"][k].data_ptr()
+            self._ms.append(ms)
+        self.n_host = n
+        self.refinements = 0
+        self._host_stale = True
+        self.sync_host(known_n=n)
+
+    def sync_host(self, known_n: Optional[int] = None) -> int:
+        """Re-point the torch-side handles -- ParameterDict entries, Adam state, `.grad`, the strategy statistics -- at
+        the live rows of the active model set.  One device->host read of N (skipped when nothing changed since the last
+        call); the training step itself never needs it."""
+        if not self.device_refine:
+            return self.splats["means"].shape[0]
+        with self._lock:
+            if not self._host_stale:
+                return self.n_host
+            if known_n is None:
+                rep = self._report.cpu()                       # synchronises
+                n = int(self._n_dev[self.active].item())
+                if int(rep[4]):
+                    self._report[4] = 0
+                    import warnings
+                    warnings.warn(f"splat_one_amd: a refinement grew the model past the capacity of {self.cap} Gaussians -- the "
+                                  "rows beyond it were dropped; the buffers are being enlarged (Config.max_gaussians)", RuntimeWarning)
+                    self._grow_after_sync = True
+            else:
+                n = known_n
+            a = self.sets[self.active]
+            for k in PARAM_ORDER:
+                old = self.splats[k]
+                new = torch.nn.Parameter(a["p"][k][:n], requires_grad=True)
+                opt = self.optimizers[k]
+                st = opt.state.pop(old, None) or {"step": torch.tensor(float(self.steps_done))}
+                st["exp_avg"], st["exp_avg_sq"] = a["m"][k][:n], a["v"][k][:n]
+                opt.state[new] = st
+                opt.param_groups[0]["params"] = [new]
+                self.splats[k] = new
+                g = getattr(self, "ws", None)
+                if g is not None and "grads" in g:
+                    new.grad = g["grads"][k][:n]
+            if self.strategy_state is not None:
+                self.strategy_state["grad2d"], self.strategy_state["count"] = self.stats["grad2d"][:n], self.stats["count"][:n]
+            self.n_host, self._host_stale = n, False
+            if getattr(self, "_grow_after_sync", False):
+                self._grow_after_sync = False
+                self._build_model_sets(2 * self.cap)
+                self._build_workspace()
+            return n
+
+    def refine(self, strategy, step: int, scene_scale: float, seed: int = 0) -> None:
+        """One DefaultStrategy refinement (duplicate / split / prune) on the device: active set -> other set, which
+        becomes the active one.  Statistics are zeroed.  Nothing is read back; `refine_report()` gives the counts."""
+        assert self.device_refine
+        with self._lock:
+            src, dst = self.active, 1 - self.active
+            prm = _lib.RefineParams(float(strategy.grow_grad2d), float(strategy.grow_scale3d * scene_scale), float(strategy.prune_opa),
+                                    float(strategy.prune_scale3d * scene_scale), int(step > strategy.reset_every),
+                                    int(bool(strategy.revised_opacity)), int(seed) & 0xFFFFFFFFFFFFFFFF, int(step), 0)
+            _lib.call("so_refine_default", self.cap, self.K, ctypes.byref(self._ms[src]), _lib.ptr(self._n_dev[src:src + 1]),
+                      ctypes.byref(self._ms[dst]), _lib.ptr(self._n_dev[dst:dst + 1]), _lib.ptr(self.stats["grad2d"]),
+                      _lib.ptr(self.stats["count"]), ctypes.byref(prm), _lib.ptr(self._refine_scratch), _lib.ptr(self._report),
+                      _lib.stream())
+            self.active = dst
+            self.refinements += 1
+            self._host_stale = True
+
+    def reset_opacity(self, value: float) -> None:
+        """gsplat `reset_opa`: opacity logits clamped to logit(value), their Adam moments zeroed -- in place, on the device."""
+        assert self.device_refine
+        with self._lock:
+            a = self.sets[self.active]
+            max_logit = torch.logit(torch.tensor(float(value))).item()
+            _lib.call("so_reset_opacity", self.cap, _lib.ptr(self._n_dev[self.active:self.active + 1]), _lib.ptr(a["p"]["opacities"]),
+                      _lib.ptr(a["m"]["opacities"]), _lib.ptr(a["v"]["opacities"]), float(max_logit), _lib.stream())
+
+    def refine_report(self) -> dict:
+        """Counts of the last refinement (synchronises): duplicated, split, pruned, N after, capacity overflow, N before."""
+        r = self._report.cpu().tolist()
+        return {"n_dupli": r[0], "n_split": r[1], "n_prune": r[2], "n_new": r[3], "overflow": r[4], "n_old": r[5], "refinements": r[6]}
+
+    def _adam_args_host(self) -> None:
+        for k in PARAM_ORDER:
+            prm = self.splats[k]
+            st = self.optimizers[k].state[prm]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(prm)
+                st["exp_avg_sq"] = torch.zeros_like(prm)
 
     # ---------------------------------------------------------------------------------------------
     def _build_workspace(self) -> None:
         dev, C, W, H = self.device, self.C, self.W, self.H
-        N = self.splats["means"].shape[0]
+        N = self.cap if self.device_refine else self.splats["means"].shape[0]   # rows of every per-Gaussian buffer
         K = 1 + self.splats["shN"].shape[1]
         ts = self.cfg["tile_size"]
         tw, th = math.ceil(W / ts), math.ceil(H / ts)
@@ -138,7 +284,10 @@ class FusedEngine:
         # gradients: ONE flat static buffer (the data-parallel all-reduce runs on it directly, no
         # flatten copy); per-tensor views are bound to .grad so optimisers / callers see them
         pad = lambda n: (n + 63) // 64 * 64                  # 256-byte aligned segments (float4 access)
-        total = sum(pad(self.splats[k].numel()) for k in PARAM_ORDER)
+        numel = {k: N * (self.splats[k][0].numel() if len(self.splats[k]) else max(1, self.splats[k].numel())) for k in PARAM_ORDER}
+        if not self.device_refine:
+            numel = {k: self.splats[k].numel() for k in PARAM_ORDER}
+        total = sum(pad(numel[k]) for k in PARAM_ORDER)
         # one spare slot behind the gradients carries "this iteration is void" through a gradient all-reduce
         w["grads_flat"] = torch.zeros(total + 64, dtype=f32, device=dev)
         w["ovf_f32"] = w["grads_flat"][total:total + 1]
@@ -146,21 +295,22 @@ class FusedEngine:
         self._probe_capacity = self._bin_hint is None if self.binned else self._capacity_hint is None
         w["grads"], off = {}, 0
         for k in PARAM_ORDER:
-            n = self.splats[k].numel()
-            w["grads"][k] = w["grads_flat"][off:off + n].view_as(self.splats[k])
+            n = numel[k]
+            w["grads"][k] = w["grads_flat"][off:off + n].view((N,) + tuple(self.splats[k].shape[1:]))
             off += pad(n)
         for k in PARAM_ORDER:
-            self.splats[k].grad = w["grads"][k]
+            self.splats[k].grad = w["grads"][k][:self.splats[k].shape[0]]
         if self.attr_dtype == "f16":
             self.attr_stride = int(_lib.load().so_attr_rec_stride(K))
             w["arec"] = torch.empty(N * self.attr_stride // 4, dtype=f32, device=dev)
             self.refresh_attrs()
-        if self.strategy_state is not None:
+        if self.strategy_state is not None and not self.device_refine:
             for k in ("grad2d", "count"):
                 if self.strategy_state.get(k) is None or self.strategy_state[k].shape[0] != N:
                     self.strategy_state[k] = torch.zeros(N, device=dev)
         self._graph = None
         self._graph_fb = self._graph_opt = None
+        self._graphs, self._graphs_fb = {}, {}
 
     def refresh_attrs(self) -> None:
         """Rebuild the float16 attribute rows from the float32 masters (after anything but the engine's own
@@ -183,8 +333,14 @@ class FusedEngine:
         w, s, c = self.ws, self.splats, self.cfg
         p = _lib.ptr
         d = _lib.StepDesc()
-        d.means, d.log_scales, d.quats, d.logit_opacities = p(s["means"].data), p(s["scales"].data), p(s["quats"].data), p(s["opacities"].data)
-        d.sh0, d.shN = p(s["sh0"].data), p(s["shN"].data)
+        if self.device_refine:      # the active capacity-sized set; the kernels read the live count from n_dev
+            s = self.sets[self.active]["p"]
+            d.n_dev = p(self._n_dev[self.active:self.active + 1])
+            d.means, d.log_scales, d.quats, d.logit_opacities = p(s["means"]), p(s["scales"]), p(s["quats"]), p(s["opacities"])
+            d.sh0, d.shN = p(s["sh0"]), p(s["shN"])
+        else:
+            d.means, d.log_scales, d.quats, d.logit_opacities = p(s["means"].data), p(s["scales"].data), p(s["quats"].data), p(s["opacities"].data)
+            d.sh0, d.shN = p(s["sh0"].data), p(s["shN"].data)
         d.viewmats, d.Ks, d.pixels, d.backgrounds = p(w["viewmats"]), p(w["Ks"]), p(w["pixels"]), 0
         for k in ("radii", "means2d", "depths", "conics", "opacities", "colors", "tiles_per_gauss", "counters",
                   "isect_offsets", "key_buf", "flatten_ids", "render_colors", "render_alphas", "last_ids", "loss_sums",
@@ -194,6 +350,8 @@ class FusedEngine:
         d.v_means, d.v_log_scales, d.v_quats, d.v_logit_opacities = p(g["means"]), p(g["scales"]), p(g["quats"]), p(g["opacities"])
         d.v_sh0, d.v_shN = p(g["sh0"]), p(g["shN"])
         st = self.strategy_state
+        if self.device_refine:
+            st = self.stats if st is not None else None
         d.grad2d = p(st["grad2d"]) if st is not None else 0
         d.count = p(st["count"]) if st is not None else 0
         d.isect_capacity = self.capacity
@@ -217,6 +375,10 @@ class FusedEngine:
         for k in PARAM_ORDER:
             opt = self.optimizers[k]
             grp = opt.param_groups[0]
+            if self.device_refine:   # the active set's capacity-sized buffers (the torch-side handles may be stale views)
+                a = self.sets[self.active]
+                items.append((a["p"][k], {"exp_avg": a["m"][k], "exp_avg_sq": a["v"][k]}, grp))
+                continue
             prm = self.splats[k]
             st = opt.state[prm]
             if len(st) == 0:
@@ -355,6 +517,14 @@ class FusedEngine:
                       f"exceeded the buffer capacity {self.capacity}; buffers enlarged", RuntimeWarning)
         self._grow(max(n_prev, n_last))
 
+    def merge_global_overflow(self) -> None:
+        """Data-parallel steps, after the gradient all-reduce: `ovf_f32` then holds the SUM over ranks of the void
+        flags.  Fold it into this rank's own overflow word, so that the status words the next so_step_inputs publishes
+        -- and with them `_check_previous` -- agree on every rank: all ranks raise (or grow) on the same step instead
+        of one raising while its peers block in the next collective."""
+        c, i = self.ws["counters"], 2 * self.M + 2
+        c[i:i + 1].copy_(torch.maximum(c[i:i + 1], (self.ws["ovf_f32"] > 0).to(torch.int32)))
+
     def set_views(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor, schedule: bool = False) -> None:
         """Stage this step's cameras and target images.  camtoworlds[C,4,4] (inverted on the device),
         Ks[C,3,3], pixels[C,H,W,3] in 0..1 -- a contiguous float32 HIP tensor is used IN PLACE (keep it
@@ -395,6 +565,11 @@ class FusedEngine:
                                      (ctypes.c_int32 * _lib.SO_ADAM_MAX_GROUPS)(*(
                                          [where.get(k, -1) if self.splats[k].numel() else -1 for k in PARAM_ORDER]
                                          + [-1] * (_lib.SO_ADAM_MAX_GROUPS - len(PARAM_ORDER)))))
+        if self.device_refine:
+            _lib.call("so_adam_step_dev_n", n, arr, lr0, gam, float(betas[0]), float(betas[1]), float(eps),
+                      _lib.ptr(self._step_dev), 0, int(schedule_done), _lib.ptr(ovf), _lib.ptr(self.ws["ovf_f32"]),
+                      _lib.ptr(self._n_dev[self.active:self.active + 1]), _lib.stream())
+            return
         _lib.call("so_adam_step_dev_shadow", n, arr, lr0, gam, float(betas[0]), float(betas[1]), float(eps),
                   _lib.ptr(self._step_dev), 0, int(schedule_done), _lib.ptr(ovf), _lib.ptr(self.ws["ovf_f32"]),
                   ctypes.byref(shadow) if shadow is not None else None, _lib.stream())
@@ -431,9 +606,10 @@ class FusedEngine:
             self._consume_staging()
             self._launch_fwd_bwd()
             return
-        key = (self.N, self.cfg["sh_degree"], id(self.ws), self.strategy_state is not None)
-        if self._graph_fb is None or self._graph_fb_key != key:
+        key = (self.N, self.cfg["sh_degree"], id(self.ws), self.strategy_state is not None, self.active if self.device_refine else 0)
+        if key not in self._graphs_fb:
             self._capture_split(key)
+        self._graph_fb, self._graph_opt = self._graphs_fb[key]
         self._consume_staging()
         self._graph_fb.replay()
 
@@ -454,6 +630,8 @@ class FusedEngine:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             st = self.strategy_state
+            if st is not None and self.device_refine:
+                st = self.stats
             saved = [st[k].clone() for k in ("grad2d", "count")] if st is not None else None
             self._launch_fwd_bwd()
             self._stage(None, None, None, False)     # leave the counters zero again for the real launch
@@ -471,21 +649,24 @@ class FusedEngine:
         if not self._staged:
             self._stage(None, None, None, False)
         self._warm_fwd_bwd()
-        g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1):
-            self._launch_fwd_bwd()
-        opt = {}
-        for sched in (False, True):
-            opt[sched] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(opt[sched]):
-                self._launch_optimize(sched)
+        with CAPTURE_LOCK:
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self._launch_fwd_bwd()
+            opt = {}
+            for sched in (False, True):
+                opt[sched] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(opt[sched]):
+                    self._launch_optimize(sched)
+        self._graphs_fb[key] = (g1, opt)
         self._graph_fb, self._graph_opt, self._graph_fb_key = g1, opt, key
 
     def _advance_host_counters(self) -> None:
         self.steps_done += 1
         for k in PARAM_ORDER:
-            st = self.optimizers[k].state[self.splats[k]]
-            st["step"] += 1
+            st = self.optimizers[k].state.get(self.splats[k])
+            if st is not None and "step" in st:
+                st["step"] += 1
         self.optimizers["means"].param_groups[0]["lr"] *= self.lr_gamma_means
 
     def step(self) -> None:
@@ -500,13 +681,13 @@ class FusedEngine:
                 self._launch_fwd_bwd()
                 self._launch_optimize(sched)
         else:
-            key = (self.N, self.cfg["sh_degree"], id(self.ws))
-            if self._graph is None or self._graph_key != key:
+            key = (self.N, self.cfg["sh_degree"], id(self.ws), self.strategy_state is not None, self.active if self.device_refine else 0)
+            if key not in self._graphs:
                 self._sched_staged = sched
                 self._capture(key)
                 self._sched_staged = False
             self._consume_staging()
-            self._graph[sched].replay()
+            self._graphs[key][sched].replay()
         self._advance_host_counters()
 
     def _capture(self, key) -> None:
@@ -516,14 +697,16 @@ class FusedEngine:
             self._stage(None, None, None, False)
         self._warm_fwd_bwd()
         graphs = {}
-        for sched in (False, True):      # Adam with its own schedule launch / with the schedule staged by set_views
-            graphs[sched] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graphs[sched]):
-                if self._fusable(sched):
-                    self._launch_fwd_bwd(fused_adam=True)
-                else:
-                    self._launch_fwd_bwd()
-                    self._launch_optimize(sched)
+        with CAPTURE_LOCK:
+            for sched in (False, True):      # Adam with its own schedule launch / with the schedule staged by set_views
+                graphs[sched] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graphs[sched]):
+                    if self._fusable(sched):
+                        self._launch_fwd_bwd(fused_adam=True)
+                    else:
+                        self._launch_fwd_bwd()
+                        self._launch_optimize(sched)
+        self._graphs[key] = graphs
         self._graph, self._graph_key = graphs, key
 
     # ---------------------------------------------------------------------------------------------
@@ -532,10 +715,26 @@ class FusedEngine:
             self.cfg["sh_degree"] = deg
             self._graph = None
             self._graph_fb = self._graph_opt = None
+            self._graphs, self._graphs_fb = {}, {}
 
     def rebuild(self) -> None:
-        """Call after the Gaussian set changed (densification rewrote params/optimiser state)."""
+        """Call after the Gaussian set changed on the HOST side (a torch-level strategy rewrote params / optimiser state)."""
+        if self.device_refine:
+            self.sync_host()
+            self._build_model_sets(max(self.cap, 2 * self.splats["means"].shape[0]))
         self._build_workspace()
+
+    def bind_strategy_state(self, state: Optional[dict]) -> None:
+        """Switch the in-kernel densification statistics on (a DefaultStrategy state dict) or off (None)."""
+        if (state is None) == (self.strategy_state is None) and (state is None or state is self.strategy_state):
+            return
+        self.strategy_state = state
+        if self.device_refine and state is not None and not self._host_stale:
+            state["grad2d"], state["count"] = self.stats["grad2d"][:self.n_host], self.stats["count"][:self.n_host]
+        elif not self.device_refine and state is not None:
+            for k in ("grad2d", "count"):
+                if state.get(k) is None or state[k].shape[0] != self.N:
+                    state[k] = torch.zeros(self.N, device=self.device)
 
     def loss(self) -> Tensor:
         """(loss, l1, ssimloss) of the last step: a view of 3 device floats written by the step itself
@@ -546,7 +745,9 @@ class FusedEngine:
         """Workload counters of the last step (synchronises)."""
         c = self.ws["counters"]
         n = int(c[:self.M].clamp(max=self.bin_capacity).sum().item()) if self.binned else int(c[2 * self.M + 1].item())
-        return {"n_isects": n, "overflow": int(c[2 * self.M + 2].item()), "visible": int((self.ws["radii"] > 0).sum().item())}
+        live = self.sync_host() if self.device_refine else self.N
+        return {"n_isects": n, "overflow": int(c[2 * self.M + 2].item()), "visible": int((self.ws["radii"][:, :live] > 0).sum().item()),
+                "n_gaussians": live}
 
     def tile_lists(self):
         """(offsets, flatten_ids) of the last step in the compact layout -- offsets[C*tiles + 1] as a Python list, ids

@@ -324,6 +324,11 @@ class Runner:
         """{result_dir}/ckpts/ckpt_{step}_rank{world_rank}.pt holding {"step", "splats"}; readable by the
         reference's `main` (:950-957) and by `load_checkpoints`."""
         step = self.step - 1 if step is None else step
+        # The reference's loader (and load_checkpoints below) CONCATENATES the rank files of a run (:950-957), which is
+        # right for Gaussian shards only.  Replicated runs (operator path, dp_mode="allreduce") hold every Gaussian on
+        # every rank: rank 0 alone writes, so that loading "all files of the run" never duplicates the scene.
+        if self.world_size > 1 and not self.sharded and self.world_rank != 0:
+            return ""
         path = f"{self._result_dirs()['ckpts']}/ckpt_{step}_rank{self.world_rank}.pt"
         data = {"step": step, "splats": self.splats.state_dict()}
         if self.cfg.pose_opt:
@@ -351,6 +356,19 @@ class Runner:
             opt.param_groups[0]["params"] = [fresh]
         self._engine = None
         self.step = int(ckpts[0]["step"]) + 1
+        # resume where the schedule stood: ExponentialLR of the means (:512-516, :741-742), a fresh strategy state of
+        # the new length (the old statistics belong to another Gaussian set), Adam bias corrections at `step`
+        self.optimizers["means"].param_groups[0]["lr"] = self.means_lr0 * self.lr_gamma ** self.step
+        if isinstance(self.cfg.strategy, MCMCStrategy):
+            self.strategy_state = self.cfg.strategy.initialize_state()
+        else:
+            self.strategy_state = self.cfg.strategy.initialize_state(scene_scale=self.scene_scale)
+        for k, opt in self.optimizers.items():
+            if isinstance(opt, torch.optim.SparseAdam):
+                continue                      # lazily initialised per row by torch; starts over
+            prm = self.splats[k]
+            opt.state[prm] = {"step": torch.tensor(float(self.step)), "exp_avg": torch.zeros_like(prm),
+                              "exp_avg_sq": torch.zeros_like(prm)}
         return int(ckpts[0]["step"])
 
     # ------------------------------------------------------------------------------ :779-838
@@ -569,6 +587,7 @@ class Runner:
         else:
             eng.fwd_bwd()
             sdist.all_reduce_mean_(eng.ws["grads_flat"])     # ONE collective on the flat gradient SoA
+            eng.merge_global_overflow()                      # a void iteration on one rank is void (and raised) on all
             eng.optimize()
         if isinstance(s, MCMCStrategy):
             # lr = the means learning rate after this step's scheduler.step() (gsplat_trainer.py:753-761)
@@ -704,10 +723,24 @@ class Runner:
                     if prm.grad is not None and prm.grad.is_sparse:
                         prm.grad = prm.grad.to_dense()
             self._reducer.reduce(self.splats.values())
+        # Replicated Gaussians (world_size > 1, not sharded): the all-reduced gradient carries contributions from the
+        # views of ALL ranks, so the set of rows the optimiser may touch is the union of every rank's visibility -- a
+        # rank-local mask would update a different row subset on every rank and the replicas would diverge.
+        vis_union = None
+        if self.world_size > 1 and (cfg.sparse_grad or cfg.visible_adam):
+            if cfg.packed:
+                vis_union = torch.zeros(len(self.splats["means"]), dtype=torch.uint8, device=self.device)
+                vis_union[info["gaussian_ids"]] = 1
+            else:
+                vis_union = (info["radii"] > 0).any(0).to(torch.uint8)
+            sdist.all_reduce_max_(vis_union)
         if cfg.sparse_grad:                                                    # :705-717
             assert cfg.packed, "Sparse gradients only work with packed mode."
             gaussian_ids = info["gaussian_ids"]
-            rows = gaussian_ids if len(Ks) == 1 else torch.unique(gaussian_ids)    # one index per visible Gaussian
+            if vis_union is not None:
+                rows = torch.nonzero(vis_union, as_tuple=True)[0]
+            else:
+                rows = gaussian_ids if len(Ks) == 1 else torch.unique(gaussian_ids)    # one index per visible Gaussian
             for prm in self.splats.values():
                 grad = prm.grad
                 if grad is None or grad.is_sparse:
@@ -716,7 +749,9 @@ class Runner:
                                                    is_coalesced=True)
         # optimisers (one fused launch) + zero_grad(set_to_none=True)
         vis = None
-        if cfg.visible_adam:                                                   # :719-724
+        if cfg.visible_adam and vis_union is not None:
+            vis = vis_union.bool()
+        elif cfg.visible_adam:                                                 # :719-724
             if cfg.packed:
                 vis = torch.zeros_like(self.splats["opacities"], dtype=torch.bool)
                 vis.scatter_(0, info["gaussian_ids"], True)
@@ -767,6 +802,8 @@ class Runner:
                   f"Now having {len(self.splats['means'])} GSs.")
         self.strategy_state["grad2d"].zero_()
         self.strategy_state["count"].zero_()
+        if s.refine_scale2d_stop_iter > 0 and self.strategy_state.get("radii") is not None:
+            self.strategy_state["radii"].zero_()
         if step % s.reset_every == 0 and step > 0:
             from .strategy import reset_opa
             reset_opa(params=self.splats, optimizers=self.optimizers, state=self.strategy_state,

@@ -1,5 +1,6 @@
 """Builds tests/host_harness/_build/libhh.so: a TEST-ONLY g++ build of the product's per-Gaussian
-math header (splat_one_amd/csrc/splat_math.hpp).  Nothing under splat_one_amd/ loads it."""
+math header (splat_one_amd/csrc/splat_math.hpp) and of the counter-based RNG
+(csrc/so_rng.hpp).  Nothing under splat_one_amd/ loads it."""
 import os
 import subprocess
 
@@ -9,10 +10,10 @@ OUT = os.path.join(HERE, "_build", "libhh.so")
 
 def build() -> str:
     src = os.path.join(HERE, "harness.cpp")
-    hdr = os.path.join(HERE, "..", "..", "splat_one_amd", "csrc", "splat_math.hpp")
-    if (not os.path.exists(OUT)) or os.path.getmtime(OUT) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    hdrs = [os.path.join(HERE, "..", "..", "splat_one_amd", "csrc", h) for h in ("splat_math.hpp", "so_rng.hpp")]
+    if (not os.path.exists(OUT)) or os.path.getmtime(OUT) < max([os.path.getmtime(src)] + [os.path.getmtime(h) for h in hdrs]):
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
-        subprocess.run(["g++", "-O1", "-g", "-fPIC", "-shared", "-std=c++17", "-Wall", "-o", OUT, src], check=True)
+        subprocess.run(["g++", "-O1", "-g", "-fPIC", "-shared", "-std=c++17", "-Wall", "-Wno-unknown-pragmas", "-o", OUT, src], check=True)
     return OUT
 
 

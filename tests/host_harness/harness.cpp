@@ -3,6 +3,7 @@
 // per-Gaussian math (projection fwd/bwd, SH bases + derivatives) against the float64 autograd
 // oracle, in double and in float, without a GPU.  Nothing in splat_one_amd/ loads this library.
 #include "../../splat_one_amd/csrc/splat_math.hpp"
+#include "../../splat_one_amd/csrc/so_rng.hpp"
 
 template <typename T>
 static void proj_fwd(int C, int N, const T *means, const T *covars6, const T *quats, const T *scales,
@@ -92,3 +93,18 @@ static void sh_bases_all(int degree, int64_t M, const T *dirs_unit, T *Y, T *dY)
 
 INST(double, f64)
 INST(float, f32)
+
+// ---- csrc/so_rng.hpp: the counter-based split noise of the device-side densification ----------------
+extern "C" void hh_philox4x32_10(int n, const uint32_t *ctr, const uint32_t *key, uint32_t *out) {
+  for (int i = 0; i < n; ++i) {
+    const so::Philox4 r = so::philox4x32_10(ctr[4 * i], ctr[4 * i + 1], ctr[4 * i + 2], ctr[4 * i + 3], key[0], key[1]);
+    for (int k = 0; k < 4; ++k) out[4 * i + k] = r.x[k];
+  }
+}
+extern "C" void hh_split_normals(int n, unsigned long long seed, uint32_t step, const uint32_t *ids, uint32_t child, float *out) {
+  for (int i = 0; i < n; ++i) {
+    float z[3];
+    so::split_normals(seed, step, ids[i], child, z);
+    out[3 * i] = z[0]; out[3 * i + 1] = z[1]; out[3 * i + 2] = z[2];
+  }
+}

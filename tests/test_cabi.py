@@ -71,9 +71,12 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
     import subprocess
     fields = {"so_step_desc": ["means", "viewmats", "radii", "key_buf", "rec", "v_means", "grad2d", "isect_capacity", "abi_size",
                                "raster_impl", "eps2d", "scale_reg", "pixels_indirect", "inputs_staged", "tile_cull",
-                               "overflow_flag_out", "attr_rows_f16", "tile_slots"],
+                               "overflow_flag_out", "attr_rows_f16", "tile_slots", "bin_capacity", "fuse_adam", "n_dev"],
               "so_adam_group": ["param", "visibility", "numel", "row_len", "lr_step_size", "bc2_sqrt"],
-              "so_attr_shadow": ["arec", "stride_bytes", "offset_bytes"]}
+              "so_attr_shadow": ["arec", "stride_bytes", "offset_bytes"],
+              "so_model_set": ["p", "m", "v"],
+              "so_refine_params": ["grow_grad2d", "grow_scale3d", "prune_opa", "prune_scale3d", "prune_big", "revised_opacity",
+                                   "seed", "step"]}
     src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
     for st, fs in fields.items():
         src.append(f'  printf("{st} %zu\\n", sizeof({st}));')
@@ -86,7 +89,8 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-std=c11", "-o", str(exe), str(c)], check=True)
     out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
-    mirrors = {"so_step_desc": _lib.StepDesc, "so_adam_group": _lib.AdamGroup, "so_attr_shadow": _lib.AttrShadow}
+    mirrors = {"so_step_desc": _lib.StepDesc, "so_adam_group": _lib.AdamGroup, "so_attr_shadow": _lib.AttrShadow,
+               "so_model_set": _lib.ModelSet, "so_refine_params": _lib.RefineParams}
     for st, fs in fields.items():
         assert int(out[st]) == ctypes.sizeof(mirrors[st]), st
         for f in fs:

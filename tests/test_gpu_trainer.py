@@ -265,3 +265,82 @@ def test_gaussian_sharded_overflow_voids_and_grows_on_every_rank(dev, tmp_path):
         assert abs(o["lr"][0] - o["lr"][1]) <= 1e-12 * abs(o["lr"][0]), o
         for k, v in o["rel"].items():
             assert v < 2e-4, (k, v, o)
+
+
+def _replicated_operator_worker(local_rank, world_rank, world_size, args):
+    """Operator-level path (Config.fused=False) with replicated Gaussians: visible_adam / packed + sparse_grad, a
+    narrow view per rank so that the two ranks SEE DIFFERENT Gaussians, with densification inside the run."""
+    out_dir, mode = args
+    from splat_one_amd.strategy import DefaultStrategy
+    from splat_one_amd.trainer import Config, Runner
+    dev = torch.device("cuda:0")
+    W, H, N = 96, 64, 2500
+    strat = DefaultStrategy(refine_start_iter=4, refine_every=4, reset_every=1000, refine_stop_iter=100, grow_grad2d=2e-5)
+    kw = dict(visible_adam=True) if mode == "visible_adam" else dict(packed=True, sparse_grad=True)
+    cfg = Config(init_num_pts=N, init_scale=0.3, init_opa=0.3, shN_init_std=0.05, sh_degree_interval=1, fused=False,
+                 strategy=strat, result_dir=os.path.join(out_dir, "results"), **kw)
+    r = Runner(0, world_rank, world_size, cfg, scene_scale=1.0 / 1.1)
+    # cameras on opposite sides, long focal length: each rank sees a different subset of the cloud
+    c2w = ring_cameras(8)[[0, 4][world_rank]][None].to(dev)
+    Ks = pinhole_K(W, H, focal_ratio=3.0)[None].to(dev)
+    pixels = torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(100 + world_rank)).to(dev)
+    sizes = []
+    for _ in range(11):
+        r.train_step(c2w, Ks, pixels)
+        sizes.append(len(r.splats["means"]))
+    torch.cuda.synchronize()
+    vis_local = int((r.last_info["radii"] > 0).sum()) if "radii" in r.last_info else -1
+    path = r.save_checkpoint(10)
+    torch.save({"splats": {k: v.detach().cpu() for k, v in r.splats.items()}, "sizes": sizes, "vis": vis_local, "ckpt": path},
+               os.path.join(out_dir, f"rank{world_rank}.pt"))
+
+
+@pytest.mark.parametrize("mode", ["visible_adam", "sparse_grad"])
+def test_replicated_operator_path_keeps_replicas_identical(dev, tmp_path, mode):
+    """with replicated Gaussians the optimiser's row set must be the UNION of the ranks' visibility, else
+    every rank updates a different subset and N diverges at the next refinement.  Two ranks, different views,
+    densification on: parameters stay bit-equal; only rank 0 writes the (replicated) checkpoint."""
+    from splat_one_amd import distributed as sdist
+    env_backup = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        sdist.cli(_replicated_operator_worker, (str(tmp_path), mode), world_size=2, backend="gloo", port=_free_port())
+    finally:
+        for k, v in env_backup.items():
+            if v is not None:
+                os.environ[k] = v
+    a = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    b = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    assert a["sizes"] == b["sizes"] and len(set(a["sizes"])) > 1, (a["sizes"], b["sizes"])   # refined, identically
+    for k in a["splats"]:
+        assert torch.equal(a["splats"][k], b["splats"][k]), k
+    assert a["ckpt"].endswith("ckpt_10_rank0.pt") and os.path.isfile(a["ckpt"]) and b["ckpt"] == ""
+    ck = torch.load(a["ckpt"], weights_only=True)
+    assert ck["splats"]["means"].shape[0] == a["sizes"][-1]        # one copy of the scene, not world_size copies
+
+
+def test_load_checkpoint_resumes_schedule_and_state(dev, tmp_path):
+    """after load_checkpoints the means LR sits on the ExponentialLR curve at the stored step, the strategy
+    state matches the loaded Gaussian count and both step implementations continue from there."""
+    from splat_one_amd.trainer import Config, Runner
+    W, H = 96, 64
+    cfg = Config(init_num_pts=1500, init_scale=0.3, init_opa=0.3, max_steps=100, result_dir=str(tmp_path / "res"), fused=True)
+    r = Runner(0, 0, 1, cfg, scene_scale=1.0 / 1.1)
+    c2w, Ks = front_camera()[None].to(dev), pinhole_K(W, H)[None].to(dev)
+    pixels = torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(0)).to(dev)
+    for _ in range(6):
+        r.train_step(c2w, Ks, pixels)
+    path = r.save_checkpoint()
+    lr_at_6 = r.optimizers["means"].param_groups[0]["lr"]
+    for fused in (True, False):
+        cfg2 = Config(init_num_pts=700, init_scale=0.3, init_opa=0.3, max_steps=100, fused=fused)
+        r2 = Runner(0, 0, 1, cfg2, scene_scale=1.0 / 1.1)
+        r2.strategy_state["grad2d"] = torch.zeros(700, device=dev)     # a populated state of the OLD length
+        r2.strategy_state["count"] = torch.zeros(700, device=dev)
+        assert r2.load_checkpoints([path]) == 5 and r2.step == 6
+        assert abs(r2.optimizers["means"].param_groups[0]["lr"] / lr_at_6 - 1) < 1e-6
+        assert r2.strategy_state["grad2d"] is None
+        r2.train_step(c2w, Ks, pixels)
+        lr7 = r2.optimizers["means"].param_groups[0]["lr"]
+        assert abs(lr7 / (r2.means_lr0 * r2.lr_gamma ** 7) - 1) < 1e-5, (fused, lr7)
+        assert float(r2.optimizers["means"].state[r2.splats["means"]]["step"]) == 7.0
+        assert r2.strategy_state["grad2d"].shape[0] == 1500
