@@ -7,6 +7,8 @@ Workload (BASELINE.json configs[1], "c2"): 100k random Gaussians (reference init
 `mcmc` preset = trained-like small splats), 1920x1080, SH degree 3, ONE view per GPU per step;
 a step = forward + photometric loss + backward + fused Adam (+ densification statistics), i.e.
 one iteration of Runner.train (/root/reference/utils/gsplat_utils/gsplat_trainer.py:551-763).
+As the reference samples a new view every iteration (:561-572), every step stages ANOTHER camera and target
+image: 8 ring cameras (camera 0 = the front camera of BASELINE.md) and 8 resident targets per GPU, cycled.
 N GPUs = N views per step, replicated Gaussians, one RCCL all-reduce of the gradients (weak scaling).
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
@@ -103,6 +105,7 @@ def main():
     ap.add_argument("--densify", type=int, default=0, metavar="EVERY",
                     help="BASELINE.json configs[3]: DefaultStrategy duplicates / splits / prunes every EVERY iterations "
                          "(reference default 100) inside the timed region; 0 = the reference's first 500 iterations (off)")
+    ap.add_argument("--views", type=int, default=8, help="ring cameras / target images cycled per GPU (the reference draws a new view per step)")
     ap.add_argument("--attr-dtype", default="f32", choices=["f32", "f16"],
                     help="f16: float16 attribute rows (BASELINE.json configs[4]); float32 arithmetic and masters")
     ap.add_argument("--dp-mode", default="auto", choices=["auto", "gaussian_sharded", "allreduce"],
@@ -110,8 +113,8 @@ def main():
                          "north_star), exchange of projected Gaussians (the reference's own scheme), or auto = time "
                          "both for a few steps on this node and keep the faster")
     args = ap.parse_args()
-    if args.densify:      # the first refinement loads torch's einsum / index kernels (~1 s, once per process): warm it up
-        args.warmup = max(args.warmup, args.densify + 1)
+    if args.densify:      # warm up past the first two refinements: both model sets' graphs are captured before timing
+        args.warmup = max(args.warmup, 2 * args.densify + 1)
 
     from splat_one_amd import _lib, distributed as sdist
     from splat_one_amd.scene import pinhole_K, ring_cameras, front_camera
@@ -125,9 +128,17 @@ def main():
 
     W, H, N = args.width, args.height, args.n
     init_scale, init_opa = (1.0, 0.1) if args.regime == "ref" else (0.1, 0.5)
-    cams = front_camera()[None] if world == 1 else ring_cameras(world)
+    # views: step i of rank r renders ring camera (i mod 8) * world + r against its own resident target image
+    NV = max(1, args.views)
+    ring = ring_cameras(NV * world) if NV * world > 1 else front_camera()[None]
     g = torch.Generator().manual_seed(100 + rank)
-    pixels = torch.rand(1, H, W, 3, generator=g).to(dev)
+    if args.densify:      # a smooth target (a shifted colour ramp per view): gradients that make densification grow the set
+        yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
+        targets = [torch.stack([(xx + 0.1 * v) % 1.0, (yy + 0.07 * v) % 1.0, 0.5 * (xx + yy)], -1)[None].contiguous().to(dev)
+                   for v in range(NV)]
+    else:
+        targets = [torch.rand(1, H, W, 3, generator=g).to(dev) for _ in range(NV)]
+    K1 = pinhole_K(W, H)[None]
 
     def make_runner(dp_mode):
         cfg = Config(init_num_pts=N, init_scale=init_scale, init_opa=init_opa, batch_size=1, shN_init_std=0.1,
@@ -138,9 +149,21 @@ def main():
             cfg.strategy = DefaultStrategy(refine_start_iter=0, refine_every=args.densify, reset_every=3000, verbose=False)
         r = Runner(local_rank, rank, world, cfg, scene_scale=1.0 / 1.1)   # effective scene_scale 1.0
         r.raster_impl = args.raster_impl
-        if r.sharded:      # the step takes the cameras of every rank (rank r renders camera r)
-            return cfg, r, cams.to(dev), pinhole_K(W, H)[None].repeat(world, 1, 1).to(dev)
-        return cfg, r, cams[rank:rank + 1].to(dev), pinhole_K(W, H)[None].to(dev)
+        if r.sharded:      # the step takes the cameras of every rank (rank r renders camera r of the step's group)
+            views = [(ring[v * world:(v + 1) * world].contiguous().to(dev), K1.repeat(world, 1, 1).to(dev), targets[v]) for v in range(NV)]
+        else:
+            views = [(ring[v * world + rank:v * world + rank + 1].contiguous().to(dev), K1.to(dev), targets[v]) for v in range(NV)]
+        return cfg, r, views
+
+    class Stepper:
+        """One training iteration per call, on the next view of the cycle."""
+        def __init__(self, runner, views):
+            self.runner, self.views, self.i = runner, views, 0
+
+        def __call__(self):
+            c2w, Ks, px = self.views[self.i % len(self.views)]
+            self.i += 1
+            return self.runner.train_step(c2w, Ks, px)
 
     def probe(mode, n_warm=8, n_timed=16):
         """(seconds per step, runner tuple) of one scheme, max over ranks; (inf, None) if any rank failed."""
@@ -148,13 +171,14 @@ def main():
         tup, dt = None, float("inf")
         try:
             tup = make_runner(mode)
+            st = Stepper(tup[1], tup[2])
             for _ in range(n_warm):
-                tup[1].train_step(tup[2], tup[3], pixels)
+                st()
             dist.barrier()
             torch.cuda.synchronize()
             t0 = time.time()
             for _ in range(n_timed):
-                tup[1].train_step(tup[2], tup[3], pixels)
+                st()
             torch.cuda.synchronize()
             dt = (time.time() - t0) / n_timed
         except Exception as e:   # noqa: BLE001
@@ -167,14 +191,14 @@ def main():
 
     dp_probe = None
     if world == 1:
-        cfg, runner, c2w, Ks = make_runner("allreduce")
+        cfg, runner, views = make_runner("allreduce")
     elif args.dp_mode == "auto":
         t_ar, tup_ar = probe("allreduce")
         t_gs, tup_gs = probe("gaussian_sharded")
         dp_probe = {"allreduce_ms": None if tup_ar is None else t_ar * 1e3,
                     "gaussian_sharded_ms": None if tup_gs is None else t_gs * 1e3}
         assert tup_ar is not None or tup_gs is not None, "both multi-GPU schemes failed"
-        cfg, runner, c2w, Ks = tup_gs if t_gs < t_ar else tup_ar
+        cfg, runner, views = tup_gs if t_gs < t_ar else tup_ar
         del tup_ar, tup_gs
         torch.cuda.empty_cache()
     else:
@@ -183,7 +207,9 @@ def main():
             other = "allreduce" if args.dp_mode == "gaussian_sharded" else "gaussian_sharded"
             t_one, tup = probe(other)
         assert tup is not None, "both multi-GPU schemes failed"
-        cfg, runner, c2w, Ks = tup
+        cfg, runner, views = tup
+    step_once = Stepper(runner, views)
+    c2w, Ks, pixels = views[0]
 
     def barrier():
         if world > 1:
@@ -196,8 +222,15 @@ def main():
     # warm-up
     if not fused:
         _lib.PROFILE = "all"     # operator path: per-entry-point HIP events from Python
-    for _ in range(max(1, args.warmup)):
-        runner.train_step(c2w, Ks, pixels)
+    for i in range(max(1, args.warmup)):
+        step_once()
+        if args.densify and fused and i == args.densify - 2 and getattr(runner._engine, "device_refine", False):
+            # densification that actually grows the set: refine the top 10 % of the accumulated screen-space
+            # gradient at every refinement (one read of the statistics, in the warm-up)
+            eng = runner._engine
+            n_live = eng.sync_host()
+            avg = (eng.dstats["grad2d"][:n_live] / eng.dstats["count"][:n_live].clamp_min(1))
+            cfg.strategy.grow_grad2d = float(torch.quantile(avg[torch.randperm(n_live, device=dev)[:1_000_000]], 0.9))
     torch.cuda.synchronize()
     if not fused:
         prof = _lib.profile_summary()
@@ -225,12 +258,15 @@ def main():
     _lib.profile_summary()  # discard
 
     # timed region: EXACTLY --steps iterations between barriers
+    n_before_timed = runner._engine.sync_host() if (fused and not runner.sharded and getattr(runner._engine, "device_refine", False)) else None
+    void0 = getattr(getattr(runner, "_engine", None), "void_steps", 0)
     barrier()
     t0 = time.time()
     for _ in range(args.steps):
-        runner.train_step(c2w, Ks, pixels)
+        step_once()
     barrier()
     elapsed = time.time() - t0
+    void_steps = getattr(getattr(runner, "_engine", None), "void_steps", 0) - void0
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -241,7 +277,7 @@ def main():
         _lib.PROFILE = "all"
         _lib.profile_summary()
         for _ in range(args.steps):
-            runner.train_step(c2w, Ks, pixels)
+            step_once()
         prof = {k.replace("_packed", ""): v for k, v in _lib.profile_summary().items()}
         _lib.PROFILE = None
         dominant = max(prof.items(), key=lambda kv: kv[1][0] * kv[1][1])[0]
@@ -255,7 +291,7 @@ def main():
         eng.use_graph = False
         lib.so_profile_enable(1)
         for _ in range(args.steps):
-            runner.train_step(c2w, Ks, pixels)
+            step_once()
         prof = _lib.stage_profile()
         lib.so_profile_enable(0)
         eng.use_graph = saved_graph_flag
@@ -269,17 +305,37 @@ def main():
         for k, (n, ms) in sorted(prof.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
             print(f"  {k:24s} calls {n:5d}  mean {ms * 1e3:9.1f} us  share {n * ms / tot:5.1%}", file=sys.stderr)
 
-    if args.densify:      # a refinement rebuilt the workspace: read the workload counters after a plain iteration
-        runner.train_step(c2w, Ks, pixels)
+    # cost of ONE refinement on the device (after the timed region; HIP events around the five launches)
+    refine_ms = None
+    if args.densify and fused and not runner.sharded and getattr(runner._engine, "device_refine", False):
+        eng = runner._engine
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        eng.refine(cfg.strategy, runner.step, runner.scene_scale, seed=cfg.refine_seed)
+        e1.record()
+        torch.cuda.synchronize()
+        refine_ms = e0.elapsed_time(e1)
+        step_once()
+    if args.densify and not (fused and getattr(runner._engine, "device_refine", False)):
+        step_once()       # a host-side refinement rebuilt the workspace: read the workload counters after a plain iteration
         while (runner.step - 1) % args.densify == 0:
-            runner.train_step(c2w, Ks, pixels)
-    info = runner.last_info
+            step_once()
+    # workload counters: mean over the views of the cycle (one more pass, each read back)
     N0, N = N, (N if runner.sharded else int(runner.splats["means"].shape[0]))     # densification changes N
-    V = int((info["radii"] > 0).sum().item())
-    if "engine" in info:
-        I = info["engine"].stats()["n_isects"]
-    else:
-        I = int(info["flatten_ids"].numel()) if "n_isects" not in info else int(info["n_isects"].item())
+    Vs, Is = [], []
+    for _ in range(len(views)):
+        step_once()
+        info = runner.last_info
+        if "engine" in info:
+            st_ = info["engine"].stats()
+            Vs.append(st_["visible"])
+            Is.append(st_["n_isects"])
+        else:
+            n_rows = info["radii"].shape[-1]
+            Vs.append(int((info["radii"] > 0).sum().item()))
+            Is.append(int(info["flatten_ids"].numel()) if "n_isects" not in info else int(info["n_isects"].item()))
+    V, I = int(sum(Vs) / len(Vs)), int(sum(Is) / len(Is))
     P = W * H
     K = (cfg.sh_degree + 1) ** 2
     ab = algorithmic_bytes(N, V, I, P, K)
@@ -295,7 +351,7 @@ def main():
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     # the PMC traffic in profiles/ was collected on c2 with the fused engine: it says nothing about another workload
-    is_c2_engine = ((N0, W, H, args.densify, world) == (100_000, 1920, 1080, 0, 1) and fused and args.attr_dtype == "f32"
+    is_c2_engine = ((N0, W, H, args.densify, world, len(views)) == (100_000, 1920, 1080, 0, 1, 8) and fused and args.attr_dtype == "f32"
                     and args.regime == "mcmc")
     if os.path.exists(tpath) and is_c2_engine:
         try:
@@ -338,10 +394,12 @@ def main():
                  "fused engine (hipGraph replay)" if fused else "operator-level autograd path"),
         "config": {"workload": f"{'c2' if (N0, W, H, args.densify) == (100_000, 1920, 1080, 0) else 'custom'}: {N0} Gaussians "
                                f"(reference random init, '{args.regime}' preset), "
-                               f"{W}x{H}, SH degree 3, 1 view per GPU per step, pinhole"
-                               + (f", DefaultStrategy refining every {args.densify} iterations ({N0} -> {N} Gaussians)" if args.densify else "")
+                               f"{W}x{H}, SH degree 3, 1 view per GPU per step ({len(views)} ring cameras and targets cycled), pinhole"
+                               + (f", DefaultStrategy refining every {args.densify} iterations ({n_before_timed or N0} -> {N} Gaussians "
+                                  f"over the timed region and the stage-timer pass)" if args.densify else "")
                                + (", float16 attribute rows" if args.attr_dtype == "f16" else ""),
-                   "views_per_step": world, "visible_gaussians": V, "tile_intersections": I,
+                   "views_per_step": world, "views_cycled": len(views), "visible_gaussians": V, "tile_intersections": I,
+                   "visible_gaussians_per_view": Vs, "tile_intersections_per_view": Is,
                    "tile_cull": bool(cfg.tile_cull and fused),   # I counts what is left after exact tile culling
                    "binned_lists": bool(fused and not runner.sharded and runner._engine.binned),
                    "parallelism": (f"gaussian-sharded dp{world}: one view per GPU, N/{world} Gaussians per GPU, "
@@ -356,7 +414,12 @@ def main():
                      "algorithmic_bytes_per_launch": dom_bytes, "mean_launch_us": dom_ms * 1e3,
                      "launches_timed": dom_calls},
         "roofline_by_kernel": by_kernel,
+        "void_steps": void_steps,
     }
+    if args.densify:
+        out["densify"] = {"every": args.densify, "gaussians_before_timed_region": n_before_timed, "gaussians_after": N,
+                          "device_side": bool(fused and getattr(runner._engine, "device_refine", False)),
+                          "grow_grad2d": cfg.strategy.grow_grad2d, "one_refinement_ms": refine_ms}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N0, W, H, args.regime)
     if rank == 0:

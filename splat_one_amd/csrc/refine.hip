@@ -54,7 +54,8 @@ __device__ __forceinline__ uint32_t classify_one(int64_t i, const float *__restr
   const bool dup = high && small, split = high && !small;
   const float op = sigmoid_f(lo[i]);
   const bool prune_self = (op < P.prune_opa) || (P.prune_big && s_max > P.prune_scale3d);
-  const float child_op = P.revised_opacity ? 1.f - sqrtf(1.f - op) : op;
+  // revised opacity 1 - sqrt(1 - op) = op / (1 + sqrt(1 - op)), with 1 - op = sigmoid(-x): no cancellation at either end
+  const float child_op = P.revised_opacity ? op / (1.f + sqrtf(sigmoid_f(-lo[i]))) : op;
   const bool prune_child = (child_op < P.prune_opa) || (P.prune_big && s_max / 1.6f > P.prune_scale3d);
   uint32_t f = 0;
   if (!split && !prune_self) f |= RF_A;
@@ -238,8 +239,9 @@ k_refine_gather(int64_t cap, int K, const ModelSet src, const ModelSet dst, cons
       } else if (g == 1) {   // log(exp(log s) / 1.6)
         val = logf(expf(val) / 1.6f);
       } else if (g == 3 && revised_opacity) {
-        const float o = 1.f - sqrtf(1.f - sigmoid_f(val));
-        val = logf(o / (1.f - o));
+        // o' = 1 - sqrt(1 - o) = o / (1 + s) and 1 - o' = s with s = sqrt(1 - o) = sqrt(sigmoid(-x)): stable at both ends
+        const float op = sigmoid_f(val), sq = sqrtf(sigmoid_f(-val));
+        val = logf(op / ((1.f + sq) * sq));
       }
     }
     Pd[e] = val; Md[e] = mo; Vd[e] = vo;

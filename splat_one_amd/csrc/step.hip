@@ -230,7 +230,11 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
   const int32_t *list_n = bins ? nullptr : n_isects;
   const int64_t list_cap = bins ? -bins : d->isect_capacity;
   const bool wave_impl = d->raster_impl == 1 && ts == 16;
-  if (wave_impl)
+  const bool rows_impl = d->raster_impl == 2 && ts == 16;
+  if (rows_impl)
+    SO_STAGE(3, so_rasterize_fwd_rows(C, N, W, H, d->rec, d->backgrounds, list_off, d->flatten_ids, list_n, list_cap,
+                                      d->render_colors, d->render_alphas, d->last_ids, stream));
+  else if (wave_impl)
     SO_STAGE(3, so_rasterize_fwd_wave(C, N, W, H, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects, d->isect_capacity,
                                       d->render_colors, d->render_alphas, d->last_ids, stream));
   else
@@ -245,7 +249,11 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
                         d->ssim_lambda, stream));
   // gradients of the intermediates accumulate in the 64-byte records vrec[C*N] (zeroed by the
   // forward preprocess kernel): one atomic request per (tile quadrant, Gaussian)
-  if (wave_impl)
+  if (rows_impl)
+    SO_STAGE(6, so_rasterize_bwd_rows(C, N, W, H, d->rec, d->backgrounds, list_off, d->flatten_ids, list_n, list_cap,
+                                      d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
+                                      d->absgrad, stream));
+  else if (wave_impl)
     SO_STAGE(6, so_rasterize_bwd_wave(C, N, W, H, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects, d->isect_capacity,
                                       d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
                                       d->absgrad, stream));

@@ -127,12 +127,12 @@ class FusedEngine:
         stats = {q: torch.zeros(cap, dtype=torch.float32, device=dev) for q in ("grad2d", "count")}
         if old is not None:
             for q in stats:
-                stats[q][:n].copy_(self.stats[q][:n])
+                stats[q][:n].copy_(self.dstats[q][:n])
         elif self.strategy_state is not None:
             for q in stats:
                 if isinstance(self.strategy_state.get(q), torch.Tensor) and self.strategy_state[q].shape[0] == n:
                     stats[q][:n].copy_(self.strategy_state[q])
-        self.sets, self.stats, self.active, self.cap = sets, stats, 0, cap
+        self.sets, self.dstats, self.active, self.cap = sets, stats, 0, cap
         self._n_dev = torch.tensor([n, 0], dtype=torch.int32, device=dev)
         self._report = torch.zeros(8, dtype=torch.int32, device=dev)
         words = int(_lib.load().so_refine_scratch_words(cap))
@@ -182,7 +182,7 @@ class FusedEngine:
                 if g is not None and "grads" in g:
                     new.grad = g["grads"][k][:n]
             if self.strategy_state is not None:
-                self.strategy_state["grad2d"], self.strategy_state["count"] = self.stats["grad2d"][:n], self.stats["count"][:n]
+                self.strategy_state["grad2d"], self.strategy_state["count"] = self.dstats["grad2d"][:n], self.dstats["count"][:n]
             self.n_host, self._host_stale = n, False
             if getattr(self, "_grow_after_sync", False):
                 self._grow_after_sync = False
@@ -200,8 +200,8 @@ class FusedEngine:
                                     float(strategy.prune_scale3d * scene_scale), int(step > strategy.reset_every),
                                     int(bool(strategy.revised_opacity)), int(seed) & 0xFFFFFFFFFFFFFFFF, int(step), 0)
             _lib.call("so_refine_default", self.cap, self.K, ctypes.byref(self._ms[src]), _lib.ptr(self._n_dev[src:src + 1]),
-                      ctypes.byref(self._ms[dst]), _lib.ptr(self._n_dev[dst:dst + 1]), _lib.ptr(self.stats["grad2d"]),
-                      _lib.ptr(self.stats["count"]), ctypes.byref(prm), _lib.ptr(self._refine_scratch), _lib.ptr(self._report),
+                      ctypes.byref(self._ms[dst]), _lib.ptr(self._n_dev[dst:dst + 1]), _lib.ptr(self.dstats["grad2d"]),
+                      _lib.ptr(self.dstats["count"]), ctypes.byref(prm), _lib.ptr(self._refine_scratch), _lib.ptr(self._report),
                       _lib.stream())
             self.active = dst
             self.refinements += 1
@@ -351,7 +351,7 @@ class FusedEngine:
         d.v_sh0, d.v_shN = p(g["sh0"]), p(g["shN"])
         st = self.strategy_state
         if self.device_refine:
-            st = self.stats if st is not None else None
+            st = self.dstats if st is not None else None
         d.grad2d = p(st["grad2d"]) if st is not None else 0
         d.count = p(st["count"]) if st is not None else 0
         d.isect_capacity = self.capacity
@@ -631,7 +631,7 @@ class FusedEngine:
         with torch.cuda.stream(side):
             st = self.strategy_state
             if st is not None and self.device_refine:
-                st = self.stats
+                st = self.dstats
             saved = [st[k].clone() for k in ("grad2d", "count")] if st is not None else None
             self._launch_fwd_bwd()
             self._stage(None, None, None, False)     # leave the counters zero again for the real launch
@@ -662,12 +662,13 @@ class FusedEngine:
         self._graph_fb, self._graph_opt, self._graph_fb_key = g1, opt, key
 
     def _advance_host_counters(self) -> None:
-        self.steps_done += 1
-        for k in PARAM_ORDER:
-            st = self.optimizers[k].state.get(self.splats[k])
-            if st is not None and "step" in st:
-                st["step"] += 1
-        self.optimizers["means"].param_groups[0]["lr"] *= self.lr_gamma_means
+        with self._lock:                 # (another thread may be re-pointing the handles: sync_host)
+            self.steps_done += 1
+            for k in PARAM_ORDER:
+                st = self.optimizers[k].state.get(self.splats[k])
+                if st is not None and "step" in st:
+                    st["step"] += 1
+            self.optimizers["means"].param_groups[0]["lr"] *= self.lr_gamma_means
 
     def step(self) -> None:
         """One full iteration (fwd + loss + bwd + Adam); a hipGraph replay when `use_graph`."""
@@ -730,7 +731,7 @@ class FusedEngine:
             return
         self.strategy_state = state
         if self.device_refine and state is not None and not self._host_stale:
-            state["grad2d"], state["count"] = self.stats["grad2d"][:self.n_host], self.stats["count"][:self.n_host]
+            state["grad2d"], state["count"] = self.dstats["grad2d"][:self.n_host], self.dstats["count"][:self.n_host]
         elif not self.device_refine and state is not None:
             for k in ("grad2d", "count"):
                 if state.get(k) is None or state[k].shape[0] != self.N:

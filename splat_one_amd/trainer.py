@@ -125,6 +125,12 @@ class Config:
     binned: bool = True
     fuse_adam: bool = True                 # single-GPU fused step: Adam inside the backward kernel (no gradient round trip)
     bin_capacity: Optional[int] = None     # slots per tile; None: 8x the fullest tile of the first view, >= 1024
+    # single-GPU fused step with DefaultStrategy: the refinement (duplicate / split / prune / opacity reset) runs as a
+    # stream compaction ON THE DEVICE (so_refine_default): capacity-preallocated parameters + Adam moments, N in device
+    # memory, counter-based split noise, no host read-back, no graph re-capture.  False: the torch-level strategy ops.
+    device_refine: bool = True
+    max_gaussians: Optional[int] = None    # capacity of the device-resident model; None: max(2 N, 2^20), doubled when exceeded
+    refine_seed: int = 1234                # seed of the split noise (same on every rank)
     shN_init_std: float = 0.0              # >0: noise instead of zeros in the higher SH bands (bench scenes)
 
     def adjust_steps(self, factor: float):
@@ -202,6 +208,41 @@ class Runner:
     """Engine for training (hot path only).  `views` replaces the reference's dataset/parser:
     a list of dicts {"K":[3,3], "camtoworld":[4,4], "image":[H,W,3] in 0..255} like
     `Dataset.__getitem__` (utils/datasets/opensfm.py:341-389)."""
+
+    # `splats`, `optimizers`, `strategy_state`: with Config.device_refine the model lives in the engine's capacity-sized
+    # buffers and its size on the device; these torch-side handles are re-pointed at the live rows lazily, on access
+    # (one device->host read of N after a refinement, none otherwise) -- the training step itself never touches them.
+    def _fresh(self):
+        eng = self.__dict__.get("_engine")
+        if eng is not None and getattr(eng, "_host_stale", False):
+            eng.sync_host()
+
+    @property
+    def splats(self):
+        self._fresh()
+        return self._splats
+
+    @splats.setter
+    def splats(self, v):
+        self._splats = v
+
+    @property
+    def optimizers(self):
+        self._fresh()
+        return self._optimizers
+
+    @optimizers.setter
+    def optimizers(self, v):
+        self._optimizers = v
+
+    @property
+    def strategy_state(self):
+        self._fresh()
+        return self._strategy_state
+
+    @strategy_state.setter
+    def strategy_state(self, v):
+        self._strategy_state = v
 
     def __init__(self, local_rank: int, world_rank: int, world_size: int, cfg: Config,
                  views: Optional[List[Dict[str, Tensor]]] = None, scene_scale: float = 1.0,
@@ -519,6 +560,14 @@ class Runner:
     def rasterize_splats(self, camtoworlds: Tensor, Ks: Tensor, width: int, height: int,
                          masks: Optional[Tensor] = None, camera_model: Optional[str] = None,
                          **kwargs) -> Tuple[Tensor, Tensor, Dict]:
+        if getattr(self, "_engine", None) is not None and not kwargs.pop("_locked", False):
+            # another thread (the reference's GUI renders from the Qt thread, app/gsplat_manager.py:185) must not put
+            # work on the default stream while the training thread captures a hipGraph
+            from .engine import CAPTURE_LOCK
+            with CAPTURE_LOCK:
+                return self.rasterize_splats(camtoworlds, Ks, width, height, masks=masks, camera_model=camera_model,
+                                             _locked=True, **kwargs)
+        kwargs.pop("_locked", None)
         sp = self.full_splats() if self.sharded else self.splats
         means = sp["means"]
         quats = sp["quats"]
@@ -558,6 +607,8 @@ class Runner:
         B, H, W = pixels.shape[0], pixels.shape[1], pixels.shape[2]
         eng = getattr(self, "_engine", None)
         if eng is None or (eng.C, eng.H, eng.W) != (B, H, W):
+            dev_refine = (cfg.device_refine and isinstance(s, DefaultStrategy) and self.world_size == 1
+                          and cfg.attr_dtype == "f32" and s.refine_scale2d_stop_iter == 0)
             eng = self._engine = FusedEngine(
                 self.splats, self.optimizers, W, H, B, sh_degree=0, camera_model=cfg.camera_model,
                 near_plane=cfg.near_plane, far_plane=cfg.far_plane, antialiased=cfg.antialiased,
@@ -569,7 +620,7 @@ class Runner:
                 raster_impl=getattr(self, "raster_impl", 0), attr_dtype=cfg.attr_dtype, tile_cull=cfg.tile_cull,
                 binned=(cfg.binned and self.world_size == 1),   # replicas keep the compact layout: one global
                 bin_capacity=cfg.bin_capacity,                  # slack instead of a per-tile one, and no per-rank growth
-                fuse_adam=cfg.fuse_adam)
+                fuse_adam=cfg.fuse_adam, device_refine=dev_refine, capacity=cfg.max_gaussians)
             eng.steps_done = step
             eng._step_dev[0] = step
             if self.world_size > 1:
@@ -578,9 +629,7 @@ class Runner:
         # densification statistics are accumulated inside the backward kernel while refinement is active
         stats_on = isinstance(s, DefaultStrategy) and step < s.refine_stop_iter
         if stats_on != (eng.strategy_state is not None):
-            eng.strategy_state = self.strategy_state if stats_on else None
-            eng._graph = None
-            eng._graph_fb = eng._graph_opt = None
+            eng.bind_strategy_state(self._strategy_state if stats_on else None)
         eng.set_views(camtoworlds, Ks, pixels, schedule=True)   # the step below always runs the optimiser
         if self.world_size == 1:
             eng.step()
@@ -605,23 +654,36 @@ class Runner:
         refine_now = (step < s.refine_stop_iter and step > s.refine_start_iter and step % s.refine_every == 0
                       and step % s.reset_every >= s.pause_refine_after_reset)
         reset_now = step < s.refine_stop_iter and step % s.reset_every == 0 and step > 0
-        if refine_now or reset_now:
-            n_before = len(self.splats["means"])
+        if eng.device_refine:
+            # densification on the device: five launches, nothing read back, the next step replays the other set's graph
             if refine_now:
-                if self.world_size > 1:
-                    sdist.all_reduce_strategy_state(self.strategy_state)
-                n_dupli, n_split = s._grow_gs(self.splats, self.optimizers, self.strategy_state, step, self._split_gen)
-                n_prune = s._prune_gs(self.splats, self.optimizers, self.strategy_state, step)
+                eng.refine(s, step, self.scene_scale, seed=cfg.refine_seed)
                 if s.verbose:
-                    print(f"Step {step}: {n_dupli} GSs duplicated, {n_split} GSs split, {n_prune} GSs pruned. "
-                          f"Now having {len(self.splats['means'])} GSs.")
-                self.strategy_state["grad2d"].zero_()
-                self.strategy_state["count"].zero_()
+                    rep = eng.refine_report()           # (synchronises; verbose runs only)
+                    print(f"Step {step}: {rep['n_dupli']} GSs duplicated, {rep['n_split']} GSs split, {rep['n_prune']} GSs pruned. "
+                          f"Now having {rep['n_new']} GSs.")
             if reset_now:
-                from .strategy import reset_opa
-                reset_opa(params=self.splats, optimizers=self.optimizers, state=self.strategy_state,
-                          value=s.prune_opa * 2.0)
-            eng.rebuild()
+                eng.reset_opacity(s.prune_opa * 2.0)
+        elif refine_now or reset_now:
+            # torch-level refinement: the tensors of the ParameterDict are replaced one by one -- a render from another
+            # thread (Runner.rasterize_splats holds the same lock) must not see half of them
+            from .engine import CAPTURE_LOCK
+            with CAPTURE_LOCK:
+                if refine_now:
+                    if self.world_size > 1:
+                        sdist.all_reduce_strategy_state(self.strategy_state)
+                    n_dupli, n_split = s._grow_gs(self.splats, self.optimizers, self.strategy_state, step, self._split_gen)
+                    n_prune = s._prune_gs(self.splats, self.optimizers, self.strategy_state, step)
+                    if s.verbose:
+                        print(f"Step {step}: {n_dupli} GSs duplicated, {n_split} GSs split, {n_prune} GSs pruned. "
+                              f"Now having {len(self.splats['means'])} GSs.")
+                    self.strategy_state["grad2d"].zero_()
+                    self.strategy_state["count"].zero_()
+                if reset_now:
+                    from .strategy import reset_opa
+                    reset_opa(params=self.splats, optimizers=self.optimizers, state=self.strategy_state,
+                              value=s.prune_opa * 2.0)
+                eng.rebuild()
         self.last_info = {"radii": eng.ws["radii"], "engine": eng,   # eng.stats() / eng.tile_lists(): counts and lists
                           "flatten_ids": eng.ws["flatten_ids"], "means2d": eng.ws["means2d"]}
         self.step += 1

