@@ -223,20 +223,6 @@ int so_rasterize_bwd_wave(int C, int N, int width, int height, const float *rec,
                           const float *v_render_colors, const float *v_render_alphas, float *vrec, int absgrad,
                           void *stream);
 
-/* Row-independent variants (tile 16, D = 3, packed records; csrc/rasterize_rows.hip): the 8x8 quadrant of a wave is
- * cut into four 4x4 blocks, one per 16-lane DPP row, and every row walks its own list of the Gaussians whose
- * alpha >= 1/255 ellipse touches its block -- four different Gaussians per pass instead of one on 64 pixels of which
- * 39 % contribute.  Same results as the *_packed entry points (forward bit-identical); both list layouts. */
-int so_rasterize_fwd_rows(int C, int N, int width, int height, const float *rec, const float *backgrounds,
-                          const int32_t *isect_offsets, const int32_t *flatten_ids, const int32_t *n_isects_dev,
-                          int64_t n_isects_host, float *render_colors, float *render_alphas, int32_t *last_ids,
-                          void *stream);
-int so_rasterize_bwd_rows(int C, int N, int width, int height, const float *rec, const float *backgrounds,
-                          const int32_t *isect_offsets, const int32_t *flatten_ids, const int32_t *n_isects_dev,
-                          int64_t n_isects_host, const float *render_alphas, const int32_t *last_ids,
-                          const float *v_render_colors, const float *v_render_alphas, float *vrec, int absgrad,
-                          void *stream);
-
 /* diagnostic build of so_rasterize_bwd_wave with per-wave s_memtime stamps (profiling only) */
 int so_debug_rasterize_bwd_wave_stamps(int C, int N, int width, int height, const float *rec,
                                        const int32_t *isect_offsets, const int32_t *flatten_ids,
@@ -396,7 +382,9 @@ typedef struct so_step_desc {
   const float *means, *log_scales, *quats, *logit_opacities, *sh0, *shN;
   /* cameras and target */
   const float *viewmats, *Ks, *pixels, *backgrounds /* nullable [C,3] */;
-  /* per-view intermediates */
+  /* per-view intermediates.  radii, means2d, depths, conics, opacities, colors, tiles_per_gauss may ALL be NULL
+   * ("record-only views"; needs rec, float32 attributes and bin_capacity > 0): the forward then writes only the
+   * 64-byte records -- which hold the same values -- and the backward reads radius / colour / opacity from them. */
   int32_t *radii;
   float *means2d, *depths, *conics, *opacities, *colors;
   int32_t *tiles_per_gauss, *counters, *isect_offsets;
@@ -413,7 +401,7 @@ typedef struct so_step_desc {
   float *grad2d, *count;
   int64_t isect_capacity;
   int32_t abi_size, C, N, K, width, height, tile_size, sh_degree, camera_model, antialiased, absgrad;
-  int32_t raster_impl; /* 0: LDS-tiled quadrant kernels, 1: wave-per-quadrant kernels, 2: row-independent kernels (1, 2: tile 16 only) */
+  int32_t raster_impl; /* 0: LDS-tiled quadrant kernels, 1: wave-per-quadrant kernels (tile 16 only) */
   float eps2d, near_plane, far_plane, radius_clip, ssim_lambda, opacity_reg, scale_reg;
   /* Inputs staged by so_step_inputs (both optional, zero = off):
    *   pixels_indirect  device slot holding the address of this iteration's target image [C,H,W,3]; when set it

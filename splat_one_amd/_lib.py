@@ -97,8 +97,6 @@ _SIGS = {
     "so_rasterize_fwd_packed": [c_int] * 5 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 4,
     "so_rasterize_fwd_wave": [c_int] * 4 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 4,
     "so_rasterize_bwd_wave": [c_int] * 4 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 5 + [c_int, c_ptr],
-    "so_rasterize_fwd_rows": [c_int] * 4 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 4,
-    "so_rasterize_bwd_rows": [c_int] * 4 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 5 + [c_int, c_ptr],
     "so_debug_rasterize_bwd_wave_stamps": [c_int] * 4 + [c_ptr] * 10 + [c_int, c_ptr],
     "so_rasterize_bwd_packed": [c_int] * 5 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 5 + [c_int, c_ptr],
     "so_train_step_fwd_bwd": [ctypes.POINTER(StepDesc), c_ptr],

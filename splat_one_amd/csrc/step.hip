@@ -57,7 +57,7 @@ int preprocess_bwd_fused_adam(int C, int N, int K, int sh_degree, const float *m
                               const int32_t *radii, const float *opacities, const float *colors, float opacity_reg,
                               float scale_reg, float *grad2d, float *count, const float *vrec, int absgrad_stats,
                               const int32_t *skip_flag, float *skip_out, const AdamFuse &fuse, void *stream,
-                              const int32_t *n_dev);
+                              const int32_t *n_dev, const float *rec);
 int preprocess_fwd_n(int C, int N, int K, int sh_degree, const float *means, const float *log_scales, const float *quats,
                      const float *logit_opacities, const float *sh0, const float *shN, const float *viewmats, const float *Ks,
                      int width, int height, float eps2d, float near_plane, float far_plane, float radius_clip, int camera_model,
@@ -71,7 +71,7 @@ int preprocess_bwd_n(int C, int N, int K, int sh_degree, const float *means, con
                      const float *opacities, const float *colors, float opacity_reg, float scale_reg, float *v_means,
                      float *v_log_scales, float *v_quats, float *v_logit_opacities, float *v_sh0, float *v_shN, float *grad2d,
                      float *count, const float *vrec, int absgrad_stats, const int32_t *skip_flag, float *skip_out,
-                     const int32_t *n_dev, void *stream);
+                     const int32_t *n_dev, const float *rec, void *stream);
 
 // Per-iteration inputs in one launch (see so_step_inputs in the header).  Workgroup 0 does the small serial
 // pieces (one lane per camera / per Ks entry / per Adam group); every workgroup zeroes its share of the counters.
@@ -202,7 +202,8 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
   int32_t *slots = bins ? nullptr : d->tile_slots;
   uint64_t *bin_keys = bins ? d->key_buf : nullptr;
   SO_REQUIRE(!(d->n_dev && d->attr_rows_f16), "so_train_step_fwd_bwd: n_dev (device-resident N) needs float32 attributes");
-  if (d->n_dev)
+  SO_REQUIRE(d->radii || (d->rec && !d->attr_rows_f16 && bins), "so_train_step_fwd_bwd: record-only views (radii == NULL) need rec, float32 attributes and binned lists");
+  if (d->n_dev || !d->radii)
     SO_STAGE(0, so::preprocess_fwd_n(C, N, K, d->sh_degree, d->means, d->log_scales, d->quats, d->logit_opacities, d->sh0, d->shN,
                                      d->viewmats, d->Ks, W, H, d->eps2d, d->near_plane, d->far_plane, d->radius_clip,
                                      d->camera_model, d->antialiased, ts, d->radii, d->means2d, d->depths, d->conics,
@@ -230,11 +231,7 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
   const int32_t *list_n = bins ? nullptr : n_isects;
   const int64_t list_cap = bins ? -bins : d->isect_capacity;
   const bool wave_impl = d->raster_impl == 1 && ts == 16;
-  const bool rows_impl = d->raster_impl == 2 && ts == 16;
-  if (rows_impl)
-    SO_STAGE(3, so_rasterize_fwd_rows(C, N, W, H, d->rec, d->backgrounds, list_off, d->flatten_ids, list_n, list_cap,
-                                      d->render_colors, d->render_alphas, d->last_ids, stream));
-  else if (wave_impl)
+  if (wave_impl)
     SO_STAGE(3, so_rasterize_fwd_wave(C, N, W, H, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects, d->isect_capacity,
                                       d->render_colors, d->render_alphas, d->last_ids, stream));
   else
@@ -249,11 +246,7 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
                         d->ssim_lambda, stream));
   // gradients of the intermediates accumulate in the 64-byte records vrec[C*N] (zeroed by the
   // forward preprocess kernel): one atomic request per (tile quadrant, Gaussian)
-  if (rows_impl)
-    SO_STAGE(6, so_rasterize_bwd_rows(C, N, W, H, d->rec, d->backgrounds, list_off, d->flatten_ids, list_n, list_cap,
-                                      d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
-                                      d->absgrad, stream));
-  else if (wave_impl)
+  if (wave_impl)
     SO_STAGE(6, so_rasterize_bwd_wave(C, N, W, H, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects, d->isect_capacity,
                                       d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
                                       d->absgrad, stream));
@@ -275,13 +268,13 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
     SO_STAGE(7, so::preprocess_bwd_fused_adam(C, N, K, d->sh_degree, d->means, d->log_scales, d->quats, d->logit_opacities, d->sh0,
                                               d->shN, d->viewmats, d->Ks, W, H, d->eps2d, d->camera_model, d->antialiased, d->radii,
                                               d->opacities, d->colors, d->opacity_reg, d->scale_reg, d->grad2d, d->count, d->vrec,
-                                              d->absgrad, overflow, d->overflow_flag_out, F, stream, d->n_dev));
-  } else if (d->n_dev)
+                                              d->absgrad, overflow, d->overflow_flag_out, F, stream, d->n_dev, d->rec));
+  } else if (d->n_dev || !d->radii)
     SO_STAGE(7, so::preprocess_bwd_n(C, N, K, d->sh_degree, d->means, d->log_scales, d->quats, d->logit_opacities, d->sh0, d->shN,
                                      d->viewmats, d->Ks, W, H, d->eps2d, d->camera_model, d->antialiased, d->radii, d->opacities,
                                      d->colors, d->opacity_reg, d->scale_reg, d->v_means, d->v_log_scales, d->v_quats,
                                      d->v_logit_opacities, d->v_sh0, d->v_shN, d->grad2d, d->count, d->vrec, d->absgrad,
-                                     overflow, d->overflow_flag_out, d->n_dev, stream));
+                                     overflow, d->overflow_flag_out, d->n_dev, d->rec, stream));
   else if (d->attr_rows_f16)
     SO_STAGE(7, so_preprocess_bwd_f16(C, N, K, d->sh_degree, d->means, d->logit_opacities, d->attr_rows_f16, d->viewmats, d->Ks,
                                       W, H, d->eps2d, d->camera_model, d->antialiased, d->radii, d->opacities, d->colors,

@@ -45,7 +45,7 @@ class FusedEngine:
                  isect_capacity: Optional[int] = None, use_graph: bool = True, raster_impl: int = 0,
                  attr_dtype: str = "f32", tile_cull: bool = True, binned: bool = True,
                  bin_capacity: Optional[int] = None, fuse_adam: bool = True, device_refine: bool = False,
-                 capacity: Optional[int] = None):
+                 capacity: Optional[int] = None, lean_views: bool = True):
         """attr_dtype="f16": quaternions, log-scales and SH coefficients are READ from float16 attribute rows
         (include/splat_one_amd.h, so_attr_pack_f16: 112 instead of 224 bytes per Gaussian at SH degree 3); the
         float32 parameters stay the masters Adam updates, and the same Adam launch refreshes the halves."""
@@ -72,6 +72,10 @@ class FusedEngine:
         self.fuse_adam = bool(fuse_adam) and attr_dtype == "f32"
         self.binned = bool(binned) and raster_impl != 1
         self._bin_hint = bin_capacity
+        # record-only views: the per-view arrays (radii, means2d, depths, conics, opacities, colors) are not written by
+        # the forward kernel -- `ws[...]` of those names are strided VIEWS of the 64-byte records, which hold the same
+        # values (48 B per Gaussian and view of stores less; the backward reads radius / colour / opacity from the record)
+        self.lean = bool(lean_views) and self.binned and attr_dtype == "f32"
         self.splats, self.optimizers = splats, optimizers
         self.W, self.H, self.C = int(width), int(height), int(n_views)
         self.cfg = dict(sh_degree=sh_degree, camera_model=camera_model, near_plane=near_plane, far_plane=far_plane,
@@ -263,9 +267,10 @@ class FusedEngine:
         w["pixels_slot"] = torch.tensor([w["pixels"].data_ptr()], dtype=torch.int64, device=dev)
         self._pixels_ref = w["pixels"]
         self._staged = self._sched_staged = False
-        w["radii"], w["tiles_per_gauss"] = e(C, N, dtype=i32), e(C, N, dtype=i32)
-        w["means2d"], w["depths"], w["conics"] = e(C, N, 2), e(C, N), e(C, N, 3)
-        w["opacities"], w["colors"] = e(C, N), e(C, N, 3)
+        if not self.lean:
+            w["radii"], w["tiles_per_gauss"] = e(C, N, dtype=i32), e(C, N, dtype=i32)
+            w["means2d"], w["depths"], w["conics"] = e(C, N, 2), e(C, N), e(C, N, 3)
+            w["opacities"], w["colors"] = e(C, N), e(C, N, 3)
         # counters (2M+3 ints) | loss sums (2 floats) | loss, l1, ssimloss (3 floats) in one allocation
         w["counters"] = torch.zeros(2 * M + 8, dtype=i32, device=dev)
         w["isect_offsets"] = e(C, th, tw, dtype=i32)
@@ -279,6 +284,12 @@ class FusedEngine:
         w["v_render_colors"] = e(C, H, W, 3)
         w["zero_v_alphas"] = torch.zeros(C, H, W, device=dev)
         w["rec"], w["vrec"] = e(C * N, 16), e(C * N, 16)     # 64-byte packed records (allocator aligns to 512 B)
+        if self.lean:        # {x, y, conic a b c, opacity, r g b, depth, radius bits}: include/splat_one_amd.h
+            w["rec"].zero_()
+            rv = w["rec"].view(C, N, 16)
+            w["radii"], w["tiles_per_gauss"] = rv[:, :, 10].view(i32), None
+            w["means2d"], w["depths"], w["conics"] = rv[:, :, 0:2], rv[:, :, 9], rv[:, :, 2:5]
+            w["opacities"], w["colors"] = rv[:, :, 5], rv[:, :, 6:9]
         # slots the binning histogram's returning atomics hand out (the scatter pass then needs no atomics)
         w["tile_slots"] = None if self.binned else e(C * N, _lib.SO_TILE_SLOTS, dtype=i32)
         # gradients: ONE flat static buffer (the data-parallel all-reduce runs on it directly, no
@@ -342,10 +353,10 @@ class FusedEngine:
             d.means, d.log_scales, d.quats, d.logit_opacities = p(s["means"].data), p(s["scales"].data), p(s["quats"].data), p(s["opacities"].data)
             d.sh0, d.shN = p(s["sh0"].data), p(s["shN"].data)
         d.viewmats, d.Ks, d.pixels, d.backgrounds = p(w["viewmats"]), p(w["Ks"]), p(w["pixels"]), 0
-        for k in ("radii", "means2d", "depths", "conics", "opacities", "colors", "tiles_per_gauss", "counters",
-                  "isect_offsets", "key_buf", "flatten_ids", "render_colors", "render_alphas", "last_ids", "loss_sums",
-                  "dmaps", "v_render_colors", "zero_v_alphas", "rec", "vrec"):
-            setattr(d, k, p(w[k]))
+        views = ("radii", "means2d", "depths", "conics", "opacities", "colors", "tiles_per_gauss")
+        for k in views + ("counters", "isect_offsets", "key_buf", "flatten_ids", "render_colors", "render_alphas", "last_ids",
+                          "loss_sums", "dmaps", "v_render_colors", "zero_v_alphas", "rec", "vrec"):
+            setattr(d, k, 0 if (self.lean and k in views) else p(w[k]))
         g = w["grads"]
         d.v_means, d.v_log_scales, d.v_quats, d.v_logit_opacities = p(g["means"]), p(g["scales"]), p(g["quats"]), p(g["opacities"])
         d.v_sh0, d.v_shN = p(g["sh0"]), p(g["shN"])
