@@ -108,10 +108,11 @@ def main():
     ap.add_argument("--views", type=int, default=8, help="ring cameras / target images cycled per GPU (the reference draws a new view per step)")
     ap.add_argument("--attr-dtype", default="f32", choices=["f32", "f16"],
                     help="f16: float16 attribute rows (BASELINE.json configs[4]); float32 arithmetic and masters")
-    ap.add_argument("--dp-mode", default="auto", choices=["auto", "gaussian_sharded", "allreduce"],
-                    help="multi-GPU scheme (ignored at --gpus 1): all-reduce of the Gaussian gradients (BASELINE.json's "
-                         "north_star), exchange of projected Gaussians (the reference's own scheme), or auto = time "
-                         "both for a few steps on this node and keep the faster")
+    ap.add_argument("--dp-mode", default="allreduce", choices=["auto", "gaussian_sharded", "allreduce"],
+                    help="multi-GPU scheme of the headline value (ignored at --gpus 1): allreduce (= auto) -- replicated "
+                         "Gaussians, reduce-scatter / sharded Adam / all-gather of the gradient SoA, BASELINE.json's "
+                         "north_star; gaussian_sharded -- the reference's own scheme (projected Gaussians exchanged by "
+                         "all-to-all).  The other scheme is timed too and reported in config.other_scheme")
     args = ap.parse_args()
     if args.densify:      # warm up past the first two refinements: both model sets' graphs are captured before timing
         args.warmup = max(args.warmup, 2 * args.densify + 1)
@@ -190,22 +191,22 @@ def main():
         return (float(t.item()), tup) if ok.item() else (float("inf"), None)
 
     dp_probe = None
+    other_mode = None
     if world == 1:
         cfg, runner, views = make_runner("allreduce")
-    elif args.dp_mode == "auto":
-        t_ar, tup_ar = probe("allreduce")
-        t_gs, tup_gs = probe("gaussian_sharded")
-        dp_probe = {"allreduce_ms": None if tup_ar is None else t_ar * 1e3,
-                    "gaussian_sharded_ms": None if tup_gs is None else t_gs * 1e3}
-        assert tup_ar is not None or tup_gs is not None, "both multi-GPU schemes failed"
-        cfg, runner, views = tup_gs if t_gs < t_ar else tup_ar
-        del tup_ar, tup_gs
-        torch.cuda.empty_cache()
     else:
-        t_one, tup = probe(args.dp_mode)
-        if tup is None:      # the requested scheme failed on some rank: every rank falls back together
-            other = "allreduce" if args.dp_mode == "gaussian_sharded" else "gaussian_sharded"
-            t_one, tup = probe(other)
+        # BASELINE.json's north_star scheme -- replicated Gaussians, gradients reduced over xGMI -- is the headline
+        # unless --dp-mode asks for the reference's Gaussian sharding; the OTHER scheme is timed for the same --steps
+        # after the headline run and reported next to it (config.other_scheme).  A scheme that fails on any rank is
+        # replaced by the other one on every rank.
+        first = "gaussian_sharded" if args.dp_mode == "gaussian_sharded" else "allreduce"
+        other_mode = "allreduce" if first == "gaussian_sharded" else "gaussian_sharded"
+        t_one, tup = probe(first)
+        dp_probe = {first + "_ms": None if tup is None else t_one * 1e3}
+        if tup is None:
+            first, other_mode = other_mode, None
+            t_one, tup = probe(first)
+            dp_probe[first + "_ms"] = None if tup is None else t_one * 1e3
         assert tup is not None, "both multi-GPU schemes failed"
         cfg, runner, views = tup
     step_once = Stepper(runner, views)
@@ -404,7 +405,8 @@ def main():
                    "binned_lists": bool(fused and not runner.sharded and runner._engine.binned),
                    "parallelism": (f"gaussian-sharded dp{world}: one view per GPU, N/{world} Gaussians per GPU, "
                                    "projected Gaussians exchanged by all-to-all" if runner.sharded else
-                                   f"view-sharded dp{world}" + (", gradient all-reduce" if world > 1 else "")),
+                                   f"view-sharded dp{world}" + (f", replicated Gaussians: reduce-scatter / 1/{world} Adam / all-gather of the "
+                                                                f"gradient SoA in {cfg.dp_chunks} chunks over RCCL" if world > 1 else "")),
                    "dp_mode_probe_ms_per_step": dp_probe},
         "forward_mpix_per_s": None if runner.sharded else world * P / fwd_s / 1e6,
         "hbm_iter_fraction": b_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9),
@@ -420,6 +422,32 @@ def main():
         out["densify"] = {"every": args.densify, "gaussians_before_timed_region": n_before_timed, "gaussians_after": N,
                           "device_side": bool(fused and getattr(runner._engine, "device_refine", False)),
                           "grow_grad2d": cfg.strategy.grow_grad2d, "one_refinement_ms": refine_ms}
+    if world > 1 and other_mode is not None:
+        del runner
+        torch.cuda.empty_cache()
+        other = {"dp_mode": other_mode, "value": None, "ms_per_step": None}
+        ok = torch.ones(1, device=dev)
+        dt = 0.0
+        try:
+            _cfg2, r2, v2 = make_runner(other_mode)
+            st2 = Stepper(r2, v2)
+            for _ in range(max(1, args.warmup)):
+                st2()
+            barrier()
+            t0 = time.time()
+            for _ in range(args.steps):
+                st2()
+            barrier()
+            dt = time.time() - t0
+        except Exception as e:   # noqa: BLE001
+            print(f"[bench] dp_mode {other_mode} failed on rank {rank}: {e!r}", file=sys.stderr)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        if ok.item():
+            other.update(value=world * args.steps / float(tt.item()), ms_per_step=float(tt.item()) / args.steps * 1e3)
+        out["config"]["other_scheme"] = other
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N0, W, H, args.regime)
     if rank == 0:

@@ -129,6 +129,114 @@ def all_reduce_mean_(flat: torch.Tensor, group=None) -> None:
     flat.mul_(1.0 / dist.get_world_size(group))
 
 
+class ShardedFlatAdam:
+    """Optimiser step of the replicated ("allreduce") data-parallel scheme, SURVEY.md section 8(e): instead of ONE
+    blocking all-reduce of the flat gradient followed by a full Adam on every rank, the flat buffer is cut into
+    `n_chunks` chunks and every chunk into `world` pieces;
+
+        reduce-scatter(chunk c)   -> rank r holds the SUM of piece (c, r)            (all chunks issued up front)
+        Adam on piece (c, r)      -> as soon as reduction c has landed (1/world of the parameters per rank)
+        all-gather(chunk c)       -> every rank has the updated parameters of chunk c
+
+    so the collectives of chunk c+1 run on the RCCL stream while Adam of chunk c runs on the compute stream, the
+    optimiser's HBM traffic (28 B per parameter float) shrinks by `world`, and the moments of a parameter live on one
+    rank only (`gather_moments` all-gathers them before a structural edit, i.e. a refinement).  On xGMI (point-to-point,
+    7 links per GPU) reduce-scatter + all-gather move (world-1)/world of the buffer per rank and phase, spread over all
+    links, where a ring all-reduce pushes 2 (world-1)/world of it through one link.
+
+    Layout contract: gradients, parameters and both moments are FLAT float32 buffers of at least `padded_total`
+    elements sharing one segment layout (the engine's: tensors in a fixed order, each starting at a multiple of 64
+    floats).  `adam_fn(start, stop)` updates parameters and moments of the flat range [start, stop) from the (already
+    averaged) gradient of that range; it is the HIP launch on the GPU (FusedEngine.adam_on_flat_range) and a torch
+    restatement in the CPU tests.
+
+    Backends: "nccl" (= RCCL) uses reduce_scatter_tensor / all_gather_into_tensor in place; gloo, which has no
+    reduce-scatter, reduces every piece to its owner (`dist.reduce`, the same bytes) and all-gathers into views."""
+
+    ALIGN = 64   # floats: piece boundaries stay 256-byte aligned (float4 kernels)
+
+    def __init__(self, total: int, n_chunks: int = 4, group=None):
+        self.group = group
+        self.rank, self.world = (dist.get_rank(group), dist.get_world_size(group)) if is_initialized() else (0, 1)
+        self.n_chunks = max(1, int(n_chunks))
+        q = self.world * self.ALIGN
+        self.chunk = -(-int(total) // (self.n_chunks * q)) * q          # elements per chunk, a multiple of world * ALIGN
+        self.piece = self.chunk // self.world
+        self.total = int(total)
+        self.padded_total = self.chunk * self.n_chunks
+        self.backend = dist.get_backend(group) if is_initialized() else "none"
+
+    def piece_range(self, c: int, r: Optional[int] = None):
+        r = self.rank if r is None else r
+        a = c * self.chunk + r * self.piece
+        return a, a + self.piece
+
+    def my_ranges(self):
+        return [self.piece_range(c) for c in range(self.n_chunks)]
+
+    def bytes_per_link_and_step(self) -> float:
+        """Bytes every rank sends (= receives) per optimiser step: reduce-scatter + all-gather of the padded buffer."""
+        return 2.0 * (self.world - 1) / max(1, self.world) * self.padded_total * 4.0
+
+    def _reduce_scatter(self, flat: torch.Tensor, c: int):
+        chunk = flat[c * self.chunk:(c + 1) * self.chunk]
+        if self.backend != "nccl" and flat.is_cuda:
+            # gloo moves HIP tensors only through broadcast / all_reduce (several ranks on one GPU in the tests)
+            return [dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+        if self.backend == "nccl":
+            a, b = self.piece_range(c)
+            return [dist.reduce_scatter_tensor(flat[a:b], chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+        works = []
+        for j in range(self.world):      # gloo: piece j is reduced to rank j
+            a, b = self.piece_range(c, j)
+            works.append(dist.reduce(flat[a:b], dst=j if self.group is None else dist.get_global_rank(self.group, j),
+                                     op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return works
+
+    def _all_gather(self, flat: torch.Tensor, c: int):
+        chunk = flat[c * self.chunk:(c + 1) * self.chunk]
+        a, b = self.piece_range(c)
+        if self.backend != "nccl" and flat.is_cuda:      # gloo + HIP tensors: x + 0 + ... + 0 is an all-gather
+            chunk[:a - c * self.chunk].zero_()
+            chunk[b - c * self.chunk:].zero_()
+            return dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self.backend == "nccl":
+            return dist.all_gather_into_tensor(chunk, flat[a:b], group=self.group, async_op=True)
+        outs = [chunk[j * self.piece:(j + 1) * self.piece] for j in range(self.world)]
+        return dist.all_gather(outs, flat[a:b].clone(), group=self.group, async_op=True)
+
+    @torch.no_grad()
+    def step(self, grad_flat: torch.Tensor, param_flat: torch.Tensor, adam_fn: Callable[[int, int], None]) -> None:
+        assert grad_flat.numel() >= self.padded_total and param_flat.numel() >= self.padded_total, \
+            (grad_flat.numel(), param_flat.numel(), self.padded_total)
+        if self.world == 1:
+            adam_fn(0, self.padded_total)
+            return
+        rs = [self._reduce_scatter(grad_flat, c) for c in range(self.n_chunks)]
+        ag = []
+        inv = 1.0 / self.world
+        for c in range(self.n_chunks):
+            for w in rs[c]:
+                w.wait()
+            a, b = self.piece_range(c)
+            grad_flat[a:b].mul_(inv)                 # mean over the views of all ranks
+            adam_fn(a, b)
+            ag.append(self._all_gather(param_flat, c))
+        for w in ag:
+            w.wait()
+
+    @torch.no_grad()
+    def gather_moments(self, *flats: torch.Tensor) -> None:
+        """All-gather the owner pieces of the given flat buffers (exp_avg, exp_avg_sq) so that every rank holds all of
+        them -- before a refinement rewrites the Gaussian set identically on every rank."""
+        if self.world == 1:
+            return
+        for f in flats:
+            works = [self._all_gather(f, c) for c in range(self.n_chunks)]
+            for w in works:
+                w.wait()
+
+
 def all_reduce_max_(t: torch.Tensor, group=None) -> None:
     """In-place element-wise maximum over ranks (visibility masks, overflow flags)."""
     if not is_initialized() or dist.get_world_size(group) == 1:

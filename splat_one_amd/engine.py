@@ -45,7 +45,7 @@ class FusedEngine:
                  isect_capacity: Optional[int] = None, use_graph: bool = True, raster_impl: int = 0,
                  attr_dtype: str = "f32", tile_cull: bool = True, binned: bool = True,
                  bin_capacity: Optional[int] = None, fuse_adam: bool = True, device_refine: bool = False,
-                 capacity: Optional[int] = None, lean_views: bool = True):
+                 capacity: Optional[int] = None, lean_views: bool = True, flat_multiple: int = 0):
         """attr_dtype="f16": quaternions, log-scales and SH coefficients are READ from float16 attribute rows
         (include/splat_one_amd.h, so_attr_pack_f16: 112 instead of 224 bytes per Gaussian at SH degree 3); the
         float32 parameters stay the masters Adam updates, and the same Adam launch refreshes the halves."""
@@ -58,6 +58,11 @@ class FusedEngine:
         # (ParameterDict, optimiser state, statistics) are re-pointed lazily by `sync_host()`.
         self.device_refine = bool(device_refine)
         assert not (self.device_refine and attr_dtype != "f32"), "device_refine needs float32 attributes"
+        # flat_multiple > 0 (replicated data parallelism, distributed.ShardedFlatAdam): parameters and both moments live
+        # in FLAT buffers with the segment layout of the flat gradient, padded to a multiple of `flat_multiple` floats,
+        # so that reduce-scatter / sharded Adam / all-gather work on contiguous ranges of all four
+        self.flat_multiple = int(flat_multiple)
+        assert not (self.flat_multiple and self.device_refine), "flat_multiple and device_refine are separate modes"
         self._capacity_request = capacity
         self._host_stale = False
         self._lock = threading.RLock()
@@ -225,6 +230,29 @@ class FusedEngine:
         r = self._report.cpu().tolist()
         return {"n_dupli": r[0], "n_split": r[1], "n_prune": r[2], "n_new": r[3], "overflow": r[4], "n_old": r[5], "refinements": r[6]}
 
+    def adam_on_flat_range(self, a: int, b: int) -> None:
+        """Adam (host-scheduled: so_adam_step) on the flat range [a, b) of parameters / moments / gradient -- the piece of
+        the model this rank owns in a reduce-scattered step (distributed.ShardedFlatAdam).  The range is cut at the
+        tensor boundaries: every tensor keeps its own learning rate (gsplat_trainer.py:246-257, :266-278)."""
+        assert self.flat_multiple, "adam_on_flat_range needs FusedEngine(flat_multiple=...)"
+        w, t = self.ws, self.steps_done + 1
+        groups, betas, eps = [], None, None
+        for k in PARAM_ORDER:
+            o, n = self.flat_segments[k]
+            lo, hi = max(a, o), min(b, o + n)
+            if lo >= hi:
+                continue
+            grp = self.optimizers[k].param_groups[0]
+            betas, eps = grp["betas"], grp["eps"]
+            sl = lambda name: w[name][lo:hi]
+            groups.append(_lib.AdamGroup(_lib.ptr(sl("params_flat")), _lib.ptr(sl("grads_flat")), _lib.ptr(sl("m_flat")),
+                                         _lib.ptr(sl("v_flat")), 0, hi - lo, 1, grp["lr"] / (1.0 - betas[0] ** t),
+                                         math.sqrt(1.0 - betas[1] ** t)))
+        if not groups:
+            return
+        arr = (_lib.AdamGroup * len(groups))(*groups)
+        _lib.call("so_adam_step", len(groups), arr, float(betas[0]), float(betas[1]), float(eps), 0, _lib.stream())
+
     def _adam_args_host(self) -> None:
         for k in PARAM_ORDER:
             prm = self.splats[k]
@@ -299,16 +327,39 @@ class FusedEngine:
         if not self.device_refine:
             numel = {k: self.splats[k].numel() for k in PARAM_ORDER}
         total = sum(pad(numel[k]) for k in PARAM_ORDER)
+        self.flat_total = total
+        alloc = total if not self.flat_multiple else -(-total // self.flat_multiple) * self.flat_multiple
         # one spare slot behind the gradients carries "this iteration is void" through a gradient all-reduce
-        w["grads_flat"] = torch.zeros(total + 64, dtype=f32, device=dev)
-        w["ovf_f32"] = w["grads_flat"][total:total + 1]
+        w["grads_flat"] = torch.zeros(alloc + 64, dtype=f32, device=dev)
+        w["ovf_f32"] = w["grads_flat"][alloc:alloc + 1]
+        self.flat_segments = {}
         # measure the first view's intersection count (fullest tile) unless the caller fixed the size
         self._probe_capacity = self._bin_hint is None if self.binned else self._capacity_hint is None
         w["grads"], off = {}, 0
         for k in PARAM_ORDER:
             n = numel[k]
             w["grads"][k] = w["grads_flat"][off:off + n].view((N,) + tuple(self.splats[k].shape[1:]))
+            self.flat_segments[k] = (off, n)
             off += pad(n)
+        if self.flat_multiple:      # flat parameters / moments; the torch-side handles become views of them
+            self._adam_args_host()
+            for name, src in (("params_flat", lambda k: self.splats[k].detach()),
+                              ("m_flat", lambda k: self.optimizers[k].state[self.splats[k]]["exp_avg"]),
+                              ("v_flat", lambda k: self.optimizers[k].state[self.splats[k]]["exp_avg_sq"])):
+                w[name] = torch.zeros(alloc + 64, dtype=f32, device=dev)
+                for k in PARAM_ORDER:
+                    o, n = self.flat_segments[k]
+                    w[name][o:o + n].copy_(src(k).reshape(-1))
+            for k in PARAM_ORDER:
+                o, n = self.flat_segments[k]
+                old = self.splats[k]
+                new = torch.nn.Parameter(w["params_flat"][o:o + n].view(old.shape), requires_grad=True)
+                opt = self.optimizers[k]
+                st = opt.state.pop(old)
+                st["exp_avg"], st["exp_avg_sq"] = w["m_flat"][o:o + n].view(old.shape), w["v_flat"][o:o + n].view(old.shape)
+                opt.state[new] = st
+                opt.param_groups[0]["params"] = [new]
+                self.splats[k] = new
         for k in PARAM_ORDER:
             self.splats[k].grad = w["grads"][k][:self.splats[k].shape[0]]
         if self.attr_dtype == "f16":
@@ -528,14 +579,6 @@ class FusedEngine:
                       f"exceeded the buffer capacity {self.capacity}; buffers enlarged", RuntimeWarning)
         self._grow(max(n_prev, n_last))
 
-    def merge_global_overflow(self) -> None:
-        """Data-parallel steps, after the gradient all-reduce: `ovf_f32` then holds the SUM over ranks of the void
-        flags.  Fold it into this rank's own overflow word, so that the status words the next so_step_inputs publishes
-        -- and with them `_check_previous` -- agree on every rank: all ranks raise (or grow) on the same step instead
-        of one raising while its peers block in the next collective."""
-        c, i = self.ws["counters"], 2 * self.M + 2
-        c[i:i + 1].copy_(torch.maximum(c[i:i + 1], (self.ws["ovf_f32"] > 0).to(torch.int32)))
-
     def set_views(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor, schedule: bool = False) -> None:
         """Stage this step's cameras and target images.  camtoworlds[C,4,4] (inverted on the device),
         Ks[C,3,3], pixels[C,H,W,3] in 0..1 -- a contiguous float32 HIP tensor is used IN PLACE (keep it
@@ -621,6 +664,7 @@ class FusedEngine:
         if key not in self._graphs_fb:
             self._capture_split(key)
         self._graph_fb, self._graph_opt = self._graphs_fb[key]
+        self._graph_opt = self._graph_opt or None
         self._consume_staging()
         self._graph_fb.replay()
 
@@ -666,6 +710,8 @@ class FusedEngine:
                 self._launch_fwd_bwd()
             opt = {}
             for sched in (False, True):
+                if self.flat_multiple:           # the optimiser of this mode is distributed.ShardedFlatAdam
+                    break
                 opt[sched] = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(opt[sched]):
                     self._launch_optimize(sched)

@@ -131,6 +131,7 @@ class Config:
     device_refine: bool = True
     max_gaussians: Optional[int] = None    # capacity of the device-resident model; None: max(2 N, 2^20), doubled when exceeded
     refine_seed: int = 1234                # seed of the split noise (same on every rank)
+    dp_chunks: int = 4                     # dp_mode="allreduce": chunks of the reduce-scatter / Adam / all-gather pipeline
     shN_init_std: float = 0.0              # >0: noise instead of zeros in the higher SH bands (bench scenes)
 
     def adjust_steps(self, factor: float):
@@ -620,7 +621,9 @@ class Runner:
                 raster_impl=getattr(self, "raster_impl", 0), attr_dtype=cfg.attr_dtype, tile_cull=cfg.tile_cull,
                 binned=(cfg.binned and self.world_size == 1),   # replicas keep the compact layout: one global
                 bin_capacity=cfg.bin_capacity,                  # slack instead of a per-tile one, and no per-rank growth
-                fuse_adam=cfg.fuse_adam, device_refine=dev_refine, capacity=cfg.max_gaussians)
+                fuse_adam=cfg.fuse_adam, device_refine=dev_refine, capacity=cfg.max_gaussians,
+                flat_multiple=(cfg.dp_chunks * self.world_size * sdist.ShardedFlatAdam.ALIGN if self.world_size > 1 else 0))
+            self._sadam = None
             eng.steps_done = step
             eng._step_dev[0] = step
             if self.world_size > 1:
@@ -630,14 +633,20 @@ class Runner:
         stats_on = isinstance(s, DefaultStrategy) and step < s.refine_stop_iter
         if stats_on != (eng.strategy_state is not None):
             eng.bind_strategy_state(self._strategy_state if stats_on else None)
-        eng.set_views(camtoworlds, Ks, pixels, schedule=True)   # the step below always runs the optimiser
         if self.world_size == 1:
+            eng.set_views(camtoworlds, Ks, pixels, schedule=True)   # the step below always runs the optimiser
             eng.step()
         else:
+            # replicated Gaussians: reduce-scatter of the flat gradient in chunks, Adam on this rank's 1/world of every
+            # chunk as it lands, all-gather of the updated parameters (distributed.ShardedFlatAdam)
+            eng.set_views(camtoworlds, Ks, pixels, schedule=False)
             eng.fwd_bwd()
-            sdist.all_reduce_mean_(eng.ws["grads_flat"])     # ONE collective on the flat gradient SoA
-            eng.merge_global_overflow()                      # a void iteration on one rank is void (and raised) on all
-            eng.optimize()
+            if self._sadam is None or self._sadam.total != eng.flat_total:
+                self._sadam = sdist.ShardedFlatAdam(eng.flat_total, n_chunks=cfg.dp_chunks)
+            M = eng.M
+            sdist.all_reduce_max_(eng.ws["counters"][2 * M + 2:2 * M + 3])   # a void iteration on one rank is raised on all
+            self._sadam.step(eng.ws["grads_flat"], eng.ws["params_flat"], eng.adam_on_flat_range)
+            eng._advance_host_counters()
         if isinstance(s, MCMCStrategy):
             # lr = the means learning rate after this step's scheduler.step() (gsplat_trainer.py:753-761)
             n_before = len(self.splats["means"])
@@ -672,6 +681,8 @@ class Runner:
                 if refine_now:
                     if self.world_size > 1:
                         sdist.all_reduce_strategy_state(self.strategy_state)
+                        if self._sadam is not None:      # every rank rewrites ALL moments: fetch the other owners' pieces
+                            self._sadam.gather_moments(eng.ws["m_flat"], eng.ws["v_flat"])
                     n_dupli, n_split = s._grow_gs(self.splats, self.optimizers, self.strategy_state, step, self._split_gen)
                     n_prune = s._prune_gs(self.splats, self.optimizers, self.strategy_state, step)
                     if s.verbose:

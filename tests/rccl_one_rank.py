@@ -5,6 +5,8 @@ import os
 import sys
 import time
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
 import torch
 import torch.distributed as dist
 
@@ -42,6 +44,23 @@ red._flat = None
 flat = torch.ones(16, device=dev)
 dist.all_reduce(flat)
 sdist.all_reduce_strategy_state({"grad2d": torch.ones(4, device=dev), "count": torch.ones(4, device=dev)})
+# reduce-scatter / sharded Adam / all-gather of the replicated scheme: the RCCL branches (in-place
+# reduce_scatter_tensor, all_gather_into_tensor, async work handles) -- with one rank step() short-cuts, so the
+# collective helpers are called directly
+sa = sdist.ShardedFlatAdam(1000, n_chunks=3)
+assert sa.backend == "nccl" and sa.world == 1 and sa.padded_total % (3 * 64) == 0
+buf = torch.arange(sa.padded_total, dtype=torch.float32, device=dev)
+ref = buf.clone()
+for c in range(sa.n_chunks):
+    for wk in sa._reduce_scatter(buf, c):
+        wk.wait()
+    sa._all_gather(buf, c).wait()
+torch.cuda.synchronize()
+assert torch.equal(buf, ref)
+sa.gather_moments(buf, buf.clone())
+mx = torch.tensor([3], dtype=torch.int32, device=dev)
+sdist.all_reduce_max_(mx)
+assert int(mx) == 3
 print("helpers ok", flush=True)
 
 # rasterization(distributed=True) == the plain call when the group has one rank

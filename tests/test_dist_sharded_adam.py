@@ -1,0 +1,121 @@
+"""The reduce-scatter / sharded-Adam / all-gather step of the replicated data-parallel scheme (SURVEY.md section 8e;
+hyper-parameters per /root/reference/utils/gsplat_utils/gsplat_trainer.py:266-278) on CPU over gloo with 2, 4 and 8
+ranks and a Gaussian count that divides by nothing: after several steps every rank holds the parameters a
+single-process `torch.optim.Adam` reaches on the MEAN of the ranks' gradients, bit-equal across ranks; the moments of a
+piece live on its owner and `gather_moments` restores them everywhere (what a refinement needs)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+ROWS = {"means": 3, "scales": 3, "quats": 4, "opacities": 1, "sh0": 3, "shN": 45}
+LRS = {"means": 1.6e-4, "scales": 5e-3, "quats": 1e-3, "opacities": 5e-2, "sh0": 2.5e-3, "shN": 2.5e-3 / 20}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _layout(N):
+    pad = lambda n: (n + 63) // 64 * 64
+    segs, off = {}, 0
+    for k, rl in ROWS.items():
+        segs[k] = (off, N * rl)
+        off += pad(N * rl)
+    return segs, off
+
+
+def _grads(N, rank, step):
+    g = torch.Generator().manual_seed(1000 * step + rank)
+    return {k: torch.randn(N * rl, generator=g) * (1 + rank) for k, rl in ROWS.items()}
+
+
+def _hyper(world):
+    from splat_one_amd.trainer import adam_hyperparameters
+    return {k: adam_hyperparameters(LRS[k], 1, world) for k in ROWS}
+
+
+def _worker(local_rank, world_rank, world_size, args):
+    out_dir, N, n_chunks, steps = args
+    from splat_one_amd.distributed import ShardedFlatAdam
+    segs, total = _layout(N)
+    sa = ShardedFlatAdam(total, n_chunks=n_chunks)
+    assert sa.padded_total >= total and sa.piece % 64 == 0 and sa.chunk == sa.piece * world_size
+    P = torch.zeros(sa.padded_total)
+    G = torch.zeros(sa.padded_total)
+    M = torch.zeros(sa.padded_total)
+    V = torch.zeros(sa.padded_total)
+    g0 = torch.Generator().manual_seed(7)
+    for k, (off, n) in segs.items():
+        P[off:off + n] = torch.randn(n, generator=g0)
+    hyper = _hyper(world_size)
+    t = [0]
+
+    def adam_fn(a, b):
+        # torch restatement of so_adam_step on the flat range [a, b): one group per tensor segment it intersects
+        for k, (off, n) in segs.items():
+            lo, hi = max(a, off), min(b, off + n)
+            if lo >= hi:
+                continue
+            lr, eps, (b1, b2) = hyper[k]
+            g = G[lo:hi]
+            M[lo:hi].mul_(b1).add_(g, alpha=1 - b1)
+            V[lo:hi].mul_(b2).addcmul_(g, g, value=1 - b2)
+            denom = (V[lo:hi].sqrt() / (1 - b2 ** t[0]) ** 0.5).add_(eps)
+            P[lo:hi].addcdiv_(M[lo:hi], denom, value=-lr / (1 - b1 ** t[0]))
+
+    for step in range(steps):
+        G.zero_()
+        for k, (off, n) in segs.items():
+            G[off:off + n] = _grads(N, world_rank, step)[k]
+        t[0] = step + 1
+        sa.step(G, P, adam_fn)
+    m_own = M.clone()
+    sa.gather_moments(M, V)
+    mine = torch.zeros(sa.padded_total, dtype=torch.bool)
+    for a, b in sa.my_ranges():
+        mine[a:b] = True
+    assert torch.equal(M[mine], m_own[mine]) and not m_own[~mine].any() and M[~mine].any()
+    torch.save({"P": P, "M": M, "V": V, "bytes": sa.bytes_per_link_and_step()}, os.path.join(out_dir, f"r{world_rank}.pt"))
+
+
+@pytest.mark.parametrize("world,n_chunks,N", [(2, 4, 1001), (4, 4, 777), (8, 5, 1234)])
+def test_sharded_adam_equals_adam_on_the_mean_gradient(tmp_path, world, n_chunks, N):
+    from splat_one_amd import distributed as sdist
+    steps = 3
+    env_backup = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        sdist.cli(_worker, (str(tmp_path), N, n_chunks, steps), world_size=world, backend="gloo", port=_free_port())
+    finally:
+        for k, v in env_backup.items():
+            if v is not None:
+                os.environ[k] = v
+    outs = [torch.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(world)]
+    for o in outs[1:]:
+        assert torch.equal(o["P"], outs[0]["P"]) and torch.equal(o["M"], outs[0]["M"]) and torch.equal(o["V"], outs[0]["V"])
+    # single-process reference: torch.optim.Adam per tensor on the mean gradient, the reference's hyper-parameter rule
+    segs, total = _layout(N)
+    hyper = _hyper(world)
+    g0 = torch.Generator().manual_seed(7)
+    params, opts = {}, {}
+    for k, (off, n) in segs.items():
+        params[k] = torch.nn.Parameter(torch.randn(n, generator=g0))
+        lr, eps, betas = hyper[k]
+        opts[k] = torch.optim.Adam([params[k]], lr=lr, eps=eps, betas=betas)
+    for step in range(steps):
+        for k in ROWS:
+            params[k].grad = sum(_grads(N, r, step)[k] for r in range(world)) / world
+            opts[k].step()
+    for k, (off, n) in segs.items():
+        got = outs[0]["P"][off:off + n]
+        assert torch.allclose(got, params[k].detach(), rtol=1e-5, atol=1e-7), k
+        st = opts[k].state[params[k]]
+        assert torch.allclose(outs[0]["M"][off:off + n], st["exp_avg"], rtol=1e-5, atol=1e-6), k
+    padded = outs[0]["P"].numel()
+    assert abs(outs[0]["bytes"] - 2 * (world - 1) / world * padded * 4) < 1
