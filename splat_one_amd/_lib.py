@@ -75,6 +75,8 @@ class AttrShadow(ctypes.Structure):
 _SIGS = {
     "so_projection_fwd": [c_int, c_int] + [c_ptr] * 6 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int] + [c_ptr] * 6,
     "so_projection_bwd": [c_int, c_int] + [c_ptr] * 6 + [c_int, c_int, c_f32, c_int] + [c_ptr] * 11,
+    "so_projection_packed": [c_int, c_int] + [c_ptr] * 6 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int] + [c_ptr] * 11,
+    "so_projection_bwd_packed": [c_int, c_int, c_i64] + [c_ptr] * 6 + [c_int, c_int, c_f32, c_int] + [c_ptr] * 12,
     "so_sh_fwd": [c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr],
     "so_sh_bwd": [c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
     "so_isect_count": [c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_int] + [c_ptr] * 6,
@@ -128,7 +130,7 @@ _lib: Optional[ctypes.CDLL] = None
 
 def exported_symbols():
     return ["so_abi_version", "so_last_error", "so_device_cu_count", "so_profile_num_stages",
-            "so_profile_stage_name", "so_profile_stage_begin_end", "so_attr_rec_stride", "so_refine_scratch_words"] + list(_SIGS)
+            "so_profile_stage_name", "so_profile_stage_begin_end", "so_attr_rec_stride", "so_refine_scratch_words", "so_projection_packed_blocks"] + list(_SIGS)
 
 
 def load() -> ctypes.CDLL:
@@ -148,6 +150,8 @@ def load() -> ctypes.CDLL:
         lib.so_profile_stage_name.argtypes = [c_int]
         lib.so_attr_rec_stride.restype = c_i64
         lib.so_attr_rec_stride.argtypes = [c_int]
+        lib.so_projection_packed_blocks.restype = c_i64
+        lib.so_projection_packed_blocks.argtypes = [c_int, c_int]
         lib.so_refine_scratch_words.restype = c_i64
         lib.so_refine_scratch_words.argtypes = [c_i64]
         for name, argtypes in _SIGS.items():

@@ -147,32 +147,36 @@ def _sparse_rows(dense: Optional[Tensor], rows: Tensor) -> Optional[Tensor]:
 
 class _PackedProjection(torch.autograd.Function):
     """Packed layout of gsplat's `fully_fused_projection(packed=True)`: one row per (camera, Gaussian) pair with a
-    positive radius, camera-major.  The projection kernel works on the [C,N] grid; what is returned and what is kept for
-    the backward are the nnz packed rows (the [C,N] scratch is released when forward returns)."""
+    positive radius, in ascending flattened index (camera-major).  Two passes of `so_projection_packed` over the raw
+    inputs -- count + scan, then write -- with ONE host read (nnz, to size the outputs) and no [C,N] array; the backward
+    (`so_projection_bwd_packed`) works on the nnz rows too."""
 
     @staticmethod
     def forward(ctx, means, covars6, quats, scales, viewmats, Ks, width, height, eps2d, near_plane,
                 far_plane, radius_clip, calc_compensations, camera_model, sparse_grad):
+        from . import _lib
         C, N = viewmats.shape[0], means.shape[0]
         dev = means.device
-        radii = torch.empty(C, N, dtype=torch.int32, device=dev)
-        means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
-        depths = torch.empty(C, N, dtype=torch.float32, device=dev)
-        conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
-        comps = torch.empty(C, N, dtype=torch.float32, device=dev) if calc_compensations else None
-        call("so_projection_fwd", C, N, ptr(means), ptr(covars6), ptr(quats), ptr(scales), ptr(viewmats),
-             ptr(Ks), width, height, eps2d, near_plane, far_plane, radius_clip, camera_model, ptr(radii),
-             ptr(means2d), ptr(depths), ptr(conics), ptr(comps), stream())
-        sel = torch.nonzero(radii.reshape(-1) > 0).squeeze(1)        # [nnz] row-major = camera-major (one host read: nnz)
-        camera_ids = torch.div(sel, max(N, 1), rounding_mode="floor")
-        gaussian_ids = sel - camera_ids * N
-        radii_p = radii.reshape(-1)[sel]
-        means2d_p = means2d.reshape(-1, 2)[sel]
-        depths_p = depths.reshape(-1)[sel]
-        conics_p = conics.reshape(-1, 3)[sel]
-        comps_p = comps.reshape(-1)[sel] if comps is not None else None
-        ctx.save_for_backward(means, covars6, quats, scales, viewmats, Ks, sel, gaussian_ids, radii_p, conics_p, comps_p)
-        ctx.cfg = (width, height, eps2d, camera_model, sparse_grad)
+        nblk = int(_lib.load().so_projection_packed_blocks(C, N))
+        counts = torch.empty(max(nblk, 1), dtype=torch.int32, device=dev)
+        offsets = torch.empty(max(nblk, 1), dtype=torch.int64, device=dev)
+        total = torch.zeros(1, dtype=torch.int64, device=dev)
+        common = (C, N, ptr(means), ptr(covars6), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), width, height, eps2d,
+                  near_plane, far_plane, radius_clip, camera_model)
+        call("so_projection_packed", *common, ptr(counts), ptr(offsets), ptr(total), 0, 0, 0, 0, 0, 0, 0, stream())
+        nnz = int(total.item())                                   # the one host read: sizes of the returned tensors
+        camera_ids = torch.empty(nnz, dtype=torch.int64, device=dev)
+        gaussian_ids = torch.empty(nnz, dtype=torch.int64, device=dev)
+        radii_p = torch.empty(nnz, dtype=torch.int32, device=dev)
+        means2d_p = torch.empty(nnz, 2, dtype=torch.float32, device=dev)
+        depths_p = torch.empty(nnz, dtype=torch.float32, device=dev)
+        conics_p = torch.empty(nnz, 3, dtype=torch.float32, device=dev)
+        comps_p = torch.empty(nnz, dtype=torch.float32, device=dev) if calc_compensations else None
+        if nnz:
+            call("so_projection_packed", *common, 0, ptr(offsets), 0, ptr(camera_ids), ptr(gaussian_ids), ptr(radii_p),
+                 ptr(means2d_p), ptr(depths_p), ptr(conics_p), ptr(comps_p), stream())
+        ctx.save_for_backward(means, covars6, quats, scales, viewmats, Ks, camera_ids, gaussian_ids)
+        ctx.cfg = (width, height, eps2d, camera_model, sparse_grad, comps_p is not None)
         ctx.mark_non_differentiable(camera_ids, gaussian_ids, radii_p)
         if comps_p is None:
             return camera_ids, gaussian_ids, radii_p, means2d_p, depths_p, conics_p
@@ -180,32 +184,23 @@ class _PackedProjection(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, _v_cid, _v_gid, _v_radii, v_means2d, v_depths, v_conics, v_comps=None):
-        means, covars6, quats, scales, viewmats, Ks, sel, gaussian_ids, radii_p, conics_p, comps_p = ctx.saved_tensors
-        width, height, eps2d, camera_model, sparse_grad = ctx.cfg
+        means, covars6, quats, scales, viewmats, Ks, camera_ids, gaussian_ids = ctx.saved_tensors
+        width, height, eps2d, camera_model, sparse_grad, has_comps = ctx.cfg
         C, N = viewmats.shape[0], means.shape[0]
+        nnz = camera_ids.shape[0]
         dev = means.device
-
-        def dense(rows, shape, dtype=torch.float32):     # packed rows back onto the [C,N] grid (zeros elsewhere)
-            out = torch.zeros(shape, dtype=dtype, device=dev)
-            if rows is not None:
-                out.view(C * N, *shape[2:])[sel] = rows.to(dtype)
-            return out
-        radii = dense(radii_p, (C, N), torch.int32)
-        conics = dense(conics_p, (C, N, 3))
-        comps = None if comps_p is None else dense(comps_p, (C, N))
-        v_means2d = dense(v_means2d, (C, N, 2))
-        v_depths = dense(v_depths, (C, N))
-        v_conics = dense(v_conics, (C, N, 3))
-        v_comps = None if comps_p is None else dense(v_comps, (C, N))
-        v_means = torch.empty_like(means)
-        v_covars6 = torch.empty_like(covars6) if covars6 is not None else None
-        v_quats = torch.empty_like(quats) if covars6 is None else None
-        v_scales = torch.empty_like(scales) if covars6 is None else None
+        z = lambda t, shape: torch.zeros(shape, dtype=torch.float32, device=dev) if t is None else _f32(t)
+        v_means2d, v_depths, v_conics = z(v_means2d, (nnz, 2)), z(v_depths, (nnz,)), z(v_conics, (nnz, 3))
+        v_comps = z(v_comps, (nnz,)) if has_comps else None
+        v_means = torch.zeros_like(means)
+        v_covars6 = torch.zeros_like(covars6) if covars6 is not None else None
+        v_quats = torch.zeros_like(quats) if covars6 is None else None
+        v_scales = torch.zeros_like(scales) if covars6 is None else None
         v_viewmats = torch.zeros_like(viewmats) if ctx.needs_input_grad[4] else None
-        call("so_projection_bwd", C, N, ptr(means), ptr(covars6), ptr(quats), ptr(scales), ptr(viewmats),
-             ptr(Ks), width, height, eps2d, camera_model, ptr(radii), ptr(v_means2d), ptr(v_depths),
-             ptr(v_conics), ptr(v_comps), ptr(v_means), ptr(v_covars6), ptr(v_quats), ptr(v_scales),
-             ptr(v_viewmats), stream())
+        call("so_projection_bwd_packed", C, N, nnz, ptr(means), ptr(covars6), ptr(quats), ptr(scales), ptr(viewmats),
+             ptr(Ks), width, height, eps2d, camera_model, ptr(camera_ids), ptr(gaussian_ids), ptr(v_means2d), ptr(v_depths),
+             ptr(v_conics), ptr(v_comps), ptr(v_means), ptr(v_covars6), ptr(v_quats), ptr(v_scales), ptr(v_viewmats),
+             stream())
         if sparse_grad:      # rows of Gaussians no camera sees are exactly zero: hand back only the visible rows
             rows = gaussian_ids if C == 1 else torch.unique(gaussian_ids)
             v_means, v_covars6 = _sparse_rows(v_means, rows), _sparse_rows(v_covars6, rows)

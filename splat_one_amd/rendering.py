@@ -112,8 +112,9 @@ def rasterization(
         projected into ALL of them, and ONE differentiable all-to-all of the projected rows {radius, centre, depth, conic,
         opacity, colour} (RCCL; its backward is the reverse all-to-all) gives every rank all Gaussians for its own
         cameras.  `meta` keeps the shard-local pre-exchange tensors ([C_world, N_local], what a per-rank strategy needs),
-        `meta["n_cameras"]` the local count.  Not combined with `packed` here; viewmats / Ks are gathered without a
-        gradient path.  (`splat_one_amd.sharded.ShardedEngine` is the fused form of the same scheme.)
+        `meta["n_cameras"]` the local count.  With `packed=True` only the visible (camera, Gaussian) rows travel (their
+        per-destination counts are exchanged first) and the rank rasterises the received packed rows; viewmats / Ks are
+        gathered without a gradient path.  (`splat_one_amd.sharded.ShardedEngine` is the fused form of the same scheme.)
       * `isect_capacity` / `workspace` (extensions): preallocated intersection buffers make the call
         free of host synchronisation (hipGraph-capturable); `meta["n_isects"]` then lives on the device.
     """
@@ -134,7 +135,6 @@ def rasterization(
     assert render_mode in RENDER_MODES, render_mode
     assert rasterize_mode in ("classic", "antialiased"), rasterize_mode
     if distributed:
-        assert not packed, "distributed=True with packed=True is not provided: pass packed=False (the reference's default)"
         assert isect_capacity is None, "distributed=True: the exchange sizes are read on the host anyway"
         N_world, viewmats, Ks = _gather_cameras(N, viewmats, Ks)
         C_local, C = C, viewmats.shape[0]
@@ -196,7 +196,26 @@ def rasterization(
         if backgrounds is not None:
             backgrounds = torch.zeros(backgrounds.shape[0], 1, device=device)
 
-    if distributed:
+    if distributed and packed:
+        # packed rows are camera-major over the cameras of ALL ranks: the rows of the cameras rank j owns go to rank j
+        world, rank = len(N_world), dist.get_rank()
+        owner = torch.div(camera_ids, C_local, rounding_mode="floor")
+        send = torch.bincount(owner, minlength=world)
+        every = [torch.zeros_like(send) for _ in range(world)]
+        dist.all_gather(every, send)
+        send_counts = [int(v) for v in send.tolist()]
+        recv_counts = [int(e[rank]) for e in every]
+        as_f = lambda ids: ids.to(torch.int32).view(torch.float32)[:, None]         # bit-preserving through the exchange
+        rec = torch.cat([as_f(radii), as_f(camera_ids - owner * C_local), as_f(gaussian_ids + sum(N_world[:rank])),
+                         means2d, depths[:, None], conics, opacities[:, None], colors], dim=-1)
+        rows = _AllToAllRows.apply(rec, send_counts, recv_counts)
+        C, N = C_local, sum(N_world)
+        radii = rows[:, 0].contiguous().view(torch.int32)
+        camera_ids = rows[:, 1].contiguous().view(torch.int32).long()
+        gaussian_ids = rows[:, 2].contiguous().view(torch.int32).long()
+        means2d, depths, conics = rows[:, 3:5].contiguous(), rows[:, 5].contiguous(), rows[:, 6:9].contiguous()
+        opacities, colors = rows[:, 9].contiguous(), rows[:, 10:]
+    elif distributed:
         # one all-to-all of the projected rows: block c of the shard's [C_world, N_local] grid goes to the rank owning camera c
         F = 8 + colors.shape[-1]
         rec = torch.cat([radii.view(torch.float32)[..., None], means2d, depths[..., None], conics, opacities[..., None],

@@ -13,7 +13,7 @@ from tests.util import rel_err
 pytestmark = pytest.mark.gpu
 
 W, H, N = 128, 96, 2001            # odd: the shards differ in length
-KW = dict(sh_degree=3, near_plane=0.01, far_plane=1e8, packed=False, render_mode="RGB+ED", rasterize_mode="antialiased")
+KW = dict(sh_degree=3, near_plane=0.01, far_plane=1e8, render_mode="RGB+ED", rasterize_mode="antialiased")
 
 
 def _inputs():
@@ -28,6 +28,7 @@ def _inputs():
 
 def _render(dev, p, viewmats, Ks, bg, w, **kw):
     from splat_one_amd import rasterization
+    kw.setdefault("packed", False)
     rc, ra, meta = rasterization(p["means"], p["quats"], torch.exp(p["scales"]), torch.sigmoid(p["opacities"]),
                                  torch.cat([p["sh0"], p["shN"]], 1), viewmats.to(dev), Ks.to(dev), W, H,
                                  backgrounds=bg.to(dev), **KW, **kw)
@@ -36,16 +37,20 @@ def _render(dev, p, viewmats, Ks, bg, w, **kw):
     return rc.detach().cpu(), ra.detach().cpu(), meta
 
 
-def _worker(local_rank, world_rank, world_size, out_dir):
+def _worker(local_rank, world_rank, world_size, args):
+    out_dir, packed = args
     dev = torch.device("cuda:0")
     splats, viewmats, Ks, bg, w = _inputs()
     r = world_rank
     p = {k: v[r::world_size].clone().to(dev).requires_grad_(True) for k, v in splats.items()}
-    rc, ra, meta = _render(dev, p, viewmats[r:r + 1], Ks[r:r + 1], bg[r:r + 1], w[r:r + 1], distributed=True)
+    rc, ra, meta = _render(dev, p, viewmats[r:r + 1], Ks[r:r + 1], bg[r:r + 1], w[r:r + 1], distributed=True, packed=packed)
     torch.cuda.synchronize()
-    torch.save({"rc": rc, "ra": ra, "grads": {k: v.grad.detach().cpu() for k, v in p.items()},
-                "v_means2d": meta["means2d"].grad.detach().cpu(), "radii": meta["radii"].cpu(),
-                "n_cameras": meta["n_cameras"], "flat": meta["flatten_ids"].numel()}, os.path.join(out_dir, f"d{r}.pt"))
+    out = {"rc": rc, "ra": ra, "grads": {k: v.grad.detach().cpu() for k, v in p.items()},
+           "v_means2d": meta["means2d"].grad.detach().cpu(), "radii": meta["radii"].cpu(),
+           "n_cameras": meta["n_cameras"], "flat": meta["flatten_ids"].numel()}
+    if packed:
+        out.update(camera_ids=meta["camera_ids"].cpu(), gaussian_ids=meta["gaussian_ids"].cpu())
+    torch.save(out, os.path.join(out_dir, f"d{r}.pt"))
 
 
 def _free_port():
@@ -56,11 +61,13 @@ def _free_port():
     return port
 
 
-def test_rasterization_distributed_two_ranks_one_gpu(dev, tmp_path):
+@pytest.mark.parametrize("packed", [False, True])
+def test_rasterization_distributed_two_ranks_one_gpu(dev, tmp_path, packed):
+    """packed=True (gsplat's default; `cfg.packed`, gsplat_trainer.py:133, :487-490): only the visible rows travel."""
     from splat_one_amd import distributed as sdist
     env_backup = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     try:
-        sdist.cli(_worker, str(tmp_path), world_size=2, backend="gloo", port=_free_port())
+        sdist.cli(_worker, (str(tmp_path), packed), world_size=2, backend="gloo", port=_free_port())
     finally:
         for k, v in env_backup.items():
             if v is not None:
@@ -77,8 +84,15 @@ def test_rasterization_distributed_two_ranks_one_gpu(dev, tmp_path):
         o = out[r]
         assert o["n_cameras"] == 1 and o["flat"] > 0
         assert (o["rc"][0] - rc[r]).abs().max().item() < 1e-5 and (o["ra"][0] - ra[r]).abs().max().item() < 1e-6
-        # meta keeps the shard-local grid over the cameras of ALL ranks
-        assert torch.equal(o["radii"], meta["radii"][:, rows[r]].cpu())
-        assert rel_err(o["v_means2d"], meta["means2d"].grad[:, rows[r]].cpu()) < 1e-5
+        # meta keeps the shard-local grid over the cameras of ALL ranks (packed: its visible rows, camera-major)
+        if packed:
+            dense_r, dense_g = meta["radii"][:, rows[r]].cpu(), meta["means2d"].grad[:, rows[r]].cpu()
+            cid, gid = o["camera_ids"], o["gaussian_ids"]
+            assert torch.equal(torch.nonzero(dense_r.reshape(-1) > 0).squeeze(1), cid * dense_r.shape[1] + gid)
+            assert torch.equal(o["radii"], dense_r[cid, gid])
+            assert rel_err(o["v_means2d"], dense_g[cid, gid]) < 1e-5
+        else:
+            assert torch.equal(o["radii"], meta["radii"][:, rows[r]].cpu())
+            assert rel_err(o["v_means2d"], meta["means2d"].grad[:, rows[r]].cpu()) < 1e-5
         for k, g in o["grads"].items():
             assert rel_err(g, p[k].grad[rows[r]].cpu()) < 1e-5, (k, r)

@@ -163,3 +163,51 @@ def test_trainer_sparse_grad(dev):
     for k, v in r.splats.items():
         assert torch.equal(v.detach()[:300], before[k][:300]), k
         assert not torch.equal(v.detach()[vis], before[k][vis]), k
+
+
+@pytest.mark.parametrize("C,sparse_grad,camera_model", [(1, True, "pinhole"), (3, True, "pinhole"), (2, False, "fisheye")])
+def test_packed_against_the_oracle(dev, C, sparse_grad, camera_model):
+    """Oracle parity of the packed layout itself (not packed-vs-dense of the same kernels): rows, ids, image and every
+    gradient -- row-sparse COO ones densified -- against the float64 oracle's dense [C,N] results gathered at
+    (camera_ids, gaussian_ids).  No [C,N] array is allocated by the product on this path (so_projection_packed)."""
+    from oracle import c_oracle as CO
+    from oracle import torch_oracle as O
+    from splat_one_amd import rasterization
+    splats, viewmats, Ks, W, H = _scene(dev, C)
+    N = splats["means"].shape[0]
+    g = torch.Generator().manual_seed(11)
+    w_rgb = torch.rand(C, H, W, 3, generator=g)
+    w_a = torch.rand(C, H, W, 1, generator=g)
+    # product, packed
+    p = {k: v.detach().clone().to(dev).requires_grad_(True) for k, v in splats.items()}
+    torch.cuda.reset_peak_memory_stats()
+    rc, ra, meta = rasterization(p["means"], p["quats"], torch.exp(p["scales"]), torch.sigmoid(p["opacities"]),
+                                 torch.cat([p["sh0"], p["shN"]], 1), viewmats, Ks, W, H, sh_degree=3, near_plane=0.01,
+                                 far_plane=1e8, packed=True, sparse_grad=sparse_grad, camera_model=camera_model)
+    meta["means2d"].retain_grad()
+    ((rc * w_rgb.to(dev)).sum() + (ra * w_a.to(dev)).sum()).backward()
+    # oracle, dense
+    q = {k: v.detach().clone().requires_grad_(True) for k, v in splats.items()}
+    rc_o, ra_o, m_o = O.rasterization(q["means"], q["quats"], torch.exp(q["scales"]), torch.sigmoid(q["opacities"]),
+                                      torch.cat([q["sh0"], q["shN"]], 1), viewmats.cpu(), Ks.cpu(), W, H, sh_degree=3,
+                                      near_plane=0.01, far_plane=1e8, camera_model=camera_model, raster_fn=CO.raster_fn())
+    m_o["means2d"].retain_grad()
+    ((rc_o * w_rgb).sum() + (ra_o * w_a).sum()).backward()
+    cam, gid = torch.nonzero(m_o["radii"] > 0, as_tuple=True)
+    assert torch.equal(meta["camera_ids"].cpu(), cam) and torch.equal(meta["gaussian_ids"].cpu(), gid)   # sorted, camera-major
+    assert torch.equal(meta["radii"].cpu(), m_o["radii"][cam, gid])
+    assert rel_err(meta["means2d"], m_o["means2d"][cam, gid]) < 1e-5 and rel_err(meta["conics"], m_o["conics"][cam, gid]) < 1e-4
+    assert rel_err(meta["depths"], m_o["depths"][cam, gid]) < 1e-6
+    assert (rc.detach().cpu().double() - rc_o).abs().mean().item() <= 1e-4
+    assert rel_err(meta["means2d"].grad, m_o["means2d"].grad[cam, gid]) < 1e-3
+    for k in q:
+        gk = p[k].grad
+        if sparse_grad and k in ("quats", "scales"):              # (means also receives a dense part through the SH view directions)
+            assert gk.is_sparse and gk.is_coalesced()
+            rows = gk.indices()[0].cpu()
+            assert torch.equal(rows, torch.unique(gid))             # exactly the visible Gaussians, sorted
+        if gk.is_sparse:
+            gk = gk.to_dense()
+        floor = 1e-5 * q["scales"].grad.norm().item() if k == "quats" else 0.0
+        err = (gk.detach().cpu().double() - q[k].grad.double()).norm().item()
+        assert err <= 1e-3 * q[k].grad.norm().item() + floor, (k, err)
