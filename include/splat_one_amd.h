@@ -53,6 +53,17 @@ enum so_camera_model { SO_CAM_PINHOLE = 0, SO_CAM_ORTHO = 1, SO_CAM_FISHEYE = 2,
  * in one batch:  SO_CAM_PER_VIEW | m_0 | m_1 << 2 | ... | m_{C-1} << 2 (C-1),  2 bits per view, C <= 15. */
 #define SO_CAM_PER_VIEW 0x40000000
 #define SO_CAM_PER_VIEW_MAX 15
+/* Periodic images.  A spherical (equirectangular) view is periodic in x: a Gaussian whose footprint crosses the
+ * +-pi seam (x = 0 / x = W) continues on the other side of the image.  The binning and rasteriser entry points learn
+ * which cameras are periodic from flags OR-ed into their `tile_size` argument (its low byte stays the tile size):
+ *   tile_size | SO_TILE_WRAP_ALL          every camera;      tile_size | SO_TILE_WRAP_CAM(c)   camera c (c < 16).
+ * Binning then walks VIRTUAL tile columns (floor((x - r)/ts) .. ceil((x + r)/ts), not clamped to the image, at most one
+ * image width) and files column x under x mod tile_width; the rasteriser shifts every staged Gaussian by the multiple
+ * of W that brings it closest to the tile.  Requires width % tile_size == 0 (the virtual tile grid must line up across
+ * the seam): callers pass no flag otherwise.  so_preprocess_fwd / so_train_step_fwd_bwd derive the flags from
+ * camera_model themselves. */
+#define SO_TILE_WRAP_ALL (1 << 24)
+#define SO_TILE_WRAP_CAM(c) (1 << (8 + (c)))
 
 int so_abi_version(void);
 const char *so_last_error(void);

@@ -33,6 +33,12 @@
 
 static inline REAL real_exp(REAL x) { return sizeof(REAL) == 4 ? (REAL)expf((float)x) : (REAL)exp((double)x); }
 
+/* periodic images (equirectangular panoramas; build-defined, see torch_oracle.isect_tiles): a Gaussian is evaluated at
+ * the copy  x - W * round((x - tile centre) / W)  nearest to the tile being rasterised */
+static inline REAL nearest_copy(REAL x, REAL tile_cx, int W, int periodic) {
+  return periodic ? x - (REAL)W * (REAL)rint((double)((x - tile_cx) / (REAL)W)) : x;
+}
+
 int oracle_real_size(void) { return (int)sizeof(REAL); }
 
 int oracle_max_threads(void) {
@@ -46,7 +52,7 @@ int oracle_max_threads(void) {
 /* means2d[C*N*2] conics[C*N*3] colors[C*N*D] opacities[C*N] backgrounds[C*D]|NULL
  * isect_offsets[C*tile_h*tile_w] flatten_ids[n_isects]
  * -> render_colors[C*H*W*D] render_alphas[C*H*W] last_ids[C*H*W] */
-int oracle_rasterize_fwd(int C, int N, int D, int W, int H, int tile_size, int tile_w, int tile_h,
+int oracle_rasterize_fwd(int C, int N, int D, int W, int H, int tile_size, int tile_w, int tile_h, int periodic,
                          const REAL *means2d, const REAL *conics, const REAL *colors,
                          const REAL *opacities, const REAL *backgrounds,
                          const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects,
@@ -59,6 +65,7 @@ int oracle_rasterize_fwd(int C, int N, int D, int W, int H, int tile_size, int t
   for (int64_t ct = 0; ct < total_tiles; ++ct) {
     const int c = (int)(ct / n_tiles), t = (int)(ct % n_tiles);
     const int ty = t / tile_w, tx = t % tile_w;
+    const REAL tile_cx = (REAL)(tx * tile_size) + (REAL)0.5 * (REAL)tile_size;
     const int64_t lo = isect_offsets[ct];
     const int64_t hi = (ct == total_tiles - 1) ? n_isects : isect_offsets[ct + 1];
     for (int i = ty * tile_size; i < (ty + 1) * tile_size && i < H; ++i) {
@@ -68,7 +75,7 @@ int oracle_rasterize_fwd(int C, int N, int D, int W, int H, int tile_size, int t
         int32_t last = 0;
         for (int64_t k = lo; k < hi; ++k) {
           const int32_t g = flatten_ids[k];
-          const REAL dx = means2d[2 * g] - px, dy = means2d[2 * g + 1] - py;
+          const REAL dx = nearest_copy(means2d[2 * g], tile_cx, W, periodic) - px, dy = means2d[2 * g + 1] - py;
           const REAL a = conics[3 * g], b = conics[3 * g + 1], cc = conics[3 * g + 2];
           const REAL sigma = (REAL)0.5 * (a * dx * dx + cc * dy * dy) + b * dx * dy;
           REAL alpha = opacities[g] * real_exp(-sigma);
@@ -94,7 +101,7 @@ int oracle_rasterize_fwd(int C, int N, int D, int W, int H, int tile_size, int t
 
 /* v_render_colors[C*H*W*D] v_render_alphas[C*H*W] -> (accumulated into zero-initialised)
  * v_means2d[C*N*2] v_means2d_abs[C*N*2]|NULL v_conics[C*N*3] v_colors[C*N*D] v_opacities[C*N] */
-int oracle_rasterize_bwd(int C, int N, int D, int W, int H, int tile_size, int tile_w, int tile_h,
+int oracle_rasterize_bwd(int C, int N, int D, int W, int H, int tile_size, int tile_w, int tile_h, int periodic,
                          const REAL *means2d, const REAL *conics, const REAL *colors,
                          const REAL *opacities, const REAL *backgrounds,
                          const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects,
@@ -110,6 +117,7 @@ int oracle_rasterize_bwd(int C, int N, int D, int W, int H, int tile_size, int t
   for (int64_t ct = 0; ct < total_tiles; ++ct) {
     const int c = (int)(ct / n_tiles), t = (int)(ct % n_tiles);
     const int ty = t / tile_w, tx = t % tile_w;
+    const REAL tile_cx = (REAL)(tx * tile_size) + (REAL)0.5 * (REAL)tile_size;
     const int64_t lo = isect_offsets[ct];
     const int64_t hi = (ct == total_tiles - 1) ? n_isects : isect_offsets[ct + 1];
     if (hi <= lo) continue;
@@ -130,7 +138,7 @@ int oracle_rasterize_bwd(int C, int N, int D, int W, int H, int tile_size, int t
           for (int d = 0; d < D; ++d) bg_dot += backgrounds[c * D + d] * v_c[d];
         for (int64_t k = last_ids[p]; k >= lo; --k) {
           const int32_t g = flatten_ids[k];
-          const REAL dx = means2d[2 * g] - px, dy = means2d[2 * g + 1] - py;
+          const REAL dx = nearest_copy(means2d[2 * g], tile_cx, W, periodic) - px, dy = means2d[2 * g + 1] - py;
           const REAL a = conics[3 * g], b = conics[3 * g + 1], cc = conics[3 * g + 2];
           const REAL sigma = (REAL)0.5 * (a * dx * dx + cc * dy * dy) + b * dx * dy;
           const REAL vis = real_exp(-sigma);

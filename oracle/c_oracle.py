@@ -46,7 +46,7 @@ def _p(t: Optional[torch.Tensor]):
 class _RasterC(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, width, height, tile_size,
-                isect_offsets, flatten_ids, want_abs):
+                isect_offsets, flatten_ids, want_abs, periodic=False):
         dtype = means2d.dtype
         lib = _lib(dtype)
         C, N = opacities.shape
@@ -59,20 +59,20 @@ class _RasterC(torch.autograd.Function):
         rc = torch.empty(C, height, width, D, dtype=dtype)
         ra = torch.empty(C, height, width, 1, dtype=dtype)
         last = torch.empty(C, height, width, dtype=torch.int32)
-        r = lib.oracle_rasterize_fwd(C, N, D, width, height, tile_size, tw, th, _p(means2d), _p(conics),
+        r = lib.oracle_rasterize_fwd(C, N, D, width, height, tile_size, tw, th, int(periodic), _p(means2d), _p(conics),
                                      _p(colors), _p(opacities), _p(bg), _p(off), _p(fid),
                                      ctypes.c_int64(fid.numel()), _p(rc), _p(ra), _p(last))
         assert r == 0
         ctx.save_for_backward(means2d, conics, colors, opacities, bg if bg is not None else torch.empty(0),
                               off, fid, ra, last)
-        ctx.dims = (C, N, D, width, height, tile_size, tw, th, bg is not None, want_abs)
+        ctx.dims = (C, N, D, width, height, tile_size, tw, th, bg is not None, want_abs, int(periodic))
         ctx.absgrad = None
         return rc, ra, last
 
     @staticmethod
     def backward(ctx, v_rc, v_ra, _v_last):
         means2d, conics, colors, opacities, bg, off, fid, ra, last = ctx.saved_tensors
-        C, N, D, width, height, tile_size, tw, th, has_bg, want_abs = ctx.dims
+        C, N, D, width, height, tile_size, tw, th, has_bg, want_abs, periodic = ctx.dims
         dtype = means2d.dtype
         lib = _lib(dtype)
         v_rc = v_rc.to(dtype).contiguous()
@@ -82,7 +82,7 @@ class _RasterC(torch.autograd.Function):
         v_cn = torch.zeros_like(conics)
         v_col = torch.zeros_like(colors)
         v_op = torch.zeros_like(opacities)
-        r = lib.oracle_rasterize_bwd(C, N, D, width, height, tile_size, tw, th, _p(means2d), _p(conics),
+        r = lib.oracle_rasterize_bwd(C, N, D, width, height, tile_size, tw, th, periodic, _p(means2d), _p(conics),
                                      _p(colors), _p(opacities), _p(bg if has_bg else None), _p(off), _p(fid),
                                      ctypes.c_int64(fid.numel()), _p(ra), _p(last), _p(v_rc), _p(v_ra),
                                      _p(v_m), _p(v_abs), _p(v_cn), _p(v_col), _p(v_op))
@@ -92,23 +92,23 @@ class _RasterC(torch.autograd.Function):
         v_bg = None
         if has_bg and ctx.needs_input_grad[4]:
             v_bg = ((1.0 - ra) * v_rc).sum(dim=(1, 2))
-        return v_m, v_cn, v_col, v_op, v_bg, None, None, None, None, None, None
+        return v_m, v_cn, v_col, v_op, v_bg, None, None, None, None, None, None, None
 
 
 def rasterize_to_pixels(means2d, conics, colors, opacities, width, height, tile_size, isect_offsets,
                         flatten_ids, backgrounds=None, absgrad_out: Optional[list] = None,
-                        return_last_ids: bool = False):
+                        return_last_ids: bool = False, periodic: bool = False):
     """Same contract as torch_oracle.rasterize_to_pixels.  If `absgrad_out` is a list, the
     backward appends v_means2d_abs[C,N,2] to it."""
     rc, ra, last = _RasterC.apply(means2d, conics, colors, opacities, backgrounds, width, height,
-                                  tile_size, isect_offsets, flatten_ids, absgrad_out)
+                                  tile_size, isect_offsets, flatten_ids, absgrad_out, periodic)
     if return_last_ids:
         return rc, ra, last
     return rc, ra
 
 
 def raster_fn(absgrad_out: Optional[list] = None):
-    def fn(means2d, conics, cols, opac, width, height, tile_size, isect_offsets, flatten_ids, bg):
+    def fn(means2d, conics, cols, opac, width, height, tile_size, isect_offsets, flatten_ids, bg, periodic=False):
         return rasterize_to_pixels(means2d, conics, cols, opac, width, height, tile_size, isect_offsets,
-                                   flatten_ids, backgrounds=bg, absgrad_out=absgrad_out)
+                                   flatten_ids, backgrounds=bg, absgrad_out=absgrad_out, periodic=periodic)
     return fn

@@ -264,13 +264,19 @@ def tile_bits(n_tiles: int) -> int:
 
 
 def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int,
-                tile_width: int, tile_height: int, sort: bool = True
+                tile_width: int, tile_height: int, sort: bool = True, periodic: bool = False
                 ) -> Tuple[Tensor, Tensor, Tensor]:
     """AABB tile overlap + 64-bit keys (cam | tile | fp32 depth bits) + stable sort.
 
     The AABB arithmetic is done in float32 (as the published kernel does) so that tile
     membership is bit-identical with a float32 device implementation fed the same float32
     means2d / radii.  Returns tiles_per_gauss[C,N] i32, isect_ids[I] i64, flatten_ids[I] i32.
+
+    periodic (BUILD-DEFINED, like the `spherical` model itself -- the fork that defines it is absent, SURVEY.md
+    section 8c): the image is periodic in x with period tile_width * tile_size.  The column range is then not clamped
+    to the image but taken modulo tile_width (at most one full turn: a box wider than the image covers every column
+    once), so a footprint that crosses the +-pi seam of an equirectangular panorama reaches the tiles on the other
+    side; `rasterize_to_pixels(periodic=True)` evaluates it there at its nearest copy.
     """
     C, N = radii.shape
     m = means2d.detach().to(torch.float32)
@@ -279,8 +285,15 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int,
     tile_r = r / ts
     tx = m[..., 0] / ts
     ty = m[..., 1] / ts
-    x0 = torch.floor(tx - tile_r).clamp(0, tile_width).to(torch.int64)
-    x1 = torch.ceil(tx + tile_r).clamp(0, tile_width).to(torch.int64)
+    if periodic:
+        x0 = torch.floor(tx - tile_r).clamp(min=-tile_width).to(torch.int64)
+        x1 = torch.ceil(tx + tile_r).clamp(max=2 * tile_width).to(torch.int64)
+        full = (x1 - x0) > tile_width
+        x0 = torch.where(full, torch.zeros_like(x0), x0)
+        x1 = torch.where(full, torch.full_like(x1, tile_width), x1)
+    else:
+        x0 = torch.floor(tx - tile_r).clamp(0, tile_width).to(torch.int64)
+        x1 = torch.ceil(tx + tile_r).clamp(0, tile_width).to(torch.int64)
     y0 = torch.floor(ty - tile_r).clamp(0, tile_height).to(torch.int64)
     y1 = torch.ceil(ty + tile_r).clamp(0, tile_height).to(torch.int64)
     vis = radii > 0
@@ -300,6 +313,8 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int,
     nxg = nx.reshape(-1)[gid]
     iy = y0.reshape(-1)[gid] + local // nxg                                  # row-major emission
     ix = x0.reshape(-1)[gid] + local % nxg
+    if periodic:
+        ix = ix % tile_width                                                 # Python modulo: -1 -> tile_width - 1
     tile_id = iy * tile_width + ix
     cam = gid // N
     dbits = depths.detach().to(torch.float32).reshape(-1)[gid].view(torch.int32).to(torch.int64) & 0xFFFFFFFF
@@ -332,9 +347,11 @@ def rasterize_to_pixels(
     means2d: Tensor, conics: Tensor, colors: Tensor, opacities: Tensor,
     width: int, height: int, tile_size: int, isect_offsets: Tensor, flatten_ids: Tensor,
     backgrounds: Optional[Tensor] = None, absgrad_probe: Optional[List] = None,
-    dtype: torch.dtype = torch.float64, return_last_ids: bool = False,
+    dtype: torch.dtype = torch.float64, return_last_ids: bool = False, periodic: bool = False,
 ):
     """Front-to-back alpha compositing.
+    periodic: see `isect_tiles` -- inside tile (ty, tx) a Gaussian at x is evaluated at the copy
+    x - width * round((x - tile centre x) / width) (round half to even), width % tile_size == 0 required.
 
     means2d[C,N,2] conics[C,N,3] colors[C,N,D] opacities[C,N] -> colors[C,H,W,D], alphas[C,H,W,1].
     If `absgrad_probe` is a list, per-(Gaussian,pixel) zero offsets are spliced into the
@@ -369,7 +386,10 @@ def rasterize_to_pixels(
             px = gj.reshape(-1).to(dtype) + 0.5
             py = gi.reshape(-1).to(dtype) + 0.5
             g = fid[lo:hi]                                                        # [L]
-            dx = m2[g, 0][:, None] - px[None, :]                                  # [L,p]
+            mx = m2[g, 0]
+            if periodic:
+                mx = mx - width * torch.round((mx.detach() - (tx * tile_size + 0.5 * tile_size)) / width)
+            dx = mx[:, None] - px[None, :]                                        # [L,p]
             dy = m2[g, 1][:, None] - py[None, :]
             if absgrad_probe is not None:
                 e = torch.zeros(g.numel(), pix.numel(), 2, dtype=dtype, requires_grad=True)
@@ -482,8 +502,10 @@ def rasterization(
     if sort_depths is not None:
         assert sort_depths.shape == depths.shape, (sort_depths.shape, depths.shape)
         key_depths = sort_depths.detach().to("cpu", torch.float32)
+    # build-defined: a panorama is periodic in x when the tile grid lines up across the seam
+    periodic = camera_model == "spherical" and width % tile_size == 0
     tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(
-        means2d, radii, key_depths, tile_size, tile_width, tile_height)
+        means2d, radii, key_depths, tile_size, tile_width, tile_height, periodic=periodic)
     isect_offsets = isect_offset_encode(isect_ids, C, tile_width, tile_height)
     meta = dict(radii=radii, means2d=means2d, depths=depths, conics=conics, opacities=opac,
                 tile_width=tile_width, tile_height=tile_height, tiles_per_gauss=tiles_per_gauss,
@@ -492,10 +514,11 @@ def rasterization(
     if raster_fn is None:
         render_colors, render_alphas = rasterize_to_pixels(
             means2d, conics, cols, opac, width, height, tile_size, isect_offsets, flatten_ids,
-            backgrounds=bg, absgrad_probe=absgrad_probe, dtype=dtype)
+            backgrounds=bg, absgrad_probe=absgrad_probe, dtype=dtype, periodic=periodic)
     else:
+        kw = {"periodic": True} if periodic else {}
         render_colors, render_alphas = raster_fn(
-            means2d, conics, cols, opac, width, height, tile_size, isect_offsets, flatten_ids, bg)
+            means2d, conics, cols, opac, width, height, tile_size, isect_offsets, flatten_ids, bg, **kw)
     if render_mode in ("ED", "RGB+ED"):
         render_colors = torch.cat([render_colors[..., :-1],
                                    render_colors[..., -1:] / render_alphas.clamp(min=1e-10)], dim=-1)

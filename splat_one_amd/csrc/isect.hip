@@ -26,12 +26,21 @@ struct TileBox {
 };
 
 // float32 AABB arithmetic exactly as published
-__device__ __forceinline__ TileBox tile_box(float mx, float my, float radius, float tile_size, int tile_w, int tile_h) {
+// wrap: the image is periodic in x -- the columns are VIRTUAL (x0 may be negative, x1 beyond tile_w; at most one image
+// width of them), every user files column x under wrapx(x, tile_w)
+__device__ __forceinline__ TileBox tile_box(float mx, float my, float radius, float tile_size, int tile_w, int tile_h,
+                                            bool wrap = false) {
   const float tile_r = radius / tile_size;
   const float tx = mx / tile_size, ty = my / tile_size;
   TileBox b;
+  if (wrap) {
+    b.x0 = (int)fmaxf(floorf(tx - tile_r), (float)-tile_w);
+    b.x1 = (int)fminf(ceilf(tx + tile_r), (float)(2 * tile_w));
+    if (b.x1 - b.x0 > tile_w) { b.x0 = 0; b.x1 = tile_w; }
+  } else {
   b.x0 = (int)fminf(fmaxf(floorf(tx - tile_r), 0.f), (float)tile_w);
   b.x1 = (int)fminf(fmaxf(ceilf(tx + tile_r), 0.f), (float)tile_w);
+  }
   b.y0 = (int)fminf(fmaxf(floorf(ty - tile_r), 0.f), (float)tile_h);
   b.y1 = (int)fminf(fmaxf(ceilf(ty + tile_r), 0.f), (float)tile_h);
   return b;
@@ -40,7 +49,7 @@ __device__ __forceinline__ TileBox tile_box(float mx, float my, float radius, fl
 __global__ void __launch_bounds__(256)
 k_isect_count(int C, int N, const float *__restrict__ means2d, const int32_t *__restrict__ radii, float tile_size,
               int tile_w, int tile_h, int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ tile_counts,
-              const float4 *__restrict__ cull_rec) {
+              const float4 *__restrict__ cull_rec, int wrap_flags) {
   const int64_t total = (int64_t)C * N;
   const int n_tiles = tile_w * tile_h;
   // uniform trip count: the cooperative part needs every lane of a wave (same scheme as k_preprocess_fwd)
@@ -53,9 +62,9 @@ k_isect_count(int C, int N, const float *__restrict__ means2d, const int32_t *__
       const int r = radii[idx];
       if (r > 0) {
         const float2 m = *reinterpret_cast<const float2 *>(means2d + 2 * idx);
-        b = tile_box(m.x, m.y, (float)r, tile_size, tile_w, tile_h);
-        cnt = (b.x1 - b.x0) * (b.y1 - b.y0);
         c = (int)(idx / N);
+        b = tile_box(m.x, m.y, (float)r, tile_size, tile_w, tile_h, wrap_for(wrap_flags, c));
+        cnt = (b.x1 - b.x0) * (b.y1 - b.y0);
         mx = m.x; my = m.y;
         if (cull_rec) {
           const float4 q0 = cull_rec[4 * idx], q1 = cull_rec[4 * idx + 1];
@@ -72,7 +81,7 @@ k_isect_count(int C, int N, const float *__restrict__ means2d, const int32_t *__
       int32_t *row = tile_counts + (int64_t)c * n_tiles;
       for (int y = b.y0; y < b.y1; ++y)
         for (int x = b.x0; x < b.x1; ++x)
-          if (!cull_rec || tile_touches(mx, my, qa, qb, qc, tau, x, y, tile_size)) atomicAdd(row + y * tile_w + x, 1);
+          if (!cull_rec || tile_touches(mx, my, qa, qb, qc, tau, x, y, tile_size)) atomicAdd(row + y * tile_w + wrapx(x, tile_w), 1);
     }
     unsigned long long todo = __ballot(big);
     const int lane = lane_id();
@@ -86,7 +95,7 @@ k_isect_count(int C, int N, const float *__restrict__ means2d, const int32_t *__
       int32_t *row = tile_counts + (int64_t)__builtin_amdgcn_readlane(c, src) * n_tiles;
       for (int y = sy0 + (lane >> 3); y < sy1; y += 8)
         for (int x = sx0 + (lane & 7); x < sx1; x += 8)
-          if (!cull_rec || tile_touches(smx, smy, sqa, sqb, sqc, stau, x, y, tile_size)) atomicAdd(row + y * tile_w + x, 1);
+          if (!cull_rec || tile_touches(smx, smy, sqa, sqb, sqc, stau, x, y, tile_size)) atomicAdd(row + y * tile_w + wrapx(x, tile_w), 1);
     }
   }
 }
@@ -174,7 +183,7 @@ k_isect_scatter(int C, int N, const float *__restrict__ means2d, const int32_t *
                 const int32_t *__restrict__ offsets, int32_t *__restrict__ cursor, int64_t capacity,
                 uint64_t *__restrict__ key_buf, int32_t *__restrict__ overflow,
                 const int32_t *__restrict__ tile_slots, const int32_t *__restrict__ n_isects,
-                const float4 *__restrict__ cull_rec) {
+                const float4 *__restrict__ cull_rec, int wrap_flags) {
   const int64_t total = (int64_t)C * N;
   const int n_tiles = tile_w * tile_h;
   const int sub = threadIdx.x & (kScatterLanes - 1);
@@ -183,7 +192,7 @@ k_isect_scatter(int C, int N, const float *__restrict__ means2d, const int32_t *
     const int r = radii[idx];
     if (r <= 0) continue;
     const float2 m = *reinterpret_cast<const float2 *>(means2d + 2 * idx);
-    const TileBox b = tile_box(m.x, m.y, (float)r, tile_size, tile_w, tile_h);
+    const TileBox b = tile_box(m.x, m.y, (float)r, tile_size, tile_w, tile_h, wrap_for(wrap_flags, (int)(idx / N)));
     const int nx = b.x1 - b.x0, cnt = nx * (b.y1 - b.y0);
     const uint64_t key = ((uint64_t)__float_as_uint(depths[idx]) << 32) | (uint64_t)(uint32_t)idx;
     const int64_t row = (idx / N) * n_tiles;
@@ -202,7 +211,7 @@ k_isect_scatter(int C, int N, const float *__restrict__ means2d, const int32_t *
     for (int k = sub; k < cnt; k += kScatterLanes) {
       const int y = b.y0 + k / nx, x = b.x0 + k % nx;
       if (cull_rec && !tile_touches(m.x, m.y, qa, qb, qc, tau, x, y, tile_size)) continue;
-      const int64_t t = row + y * tile_w + x;
+      const int64_t t = row + y * tile_w + wrapx(x, tile_w);
       int64_t pos;
       if (have) {
         pos = (int64_t)offsets[t] + tile_slots[idx * SO_TILE_SLOTS + k];
@@ -472,20 +481,20 @@ __global__ void __launch_bounds__(256)
 k_isect_emit_unsorted(int C, int N, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
                       const float *__restrict__ depths, const int64_t *__restrict__ cum_tiles, float tile_size,
                       int tile_w, int tile_h, int tile_bits, int64_t *__restrict__ isect_ids,
-                      int32_t *__restrict__ flatten_ids) {
+                      int32_t *__restrict__ flatten_ids, int wrap_flags) {
   const int64_t total = (int64_t)C * N;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int r = radii[idx];
     if (r <= 0) continue;
     const float2 m = *reinterpret_cast<const float2 *>(means2d + 2 * idx);
-    const TileBox b = tile_box(m.x, m.y, (float)r, tile_size, tile_w, tile_h);
+    const TileBox b = tile_box(m.x, m.y, (float)r, tile_size, tile_w, tile_h, wrap_for(wrap_flags, (int)(idx / N)));
     int64_t cur = (idx == 0) ? 0 : cum_tiles[idx - 1];
     const int64_t cam_enc = (idx / N) << (32 + tile_bits);
     const int64_t dbits = (int64_t)__float_as_uint(depths[idx]);
     for (int y = b.y0; y < b.y1; ++y)
       for (int x = b.x0; x < b.x1; ++x) {
-        isect_ids[cur] = cam_enc | ((int64_t)(y * tile_w + x) << 32) | dbits;
+        isect_ids[cur] = cam_enc | ((int64_t)(y * tile_w + wrapx(x, tile_w)) << 32) | dbits;
         flatten_ids[cur] = (int32_t)idx;
         ++cur;
       }
@@ -565,6 +574,8 @@ static void launch_tile_sorts(int64_t M, int n_tiles, int tb, const int32_t *ise
 extern "C" int so_isect_count(int C, int N, const float *means2d, const int32_t *radii, int tile_size,
                               int tile_width, int tile_height, int32_t *tiles_per_gauss, int32_t *tile_counts,
                               int32_t *isect_offsets, int32_t *n_isects, const float *cull_rec, void *stream) {
+  const int wrap_flags = tile_size & ~0xFF;
+  tile_size = so::tile_size_of(tile_size);
   SO_REQUIRE(C >= 0 && N >= 0 && tile_size > 0 && tile_width > 0 && tile_height > 0, "so_isect_count: bad sizes");
   SO_REQUIRE(tile_counts && isect_offsets && n_isects, "so_isect_count: null pointer");
   SO_REQUIRE((int64_t)C * N < ((int64_t)1 << 31), "so_isect_count: C*N must fit int32 flatten ids");
@@ -574,7 +585,7 @@ extern "C" int so_isect_count(int C, int N, const float *means2d, const int32_t 
     SO_REQUIRE(means2d && radii && tiles_per_gauss, "so_isect_count: null pointer");
     hipLaunchKernelGGL(so::k_isect_count, dim3(so::grid_1d((int64_t)C * N, 256)), dim3(256), 0, st, C, N, means2d,
                        radii, (float)tile_size, tile_width, tile_height, tiles_per_gauss, tile_counts,
-                       reinterpret_cast<const float4 *>(cull_rec));
+                       reinterpret_cast<const float4 *>(cull_rec), wrap_flags);
   }
   so::launch_scan(M, tile_counts, nullptr, isect_offsets, n_isects, st);
   return so::check_launch("so_isect_count");
@@ -593,6 +604,8 @@ extern "C" int so_isect_fill(int C, int N, const float *means2d, const int32_t *
                              const int32_t *n_isects, int32_t *tile_cursor, int64_t capacity, uint64_t *key_buf,
                              int32_t *flatten_ids, int64_t *isect_ids, int32_t *overflow, const int32_t *tile_slots,
                              const float *cull_rec, void *stream) {
+  const int wrap_flags = tile_size & ~0xFF;
+  tile_size = so::tile_size_of(tile_size);
   SO_REQUIRE(C >= 0 && N >= 0 && tile_size > 0 && tile_width > 0 && tile_height > 0 && capacity >= 0,
              "so_isect_fill: bad sizes");
   if ((int64_t)C * N == 0 || capacity == 0) return SO_OK;
@@ -609,7 +622,7 @@ extern "C" int so_isect_fill(int C, int N, const float *means2d, const int32_t *
 #define SO_SCATTER(L)                                                                                                         \
     hipLaunchKernelGGL(so::k_isect_scatter<L>, dim3(so::grid_1d((int64_t)C * N * L, 256, 16384)), dim3(256), 0, st, C, N, means2d, \
                        radii, depths, (float)tile_size, tile_width, tile_height, isect_offsets, tile_cursor, capacity,        \
-                       key_buf, overflow, tile_slots, n_isects, reinterpret_cast<const float4 *>(cull_rec))
+                       key_buf, overflow, tile_slots, n_isects, reinterpret_cast<const float4 *>(cull_rec), wrap_flags)
   if (tile_slots && slotted_lanes == 2) SO_SCATTER(2);
   else if (tile_slots && slotted_lanes == 4) SO_SCATTER(4);
   else if (tile_slots && slotted_lanes == 8) SO_SCATTER(8);
@@ -625,13 +638,15 @@ extern "C" int so_isect_emit_unsorted(int C, int N, const float *means2d, const 
                                       const float *depths, const int64_t *cum_tiles, int tile_size,
                                       int tile_width, int tile_height, int64_t *isect_ids, int32_t *flatten_ids,
                                       void *stream) {
+  const int wrap_flags = tile_size & ~0xFF;
+  tile_size = so::tile_size_of(tile_size);
   SO_REQUIRE(C >= 0 && N >= 0 && tile_size > 0 && tile_width > 0 && tile_height > 0, "so_isect_emit_unsorted: bad sizes");
   if ((int64_t)C * N == 0) return SO_OK;
   SO_REQUIRE(means2d && radii && depths && cum_tiles && isect_ids && flatten_ids, "so_isect_emit_unsorted: null pointer");
   const int tb = so::tile_bits_of(tile_width * tile_height);
   hipLaunchKernelGGL(so::k_isect_emit_unsorted, dim3(so::grid_1d((int64_t)C * N, 256)), dim3(256), 0,
                      so::as_stream(stream), C, N, means2d, radii, depths, cum_tiles, (float)tile_size, tile_width,
-                     tile_height, tb, isect_ids, flatten_ids);
+                     tile_height, tb, isect_ids, flatten_ids, wrap_flags);
   return so::check_launch("so_isect_emit_unsorted");
 }
 

@@ -314,8 +314,13 @@ __device__ __forceinline__ void bwd_gload(BwdStage<CH> &st, const StageGeom<CH> 
   float rm;
   const float *r0 = row_ptr(dmaps, H, stride, y, rm);
   const float *r1 = r0 + map_stride, *r2 = r1 + map_stride;
+#ifdef SO_SSIM_DBG_BWD_NOGLOAD      // ablation (tools/gpu_ssim.sh): the backward without its derivative-map reads
+  st.a0 = (float)g.off0; st.b0 = rm; st.c0 = (float)y; st.a1 = (float)g.off1; st.b1 = rm; st.c1 = (float)y;
+  (void)r1; (void)r2;
+#else
   st.a0 = r0[g.off0]; st.b0 = r1[g.off0]; st.c0 = r2[g.off0];
   st.a1 = r0[g.off1]; st.b1 = r1[g.off1]; st.c1 = r2[g.off1];
+#endif
 }
 
 template <int CH>

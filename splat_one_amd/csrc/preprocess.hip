@@ -71,7 +71,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
                  int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ tile_counts,
                  float4 *__restrict__ rec, float4 *__restrict__ vrec, int64_t cam_stride,
                  int32_t *__restrict__ tile_slots, int tile_cull, uint64_t *__restrict__ bin_keys, int64_t bin_cap,
-                 int32_t *__restrict__ bin_overflow, const int32_t *__restrict__ n_dev) {
+                 int32_t *__restrict__ bin_overflow, const int32_t *__restrict__ n_dev, int wrap_ok) {
   // n_dev (nullable): the number of Gaussians lives in device memory (device-side densification, so_refine_default):
   // N is then the CAPACITY of the buffers, rows n >= *n_dev are idle -- a captured launch follows N without re-capture
   const int n_live = n_dev ? min(*n_dev, N) : N;
@@ -123,8 +123,14 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
       // first binning pass (same float arithmetic as isect.hip::tile_box)
       const float tile_r = (float)o.radius / tile_size;
       const float tx = o.m2d[0] / tile_size, ty = o.m2d[1] / tile_size;
-      const int x0 = (int)fminf(fmaxf(floorf(tx - tile_r), 0.f), (float)tile_w);
-      const int x1 = (int)fminf(fmaxf(ceilf(tx + tile_r), 0.f), (float)tile_w);
+      int x0 = (int)fminf(fmaxf(floorf(tx - tile_r), 0.f), (float)tile_w);
+      int x1 = (int)fminf(fmaxf(ceilf(tx + tile_r), 0.f), (float)tile_w);
+      if (SPH && wrap_ok && cam_model_of(model, c) == SO_CAM_SPHERICAL) {
+        // a panorama is periodic in x: VIRTUAL tile columns (isect.hip::tile_box), filed under wrapx(x) below
+        x0 = (int)fmaxf(floorf(tx - tile_r), (float)-tile_w);
+        x1 = (int)fminf(ceilf(tx + tile_r), (float)(2 * tile_w));
+        if (x1 - x0 > tile_w) { x0 = 0; x1 = tile_w; }
+      }
       const int y0 = (int)fminf(fmaxf(floorf(ty - tile_r), 0.f), (float)tile_h);
       const int y1 = (int)fminf(fmaxf(ceilf(ty + tile_r), 0.f), (float)tile_h);
       cnt = (x1 - x0) * (y1 - y0);
@@ -169,7 +175,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
           for (int i = 0; i < kOwn; ++i) {
             if (i < cnt) {
               if (!tile_cull || tile_touches(cmx, cmy, cqa, cqb, cqc, ctau, x, y, tile_size)) {
-                const int64_t t = (int64_t)c * n_tiles + y * tile_w + x;
+                const int64_t t = (int64_t)c * n_tiles + y * tile_w + wrapx(x, tile_w);
                 const int32_t s = atomicAdd(tile_counts + t, 1);
                 if (s < bin_cap) bin_keys[t * bin_cap + s] = key;
                 else *bin_overflow = 1;
@@ -186,7 +192,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
 #pragma unroll
           for (int i = 0; i < kOwn; ++i) {
             if (i < cnt) {
-              if (!tile_cull || tile_touches(cmx, cmy, cqa, cqb, cqc, ctau, x, y, tile_size)) got[i] = atomicAdd(row + y * tile_w + x, 1);
+              if (!tile_cull || tile_touches(cmx, cmy, cqa, cqb, cqc, ctau, x, y, tile_size)) got[i] = atomicAdd(row + y * tile_w + wrapx(x, tile_w), 1);
               if (++x == bx1) { x = bx0; ++y; }
             }
           }
@@ -197,7 +203,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
         } else {
           for (int y = by0; y < by1; ++y)
             for (int x = bx0; x < bx1; ++x)
-              if (!tile_cull || tile_touches(cmx, cmy, cqa, cqb, cqc, ctau, x, y, tile_size)) atomicAdd(row + y * tile_w + x, 1);
+              if (!tile_cull || tile_touches(cmx, cmy, cqa, cqb, cqc, ctau, x, y, tile_size)) atomicAdd(row + y * tile_w + wrapx(x, tile_w), 1);
         }
       }
       unsigned long long todo = __ballot(big);
@@ -218,12 +224,12 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
           for (int x = sx0 + (lane & 7); x < sx1; x += 8)
             if (!tile_cull || tile_touches(smx, smy, sqa, sqb, sqc, stau, x, y, tile_size)) {
               if (bin_keys) {
-                const int64_t t = srow + y * tile_w + x;
+                const int64_t t = srow + y * tile_w + wrapx(x, tile_w);
                 const int32_t s = atomicAdd(tile_counts + t, 1);
                 if (s < bin_cap) bin_keys[t * bin_cap + s] = skey;
                 else *bin_overflow = 1;
               } else {
-                atomicAdd(row + y * tile_w + x, 1);
+                atomicAdd(row + y * tile_w + wrapx(x, tile_w), 1);
               }
             }
       }
@@ -538,7 +544,7 @@ static int preprocess_fwd_impl(const char *what, int C, int N, int K, int sh_deg
                      Ks, width, height, eps2d, near_plane, far_plane, radius_clip, camera_model, antialiased,      \
                      (float)tile_size, tile_w, tile_h, radii, means2d, depths, conics, opacities, colors,          \
                      tiles_per_gauss, tile_counts, reinterpret_cast<float4 *>(rec), reinterpret_cast<float4 *>(vrec), \
-                     cam_stride, tile_slots, tile_cull, bin_keys, bin_cap, bin_overflow, n_dev)
+                     cam_stride, tile_slots, tile_cull, bin_keys, bin_cap, bin_overflow, n_dev, (int)(width % tile_size == 0))
   switch (sh_degree) {
     case 0: SO_LAUNCH(0); break;
     case 1: SO_LAUNCH(1); break;

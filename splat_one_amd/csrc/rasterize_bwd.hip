@@ -26,7 +26,7 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
                 const int32_t *__restrict__ last_ids, const float *__restrict__ v_render_colors,
                 const float *__restrict__ v_render_alphas, float *__restrict__ v_means2d,
                 float *__restrict__ v_means2d_abs, float *__restrict__ v_conics, float *__restrict__ v_colors,
-                float *__restrict__ v_opacities) {
+                float *__restrict__ v_opacities, int wrap_flags) {
   constexpr int BLOCK = TS * TS;
   constexpr int NWAVES = (BLOCK + 63) / 64;
   // staged per Gaussian (same records as the forward): A = (x, y, conic a, conic b),
@@ -48,6 +48,10 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
   const int c = ct / n_tiles;
   const int t = ct - c * n_tiles;
   const int ty = t / tile_w, tx = t - ty * tile_w;
+  // periodic image (SO_TILE_WRAP_*): every staged Gaussian is shifted by the multiple of W that brings it closest to
+  // this tile, so a footprint that crosses the +-pi seam of a panorama continues on the other side
+  const bool wrap = wrap_for(wrap_flags, c);
+  const float wrap_w = (float)W, wrap_cx = (float)(tx * TS) + 0.5f * (float)TS;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   int lx, ly, wx0, wy0;
   PixelMap<TS>::get(tid, lx, ly, wx0, wy0);
@@ -113,13 +117,16 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
       s_id[tid] = g;
       if (PACKED) {
         const float4 *r4 = reinterpret_cast<const float4 *>(colors) + 4 * (int64_t)g;
-        const float4 q0 = r4[0], q1 = r4[1];   // x,y,ca,cb | cc,opac,r,g
+        float4 q0 = r4[0];
+        const float4 q1 = r4[1];   // x,y,ca,cb | cc,opac,r,g
+        if (wrap) q0.x -= wrap_w * rintf((q0.x - wrap_cx) / wrap_w);
         s_A[tid] = q0;
         s_B[tid] = q1;
         s_box[tid] = alpha_bound_box(q0.x, q0.y, q1.y, q0.z, q0.w, q1.x);
         s_C[tid].x = reinterpret_cast<const float *>(r4 + 2)[0];
       } else {
-        const float2 xy = means2d[g];
+        float2 xy = means2d[g];
+        if (wrap) xy.x -= wrap_w * rintf((xy.x - wrap_cx) / wrap_w);
         const float op = opacities[g];
         const float ca = conics[3 * (int64_t)g], cb = conics[3 * (int64_t)g + 1], cc = conics[3 * (int64_t)g + 2];
         s_A[tid] = make_float4(xy.x, xy.y, ca, cb);
@@ -247,12 +254,12 @@ static int launch_bwd(int TS, bool abs_, dim3 grid, hipStream_t st, int C, int N
                       const float *backgrounds, const uint8_t *tile_masks, const int32_t *offsets,
                       const int32_t *flatten_ids, const int32_t *n_dev, int64_t n_host, const float *ra,
                       const int32_t *last, const float *v_rc, const float *v_ra, float *v_m, float *v_abs, float *v_cn,
-                      float *v_col, float *v_op) {
+                      float *v_col, float *v_op, int wrap_flags) {
   const float2 *m2 = reinterpret_cast<const float2 *>(means2d);
 #define SO_GO(TSV, ABSV)                                                                                         \
   hipLaunchKernelGGL((k_rasterize_bwd<D, TSV, ABSV, false>), grid, dim3(TSV * TSV), 0, st, C, N, W, H, tile_w, tile_h, \
                      m2, conics, colors, opacities, backgrounds, tile_masks, offsets, flatten_ids, n_dev,       \
-                     n_host, ra, last, v_rc, v_ra, v_m, v_abs, v_cn, v_col, v_op)
+                     n_host, ra, last, v_rc, v_ra, v_m, v_abs, v_cn, v_col, v_op, wrap_flags)
   if (TS == 16) { if (abs_) SO_GO(16, true); else SO_GO(16, false); }
   else          { if (abs_) SO_GO(8, true);  else SO_GO(8, false); }
 #undef SO_GO
@@ -270,7 +277,10 @@ extern "C" int so_rasterize_bwd(int C, int N, int D, int width, int height, int 
                                 const float *v_render_alphas, float *v_means2d, float *v_means2d_abs,
                                 float *v_conics, float *v_colors, float *v_opacities, void *stream) {
   SO_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, "so_rasterize_bwd: bad sizes");
+  const int wrap_flags = tile_size & ~0xFF;
+  tile_size = so::tile_size_of(tile_size);
   SO_REQUIRE(tile_size == 16 || tile_size == 8, "so_rasterize_bwd: tile_size %d not in {8,16}", tile_size);
+  SO_REQUIRE(!wrap_flags || width % tile_size == 0, "so_rasterize_bwd: SO_TILE_WRAP_* needs width %% tile_size == 0");
   if (C == 0 || N == 0) return SO_OK;
   SO_REQUIRE(means2d && conics && colors && opacities && isect_offsets && render_alphas && last_ids &&
                  v_render_colors && v_render_alphas && v_means2d && v_conics && v_colors && v_opacities,
@@ -287,7 +297,7 @@ extern "C" int so_rasterize_bwd(int C, int N, int D, int width, int height, int 
                               tile_h, means2d, conics, colors, opacities, backgrounds, tile_masks,              \
                               isect_offsets, flatten_ids, n_isects_dev, n_isects_host, render_alphas, last_ids, \
                               v_render_colors, v_render_alphas, v_means2d, v_means2d_abs, v_conics, v_colors,   \
-                              v_opacities);
+                              v_opacities, wrap_flags);
   switch (D) {
     SO_CASE(1) SO_CASE(2) SO_CASE(3) SO_CASE(4) SO_CASE(5) SO_CASE(8) SO_CASE(9) SO_CASE(16) SO_CASE(17) SO_CASE(32) SO_CASE(33)
     default:
@@ -304,7 +314,10 @@ extern "C" int so_rasterize_bwd_packed(int C, int N, int width, int height, int 
                                        const float *v_render_colors, const float *v_render_alphas, float *vrec,
                                        int absgrad, void *stream) {
   SO_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, "so_rasterize_bwd_packed: bad sizes");
+  const int wrap_flags = tile_size & ~0xFF;
+  tile_size = so::tile_size_of(tile_size);
   SO_REQUIRE(tile_size == 16 || tile_size == 8, "so_rasterize_bwd_packed: tile_size %d not in {8,16}", tile_size);
+  SO_REQUIRE(!wrap_flags || width % tile_size == 0, "so_rasterize_bwd_packed: SO_TILE_WRAP_* needs width %% tile_size == 0");
   if (C == 0 || N == 0) return SO_OK;
   SO_REQUIRE(rec && isect_offsets && render_alphas && last_ids && v_render_colors && v_render_alphas && vrec,
              "so_rasterize_bwd_packed: null pointer");
@@ -318,7 +331,7 @@ extern "C" int so_rasterize_bwd_packed(int C, int N, int width, int height, int 
   hipLaunchKernelGGL((so::k_rasterize_bwd<3, TSV, ABSV, true>), grid, dim3(TSV * TSV), 0, st, C, N, width, height, \
                      tile_w, tile_h, nullptr, nullptr, rec, nullptr, backgrounds, nullptr, isect_offsets,         \
                      flatten_ids, n_isects_dev, n_isects_host, render_alphas, last_ids, v_render_colors,          \
-                     v_render_alphas, nullptr, nullptr, nullptr, vrec, nullptr)
+                     v_render_alphas, nullptr, nullptr, nullptr, vrec, nullptr, wrap_flags)
   if (tile_size == 16) { if (absgrad) SO_GO(16, true); else SO_GO(16, false); }
   else                 { if (absgrad) SO_GO(8, true);  else SO_GO(8, false); }
 #undef SO_GO

@@ -24,7 +24,7 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
                 const uint8_t *__restrict__ tile_masks, const int32_t *__restrict__ offsets,
                 const int32_t *__restrict__ flatten_ids, const int32_t *__restrict__ n_isects_dev,
                 int64_t n_isects_host, float *__restrict__ render_colors, float *__restrict__ render_alphas,
-                int32_t *__restrict__ last_ids) {
+                int32_t *__restrict__ last_ids, int wrap_flags) {
   constexpr int BLOCK = TS * TS;
   // staged per Gaussian: A = (x, y, conic a, conic b), B = (conic c, opacity [, r, g when D == 3]),
   // remaining colour channels in s_col -- two 16-byte broadcast reads + one 4-byte read per pass for RGB
@@ -43,6 +43,10 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
   const int c = ct / n_tiles;
   const int t = ct - c * n_tiles;
   const int ty = t / tile_w, tx = t - ty * tile_w;
+  // periodic image (SO_TILE_WRAP_*): every staged Gaussian is shifted by the multiple of W that brings it closest to
+  // this tile, so a footprint that crosses the +-pi seam of a panorama continues on the other side
+  const bool wrap = wrap_for(wrap_flags, c);
+  const float wrap_w = (float)W, wrap_cx = (float)(tx * TS) + 0.5f * (float)TS;
   const int tid = threadIdx.x;
   int lx, ly, wx0, wy0;
   PixelMap<TS>::get(tid, lx, ly, wx0, wy0);
@@ -84,13 +88,16 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
       const int32_t g = flatten_ids[idx];
       if (PACKED) {
         const float4 *r4 = reinterpret_cast<const float4 *>(colors) + 4 * (int64_t)g;
-        const float4 q0 = r4[0], q1 = r4[1];   // x,y,ca,cb | cc,opac,r,g
+        float4 q0 = r4[0];
+        const float4 q1 = r4[1];   // x,y,ca,cb | cc,opac,r,g
+        if (wrap) q0.x -= wrap_w * rintf((q0.x - wrap_cx) / wrap_w);
         s_A[tid] = q0;
         s_B[tid] = q1;
         s_box[tid] = alpha_bound_box(q0.x, q0.y, q1.y, q0.z, q0.w, q1.x);
         s_C[tid].x = reinterpret_cast<const float *>(r4 + 2)[0];
       } else {
-        const float2 xy = means2d[g];
+        float2 xy = means2d[g];
+        if (wrap) xy.x -= wrap_w * rintf((xy.x - wrap_cx) / wrap_w);
         const float op = opacities[g];
         const float ca = conics[3 * (int64_t)g], cb = conics[3 * (int64_t)g + 1], cc = conics[3 * (int64_t)g + 2];
         s_A[tid] = make_float4(xy.x, xy.y, ca, cb);
@@ -167,14 +174,14 @@ static int launch_fwd(int TS, dim3 grid, hipStream_t st, int C, int N, int W, in
                       const float *means2d, const float *conics, const float *colors, const float *opacities,
                       const float *backgrounds, const uint8_t *tile_masks, const int32_t *offsets,
                       const int32_t *flatten_ids, const int32_t *n_dev, int64_t n_host, float *rc, float *ra,
-                      int32_t *last) {
+                      int32_t *last, int wrap_flags) {
   const float2 *m2 = reinterpret_cast<const float2 *>(means2d);
   if (TS == 16)
     hipLaunchKernelGGL((k_rasterize_fwd<D, 16, false>), grid, dim3(256), 0, st, C, N, W, H, tile_w, tile_h, m2, conics, colors,
-                       opacities, backgrounds, tile_masks, offsets, flatten_ids, n_dev, n_host, rc, ra, last);
+                       opacities, backgrounds, tile_masks, offsets, flatten_ids, n_dev, n_host, rc, ra, last, wrap_flags);
   else
     hipLaunchKernelGGL((k_rasterize_fwd<D, 8, false>), grid, dim3(64), 0, st, C, N, W, H, tile_w, tile_h, m2, conics, colors,
-                       opacities, backgrounds, tile_masks, offsets, flatten_ids, n_dev, n_host, rc, ra, last);
+                       opacities, backgrounds, tile_masks, offsets, flatten_ids, n_dev, n_host, rc, ra, last, wrap_flags);
   return check_launch("so_rasterize_fwd");
 }
 
@@ -187,7 +194,10 @@ extern "C" int so_rasterize_fwd(int C, int N, int D, int width, int height, int 
                                 const int32_t *n_isects_dev, int64_t n_isects_host, float *render_colors,
                                 float *render_alphas, int32_t *last_ids, void *stream) {
   SO_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, "so_rasterize_fwd: bad sizes");
+  const int wrap_flags = tile_size & ~0xFF;
+  tile_size = so::tile_size_of(tile_size);
   SO_REQUIRE(tile_size == 16 || tile_size == 8, "so_rasterize_fwd: tile_size %d not in {8,16}", tile_size);
+  SO_REQUIRE(!wrap_flags || width % tile_size == 0, "so_rasterize_fwd: SO_TILE_WRAP_* needs width %% tile_size == 0");
   if (C == 0) return SO_OK;
   SO_REQUIRE(isect_offsets && render_colors && render_alphas && last_ids, "so_rasterize_fwd: null pointer");
   SO_REQUIRE(N == 0 || (means2d && conics && colors && opacities), "so_rasterize_fwd: null pointer");
@@ -201,7 +211,7 @@ extern "C" int so_rasterize_fwd(int C, int N, int D, int width, int height, int 
   case DD:                                                                                                       \
     return so::launch_fwd<DD>(tile_size, grid, st, C, N, width, height, tile_w, tile_h, means2d, conics, colors, \
                               opacities, backgrounds, tile_masks, isect_offsets, flatten_ids, n_isects_dev,      \
-                              n_isects_host, render_colors, render_alphas, last_ids);
+                              n_isects_host, render_colors, render_alphas, last_ids, wrap_flags);
   switch (D) {
     SO_CASE(1) SO_CASE(2) SO_CASE(3) SO_CASE(4) SO_CASE(5) SO_CASE(8) SO_CASE(9) SO_CASE(16) SO_CASE(17) SO_CASE(32) SO_CASE(33)
     default:
@@ -217,7 +227,10 @@ extern "C" int so_rasterize_fwd_packed(int C, int N, int width, int height, int 
                                        int64_t n_isects_host, float *render_colors, float *render_alphas,
                                        int32_t *last_ids, void *stream) {
   SO_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, "so_rasterize_fwd_packed: bad sizes");
+  const int wrap_flags = tile_size & ~0xFF;
+  tile_size = so::tile_size_of(tile_size);
   SO_REQUIRE(tile_size == 16 || tile_size == 8, "so_rasterize_fwd_packed: tile_size %d not in {8,16}", tile_size);
+  SO_REQUIRE(!wrap_flags || width % tile_size == 0, "so_rasterize_fwd_packed: SO_TILE_WRAP_* needs width %% tile_size == 0");
   if (C == 0) return SO_OK;
   SO_REQUIRE(isect_offsets && render_colors && render_alphas && last_ids && (N == 0 || rec), "so_rasterize_fwd_packed: null pointer");
   SO_REQUIRE((((uintptr_t)rec) & 63) == 0, "so_rasterize_fwd_packed: rec must be 64-byte aligned");
@@ -229,10 +242,10 @@ extern "C" int so_rasterize_fwd_packed(int C, int N, int width, int height, int 
   if (tile_size == 16)
     hipLaunchKernelGGL((so::k_rasterize_fwd<3, 16, true>), grid, dim3(256), 0, st, C, N, width, height, tile_w, tile_h,
                        nullptr, nullptr, rec, nullptr, backgrounds, nullptr, isect_offsets, flatten_ids, n_isects_dev,
-                       n_isects_host, render_colors, render_alphas, last_ids);
+                       n_isects_host, render_colors, render_alphas, last_ids, wrap_flags);
   else
     hipLaunchKernelGGL((so::k_rasterize_fwd<3, 8, true>), grid, dim3(64), 0, st, C, N, width, height, tile_w, tile_h,
                        nullptr, nullptr, rec, nullptr, backgrounds, nullptr, isect_offsets, flatten_ids, n_isects_dev,
-                       n_isects_host, render_colors, render_alphas, last_ids);
+                       n_isects_host, render_colors, render_alphas, last_ids, wrap_flags);
   return so::check_launch("so_rasterize_fwd_packed");
 }

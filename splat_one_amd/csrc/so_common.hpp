@@ -34,6 +34,16 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 constexpr int kWave = 64;  // CDNA wavefront
 
+// Periodic images (include/splat_one_amd.h, SO_TILE_WRAP_*): the `tile_size` argument of the binning / rasteriser entry
+// points carries, above its low byte, which cameras see an image that is periodic in x (the 360-degree panoramas of
+// the spherical camera model: a Gaussian whose footprint crosses x = 0 continues at x = W).
+__host__ __device__ inline int tile_size_of(int flags) { return flags & 0xFF; }
+__host__ __device__ inline bool wrap_for(int flags, int c) {
+  return (flags & SO_TILE_WRAP_ALL) != 0 || (c < 16 && ((flags >> (8 + c)) & 1) != 0);
+}
+// tile column of a VIRTUAL column x in [-tile_w, 2 tile_w): columns left of 0 / right of tile_w - 1 are the other end
+__host__ __device__ inline int wrapx(int x, int tile_w) { return x < 0 ? x + tile_w : (x >= tile_w ? x - tile_w : x); }
+
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---------------------------------------------------------------------------------------------

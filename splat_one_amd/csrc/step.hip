@@ -230,12 +230,21 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
   const int32_t *list_off = bins ? tile_counts : d->isect_offsets;
   const int32_t *list_n = bins ? nullptr : n_isects;
   const int64_t list_cap = bins ? -bins : d->isect_capacity;
+  // periodic views: spherical cameras, when the tile grid lines up across the seam
+  int wrap_flags = 0;
+  if (W % ts == 0) {
+    if (!(d->camera_model & SO_CAM_PER_VIEW)) wrap_flags = d->camera_model == SO_CAM_SPHERICAL ? SO_TILE_WRAP_ALL : 0;
+    else
+      for (int c = 0; c < C && c < 16; ++c)
+        if (((d->camera_model >> (2 * c)) & 3) == SO_CAM_SPHERICAL) wrap_flags |= SO_TILE_WRAP_CAM(c);
+  }
+  SO_REQUIRE(!(wrap_flags && (d->raster_impl == 1 || !bins)), "so_train_step_fwd_bwd: spherical views need the binned lists and raster_impl 0");
   const bool wave_impl = d->raster_impl == 1 && ts == 16;
   if (wave_impl)
     SO_STAGE(3, so_rasterize_fwd_wave(C, N, W, H, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects, d->isect_capacity,
                                       d->render_colors, d->render_alphas, d->last_ids, stream));
   else
-    SO_STAGE(3, so_rasterize_fwd_packed(C, N, W, H, ts, d->rec, d->backgrounds, list_off, d->flatten_ids, list_n,
+    SO_STAGE(3, so_rasterize_fwd_packed(C, N, W, H, ts | wrap_flags, d->rec, d->backgrounds, list_off, d->flatten_ids, list_n,
                                         list_cap, d->render_colors, d->render_alphas, d->last_ids, stream));
   if (forward_only) return SO_OK;
   // loss = (1-l) * mean|.| + l * (1 - mean SSIM_valid)
@@ -251,7 +260,7 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
                                       d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
                                       d->absgrad, stream));
   else
-    SO_STAGE(6, so_rasterize_bwd_packed(C, N, W, H, ts, d->rec, d->backgrounds, list_off, d->flatten_ids, list_n,
+    SO_STAGE(6, so_rasterize_bwd_packed(C, N, W, H, ts | wrap_flags, d->rec, d->backgrounds, list_off, d->flatten_ids, list_n,
                                         list_cap, d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
                                         d->absgrad, stream));
   if (d->fuse_adam) {

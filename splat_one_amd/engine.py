@@ -575,8 +575,9 @@ class FusedEngine:
             self.optimizers["means"].param_groups[0]["lr"] /= self.lr_gamma_means
         self._step_dev[0] = self.steps_done
         import warnings
-        warnings.warn(f"splat_one_amd: {void} training iteration(s) skipped -- {max(n_prev, n_last)} tile intersections "
-                      f"exceeded the buffer capacity {self.capacity}; buffers enlarged", RuntimeWarning)
+        what = (f"{max(n_prev, n_last)} Gaussians over one tile exceeded its bin of {self.bin_capacity} slots" if self.binned else
+                f"{max(n_prev, n_last)} tile intersections exceeded the buffer capacity {self.capacity}")
+        warnings.warn(f"splat_one_amd: {void} training iteration(s) skipped -- {what}; buffers enlarged", RuntimeWarning)
         self._grow(max(n_prev, n_last))
 
     def set_views(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor, schedule: bool = False) -> None:

@@ -341,18 +341,30 @@ def _eval_sh_bases_fast(basis_dim: int, dirs: Tensor) -> Tensor:
 # ---------------------------------------------------------------------------------------------
 # K6-K8 tile binning / sort / offsets  (non-differentiable)
 # ---------------------------------------------------------------------------------------------
+SO_TILE_WRAP_ALL = 1 << 24          # include/splat_one_amd.h: every camera's image is periodic in x
+
+
+def _periodic_tile_size(tile_size: int, periodic: bool) -> int:
+    """The C ABI carries the periodic-image flag in the high bits of its `tile_size` argument."""
+    return int(tile_size) | (SO_TILE_WRAP_ALL if periodic else 0)
+
+
 @torch.no_grad()
 def isect_tiles(
     means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int, tile_height: int,
     sort: bool = True, packed: bool = False, n_cameras: Optional[int] = None,
     camera_ids: Optional[Tensor] = None, gaussian_ids: Optional[Tensor] = None,
-    return_offsets: bool = False,
+    return_offsets: bool = False, periodic: bool = False,
 ):
     """means2d[C,N,2], radii[C,N] i32, depths[C,N] -> (tiles_per_gauss[C,N] i32, isect_ids[I] i64,
     flatten_ids[I] i32).  Exact-size outputs need I on the host: this entry point performs ONE
     device->host read (the sync-free path with preallocated capacity is `isect_tiles_static`).
     packed=True: means2d[nnz,2], radii[nnz], depths[nnz] with n_cameras and camera_ids[nnz] (gaussian_ids is accepted
-    and not needed); flatten_ids then index the packed rows."""
+    and not needed); flatten_ids then index the packed rows.
+    periodic=True (not in gsplat; `rasterization` sets it for camera_model="spherical"): the image is periodic in x
+    with period tile_width*tile_size, so a footprint that leaves through one side edge is binned into the tile columns
+    of the other side (the +-pi seam of an equirectangular panorama)."""
+    tile_size = _periodic_tile_size(tile_size, periodic)
     if packed:
         return _isect_tiles_packed(means2d, radii, depths, tile_size, tile_width, tile_height, sort, n_cameras,
                                    camera_ids, return_offsets)
@@ -419,10 +431,12 @@ def _isect_tiles_packed(means2d, radii, depths, tile_size, tile_width, tile_heig
 @torch.no_grad()
 def isect_tiles_static(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int,
                        tile_height: int, capacity: int, workspace: Optional[dict] = None,
-                       want_isect_ids: bool = False) -> dict:
+                       want_isect_ids: bool = False, periodic: bool = False) -> dict:
     """Sync-free binning into caller-sized buffers (hipGraph-capturable).  Returns a dict with
     tiles_per_gauss, isect_offsets, flatten_ids[capacity], n_isects (device i32[1]), overflow
-    (device i32[1]) and optionally isect_ids[capacity].  Nothing is read back to the host."""
+    (device i32[1]) and optionally isect_ids[capacity].  Nothing is read back to the host.
+    periodic: as in `isect_tiles`."""
+    tile_size = _periodic_tile_size(tile_size, periodic)
     C, N = radii.shape
     dev = means2d.device
     M = C * tile_width * tile_height
@@ -516,13 +530,15 @@ def rasterize_to_pixels(
     means2d: Tensor, conics: Tensor, colors: Tensor, opacities: Tensor, image_width: int,
     image_height: int, tile_size: int, isect_offsets: Tensor, flatten_ids: Tensor,
     backgrounds: Optional[Tensor] = None, masks: Optional[Tensor] = None, packed: bool = False,
-    absgrad: bool = False, n_isects: Optional[Tensor] = None,
+    absgrad: bool = False, n_isects: Optional[Tensor] = None, periodic: bool = False,
 ) -> Tuple[Tensor, Tensor]:
     """means2d[C,N,2] conics[C,N,3] colors[C,N,D] opacities[C,N] -> (render_colors[C,H,W,D],
     render_alphas[C,H,W,1]).  `n_isects` (device i32[1]) switches to the static-capacity mode of
     `isect_tiles_static`.  Channel counts outside the compiled set are zero-padded (as gsplat does).
     packed=True: means2d[nnz,2] conics[nnz,3] colors[nnz,D] opacities[nnz], flatten_ids indexing those rows (the
-    kernels address Gaussians through flatten_ids only, so both layouts run the same code)."""
+    kernels address Gaussians through flatten_ids only, so both layouts run the same code).
+    periodic=True (not in gsplat): the image is periodic in x with period image_width (which tile_size must divide);
+    every Gaussian is evaluated at the copy nearest to the tile, matching `isect_tiles(periodic=True)`."""
     C = isect_offsets.shape[0]
     lead = tuple(opacities.shape)
     if packed:
@@ -536,6 +552,7 @@ def rasterize_to_pixels(
     th, tw = isect_offsets.shape[1:]
     assert isect_offsets.shape[0] == C
     assert tw * tile_size >= image_width and th * tile_size >= image_height, "tile grid does not cover the image"
+    assert not periodic or image_width % tile_size == 0, "periodic images need image_width % tile_size == 0"
     D = colors.shape[-1]
     if backgrounds is not None:
         assert backgrounds.shape == (C, D), backgrounds.shape
@@ -553,7 +570,7 @@ def rasterize_to_pixels(
             backgrounds = torch.cat([backgrounds, torch.zeros(C, pad, dtype=torch.float32, device=colors.device)], -1)
     rc, ra = _RasterizeToPixels.apply(
         _f32(means2d), _f32(conics), _f32(colors), _f32(opacities), backgrounds, masks, int(image_width),
-        int(image_height), int(tile_size), isect_offsets.to(torch.int32).contiguous(),
+        int(image_height), _periodic_tile_size(tile_size, periodic), isect_offsets.to(torch.int32).contiguous(),
         flatten_ids.to(torch.int32).contiguous(), n_isects, bool(absgrad))
     if pad:
         rc = rc[..., :D]

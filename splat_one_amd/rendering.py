@@ -232,13 +232,15 @@ def rasterization(
     tile_width = math.ceil(width / float(tile_size))
     tile_height = math.ceil(height / float(tile_size))
     n_isects_dev = None
+    # an equirectangular panorama is periodic in x: footprints continue across the +-pi seam when the tile grid lines up
+    periodic = camera_model == "spherical" and width % tile_size == 0
     if isect_capacity is None:
         tiles_per_gauss, isect_ids, flatten_ids, isect_offsets = isect_tiles(
             means2d, radii, depths, tile_size, tile_width, tile_height, packed=packed, n_cameras=C,
-            camera_ids=camera_ids, gaussian_ids=gaussian_ids, return_offsets=True)
+            camera_ids=camera_ids, gaussian_ids=gaussian_ids, return_offsets=True, periodic=periodic)
     else:
         st = isect_tiles_static(means2d, radii, depths, tile_size, tile_width, tile_height, int(isect_capacity),
-                                workspace=workspace, want_isect_ids=False)
+                                workspace=workspace, want_isect_ids=False, periodic=periodic)
         tiles_per_gauss, isect_ids, flatten_ids, isect_offsets = (
             st["tiles_per_gauss"], st["isect_ids"], st["flatten_ids"], st["isect_offsets"])
         n_isects_dev = st["n_isects"]
@@ -258,7 +260,7 @@ def rasterization(
             bg_chunk = backgrounds[..., i * channel_chunk:(i + 1) * channel_chunk] if backgrounds is not None else None
             rc, ra = rasterize_to_pixels(means2d, conics, colors_chunk, opacities, width, height, tile_size,
                                          isect_offsets, flatten_ids, backgrounds=bg_chunk, packed=packed,
-                                         absgrad=absgrad, n_isects=n_isects_dev)
+                                         absgrad=absgrad, n_isects=n_isects_dev, periodic=periodic)
             render_colors.append(rc)
             render_alphas.append(ra)
         render_colors = torch.cat(render_colors, dim=-1)
@@ -266,7 +268,7 @@ def rasterization(
     else:
         render_colors, render_alphas = rasterize_to_pixels(
             means2d, conics, colors, opacities, width, height, tile_size, isect_offsets, flatten_ids,
-            backgrounds=backgrounds, packed=packed, absgrad=absgrad, n_isects=n_isects_dev)
+            backgrounds=backgrounds, packed=packed, absgrad=absgrad, n_isects=n_isects_dev, periodic=periodic)
     if render_mode in ("ED", "RGB+ED"):
         # normalise the accumulated depth to get the expected depth
         render_colors = torch.cat(

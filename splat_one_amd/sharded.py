@@ -243,6 +243,9 @@ class ShardedEngine:
         ts = c["tile_size"]
         tw, th = math.ceil(W / ts), math.ceil(H / ts)
         cam = camera_model_code(c["camera_model"], n)
+        own_model = c["camera_model"] if isinstance(c["camera_model"], str) else list(c["camera_model"])[self.rank]
+        # this rank's image is periodic in x when its camera is a panorama (include/splat_one_amd.h SO_TILE_WRAP_ALL)
+        tsw = ts | ((1 << 24) if own_model == "spherical" and W % ts == 0 else 0)
         f16 = self.attr_dtype == "f16"
         if N > 0 and f16:
             _lib.call("so_preprocess_fwd_f16", n, N, self.K, c["sh_degree"], P("s.means"), P("s.opacities"),
@@ -258,7 +261,7 @@ class ShardedEngine:
         all_to_all_rows(w["rec_full"], w["rec_shard"], self.group)
         _lib.call("so_rec_unpack", Nf, P("w.rec_full"), P("w.means2d_full"), P("w.radii_full"), P("w.depths_full"),
                   P("w.vrec_full"), st)
-        _lib.call("so_isect_count", 1, Nf, P("w.means2d_full"), P("w.radii_full"), ts, tw, th, P("w.tiles_full"),
+        _lib.call("so_isect_count", 1, Nf, P("w.means2d_full"), P("w.radii_full"), tsw, tw, th, P("w.tiles_full"),
                   P("w.counters"), P("w.isect_offsets"), P("c.n_isects"), P("w.rec_full") if self.tile_cull else 0, st)
         if self._probe_capacity:     # once per workspace: the largest intersection count over the ranks decides the buffers
             self._probe_capacity = False
@@ -270,10 +273,10 @@ class ShardedEngine:
                 self._step_dev[0] = self.steps_done
                 self._build_workspace()
                 return self.fwd_bwd(camtoworlds, Ks, pixels, schedule)
-        _lib.call("so_isect_fill", 1, Nf, P("w.means2d_full"), P("w.radii_full"), P("w.depths_full"), ts, tw, th,
+        _lib.call("so_isect_fill", 1, Nf, P("w.means2d_full"), P("w.radii_full"), P("w.depths_full"), tsw, tw, th,
                   P("w.isect_offsets"), P("c.n_isects"), P("c.cursor"), self.capacity, P("w.key_buf"), P("w.flatten_ids"), 0,
                   P("c.overflow"), 0, P("w.rec_full") if self.tile_cull else 0, st)
-        _lib.call("so_rasterize_fwd_packed", 1, Nf, W, H, ts, P("w.rec_full"), 0, P("w.isect_offsets"), P("w.flatten_ids"),
+        _lib.call("so_rasterize_fwd_packed", 1, Nf, W, H, tsw, P("w.rec_full"), 0, P("w.isect_offsets"), P("w.flatten_ids"),
                   P("c.n_isects"), self.capacity, P("w.render_colors"), P("w.render_alphas"), P("w.last_ids"), st)
         lam = float(c["ssim_lambda"])
         n_l1 = float(H * W * 3)
@@ -282,7 +285,7 @@ class ShardedEngine:
         # weight 1/world: the step's loss is the mean over the global batch of views
         _lib.call("so_ssim_l1_bwd", 1, H, W, 3, P("w.render_colors"), p(px), P("w.dmaps"), (1.0 - lam) / n_l1 / n,
                   -lam / n_ss / n, 0, P("w.v_render_colors"), P("w.loss_sums"), P("c.loss_out"), 1, lam / n, st)
-        _lib.call("so_rasterize_bwd_packed", 1, Nf, W, H, ts, P("w.rec_full"), 0, P("w.isect_offsets"), P("w.flatten_ids"),
+        _lib.call("so_rasterize_bwd_packed", 1, Nf, W, H, tsw, P("w.rec_full"), 0, P("w.isect_offsets"), P("w.flatten_ids"),
                   P("c.n_isects"), self.capacity, P("w.render_alphas"), P("w.last_ids"), P("w.v_render_colors"), P("w.zero_v_alphas"),
                   P("w.vrec_full"), int(c["absgrad"]), st)
         _lib.call("so_shard_flag_put", n, cap, P("c.overflow"), P("w.vrec_full"), st)

@@ -291,5 +291,7 @@ def test_spherical_views_fused_engine(dev):
     eng.set_views(c2w, Ks, pixels)
     eng.fwd_bwd()
     assert int((eng.ws["radii"][0] > 0).sum()) > 0.9 * N          # the panorama sees (nearly) everything
+    x, rad = eng.ws["means2d"][0, :, 0], eng.ws["radii"][0].float()
+    assert int((((x - rad < 0) | (x + rad > W)) & (rad > 0)).sum()) > 50      # footprints that straddle the +-pi seam (periodic image)
     _three_way("spherical_plus_pinhole_20k", r.splats, c2w, Ks, W, H, pixels, eng.ws["depths"], eng.ws["radii"],
                eng.ws["render_colors"], _engine_grads(r), eng.loss()[0].item(), models=models, with_f32=True, with_plain=True)

@@ -87,6 +87,47 @@ def test_camera_models(dev, camera_model):
     _compare(splats, c2w, Ks, 128, 96, sh_degree=3, camera_model=camera_model)
 
 
+@pytest.mark.parametrize("packed", [False, True])
+def test_spherical_seam(dev, packed):
+    """A panorama is periodic in x (build-defined; include/splat_one_amd.h SO_TILE_WRAP_*): splats straddling the +-pi
+    seam directly behind the camera continue on the other side of the image -- against the oracle's statement of the same
+    rule, forward and backward; and turning the camera by three tile columns of longitude rolls the image by 48 pixels."""
+    import math
+    from splat_one_amd import rasterization
+    W, H, N = 256, 128, 600
+    g = torch.Generator().manual_seed(31)
+    lon = math.pi + (torch.rand(N, generator=g) - 0.5) * 0.5            # within +-14 degrees of the seam
+    lat = (torch.rand(N, generator=g) - 0.5) * 1.2
+    rng = 1.5 + torch.rand(N, generator=g)
+    means = torch.stack([rng * torch.cos(lat) * torch.sin(lon), rng * torch.sin(lat), rng * torch.cos(lat) * torch.cos(lon)], -1)
+    splats = {"means": means, "quats": torch.randn(N, 4, generator=g), "scales": torch.log(torch.rand(N, 3, generator=g) * 0.12 + 0.02),
+              "opacities": torch.logit(torch.rand(N, generator=g) * 0.5 + 0.2), "sh0": torch.rand(N, 1, 3, generator=g),
+              "shN": torch.randn(N, 15, 3, generator=g) * 0.1}
+    c2w = torch.eye(4)[None].clone()
+    Ks = torch.eye(3)[None].clone()
+    if not packed:
+        m_h, m_o = _compare(splats, c2w, Ks, W, H, sh_degree=3, camera_model="spherical")
+        x, r = m_o["means2d"][0, :, 0], m_o["radii"][0].double()
+        assert int(((x - r < 0) | (x + r > W)).sum()) > 100                 # the footprints do cross the edge
+    p = {k: v.to(dev) for k, v in splats.items()}
+    k = 48
+    th = 2.0 * math.pi * k / W
+    Ry = torch.tensor([[math.cos(th), 0.0, math.sin(th), 0.0], [0.0, 1.0, 0.0, 0.0],
+                       [-math.sin(th), 0.0, math.cos(th), 0.0], [0.0, 0.0, 0.0, 1.0]])
+    outs = []
+    for vm in (torch.eye(4)[None], Ry[None]):
+        with torch.no_grad():
+            rc, ra, meta = rasterization(p["means"], p["quats"], torch.exp(p["scales"]), torch.sigmoid(p["opacities"]),
+                                         torch.cat([p["sh0"], p["shN"]], 1), vm.to(dev), Ks.to(dev), W, H, sh_degree=3,
+                                         camera_model="spherical", packed=packed)
+        outs.append((rc, ra))
+    a = outs[0][1][0, :, :, 0]
+    assert float(a[:, 0].max()) > 0.3 and float(a[:, W - 1].max()) > 0.3   # both edges are covered ...
+    assert float((a[:, 0] - a[:, W - 1]).abs().max()) < 0.2                 # ... and the image does not tear between them
+    assert float((torch.roll(outs[0][0], k, dims=2) - outs[1][0]).abs().max()) < 2e-5
+    assert float((torch.roll(outs[0][1], k, dims=2) - outs[1][1]).abs().max()) < 2e-5
+
+
 def test_antialiased_multiview_sh_ramp(dev):
     splats, c2w, Ks = make_scene(3000, 80, 60, regime="ref", n_views=3)
     _compare(splats, c2w, Ks, 80, 60, sh_degree=1, rasterize_mode="antialiased")

@@ -242,6 +242,60 @@ def test_kat9_permutation_invariance_and_kat10_absgrad():
     assert (ab + 1e-15 >= meta["means2d"].grad.abs()).all() and ab.sum() > 0
 
 
+def _seam_checks():
+    """The panorama is periodic in x (build-defined, oracle/torch_oracle.py::isect_tiles periodic=True): a splat straddling
+    the +-pi seam (directly BEHIND the camera) continues on the other side of the image, and turning the camera about
+    its vertical axis by k columns' worth of longitude rolls the image by k pixels (k a multiple of the tile size, so
+    that the 3-sigma tile boxes turn with it)."""
+    W, H = 128, 64
+    vm, K = _cam(W, H, 50.0)
+    means = torch.tensor([[0.0, 0.0, -2.0]], dtype=dt)                 # longitude pi: the seam
+    quats = torch.tensor([[1.0, 0, 0, 0]], dtype=dt)
+    args = (quats, torch.full((1, 3), 0.3, dtype=dt), torch.tensor([0.9], dtype=dt), torch.tensor([[0.2, 0.6, 0.9]], dtype=dt))
+    rc, ra, meta = O.rasterization(means, *args, vm, K, W, H, camera_model="spherical")
+    x_seam = float(meta["means2d"][0, 0, 0])
+    assert min(x_seam, W - x_seam) < 1e-6 and int(meta["radii"][0, 0]) > 8
+    assert int(meta["tiles_per_gauss"][0, 0]) >= 4                      # tile columns on BOTH sides
+    a = ra[0, :, :, 0]
+    assert float(a[H // 2, 0]) > 0.5 and float(a[H // 2, W - 1]) > 0.5
+    assert (a - a.flip(1)).abs().max() < 1e-9                           # an isotropic blob on the seam: mirror symmetric
+    # the C restatement takes the same decision
+    rc_c, ra_c, _ = O.rasterization(means, *args, vm, K, W, H, camera_model="spherical", raster_fn=CO.raster_fn())
+    assert (rc_c - rc).abs().max() < 1e-12 and (ra_c - ra).abs().max() < 1e-12
+    # when the tile grid does not line up (W % tile_size != 0) the image is not periodic: the blob is cut at the edge
+    W2 = 120
+    _, ra2, meta2 = O.rasterization(means, *args, vm, K, W2, H, camera_model="spherical")
+    a2 = ra2[0, :, :, 0]
+    assert min(float(a2[H // 2, 0]), float(a2[H // 2, W2 - 1])) == 0.0
+    # yaw <-> roll, with Gaussians all around and gradients
+    g = torch.Generator().manual_seed(21)
+    N = 40
+    d = torch.randn(N, 3, generator=g, dtype=dt)
+    d[:, 1] *= 0.5
+    means = (d / d.norm(dim=-1, keepdim=True) * (1.5 + torch.rand(N, 1, generator=g, dtype=dt))).requires_grad_()
+    qs = torch.randn(N, 4, generator=g, dtype=dt)
+    scales = torch.rand(N, 3, generator=g, dtype=dt) * 0.3 + 0.05
+    opac = torch.rand(N, generator=g, dtype=dt) * 0.6 + 0.2
+    cols = torch.rand(N, 3, generator=g, dtype=dt)
+    k = 48                                                              # three tile columns
+    th = 2.0 * math.pi * k / W
+    # x = W/2 + W lon / (2 pi), lon = atan2(x_cam, z_cam): adding th to every longitude = turning the camera by -th
+    Ry = torch.tensor([[math.cos(th), 0.0, math.sin(th), 0.0], [0.0, 1.0, 0.0, 0.0],
+                       [-math.sin(th), 0.0, math.cos(th), 0.0], [0.0, 0.0, 0.0, 1.0]], dtype=dt)
+    wgt = torch.rand(1, H, W, 3, generator=g, dtype=dt)
+    out = []
+    for view, w in ((vm, wgt), (Ry[None] @ vm, torch.roll(wgt, k, dims=2))):
+        rc, ra, meta = O.rasterization(means, qs, scales, opac, cols, view, K, W, H, camera_model="spherical",
+                                       raster_fn=CO.raster_fn())
+        (gm,) = torch.autograd.grad((rc * w).sum(), means)
+        out.append((rc, gm, meta))
+    dx = (out[1][2]["means2d"][0, :, 0] - out[0][2]["means2d"][0, :, 0] - k) / W
+    assert (dx - dx.round()).abs().max() < 1e-9                         # every centre moved by k columns (mod W)
+    assert (torch.roll(out[0][0], k, dims=2) - out[1][0]).abs().max() < 1e-9
+    assert (out[0][1] - out[1][1]).abs().max() < 1e-9 * max(1.0, float(out[0][1].abs().max()))
+    assert int((out[0][2]["radii"] > 0).sum()) == N
+
+
 def test_kat11_spherical_mapping_and_gradcheck():
     """The 360-degree model as this build defines it (oracle/torch_oracle.py::_spherical_proj; the fork's kernel is absent
     from the reference): longitude / latitude of the camera-space direction map linearly onto the W x H panorama, depth
