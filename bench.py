@@ -226,12 +226,12 @@ def main():
     for i in range(max(1, args.warmup)):
         step_once()
         if args.densify and fused and i == args.densify - 2 and getattr(runner._engine, "device_refine", False):
-            # densification that actually grows the set: refine the top quarter of the accumulated screen-space
+            # densification that actually grows the set: refine the top 40 % of the accumulated screen-space
             # gradient at every refinement (one read of the statistics, in the warm-up)
             eng = runner._engine
             n_live = eng.sync_host()
             avg = (eng.dstats["grad2d"][:n_live] / eng.dstats["count"][:n_live].clamp_min(1))
-            cfg.strategy.grow_grad2d = float(torch.quantile(avg[torch.randperm(n_live, device=dev)[:1_000_000]], 0.75))
+            cfg.strategy.grow_grad2d = float(torch.quantile(avg[torch.randperm(n_live, device=dev)[:1_000_000]], 0.6))
     torch.cuda.synchronize()
     if not fused:
         prof = _lib.profile_summary()

@@ -1,26 +1,45 @@
-"""Copies the summaries of the last gpurun profile calls into profiles/ (tracked) and regenerates
-profiles/traffic.json (entry point -> corrected HBM bytes per launch, read by bench.py)."""
-import json, os, shutil, sys
+"""Copies the summaries of the last gpurun measurement calls into profiles/ (tracked) and regenerates
+profiles/traffic.json (entry point -> corrected HBM bytes per launch, read by bench.py).
+
+    python tools/refresh_profiles.py r02      # after tools/gpu_profiles_r02.sh and tools/gpu_c4_r02.sh
+"""
+import glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
-pairs = [("prof/bench_kernel_stats.csv", f"{tag}_engine_kernel_stats.csv"),
-         ("pmc/traffic_summary.json", f"{tag}_engine_pmc_traffic.json"),
-         ("bench.json", f"{tag}_engine_bench.json")]
+
+
+def first(pattern):
+    hits = sorted(glob.glob(os.path.join(src, pattern), recursive=True))
+    return hits[0] if hits else None
+
+
+pairs = [(f"{tag}/prof/**/bench_kernel_stats.csv", f"{tag}_engine_kernel_stats.csv"),
+         (f"{tag}/pmc/traffic_summary.json", f"{tag}_engine_pmc_traffic.json"),
+         (f"{tag}/bench.json", f"{tag}_engine_bench.json"),
+         (f"{tag}/other_lines.jsonl", f"{tag}_other_bench_lines.jsonl"),
+         (f"c4{tag}/bench.json", f"{tag}_c4_densify_bench.json"),
+         (f"c4{tag}/**/c4_kernel_stats.csv", f"{tag}_c4_densify_kernel_stats.csv"),
+         (f"c4{tag}/hip_api_diff.json", f"{tag}_c4_refine_hip_api_calls.json"),
+         (f"parity_{tag}.json", f"parity_{tag}.json")]
 for a, b in pairs:
-    p = os.path.join(src, a)
-    if os.path.exists(p):
+    p = first(a)
+    if p:
         shutil.copy(p, os.path.join(dst, b))
-        print("copied", a, "->", b)
+        print("copied", os.path.relpath(p, ROOT), "->", b)
+    else:
+        print("MISSING", a)
 d = json.load(open(os.path.join(dst, f"{tag}_engine_pmc_traffic.json")))
 names = {"so_rasterize_bwd": "void so::k_rasterize_bwd<3, 16, false, true>", "so_rasterize_fwd": "void so::k_rasterize_fwd<3, 16, true>",
          "so_adam_step_dev": "so::k_adam_dev", "so_ssim_l1_fwd": "void so::k_ssim_l1_fwd<3>", "so_ssim_l1_bwd": "void so::k_ssim_l1_bwd<3>",
          "so_preprocess_fwd": "void so::k_preprocess_fwd<3, so::AttrSoA, false>",
-         "so_preprocess_bwd": "void so::k_preprocess_bwd<3, so::AttrSoA, true, true, false>"}
+         "so_preprocess_bwd": "void so::k_preprocess_bwd<3, so::AttrSoA, true, true, false>",
+         "so_isect_fill": "void so::k_tile_sort_waves<256, 2048>"}
 out = {k: d[v]["hbm_bytes_per_launch_corrected"] for k, v in names.items() if v in d}
-out["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_pmc.sh), KB -> bytes, FETCH_SIZE doubled as "
-                "MI355X_MICROARCH.md prescribes for gfx950; source profiles/%s_engine_pmc_traffic.json" % tag)
+out["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profiles_%s.sh) of the default bench (c2, 8 ring views "
+                "cycled), KB -> bytes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; source "
+                "profiles/%s_engine_pmc_traffic.json" % (tag, tag))
 json.dump(out, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print(out)
