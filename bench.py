@@ -235,7 +235,8 @@ def main():
     torch.cuda.synchronize()
     if not fused:
         prof = _lib.profile_summary()
-        dominant = max(prof.items(), key=lambda kv: kv[1][0] * kv[1][1])[0]
+        dominant = max(((k, v) for k, v in prof.items() if k not in ("so_rec_pack", "so_rec_unpack_grads", "so_camera_inverse")),
+                       key=lambda kv: kv[1][0] * kv[1][1])[0]
         _lib.PROFILE = {dominant}
 
     # forward-only rate: the eval / viewer render (projection + SH + binning + sort + rasterise)
@@ -281,7 +282,10 @@ def main():
             step_once()
         prof = {k.replace("_packed", ""): v for k, v in _lib.profile_summary().items()}
         _lib.PROFILE = None
-        dominant = max(prof.items(), key=lambda kv: kv[1][0] * kv[1][1])[0]
+        # (the first launch after isect_tiles' host read starts on an idle GPU: its event pair also spans the host time up
+        # to the launch, so the small record-packing helpers are not candidates for "dominant kernel")
+        helpers = ("so_rec_pack", "so_rec_unpack_grads", "so_camera_inverse")
+        dominant = max(((k, v) for k, v in prof.items() if k not in helpers), key=lambda kv: kv[1][0] * kv[1][1])[0]
         dom_calls, dom_ms = prof[dominant]
     elif fused:
         # Per-kernel durations with HIP events on the launch stream.  Events cannot be recorded

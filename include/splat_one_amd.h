@@ -197,7 +197,8 @@ int so_isect_sort_bins(int C, int tile_width, int tile_height, const int32_t *ti
  * rectangle lies wholly outside the ellipse sigma <= ln(255 opacity) (+ margin) therefore changes no output and is left
  * out of the lists: 15 % fewer intersections on isotropic trained-like scenes, 60 % on dense anisotropic low-opacity
  * ones.  Images, losses and gradients are unchanged (tests/test_gpu_engine.py); the LISTS differ from gsplat's, so the
- * operator-level isect_tiles never culls. */
+ * operator-level isect_tiles culls only when asked to (conics + opacities given: so_rec_pack builds the records;
+ * rasterization(tile_cull=True), the default of this build, does). */
 
 /* gsplat `isect_tiles(sort=False)`: Gaussian-major, row-major-tile emission order.
  * cum_tiles[C*N] i64 = inclusive prefix sum of tiles_per_gauss (caller-provided). */
@@ -368,6 +369,15 @@ int so_preprocess_bwd(int C, int N, int K, int sh_degree, const float *means, co
                       float *skip_flag_out, void *stream);
 int so_rec_unpack(int64_t n, const float *rec, float *means2d, int32_t *radii, float *depths, float *vrec,
                   void *stream);
+/* Operator-level `rasterize_to_pixels` with RGB colours (gsplat_trainer.py:477-494 through `rasterization`): the
+ * separate arrays means2d[n,2], conics[n,3], colors[n,3], opacities[n] packed into rec[n][16] for
+ * so_rasterize_fwd_packed / so_rasterize_bwd_packed (vrec, nullable, is zeroed; colors may be NULL when the records
+ * only serve the exact tile culling of so_isect_count / so_isect_fill), and the gradient records
+ * vrec[n][16] spread back into v_means2d / v_conics / v_colors / v_opacities (+ v_means2d_abs, nullable). */
+int so_rec_pack(int64_t n, const float *means2d, const float *conics, const float *colors, const float *opacities,
+                float *rec, float *vrec, void *stream);
+int so_rec_unpack_grads(int64_t n, const float *vrec, float *v_means2d, float *v_conics, float *v_colors,
+                        float *v_opacities, float *v_means2d_abs, void *stream);
 int so_shard_flag_put(int world, int64_t cap, const int32_t *overflow, float *vrec_full, void *stream);
 int so_shard_flag_get(int world, int64_t cap, const float *vrec_shard, int32_t *overflow, void *stream);
 

@@ -96,6 +96,8 @@ _SIGS = {
     "so_shard_flag_put": [c_int, c_i64, c_ptr, c_ptr, c_ptr],
     "so_shard_flag_get": [c_int, c_i64, c_ptr, c_ptr, c_ptr],
     "so_preprocess_bwd": [c_int] * 4 + [c_ptr] * 8 + [c_int, c_int, c_f32, c_int, c_int] + [c_ptr] * 9 + [c_f32, c_f32] + [c_ptr] * 9 + [c_int, c_i64, c_ptr, c_ptr, c_ptr],
+    "so_rec_pack": [c_i64] + [c_ptr] * 7,
+    "so_rec_unpack_grads": [c_i64] + [c_ptr] * 7,
     "so_rasterize_fwd_packed": [c_int] * 5 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 4,
     "so_rasterize_fwd_wave": [c_int] * 4 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 4,
     "so_rasterize_bwd_wave": [c_int] * 4 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 5 + [c_int, c_ptr],
@@ -174,7 +176,14 @@ def ptr(t: Optional[torch.Tensor]) -> int:
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream() -> int:
+    """Handle of torch's current HIP stream on the current device (the raw getter: 0.3 us against 10 us for
+    `torch.cuda.current_stream().cuda_stream`, ten launches per operator-level step)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

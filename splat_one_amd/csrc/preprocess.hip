@@ -460,6 +460,39 @@ k_rec_unpack(int64_t n, const float4 *__restrict__ rec, float2 *__restrict__ mea
   }
 }
 
+// Operator-level rasterize_to_pixels (RGB): the separate per-row arrays packed into the 64-byte records the packed
+// rasteriser kernels gather (one line per list entry instead of four), and the gradient records spread back out.
+__global__ void __launch_bounds__(256)
+k_rec_pack(int64_t n, const float2 *__restrict__ means2d, const float *__restrict__ conics,
+           const float *__restrict__ colors, const float *__restrict__ opacities, float4 *__restrict__ rec,
+           float4 *__restrict__ vrec) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float2 m = means2d[i];
+    rec[4 * i] = make_float4(m.x, m.y, conics[3 * i], conics[3 * i + 1]);
+    float r = 0.f, g = 0.f, b = 0.f;
+    if (colors) { r = colors[3 * i]; g = colors[3 * i + 1]; b = colors[3 * i + 2]; }
+    rec[4 * i + 1] = make_float4(conics[3 * i + 2], opacities[i], r, g);
+    rec[4 * i + 2] = make_float4(b, 0.f, 0.f, 0.f);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    rec[4 * i + 3] = z;
+    if (vrec) { vrec[4 * i] = z; vrec[4 * i + 1] = z; vrec[4 * i + 2] = z; vrec[4 * i + 3] = z; }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_rec_unpack_grads(int64_t n, const float4 *__restrict__ vrec, float2 *__restrict__ v_means2d,
+                   float *__restrict__ v_conics, float *__restrict__ v_colors, float *__restrict__ v_opacities,
+                   float2 *__restrict__ v_means2d_abs) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 q0 = vrec[4 * i], q1 = vrec[4 * i + 1], q2 = vrec[4 * i + 2];
+    v_means2d[i] = make_float2(q0.x, q0.y);
+    v_conics[3 * i] = q0.z; v_conics[3 * i + 1] = q0.w; v_conics[3 * i + 2] = q1.x;
+    v_colors[3 * i] = q1.y; v_colors[3 * i + 1] = q1.z; v_colors[3 * i + 2] = q1.w;
+    v_opacities[i] = q2.x;
+    if (v_means2d_abs) v_means2d_abs[i] = make_float2(q2.y, q2.z);
+  }
+}
+
 // Gaussian-sharded steps: "the binning pass of my view overflowed" has to reach every rank before any optimiser
 // runs (the gradients that view sent to the other shards are incomplete).  It travels with the gradient records:
 // slot 15 of the first record of every block of vrec_full (the rasteriser's backward accumulates into slots 0..10
@@ -783,6 +816,30 @@ extern "C" int so_rec_unpack(int64_t n, const float *rec, float *means2d, int32_
                      reinterpret_cast<const float4 *>(rec), reinterpret_cast<float2 *>(means2d), radii, depths,
                      reinterpret_cast<float4 *>(vrec));
   return so::check_launch("so_rec_unpack");
+}
+
+extern "C" int so_rec_pack(int64_t n, const float *means2d, const float *conics, const float *colors,
+                           const float *opacities, float *rec, float *vrec, void *stream) {
+  SO_REQUIRE(n >= 0, "so_rec_pack: bad size");
+  if (n == 0) return SO_OK;
+  SO_REQUIRE(means2d && conics && opacities && rec, "so_rec_pack: null pointer");
+  SO_REQUIRE(((((uintptr_t)rec) | ((uintptr_t)vrec)) & 63) == 0, "so_rec_pack: records must be 64-byte aligned");
+  hipLaunchKernelGGL(so::k_rec_pack, dim3(so::pp_grid(n)), dim3(256), 0, so::as_stream(stream), n,
+                     reinterpret_cast<const float2 *>(means2d), conics, colors, opacities,
+                     reinterpret_cast<float4 *>(rec), reinterpret_cast<float4 *>(vrec));
+  return so::check_launch("so_rec_pack");
+}
+
+extern "C" int so_rec_unpack_grads(int64_t n, const float *vrec, float *v_means2d, float *v_conics, float *v_colors,
+                                   float *v_opacities, float *v_means2d_abs, void *stream) {
+  SO_REQUIRE(n >= 0, "so_rec_unpack_grads: bad size");
+  if (n == 0) return SO_OK;
+  SO_REQUIRE(vrec && v_means2d && v_conics && v_colors && v_opacities, "so_rec_unpack_grads: null pointer");
+  SO_REQUIRE((((uintptr_t)vrec) & 63) == 0, "so_rec_unpack_grads: records must be 64-byte aligned");
+  hipLaunchKernelGGL(so::k_rec_unpack_grads, dim3(so::pp_grid(n)), dim3(256), 0, so::as_stream(stream), n,
+                     reinterpret_cast<const float4 *>(vrec), reinterpret_cast<float2 *>(v_means2d), v_conics, v_colors,
+                     v_opacities, reinterpret_cast<float2 *>(v_means2d_abs));
+  return so::check_launch("so_rec_unpack_grads");
 }
 
 extern "C" int so_shard_flag_put(int world, int64_t cap, const int32_t *overflow, float *vrec_full, void *stream) {

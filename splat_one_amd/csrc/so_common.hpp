@@ -250,25 +250,39 @@ __device__ __forceinline__ int lane_id() {
 // whose pixel-centre rectangle lies entirely outside that ellipse contributes to no pixel, exactly; leaving it out
 // of the tile's list changes no output and removes 15 % (isotropic trained-like) to 60 % (dense, low-opacity,
 // anisotropic) of the per-pixel work.  The minimum of the convex quadratic over the rectangle is 0 if the centre is
-// inside, else it lies on one of the four edges.  `tau` carries a safety margin (the caller adds it), and every
-// operation is an explicitly rounded intrinsic: the histogram pass and the scatter pass evaluate this in different
-// kernels and must agree bit for bit, whatever the optimiser contracts elsewhere.
+// inside, else it lies on one of the four edges.  `tau` carries a safety margin (the caller adds it).  The histogram
+// pass and the scatter pass evaluate this in different kernels and MUST agree bit for bit -- a pair that is counted but
+// not filled leaves a slot of the tile's list unwritten.  HIP's __fmul_rn / __fadd_rn are plain `*` / `+` to the
+// compiler, which fused them into FMAs in one kernel and not in the other (round 2: one disagreement in ~2e8 tests, found
+// through exact-size lists in ops.isect_tiles); `#pragma clang fp contract(off)` in each body is what pins the rounding
+// (hipcc's default -ffp-contract=fast-honor-pragmas honours it through inlining; checked in the ISA of every user).
 // d = pixel - mean; conic (a, b, c): sigma = 0.5 (a dx^2 + c dy^2) + b dx dy.
 // ---------------------------------------------------------------------------------------------
 #if defined(__HIPCC__)
+// (plain operators under the pragma: the bodies of HIP's __fmul_rn / __fadd_rn wrappers are compiled under the
+// translation unit's default mode and WOULD be contracted)
 __device__ __forceinline__ float cull_edge(float fixed, float lo, float hi, float q_fixed, float q_free, float b, float ratio) {
   // minimise over t in [lo, hi]:  0.5 (q_fixed fixed^2 + q_free t^2) + b fixed t ;  ratio = -b / q_free
-  float t = __fmul_rn(ratio, fixed);
+#pragma clang fp contract(off)
+  float t = ratio * fixed;
   t = fminf(fmaxf(t, lo), hi);
-  const float quad = __fadd_rn(__fmul_rn(q_fixed, __fmul_rn(fixed, fixed)), __fmul_rn(q_free, __fmul_rn(t, t)));
-  return __fadd_rn(__fmul_rn(0.5f, quad), __fmul_rn(b, __fmul_rn(fixed, t)));
+  const float f2 = fixed * fixed, t2 = t * t, ft = fixed * t;
+  const float qa = q_fixed * f2, qb = q_free * t2;
+  const float quad = qa + qb;
+  const float h = 0.5f * quad, cross = b * ft;
+  return h + cross;
 }
 
 __device__ __forceinline__ bool tile_touches(float mx, float my, float a, float b, float c, float tau, int tx, int ty,
                                              float tile_size) {
-  const float xlo = __fadd_rn(__fadd_rn(__fmul_rn((float)tx, tile_size), 0.5f), -mx), xhi = __fadd_rn(xlo, tile_size - 1.f);
-  const float ylo = __fadd_rn(__fadd_rn(__fmul_rn((float)ty, tile_size), 0.5f), -my), yhi = __fadd_rn(ylo, tile_size - 1.f);
-  if (!(a > 0.f) || !(c > 0.f) || !(__fadd_rn(__fmul_rn(a, c), -__fmul_rn(b, b)) > 0.f)) return true;   // degenerate conic: never cull
+#pragma clang fp contract(off)
+  const float x0 = (float)tx * tile_size, y0 = (float)ty * tile_size;       // exact: small integers times the tile size
+  const float x0h = x0 + 0.5f, y0h = y0 + 0.5f;
+  const float xlo = x0h - mx, ylo = y0h - my;
+  const float xhi = xlo + (tile_size - 1.f), yhi = ylo + (tile_size - 1.f);
+  const float ac = a * c, bb = b * b;
+  const float det = ac - bb;
+  if (!(a > 0.f) || !(c > 0.f) || !(det > 0.f)) return true;   // degenerate conic: never cull
   if (xlo <= 0.f && xhi >= 0.f && ylo <= 0.f && yhi >= 0.f) return tau >= 0.f;   // centre inside: sigma_min = 0
   const float ry = __fdiv_rn(-b, c), rx = __fdiv_rn(-b, a);
   float best = cull_edge(xlo, ylo, yhi, a, c, b, ry);
@@ -279,7 +293,12 @@ __device__ __forceinline__ bool tile_touches(float mx, float my, float a, float 
 }
 
 // tau with its margin: 1 % of alpha at the threshold, far above the float32 error of sigma at |d| ~ image size
-__device__ __forceinline__ float cull_tau(float opacity) { return __fadd_rn(__logf(__fmul_rn(255.f, opacity)), 0.01f); }
+__device__ __forceinline__ float cull_tau(float opacity) {
+#pragma clang fp contract(off)
+  const float x = 255.f * opacity;
+  const float l = __logf(x);
+  return l + 0.01f;
+}
 #endif
 
 }  // namespace so

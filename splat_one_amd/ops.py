@@ -14,6 +14,8 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import os
+
 import torch
 from torch import Tensor
 
@@ -355,6 +357,7 @@ def isect_tiles(
     sort: bool = True, packed: bool = False, n_cameras: Optional[int] = None,
     camera_ids: Optional[Tensor] = None, gaussian_ids: Optional[Tensor] = None,
     return_offsets: bool = False, periodic: bool = False,
+    conics: Optional[Tensor] = None, opacities: Optional[Tensor] = None,
 ):
     """means2d[C,N,2], radii[C,N] i32, depths[C,N] -> (tiles_per_gauss[C,N] i32, isect_ids[I] i64,
     flatten_ids[I] i32).  Exact-size outputs need I on the host: this entry point performs ONE
@@ -363,11 +366,16 @@ def isect_tiles(
     and not needed); flatten_ids then index the packed rows.
     periodic=True (not in gsplat; `rasterization` sets it for camera_model="spherical"): the image is periodic in x
     with period tile_width*tile_size, so a footprint that leaves through one side edge is binned into the tile columns
-    of the other side (the +-pi seam of an equirectangular panorama)."""
+    of the other side (the +-pi seam of an equirectangular panorama).
+    conics + opacities (not in gsplat; `rasterization(tile_cull=True)` passes them): EXACT tile culling -- a tile none of
+    whose pixel centres can reach alpha = opacity * exp(-sigma) >= 1/255 is left out of the lists.  gsplat files a Gaussian
+    under the whole square of half-width ceil(3 sqrt(lambda_max)); the rasteriser then discards such pairs pixel by pixel, so
+    the rendered image is bit-identical and only the lists are shorter (about half the entries for small splats)."""
     tile_size = _periodic_tile_size(tile_size, periodic)
+    cull = conics is not None and opacities is not None
     if packed:
         return _isect_tiles_packed(means2d, radii, depths, tile_size, tile_width, tile_height, sort, n_cameras,
-                                   camera_ids, return_offsets)
+                                   camera_ids, return_offsets, conics if cull else None, opacities if cull else None)
     C, N = radii.shape
     assert means2d.shape == (C, N, 2), means2d.shape
     assert depths.shape == (C, N), depths.shape
@@ -380,18 +388,32 @@ def isect_tiles(
     tile_counts, cursor = counters[:M], counters[M:2 * M + 1]
     n_isects, overflow = counters[2 * M + 1:2 * M + 2], counters[2 * M + 2:]
     offsets = torch.empty(C, tile_height, tile_width, dtype=torch.int32, device=dev)
+    cull_rec = _cull_records(means2d, conics, opacities) if cull else None
     call("so_isect_count", C, N, ptr(means2d), ptr(radii), tile_size, tile_width, tile_height,
-         ptr(tiles_per_gauss), ptr(tile_counts), ptr(offsets), ptr(n_isects), 0, stream())
+         ptr(tiles_per_gauss), ptr(tile_counts), ptr(offsets), ptr(n_isects), ptr(cull_rec), stream())
     total = int(n_isects.item())
     isect_ids = torch.empty(total, dtype=torch.int64, device=dev)
     flatten_ids = torch.empty(total, dtype=torch.int32, device=dev)
     if total > 0:
         if sort:
-            keys = torch.empty(total, dtype=torch.int64, device=dev)
+            check = os.environ.get("SPLAT_ONE_AMD_CHECK_LISTS") == "1"     # debugging aid: did the fill pass write every slot?
+            # culled lists: the fill pass repeats the count pass's tile test (bit-identical arithmetic, so_common.hpp); should
+            # the two ever disagree, a zero key (Gaussian 0, sorted first) is a harmless slot where garbage would be a fault
+            keys = (torch.full((total,), -1, dtype=torch.int64, device=dev) if check
+                    else (torch.zeros if cull else torch.empty)(total, dtype=torch.int64, device=dev))
             call("so_isect_fill", C, N, ptr(means2d), ptr(radii), ptr(depths), tile_size, tile_width,
                  tile_height, ptr(offsets), ptr(n_isects), ptr(cursor), total, ptr(keys), ptr(flatten_ids),
-                 ptr(isect_ids), ptr(overflow), 0, 0, stream())
+                 ptr(isect_ids), ptr(overflow), 0, ptr(cull_rec), stream())
+            if check:
+                bad = (flatten_ids < 0) | (flatten_ids >= C * N)
+                if bool(bad.any()) or int(overflow.item()) != 0:
+                    pos = torch.nonzero(bad)[:8, 0].tolist()
+                    tiles = [int(torch.searchsorted(offsets.reshape(-1).long(), torch.tensor(p_, device=dev), right=True)) - 1 for p_ in pos]
+                    raise RuntimeError(f"isect_tiles: {int(bad.sum())} of {total} list slots were not written by the fill pass "
+                                       f"(overflow flag {int(overflow.item())}); first positions {pos} in tiles {tiles}, "
+                                       f"ids {flatten_ids[pos].tolist() if pos else []}")
         else:
+            assert not cull, "isect_tiles(sort=False) keeps gsplat's lists (no tile culling)"
             cum = torch.cumsum(tiles_per_gauss.reshape(-1).to(torch.int64), 0).contiguous()
             call("so_isect_emit_unsorted", C, N, ptr(means2d), ptr(radii), ptr(depths), ptr(cum), tile_size,
                  tile_width, tile_height, ptr(isect_ids), ptr(flatten_ids), stream())
@@ -400,15 +422,43 @@ def isect_tiles(
     return tiles_per_gauss, isect_ids, flatten_ids
 
 
+def _cull_records(means2d: Tensor, conics: Tensor, opacities: Tensor) -> Tensor:
+    """64-byte records {x, y, conic, opacity, ...} for the exact tile test of the binning kernels."""
+    rows = opacities.numel()
+    assert conics.shape == opacities.shape + (3,) and means2d.shape == opacities.shape + (2,), (conics.shape, opacities.shape)
+    rec = torch.empty(max(rows, 1), 16, dtype=torch.float32, device=means2d.device)
+    call("so_rec_pack", rows, ptr(_f32(means2d)), ptr(_f32(conics.detach())), 0, ptr(_f32(opacities.detach())), ptr(rec), 0,
+         stream())
+    return rec
+
+
+def rec_pack_unpack_roundtrip(dev) -> bool:
+    """Self-check of `so_rec_pack` / `so_rec_unpack_grads` (the record helpers of `rasterize_to_pixels`): what is packed
+    into slots {x, y, conic, opacity, rgb} comes back from the gradient slots {v_x, v_y, v_conic, v_rgb, v_opacity}."""
+    n = 1000
+    g = torch.Generator(device=dev).manual_seed(3)
+    m, cn, col, op = (torch.rand(n, k, generator=g, device=dev) for k in (2, 3, 3, 1))
+    rec = torch.empty(n, 16, device=dev)
+    call("so_rec_pack", n, ptr(m), ptr(cn), ptr(col), ptr(op), ptr(rec), 0, stream())
+    ok = (torch.equal(rec[:, 0:2], m) and torch.equal(rec[:, 2:5], cn) and torch.equal(rec[:, 5:6], op)
+          and torch.equal(rec[:, 6:9], col))
+    vrec = torch.arange(n * 16, device=dev, dtype=torch.float32).reshape(n, 16).contiguous()
+    outs = [torch.empty(n, k, device=dev) for k in (2, 3, 3, 1, 2)]
+    call("so_rec_unpack_grads", n, ptr(vrec), *[ptr(o) for o in outs], stream())
+    return bool(ok and torch.equal(outs[0], vrec[:, 0:2]) and torch.equal(outs[1], vrec[:, 2:5])
+                and torch.equal(outs[2], vrec[:, 5:8]) and torch.equal(outs[3], vrec[:, 8:9]) and torch.equal(outs[4], vrec[:, 9:11]))
+
+
 def _isect_tiles_packed(means2d, radii, depths, tile_size, tile_width, tile_height, sort, n_cameras, camera_ids,
-                        return_offsets):
+                        return_offsets, conics=None, opacities=None):
     nnz = radii.shape[0]
     assert means2d.shape == (nnz, 2) and depths.shape == (nnz,), (means2d.shape, depths.shape)
     assert n_cameras is not None and camera_ids is not None and camera_ids.shape == (nnz,), "packed: n_cameras / camera_ids"
     C = int(n_cameras)
     if C == 1:          # one camera: the packed rows ARE a dense [1, nnz] problem
+        kw = {"conics": conics[None], "opacities": opacities[None]} if conics is not None else {}
         out = isect_tiles(means2d[None], radii[None], depths[None], tile_size, tile_width, tile_height, sort=sort,
-                          return_offsets=return_offsets)
+                          return_offsets=return_offsets, **kw)
         return (out[0][0],) + tuple(out[1:])
     # several cameras: the binning kernels take the camera of a row from its position in a [C, n] grid -- give every
     # camera a row of nnz slots and put packed row r into slot (camera_ids[r], r); empty slots have radius 0
@@ -421,8 +471,15 @@ def _isect_tiles_packed(means2d, radii, depths, tile_size, tile_width, tile_heig
     g_radii[slot] = radii.to(torch.int32)
     g_means2d[slot] = means2d.to(torch.float32)
     g_depths[slot] = depths.to(torch.float32)
+    cull_kw = {}
+    if conics is not None:
+        g_conics = torch.zeros(C * nnz, 3, dtype=torch.float32, device=dev)
+        g_opac = torch.zeros(C * nnz, dtype=torch.float32, device=dev)
+        g_conics[slot] = conics.detach().to(torch.float32)
+        g_opac[slot] = opacities.detach().to(torch.float32)
+        cull_kw = {"conics": g_conics.view(C, nnz, 3), "opacities": g_opac.view(C, nnz)}
     out = isect_tiles(g_means2d.view(C, nnz, 2), g_radii.view(C, nnz), g_depths.view(C, nnz), tile_size, tile_width,
-                      tile_height, sort=sort, return_offsets=return_offsets)
+                      tile_height, sort=sort, return_offsets=return_offsets, **cull_kw)
     tiles_per_gauss = out[0].reshape(-1)[slot]
     flatten_ids = out[2] % max(nnz, 1)                 # slot index -> packed row
     return (tiles_per_gauss, out[1], flatten_ids) + tuple(out[3:])
@@ -431,12 +488,14 @@ def _isect_tiles_packed(means2d, radii, depths, tile_size, tile_width, tile_heig
 @torch.no_grad()
 def isect_tiles_static(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int,
                        tile_height: int, capacity: int, workspace: Optional[dict] = None,
-                       want_isect_ids: bool = False, periodic: bool = False) -> dict:
+                       want_isect_ids: bool = False, periodic: bool = False,
+                       conics: Optional[Tensor] = None, opacities: Optional[Tensor] = None) -> dict:
     """Sync-free binning into caller-sized buffers (hipGraph-capturable).  Returns a dict with
     tiles_per_gauss, isect_offsets, flatten_ids[capacity], n_isects (device i32[1]), overflow
     (device i32[1]) and optionally isect_ids[capacity].  Nothing is read back to the host.
-    periodic: as in `isect_tiles`."""
+    periodic, conics + opacities: as in `isect_tiles`."""
     tile_size = _periodic_tile_size(tile_size, periodic)
+    cull_rec = _cull_records(means2d, conics, opacities) if (conics is not None and opacities is not None) else None
     C, N = radii.shape
     dev = means2d.device
     M = C * tile_width * tile_height
@@ -458,10 +517,10 @@ def isect_tiles_static(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size
     n_isects, overflow = counters[2 * M + 1:2 * M + 2], counters[2 * M + 2:]
     means2d, depths = _f32(means2d), _f32(depths)
     call("so_isect_count", C, N, ptr(means2d), ptr(radii), tile_size, tile_width, tile_height,
-         ptr(tiles_per_gauss), ptr(tile_counts), ptr(offsets), ptr(n_isects), 0, stream())
+         ptr(tiles_per_gauss), ptr(tile_counts), ptr(offsets), ptr(n_isects), ptr(cull_rec), stream())
     call("so_isect_fill", C, N, ptr(means2d), ptr(radii), ptr(depths), tile_size, tile_width, tile_height,
          ptr(offsets), ptr(n_isects), ptr(cursor), capacity, ptr(keys), ptr(flatten_ids), ptr(isect_ids),
-         ptr(overflow), 0, 0, stream())
+         ptr(overflow), 0, ptr(cull_rec), stream())
     return dict(tiles_per_gauss=tiles_per_gauss, isect_offsets=offsets, flatten_ids=flatten_ids,
                 isect_ids=isect_ids, n_isects=n_isects, overflow=overflow)
 
@@ -481,6 +540,11 @@ def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile
 # K9/K10 rasterise
 # ---------------------------------------------------------------------------------------------
 class _RasterizeToPixels(torch.autograd.Function):
+    """RGB without tile masks goes through the 64-byte-record kernels (`so_rec_pack` -> `so_rasterize_*_packed` ->
+    `so_rec_unpack_grads`): one cache line per list entry for the gathers and ONE atomic record per (quadrant, Gaussian)
+    in the backward instead of nine atomics into four arrays (c2: forward 113 -> 70 us, backward 280 -> 150 us).  Other
+    channel counts and masked renders use the array kernels.  Same results either way (tests/test_gpu_ops.py)."""
+
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, masks, width, height, tile_size,
                 isect_offsets, flatten_ids, n_isects_dev, absgrad):
@@ -491,33 +555,63 @@ class _RasterizeToPixels(torch.autograd.Function):
         render_alphas = torch.empty(C, height, width, 1, dtype=torch.float32, device=dev)
         last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
         n_host = flatten_ids.numel()      # exact count, or (static mode) the capacity that bounds the device count
-        call("so_rasterize_fwd", C, N, D, width, height, tile_size, ptr(means2d), ptr(conics), ptr(colors),
-             ptr(opacities), ptr(backgrounds), ptr(masks), ptr(isect_offsets), ptr(flatten_ids),
-             ptr(n_isects_dev), n_host, ptr(render_colors), ptr(render_alphas), ptr(last_ids), stream())
-        ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, masks, isect_offsets,
-                              flatten_ids, n_isects_dev, render_alphas, last_ids)
-        ctx.cfg = (width, height, tile_size, absgrad, n_host)
+        rows = opacities.numel()
+        rec = None
+        if D == 3 and masks is None and rows > 0:
+            rec = torch.empty(rows, 16, dtype=torch.float32, device=dev)
+            call("so_rec_pack", rows, ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(rec), 0, stream())
+            # (C, N) only size the grid and bound the row index: the records are addressed through flatten_ids
+            call("so_rasterize_fwd_packed", C, N, width, height, tile_size, ptr(rec), ptr(backgrounds),
+                 ptr(isect_offsets), ptr(flatten_ids), ptr(n_isects_dev), n_host, ptr(render_colors),
+                 ptr(render_alphas), ptr(last_ids), stream())
+            ctx.save_for_backward(rec, backgrounds, isect_offsets, flatten_ids, n_isects_dev, render_alphas, last_ids,
+                                  means2d)       # (means2d only carries the `.absgrad` side channel)
+            ctx.shapes = (means2d.shape, conics.shape, colors.shape, opacities.shape)
+        else:
+            call("so_rasterize_fwd", C, N, D, width, height, tile_size, ptr(means2d), ptr(conics), ptr(colors),
+                 ptr(opacities), ptr(backgrounds), ptr(masks), ptr(isect_offsets), ptr(flatten_ids),
+                 ptr(n_isects_dev), n_host, ptr(render_colors), ptr(render_alphas), ptr(last_ids), stream())
+            ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, masks, isect_offsets,
+                                  flatten_ids, n_isects_dev, render_alphas, last_ids)
+        ctx.records = rec is not None
+        ctx.cfg = (width, height, tile_size, absgrad, n_host, C, N, D)
         return render_colors, render_alphas
 
     @staticmethod
     def backward(ctx, v_render_colors, v_render_alphas):
-        (means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids, n_isects_dev,
-         render_alphas, last_ids) = ctx.saved_tensors
-        width, height, tile_size, absgrad, n_host = ctx.cfg
-        C, N = isect_offsets.shape[0], opacities.shape[-1]
-        D = colors.shape[-1]
+        width, height, tile_size, absgrad, n_host, C, N, D = ctx.cfg
         v_render_colors = v_render_colors.contiguous()
         v_render_alphas = v_render_alphas.contiguous()
-        v_means2d = torch.zeros_like(means2d)
-        v_conics = torch.zeros_like(conics)
-        v_colors = torch.zeros_like(colors)
-        v_opacities = torch.zeros_like(opacities)
-        v_abs = torch.zeros_like(means2d) if absgrad else None
-        call("so_rasterize_bwd", C, N, D, width, height, tile_size, ptr(means2d), ptr(conics), ptr(colors),
-             ptr(opacities), ptr(backgrounds), ptr(masks), ptr(isect_offsets), ptr(flatten_ids),
-             ptr(n_isects_dev), n_host, ptr(render_alphas), ptr(last_ids), ptr(v_render_colors),
-             ptr(v_render_alphas), ptr(v_means2d), ptr(v_abs), ptr(v_conics), ptr(v_colors), ptr(v_opacities),
-             stream())
+        if ctx.records:
+            (rec, backgrounds, isect_offsets, flatten_ids, n_isects_dev, render_alphas, last_ids,
+             means2d) = ctx.saved_tensors
+            s_m, s_cn, s_col, s_op = ctx.shapes
+            dev = rec.device
+            rows = rec.shape[0]
+            vrec = torch.zeros(rows, 16, dtype=torch.float32, device=dev)
+            call("so_rasterize_bwd_packed", C, N, width, height, tile_size, ptr(rec), ptr(backgrounds),
+                 ptr(isect_offsets), ptr(flatten_ids), ptr(n_isects_dev), n_host, ptr(render_alphas), ptr(last_ids),
+                 ptr(v_render_colors), ptr(v_render_alphas), ptr(vrec), int(absgrad), stream())
+            v_means2d = torch.empty(s_m, dtype=torch.float32, device=dev)
+            v_conics = torch.empty(s_cn, dtype=torch.float32, device=dev)
+            v_colors = torch.empty(s_col, dtype=torch.float32, device=dev)
+            v_opacities = torch.empty(s_op, dtype=torch.float32, device=dev)
+            v_abs = torch.empty(s_m, dtype=torch.float32, device=dev) if absgrad else None
+            call("so_rec_unpack_grads", rows, ptr(vrec), ptr(v_means2d), ptr(v_conics), ptr(v_colors),
+                 ptr(v_opacities), ptr(v_abs), stream())
+        else:
+            (means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids, n_isects_dev,
+             render_alphas, last_ids) = ctx.saved_tensors
+            v_means2d = torch.zeros_like(means2d)
+            v_conics = torch.zeros_like(conics)
+            v_colors = torch.zeros_like(colors)
+            v_opacities = torch.zeros_like(opacities)
+            v_abs = torch.zeros_like(means2d) if absgrad else None
+            call("so_rasterize_bwd", C, N, D, width, height, tile_size, ptr(means2d), ptr(conics), ptr(colors),
+                 ptr(opacities), ptr(backgrounds), ptr(masks), ptr(isect_offsets), ptr(flatten_ids),
+                 ptr(n_isects_dev), n_host, ptr(render_alphas), ptr(last_ids), ptr(v_render_colors),
+                 ptr(v_render_alphas), ptr(v_means2d), ptr(v_abs), ptr(v_conics), ptr(v_colors), ptr(v_opacities),
+                 stream())
         if absgrad:
             means2d.absgrad = v_abs          # same side channel as gsplat: strategy reads `.absgrad`
         v_bg = None

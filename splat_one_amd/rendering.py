@@ -14,7 +14,7 @@ import torch
 import torch.distributed as dist
 from torch import Tensor
 
-from .ops import (fully_fused_projection, isect_offset_encode, isect_tiles, isect_tiles_static,
+from .ops import (camera_inverse, fully_fused_projection, isect_offset_encode, isect_tiles, isect_tiles_static,
                   rasterize_to_pixels, spherical_harmonics)
 
 RENDER_MODES = ("RGB", "D", "ED", "RGB+D", "RGB+ED")
@@ -97,10 +97,15 @@ def rasterization(
     covars: Optional[Tensor] = None,
     isect_capacity: Optional[int] = None,
     workspace: Optional[dict] = None,
+    tile_cull: bool = True,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Rasterise N Gaussians to C cameras.  Returns (render_colors[C,H,W,X], render_alphas[C,H,W,1], meta).
 
     Differences from the gsplat call, all explicit:
+      * `tile_cull=True` (default): the per-tile lists leave out (Gaussian, tile) pairs that provably reach no pixel with
+        alpha >= 1/255 (`isect_tiles(conics=, opacities=)`).  Images are bit-identical to the un-culled call and gradients
+        equal up to the order of the float atomics; `meta["tiles_per_gauss"]`, `meta["isect_ids"]`, `meta["flatten_ids"]`
+        and `meta["isect_offsets"]` describe the shorter lists.  `tile_cull=False` reproduces gsplat's lists entry for entry.
       * `packed=True` (gsplat's default; the reference passes `Config.packed` = False, gsplat_trainer.py:133, 487):
         every per-Gaussian intermediate and `meta` entry has one row per (camera, Gaussian) pair with a positive
         radius, camera-major, with `meta["camera_ids"]` / `meta["gaussian_ids"]` naming the pair; the rasteriser
@@ -176,7 +181,7 @@ def rasterization(
         elif colors.dim() == 2:
             colors = colors[None].expand(C, -1, -1)
     else:
-        camtoworlds = torch.inverse(viewmats)
+        camtoworlds = camera_inverse(viewmats)      # (no device synchronisation, unlike torch.inverse)
         if packed:
             dirs = means[gaussian_ids] - camtoworlds[camera_ids, :3, 3]  # [nnz, 3]
             shs = colors[gaussian_ids] if colors.dim() == 3 else colors[camera_ids, gaussian_ids]     # [nnz, K, 3]
@@ -234,13 +239,14 @@ def rasterization(
     n_isects_dev = None
     # an equirectangular panorama is periodic in x: footprints continue across the +-pi seam when the tile grid lines up
     periodic = camera_model == "spherical" and width % tile_size == 0
+    cull_kw = {"conics": conics, "opacities": opacities} if tile_cull else {}
     if isect_capacity is None:
         tiles_per_gauss, isect_ids, flatten_ids, isect_offsets = isect_tiles(
             means2d, radii, depths, tile_size, tile_width, tile_height, packed=packed, n_cameras=C,
-            camera_ids=camera_ids, gaussian_ids=gaussian_ids, return_offsets=True, periodic=periodic)
+            camera_ids=camera_ids, gaussian_ids=gaussian_ids, return_offsets=True, periodic=periodic, **cull_kw)
     else:
         st = isect_tiles_static(means2d, radii, depths, tile_size, tile_width, tile_height, int(isect_capacity),
-                                workspace=workspace, want_isect_ids=False, periodic=periodic)
+                                workspace=workspace, want_isect_ids=False, periodic=periodic, **cull_kw)
         tiles_per_gauss, isect_ids, flatten_ids, isect_offsets = (
             st["tiles_per_gauss"], st["isect_ids"], st["flatten_ids"], st["isect_offsets"])
         n_isects_dev = st["n_isects"]

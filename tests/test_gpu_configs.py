@@ -140,7 +140,8 @@ def test_c2_100k_1080p_both_paths(dev, regime):
                                 info["radii"], renders, _engine_grads(r), loss.item(),
                                 extra={"N": N, "width": W, "height": H})
     I_o = metas[0]["flatten_ids"].numel()
-    assert abs(info["flatten_ids"].numel() - I_o) <= max(8, 2e-5 * I_o)
+    # rasterization() culls tiles exactly by default: its lists are the oracle's (gsplat's) minus pairs that reach no pixel
+    assert 0.2 * I_o < info["flatten_ids"].numel() <= I_o
     # (2) fused engine (the path bench.py times)
     eng = FusedEngine(r.splats, r.optimizers, W, H, 1, sh_degree=3, use_graph=False)
     eng.set_views(c2w, Ks, pixels)
@@ -202,7 +203,7 @@ def test_c4_1m_1440p_operator_forward(dev):
                        torch.sigmoid(splats["opacities"]).to(to), torch.cat([splats["sh0"], splats["shN"]], 1).to(to),
                        torch.linalg.inv(c2w).to(to), Ks.to(to), W, H)
     with torch.no_grad():
-        rc_h, ra_h, m_h = rasterization(*args(dev), sh_degree=3, near_plane=0.01, far_plane=1e8, packed=False)
+        rc_h, ra_h, m_h = rasterization(*args(dev), sh_degree=3, near_plane=0.01, far_plane=1e8, packed=False, tile_cull=False)
         rc_o, ra_o, m_o = O.rasterization(*args("cpu"), sh_degree=3, near_plane=0.01, far_plane=1e8, raster_fn=CO.raster_fn(),
                                           sort_depths=m_h["depths"])
     l1 = (rc_h.cpu().double() - rc_o).abs().mean().item()

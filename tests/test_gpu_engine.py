@@ -226,13 +226,14 @@ def test_engine_tile_cull_is_exact(dev, regime, C, aa, binned):
         res[cull] = dict(img=eng.ws["render_colors"].clone(), alpha=eng.ws["render_alphas"].clone(), n=st["n_isects"],
                          grads={k: v.grad.detach().clone() for k, v in r.splats.items()}, offs=offs, ids=ids,
                          loss=eng.loss().clone(), radii=eng.ws["radii"].clone())
-        if not cull:       # culling off == the operator-level lists (gsplat semantics), bit for bit
-            sp = r.splats
+        # the operator-level lists with the same switch are the engine's, bit for bit (off = gsplat semantics)
+        sp = r.splats
+        with torch.no_grad():
             _, _, info = rasterization(sp["means"], sp["quats"], torch.exp(sp["scales"]), torch.sigmoid(sp["opacities"]),
                                        torch.cat([sp["sh0"], sp["shN"]], 1), torch.linalg.inv(c2w), Ks, W, H, sh_degree=3,
                                        near_plane=0.01, far_plane=1e8, rasterize_mode="antialiased" if aa else "classic",
-                                       packed=False)
-            assert torch.equal(info["flatten_ids"].cpu(), ids)
+                                       packed=False, tile_cull=cull)
+        assert torch.equal(info["flatten_ids"].cpu(), ids)
     a, b = res[False], res[True]
     assert b["n"] < 0.9 * a["n"], (a["n"], b["n"])
     assert torch.equal(a["img"], b["img"]) and torch.equal(a["alpha"], b["alpha"])

@@ -524,3 +524,35 @@ def test_camera_inverse_matches_torch_and_is_differentiable(dev):
     (inv_h * w).sum().backward()
     (torch.linalg.inv(B) * w).sum().backward()
     assert rel_err(A.grad, B.grad) < 1e-4
+
+
+def test_tile_cull_count_and_fill_passes_agree(dev, monkeypatch):
+    """Exact tile culling is evaluated twice -- by the histogram pass that sizes the lists and by the fill pass that
+    writes them -- in two different kernels, and the two must agree bit for bit: with exact-size lists a pair that is
+    counted but not filled is an unwritten slot.  (Round 2: the compiler had fused the test's multiplies and adds into
+    FMAs in one kernel only; one disagreement per ~2e8 tests.  so_common.hpp now pins the rounding.)  ~4e8 borderline-rich
+    tests: random anisotropic conics, opacities down to the 1/255 threshold, centres on a 1080p image."""
+    from splat_one_amd.ops import isect_tiles, rec_pack_unpack_roundtrip
+    monkeypatch.setenv("SPLAT_ONE_AMD_CHECK_LISTS", "1")       # isect_tiles raises if any list slot stays unwritten
+    W, H, ts = 1920, 1080, 16
+    tw, th = W // ts, (H + ts - 1) // ts
+    N = 2_000_000
+    g = torch.Generator(device=dev).manual_seed(99)
+    n_pairs = 0
+    for rnd in range(12):
+        means2d = torch.rand(1, N, 2, generator=g, device=dev) * torch.tensor([W, H], device=dev)
+        s1 = torch.rand(1, N, generator=g, device=dev) * 12 + 0.6
+        s2 = s1 * (torch.rand(1, N, generator=g, device=dev) * 0.9 + 0.1)
+        th_ = torch.rand(1, N, generator=g, device=dev) * math.pi
+        c, s = torch.cos(th_), torch.sin(th_)
+        i1, i2 = 1.0 / (s1 * s1), 1.0 / (s2 * s2)
+        conics = torch.stack([c * c * i1 + s * s * i2, c * s * (i1 - i2), s * s * i1 + c * c * i2], -1).contiguous()
+        radii = torch.ceil(3.0 * s1).to(torch.int32)
+        opac = (torch.rand(1, N, generator=g, device=dev) ** 3) * 0.99 + 0.004
+        depths = torch.rand(1, N, generator=g, device=dev) + 1.0
+        tpg, ids, flat = isect_tiles(means2d, radii, depths, ts, tw, th, conics=conics, opacities=opac)
+        _, ids0, _ = isect_tiles(means2d, radii, depths, ts, tw, th)
+        assert 0.2 * ids0.numel() < ids.numel() < ids0.numel()
+        n_pairs += ids0.numel()
+    assert n_pairs > 3e8
+    assert rec_pack_unpack_roundtrip(dev)

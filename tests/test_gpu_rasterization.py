@@ -34,7 +34,8 @@ def _compare(splats, c2w, Ks, W, H, X=3, **kw):
     w_rgb = torch.rand(C, H, W, X, generator=g)
     w_a = torch.rand(C, H, W, 1, generator=g)
     dev = torch.device("cuda:0")
-    rc_h, ra_h, g_h, m_h = _run(rasterization, dev, splats, viewmats, Ks, W, H, w_rgb, w_a, packed=False, **kw)
+    # tile_cull=False: gsplat's lists entry for entry (the counters below); test_tile_cull_is_exact covers the default
+    rc_h, ra_h, g_h, m_h = _run(rasterization, dev, splats, viewmats, Ks, W, H, w_rgb, w_a, packed=False, tile_cull=False, **kw)
     rc_o, ra_o, g_o, m_o = _run(O.rasterization, "cpu", splats, viewmats, Ks, W, H, w_rgb, w_a,
                                 raster_fn=CO.raster_fn(), **kw)
     l1 = (rc_h - rc_o).abs().mean().item()
@@ -126,6 +127,29 @@ def test_spherical_seam(dev, packed):
     assert float((a[:, 0] - a[:, W - 1]).abs().max()) < 0.2                 # ... and the image does not tear between them
     assert float((torch.roll(outs[0][0], k, dims=2) - outs[1][0]).abs().max()) < 2e-5
     assert float((torch.roll(outs[0][1], k, dims=2) - outs[1][1]).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("regime,kw", [("mcmc", {}), ("ref", {"rasterize_mode": "antialiased"}), ("mcmc", {"packed": True})])
+def test_tile_cull_is_exact(dev, regime, kw):
+    """`rasterization(tile_cull=True)` (this build's default) against `tile_cull=False` (gsplat's lists): the (Gaussian, tile)
+    pairs it leaves out reach no pixel with alpha >= 1/255, so the image is bit-identical, the gradients equal up to the
+    order of the float atomics, and only the lists are shorter."""
+    from splat_one_amd import rasterization
+    W, H = 320, 240
+    splats, c2w, Ks = make_scene(20_000, W, H, regime=regime, n_views=2)
+    g = torch.Generator().manual_seed(4)
+    splats["scales"] = splats["scales"] + torch.randn(20_000, 3, generator=g) * 0.4
+    viewmats = torch.linalg.inv(c2w)
+    w_rgb, w_a = torch.rand(2, H, W, 3, generator=g), torch.rand(2, H, W, 1, generator=g)
+    kw = {"packed": False, **kw}
+    out = {c: _run(rasterization, dev, splats, viewmats, Ks, W, H, w_rgb, w_a, sh_degree=3, tile_cull=c, **kw) for c in (False, True)}
+    (rc0, ra0, g0, m0), (rc1, ra1, g1, m1) = out[False], out[True]
+    assert torch.equal(rc0, rc1) and torch.equal(ra0, ra1)
+    n0, n1 = m0["flatten_ids"].numel(), m1["flatten_ids"].numel()
+    assert 0.2 * n0 < n1 < 0.95 * n0, (n0, n1)
+    assert torch.equal(m0["radii"], m1["radii"])
+    for k in g0:
+        assert (g0[k] - g1[k]).norm().item() <= 1e-5 * g0[k].norm().item() + 1e-12, k
 
 
 def test_antialiased_multiview_sh_ramp(dev):

@@ -186,7 +186,9 @@ def test_gaussian_sharded_dp_two_ranks_one_gpu(dev, tmp_path, mixed):
         for i in range(2):
             a = out[i]["splats"][k]
             assert a.shape == ref[i::2].shape, (k, a.shape)
-            assert ((a - ref[i::2]).norm() / ref[i::2].norm()).item() < 2e-4, (k, i)
+            # four Adam steps: early updates are ~lr * sign(g), so a gradient entry near zero that rounds to the other sign
+            # in the other summation order moves its parameter by 2 lr (measured 1.2e-4 .. 2.1e-4 over library builds)
+            assert ((a - ref[i::2]).norm() / ref[i::2].norm()).item() < 3e-4, (k, i)
         # full_splats: rank-major concatenation, identical on both ranks
         assert torch.equal(out[0]["full"][k], out[1]["full"][k])
         assert torch.equal(out[0]["full"][k], torch.cat([out[0]["splats"][k], out[1]["splats"][k]]))

@@ -6,7 +6,7 @@ from splat_one_amd.scene import pinhole_K, front_camera
 from splat_one_amd.trainer import Config, Runner
 dev = torch.device("cuda:0")
 N, W, H = 100000, 1920, 1080
-cfg = Config(init_num_pts=N, init_scale=0.1, init_opa=0.5, shN_init_std=0.1, sh_degree_interval=1, fused=True)
+cfg = Config(init_num_pts=N, init_scale=0.1, init_opa=0.5, shN_init_std=0.1, sh_degree_interval=1, fused=("--operator" not in sys.argv))
 r = Runner(0, 0, 1, cfg, scene_scale=1 / 1.1)
 c2w = front_camera()[None].to(dev); Ks = pinhole_K(W, H)[None].to(dev)
 pixels = torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(1)).to(dev)
@@ -26,4 +26,4 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(100):
     r.train_step(c2w, Ks, pixels)
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(45 if "--operator" in sys.argv else 14)
