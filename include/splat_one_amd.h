@@ -103,9 +103,11 @@ int so_projection_bwd(int C, int N, const float *means, const float *covars6, co
  * gsplat_trainer.py:133, :487): one row per (camera, Gaussian) pair with a positive radius, in ascending flattened
  * index c*N + n (camera-major; the reference builds coalesced sparse gradients from gaussian_ids, :705-717).  No [C,N]
  * array exists at any point: so_projection_packed is called TWICE --
- *   counting pass (camera_ids == NULL): block_counts[so_projection_packed_blocks(C,N)] i32, block_offsets[same] i64 and
- *     *total_dev (i64, device) = nnz are written (projection + wave-ballot counts + one-workgroup scan);
- *   writing pass (camera_ids != NULL, after the caller sized its nnz-row outputs): the projection is recomputed and row
+ *   counting pass (camera_ids == NULL): block_counts[B] i32, vis_masks[16 B] u64, block_offsets[B] i64 with
+ *     B = so_projection_packed_blocks(C,N), and *total_dev (i64, device) = nnz are written (projection + wave-ballot counts
+ *     + one-workgroup scan); vis_masks holds one bit per (camera, Gaussian) pair: the rows;
+ *   writing pass (camera_ids != NULL, after the caller sized its nnz-row outputs; same vis_masks / block_offsets): the
+ *     projection is recomputed for the values, WHICH pairs are rows is read from vis_masks (decided once), and row
  *     block_offsets[b] + rank is written: camera_ids / gaussian_ids [nnz] i64, radii[nnz] i32, means2d[nnz,2],
  *     depths[nnz], conics[nnz,3], compensations[nnz] (nullable).
  * so_projection_bwd_packed: one lane per packed row; v_means / v_quats / v_scales (or v_covars6) and the nullable
@@ -113,7 +115,7 @@ int so_projection_bwd(int C, int N, const float *means, const float *covars6, co
 int64_t so_projection_packed_blocks(int C, int N);
 int so_projection_packed(int C, int N, const float *means, const float *covars6, const float *quats, const float *scales,
                          const float *viewmats, const float *Ks, int width, int height, float eps2d, float near_plane,
-                         float far_plane, float radius_clip, int camera_model, int32_t *block_counts,
+                         float far_plane, float radius_clip, int camera_model, int32_t *block_counts, uint64_t *vis_masks,
                          int64_t *block_offsets, int64_t *total_dev, int64_t *camera_ids, int64_t *gaussian_ids,
                          int32_t *radii, float *means2d, float *depths, float *conics, float *compensations, void *stream);
 int so_projection_bwd_packed(int C, int N, int64_t nnz, const float *means, const float *covars6, const float *quats,

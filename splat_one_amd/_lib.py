@@ -75,7 +75,7 @@ class AttrShadow(ctypes.Structure):
 _SIGS = {
     "so_projection_fwd": [c_int, c_int] + [c_ptr] * 6 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int] + [c_ptr] * 6,
     "so_projection_bwd": [c_int, c_int] + [c_ptr] * 6 + [c_int, c_int, c_f32, c_int] + [c_ptr] * 11,
-    "so_projection_packed": [c_int, c_int] + [c_ptr] * 6 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int] + [c_ptr] * 11,
+    "so_projection_packed": [c_int, c_int] + [c_ptr] * 6 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int] + [c_ptr] * 12,
     "so_projection_bwd_packed": [c_int, c_int, c_i64] + [c_ptr] * 6 + [c_int, c_int, c_f32, c_int] + [c_ptr] * 12,
     "so_sh_fwd": [c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr],
     "so_sh_bwd": [c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],

@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256)
 k_projection_packed(int C, int N, const float *__restrict__ means, const float *__restrict__ covars6,
                     const float *__restrict__ quats, const float *__restrict__ scales, const float *__restrict__ viewmats,
                     const float *__restrict__ Ks, int W, int H, float eps2d, float near_plane, float far_plane,
-                    float radius_clip, int model, int32_t *__restrict__ block_counts,
+                    float radius_clip, int model, int32_t *__restrict__ block_counts, uint64_t *__restrict__ vis_masks,
                     const int64_t *__restrict__ block_offsets, int64_t *__restrict__ camera_ids,
                     int64_t *__restrict__ gaussian_ids, int32_t *__restrict__ radii, float *__restrict__ means2d,
                     float *__restrict__ depths, float *__restrict__ conics, float *__restrict__ comps) {
@@ -183,6 +183,7 @@ k_projection_packed(int C, int N, const float *__restrict__ means, const float *
   const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
   ProjOut<float> o[kPackItems];
   int cc[kPackItems], nn[kPackItems], rank[kPackItems];
+  bool vis[kPackItems];
 #pragma unroll
   for (int it = 0; it < kPackItems; ++it) {
     const int64_t idx = (int64_t)blockIdx.x * kPackChunk + it * 256 + threadIdx.x;
@@ -191,7 +192,17 @@ k_projection_packed(int C, int N, const float *__restrict__ means, const float *
     if (idx < total)
       project_pair<HAS_COV>(idx, N, means, covars6, quats, scales, viewmats, Ks, W, H, eps2d, near_plane, far_plane,
                             radius_clip, model, cc[it], nn[it], o[it]);
-    const unsigned long long m = __ballot(o[it].radius > 0);
+    // WHICH pairs are rows is decided once, by the counting pass (it sized the outputs): the two instantiations of this
+    // kernel are optimised differently and need not round a borderline radius / depth test alike
+    unsigned long long m;
+    const int64_t word = ((int64_t)blockIdx.x * kPackItems + it) * 4 + wv;
+    if (WRITE) {
+      m = vis_masks[word];
+    } else {
+      m = __ballot(o[it].radius > 0);
+      if (lane == 0) vis_masks[word] = m;
+    }
+    vis[it] = (m >> lane) & 1ull;
     rank[it] = __popcll(m & lt);
     if (lane == 0) s_cnt[it * 4 + wv] = __popcll(m);
   }
@@ -208,13 +219,13 @@ k_projection_packed(int C, int N, const float *__restrict__ means, const float *
   const int64_t base = block_offsets[blockIdx.x];
 #pragma unroll
   for (int it = 0; it < kPackItems; ++it) {
-    if (o[it].radius <= 0) continue;
+    if (!vis[it]) continue;
     int32_t before = 0;
     for (int e = 0; e < it * 4 + wv; ++e) before += s_cnt[e];
     const int64_t r = base + before + rank[it];
     camera_ids[r] = cc[it];
     gaussian_ids[r] = nn[it];
-    radii[r] = o[it].radius;
+    radii[r] = o[it].radius > 0 ? o[it].radius : 0;     // (a row this pass would not have kept: radius 0, skipped downstream)
     *reinterpret_cast<float2 *>(means2d + 2 * r) = make_float2(o[it].m2d[0], o[it].m2d[1]);
     depths[r] = o[it].depth;
     conics[3 * r] = o[it].conic[0]; conics[3 * r + 1] = o[it].conic[1]; conics[3 * r + 2] = o[it].conic[2];
@@ -380,7 +391,7 @@ extern "C" int64_t so_projection_packed_blocks(int C, int N) {
 extern "C" int so_projection_packed(int C, int N, const float *means, const float *covars6, const float *quats,
                                     const float *scales, const float *viewmats, const float *Ks, int width, int height,
                                     float eps2d, float near_plane, float far_plane, float radius_clip, int camera_model,
-                                    int32_t *block_counts, int64_t *block_offsets, int64_t *total_dev, int64_t *camera_ids,
+                                    int32_t *block_counts, uint64_t *vis_masks, int64_t *block_offsets, int64_t *total_dev, int64_t *camera_ids,
                                     int64_t *gaussian_ids, int32_t *radii, float *means2d, float *depths, float *conics,
                                     float *compensations, void *stream) {
   SO_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, "so_projection_packed: bad sizes C=%d N=%d %dx%d", C, N, width, height);
@@ -395,18 +406,18 @@ extern "C" int so_projection_packed(int C, int N, const float *means, const floa
   hipStream_t st = so::as_stream(stream);
   const bool write = camera_ids != nullptr;
   if (!write) {      // pass 0 + scan
-    SO_REQUIRE(block_counts && block_offsets && total_dev, "so_projection_packed: counting pass needs block_counts, block_offsets, total_dev");
+    SO_REQUIRE(block_counts && vis_masks && block_offsets && total_dev, "so_projection_packed: counting pass needs block_counts, vis_masks, block_offsets, total_dev");
     auto kern = covars6 ? so::k_projection_packed<true, false> : so::k_projection_packed<false, false>;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), 0, st, C, N, means, covars6, quats, scales, viewmats, Ks, width,
-                       height, eps2d, near_plane, far_plane, radius_clip, camera_model, block_counts, nullptr, nullptr, nullptr,
-                       nullptr, nullptr, nullptr, nullptr, nullptr);
+                       height, eps2d, near_plane, far_plane, radius_clip, camera_model, block_counts, vis_masks, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(so::k_scan_counts, dim3(1), dim3(1024), 0, st, nblk, block_counts, block_offsets, total_dev);
     return so::check_launch("so_projection_packed (count)");
   }
-  SO_REQUIRE(block_offsets && gaussian_ids && radii && means2d && depths && conics, "so_projection_packed: writing pass: null pointer");
+  SO_REQUIRE(vis_masks && block_offsets && gaussian_ids && radii && means2d && depths && conics, "so_projection_packed: writing pass: null pointer");
   auto kern = covars6 ? so::k_projection_packed<true, true> : so::k_projection_packed<false, true>;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), 0, st, C, N, means, covars6, quats, scales, viewmats, Ks, width,
-                     height, eps2d, near_plane, far_plane, radius_clip, camera_model, nullptr, block_offsets, camera_ids,
+                     height, eps2d, near_plane, far_plane, radius_clip, camera_model, nullptr, vis_masks, block_offsets, camera_ids,
                      gaussian_ids, radii, means2d, depths, conics, compensations);
   return so::check_launch("so_projection_packed (write)");
 }

@@ -162,10 +162,11 @@ class _PackedProjection(torch.autograd.Function):
         nblk = int(_lib.load().so_projection_packed_blocks(C, N))
         counts = torch.empty(max(nblk, 1), dtype=torch.int32, device=dev)
         offsets = torch.empty(max(nblk, 1), dtype=torch.int64, device=dev)
+        masks = torch.empty(16 * max(nblk, 1), dtype=torch.int64, device=dev)      # one bit per (camera, Gaussian) pair
         total = torch.zeros(1, dtype=torch.int64, device=dev)
         common = (C, N, ptr(means), ptr(covars6), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks), width, height, eps2d,
                   near_plane, far_plane, radius_clip, camera_model)
-        call("so_projection_packed", *common, ptr(counts), ptr(offsets), ptr(total), 0, 0, 0, 0, 0, 0, 0, stream())
+        call("so_projection_packed", *common, ptr(counts), ptr(masks), ptr(offsets), ptr(total), 0, 0, 0, 0, 0, 0, 0, stream())
         nnz = int(total.item())                                   # the one host read: sizes of the returned tensors
         camera_ids = torch.empty(nnz, dtype=torch.int64, device=dev)
         gaussian_ids = torch.empty(nnz, dtype=torch.int64, device=dev)
@@ -175,7 +176,7 @@ class _PackedProjection(torch.autograd.Function):
         conics_p = torch.empty(nnz, 3, dtype=torch.float32, device=dev)
         comps_p = torch.empty(nnz, dtype=torch.float32, device=dev) if calc_compensations else None
         if nnz:
-            call("so_projection_packed", *common, 0, ptr(offsets), 0, ptr(camera_ids), ptr(gaussian_ids), ptr(radii_p),
+            call("so_projection_packed", *common, 0, ptr(masks), ptr(offsets), 0, ptr(camera_ids), ptr(gaussian_ids), ptr(radii_p),
                  ptr(means2d_p), ptr(depths_p), ptr(conics_p), ptr(comps_p), stream())
         ctx.save_for_backward(means, covars6, quats, scales, viewmats, Ks, camera_ids, gaussian_ids)
         ctx.cfg = (width, height, eps2d, camera_model, sparse_grad, comps_p is not None)

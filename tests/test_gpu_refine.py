@@ -291,6 +291,10 @@ def test_c4_refinement_at_size(dev):
     strat = DefaultStrategy()
     r = Runner(0, 0, 1, Config(init_num_pts=N, init_scale=0.1, init_opa=0.5, shN_init_std=0.1, strategy=strat), scene_scale=1.0 / 1.1)
     state = strat.initialize_state(scene_scale=r.scene_scale)
+    with torch.no_grad():      # sizes on both sides of grow_scale3d / prune_scale3d and some transparent Gaussians: all three decisions occur
+        g = torch.Generator().manual_seed(7)
+        r.splats["scales"].add_((torch.randn(N, 1, generator=g) * 1.0).to(dev))
+        r.splats["opacities"][(torch.rand(N, generator=g) < 0.02).to(dev)] = -6.0
     eng = FusedEngine(r.splats, r.optimizers, W, H, 1, sh_degree=3, use_graph=False, strategy_state=state, device_refine=True,
                       capacity=2_500_000)
     ring = ring_cameras(8)
@@ -315,6 +319,7 @@ def test_c4_refinement_at_size(dev):
     orep, errs = _compare(out, n_new, [rep[k] for k in ("n_dupli", "n_split", "n_prune", "n_new", "overflow", "n_old")],
                           S[0], S[1], S[2], g2, cn, step, r.scene_scale, seed, grow_grad2d=strat.grow_grad2d)
     assert orep["n_dupli"] + orep["n_split"] > 0.15 * N and orep["n_new"] > 1.1 * N
+    assert min(orep["n_dupli"], orep["n_split"], orep["n_prune"]) > 0.01 * N, orep
     record("c4_1m_1440p_refinement", N=N, width=W, height=H, **orep, child_max_abs_err=errs,
            rows_bit_exact="all copied rows and all Adam moments", step=step)
     # and the model trains on: one more iteration on the grown set
