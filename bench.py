@@ -98,7 +98,6 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--regime", default="mcmc", choices=["mcmc", "ref"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--raster-impl", type=int, default=0, help="0: LDS-tiled rasteriser, 1: wave-per-quadrant")
     ap.add_argument("--operator-path", action="store_true",
                     help="time the operator-level autograd path instead of the fused engine")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel times to stderr")
@@ -149,7 +148,6 @@ def main():
             from splat_one_amd.strategy import DefaultStrategy
             cfg.strategy = DefaultStrategy(refine_start_iter=0, refine_every=args.densify, reset_every=3000, verbose=False)
         r = Runner(local_rank, rank, world, cfg, scene_scale=1.0 / 1.1)   # effective scene_scale 1.0
-        r.raster_impl = args.raster_impl
         if r.sharded:      # the step takes the cameras of every rank (rank r renders camera r of the step's group)
             views = [(ring[v * world:(v + 1) * world].contiguous().to(dev), K1.repeat(world, 1, 1).to(dev), targets[v]) for v in range(NV)]
         else:

@@ -248,26 +248,6 @@ int so_rasterize_bwd_packed(int C, int N, int width, int height, int tile_size, 
                             const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
                             float *vrec, int absgrad, void *stream);
 
-/* Wave-per-quadrant variants (tile 16, D = 3, packed records): every 8x8 pixel quadrant is an
- * independent 64-lane workgroup, list entries are staged in registers and broadcast with
- * v_readlane -- no LDS, no barriers.  Same results as the *_packed entry points. */
-int so_rasterize_fwd_wave(int C, int N, int width, int height, const float *rec, const float *backgrounds,
-                          const int32_t *isect_offsets, const int32_t *flatten_ids, const int32_t *n_isects_dev,
-                          int64_t n_isects_host, float *render_colors, float *render_alphas, int32_t *last_ids,
-                          void *stream);
-int so_rasterize_bwd_wave(int C, int N, int width, int height, const float *rec, const float *backgrounds,
-                          const int32_t *isect_offsets, const int32_t *flatten_ids, const int32_t *n_isects_dev,
-                          int64_t n_isects_host, const float *render_alphas, const int32_t *last_ids,
-                          const float *v_render_colors, const float *v_render_alphas, float *vrec, int absgrad,
-                          void *stream);
-
-/* diagnostic build of so_rasterize_bwd_wave with per-wave s_memtime stamps (profiling only) */
-int so_debug_rasterize_bwd_wave_stamps(int C, int N, int width, int height, const float *rec,
-                                       const int32_t *isect_offsets, const int32_t *flatten_ids,
-                                       const int32_t *n_isects_dev, const float *render_alphas,
-                                       const int32_t *last_ids, const float *v_render_colors,
-                                       const float *v_render_alphas, float *vrec, unsigned long long *stamps,
-                                       int variant, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimiser.  Replaces the six torch.optim.Adam steps + zero_grad of gsplat_trainer.py:726-731
@@ -448,7 +428,7 @@ typedef struct so_step_desc {
   float *grad2d, *count;
   int64_t isect_capacity;
   int32_t abi_size, C, N, K, width, height, tile_size, sh_degree, camera_model, antialiased, absgrad;
-  int32_t raster_impl; /* 0: LDS-tiled quadrant kernels, 1: wave-per-quadrant kernels (tile 16 only) */
+  int32_t raster_impl; /* must be 0 (the wave-per-quadrant kernels of round 1 moved to tools/experiments/) */
   float eps2d, near_plane, far_plane, radius_clip, ssim_lambda, opacity_reg, scale_reg;
   /* Inputs staged by so_step_inputs (both optional, zero = off):
    *   pixels_indirect  device slot holding the address of this iteration's target image [C,H,W,3]; when set it
@@ -512,8 +492,9 @@ int so_step_inputs(int C, const float *camtoworlds, const float *Ks_src, float *
 int so_render_forward(const so_step_desc *desc, void *stream);
 
 /* Per-stage HIP-event timing of so_train_step_fwd_bwd / so_adam_step_dev on their launch stream
- * (measurement only, not thread-safe; events cannot be recorded inside a hipGraph replay, so
- * profile un-captured launches).  so_profile_read synchronises the device, returns the summed
+ * (measurement only; the switch and the event log belong to the CALLING THREAD, so another thread's launches are
+ * neither timed nor affected; events cannot be recorded inside a hipGraph replay, so profile un-captured launches).
+ * so_profile_read (same thread) synchronises the device, returns the summed
  * milliseconds and call counts of the so_profile_num_stages() stages and clears the log. */
 int so_profile_enable(int enabled);
 int so_profile_num_stages(void);

@@ -99,9 +99,6 @@ _SIGS = {
     "so_rec_pack": [c_i64] + [c_ptr] * 7,
     "so_rec_unpack_grads": [c_i64] + [c_ptr] * 7,
     "so_rasterize_fwd_packed": [c_int] * 5 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 4,
-    "so_rasterize_fwd_wave": [c_int] * 4 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 4,
-    "so_rasterize_bwd_wave": [c_int] * 4 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 5 + [c_int, c_ptr],
-    "so_debug_rasterize_bwd_wave_stamps": [c_int] * 4 + [c_ptr] * 10 + [c_int, c_ptr],
     "so_rasterize_bwd_packed": [c_int] * 5 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 5 + [c_int, c_ptr],
     "so_train_step_fwd_bwd": [ctypes.POINTER(StepDesc), c_ptr],
     "so_render_forward": [ctypes.POINTER(StepDesc), c_ptr],

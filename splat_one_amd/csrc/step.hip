@@ -17,8 +17,9 @@ static const char *kStageNames[] = {"so_preprocess_fwd", "so_isect_scan", "so_is
                                     "so_ssim_l1_fwd", "so_ssim_l1_bwd", "so_rasterize_bwd", "so_preprocess_bwd",
                                     "so_adam_step_dev"};
 constexpr int kNumStages = 9;
-static bool g_prof_on = false;
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events[kNumStages];
+// per calling thread: the trainer thread's timers neither see nor are switched by a viewer thread's renders
+static thread_local bool g_prof_on = false;
+static thread_local std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events[kNumStages];
 
 struct StageTimer {
   int stage;
@@ -197,7 +198,17 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
   // binned lists: every tile owns bin_capacity slots of key_buf / flatten_ids; the forward kernel's returning atomics
   // place the keys, so the scan and the scatter pass do not exist (tile_counts doubles as the per-tile list length)
   const int64_t bins = d->bin_capacity;
-  SO_REQUIRE(bins >= 0 && (bins == 0 || d->raster_impl != 1), "so_train_step_fwd_bwd: bin_capacity needs raster_impl 0");
+  SO_REQUIRE(d->raster_impl == 0, "so_train_step_fwd_bwd: raster_impl must be 0");
+  SO_REQUIRE(bins >= 0, "so_train_step_fwd_bwd: bad bin_capacity");
+  // periodic views: spherical cameras, when the tile grid lines up across the seam (so_preprocess_fwd derives the same
+  // from camera_model; the fill pass and the rasteriser take it as flags in their tile_size argument)
+  int wrap_flags = 0;
+  if (W % ts == 0) {
+    if (!(d->camera_model & SO_CAM_PER_VIEW)) wrap_flags = d->camera_model == SO_CAM_SPHERICAL ? SO_TILE_WRAP_ALL : 0;
+    else
+      for (int c = 0; c < C && c < 16; ++c)
+        if (((d->camera_model >> (2 * c)) & 3) == SO_CAM_SPHERICAL) wrap_flags |= SO_TILE_WRAP_CAM(c);
+  }
   SO_REQUIRE(bins == 0 || M * bins < ((int64_t)1 << 31), "so_train_step_fwd_bwd: C*tiles*bin_capacity does not fit 31 bits");
   int32_t *slots = bins ? nullptr : d->tile_slots;
   uint64_t *bin_keys = bins ? d->key_buf : nullptr;
@@ -223,27 +234,13 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
     SO_STAGE(2, so_isect_sort_bins(C, tile_w, tile_h, tile_counts, bins, d->key_buf, d->flatten_ids, cursor, stream));
   } else {
     SO_STAGE(1, so_isect_scan(C, tile_w, tile_h, tile_counts, slots ? cursor : nullptr, d->isect_offsets, n_isects, stream));
-    SO_STAGE(2, so_isect_fill(C, N, d->means2d, d->radii, d->depths, ts, tile_w, tile_h, d->isect_offsets, n_isects, cursor,
+    SO_STAGE(2, so_isect_fill(C, N, d->means2d, d->radii, d->depths, ts | wrap_flags, tile_w, tile_h, d->isect_offsets, n_isects, cursor,
                          d->isect_capacity, d->key_buf, d->flatten_ids, nullptr, overflow, slots, d->tile_cull ? d->rec : nullptr, stream));
   }
   // list layout handed to the rasteriser: compact (offsets, device count, capacity) or binned (counts, NULL, -slots)
   const int32_t *list_off = bins ? tile_counts : d->isect_offsets;
   const int32_t *list_n = bins ? nullptr : n_isects;
   const int64_t list_cap = bins ? -bins : d->isect_capacity;
-  // periodic views: spherical cameras, when the tile grid lines up across the seam
-  int wrap_flags = 0;
-  if (W % ts == 0) {
-    if (!(d->camera_model & SO_CAM_PER_VIEW)) wrap_flags = d->camera_model == SO_CAM_SPHERICAL ? SO_TILE_WRAP_ALL : 0;
-    else
-      for (int c = 0; c < C && c < 16; ++c)
-        if (((d->camera_model >> (2 * c)) & 3) == SO_CAM_SPHERICAL) wrap_flags |= SO_TILE_WRAP_CAM(c);
-  }
-  SO_REQUIRE(!(wrap_flags && (d->raster_impl == 1 || !bins)), "so_train_step_fwd_bwd: spherical views need the binned lists and raster_impl 0");
-  const bool wave_impl = d->raster_impl == 1 && ts == 16;
-  if (wave_impl)
-    SO_STAGE(3, so_rasterize_fwd_wave(C, N, W, H, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects, d->isect_capacity,
-                                      d->render_colors, d->render_alphas, d->last_ids, stream));
-  else
     SO_STAGE(3, so_rasterize_fwd_packed(C, N, W, H, ts | wrap_flags, d->rec, d->backgrounds, list_off, d->flatten_ids, list_n,
                                         list_cap, d->render_colors, d->render_alphas, d->last_ids, stream));
   if (forward_only) return SO_OK;
@@ -255,11 +252,6 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
                         d->ssim_lambda, stream));
   // gradients of the intermediates accumulate in the 64-byte records vrec[C*N] (zeroed by the
   // forward preprocess kernel): one atomic request per (tile quadrant, Gaussian)
-  if (wave_impl)
-    SO_STAGE(6, so_rasterize_bwd_wave(C, N, W, H, d->rec, d->backgrounds, d->isect_offsets, d->flatten_ids, n_isects, d->isect_capacity,
-                                      d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
-                                      d->absgrad, stream));
-  else
     SO_STAGE(6, so_rasterize_bwd_packed(C, N, W, H, ts | wrap_flags, d->rec, d->backgrounds, list_off, d->flatten_ids, list_n,
                                         list_cap, d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
                                         d->absgrad, stream));

@@ -42,7 +42,7 @@ class FusedEngine:
                  antialiased: bool = False, absgrad: bool = False, ssim_lambda: float = 0.2,
                  opacity_reg: float = 0.0, scale_reg: float = 0.0, tile_size: int = 16,
                  strategy_state: Optional[dict] = None, lr_gamma_means: float = 1.0,
-                 isect_capacity: Optional[int] = None, use_graph: bool = True, raster_impl: int = 0,
+                 isect_capacity: Optional[int] = None, use_graph: bool = True,
                  attr_dtype: str = "f32", tile_cull: bool = True, binned: bool = True,
                  bin_capacity: Optional[int] = None, fuse_adam: bool = True, device_refine: bool = False,
                  capacity: Optional[int] = None, lean_views: bool = True, flat_multiple: int = 0):
@@ -75,7 +75,7 @@ class FusedEngine:
         # step(): Adam runs inside the backward kernel (so_step_desc.fuse_adam) -- the gradients of a single-GPU step
         # never reach HBM.  fwd_bwd() + optimize() (data-parallel steps, gradient inspection) keep the two kernels.
         self.fuse_adam = bool(fuse_adam) and attr_dtype == "f32"
-        self.binned = bool(binned) and raster_impl != 1
+        self.binned = bool(binned)
         self._bin_hint = bin_capacity
         # record-only views: the per-view arrays (radii, means2d, depths, conics, opacities, colors) are not written by
         # the forward kernel -- `ws[...]` of those names are strided VIEWS of the 64-byte records, which hold the same
@@ -86,7 +86,7 @@ class FusedEngine:
         self.cfg = dict(sh_degree=sh_degree, camera_model=camera_model, near_plane=near_plane, far_plane=far_plane,
                         radius_clip=radius_clip, eps2d=eps2d, antialiased=antialiased, absgrad=absgrad,
                         ssim_lambda=ssim_lambda, opacity_reg=opacity_reg, scale_reg=scale_reg, tile_size=tile_size,
-                        raster_impl=raster_impl)
+                        raster_impl=0)
         self.strategy_state = strategy_state
         self.lr_gamma_means = lr_gamma_means
         self.use_graph = use_graph

@@ -618,7 +618,7 @@ class Runner:
                 strategy_state=(self.strategy_state if isinstance(s, DefaultStrategy) else None),
                 lr_gamma_means=self.lr_gamma,
                 isect_capacity=cfg.isect_capacity, use_graph=True,
-                raster_impl=getattr(self, "raster_impl", 0), attr_dtype=cfg.attr_dtype, tile_cull=cfg.tile_cull,
+                attr_dtype=cfg.attr_dtype, tile_cull=cfg.tile_cull,
                 binned=(cfg.binned and self.world_size == 1),   # replicas keep the compact layout: one global
                 bin_capacity=cfg.bin_capacity,                  # slack instead of a per-tile one, and no per-rank growth
                 fuse_adam=cfg.fuse_adam, device_refine=dev_refine, capacity=cfg.max_gaussians,

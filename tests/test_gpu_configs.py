@@ -271,7 +271,8 @@ def test_camera_model_lists_are_validated():
         camera_model_code(["pinhole", "cylindrical"], 2)
 
 
-def test_spherical_views_fused_engine(dev):
+@pytest.mark.parametrize("binned", [True, False])
+def test_spherical_views_fused_engine(dev, binned):
     """The reference's default camera model (gsplat_trainer.py:89): 360-degree equirectangular views, here one from
     inside the point cloud (Gaussians all around, behind the camera included; depth = range) and one perspective view in
     the same batch (per-view camera models).  Model defined by this build (csrc/splat_math.hpp) -- checked against the
@@ -288,11 +289,12 @@ def test_spherical_views_fused_engine(dev):
     inside[:3, 3] = torch.tensor([0.3, -0.2, 0.1])
     c2w = torch.stack([inside, front_camera()]).to(dev)
     pixels = torch.cat([torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(v)) for v in range(2)]).to(dev)
-    eng = FusedEngine(r.splats, r.optimizers, W, H, 2, sh_degree=3, camera_model=models, use_graph=False)
+    # binned: the single-GPU list layout; compact (slotted histogram + scatter): the layout of data-parallel replicas
+    eng = FusedEngine(r.splats, r.optimizers, W, H, 2, sh_degree=3, camera_model=models, use_graph=False, binned=binned)
     eng.set_views(c2w, Ks, pixels)
     eng.fwd_bwd()
     assert int((eng.ws["radii"][0] > 0).sum()) > 0.9 * N          # the panorama sees (nearly) everything
     x, rad = eng.ws["means2d"][0, :, 0], eng.ws["radii"][0].float()
     assert int((((x - rad < 0) | (x + rad > W)) & (rad > 0)).sum()) > 50      # footprints that straddle the +-pi seam (periodic image)
-    _three_way("spherical_plus_pinhole_20k", r.splats, c2w, Ks, W, H, pixels, eng.ws["depths"], eng.ws["radii"],
+    _three_way("spherical_plus_pinhole_20k" + ("" if binned else "_compact_lists"), r.splats, c2w, Ks, W, H, pixels, eng.ws["depths"], eng.ws["radii"],
                eng.ws["render_colors"], _engine_grads(r), eng.loss()[0].item(), models=models, with_f32=True, with_plain=True)

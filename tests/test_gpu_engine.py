@@ -30,17 +30,16 @@ def _make(dev, N, W, H, regime, C=1, anisotropic=True, **cfgkw):
     return r, c2w, Ks, pixels
 
 
-@pytest.mark.parametrize("raster_impl", [0, 1])
 @pytest.mark.parametrize("regime,C,kw", [("ref", 1, {}), ("mcmc", 2, {"opacity_reg": 0.01, "scale_reg": 0.01}),
                                          ("ref", 1, {"antialiased": True})])
-def test_engine_gradients_match_oracle_and_operator_path(dev, regime, C, kw, raster_impl):
+def test_engine_gradients_match_oracle_and_operator_path(dev, regime, C, kw):
     from splat_one_amd.engine import FusedEngine
     N, W, H = 6000, 160, 96
     r, c2w, Ks, pixels = _make(dev, N, W, H, regime, C, **kw)
     r.step = 5                                   # SH degree 3
     st = r.cfg.strategy.initialize_state(1.0)
     eng = FusedEngine(r.splats, r.optimizers, W, H, C, sh_degree=3, strategy_state=st, use_graph=False,
-                      raster_impl=raster_impl, antialiased=kw.get("antialiased", False), opacity_reg=kw.get("opacity_reg", 0.0),
+                      antialiased=kw.get("antialiased", False), opacity_reg=kw.get("opacity_reg", 0.0),
                       scale_reg=kw.get("scale_reg", 0.0))
     eng.set_views(c2w, Ks, pixels)
     eng.fwd_bwd()
