@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--densify", type=int, default=0, metavar="EVERY",
                     help="BASELINE.json configs[3]: DefaultStrategy duplicates / splits / prunes every EVERY iterations "
                          "(reference default 100) inside the timed region; 0 = the reference's first 500 iterations (off)")
+    ap.add_argument("--cloud-scale", type=float, default=1.0,
+                    help="multiply the initial positions by this factor (< 1: the splats gather in the middle of the image -- an "
+                         "unevenly loaded tile grid, as real scenes have; the default workload is the uniform cube of BASELINE.md)")
     ap.add_argument("--views", type=int, default=8, help="ring cameras / target images cycled per GPU (the reference draws a new view per step)")
     ap.add_argument("--attr-dtype", default="f32", choices=["f32", "f16"],
                     help="f16: float16 attribute rows (BASELINE.json configs[4]); float32 arithmetic and masters")
@@ -148,6 +151,9 @@ def main():
             from splat_one_amd.strategy import DefaultStrategy
             cfg.strategy = DefaultStrategy(refine_start_iter=0, refine_every=args.densify, reset_every=3000, verbose=False)
         r = Runner(local_rank, rank, world, cfg, scene_scale=1.0 / 1.1)   # effective scene_scale 1.0
+        if args.cloud_scale != 1.0:
+            with torch.no_grad():
+                r.splats["means"].mul_(args.cloud_scale)
         if r.sharded:      # the step takes the cameras of every rank (rank r renders camera r of the step's group)
             views = [(ring[v * world:(v + 1) * world].contiguous().to(dev), K1.repeat(world, 1, 1).to(dev), targets[v]) for v in range(NV)]
         else:
@@ -355,7 +361,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     # the PMC traffic in profiles/ was collected on c2 with the fused engine: it says nothing about another workload
     is_c2_engine = ((N0, W, H, args.densify, world, len(views)) == (100_000, 1920, 1080, 0, 1, 8) and fused and args.attr_dtype == "f32"
-                    and args.regime == "mcmc")
+                    and args.regime == "mcmc" and args.cloud_scale == 1.0)
     if os.path.exists(tpath) and is_c2_engine:
         try:
             traffic = json.load(open(tpath)).get(dominant)
@@ -395,12 +401,13 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "path": ("sharded engine (C-ABI launches + 2 all-to-all)" if runner.sharded else
                  "fused engine (hipGraph replay)" if fused else "operator-level autograd path"),
-        "config": {"workload": f"{'c2' if (N0, W, H, args.densify) == (100_000, 1920, 1080, 0) else 'custom'}: {N0} Gaussians "
+        "config": {"workload": f"{'c2' if (N0, W, H, args.densify, args.cloud_scale) == (100_000, 1920, 1080, 0, 1.0) else 'custom'}: {N0} Gaussians "
                                f"(reference random init, '{args.regime}' preset), "
                                f"{W}x{H}, SH degree 3, 1 view per GPU per step ({len(views)} ring cameras and targets cycled), pinhole"
                                + (f", DefaultStrategy refining every {args.densify} iterations ({n_before_timed or N0} -> {N} Gaussians "
                                   f"over the timed region and the stage-timer pass)" if args.densify else "")
-                               + (", float16 attribute rows" if args.attr_dtype == "f16" else ""),
+                               + (", float16 attribute rows" if args.attr_dtype == "f16" else "")
+                               + (f", initial positions scaled by {args.cloud_scale}" if args.cloud_scale != 1.0 else ""),
                    "views_per_step": world, "views_cycled": len(views), "visible_gaussians": V, "tile_intersections": I,
                    "visible_gaussians_per_view": Vs, "tile_intersections_per_view": Is,
                    "tile_cull": bool(cfg.tile_cull and fused),   # I counts what is left after exact tile culling

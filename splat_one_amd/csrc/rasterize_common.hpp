@@ -8,12 +8,30 @@ constexpr float kAlphaMax = 0.999f;
 constexpr float kAlphaMin = 1.f / 255.f;
 constexpr float kTStop = 1e-4f;
 
-// XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2), so give each XCD a
-// contiguous run of tiles -- neighbouring tiles gather mostly the same Gaussians.  Speed only.
+// XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2).  SO_TILE_ORDER (compile time, measured in
+// tools/gpu_tileorder.sh):
+//   0  every XCD a contiguous eighth of the tile range -- neighbouring tiles gather mostly the same Gaussians, but an
+//      image whose splats sit in one region loads the XCDs unevenly;
+//   1  plain order: consecutive tiles on consecutive XCDs (balanced, no locality);
+//   2  runs of 8 consecutive tiles per XCD, the runs dealt round-robin (balanced AND local) -- the default since round 2:
+//      c2 (uniform cube) forward 61.0 -> 57.9 us, backward 131.7 -> 125.5 us; splats gathered in the middle of the image
+//      (bench.py --cloud-scale 0.4) 88 -> 66 us and 204 -> 150 us; order 1 measures the same as 2 within noise.
+// Speed only: any bijection gives the same results.
+#ifndef SO_TILE_ORDER
+#define SO_TILE_ORDER 2
+#endif
 __device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t n) {
+#if SO_TILE_ORDER == 1
+  return b;
+#elif SO_TILE_ORDER == 2
+  const int64_t grp = b >> 6;
+  if ((grp + 1) * 64 > n) return b;                 // the ragged last group keeps plain order
+  return grp * 64 + ((b & 7) << 3) + ((b >> 3) & 7);
+#else
   const int64_t q = n >> 3, r = n & 7;
   const int64_t xcd = b & 7, k = b >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+#endif
 }
 
 // Pixel owned by a thread.  16x16 tiles: each of the 4 waves owns an 8x8 quadrant (compact
