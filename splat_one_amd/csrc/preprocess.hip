@@ -60,6 +60,22 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 
+// -DPP_STAMPS (tools/gpu_ppstamps.sh, not the product build): s_memrealtime stamps (100 MHz) of the phases of
+// k_preprocess_fwd, one row per wave, read back with so_debug_pp_stamps_read.
+#ifdef PP_STAMPS
+__device__ unsigned long long g_pp_stamps[16384 * 8];
+#define PP_STAMP(k)                                                                                             \
+  do {                                                                                                          \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                 \
+    if (first_trip && (threadIdx.x & 63) == 0) {                                                                \
+      const int wv = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));                                \
+      if (wv < 16384) g_pp_stamps[wv * 8 + (k)] = wall_clock64();                                               \
+    }                                                                                                           \
+  } while (0)
+#else
+#define PP_STAMP(k) do { } while (0)
+#endif
+
 template <int DEG, class A, bool SPH>
 __global__ void __launch_bounds__(256)
 k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__restrict__ logit_opac, const A attrs,
@@ -80,6 +96,10 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
   // the trip count is uniform over the workgroup: the histogram section below needs every lane of a wave
   for (int64_t lin0 = (int64_t)blockIdx.x * blockDim.x; lin0 < total; lin0 += (int64_t)gridDim.x * blockDim.x) {
     const int64_t lin = lin0 + threadIdx.x;
+#ifdef PP_STAMPS
+    const bool first_trip = lin0 == (int64_t)blockIdx.x * blockDim.x;
+#endif
+    PP_STAMP(0);
     int cnt = 0, bx0 = 0, bx1 = 0, by0 = 0, by1 = 0, c = 0;
     float cmx = 0.f, cmy = 0.f, cqa = 0.f, cqb = 0.f, cqc = 0.f, ctau = 0.f;   // what the exact tile test needs
     float cdepth = 0.f;
@@ -109,6 +129,10 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
     if (antialiased) op *= o.comp;
     if (radii) opacities[idx] = op;
     float r = 0.f, g = 0.f, b = 0.f;
+#ifdef PP_STAMPS
+    if (o.radius == -12345) r = 1.f;      // (keeps the projection ahead of the stamp)
+#endif
+    PP_STAMP(1);
     if (o.radius > 0) {
       float dx = mean[0] - cam.pos[0], dy = mean[1] - cam.pos[1], dz = mean[2] - cam.pos[2];
       const float inorm = rsqrtf(dx * dx + dy * dy + dz * dz);
@@ -143,6 +167,10 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
       colors[3 * idx] = r; colors[3 * idx + 1] = g; colors[3 * idx + 2] = b;
       tiles_per_gauss[idx] = cnt;
     }
+#ifdef PP_STAMPS
+    if (r == -12345.f) cnt = 0;
+#endif
+    PP_STAMP(2);
 #ifdef PP_NO_REC
     if (rec && o.depth == 12345.678f) {
 #else
@@ -157,6 +185,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       vrec[4 * idx] = z; vrec[4 * idx + 1] = z; vrec[4 * idx + 2] = z; vrec[4 * idx + 3] = z;
     }
+    PP_STAMP(3);
     }   // lin < total, n < n_live
     if (tile_counts) {   // null: the caller bins later (Gaussian-sharded runs bin after the exchange)
       // Histogram of the first binning pass.  A lane walks a small rectangle itself; a large one (the dense
@@ -169,20 +198,37 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
         if (bin_keys) {
           // binned lists (so_step_desc.bin_capacity): every tile owns bin_cap key slots, the returning atomic IS the
           // slot -- the key goes straight to its place and neither a scan nor a scatter pass exists
+          // Two sweeps over the rectangle: ALL returning atomics are issued before the first slot is consumed (one
+          // s_waitcnt for the lane instead of one per tile).  s_memrealtime stamps (tools/dbg_ppstamps.py): the binning
+          // section is 15.0 -> 11.6 of a wave's 23.5 -> 21.6 us; what remains is the throughput of the memory-side atomic
+          // units with every wave of the launch in this section at once (357k returning atomics in ~12 us).
           const uint64_t key = ((uint64_t)__float_as_uint(cdepth) << 32) | (uint64_t)(uint32_t)idx;
+          int32_t got[kOwn];
           int x = bx0, y = by0;
 #pragma unroll
           for (int i = 0; i < kOwn; ++i) {
+            got[i] = -1;
             if (i < cnt) {
-              if (!tile_cull || tile_touches(cmx, cmy, cqa, cqb, cqc, ctau, x, y, tile_size)) {
+              if (!tile_cull || tile_touches(cmx, cmy, cqa, cqb, cqc, ctau, x, y, tile_size))
+                got[i] = atomicAdd(tile_counts + ((int64_t)c * n_tiles + y * tile_w + wrapx(x, tile_w)), 1);
+              if (++x == bx1) { x = bx0; ++y; }
+            }
+          }
+          x = bx0; y = by0;
+          bool over = false;
+#pragma unroll
+          for (int i = 0; i < kOwn; ++i) {
+            if (i < cnt) {
+              const int32_t s = got[i];
+              if (s >= 0) {
                 const int64_t t = (int64_t)c * n_tiles + y * tile_w + wrapx(x, tile_w);
-                const int32_t s = atomicAdd(tile_counts + t, 1);
                 if (s < bin_cap) bin_keys[t * bin_cap + s] = key;
-                else *bin_overflow = 1;
+                else over = true;
               }
               if (++x == bx1) { x = bx0; ++y; }
             }
           }
+          if (over) *bin_overflow = 1;
         } else if (tile_slots) {
           // the value an atomic returns IS this Gaussian's slot in that tile's list: keep it, and the scatter pass
           // (k_isect_scatter) places the key at offsets[tile] + slot without a second round of atomics.  All
@@ -234,6 +280,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
             }
       }
     }
+    PP_STAMP(4);
   }
 }
 
@@ -817,6 +864,13 @@ extern "C" int so_rec_unpack(int64_t n, const float *rec, float *means2d, int32_
                      reinterpret_cast<float4 *>(vrec));
   return so::check_launch("so_rec_unpack");
 }
+
+#ifdef PP_STAMPS
+extern "C" int so_debug_pp_stamps_read(unsigned long long *host, int n_words) {
+  if (hipDeviceSynchronize() != hipSuccess) return SO_ERR_LAUNCH;
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(so::g_pp_stamps), (size_t)n_words * 8) == hipSuccess ? SO_OK : SO_ERR_LAUNCH;
+}
+#endif
 
 extern "C" int so_rec_pack(int64_t n, const float *means2d, const float *conics, const float *colors,
                            const float *opacities, float *rec, float *vrec, void *stream) {
