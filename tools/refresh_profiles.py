@@ -26,7 +26,13 @@ pairs = [(f"{tag}/prof/**/bench_kernel_stats.csv", f"{tag}_engine_kernel_stats.c
          (f"parity_{tag}.json", f"parity_{tag}.json")]
 for a, b in pairs:
     p = first(a)
-    if p:
+    if p and b.startswith("parity_") and os.path.exists(os.path.join(dst, b)):
+        # a test run records only the cases it ran: merge into the tracked file, newest entry per case wins
+        old, new = json.load(open(os.path.join(dst, b))), json.load(open(p))
+        old.update(new)
+        json.dump(old, open(os.path.join(dst, b), "w"), indent=1, sort_keys=True)
+        print("merged", os.path.relpath(p, ROOT), "->", b, f"({len(new)} cases of {len(old)})")
+    elif p:
         shutil.copy(p, os.path.join(dst, b))
         print("copied", os.path.relpath(p, ROOT), "->", b)
     else:
