@@ -134,6 +134,15 @@ int so_projection_bwd_packed(int C, int N, int64_t nnz, const float *means, cons
  * Backward: v_coeffs (same shape as coeffs) is OVERWRITTEN (sum over cameras when shared);
  * v_dirs[C,N,3] nullable, overwritten.
  * ---------------------------------------------------------------------------------------- */
+/* The whole colour stage of `rasterization(sh_degree=...)` in one launch each way (dense layout, coefficients shared by
+ * the cameras): colors[c,n] = max(SH(normalise(means[n] - campos[c])) . coeffs[n] + 0.5, 0) where radii[c,n] > 0, 0.5
+ * elsewhere (radii nullable: all visible); the backward OVERWRITES v_coeffs[N,K,3] and v_means[N,3] (sums over the
+ * cameras) and takes the clamp from the forward's output `colors`. */
+int so_sh_view_colors_fwd(int C, int N, int K, int degrees_to_use, const float *means, const float *campos,
+                          const float *coeffs, const int32_t *radii, float *colors, void *stream);
+int so_sh_view_colors_bwd(int C, int N, int K, int degrees_to_use, const float *means, const float *campos,
+                          const float *coeffs, const int32_t *radii, const float *colors, const float *v_colors,
+                          float *v_coeffs, float *v_means, void *stream);
 int so_sh_fwd(int C, int N, int K, int degrees_to_use, const float *dirs, const float *coeffs,
               int coeffs_per_camera, const uint8_t *masks, float *colors, void *stream);
 int so_sh_bwd(int C, int N, int K, int degrees_to_use, const float *dirs, const float *coeffs,
@@ -553,6 +562,14 @@ int so_refine_default(int64_t capacity, int K, const so_model_set *src, const in
                       const so_refine_params *prm, int32_t *scratch, int32_t *report_dev, void *stream);
 int so_reset_opacity(int64_t capacity, const int32_t *n_dev, float *logit_opacities, float *exp_avg, float *exp_avg_sq,
                      float max_logit, void *stream);
+/* gsplat `DefaultStrategy._update_state` (the `step_post_backward` hook, gsplat_trainer.py:744-752) on the dense layout:
+ * for every Gaussian n and every camera c with radii[c,n] > 0:
+ *   grad2d[n] += |(v_means2d[c,n].x * sx, v_means2d[c,n].y * sy)|,  count[n] += 1,
+ *   radii_state[n] = max(radii_state[n], radii[c,n] * inv_max_wh)   (radii_state nullable)
+ * with sx = width / 2 * n_cameras, sy = height / 2 * n_cameras, inv_max_wh = 1 / max(width, height).  (The fused engine
+ * accumulates the same inside so_preprocess_bwd.) */
+int so_strategy_update_state(int C, int64_t N, const float *v_means2d, const int32_t *radii, float sx, float sy,
+                             float inv_max_wh, float *grad2d, float *count, float *radii_state, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * MCMC densification strategy (the reference's `mcmc` preset, gsplat_trainer.py:975-983, :753-761).

@@ -96,6 +96,9 @@ _SIGS = {
     "so_shard_flag_put": [c_int, c_i64, c_ptr, c_ptr, c_ptr],
     "so_shard_flag_get": [c_int, c_i64, c_ptr, c_ptr, c_ptr],
     "so_preprocess_bwd": [c_int] * 4 + [c_ptr] * 8 + [c_int, c_int, c_f32, c_int, c_int] + [c_ptr] * 9 + [c_f32, c_f32] + [c_ptr] * 9 + [c_int, c_i64, c_ptr, c_ptr, c_ptr],
+    "so_sh_view_colors_fwd": [c_int] * 4 + [c_ptr] * 6,
+    "so_sh_view_colors_bwd": [c_int] * 4 + [c_ptr] * 9,
+    "so_strategy_update_state": [c_int, c_i64, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr],
     "so_rec_pack": [c_i64] + [c_ptr] * 7,
     "so_rec_unpack_grads": [c_i64] + [c_ptr] * 7,
     "so_rasterize_fwd_packed": [c_int] * 5 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 4,

@@ -259,6 +259,33 @@ k_reset_opacity(int64_t cap, const int32_t *__restrict__ n_dev, float *__restric
   }
 }
 
+// DefaultStrategy._update_state on the dense [C,N] layout (the operator-level path; the fused engine accumulates the same
+// statistic inside k_preprocess_bwd): one lane per Gaussian sums over the cameras that see it -- no atomics, no
+// intermediate [C,N] tensors (the torch formulation is a dozen launches).
+__global__ void __launch_bounds__(256)
+k_strategy_update(int C, int64_t N, const float2 *__restrict__ v_means2d, const int32_t *__restrict__ radii, float sx,
+                  float sy, float inv_max_wh, float *__restrict__ grad2d, float *__restrict__ count,
+                  float *__restrict__ radii_state) {
+  for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+    float g = 0.f, cn = 0.f, rmax = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const int32_t r = radii[(int64_t)c * N + n];
+      if (r > 0) {
+        const float2 v = v_means2d[(int64_t)c * N + n];
+        const float gx = v.x * sx, gy = v.y * sy;
+        g += sqrtf(gx * gx + gy * gy);
+        cn += 1.f;
+        rmax = fmaxf(rmax, (float)r * inv_max_wh);
+      }
+    }
+    if (cn > 0.f) {
+      grad2d[n] += g;
+      count[n] += cn;
+      if (radii_state) radii_state[n] = fmaxf(radii_state[n], rmax);
+    }
+  }
+}
+
 static inline int ref_nblk(int64_t cap) { return (int)ceil_div(cap, kRefChunk); }
 
 }  // namespace so
@@ -320,4 +347,16 @@ extern "C" int so_reset_opacity(int64_t capacity, const int32_t *n_dev, float *l
   hipLaunchKernelGGL(so::k_reset_opacity, dim3((unsigned)gx), dim3(256), 0, so::as_stream(stream), capacity, n_dev,
                      logit_opacities, exp_avg, exp_avg_sq, max_logit);
   return so::check_launch("so_reset_opacity");
+}
+
+extern "C" int so_strategy_update_state(int C, int64_t N, const float *v_means2d, const int32_t *radii, float sx, float sy,
+                                        float inv_max_wh, float *grad2d, float *count, float *radii_state, void *stream) {
+  SO_REQUIRE(C >= 0 && N >= 0, "so_strategy_update_state: bad sizes");
+  if (C == 0 || N == 0) return SO_OK;
+  SO_REQUIRE(v_means2d && radii && grad2d && count, "so_strategy_update_state: null pointer");
+  int64_t gx = so::ceil_div(N, 256);
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(so::k_strategy_update, dim3((unsigned)gx), dim3(256), 0, so::as_stream(stream), C, N,
+                     reinterpret_cast<const float2 *>(v_means2d), radii, sx, sy, inv_max_wh, grad2d, count, radii_state);
+  return so::check_launch("so_strategy_update_state");
 }

@@ -281,6 +281,39 @@ class _SphericalHarmonics(torch.autograd.Function):
         return None, v_dirs, v_coeffs, None, None, None, None
 
 
+class _ShViewColors(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, degree, means, campos, coeffs, radii):
+        C, N, K = campos.shape[0], means.shape[0], coeffs.shape[-2]
+        colors = torch.empty(C, N, 3, dtype=torch.float32, device=means.device)
+        call("so_sh_view_colors_fwd", C, N, K, degree, ptr(means), ptr(campos), ptr(coeffs), ptr(radii), ptr(colors), stream())
+        ctx.save_for_backward(means, campos, coeffs, radii, colors)
+        ctx.degree = degree
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        means, campos, coeffs, radii, colors = ctx.saved_tensors
+        C, N, K = campos.shape[0], means.shape[0], coeffs.shape[-2]
+        v_coeffs = torch.empty_like(coeffs)
+        v_means = torch.empty_like(means)
+        call("so_sh_view_colors_bwd", C, N, K, ctx.degree, ptr(means), ptr(campos), ptr(coeffs), ptr(radii), ptr(colors),
+             ptr(v_colors.contiguous()), ptr(v_coeffs), ptr(v_means), stream())
+        return None, v_means, None, v_coeffs, None
+
+
+def sh_view_colors(degrees_to_use: int, means: Tensor, campos: Tensor, coeffs: Tensor, radii: Optional[Tensor]) -> Tensor:
+    """The colour stage of `rasterization` fused: clamp_min(spherical_harmonics(degree, means[None] - campos[:, None], coeffs,
+    masks=radii > 0) + 0.5, 0) -> colors[C,N,3] in ONE launch each way (six torch-level operations otherwise).  means[N,3],
+    campos[C,3] (no gradient flows to it: callers that optimise poses use the unfused operators), coeffs[N,K,3] shared by
+    the cameras, radii[C,N] int32 or None."""
+    assert means.dim() == 2 and campos.dim() == 2 and coeffs.dim() == 3 and coeffs.shape[0] == means.shape[0], (means.shape, coeffs.shape)
+    assert (degrees_to_use + 1) ** 2 <= coeffs.shape[-2], coeffs.shape
+    assert radii is None or (radii.shape == (campos.shape[0], means.shape[0]) and radii.dtype == torch.int32), radii
+    return _ShViewColors.apply(int(degrees_to_use), _f32(means), _f32(campos.detach()), _f32(coeffs),
+                               None if radii is None else radii.contiguous())
+
+
 def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor, masks: Optional[Tensor] = None) -> Tensor:
     """dirs[...,3], coeffs[...,K,3], masks[...] -> colors[...,3].
 

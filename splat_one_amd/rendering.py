@@ -14,7 +14,7 @@ import torch
 import torch.distributed as dist
 from torch import Tensor
 
-from .ops import (camera_inverse, fully_fused_projection, isect_offset_encode, isect_tiles, isect_tiles_static,
+from .ops import (camera_inverse, sh_view_colors, fully_fused_projection, isect_offset_encode, isect_tiles, isect_tiles_static,
                   rasterize_to_pixels, spherical_harmonics)
 
 RENDER_MODES = ("RGB", "D", "ED", "RGB+D", "RGB+ED")
@@ -180,6 +180,12 @@ def rasterization(
             colors = colors[gaussian_ids] if colors.dim() == 2 else colors[camera_ids, gaussian_ids]    # [nnz, D]
         elif colors.dim() == 2:
             colors = colors[None].expand(C, -1, -1)
+    elif (not packed and not distributed and colors.dim() == 3 and not viewmats.requires_grad
+          and radii.dtype == torch.int32 and tuple(radii.shape) == (C, N)):
+        # the common call (dense layout, coefficients shared by the cameras, fixed poses): view directions, SH evaluation,
+        # "+ 0.5" and the clamp in one launch each way
+        campos = camera_inverse(viewmats)[:, :3, 3].contiguous()
+        colors = sh_view_colors(sh_degree, means, campos, colors, radii)
     else:
         camtoworlds = camera_inverse(viewmats)      # (no device synchronisation, unlike torch.inverse)
         if packed:

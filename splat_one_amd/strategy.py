@@ -344,6 +344,16 @@ class DefaultStrategy(Strategy):
             state["radii"] = torch.zeros(n_gaussian, device=grads.device)
         sx = info["width"] / 2.0 * info["n_cameras"]
         sy = info["height"] / 2.0 * info["n_cameras"]
+        if (not packed and grads.is_cuda and grads.dim() == 3 and grads.dtype == torch.float32 and grads.is_contiguous()
+                and info["radii"].dtype == torch.int32 and info["radii"].is_contiguous()
+                and all(state[k].is_contiguous() and state[k].dtype == torch.float32 for k in ("grad2d", "count"))):
+            # dense layout on the device: ONE launch instead of a dozen torch kernels (csrc/refine.hip k_strategy_update)
+            from ._lib import call, ptr, stream
+            C, N = info["radii"].shape
+            call("so_strategy_update_state", C, N, ptr(grads), ptr(info["radii"]), float(sx), float(sy),
+                 1.0 / float(max(info["width"], info["height"])), ptr(state["grad2d"]), ptr(state["count"]),
+                 ptr(state["radii"]) if self.refine_scale2d_stop_iter > 0 else 0, stream())
+            return
         norms = torch.sqrt((grads[..., 0] * sx) ** 2 + (grads[..., 1] * sy) ** 2)
         if packed:       # one row per visible (camera, Gaussian) pair, named by info["gaussian_ids"] (radii > 0 on all of them)
             gs_ids = info["gaussian_ids"]

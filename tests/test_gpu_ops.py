@@ -556,3 +556,59 @@ def test_tile_cull_count_and_fill_passes_agree(dev, monkeypatch):
         n_pairs += ids0.numel()
     assert n_pairs > 3e8
     assert rec_pack_unpack_roundtrip(dev)
+
+
+@pytest.mark.parametrize("degree,C", [(3, 1), (2, 3), (0, 2)])
+def test_sh_view_colors_equals_the_operator_chain(dev, degree, C):
+    """`sh_view_colors` (one launch each way) against what `rasterization` otherwise composes from six operators:
+    clamp_min(spherical_harmonics(deg, means - campos, coeffs, masks = radii > 0) + 0.5, 0) -- values and gradients."""
+    from splat_one_amd.ops import sh_view_colors, spherical_harmonics
+    N, K = 5000, 16
+    g = torch.Generator().manual_seed(13)
+    means0 = torch.randn(N, 3, generator=g)
+    coeffs0 = torch.randn(N, K, 3, generator=g) * 2.0
+    campos = (torch.randn(C, 3, generator=g) * 3).to(dev)
+    radii = (torch.rand(C, N, generator=g) < 0.8).to(torch.int32).to(dev) * 7
+    w = torch.rand(C, N, 3, generator=g).to(dev)
+    outs = []
+    for fused in (False, True):
+        means = means0.clone().to(dev).requires_grad_(True)
+        coeffs = coeffs0.clone().to(dev).requires_grad_(True)
+        if fused:
+            col = sh_view_colors(degree, means, campos, coeffs, radii)
+        else:
+            dirs = means[None] - campos[:, None]
+            col = torch.clamp_min(spherical_harmonics(degree, dirs, coeffs[None].expand(C, -1, -1, -1), masks=radii > 0) + 0.5, 0.0)
+        (col * w).sum().backward()
+        outs.append((col.detach(), means.grad.clone(), coeffs.grad.clone()))
+    (c0, gm0, gc0), (c1, gm1, gc1) = outs
+    assert (c0 - c1).abs().max().item() <= 2e-6
+    assert float((c1 == 0).float().mean()) > 0.01                        # the clamp is exercised
+    assert rel_err(gm1, gm0) < 1e-5 and rel_err(gc1, gc0) < 1e-6
+    # and against the float64 oracle
+    col_o = torch.clamp_min(O.spherical_harmonics(degree, (means0[None].double() - campos.cpu().double()[:, None]),
+                                                  coeffs0[None].double().expand(C, -1, -1, -1), masks=(radii > 0).cpu()) + 0.5, 0.0)
+    assert (c1.cpu().double() - col_o).abs().max().item() < 1e-5
+
+
+def test_strategy_update_state_kernel(dev):
+    """`so_strategy_update_state` (DefaultStrategy._update_state on the dense layout, one launch) against the loop oracle."""
+    from oracle import strategy_oracle as SO
+    from splat_one_amd.strategy import DefaultStrategy
+    C, N, W, H = 3, 4000, 640, 360
+    g = torch.Generator().manual_seed(2)
+    grads = torch.randn(C, N, 2, generator=g) * 1e-3
+    radii = (torch.rand(C, N, generator=g) < 0.6).to(torch.int32) * torch.randint(1, 40, (C, N), generator=g, dtype=torch.int32)
+    s = DefaultStrategy(refine_scale2d_stop_iter=4000)
+    state = {"grad2d": torch.rand(N, generator=g).to(dev), "count": torch.randint(0, 5, (N,), generator=g).float().to(dev),
+             "radii": torch.rand(N, generator=g).to(dev) * 0.01, "scene_scale": 1.0}
+    g2_0, cn_0, r_0 = (state[k].cpu().double().clone() for k in ("grad2d", "count", "radii"))
+    m2 = torch.zeros(C, N, 2, device=dev, requires_grad=True)
+    m2.grad = grads.to(dev).contiguous()
+    info = {"width": W, "height": H, "n_cameras": C, "radii": radii.to(dev), "means2d": m2}
+    s._update_state({"means": torch.zeros(N, 3)}, state, info)
+    g2, cn = SO.update_state(g2_0, cn_0, grads.double(), radii, W, H, C)
+    assert (state["grad2d"].cpu().double() - g2).abs().max().item() < 1e-5
+    assert torch.equal(state["count"].cpu().double(), cn)
+    r_want = torch.maximum(r_0, (radii.double() / max(W, H)).max(dim=0).values * (radii > 0).any(dim=0))
+    assert (state["radii"].cpu().double() - r_want).abs().max().item() < 1e-7

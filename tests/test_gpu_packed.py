@@ -49,13 +49,15 @@ def test_packed_rasterization_equals_dense(dev, C, kw):
     assert torch.equal(m_p["camera_ids"], cam) and torch.equal(m_p["gaussian_ids"], gid)
     for k in ("radii", "means2d", "depths", "conics", "opacities"):
         assert m_p[k].shape[0] == cam.numel() and torch.equal(m_p[k], m_d[k][cam, gid]), k
-    # same tile lists (flatten_ids name packed rows), same images bit for bit
+    # same tile lists (flatten_ids name packed rows), same images (see below)
     assert torch.equal(m_p["isect_offsets"], m_d["isect_offsets"])
     f = m_p["flatten_ids"].long()
     assert torch.equal(cam[f] * N + gid[f], m_d["flatten_ids"].long())
     assert torch.equal(m_p["isect_ids"], m_d["isect_ids"])
     assert torch.equal(m_p["tiles_per_gauss"], m_d["tiles_per_gauss"][cam, gid])
-    assert torch.equal(rc_p, rc_d) and torch.equal(ra_p, ra_d)
+    # alphas bit for bit; colours to rounding: the dense call evaluates view directions + SH + clamp in one fused launch,
+    # the packed one through the separate operators (two compilations of the same arithmetic)
+    assert torch.equal(ra_p, ra_d) and (rc_p - rc_d).abs().max().item() <= 2e-6
     # gradients (float atomics: order varies)
     for k in p_d:
         assert rel_err(p_p[k].grad.cpu().double(), p_d[k].grad.cpu().double()) < 1e-5, k
