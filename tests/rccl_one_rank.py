@@ -13,6 +13,9 @@ import torch.distributed as dist
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29533")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from splat_one_amd.distributed import _single_node_sockets                           # noqa: E402
+_single_node_sockets()          # bootstrap sockets on `lo`: no hostname lookups (minutes where the name does not resolve)
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1)
 dev = torch.device("cuda:0")
@@ -71,7 +74,8 @@ args = [splats["means"], splats["quats"], splats["scales"].exp(), splats["opacit
 args = [a.to(dev) for a in args] + [torch.linalg.inv(c2w).to(dev), Ks.to(dev), W, H]
 rc0, ra0, _ = rasterization(*args, sh_degree=3, packed=False)
 rc1, ra1, m1 = rasterization(*args, sh_degree=3, packed=False, distributed=True)
-assert torch.equal(rc0, rc1) and torch.equal(ra0, ra1) and m1["n_cameras"] == 2
+# (alphas bit for bit; colours to rounding: the plain dense call evaluates its colour stage in one fused launch)
+assert (rc0 - rc1).abs().max().item() <= 2e-6 and torch.equal(ra0, ra1) and m1["n_cameras"] == 2
 print("distributed operator ok", flush=True)
 
 # the sharded engine over RCCL (its all-to-alls, capacity probe, flag kernels, workspace collectives)
