@@ -72,8 +72,18 @@ __device__ unsigned long long g_pp_stamps[16384 * 8];
       if (wv < 16384) g_pp_stamps[wv * 8 + (k)] = wall_clock64();                                               \
     }                                                                                                           \
   } while (0)
+__device__ unsigned long long g_ppb_stamps[16384 * 8];
+#define PPB_STAMP(k)                                                                                            \
+  do {                                                                                                          \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                 \
+    if (first_trip && (threadIdx.x & 63) == 0) {                                                                \
+      const int wv = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));                                \
+      if (wv < 16384) g_ppb_stamps[wv * 8 + (k)] = wall_clock64();                                              \
+    }                                                                                                           \
+  } while (0)
 #else
 #define PP_STAMP(k) do { } while (0)
+#define PPB_STAMP(k) do { } while (0)
 #endif
 
 template <int DEG, class A, bool SPH>
@@ -321,6 +331,10 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
   for (int64_t n0 = (int64_t)blockIdx.x * blockDim.x; n0 < N; n0 += (int64_t)gridDim.x * blockDim.x) {
     const int64_t n = n0 + threadIdx.x;
     const bool active = n < N;
+#ifdef PP_STAMPS
+    const bool first_trip = n0 == (int64_t)blockIdx.x * blockDim.x;
+#endif
+    PPB_STAMP(0);
     float acc[NB][3];
     // staged: the 3 (NB - 1) gradient sums of shN live in this lane's LDS row from the start (45 registers fewer)
     float *const my_row = s_stage + ((size_t)(threadIdx.x >> 6) * 64 + (threadIdx.x & 63)) * R;
@@ -407,6 +421,7 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
         cn += 1.f;
       }
     }
+    PPB_STAMP(1);
     // d/d log s = s * d/ds ; scale regulariser: scale_reg * mean|exp(s)| over 3N entries
     const float sreg = scale_reg / (3.f * (float)N);
     const float gs[3] = {(vs[0] + sreg) * s[0], (vs[1] + sreg) * s[1], (vs[2] + sreg) * s[2]};
@@ -415,22 +430,30 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
       // Fused optimiser (so_step_desc.fuse_adam): the gradient of this Gaussian is in registers (and, for shN, in
       // its LDS row) -- apply Adam here instead of writing 236 B of gradient for the Adam kernel to read back.
       // Same arithmetic as adam.hip (adam_one); hyper[g] = (step size, sqrt(bias correction 2)) of group g.
-      auto upd = [&](int grp, int64_t at, int len, const float *grad) {
-        const float2 hy = af.hyper[grp];
-        float *P = af.p[grp] + at, *Mo = af.m[grp] + at, *Vo = af.v[grp] + at;
+      // All 42 values (parameter + two moments of the five small tensors) are requested BEFORE the first one is used: one
+      // memory round trip for the lane instead of one per tensor (s_memrealtime stamps, tools/dbg_ppstamps.py: this
+      // section was 9.3 us of a wave's 33 us with load -> update -> store per tensor).
+      constexpr int kLen[5] = {3, 3, 4, 1, 3};
+      const int64_t at[5] = {3 * n, 3 * n, 4 * n, n, 3 * n};
+      float pv[5][4], mv[5][4], vv[5][4];
+#pragma unroll
+      for (int g = 0; g < 5; ++g)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (j < len) {
-            float pj = P[j], mj = Mo[j], vj = Vo[j];
-            adam_one(pj, grad[j], mj, vj, af.h, hy.x, hy.y);
-            P[j] = pj; Mo[j] = mj; Vo[j] = vj;
-          }
-      };
-      upd(0, 3 * n, 3, vm);
-      upd(1, 3 * n, 3, gs);
-      upd(2, 4 * n, 4, vq);
-      upd(3, n, 1, &go);
-      upd(4, 3 * n, 3, acc[0]);
+          if (j < kLen[g]) { pv[g][j] = af.p[g][at[g] + j]; mv[g][j] = af.m[g][at[g] + j]; vv[g][j] = af.v[g][at[g] + j]; }
+      const float *grads[5] = {vm, gs, vq, &go, acc[0]};
+#pragma unroll
+      for (int g = 0; g < 5; ++g) {
+        const float2 hy = af.hyper[g];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < kLen[g]) adam_one(pv[g][j], grads[g][j], mv[g][j], vv[g][j], af.h, hy.x, hy.y);
+      }
+#pragma unroll
+      for (int g = 0; g < 5; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < kLen[g]) { af.p[g][at[g] + j] = pv[g][j]; af.m[g][at[g] + j] = mv[g][j]; af.v[g][at[g] + j] = vv[g][j]; }
     } else {
       v_means[3 * n] = vm[0]; v_means[3 * n + 1] = vm[1]; v_means[3 * n + 2] = vm[2];
       *reinterpret_cast<float4 *>(v_quats + 4 * n) = make_float4(vq[0], vq[1], vq[2], vq[3]);
@@ -439,6 +462,7 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
       v_sh0[3 * n] = acc[0][0]; v_sh0[3 * n + 1] = acc[0][1]; v_sh0[3 * n + 2] = acc[0][2];
     }
     if (grad2d) { grad2d[n] += g2; count[n] += cn; }
+    PPB_STAMP(2);
     if (!STAGE) {
       float *o = v_shN + n * (int64_t)R;
 #pragma unroll
@@ -455,6 +479,7 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
         for (int k = 3 * (NB - 1); k < R; ++k) my_row[k] = 0.f;
       }
       __syncthreads();
+      PPB_STAMP(3);
       const int64_t w0 = n0 + (int64_t)wv * 64;            // first Gaussian of this wave: a multiple of 64 -> 16-byte aligned run
       const int64_t rows = N - w0 < 64 ? N - w0 : 64;
       if (rows > 0) {
@@ -484,6 +509,7 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
           for (int i = (total & ~3) + lane; i < total; i += 64) v_shN[w0 * R + i] = mine[i];
         }
       }
+      PPB_STAMP(4);
       __syncthreads();
     }
   }
@@ -869,6 +895,10 @@ extern "C" int so_rec_unpack(int64_t n, const float *rec, float *means2d, int32_
 extern "C" int so_debug_pp_stamps_read(unsigned long long *host, int n_words) {
   if (hipDeviceSynchronize() != hipSuccess) return SO_ERR_LAUNCH;
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(so::g_pp_stamps), (size_t)n_words * 8) == hipSuccess ? SO_OK : SO_ERR_LAUNCH;
+}
+extern "C" int so_debug_ppb_stamps_read(unsigned long long *host, int n_words) {
+  if (hipDeviceSynchronize() != hipSuccess) return SO_ERR_LAUNCH;
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(so::g_ppb_stamps), (size_t)n_words * 8) == hipSuccess ? SO_OK : SO_ERR_LAUNCH;
 }
 #endif
 

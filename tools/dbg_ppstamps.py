@@ -38,3 +38,17 @@ idle = st[real:, :5]
 idle = idle[idle[:, 0] > 0]
 if len(idle):
     print("waves without work:", len(idle), " start mean %.1f us, life mean %.2f us" % (((idle[:, 0] - t0) * 0.01).mean(), ((idle[:, 4] - idle[:, 0]) * 0.01).mean()))
+
+# ---- k_preprocess_bwd (with the fused Adam)
+assert lib.so_debug_ppb_stamps_read(buf, n_w * 8) == 0
+st = np.frombuffer(buf, dtype=np.uint64).reshape(n_w, 8).astype(np.int64)
+s = st[:real, :5]
+t0 = s[:, 0].min()
+rel = (s - t0) * 0.01
+print("k_preprocess_bwd: kernel span %.1f us" % rel[:, 4].max())
+names = ["loads + projection bwd + SH bwd (camera loop)", "Adam on means/scales/quats/opacity/sh0 (per lane)", "LDS row completion + barrier", "coalesced shN sweep (Adam)"]
+for k in range(4):
+    d = rel[:, k + 1] - rel[:, k]
+    print("%-52s mean %6.2f  p50 %6.2f  p95 %6.2f  max %6.2f us" % (names[k], d.mean(), np.median(d), np.percentile(d, 95), d.max()))
+life = rel[:, 4] - rel[:, 0]
+print("wave life: mean %.2f p50 %.2f p95 %.2f max %.2f us;  start spread p95 %.2f us" % (life.mean(), np.median(life), np.percentile(life, 95), life.max(), np.percentile(rel[:, 0], 95)))
