@@ -1,6 +1,6 @@
 """`rasterization(distributed=True)` -- what the reference passes when world_size > 1 (gsplat_trainer.py:490): every
 rank brings a shard of the Gaussians and its own camera; two ranks on the one GPU of the box (gloo) must reproduce the
-single-process render of all Gaussians into both cameras, images and gradients."""
+single-process render of all Gaussians into both cameras, images and gradients -- and the float64 oracle's."""
 import os
 import socket
 
@@ -96,3 +96,19 @@ def test_rasterization_distributed_two_ranks_one_gpu(dev, tmp_path, packed):
             assert rel_err(o["v_means2d"], meta["means2d"].grad[:, rows[r]].cpu()) < 1e-5
         for k, g in o["grads"].items():
             assert rel_err(g, p[k].grad[rows[r]].cpu()) < 1e-5, (k, r)
+    # ... and the ORACLE's render of all Gaussians into both cameras (float64 autograd projection / SH / binning + the C
+    # rasteriser): images <= 1e-4, the gradients of every shard <= 1e-3 -- parity of the distributed call itself
+    from oracle import c_oracle as CO
+    from oracle import torch_oracle as O
+    q = {k: v[order].clone().double().requires_grad_(True) for k, v in splats.items()}
+    rc_o, ra_o, _ = O.rasterization(q["means"], q["quats"], torch.exp(q["scales"]), torch.sigmoid(q["opacities"]),
+                                    torch.cat([q["sh0"], q["shN"]], 1), viewmats.double(), Ks.double(), W, H,
+                                    backgrounds=bg.double(), raster_fn=CO.raster_fn(), **KW)
+    ((rc_o * w.double()).sum() + 0.1 * ra_o.sum()).backward()
+    for r in range(2):
+        o = out[r]
+        assert (o["rc"][0].double() - rc_o[r]).abs().mean().item() <= 1e-4 and (o["ra"][0].double() - ra_o[r]).abs().mean().item() <= 1e-4
+        for k, g in o["grads"].items():
+            ref = q[k].grad[rows[r]]
+            floor = 1e-5 * q["scales"].grad.norm().item() if k == "quats" else 0.0
+            assert (g.double() - ref).norm().item() <= 1e-3 * ref.norm().item() + floor, (k, r)
