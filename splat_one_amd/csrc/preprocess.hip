@@ -197,6 +197,15 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
     }
     PP_STAMP(3);
     }   // lin < total, n < n_live
+    else if (n_dev && radii && lin < total) {
+      // rows between the live count and the capacity: the kernels that read the per-view arrays over all N rows (the
+      // compact lists' scatter pass, so_isect_fill) must see them as invisible -- after a prune they still hold the
+      // radii of Gaussians that no longer exist
+      const int64_t cdead = lin / N;
+      const int64_t idead = cdead * cam_stride + (lin - cdead * N);
+      radii[idead] = 0;
+      tiles_per_gauss[idead] = 0;
+    }
     if (tile_counts) {   // null: the caller bins later (Gaussian-sharded runs bin after the exchange)
       // Histogram of the first binning pass.  A lane walks a small rectangle itself; a large one (the dense
       // init regime: ~70 tiles per Gaussian) is spread over the whole wave in 8x8 tile blocks, so the wave's
