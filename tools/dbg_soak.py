@@ -23,10 +23,26 @@ CASES = [("operator dense pinhole", dict(fused=False)),
          ("engine binned", dict(fused=True)),
          ("engine compact lists", dict(fused=True, binned=False)),
          ("engine spherical", dict(fused=True, camera_model="spherical")),
-         ("engine f16 rows (host refinement)", dict(fused=True, attr_dtype="f16"))]
+         ("engine f16 rows (host refinement)", dict(fused=True, attr_dtype="f16")),
+         ("engine two-kernel Adam", dict(fused=True, fuse_adam=False)),
+         ("engine no tile cull", dict(fused=True, tile_cull=False)),
+         ("engine antialiased", dict(fused=True, antialiased=True)),
+         ("engine host-side refinement", dict(fused=True, device_refine=False)),
+         ("engine absgrad + revised opacity", dict(fused=True, _strategy=dict(absgrad=True, revised_opacity=True, grow_grad2d=0.0008))),
+         ("engine batch of 2 (pinhole + fisheye)", dict(fused=True, batch_size=2, camera_model=["pinhole", "fisheye"])),
+         ("engine MCMC", dict(fused=True, _mcmc=True, opacity_reg=0.01, scale_reg=0.01)),
+         ("operator MCMC", dict(fused=False, _mcmc=True, opacity_reg=0.01, scale_reg=0.01)),
+         ("operator visible_adam", dict(fused=False, visible_adam=True)),
+         ("operator batch of 2", dict(fused=False, batch_size=2))]
 bad = 0
 for name, kw in CASES:
-    strat = DefaultStrategy(refine_start_iter=100, refine_every=100, reset_every=600, verbose=False)
+    kw = dict(kw)
+    skw = kw.pop("_strategy", {})
+    if kw.pop("_mcmc", False):
+        from splat_one_amd.strategy import MCMCStrategy
+        strat = MCMCStrategy(cap_max=120000, refine_start_iter=100, refine_every=100, verbose=False)
+    else:
+        strat = DefaultStrategy(refine_start_iter=100, refine_every=100, reset_every=600, verbose=False, **skw)
     cfg = Config(init_num_pts=N, init_scale=0.3, init_opa=0.3, sh_degree_interval=200, strategy=strat, shN_init_std=0.05, **kw)
     r = Runner(0, 0, 1, cfg, scene_scale=1 / 1.1)
     c2ws = inside.to(dev) if kw.get("camera_model") == "spherical" else cams
@@ -34,9 +50,14 @@ for name, kw in CASES:
     try:
         with warnings.catch_warnings(record=True) as rec:
             warnings.simplefilter("always")
+            B = int(kw.get("batch_size", 1))
             for step in range(STEPS):
                 v = (step * 3) % 8
-                loss = r.train_step(c2ws[v:v + 1], Ks, targets[v])
+                if B == 1:
+                    loss = r.train_step(c2ws[v:v + 1], Ks, targets[v])
+                else:
+                    vs = [(v + j) % 8 for j in range(B)]
+                    loss = r.train_step(c2ws[vs].contiguous(), Ks.repeat(B, 1, 1), torch.cat([targets[j] for j in vs]))
             torch.cuda.synchronize()
         ok = all(torch.isfinite(p).all().item() for p in r.splats.values()) and bool(torch.isfinite(loss).all())
         print(f"{name:38s} N {N} -> {len(r.splats['means'])}  loss {float(loss):.4f}  finite {ok}  warnings {len(rec)}  {time.time() - t0:.1f} s", flush=True)
