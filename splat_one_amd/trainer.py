@@ -131,7 +131,9 @@ class Config:
     device_refine: bool = True
     max_gaussians: Optional[int] = None    # capacity of the device-resident model; None: max(2 N, 2^20), doubled when exceeded
     refine_seed: int = 1234                # seed of the split noise (same on every rank)
-    dp_chunks: int = 4                     # dp_mode="allreduce": chunks of the reduce-scatter / Adam / all-gather pipeline
+    dp_chunks: int = 0                     # dp_mode="allreduce": chunks of the reduce-scatter / Adam / all-gather pipeline
+    #                                        (0 = by size: 4 from 64 MB of gradient on, i.e. ~285k Gaussians at SH degree 3,
+    #                                        else 1 -- below that the latency of eight collectives outweighs the overlap)
     shN_init_std: float = 0.0              # >0: noise instead of zeros in the higher SH bands (bench scenes)
 
     def adjust_steps(self, factor: float):
@@ -608,6 +610,8 @@ class Runner:
         B, H, W = pixels.shape[0], pixels.shape[1], pixels.shape[2]
         eng = getattr(self, "_engine", None)
         if eng is None or (eng.C, eng.H, eng.W) != (B, H, W):
+            n_floats = sum(int(v.numel()) for v in self.splats.values())
+            self._dp_chunks = int(cfg.dp_chunks) if cfg.dp_chunks > 0 else (4 if 4 * n_floats >= (64 << 20) else 1)
             dev_refine = (cfg.device_refine and isinstance(s, DefaultStrategy) and self.world_size == 1
                           and cfg.attr_dtype == "f32" and s.refine_scale2d_stop_iter == 0)
             eng = self._engine = FusedEngine(
@@ -622,7 +626,7 @@ class Runner:
                 binned=(cfg.binned and self.world_size == 1),   # replicas keep the compact layout: one global
                 bin_capacity=cfg.bin_capacity,                  # slack instead of a per-tile one, and no per-rank growth
                 fuse_adam=cfg.fuse_adam, device_refine=dev_refine, capacity=cfg.max_gaussians,
-                flat_multiple=(cfg.dp_chunks * self.world_size * sdist.ShardedFlatAdam.ALIGN if self.world_size > 1 else 0))
+                flat_multiple=(self._dp_chunks * self.world_size * sdist.ShardedFlatAdam.ALIGN if self.world_size > 1 else 0))
             self._sadam = None
             eng.steps_done = step
             eng._step_dev[0] = step
@@ -642,7 +646,7 @@ class Runner:
             eng.set_views(camtoworlds, Ks, pixels, schedule=False)
             eng.fwd_bwd()
             if self._sadam is None or self._sadam.total != eng.flat_total:
-                self._sadam = sdist.ShardedFlatAdam(eng.flat_total, n_chunks=cfg.dp_chunks)
+                self._sadam = sdist.ShardedFlatAdam(eng.flat_total, n_chunks=self._dp_chunks)
             M = eng.M
             sdist.all_reduce_max_(eng.ws["counters"][2 * M + 2:2 * M + 3])   # a void iteration on one rank is raised on all
             self._sadam.step(eng.ws["grads_flat"], eng.ws["params_flat"], eng.adam_on_flat_range)
