@@ -275,8 +275,9 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int,
     periodic (BUILD-DEFINED, like the `spherical` model itself -- the fork that defines it is absent, SURVEY.md
     section 8c): the image is periodic in x with period tile_width * tile_size.  The column range is then not clamped
     to the image but taken modulo tile_width (at most one full turn: a box wider than the image covers every column
-    once), so a footprint that crosses the +-pi seam of an equirectangular panorama reaches the tiles on the other
-    side; `rasterize_to_pixels(periodic=True)` evaluates it there at its nearest copy.
+    once, starting half an image to the left of its centre), so a footprint that crosses the +-pi seam of an
+    equirectangular panorama reaches the tiles on the other side; `rasterize_to_pixels(periodic=True)` evaluates it there
+    at its nearest copy.
     """
     C, N = radii.shape
     m = means2d.detach().to(torch.float32)
@@ -288,9 +289,10 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int,
     if periodic:
         x0 = torch.floor(tx - tile_r).clamp(min=-tile_width).to(torch.int64)
         x1 = torch.ceil(tx + tile_r).clamp(max=2 * tile_width).to(torch.int64)
-        full = (x1 - x0) > tile_width
-        x0 = torch.where(full, torch.zeros_like(x0), x0)
-        x1 = torch.where(full, torch.full_like(x1, tile_width), x1)
+        full = (x1 - x0) > tile_width                 # wider than the image: the tile_width columns centred on the splat
+        xc = torch.floor(tx - 0.5 * tile_width).to(torch.int64)
+        x0 = torch.where(full, xc, x0)
+        x1 = torch.where(full, xc + tile_width, x1)
     else:
         x0 = torch.floor(tx - tile_r).clamp(0, tile_width).to(torch.int64)
         x1 = torch.ceil(tx + tile_r).clamp(0, tile_width).to(torch.int64)

@@ -36,7 +36,10 @@ __device__ __forceinline__ TileBox tile_box(float mx, float my, float radius, fl
   if (wrap) {
     b.x0 = (int)fmaxf(floorf(tx - tile_r), (float)-tile_w);
     b.x1 = (int)fminf(ceilf(tx + tile_r), (float)(2 * tile_w));
-    if (b.x1 - b.x0 > tile_w) { b.x0 = 0; b.x1 = tile_w; }
+    // wider than the image (splats near the poles of a panorama): every column once -- the tile_w VIRTUAL columns centred
+    // on the splat, so that each is within half an image of it and the exact tile test / the rasteriser's nearest copy
+    // mean the same copy (round 2: columns 0 .. tile_w-1 tested the far ones against the wrong copy and culled them)
+    if (b.x1 - b.x0 > tile_w) { b.x0 = (int)floorf(tx - 0.5f * (float)tile_w); b.x1 = b.x0 + tile_w; }
   } else {
   b.x0 = (int)fminf(fmaxf(floorf(tx - tile_r), 0.f), (float)tile_w);
   b.x1 = (int)fminf(fmaxf(ceilf(tx + tile_r), 0.f), (float)tile_w);
