@@ -275,7 +275,7 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int,
     periodic (BUILD-DEFINED, like the `spherical` model itself -- the fork that defines it is absent, SURVEY.md
     section 8c): the image is periodic in x with period tile_width * tile_size.  The column range is then not clamped
     to the image but taken modulo tile_width (at most one full turn: a box wider than the image covers every column
-    once, starting half an image to the left of its centre), so a footprint that crosses the +-pi seam of an
+    once: the tile_width columns whose centres lie within half an image of its centre), so a footprint that crosses the +-pi seam of an
     equirectangular panorama reaches the tiles on the other side; `rasterize_to_pixels(periodic=True)` evaluates it there
     at its nearest copy.
     """
@@ -290,7 +290,7 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int,
         x0 = torch.floor(tx - tile_r).clamp(min=-tile_width).to(torch.int64)
         x1 = torch.ceil(tx + tile_r).clamp(max=2 * tile_width).to(torch.int64)
         full = (x1 - x0) > tile_width                 # wider than the image: the tile_width columns centred on the splat
-        xc = torch.floor(tx - 0.5 * tile_width).to(torch.int64)
+        xc = torch.ceil(tx - 0.5 * tile_width - 0.5).to(torch.int64)     # column centres within half an image of the splat
         x0 = torch.where(full, xc, x0)
         x1 = torch.where(full, xc + tile_width, x1)
     else:

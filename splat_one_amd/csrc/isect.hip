@@ -39,7 +39,8 @@ __device__ __forceinline__ TileBox tile_box(float mx, float my, float radius, fl
     // wider than the image (splats near the poles of a panorama): every column once -- the tile_w VIRTUAL columns centred
     // on the splat, so that each is within half an image of it and the exact tile test / the rasteriser's nearest copy
     // mean the same copy (round 2: columns 0 .. tile_w-1 tested the far ones against the wrong copy and culled them)
-    if (b.x1 - b.x0 > tile_w) { b.x0 = (int)floorf(tx - 0.5f * (float)tile_w); b.x1 = b.x0 + tile_w; }
+    // (the columns whose CENTRES x + 0.5 lie within half an image of the splat: what "nearest copy" means to the rasteriser)
+    if (b.x1 - b.x0 > tile_w) { b.x0 = (int)ceilf(tx - 0.5f * (float)tile_w - 0.5f); b.x1 = b.x0 + tile_w; }
   } else {
   b.x0 = (int)fminf(fmaxf(floorf(tx - tile_r), 0.f), (float)tile_w);
   b.x1 = (int)fminf(fmaxf(ceilf(tx + tile_r), 0.f), (float)tile_w);

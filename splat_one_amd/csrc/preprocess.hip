@@ -163,7 +163,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
         // a panorama is periodic in x: VIRTUAL tile columns (isect.hip::tile_box), filed under wrapx(x) below
         x0 = (int)fmaxf(floorf(tx - tile_r), (float)-tile_w);
         x1 = (int)fminf(ceilf(tx + tile_r), (float)(2 * tile_w));
-        if (x1 - x0 > tile_w) { x0 = (int)floorf(tx - 0.5f * (float)tile_w); x1 = x0 + tile_w; }   // (isect.hip::tile_box)
+        if (x1 - x0 > tile_w) { x0 = (int)ceilf(tx - 0.5f * (float)tile_w - 0.5f); x1 = x0 + tile_w; }   // (isect.hip::tile_box)
       }
       const int y0 = (int)fminf(fmaxf(floorf(ty - tile_r), 0.f), (float)tile_h);
       const int y1 = (int)fminf(fmaxf(ceilf(ty + tile_r), 0.f), (float)tile_h);

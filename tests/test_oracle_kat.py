@@ -262,6 +262,17 @@ def _seam_checks():
     # the C restatement takes the same decision
     rc_c, ra_c, _ = O.rasterization(means, *args, vm, K, W, H, camera_model="spherical", raster_fn=CO.raster_fn())
     assert (rc_c - rc).abs().max() < 1e-12 and (ra_c - ra).abs().max() < 1e-12
+    # a footprint wider than the image: every tile column once, each at the copy nearest to it -- the render is still
+    # periodic, i.e. invariant under a turn of the camera by whole tile columns
+    big = torch.tensor([[0.3, 0.9, -0.6]], dtype=dt)
+    bargs = (quats, torch.tensor([[1.5, 0.2, 0.2]], dtype=dt), torch.tensor([0.8], dtype=dt), torch.tensor([[0.9, 0.5, 0.1]], dtype=dt))
+    rc_w, ra_w, meta_w = O.rasterization(big, *bargs, vm, K, W, H, camera_model="spherical")
+    assert int(meta_w["radii"][0, 0]) > W // 2 and int(meta_w["tiles_per_gauss"][0, 0]) % (W // 16) == 0
+    th2 = 2.0 * math.pi * 32 / W
+    Ry2 = torch.tensor([[math.cos(th2), 0.0, math.sin(th2), 0.0], [0.0, 1.0, 0.0, 0.0],
+                        [-math.sin(th2), 0.0, math.cos(th2), 0.0], [0.0, 0.0, 0.0, 1.0]], dtype=dt)
+    rc_w2, _, _ = O.rasterization(big, *bargs, Ry2[None] @ vm, K, W, H, camera_model="spherical", raster_fn=CO.raster_fn())
+    assert (torch.roll(rc_w, 32, dims=2) - rc_w2).abs().max() < 1e-9
     # when the tile grid does not line up (W % tile_size != 0) the image is not periodic: the blob is cut at the edge
     W2 = 120
     _, ra2, meta2 = O.rasterization(means, *args, vm, K, W2, H, camera_model="spherical")
