@@ -1,6 +1,8 @@
 """Packed mode (`packed=True`, gsplat's default; `Config.packed` / `Config.sparse_grad` at gsplat_trainer.py:132-135,
 487-489, 705-724, 751): one row per (camera, Gaussian) pair with a positive radius.  The packed call must give the
 images, gradients, tile lists and densification statistics of the dense [C,N] call on the same inputs."""
+import math
+
 import pytest
 import torch
 
@@ -213,3 +215,38 @@ def test_packed_against_the_oracle(dev, C, sparse_grad, camera_model):
         floor = 1e-5 * q["scales"].grad.norm().item() if k == "quats" else 0.0
         err = (gk.detach().cpu().double() - q[k].grad.double()).norm().item()
         assert err <= 1e-3 * q[k].grad.norm().item() + floor, (k, err)
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_packed_projection_random_sizes(dev, seed):
+    """`fully_fused_projection(packed=True)` (count / scan / write passes over 1024-pair blocks) against the dense call on
+    sizes around the block, workgroup and wave boundaries, several cameras, all camera models: the same pairs in the
+    same (camera-major) order with the same values."""
+    import random
+    from splat_one_amd.ops import fully_fused_projection
+    rnd = random.Random(40 + seed)
+    C = rnd.choice([1, 2, 3, 5])
+    N = rnd.choice([1, 63, 64, 65, 255, 1023, 1024, 1025, 2047, 2049, rnd.randint(2, 6000), rnd.randint(2, 6000)])
+    model = rnd.choice(["pinhole", "fisheye", "ortho", "spherical"])
+    W, H = rnd.randint(40, 300), rnd.randint(30, 200)
+    g = torch.Generator().manual_seed(500 + seed)
+    means = ((torch.rand(N, 3, generator=g) * 2 - 1) * 3).to(dev)
+    quats = torch.randn(N, 4, generator=g).to(dev)
+    scales = (torch.rand(N, 3, generator=g) * 0.3 + 0.02).to(dev)
+    from splat_one_amd.scene import lookat_c2w
+    c2w = torch.stack([lookat_c2w((7.0 * math.sin(1.3 * i + seed), 0.4 * i - 0.6, -7.0 * math.cos(1.3 * i + seed))) for i in range(C)])
+    viewmats = torch.linalg.inv(c2w).to(dev)
+    f = (0.05 if model == "ortho" else 0.9) * max(W, H)
+    Ks = torch.tensor([[f, 0, W / 2.0], [0, f, H / 2.0], [0, 0, 1]])[None].repeat(C, 1, 1).to(dev)
+    kw = dict(eps2d=0.3, near_plane=0.01, far_plane=1e8, radius_clip=rnd.choice([0.0, 0.0, 2.0]), camera_model=model,
+              calc_compensations=rnd.random() < 0.5)
+    radii, m2, dep, con, comp = fully_fused_projection(means, None, quats, scales, viewmats, Ks, W, H, packed=False, **kw)
+    cam, gid, radii_p, m2_p, dep_p, con_p, comp_p = fully_fused_projection(means, None, quats, scales, viewmats, Ks, W, H, packed=True, **kw)
+    wc, wg = torch.nonzero(radii > 0, as_tuple=True)
+    assert torch.equal(cam, wc) and torch.equal(gid, wg), (C, N, model)
+    assert torch.equal(radii_p, radii[wc, wg])
+    # values: two compilations of the same arithmetic (the packed kernel and the dense one), equal to rounding
+    close = lambda a, b: bool(((a - b).abs() <= 1e-4 * b.abs() + 1e-4).all())    # (pixels / conic entries: a few ulp)
+    assert close(m2_p, m2[wc, wg]) and close(dep_p, dep[wc, wg]) and close(con_p, con[wc, wg])
+    if comp is not None:
+        assert close(comp_p, comp[wc, wg])

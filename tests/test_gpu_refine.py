@@ -357,3 +357,23 @@ def test_compact_lists_with_device_refinement_train_like_binned_lists(dev):
     assert l_c[9] < l_c[1]                                         # it trains (before the refinements / the opacity reset at 20)
     assert max(abs(a - b) for a, b in zip(l_b[:10], l_c[:10])) < 2e-4 * max(l_b)      # identical until the first refinement
     assert max(abs(a - b) for a, b in zip(l_b, l_c)) < 0.03 * max(l_b)
+
+
+@pytest.mark.parametrize("seed", list(range(20)))
+def test_refine_kernel_random_sizes_and_thresholds(dev, seed):
+    """The compaction kernels against the oracle on random sizes (wave / workgroup / chunk boundaries included), SH
+    sizes, thresholds, both prune regimes and both opacity rules."""
+    import random
+    rnd = random.Random(300 + seed)
+    N = rnd.choice([1, 2, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097, rnd.randint(3, 9000), rnd.randint(3, 9000)])
+    K = rnd.choice([1, 4, 9, 16])
+    step = rnd.choice([700, 3100])
+    revised = rnd.random() < 0.5
+    thr = dict(grow_grad2d=rnd.choice([5e-5, 2e-4, 1e-3]), grow_scale3d=rnd.choice([0.005, 0.01, 0.05]),
+               prune_opa=rnd.choice([0.0, 0.005, 0.05, 0.3]), prune_scale3d=rnd.choice([0.05, 0.1, 0.5]))
+    scene_scale = rnd.choice([0.7, 1.0, 2.5])
+    P, M, V, g2, cn = _random_model(N, K=K, seed=1000 + seed)
+    cap = 4 * N + 1024
+    out, n_new, rep, (g2_after, cn_after) = _device_refine(dev, P, M, V, g2, cn, cap, step, scene_scale, seed=seed * 7919 + 1, revised=revised, **thr)
+    _compare(out, n_new, rep, P, M, V, g2, cn, step, scene_scale, seed * 7919 + 1, revised=revised, **thr)
+    assert not g2_after.any() and not cn_after.any()
