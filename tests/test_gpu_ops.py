@@ -612,3 +612,71 @@ def test_strategy_update_state_kernel(dev):
     assert torch.equal(state["count"].cpu().double(), cn)
     r_want = torch.maximum(r_0, (radii.double() / max(W, H)).max(dim=0).values * (radii > 0).any(dim=0))
     assert (state["radii"].cpu().double() - r_want).abs().max().item() < 1e-7
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_isect_random_inputs_bit_exact(dev, seed):
+    """`isect_tiles` on random centres / radii / depths -- image sizes that are and are not multiples of the tile, both
+    tile sizes, several cameras, periodic images with footprints up to wider than the image -- bit for bit against the
+    oracle: counts, sorted keys, ids, offsets, and the unsorted emission order."""
+    import random
+    from splat_one_amd.ops import isect_tiles
+    rnd = random.Random(70 + seed)
+    ts = rnd.choice([16, 16, 8])
+    periodic = rnd.random() < 0.5
+    tw, th = rnd.randint(2, 14), rnd.randint(1, 9)
+    W, H = (tw * ts, th * ts - rnd.randint(0, ts - 1)) if periodic else (tw * ts - rnd.randint(0, ts - 1), th * ts - rnd.randint(0, ts - 1))
+    C, N = rnd.choice([1, 2, 3]), rnd.choice([1, 17, 300, 2500])
+    g = torch.Generator().manual_seed(800 + seed)
+    m2 = torch.rand(C, N, 2, generator=g) * torch.tensor([W * 1.2, H * 1.2]) - torch.tensor([W * 0.1, H * 0.1])
+    if periodic:
+        m2[..., 0] = m2[..., 0].remainder(W)          # a panorama's centres lie inside the image
+    big = rnd.choice([6, 40, int(0.8 * W)])
+    radii = (torch.rand(C, N, generator=g) ** 2 * big).to(torch.int32) * (torch.rand(C, N, generator=g) < 0.85)
+    radii = radii.to(torch.int32)
+    dep = torch.rand(C, N, generator=g) * 5 + 0.1
+    dep[:, ::7] = dep[:, :1].clone()                 # depth ties: the order falls back on the id
+    tpg_o, ids_o, flat_o = O.isect_tiles(m2, radii, dep, ts, tw, th, periodic=periodic)
+    off_o = O.isect_offset_encode(ids_o, C, tw, th)
+    tpg_h, ids_h, flat_h, off_h = isect_tiles(m2.to(dev), radii.to(dev), dep.to(dev), ts, tw, th, return_offsets=True, periodic=periodic)
+    assert torch.equal(tpg_h.cpu(), tpg_o) and torch.equal(ids_h.cpu(), ids_o) and torch.equal(flat_h.cpu(), flat_o)
+    assert torch.equal(off_h.cpu(), off_o)
+    _, ids_u_o, flat_u_o = O.isect_tiles(m2, radii, dep, ts, tw, th, sort=False, periodic=periodic)
+    _, ids_u_h, flat_u_h = isect_tiles(m2.to(dev), radii.to(dev), dep.to(dev), ts, tw, th, sort=False, periodic=periodic)
+    assert torch.equal(ids_u_h.cpu(), ids_u_o) and torch.equal(flat_u_h.cpu(), flat_u_o)
+
+
+@pytest.mark.parametrize("seed", list(range(14)))
+def test_photometric_loss_random_sizes(dev, seed):
+    """L1 + SSIM forward / backward on random image sizes around the kernels' strip boundaries (256 floats of a row, 36
+    rows), down to images smaller than the 11x11 window, batch and channel counts, both paddings, several lambdas."""
+    import random
+    from splat_one_amd.losses import fused_ssim, photometric_loss
+    from oracle import ssim_oracle as SO
+    rnd = random.Random(900 + seed)
+    CH = rnd.choice([3, 3, 1, 4])
+    B = rnd.choice([1, 1, 2, 3])
+    W = rnd.choice([11, 12, 23, 85, 86, 255 // CH, 256 // CH + 1, 171, rnd.randint(11, 300)])
+    H = rnd.choice([11, 13, 35, 36, 37, 46, 72, 73, rnd.randint(11, 150)])
+    lam = rnd.choice([0.2, 0.0, 1.0, 0.5])
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, H, W, CH, generator=g)
+    y = (x + 0.2 * torch.randn(B, H, W, CH, generator=g)).clamp(0, 1)
+    if CH == 3:
+        xh = x.to(dev).requires_grad_()
+        loss_h, l1_h, ss_h = photometric_loss(xh, y.to(dev), lam)
+        (loss_h * 2.0).backward()
+        xo = x.double().requires_grad_()
+        loss_o, l1_o, ss_o = SO.photometric_loss(xo, y, lam)
+        (loss_o * 2.0).backward()
+        assert abs(loss_h.item() - loss_o.item()) < 3e-6 and abs(l1_h.item() - l1_o.item()) < 3e-6 and abs(ss_h.item() - ss_o.item()) < 3e-6
+        assert rel_err(xh.grad, xo.grad) < 1e-4, (B, H, W, lam)
+    padding = rnd.choice(["same", "valid"])
+    xh = x.permute(0, 3, 1, 2).contiguous().to(dev).requires_grad_()
+    v_h = fused_ssim(xh, y.permute(0, 3, 1, 2).contiguous().to(dev), padding=padding)
+    v_h.backward()
+    xo = x.permute(0, 3, 1, 2).double().requires_grad_()
+    v_o = SO.fused_ssim(xo, y.permute(0, 3, 1, 2), padding=padding)
+    v_o.backward()
+    assert abs(v_h.item() - v_o.item()) < 3e-6, (B, CH, H, W, padding)
+    assert rel_err(xh.grad, xo.grad) < 1e-4, (B, CH, H, W, padding)
