@@ -118,6 +118,19 @@ def _global_perturbation(N):
 
 
 MIXED_MODELS = ["pinhole", "fisheye"]
+PANO_MODELS = ["spherical", "pinhole"]       # rank 0 owns a panorama camera inside the cloud (periodic image: 128 % 16 == 0)
+
+
+def _models(mixed):
+    return PANO_MODELS if mixed == "pano" else (MIXED_MODELS if mixed else None)
+
+
+def _sharded_cameras(mixed, n):
+    c2w = ring_cameras(8)[:n].clone()
+    if mixed == "pano":
+        c2w[0] = torch.eye(4)
+        c2w[0, :3, 3] = torch.tensor([0.3, -0.2, 0.1])
+    return c2w
 
 
 def _sharded_worker(local_rank, world_rank, world_size, args):
@@ -127,7 +140,7 @@ def _sharded_worker(local_rank, world_rank, world_size, args):
     W, H, N = 128, 96, 3001                           # odd: the shards differ in length (1501 / 1500)
     cfg = Config(init_num_pts=N, init_scale=0.3, init_opa=0.3, sh_degree_interval=1, fused=True, opacity_reg=0.01,
                  scale_reg=0.01, dp_mode="gaussian_sharded",
-                 camera_model=(MIXED_MODELS[world_rank] if mixed else "pinhole"), attr_dtype=("f16" if mixed else "f32"))
+                 camera_model=(_models(mixed)[world_rank] if mixed else "pinhole"), attr_dtype=("f16" if mixed is True else "f32"))
     r = Runner(0, world_rank, world_size, cfg, scene_scale=1.0 / 1.1)
     assert r.sharded and len(r.splats["means"]) == len(range(world_rank, N, world_size))
     ds, q, sh = _global_perturbation(N)
@@ -135,7 +148,7 @@ def _sharded_worker(local_rank, world_rank, world_size, args):
         r.splats["scales"].add_(ds[world_rank::world_size].to(dev))
         r.splats["quats"].copy_(q[world_rank::world_size].to(dev))
         r.splats["shN"].copy_(sh[world_rank::world_size].to(dev))
-    c2w = ring_cameras(8)[:world_size].to(dev)         # the cameras of ALL ranks
+    c2w = _sharded_cameras(mixed, world_size).to(dev)  # the cameras of ALL ranks
     Ks = pinhole_K(W, H)[None].repeat(world_size, 1, 1).to(dev)
     pixels = torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(100 + world_rank)).to(dev)
     losses = []
@@ -148,7 +161,7 @@ def _sharded_worker(local_rank, world_rank, world_size, args):
                 "loss": torch.stack(losses).cpu(), "stats": st}, os.path.join(out_dir, f"rank{world_rank}.pt"))
 
 
-@pytest.mark.parametrize("mixed", [False, True])
+@pytest.mark.parametrize("mixed", [False, True, "pano"])
 def test_gaussian_sharded_dp_two_ranks_one_gpu(dev, tmp_path, mixed):
     """world_size 2 over gloo with HIP tensors: the two shards, trained with the all-to-all exchange of
     projected Gaussians, equal the corresponding rows of a single-process batch-of-2 run.  mixed: rank 0 owns a
@@ -166,15 +179,15 @@ def test_gaussian_sharded_dp_two_ranks_one_gpu(dev, tmp_path, mixed):
     out = [torch.load(os.path.join(tmp_path, f"rank{i}.pt")) for i in range(2)]
     W, H, N = 128, 96, 3001
     cfg = Config(init_num_pts=N, init_scale=0.3, init_opa=0.3, sh_degree_interval=1, fused=True, batch_size=2,
-                 opacity_reg=0.01, scale_reg=0.01, camera_model=(MIXED_MODELS if mixed else "pinhole"),
-                 attr_dtype=("f16" if mixed else "f32"))
+                 opacity_reg=0.01, scale_reg=0.01, camera_model=(_models(mixed) if mixed else "pinhole"),
+                 attr_dtype=("f16" if mixed is True else "f32"))
     r = Runner(0, 0, 1, cfg, scene_scale=1.0 / 1.1)
     ds, q, sh = _global_perturbation(N)
     with torch.no_grad():
         r.splats["scales"].add_(ds.to(dev))
         r.splats["quats"].copy_(q.to(dev))
         r.splats["shN"].copy_(sh.to(dev))
-    c2w = ring_cameras(8)[0:2].to(dev)
+    c2w = _sharded_cameras(mixed, 2).to(dev)
     Ks = pinhole_K(W, H)[None].repeat(2, 1, 1).to(dev)
     pixels = torch.cat([torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(100 + i)) for i in range(2)]).to(dev)
     ref_loss = []
