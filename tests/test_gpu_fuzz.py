@@ -31,7 +31,9 @@ def _case(seed):
     bg = rnd.random() < 0.4
     packed = rnd.random() < 0.35
     scale = rnd.choice([0.08, 0.2, 0.5])
-    return dict(model=model, tile=tile, W=W, H=H, C=C, N=N, deg=deg, mode=mode, aa=aa, bg=bg, packed=packed, scale=scale)
+    static = (not packed) and rnd.random() < 0.3          # the sync-free binning into caller-sized buffers
+    return dict(model=model, tile=tile, W=W, H=H, C=C, N=N, deg=deg, mode=mode, aa=aa, bg=bg, packed=packed, scale=scale,
+                static=static)
 
 
 @pytest.mark.parametrize("seed", list(range(36)))
@@ -65,7 +67,10 @@ def test_random_configuration_against_the_oracle(dev, seed):
         grads = [(torch.zeros_like(t) if t.grad is None else t.grad).detach().cpu().double() for t in p]   # (depth-only modes: no SH gradient)
         return rc.detach().cpu().double(), ra.detach().cpu().double(), grads, meta
 
-    rc_h, ra_h, g_h, m_h = run(rasterization, dev, torch.float32, packed=cfg["packed"])
+    extra = {"isect_capacity": 400_000, "workspace": {}} if cfg["static"] else {}
+    rc_h, ra_h, g_h, m_h = run(rasterization, dev, torch.float32, packed=cfg["packed"], **extra)
+    if cfg["static"]:
+        assert int(m_h["isect_overflow"].item()) == 0 and 0 < int(m_h["n_isects"].item()) <= 400_000
     # the oracle sorts by the device's float32 depth keys
     if cfg["packed"]:
         keys = torch.full((C, N), 1e30)
