@@ -623,15 +623,17 @@ class Runner:
                 lr_gamma_means=self.lr_gamma,
                 isect_capacity=cfg.isect_capacity, use_graph=True,
                 attr_dtype=cfg.attr_dtype, tile_cull=cfg.tile_cull,
-                binned=(cfg.binned and self.world_size == 1),   # replicas keep the compact layout: one global
-                bin_capacity=cfg.bin_capacity,                  # slack instead of a per-tile one, and no per-rank growth
+                binned=cfg.binned, bin_capacity=cfg.bin_capacity,
                 fuse_adam=cfg.fuse_adam, device_refine=dev_refine, capacity=cfg.max_gaussians,
                 flat_multiple=(self._dp_chunks * self.world_size * sdist.ShardedFlatAdam.ALIGN if self.world_size > 1 else 0))
             self._sadam = None
             eng.steps_done = step
             eng._step_dev[0] = step
             if self.world_size > 1:
-                eng.on_overflow = "raise"        # replicas must not diverge: no silent per-rank buffer growth
+                # replicas must not diverge: an overflow (of a tile's bin, or of the compact buffers) is flagged on every rank
+                # (all_reduce_max below) and stops the run instead of growing buffers per rank -- the sharded Adam that follows
+                # the reduce-scatter is scheduled by the host and cannot take an iteration back
+                eng.on_overflow = "raise"
         eng.set_sh_degree(min(step // cfg.sh_degree_interval, cfg.sh_degree))
         # densification statistics are accumulated inside the backward kernel while refinement is active
         stats_on = isinstance(s, DefaultStrategy) and step < s.refine_stop_iter
