@@ -359,3 +359,49 @@ def test_load_checkpoint_resumes_schedule_and_state(dev, tmp_path):
         assert abs(lr7 / (r2.means_lr0 * r2.lr_gamma ** 7) - 1) < 1e-5, (fused, lr7)
         assert float(r2.optimizers["means"].state[r2.splats["means"]]["step"]) == 7.0
         assert r2.strategy_state["grad2d"].shape[0] == 1500
+
+
+def _dp_refine_worker(local_rank, world_rank, world_size, out_dir):
+    from splat_one_amd.strategy import DefaultStrategy
+    from splat_one_amd.trainer import Config, Runner
+    dev = torch.device("cuda:0")
+    W, H, N = 128, 96, 3000
+    strat = DefaultStrategy(refine_start_iter=4, refine_every=4, reset_every=10, grow_grad2d=5e-5, verbose=False)
+    cfg = Config(init_num_pts=N, init_scale=0.3, init_opa=0.3, shN_init_std=0.05, sh_degree_interval=1, fused=True,
+                 dp_mode="allreduce", strategy=strat)
+    r = Runner(0, world_rank, world_size, cfg, scene_scale=1.0 / 1.1)
+    with torch.no_grad():
+        r.splats["scales"].add_((torch.randn(N, 3, generator=torch.Generator().manual_seed(7)) * 0.4).to(dev))
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
+    pixels = torch.stack([(xx + 0.2 * world_rank) % 1, yy, 0.5 * (xx + yy)], -1)[None].to(dev).contiguous()
+    Ks = pinhole_K(W, H)[None].to(dev)
+    sizes = []
+    for step in range(18):                                   # refinements at 8, 12, 16; opacity reset at 10
+        v = (2 * step + world_rank) % 8
+        r.train_step(ring_cameras(8)[v:v + 1].to(dev), Ks, pixels)
+        sizes.append(len(r.splats["means"]))
+    torch.cuda.synchronize()
+    st = {k: r.optimizers[k].state[r.splats[k]] for k in r.splats.keys()}
+    torch.save({"splats": {k: v.detach().cpu() for k, v in r.splats.items()}, "sizes": sizes,
+                "m": {k: st[k]["exp_avg"].cpu() for k in st}, "step": {k: float(st[k]["step"]) for k in st}},
+               os.path.join(out_dir, f"rank{world_rank}.pt"))
+
+
+def test_replicated_dp_refinement_keeps_the_replicas_identical(dev, tmp_path):
+    """Replicated data parallelism through refinements: the statistics are all-reduced, the sharded Adam moments gathered,
+    and every rank then duplicates / splits / prunes identically -- the Gaussian sets stay bit-identical across ranks
+    while their size changes, and the reduce-scatter / sharded Adam / all-gather step goes on on the new size."""
+    from splat_one_amd import distributed as sdist
+    env_backup = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        sdist.cli(_dp_refine_worker, str(tmp_path), world_size=2, backend="gloo", port=_free_port())
+    finally:
+        for k, v in env_backup.items():
+            if v is not None:
+                os.environ[k] = v
+    a = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    b = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    assert a["sizes"] == b["sizes"] and len(set(a["sizes"])) >= 3, a["sizes"]
+    for k in a["splats"]:
+        assert torch.equal(a["splats"][k], b["splats"][k]) and torch.isfinite(a["splats"][k]).all(), k
+        assert a["step"][k] == b["step"][k] == 18.0
