@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--views", type=int, default=8, help="ring cameras / target images cycled per GPU (the reference draws a new view per step)")
     ap.add_argument("--attr-dtype", default="f32", choices=["f32", "f16"],
                     help="f16: float16 attribute rows (BASELINE.json configs[4]); float32 arithmetic and masters")
+    ap.add_argument("--loss-kernels", type=int, default=1, choices=[1, 2],
+                    help="fused step: 1 = so_ssim_l1_fused (loss and gradient in one launch); 2 = the so_ssim_l1_fwd/bwd pair")
     ap.add_argument("--dp-mode", default="allreduce", choices=["auto", "gaussian_sharded", "allreduce"],
                     help="multi-GPU scheme of the headline value (ignored at --gpus 1): allreduce (= auto) -- replicated "
                          "Gaussians, reduce-scatter / sharded Adam / all-gather of the gradient SoA, BASELINE.json's "
@@ -146,7 +148,8 @@ def main():
     def make_runner(dp_mode):
         cfg = Config(init_num_pts=N, init_scale=init_scale, init_opa=init_opa, batch_size=1, shN_init_std=0.1,
                      camera_model="pinhole", sh_degree_interval=1,    # SH degree 3 from step 3 on
-                     fused=not args.operator_path, dp_mode=dp_mode, attr_dtype=args.attr_dtype)
+                     fused=not args.operator_path, dp_mode=dp_mode, attr_dtype=args.attr_dtype,
+                     loss_kernels=args.loss_kernels)
         if args.densify:
             from splat_one_amd.strategy import DefaultStrategy
             cfg.strategy = DefaultStrategy(refine_start_iter=0, refine_every=args.densify, reset_every=3000, verbose=False)
@@ -360,6 +363,7 @@ def main():
     ab["so_isect_scan"] = 8 * (W // 16 + 1) * (H // 16 + 1)
     ab["so_ssim_l1_fwd"] = 24 * P + 36 * P
     ab["so_ssim_l1_bwd"] = 60 * P + 12 * P
+    ab["so_ssim_l1_fused"] = 24 * P + 12 * P          # two images in, one gradient image out
     b_iter = sum(ab[k] for k in ("so_projection_fwd", "so_sh_fwd", "so_isect_count", "so_isect_fill", "so_rasterize_fwd",
                                  "so_rasterize_bwd", "so_sh_bwd", "so_projection_bwd", "so_adam_step"))
     dominant = dominant.replace("_packed", "")          # the packed-record entry points share the byte model

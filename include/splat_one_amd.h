@@ -407,8 +407,9 @@ int so_preprocess_bwd_f16(int C, int N, int K, int sh_degree, const float *means
 /* ------------------------------------------------------------------------------------------
  * One training iteration (gsplat_trainer.py:586-655: render -> loss -> backward) as ONE call on
  * caller-owned static buffers: memsets + 11 launches, no allocation, no host read-back, capturable
- * in a hipGraph.  Gradients of the raw parameters are overwritten; loss_sums[5] = (sum|x-y|,
- * sum SSIM_valid, loss, l1, 1-SSIM).  counters: int32[2*C*tiles + 3] (histogram | cursor | long-list length |
+ * in a hipGraph.  Gradients of the raw parameters are overwritten; loss_sums[6] = (sum|x-y|,
+ * sum SSIM_valid, loss, l1, 1-SSIM, ticket of so_ssim_l1_fused: an int32 that is 0 before the first step).  dmaps
+ * NULL: the loss is the single kernel so_ssim_l1_fused; dmaps[3,C,H,W,3] given: the so_ssim_l1_fwd/bwd pair.  counters: int32[2*C*tiles + 3] (histogram | cursor | long-list length |
  * n_isects | overflow);
  * zero_v_alphas: float[C*H*W] of zeros (the photometric loss does
  * not depend on alpha).  `abi_size` must be sizeof(so_step_desc).
@@ -428,7 +429,7 @@ typedef struct so_step_desc {
   int32_t *flatten_ids;
   float *render_colors, *render_alphas;
   int32_t *last_ids;
-  float *loss_sums /* [2] sums then [3] loss, l1, ssimloss */, *dmaps, *v_render_colors;
+  float *loss_sums /* [2] sums, [3] loss, l1, ssimloss, [1] int32 ticket */, *dmaps /* nullable */, *v_render_colors;
   const float *zero_v_alphas;
   float *rec, *vrec; /* [C*N][16] packed records, 64-byte aligned */
   /* gradients of the raw parameters */
@@ -601,6 +602,14 @@ int so_ssim_l1_fwd(int B, int H, int W, int CH, const float *img1, const float *
 int so_ssim_l1_bwd(int B, int H, int W, int CH, const float *img1, const float *img2, const float *dmaps,
                    float w_l1, float w_ssim, const float *v_loss, float *v_img1, const float *sums,
                    float *loss_out, int padding_valid, float loss_const, void *stream);
+/* Both in ONE launch, for callers that need the gradient right away (the training step): two chained row-streaming
+ * stages per workgroup, the derivative values pass through LDS instead of dmaps.  sums[2] (zeroed by the caller) and
+ * v_img1 as above.  loss_out[3] (nullable) is written by the workgroup that finishes last; it needs `ticket`: one
+ * int32 that is 0 before the first launch (the kernel returns it to 0) and is not shared by launches that can
+ * overlap.  rows = output rows per workgroup, 0 = as few as keep the whole grid resident at once. */
+int so_ssim_l1_fused(int B, int H, int W, int CH, const float *img1, const float *img2, int padding_valid,
+                     float w_l1, float w_ssim, const float *v_loss, float *sums, float *v_img1, float *loss_out,
+                     int32_t *ticket, float loss_const, int rows, void *stream);
 
 #ifdef __cplusplus
 }

@@ -87,6 +87,8 @@ _SIGS = {
     "so_rasterize_bwd": [c_int] * 6 + [c_ptr] * 9 + [c_i64] + [c_ptr] * 10,
     "so_ssim_l1_fwd": [c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr],
     "so_ssim_l1_bwd": [c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_f32, c_ptr],
+    "so_ssim_l1_fused": [c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_f32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_int,
+                         c_ptr],
     "so_camera_inverse": [c_int, c_ptr, c_ptr, c_ptr],
     "so_debug_wave_reduce": [c_int, c_ptr, c_ptr, c_ptr],
     "so_isect_scan": [c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],

@@ -450,6 +450,251 @@ k_ssim_l1_bwd(int B, int H, int W, const float *__restrict__ img1, const float *
 #undef SO_STEP
 }
 
+// ------------------------------------------------------------------------------------ fused: loss and gradient in one kernel
+// Two chained row-streaming stages in one workgroup, no derivative maps in HBM:
+//   stage 1 = k_ssim_l1_fwd's step: input row -> LDS line A -> 11 horizontal taps -> register ring -> vertical taps ->
+//             SSIM value and the three derivative values of the row 5 above; they go to LDS line B;
+//   stage 2 = k_ssim_l1_bwd's step on line B (one step later, so that one barrier per step serves both lines):
+//             11 horizontal taps -> second register ring -> vertical taps -> gradient of the row 5 further up.
+// Cost of fusing: an output row needs derivative rows +-5, which need input rows +-10, and the same in columns: a
+// workgroup of kT floats x `rows` rows stages rows+20 input rows and runs stage 1 over rows+10 of them, but emits only
+// kT - 10*CH floats x rows; both rings live in registers (77 values, 244 VGPRs, two waves per SIMD).  `rows` is a
+// run-time argument chosen so that the whole grid is resident at once (57 at 1080p RGB: 26 x 19 workgroups on 512
+// slots).  Measured at 1080p RGB (tools/probes/ssim_bench.hip, profiles/r02_experiments.json): 90 us against
+// 52 + 47 us for the pair; with 45 or 108 rows per workgroup 111 / 131 us.
+#ifndef SO_FUSED_WAVES
+#define SO_FUSED_WAVES 2
+#endif
+#ifndef SO_FUSED_TAPGROUP
+#define SO_FUSED_TAPGROUP 6
+#endif
+constexpr int kFusedWaves = SO_FUSED_WAVES;
+constexpr int kFusedTapGroup = SO_FUSED_TAPGROUP;
+
+template <int CH>
+constexpr int fused_out_floats() { return kT - 2 * kHalf * CH; }
+template <int CH>
+constexpr int line_b_slots() { return kT + 2 * kHalf * CH; }
+
+template <int CH>
+struct FusedState {
+  v2f r1[kWin][2];   // stage 1: (blur_x mu1, mu2), (blur_x E[x^2+y^2], E[xy]) per input row
+  v2f r2a[kWin];     // stage 2: blur_x of (g_mu, dm_dE) per derivative row
+  float r2b[kWin];   //          blur_x of dm_dB2
+  float l1_acc, ss_acc;
+};
+
+struct FusedOut {
+  unsigned off;      // the thread's float inside an image row (clamped)
+  float cmask;       // float inside the row (and inside the crop): stage-1 derivative values are kept
+  float sum_l1;      // float counted in the L1 sum  (inside the row, inner thread)
+  float sum_ss;      // float counted in the SSIM sum (cmask, inner thread)
+  bool store;        // stage 2 writes this float
+};
+
+// One step = one input row.  MODE 0: stage-1 horizontal only; 1: + stage-1 vertical, line B written; 2: + stage-2
+// horizontal; 3: + stage-2 vertical and the output row.  Step `it` handles input row y0-10+it, derivative row
+// y0-15+it (written to line B), reads derivative row y0-16+it from line B, and emits output row y0-21+it.
+template <int CH, int P, int MODE>
+__device__ __forceinline__ void fused_step(FusedState<CH> &S, FwdStage<CH> &preA, FwdStage<CH> &preB,
+                                           v4f (*rowsA)[lds_line_slots<CH>()], v4f (*rowsB)[line_b_slots<CH>()],
+                                           const StageGeom<CH> &g, const FusedOut &o, const float *img1, const float *img2,
+                                           int it, int n_out, int H, int W, int y0, int tid, int valid, const Window &win,
+                                           float wl1, float wss, float *__restrict__ v_img1) {
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+  {
+    fwd_lstore<CH>(preA, g, rowsA[(it + 1) & 1], tid, y0 - 2 * kHalf + it + 1, H);
+    preA = preB;
+    fwd_gload<CH>(preB, g, img1, img2, H, W * CH, y0 - 2 * kHalf + it + 3);
+  }
+  float xv = 0.f, yv = 0.f;
+  unsigned orow = 0;
+  if constexpr (MODE == 3) {
+    orow = (unsigned)((y0 + it - 21) * (W * CH));
+    xv = (img1 + orow)[o.off];
+    yv = (img2 + orow)[o.off];
+  }
+  // ---- stage 1, horizontal
+  {
+    const v4f *R = rowsA[it & 1] + tid;
+    v2f m = {0.f, 0.f}, q = {0.f, 0.f};
+    float ctr_abs = 0.f;
+#pragma unroll
+    for (int k0 = 0; k0 < kWin; k0 += kFusedTapGroup) {
+      v4f t[kFusedTapGroup];
+#pragma unroll
+      for (int j = 0; j < kFusedTapGroup; ++j)
+        if (k0 + j < kWin) t[j] = R[(k0 + j) * CH];
+#pragma unroll
+      for (int j = 0; j < kFusedTapGroup; ++j)
+        if (k0 + j < kWin) {
+          m = pk_fma(win.w[k0 + j], v2f{t[j].x, t[j].y}, m);
+          q = pk_fma(win.w[k0 + j], v2f{t[j].z, t[j].w}, q);
+          if (k0 + j == kHalf) ctr_abs = fabsf(t[j].x - t[j].y);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    S.r1[P][0] = m; S.r1[P][1] = q;
+    const float l1m = (it >= 2 * kHalf && it < n_out + 2 * kHalf) ? o.sum_l1 : 0.f;
+    S.l1_acc = fmaf(ctr_abs, l1m, S.l1_acc);
+  }
+  // ---- stage 1, vertical: SSIM and its derivatives at row y0-15+it -> line B
+  if constexpr (MODE >= 1) {
+    const int y = y0 + it - 3 * kHalf;
+    v2f mu = {0.f, 0.f}, sq = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < kWin; ++k) {
+      const int slot = (P + 1 + k) % kWin;
+      mu = pk_fma(win.w[k], S.r1[slot][0], mu);
+      sq = pk_fma(win.w[k], S.r1[slot][1], sq);
+    }
+    const float mu1 = mu.x, mu2 = mu.y;
+    const float musq = fmaf(mu1, mu1, mu2 * mu2), m12 = mu1 * mu2;
+    const float Av = fmaf(2.f, m12, kC1), Bv = fmaf(2.f, sq.y - m12, kC2);
+    const float D = musq + kC1, E = (sq.x - musq) + kC2;
+    const float rD = fast_rcp(D), rE = fast_rcp(E), rDE = rD * rE;
+    const float ssim = Av * Bv * rDE;
+    const bool row_ok = y >= 0 && y < H && (!valid || (y >= kHalf && y < H - kHalf));
+    const float rowc = row_ok ? o.cmask : 0.f;
+    const float cnt = (row_ok && it >= 3 * kHalf && it < n_out + 3 * kHalf) ? o.sum_ss : 0.f;
+    S.ss_acc = fmaf(ssim, cnt, S.ss_acc);
+    const float dm_dA = Bv * rDE * rowc, dm_dB2 = 2.f * Av * rDE * rowc;
+    const float dm_dD = -ssim * rD * rowc, dm_dE = -ssim * rE * rowc;
+    const float g_mu = 2.f * (mu2 * dm_dA + mu1 * (dm_dD - dm_dE)) - mu2 * dm_dB2;
+    rowsB[it & 1][tid + kHalf * CH] = v4f{g_mu, dm_dE, dm_dB2, 0.f};
+  }
+  // ---- stage 2, horizontal over the derivative row written in the previous step
+  if constexpr (MODE >= 2) {
+    const v4f *R = rowsB[(it - 1) & 1] + tid;
+    v2f ac = {0.f, 0.f};
+    float d = 0.f;
+#pragma unroll
+    for (int k0 = 0; k0 < kWin; k0 += kFusedTapGroup) {
+      v4f t[kFusedTapGroup];
+#pragma unroll
+      for (int j = 0; j < kFusedTapGroup; ++j)
+        if (k0 + j < kWin) t[j] = R[(k0 + j) * CH];
+#pragma unroll
+      for (int j = 0; j < kFusedTapGroup; ++j)
+        if (k0 + j < kWin) {
+          ac = pk_fma(win.w[k0 + j], v2f{t[j].x, t[j].y}, ac);
+          d = fmaf(win.w[k0 + j], t[j].z, d);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    S.r2a[P] = ac; S.r2b[P] = d;
+  }
+  // ---- stage 2, vertical: gradient of output row y0-21+it
+  if constexpr (MODE == 3) {
+    v2f vac = {0.f, 0.f};
+    float vd = 0.f;
+#pragma unroll
+    for (int k = 0; k < kWin; ++k) {
+      const int slot = (P + 1 + k) % kWin;
+      vac = pk_fma(win.w[k], S.r2a[slot], vac);
+      vd = fmaf(win.w[k], S.r2b[slot], vd);
+    }
+    if (o.store) {
+      const float diff = xv - yv;
+      const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+      (v_img1 + orow)[o.off] = wl1 * sgn + wss * (vac.x + 2.f * xv * vac.y + yv * vd);
+    }
+  }
+}
+
+template <int CH>
+__global__ void __launch_bounds__(kT, kFusedWaves)
+k_ssim_l1_fused(int B, int H, int W, int rows, const float *__restrict__ img1, const float *__restrict__ img2_direct,
+                const float *const *__restrict__ img2_slot, int valid, Window win, float w_l1, float w_ssim,
+                const float *__restrict__ v_loss, float *__restrict__ sums, float *__restrict__ v_img1,
+                float *__restrict__ loss_out, int32_t *__restrict__ ticket, float c_const) {
+  const float *__restrict__ img2 = img2_slot ? *img2_slot : img2_direct;
+  const float up = v_loss ? *v_loss : 1.f;
+  const float wl1 = w_l1 * up, wss = w_ssim * up;
+  __shared__ v4f rowsA[2][lds_line_slots<CH>()];
+  __shared__ v4f rowsB[2][line_b_slots<CH>()];
+  __shared__ float red[2][kT / 64];
+  const int tid = threadIdx.x;
+  const int f0 = blockIdx.x * fused_out_floats<CH>() - kHalf * CH;   // float of thread 0 (negative in the first strip)
+  const int y0 = blockIdx.y * rows, b = blockIdx.z;
+  const int n_out = (H - y0) < rows ? (H - y0) : rows;
+  const int n_steps = n_out + 4 * kHalf + 1;
+  const StageGeom<CH> g(tid, f0, W);
+  const int f = f0 + tid;
+  const bool in_row = f >= 0 && f < W * CH, inner = tid >= kHalf * CH && tid < kT - kHalf * CH;
+  const int x = in_row ? f / CH : 0;
+  FusedOut o;
+  o.off = in_row ? (unsigned)f : 0u;
+  o.cmask = (in_row && (!valid || (x >= kHalf && x < W - kHalf))) ? 1.f : 0.f;
+  o.sum_l1 = (in_row && inner) ? 1.f : 0.f;
+  o.sum_ss = inner ? o.cmask : 0.f;
+  o.store = in_row && inner;
+  {
+    const int64_t ob = (int64_t)b * H * ((int64_t)W * CH);
+    img1 += ob; img2 += ob; v_img1 += ob;
+  }
+  for (int i = tid; i < 2 * line_b_slots<CH>(); i += kT) (&rowsB[0][0])[i] = v4f{0.f, 0.f, 0.f, 0.f};
+  FwdStage<CH> preA, preB;
+  fwd_gload<CH>(preA, g, img1, img2, H, W * CH, y0 - 2 * kHalf);
+  fwd_lstore<CH>(preA, g, rowsA[0], tid, y0 - 2 * kHalf, H);
+  fwd_gload<CH>(preA, g, img1, img2, H, W * CH, y0 - 2 * kHalf + 1);
+  fwd_gload<CH>(preB, g, img1, img2, H, W * CH, y0 - 2 * kHalf + 2);
+  FusedState<CH> S;
+  S.l1_acc = S.ss_acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < kWin; ++i) { S.r1[i][0] = S.r1[i][1] = S.r2a[i] = v2f{0.f, 0.f}; S.r2b[i] = 0.f; }
+#define SO_STEP(P, MODE) fused_step<CH, P, MODE>(S, preA, preB, rowsA, rowsB, g, o, img1, img2, base + P, n_out, H, W, y0, tid, valid, win, wl1, wss, v_img1)
+  {
+    const int base = 0;
+    SO_STEP(0, 0); SO_STEP(1, 0); SO_STEP(2, 0); SO_STEP(3, 0); SO_STEP(4, 0);
+    SO_STEP(5, 0); SO_STEP(6, 0); SO_STEP(7, 0); SO_STEP(8, 0); SO_STEP(9, 0);
+    SO_STEP(10, 1);
+  }
+  {
+    const int base = kWin;
+    SO_STEP(0, 2); SO_STEP(1, 2); SO_STEP(2, 2); SO_STEP(3, 2); SO_STEP(4, 2);
+    SO_STEP(5, 2); SO_STEP(6, 2); SO_STEP(7, 2); SO_STEP(8, 2); SO_STEP(9, 2);
+    SO_STEP(10, 3);
+  }
+#define SO_STEPC(P) if (base + P >= n_steps) break; SO_STEP(P, 3)
+#pragma unroll 1
+  for (int base = 2 * kWin; base < n_steps; base += kWin) {
+    SO_STEPC(0); SO_STEPC(1); SO_STEPC(2); SO_STEPC(3); SO_STEPC(4); SO_STEPC(5);
+    SO_STEPC(6); SO_STEPC(7); SO_STEPC(8); SO_STEPC(9); SO_STEPC(10);
+  }
+#undef SO_STEPC
+#undef SO_STEP
+  const float l1 = wave_reduce_sum(S.l1_acc), ss = wave_reduce_sum(S.ss_acc);
+  if ((tid & 63) == 0) { red[0][tid >> 6] = l1; red[1][tid >> 6] = ss; }
+  __syncthreads();
+  if (tid == 0) {
+    float a = 0.f, c = 0.f;
+#pragma unroll
+    for (int w = 0; w < kT / 64; ++w) { a += red[0][w]; c += red[1][w]; }
+    atomicAdd(sums, a);
+    atomicAdd(sums + 1, c);
+    if (loss_out) {
+      // the workgroup that draws the last ticket sees every other workgroup's sums (fence before the ticket, sums read
+      // back through the same memory-side atomics) and writes the scalars; it leaves the ticket at zero for the next launch
+      __threadfence();
+      const int n_wg = (int)(gridDim.x * gridDim.y * gridDim.z);
+      if (atomicAdd(ticket, 1) == n_wg - 1) {
+        __threadfence();
+        const float s0 = atomicAdd(sums, 0.f), s1 = atomicAdd(sums + 1, 0.f);
+        const float a_l1 = 1.f / ((float)B * H * W * CH);
+        const float b_ss = 1.f / ((float)B * CH * (valid ? (float)(H - 10) * (float)(W - 10) : (float)H * (float)W));
+        const float l1m = s0 * a_l1, ssm = s1 * b_ss;   // mean |x-y| , mean SSIM
+        loss_out[0] = w_l1 / a_l1 * l1m + w_ssim / b_ss * ssm + c_const;
+        loss_out[1] = l1m;
+        loss_out[2] = 1.f - ssm;
+        atomicExch(ticket, 0);
+      }
+    }
+  }
+}
+
+
 static Window make_window() {
   Window w;
   double g[kWin], s = 0.0;
@@ -523,4 +768,50 @@ int so::ssim_l1_bwd_launch(int B, int H, int W, int CH, const float *img1, const
   else if (CH == 3) hipLaunchKernelGGL(so::k_ssim_l1_bwd<3>, grid, block, 0, st, B, H, W, img1, img2, img2_slot, dmaps, win, w_l1, w_ssim, v_loss, v_img1, sums, loss_out, a_l1, b_ss, loss_const);
   else hipLaunchKernelGGL(so::k_ssim_l1_bwd<4>, grid, block, 0, st, B, H, W, img1, img2, img2_slot, dmaps, win, w_l1, w_ssim, v_loss, v_img1, sums, loss_out, a_l1, b_ss, loss_const);
   return so::check_launch("so_ssim_l1_bwd");
+}
+
+/* The loss and its gradient in ONE launch (no derivative maps):  v_img1 as so_ssim_l1_bwd writes it, sums[2] as
+ * so_ssim_l1_fwd accumulates them (zeroed by the caller).  loss_out[3] (nullable) receives (loss, mean|.|, 1 - mean SSIM)
+ * from the workgroup that finishes last; it needs `ticket`, one int32 that is zero before the first launch (the kernel
+ * returns it to zero) and is not shared by launches that may overlap.  rows: output rows per workgroup, 0 = chosen so that
+ * the grid is resident at once. */
+namespace so {
+int ssim_l1_fused_launch(int B, int H, int W, int CH, const float *img1, const float *img2, const float *const *img2_slot,
+                         int padding_valid, float w_l1, float w_ssim, const float *v_loss, float *sums, float *v_img1,
+                         float *loss_out, int32_t *ticket, float loss_const, int rows, void *stream);
+}
+extern "C" int so_ssim_l1_fused(int B, int H, int W, int CH, const float *img1, const float *img2, int padding_valid,
+                                float w_l1, float w_ssim, const float *v_loss, float *sums, float *v_img1, float *loss_out,
+                                int32_t *ticket, float loss_const, int rows, void *stream) {
+  return so::ssim_l1_fused_launch(B, H, W, CH, img1, img2, nullptr, padding_valid, w_l1, w_ssim, v_loss, sums, v_img1, loss_out,
+                                  ticket, loss_const, rows, stream);
+}
+int so::ssim_l1_fused_launch(int B, int H, int W, int CH, const float *img1, const float *img2, const float *const *img2_slot,
+                             int padding_valid, float w_l1, float w_ssim, const float *v_loss, float *sums, float *v_img1,
+                             float *loss_out, int32_t *ticket, float loss_const, int rows, void *stream) {
+  SO_REQUIRE(B >= 0 && H > 0 && W > 0 && rows >= 0, "so_ssim_l1_fused: bad sizes");
+  SO_REQUIRE(CH == 1 || CH == 3 || CH == 4, "so_ssim_l1_fused: CH=%d not in {1,3,4}", CH);
+  if (B == 0) return SO_OK;
+  SO_REQUIRE(img1 && (img2 || img2_slot) && sums && v_img1, "so_ssim_l1_fused: null pointer");
+  SO_REQUIRE(loss_out == nullptr || ticket != nullptr, "so_ssim_l1_fused: loss_out needs a ticket");
+  SO_REQUIRE((int64_t)H * W * CH < (int64_t)INT32_MAX, "so_ssim_l1_fused: one image must hold fewer than 2^31 values");
+  const so::Window win = so::make_window();
+  const int out_t = so::kT - 2 * so::kHalf * CH, nx = (W * CH + out_t - 1) / out_t;
+  if (rows == 0) {
+    const int64_t slots = 256 * so::kFusedWaves * 4 / (so::kT / 64);   // workgroups resident at once on 256 CUs
+    const int64_t ny_max = slots / ((int64_t)nx * B) > 0 ? slots / ((int64_t)nx * B) : 1;
+    rows = (int)((H + ny_max - 1) / ny_max);
+    if (rows < 24) rows = 24;
+  }
+  const int ny = (H + rows - 1) / rows;
+  SO_REQUIRE(ny <= 65535 && B <= 65535, "so_ssim_l1_fused: grid too large");
+  const dim3 grid(nx, ny, B), block(so::kT);
+  hipStream_t st = so::as_stream(stream);
+#define SO_LAUNCH_FUSED(CHV) hipLaunchKernelGGL(so::k_ssim_l1_fused<CHV>, grid, block, 0, st, B, H, W, rows, img1, img2, img2_slot, \
+                                                 padding_valid, win, w_l1, w_ssim, v_loss, sums, v_img1, loss_out, ticket, loss_const)
+  if (CH == 1) SO_LAUNCH_FUSED(1);
+  else if (CH == 3) SO_LAUNCH_FUSED(3);
+  else SO_LAUNCH_FUSED(4);
+#undef SO_LAUNCH_FUSED
+  return so::check_launch("so_ssim_l1_fused");
 }

@@ -15,8 +15,8 @@ namespace so {
 // Optional per-stage timing with HIP events on the launch stream (bench.py's roofline leg).
 static const char *kStageNames[] = {"so_preprocess_fwd", "so_isect_scan", "so_isect_fill", "so_rasterize_fwd",
                                     "so_ssim_l1_fwd", "so_ssim_l1_bwd", "so_rasterize_bwd", "so_preprocess_bwd",
-                                    "so_adam_step_dev"};
-constexpr int kNumStages = 9;
+                                    "so_adam_step_dev", "so_ssim_l1_fused"};
+constexpr int kNumStages = 10;
 // per calling thread: the trainer thread's timers neither see nor are switched by a viewer thread's renders
 static thread_local bool g_prof_on = false;
 static thread_local std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events[kNumStages];
@@ -51,6 +51,9 @@ int ssim_l1_fwd_launch(int B, int H, int W, int CH, const float *img1, const flo
 int ssim_l1_bwd_launch(int B, int H, int W, int CH, const float *img1, const float *img2, const float *const *img2_slot,
                        const float *dmaps, float w_l1, float w_ssim, const float *v_loss, float *v_img1, const float *sums,
                        float *loss_out, int padding_valid, float loss_const, void *stream);
+int ssim_l1_fused_launch(int B, int H, int W, int CH, const float *img1, const float *img2, const float *const *img2_slot,
+                         int padding_valid, float w_l1, float w_ssim, const float *v_loss, float *sums, float *v_img1,
+                         float *loss_out, int32_t *ticket, float loss_const, int rows, void *stream);
 
 int preprocess_bwd_fused_adam(int C, int N, int K, int sh_degree, const float *means, const float *log_scales, const float *quats,
                               const float *logit_opacities, const float *sh0, const float *shN, const float *viewmats,
@@ -245,11 +248,17 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
                                         list_cap, d->render_colors, d->render_alphas, d->last_ids, stream));
   if (forward_only) return SO_OK;
   // loss = (1-l) * mean|.| + l * (1 - mean SSIM_valid)
-  SO_STAGE(4, so::ssim_l1_fwd_launch(C, H, W, 3, d->render_colors, d->pixels, d->pixels_indirect, 1, d->loss_sums, d->dmaps, stream));
   const float n_l1 = (float)C * H * W * 3.f, n_ss = (float)C * 3.f * (float)(H - 10) * (float)(W - 10);
-  SO_STAGE(5, so::ssim_l1_bwd_launch(C, H, W, 3, d->render_colors, d->pixels, d->pixels_indirect, d->dmaps, (1.f - d->ssim_lambda) / n_l1,
-                        -d->ssim_lambda / n_ss, nullptr, d->v_render_colors, d->loss_sums, d->loss_sums + 2, 1,
-                        d->ssim_lambda, stream));
+  if (!d->dmaps) {   // one kernel, the derivative values never leave the CU
+    SO_STAGE(9, so::ssim_l1_fused_launch(C, H, W, 3, d->render_colors, d->pixels, d->pixels_indirect, 1, (1.f - d->ssim_lambda) / n_l1,
+                          -d->ssim_lambda / n_ss, nullptr, d->loss_sums, d->v_render_colors, d->loss_sums + 2,
+                          reinterpret_cast<int32_t *>(d->loss_sums + 5), d->ssim_lambda, 0, stream));
+  } else {           // the forward / backward pair through dmaps (kept for comparison: bench.py --loss-kernels 2)
+    SO_STAGE(4, so::ssim_l1_fwd_launch(C, H, W, 3, d->render_colors, d->pixels, d->pixels_indirect, 1, d->loss_sums, d->dmaps, stream));
+    SO_STAGE(5, so::ssim_l1_bwd_launch(C, H, W, 3, d->render_colors, d->pixels, d->pixels_indirect, d->dmaps, (1.f - d->ssim_lambda) / n_l1,
+                          -d->ssim_lambda / n_ss, nullptr, d->v_render_colors, d->loss_sums, d->loss_sums + 2, 1,
+                          d->ssim_lambda, stream));
+  }
   // gradients of the intermediates accumulate in the 64-byte records vrec[C*N] (zeroed by the
   // forward preprocess kernel): one atomic request per (tile quadrant, Gaussian)
     SO_STAGE(6, so_rasterize_bwd_packed(C, N, W, H, ts | wrap_flags, d->rec, d->backgrounds, list_off, d->flatten_ids, list_n,

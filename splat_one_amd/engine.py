@@ -45,12 +45,17 @@ class FusedEngine:
                  isect_capacity: Optional[int] = None, use_graph: bool = True,
                  attr_dtype: str = "f32", tile_cull: bool = True, binned: bool = True,
                  bin_capacity: Optional[int] = None, fuse_adam: bool = True, device_refine: bool = False,
-                 capacity: Optional[int] = None, lean_views: bool = True, flat_multiple: int = 0):
+                 capacity: Optional[int] = None, lean_views: bool = True, flat_multiple: int = 0,
+                 loss_kernels: int = 1):
         """attr_dtype="f16": quaternions, log-scales and SH coefficients are READ from float16 attribute rows
         (include/splat_one_amd.h, so_attr_pack_f16: 112 instead of 224 bytes per Gaussian at SH degree 3); the
         float32 parameters stay the masters Adam updates, and the same Adam launch refreshes the halves."""
         assert attr_dtype in ("f32", "f16"), attr_dtype
         self.attr_dtype = attr_dtype
+        # loss_kernels=1: so_ssim_l1_fused (loss and gradient in one launch); 2: the so_ssim_l1_fwd/bwd pair through
+        # three derivative maps in HBM (kept to measure one against the other)
+        assert loss_kernels in (1, 2), loss_kernels
+        self.loss_kernels = loss_kernels
         # device_refine: the model lives in two capacity-preallocated sets of (parameters, exp_avg, exp_avg_sq) and
         # the Gaussian count in device memory; `refine()` / `reset_opacity()` run DefaultStrategy's densification as
         # a stream compaction from the active set into the other one (so_refine_default) -- no host read-back, no
@@ -299,16 +304,17 @@ class FusedEngine:
             w["radii"], w["tiles_per_gauss"] = e(C, N, dtype=i32), e(C, N, dtype=i32)
             w["means2d"], w["depths"], w["conics"] = e(C, N, 2), e(C, N), e(C, N, 3)
             w["opacities"], w["colors"] = e(C, N), e(C, N, 3)
-        # counters (2M+3 ints) | loss sums (2 floats) | loss, l1, ssimloss (3 floats) in one allocation
-        w["counters"] = torch.zeros(2 * M + 8, dtype=i32, device=dev)
+        # counters (2M+3 ints) | loss sums (2 floats) | loss, l1, ssimloss (3 floats) | ticket of the loss kernel
+        # (1 int, zero at rest) in one allocation
+        w["counters"] = torch.zeros(2 * M + 9, dtype=i32, device=dev)
         w["isect_offsets"] = e(C, th, tw, dtype=i32)
         # zero-filled once: whatever a list slot holds before its key is written is a valid Gaussian index
         w["key_buf"] = torch.zeros(cap, dtype=torch.int64, device=dev)
         w["flatten_ids"] = e(cap, dtype=i32)
         w["render_colors"], w["render_alphas"] = e(C, H, W, 3), e(C, H, W, 1)
         w["last_ids"] = e(C, H, W, dtype=i32)
-        w["loss_sums"] = w["counters"][2 * M + 3:2 * M + 8].view(torch.float32)
-        w["dmaps"] = e(3, C, H, W, 3)
+        w["loss_sums"] = w["counters"][2 * M + 3:2 * M + 9].view(torch.float32)
+        w["dmaps"] = e(3, C, H, W, 3) if self.loss_kernels == 2 else None
         w["v_render_colors"] = e(C, H, W, 3)
         w["zero_v_alphas"] = torch.zeros(C, H, W, device=dev)
         w["rec"], w["vrec"] = e(C * N, 16), e(C * N, 16)     # 64-byte packed records (allocator aligns to 512 B)
@@ -407,7 +413,7 @@ class FusedEngine:
         views = ("radii", "means2d", "depths", "conics", "opacities", "colors", "tiles_per_gauss")
         for k in views + ("counters", "isect_offsets", "key_buf", "flatten_ids", "render_colors", "render_alphas", "last_ids",
                           "loss_sums", "dmaps", "v_render_colors", "zero_v_alphas", "rec", "vrec"):
-            setattr(d, k, 0 if (self.lean and k in views) else p(w[k]))
+            setattr(d, k, 0 if (self.lean and k in views) or w[k] is None else p(w[k]))
         g = w["grads"]
         d.v_means, d.v_log_scales, d.v_quats, d.v_logit_opacities = p(g["means"]), p(g["scales"]), p(g["quats"]), p(g["opacities"])
         d.v_sh0, d.v_shN = p(g["sh0"]), p(g["shN"])

@@ -1,6 +1,7 @@
 """Photometric loss of the training step: 0.8 * L1 + 0.2 * (1 - SSIM)
 (/root/reference/utils/gsplat_utils/gsplat_trainer.py:624-628), as ONE forward and ONE backward HIP
-kernel (`so_ssim_l1_fwd/bwd`) on the rasteriser's channel-last output.
+kernel (`so_ssim_l1_fwd/bwd`) on the rasteriser's channel-last output -- or, where the gradient is wanted at once
+(`photometric_loss_and_grad`, the fused training step), as a single kernel (`so_ssim_l1_fused`).
 
 `fused_ssim(img1, img2, padding="valid")` mirrors the call the reference makes into the CUDA-only
 `fused_ssim` package (Dockerfile:55-60): 11x11 Gaussian window, sigma 1.5, C1=0.01^2, C2=0.03^2,
@@ -56,6 +57,22 @@ def photometric_loss(colors: Tensor, pixels: Tensor, ssim_lambda: float = 0.2):
     loss, l1, ssim = _L1SSIM.apply(_prep(colors), _prep(pixels.detach()), 1.0 - ssim_lambda, -ssim_lambda,
                                    ssim_lambda, True)
     return loss, l1, 1.0 - ssim
+
+
+def photometric_loss_and_grad(colors: Tensor, pixels: Tensor, ssim_lambda: float = 0.2, *, rows: int = 0):
+    """The same loss AND d loss / d colors in one launch (`so_ssim_l1_fused`: the derivative values of the SSIM map pass
+    through LDS instead of three maps in HBM) -- what the fused training step runs.  No autograd graph is built.
+    Returns (loss, l1loss, ssimloss, grad[B,H,W,CH]).  rows: output rows per workgroup, 0 = chosen by the launcher."""
+    assert colors.shape == pixels.shape and colors.dim() == 4, (colors.shape, pixels.shape)
+    B, H, W, CH = colors.shape
+    assert H > 10 and W > 10, "image smaller than the 11x11 SSIM window"
+    x, y = _prep(colors.detach()), _prep(pixels.detach())
+    work = torch.zeros(6, dtype=torch.float32, device=x.device)        # sums[2] | loss, l1, ssimloss | ticket
+    grad = torch.empty_like(x)
+    n_l1, n_ss = float(B * H * W * CH), float(B * CH * (H - 10) * (W - 10))
+    call("so_ssim_l1_fused", B, H, W, CH, ptr(x), ptr(y), 1, (1.0 - ssim_lambda) / n_l1, -ssim_lambda / n_ss, 0, ptr(work), ptr(grad),
+         ptr(work[2:]), ptr(work[5:]), ssim_lambda, rows, stream())
+    return work[2], work[3], work[4], grad
 
 
 def fused_ssim(img1: Tensor, img2: Tensor, padding: str = "same", train: bool = True) -> Tensor:

@@ -9,7 +9,7 @@ Built here from the same C-ABI kernels as the single-GPU engine:
     so_step_inputs        cameras of all ranks, own target image, counters, Adam schedule   (1 launch)
     so_preprocess_fwd     own shard x C=world cameras -> 64-byte records rec_shard[world][cap]
     all_to_all            block c of rec_shard -> rank c          (world-1)/world x 64 B x N per rank
-    so_rec_unpack, so_isect_count/fill, so_rasterize_fwd_packed, so_ssim_l1_fwd/bwd,
+    so_rec_unpack, so_isect_count/fill, so_rasterize_fwd_packed, so_ssim_l1_fused,
     so_rasterize_bwd_packed  on the records of ALL Gaussians for the own view -> vrec_full
     so_shard_flag_put     "my binning pass overflowed" into a spare slot of every block of vrec_full
     all_to_all            block j of vrec_full -> rank j          same volume back
@@ -125,14 +125,13 @@ class ShardedEngine:
         w["rec_full"], w["vrec_full"] = e(Nf, 16), e(Nf, 16)
         w["means2d_full"], w["radii_full"], w["depths_full"] = e(Nf, 2), e(Nf, dtype=i32), e(Nf)
         w["tiles_full"] = e(Nf, dtype=i32)
-        w["counters"] = z(2 * M + 8, dtype=i32)
+        w["counters"] = z(2 * M + 9, dtype=i32)        # ... | loss sums (2) | loss, l1, ssimloss (3) | loss-kernel ticket (1)
         w["isect_offsets"] = e(th, tw, dtype=i32)
         w["key_buf"] = z(icap, dtype=torch.int64)
         w["flatten_ids"] = e(icap, dtype=i32)
         w["render_colors"], w["render_alphas"] = e(1, H, W, 3), e(1, H, W, 1)
         w["last_ids"] = e(1, H, W, dtype=i32)
-        w["loss_sums"] = w["counters"][2 * M + 3:2 * M + 8].view(torch.float32)
-        w["dmaps"] = e(3, 1, H, W, 3)
+        w["loss_sums"] = w["counters"][2 * M + 3:2 * M + 9].view(torch.float32)
         w["v_render_colors"] = e(1, H, W, 3)
         w["zero_v_alphas"] = z(1, H, W)
         w["pixels"] = e(1, H, W, 3)
@@ -176,7 +175,8 @@ class ShardedEngine:
                 t = self.ws["grads"][name]
             else:
                 t = {"cursor": self.ws["counters"][M:], "n_isects": self.ws["counters"][2 * M + 1:],
-                     "overflow": self.ws["counters"][2 * M + 2:], "loss_out": self.ws["loss_sums"][2:]}[name]
+                     "overflow": self.ws["counters"][2 * M + 2:], "loss_out": self.ws["loss_sums"][2:],
+                     "loss_ticket": self.ws["loss_sums"][5:]}[name]
             v = self._ptr_cache[key] = _lib.ptr(t)
         return v
 
@@ -281,10 +281,9 @@ class ShardedEngine:
         lam = float(c["ssim_lambda"])
         n_l1 = float(H * W * 3)
         n_ss = float((H - 10) * (W - 10) * 3)
-        _lib.call("so_ssim_l1_fwd", 1, H, W, 3, P("w.render_colors"), p(px), 1, P("w.loss_sums"), P("w.dmaps"), st)
         # weight 1/world: the step's loss is the mean over the global batch of views
-        _lib.call("so_ssim_l1_bwd", 1, H, W, 3, P("w.render_colors"), p(px), P("w.dmaps"), (1.0 - lam) / n_l1 / n,
-                  -lam / n_ss / n, 0, P("w.v_render_colors"), P("w.loss_sums"), P("c.loss_out"), 1, lam / n, st)
+        _lib.call("so_ssim_l1_fused", 1, H, W, 3, P("w.render_colors"), p(px), 1, (1.0 - lam) / n_l1 / n, -lam / n_ss / n, 0,
+                  P("w.loss_sums"), P("w.v_render_colors"), P("c.loss_out"), P("c.loss_ticket"), lam / n, 0, st)
         _lib.call("so_rasterize_bwd_packed", 1, Nf, W, H, tsw, P("w.rec_full"), 0, P("w.isect_offsets"), P("w.flatten_ids"),
                   P("c.n_isects"), self.capacity, P("w.render_alphas"), P("w.last_ids"), P("w.v_render_colors"), P("w.zero_v_alphas"),
                   P("w.vrec_full"), int(c["absgrad"]), st)

@@ -124,6 +124,7 @@ class Config:
     # overflow).  False: gsplat's compact layout (one buffer of Config.isect_capacity entries)
     binned: bool = True
     fuse_adam: bool = True                 # single-GPU fused step: Adam inside the backward kernel (no gradient round trip)
+    loss_kernels: int = 1                  # fused step: 1 = loss and its gradient in one launch; 2 = forward/backward pair
     bin_capacity: Optional[int] = None     # slots per tile; None: 8x the fullest tile of the first view, >= 1024
     # single-GPU fused step with DefaultStrategy: the refinement (duplicate / split / prune / opacity reset) runs as a
     # stream compaction ON THE DEVICE (so_refine_default): capacity-preallocated parameters + Adam moments, N in device
@@ -624,7 +625,7 @@ class Runner:
                 isect_capacity=cfg.isect_capacity, use_graph=True,
                 attr_dtype=cfg.attr_dtype, tile_cull=cfg.tile_cull,
                 binned=cfg.binned, bin_capacity=cfg.bin_capacity,
-                fuse_adam=cfg.fuse_adam, device_refine=dev_refine, capacity=cfg.max_gaussians,
+                fuse_adam=cfg.fuse_adam, device_refine=dev_refine, capacity=cfg.max_gaussians, loss_kernels=cfg.loss_kernels,
                 flat_multiple=(self._dp_chunks * self.world_size * sdist.ShardedFlatAdam.ALIGN if self.world_size > 1 else 0))
             self._sadam = None
             eng.steps_done = step

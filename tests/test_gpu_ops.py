@@ -680,3 +680,59 @@ def test_photometric_loss_random_sizes(dev, seed):
     v_o.backward()
     assert abs(v_h.item() - v_o.item()) < 3e-6, (B, CH, H, W, padding)
     assert rel_err(xh.grad, xo.grad) < 1e-4, (B, CH, H, W, padding)
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_fused_loss_kernel(dev, seed):
+    """so_ssim_l1_fused (loss + gradient in one launch, derivative values through LDS) against the float64 oracle and
+    against the forward/backward pair, on random sizes around its strip boundaries (256 - 10 CH floats of a row, any
+    number of rows per workgroup), batches, channel counts, both paddings; every launch is repeated on the same work
+    buffer (the loss scalars come from the workgroup that draws the last ticket, which must leave the ticket at zero)."""
+    import random
+    from splat_one_amd import _lib
+    from splat_one_amd.losses import photometric_loss, photometric_loss_and_grad
+    from oracle import ssim_oracle as SO
+    rnd = random.Random(4100 + seed)
+    CH = rnd.choice([3, 3, 3, 1, 4])
+    B = rnd.choice([1, 1, 2, 3])
+    out_t = 256 - 10 * CH
+    W = rnd.choice([11, 12, 23, out_t // CH, out_t // CH + 1, 2 * out_t // CH, 2 * out_t // CH + 1, rnd.randint(11, 400)])
+    H = rnd.choice([11, 13, 24, 25, 47, 48, 49, rnd.randint(11, 200)])
+    rows = rnd.choice([0, 0, 1, 5, 11, 24, 57, H])
+    lam = rnd.choice([0.2, 0.0, 1.0, 0.5])
+    valid = rnd.choice([True, True, False])
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, H, W, CH, generator=g)
+    y = (x + 0.2 * torch.randn(B, H, W, CH, generator=g)).clamp(0, 1)
+    xd, yd = x.to(dev), y.to(dev)
+    n_l1, n_ss = float(B * H * W * CH), float(B * CH * ((H - 10) * (W - 10) if valid else H * W))
+    work = torch.zeros(6, device=dev)
+    grad = torch.full_like(xd, float("nan"))
+    up = torch.tensor([1.7], device=dev)
+    outs = []
+    for rep in range(2):
+        work[:2].zero_()
+        _lib.call("so_ssim_l1_fused", B, H, W, CH, _lib.ptr(xd), _lib.ptr(yd), 1 if valid else 0, (1.0 - lam) / n_l1, -lam / n_ss,
+                  _lib.ptr(up), _lib.ptr(work), _lib.ptr(grad), _lib.ptr(work[2:]), _lib.ptr(work[5:]), lam, rows, _lib.stream())
+        torch.cuda.synchronize()
+        assert work[5:].view(torch.int32).item() == 0, "ticket not returned to zero"
+        outs.append((work[2:5].cpu().clone(), grad.cpu().clone()))
+    assert torch.equal(outs[0][1], outs[1][1]) and (outs[0][0] - outs[1][0]).abs().max().item() < 1e-6
+    # the float64 oracle: a * mean|x-y| + b * mean SSIM + c and its gradient, times the upstream 1.7
+    xo = x.double().requires_grad_()
+    l1_o = (xo - y.double()).abs().mean()
+    ss_o = SO.fused_ssim(xo.permute(0, 3, 1, 2), y.permute(0, 3, 1, 2), padding="valid" if valid else "same")
+    loss_o = (1.0 - lam) * l1_o + lam * (1.0 - ss_o)
+    (loss_o * 1.7).backward()
+    loss_h, grad_h = outs[0]
+    assert abs(loss_h[0].item() - loss_o.item()) < 3e-6 and abs(loss_h[1].item() - l1_o.item()) < 3e-6, (B, CH, H, W, rows)
+    assert abs(loss_h[2].item() - (1.0 - ss_o.item())) < 3e-6, (B, CH, H, W, rows)
+    assert torch.isfinite(grad_h).all()
+    assert rel_err(grad_h, xo.grad) < 1e-4, (B, CH, H, W, rows, lam, valid)
+    if CH == 3 and valid:       # the Python front ends of both formulations agree to rounding
+        xh = xd.clone().requires_grad_()
+        loss_p, l1_p, ss_p = photometric_loss(xh, yd, lam)
+        loss_p.backward()
+        loss_f, l1_f, ss_f, grad_f = photometric_loss_and_grad(xd, yd, lam, rows=rows)
+        assert abs(loss_p.item() - loss_f.item()) < 1e-6 and abs(l1_p.item() - l1_f.item()) < 1e-6 and abs(ss_p.item() - ss_f.item()) < 1e-6
+        assert rel_err(grad_f, xh.grad) < 1e-5

@@ -42,7 +42,7 @@ json.dump(summary, open(out+"/pmc/traffic_summary.json","w"), indent=1)
 PY
 cd $GRAFT_REPO_ROOT
 : > $OUT/other_lines.jsonl
-for ARGS in "--regime ref" "--operator-path" "--n 500000" "--n 2000000 --steps 50" "--n 2000000 --attr-dtype f16 --steps 50" "--views 1"; do
+for ARGS in "--regime ref" "--operator-path" "--n 500000" "--n 2000000 --steps 50" "--n 2000000 --attr-dtype f16 --steps 50" "--views 1" "--loss-kernels 2"; do
   echo "# bench.py $ARGS" >> $OUT/other_lines.jsonl
   timeout 600 python3 bench.py --no-cpu-baseline --kernel-table $ARGS >> $OUT/other_lines.jsonl 2> $OUT/other_stderr.txt || exit 1
 done

@@ -1,10 +1,11 @@
-// Micro-benchmark of the fused L1+SSIM kernels through the C ABI (tile shape chosen at compile time
-// with -DSO_SSIM_XT / -DSO_SSIM_ROWS).  Prints mean launch time and checksums at 1080p.
+// Micro-benchmark of the L1+SSIM kernels through the C ABI: the forward/backward pair and the single fused kernel
+// (shapes chosen at compile time: -DSO_SSIM_THREADS / -DSO_SSIM_ROWS / -DSO_SSIM_WAVES / -DSO_FUSED_TAPGROUP).  Prints mean launch time and checksums at 1080p.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 #include "../../include/splat_one_amd.h"
+
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
@@ -47,5 +48,36 @@ int main(int argc, char **argv) {
   for (size_t i = 0; i < n; ++i) { cs += v[i] * (double)((i % 977) + 1); ca += v[i] < 0 ? -v[i] : v[i]; }
   printf("%dx%d fwd %.1f us  bwd %.1f us  | sums %.3f %.3f loss %.7f %.7f %.7f | vsum %.9e vabs %.9e\n", W, H,
          tf / iters * 1e3, tb / iters * 1e3, hs[0], hs[1], hl[0], hl[1], hl[2], cs, ca);
+  for (int rows : {0, 45, 52, 54, 57, 60, 68, 72, 90, 108}) {   // the single kernel on the same inputs, rows per workgroup swept (0 = the launcher's choice)
+    float *dv2, *sums2;
+    CK(hipMalloc(&dv2, n * 4)); CK(hipMalloc(&sums2, 64));
+    float t = 0;
+    for (int it = 0; it < iters + 5; ++it) {
+      CK(hipMemsetAsync(sums2, 0, 64, 0));
+      CK(hipEventRecord(e0, 0));
+      if (so_ssim_l1_fused(B, H, W, CH, d1, d2, 1, 0.8f / n, -0.2f / ((H - 10.f) * (W - 10.f) * CH), nullptr, sums2, dv2, sums2 + 2, (int32_t *)(sums2 + 5), 0.2f, rows, nullptr)) { printf("fused: %s\n", so_last_error()); return 1; }
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float f;
+      CK(hipEventElapsedTime(&f, e0, e1));
+      if (it >= 5) t += f;
+    }
+    std::vector<float> v2(n);
+    float hs2[16];
+    CK(hipMemcpy(v2.data(), dv2, n * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hs2, sums2, 64, hipMemcpyDeviceToHost));
+    double md = 0, mv = 0;
+    size_t nd = 0;
+    for (size_t i = 0; i < n; ++i) {
+      const double dd = v2[i] > v[i] ? v2[i] - v[i] : v[i] - v2[i];
+      if (dd > md) md = dd;
+      if (dd != 0) ++nd;
+      const double av = v[i] < 0 ? -v[i] : v[i];
+      if (av > mv) mv = av;
+    }
+    printf("%dx%d rows %3d fused %.1f us (two kernels %.1f us) | sums %.3f %.3f | gradient: max |diff| %.3e of max %.3e, %zu of %zu values differ\n",
+           W, H, rows, t / iters * 1e3, (tf + tb) / iters * 1e3, hs2[0], hs2[1], md, mv, nd, n);
+    CK(hipFree(dv2)); CK(hipFree(sums2));
+  }
   return 0;
 }

@@ -40,6 +40,7 @@ for a, b in pairs:
 d = json.load(open(os.path.join(dst, f"{tag}_engine_pmc_traffic.json")))
 names = {"so_rasterize_bwd": "void so::k_rasterize_bwd<3, 16, false, true>", "so_rasterize_fwd": "void so::k_rasterize_fwd<3, 16, true>",
          "so_adam_step_dev": "so::k_adam_dev", "so_ssim_l1_fwd": "void so::k_ssim_l1_fwd<3>", "so_ssim_l1_bwd": "void so::k_ssim_l1_bwd<3>",
+         "so_ssim_l1_fused": "void so::k_ssim_l1_fused<3>",
          "so_preprocess_fwd": "void so::k_preprocess_fwd<3, so::AttrSoA, false>",
          "so_preprocess_bwd": "void so::k_preprocess_bwd<3, so::AttrSoA, true, true, false>",
          "so_isect_fill": "void so::k_tile_sort_waves<256, 2048>"}
