@@ -406,8 +406,8 @@ int so_preprocess_bwd_f16(int C, int N, int K, int sh_degree, const float *means
 
 /* ------------------------------------------------------------------------------------------
  * One training iteration (gsplat_trainer.py:586-655: render -> loss -> backward) as ONE call on
- * caller-owned static buffers: memsets + 11 launches, no allocation, no host read-back, capturable
- * in a hipGraph.  Gradients of the raw parameters are overwritten; loss_sums[6] = (sum|x-y|,
+ * caller-owned static buffers: 6 launches with binned lists, fused Adam and the single-kernel loss (up to
+ * 11 otherwise), no allocation, no host read-back, capturable in a hipGraph.  Gradients of the raw parameters are overwritten; loss_sums[6] = (sum|x-y|,
  * sum SSIM_valid, loss, l1, 1-SSIM, ticket of so_ssim_l1_fused: an int32 that is 0 before the first step).  dmaps
  * NULL: the loss is the single kernel so_ssim_l1_fused; dmaps[3,C,H,W,3] given: the so_ssim_l1_fwd/bwd pair.  counters: int32[2*C*tiles + 3] (histogram | cursor | long-list length |
  * n_isects | overflow);
