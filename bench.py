@@ -424,8 +424,12 @@ def main():
                    "binned_lists": bool(fused and not runner.sharded and runner._engine.binned),
                    "parallelism": (f"gaussian-sharded dp{world}: one view per GPU, N/{world} Gaussians per GPU, "
                                    "projected Gaussians exchanged by all-to-all" if runner.sharded else
-                                   f"view-sharded dp{world}" + (f", replicated Gaussians: reduce-scatter / 1/{world} Adam / all-gather of the "
-                                                                f"gradient SoA in {getattr(runner, '_dp_chunks', cfg.dp_chunks)} chunk(s) over RCCL" if world > 1 else "")),
+                                   f"view-sharded dp{world}" + ("" if world == 1 else
+                                                                ", replicated device-resident Gaussians (device-side refinement): grouped all-reduce of "
+                                                                "the live gradient rows over RCCL, replicated Adam"
+                                                                if getattr(runner._engine, "device_refine", False) else
+                                                                f", replicated Gaussians: reduce-scatter / 1/{world} Adam / all-gather of the "
+                                                                f"gradient SoA in {getattr(runner, '_dp_chunks', cfg.dp_chunks)} chunk(s) over RCCL")),
                    "dp_mode_probe_ms_per_step": dp_probe},
         "forward_mpix_per_s": None if runner.sharded else world * P / fwd_s / 1e6,
         "hbm_iter_fraction": b_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9),

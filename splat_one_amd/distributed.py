@@ -140,6 +140,29 @@ def all_reduce_mean_(flat: torch.Tensor, group=None) -> None:
     flat.mul_(1.0 / dist.get_world_size(group))
 
 
+@torch.no_grad()
+def all_reduce_mean_list_(tensors: List[torch.Tensor], group=None) -> None:
+    """In-place mean over ranks of several contiguous tensors -- the live rows [0, N) of the capacity-sized gradient
+    tensors of a device-resident model (FusedEngine(device_refine=True)), which share no flat layout that depends on N.
+    RCCL: ONE grouped launch (`allreduce_coalesced` through torch's coalescing manager), so the wire sees the same
+    2 (world-1)/world of the gradient bytes as one flat all-reduce; gloo: one collective per tensor."""
+    if not is_initialized() or dist.get_world_size(group) == 1 or not tensors:
+        return
+    _all_reduce_sum_list(tensors, group)
+    torch._foreach_mul_(list(tensors), 1.0 / dist.get_world_size(group))
+
+
+def _all_reduce_sum_list(tensors: List[torch.Tensor], group=None) -> None:
+    assert all(t.is_contiguous() for t in tensors), "all_reduce_mean_list_: contiguous tensors expected"
+    if dist.get_backend(group) == "nccl":
+        with dist._coalescing_manager(group=group, async_ops=False):
+            for t in tensors:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    else:
+        for t in tensors:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
 class ShardedFlatAdam:
     """Optimiser step of the replicated ("allreduce") data-parallel scheme, SURVEY.md section 8(e): instead of ONE
     blocking all-reduce of the flat gradient followed by a full Adam on every rank, the flat buffer is cut into

@@ -613,7 +613,10 @@ class Runner:
         if eng is None or (eng.C, eng.H, eng.W) != (B, H, W):
             n_floats = sum(int(v.numel()) for v in self.splats.values())
             self._dp_chunks = int(cfg.dp_chunks) if cfg.dp_chunks > 0 else (4 if 4 * n_floats >= (64 << 20) else 1)
-            dev_refine = (cfg.device_refine and isinstance(s, DefaultStrategy) and self.world_size == 1
+            # DefaultStrategy on the device (single GPU, and replicated data parallelism: every rank runs the same
+            # compaction on the all-reduced statistics; the gradient is then all-reduced over the live rows of the
+            # capacity-sized tensors and Adam runs replicated -- a flat reduce-scatter layout would move with N)
+            dev_refine = (cfg.device_refine and isinstance(s, DefaultStrategy)
                           and cfg.attr_dtype == "f32" and s.refine_scale2d_stop_iter == 0)
             eng = self._engine = FusedEngine(
                 self.splats, self.optimizers, W, H, B, sh_degree=0, camera_model=cfg.camera_model,
@@ -626,7 +629,8 @@ class Runner:
                 attr_dtype=cfg.attr_dtype, tile_cull=cfg.tile_cull,
                 binned=cfg.binned, bin_capacity=cfg.bin_capacity,
                 fuse_adam=cfg.fuse_adam, device_refine=dev_refine, capacity=cfg.max_gaussians, loss_kernels=cfg.loss_kernels,
-                flat_multiple=(self._dp_chunks * self.world_size * sdist.ShardedFlatAdam.ALIGN if self.world_size > 1 else 0))
+                flat_multiple=(self._dp_chunks * self.world_size * sdist.ShardedFlatAdam.ALIGN
+                               if self.world_size > 1 and not dev_refine else 0))
             self._sadam = None
             eng.steps_done = step
             eng._step_dev[0] = step
@@ -643,6 +647,15 @@ class Runner:
         if self.world_size == 1:
             eng.set_views(camtoworlds, Ks, pixels, schedule=True)   # the step below always runs the optimiser
             eng.step()
+        elif eng.device_refine:
+            # replicated Gaussians, device-resident model: all-reduce (mean) of the live gradient rows, replicated Adam
+            eng.set_views(camtoworlds, Ks, pixels, schedule=True)
+            eng.fwd_bwd()
+            M = eng.M
+            sdist.all_reduce_max_(eng.ws["counters"][2 * M + 2:2 * M + 3])   # a void iteration on one rank is void on all
+            n = eng.n_host                                                   # N as of the last refinement (sync_host below)
+            sdist.all_reduce_mean_list_([eng.ws["grads"][k][:n] for k in eng.ws["grads"]])
+            eng.optimize()
         else:
             # replicated Gaussians: reduce-scatter of the flat gradient in chunks, Adam on this rank's 1/world of every
             # chunk as it lands, all-gather of the updated parameters (distributed.ShardedFlatAdam)
@@ -673,6 +686,9 @@ class Runner:
         if eng.device_refine:
             # densification on the device: five launches, nothing read back, the next step replays the other set's graph
             if refine_now:
+                if self.world_size > 1:      # statistics of all ranks' views, then the same compaction on every rank
+                    n = eng.n_host
+                    sdist.all_reduce_strategy_state({"grad2d": eng.dstats["grad2d"][:n], "count": eng.dstats["count"][:n]})
                 eng.refine(s, step, self.scene_scale, seed=cfg.refine_seed)
                 if s.verbose:
                     rep = eng.refine_report()           # (synchronises; verbose runs only)
@@ -680,6 +696,15 @@ class Runner:
                           f"Now having {rep['n_new']} GSs.")
             if reset_now:
                 eng.reset_opacity(s.prune_opa * 2.0)
+            if refine_now and self.world_size > 1:
+                # the collectives of the following steps are sized by N: one read-back per refinement, and a check that
+                # the replicas still agree on it
+                n_new = eng.sync_host()
+                chk = torch.tensor([n_new, -n_new], dtype=torch.int32, device=eng.device)
+                sdist.all_reduce_max_(chk)
+                if int(chk[0]) != n_new or int(chk[1]) != -n_new:
+                    raise RuntimeError(f"replicas diverged: this rank holds {n_new} Gaussians after the refinement of step {step}, "
+                                       f"others between {-int(chk[1])} and {int(chk[0])}")
         elif refine_now or reset_now:
             # torch-level refinement: the tensors of the ParameterDict are replaced one by one -- a render from another
             # thread (Runner.rasterize_splats holds the same lock) must not see half of them

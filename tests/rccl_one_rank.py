@@ -61,6 +61,11 @@ for c in range(sa.n_chunks):
 torch.cuda.synchronize()
 assert torch.equal(buf, ref)
 sa.gather_moments(buf, buf.clone())
+# the grouped all-reduce of the device-resident model's live gradient rows (torch coalescing manager -> one RCCL group)
+rows = [torch.full((9, 3), 2.0, device=dev), torch.full((9,), 3.0, device=dev), torch.full((9, 15, 3), 4.0, device=dev)]
+sdist._all_reduce_sum_list([t[:6] for t in rows])
+torch.cuda.synchronize()
+assert all(torch.equal(t, torch.full_like(t, v)) for t, v in zip(rows, (2.0, 3.0, 4.0)))
 mx = torch.tensor([3], dtype=torch.int32, device=dev)
 sdist.all_reduce_max_(mx)
 assert int(mx) == 3

@@ -361,40 +361,52 @@ def test_load_checkpoint_resumes_schedule_and_state(dev, tmp_path):
         assert r2.strategy_state["grad2d"].shape[0] == 1500
 
 
-def _dp_refine_worker(local_rank, world_rank, world_size, out_dir):
+def _dp_refine_setup(dev, world_rank, world_size, device_refine, batch_size=1):
     from splat_one_amd.strategy import DefaultStrategy
     from splat_one_amd.trainer import Config, Runner
-    dev = torch.device("cuda:0")
     W, H, N = 128, 96, 3000
     strat = DefaultStrategy(refine_start_iter=4, refine_every=4, reset_every=10, grow_grad2d=5e-5, verbose=False)
     cfg = Config(init_num_pts=N, init_scale=0.3, init_opa=0.3, shN_init_std=0.05, sh_degree_interval=1, fused=True,
-                 dp_mode="allreduce", strategy=strat)
+                 dp_mode="allreduce", strategy=strat, device_refine=device_refine, batch_size=batch_size)
     r = Runner(0, world_rank, world_size, cfg, scene_scale=1.0 / 1.1)
     with torch.no_grad():
         r.splats["scales"].add_((torch.randn(N, 3, generator=torch.Generator().manual_seed(7)) * 0.4).to(dev))
     yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
-    pixels = torch.stack([(xx + 0.2 * world_rank) % 1, yy, 0.5 * (xx + yy)], -1)[None].to(dev).contiguous()
-    Ks = pinhole_K(W, H)[None].to(dev)
+    pixels = lambda rank: torch.stack([(xx + 0.2 * rank) % 1, yy, 0.5 * (xx + yy)], -1)[None].to(dev).contiguous()
+    return r, pixels, pinhole_K(W, H)[None].to(dev)
+
+
+def _dp_refine_worker(local_rank, world_rank, world_size, args):
+    out_dir, device_refine = args
+    dev = torch.device("cuda:0")
+    r, pixels, Ks = _dp_refine_setup(dev, world_rank, world_size, device_refine)
+    px = pixels(world_rank)
     sizes = []
     for step in range(18):                                   # refinements at 8, 12, 16; opacity reset at 10
         v = (2 * step + world_rank) % 8
-        r.train_step(ring_cameras(8)[v:v + 1].to(dev), Ks, pixels)
+        r.train_step(ring_cameras(8)[v:v + 1].to(dev), Ks, px)
         sizes.append(len(r.splats["means"]))
     torch.cuda.synchronize()
+    assert r._engine.device_refine == device_refine
     st = {k: r.optimizers[k].state[r.splats[k]] for k in r.splats.keys()}
     torch.save({"splats": {k: v.detach().cpu() for k, v in r.splats.items()}, "sizes": sizes,
                 "m": {k: st[k]["exp_avg"].cpu() for k in st}, "step": {k: float(st[k]["step"]) for k in st}},
                os.path.join(out_dir, f"rank{world_rank}.pt"))
 
 
-def test_replicated_dp_refinement_keeps_the_replicas_identical(dev, tmp_path):
-    """Replicated data parallelism through refinements: the statistics are all-reduced, the sharded Adam moments gathered,
-    and every rank then duplicates / splits / prunes identically -- the Gaussian sets stay bit-identical across ranks
-    while their size changes, and the reduce-scatter / sharded Adam / all-gather step goes on on the new size."""
+@pytest.mark.parametrize("device_refine", [True, False])
+def test_replicated_dp_refinement_keeps_the_replicas_identical(dev, tmp_path, device_refine):
+    """Replicated data parallelism through refinements.  device_refine=False: the statistics are all-reduced, the sharded
+    Adam moments gathered, and every rank then duplicates / splits / prunes identically with the torch-level strategy; the
+    reduce-scatter / sharded Adam / all-gather step goes on on the new size.  device_refine=True (the default): the model
+    stays in the capacity-sized device sets, every rank runs the same compaction kernels on the all-reduced statistics,
+    the gradient is all-reduced over the live rows and Adam runs replicated.  Either way the Gaussian sets stay
+    bit-identical across ranks while their size changes; the device path is also compared with ONE process that trains
+    on the two ranks' views as a batch of two (same compaction kernels, same seed)."""
     from splat_one_amd import distributed as sdist
     env_backup = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     try:
-        sdist.cli(_dp_refine_worker, str(tmp_path), world_size=2, backend="gloo", port=_free_port())
+        sdist.cli(_dp_refine_worker, (str(tmp_path), device_refine), world_size=2, backend="gloo", port=_free_port())
     finally:
         for k, v in env_backup.items():
             if v is not None:
@@ -404,4 +416,22 @@ def test_replicated_dp_refinement_keeps_the_replicas_identical(dev, tmp_path):
     assert a["sizes"] == b["sizes"] and len(set(a["sizes"])) >= 3, a["sizes"]
     for k in a["splats"]:
         assert torch.equal(a["splats"][k], b["splats"][k]) and torch.isfinite(a["splats"][k]).all(), k
+        if device_refine:       # replicated Adam: the moments too (the sharded Adam keeps a moment on its owner rank only)
+            assert torch.equal(a["m"][k], b["m"][k]), k
         assert a["step"][k] == b["step"][k] == 18.0
+    if not device_refine:
+        return
+    r, pixels, Ks = _dp_refine_setup(dev, 0, 1, True, batch_size=2)
+    px = torch.cat([pixels(0), pixels(1)])
+    sizes = []
+    for step in range(18):
+        v = [(2 * step) % 8, (2 * step + 1) % 8]
+        r.train_step(ring_cameras(8)[v].to(dev), Ks.repeat(2, 1, 1), px)
+        sizes.append(r._engine.sync_host())
+    # the two runs sum the same per-view gradients and statistics in a different order: decisions at a threshold may
+    # differ for a Gaussian or two
+    assert abs(sizes[-1] - a["sizes"][-1]) <= 0.01 * sizes[-1] and len(set(sizes)) >= 3, (sizes, a["sizes"])
+    if sizes == a["sizes"]:
+        for k in a["splats"]:
+            ref = r.splats[k].detach().cpu()
+            assert ((a["splats"][k] - ref).norm() / ref.norm()).item() < 2e-3, k
