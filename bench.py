@@ -425,8 +425,8 @@ def main():
                    "parallelism": (f"gaussian-sharded dp{world}: one view per GPU, N/{world} Gaussians per GPU, "
                                    "projected Gaussians exchanged by all-to-all" if runner.sharded else
                                    f"view-sharded dp{world}" + ("" if world == 1 else
-                                                                ", replicated device-resident Gaussians (device-side refinement): grouped all-reduce of "
-                                                                "the live gradient rows over RCCL, replicated Adam"
+                                                                f", replicated device-resident Gaussians (device-side refinement): reduce-scatter / 1/{world} Adam / "
+                                                                "all-gather over row pieces of the capacity-sized tensors, two grouped RCCL launches each"
                                                                 if getattr(runner._engine, "device_refine", False) else
                                                                 f", replicated Gaussians: reduce-scatter / 1/{world} Adam / all-gather of the "
                                                                 f"gradient SoA in {getattr(runner, '_dp_chunks', cfg.dp_chunks)} chunk(s) over RCCL")),

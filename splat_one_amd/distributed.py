@@ -140,27 +140,115 @@ def all_reduce_mean_(flat: torch.Tensor, group=None) -> None:
     flat.mul_(1.0 / dist.get_world_size(group))
 
 
-@torch.no_grad()
-def all_reduce_mean_list_(tensors: List[torch.Tensor], group=None) -> None:
-    """In-place mean over ranks of several contiguous tensors -- the live rows [0, N) of the capacity-sized gradient
-    tensors of a device-resident model (FusedEngine(device_refine=True)), which share no flat layout that depends on N.
-    RCCL: ONE grouped launch (`allreduce_coalesced` through torch's coalescing manager), so the wire sees the same
-    2 (world-1)/world of the gradient bytes as one flat all-reduce; gloo: one collective per tensor."""
-    if not is_initialized() or dist.get_world_size(group) == 1 or not tensors:
-        return
-    _all_reduce_sum_list(tensors, group)
-    torch._foreach_mul_(list(tensors), 1.0 / dist.get_world_size(group))
+class RowShardedAdam:
+    """The same reduce-scatter / sharded Adam / all-gather step for a DEVICE-RESIDENT model (FusedEngine(device_refine=
+    True)): parameters, moments and gradients are separate tensors of `capacity` rows of which the first N are live, so no
+    flat piece layout survives a refinement.  Pieces are ROW ranges instead: with p = ceil(N / world) rounded up to 16 rows,
+    rank r owns rows
+    [r p, (r+1) p) of EVERY tensor;
 
+        reduce-scatter over rows [0, p world) of each gradient tensor, in place   (rank r: the summed rows of its piece)
+        Adam on rows [r p, min((r+1) p, N)) of each tensor                         (1/world of the optimiser traffic)
+        all-gather of the parameter rows [0, p world)
 
-def _all_reduce_sum_list(tensors: List[torch.Tensor], group=None) -> None:
-    assert all(t.is_contiguous() for t in tensors), "all_reduce_mean_list_: contiguous tensors expected"
-    if dist.get_backend(group) == "nccl":
-        with dist._coalescing_manager(group=group, async_ops=False):
-            for t in tensors:
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    else:
+    issued as two groups -- shN (45 of the 59 floats of a row) and the five small tensors together -- so that the second
+    group's collectives run under the first group's Adam; on RCCL every group is ONE launch (torch's coalescing manager:
+    reduce_scatter_tensor_coalesced / allgather_into_tensor_coalesced).  Rows between N and p world belong to nobody: they
+    are reduced and gathered with the rest (capacity >= p world is the engine's contract) and never read.  `gather` all-gathers
+    any set of row-sharded tensors (the moments, before a refinement compacts them identically on every rank).  N is a
+    host integer: replicas read it back once per refinement.  Bytes on the wire equal ShardedFlatAdam's.
+
+    gloo (tests): HIP tensors move through all_reduce only (a reduce-scatter is an all-reduce whose other rows are
+    ignored, an all-gather an all-reduce of zero-padded pieces); CPU tensors through reduce / all_gather per piece."""
+
+    GROUPS = (("shN",), ("means", "scales", "quats", "opacities", "sh0"))
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank, self.world = (dist.get_rank(group), dist.get_world_size(group)) if is_initialized() else (0, 1)
+        self.backend = dist.get_backend(group) if is_initialized() else "none"
+
+    ALIGN_ROWS = 16   # piece boundaries: 16 rows = 64 bytes of the narrowest tensor (float4 kernels need 16-byte starts)
+
+    def piece(self, n: int) -> int:
+        q = self.world * self.ALIGN_ROWS
+        return -(-int(n) // q) * self.ALIGN_ROWS
+
+    def rows(self, n: int, r: Optional[int] = None):
+        p = self.piece(n)
+        r = self.rank if r is None else r
+        return r * p, (r + 1) * p
+
+    def bytes_per_link_and_step(self, n: int, floats_per_row: int = 59) -> float:
+        return 2.0 * (self.world - 1) / max(1, self.world) * self.piece(n) * self.world * floats_per_row * 4.0
+
+    def _reduce_scatter(self, tensors: List[torch.Tensor], n: int):
+        p, (a, b) = self.piece(n), self.rows(n)
+        span = p * self.world
+        assert all(t.shape[0] >= span and t.is_contiguous() for t in tensors), (n, span, [tuple(t.shape) for t in tensors])
+        if self.backend == "nccl":
+            with dist._coalescing_manager(group=self.group, async_ops=True) as cm:
+                for t in tensors:
+                    dist.reduce_scatter_tensor(t[a:b], t[:span], op=dist.ReduceOp.SUM, group=self.group)
+            return [cm]
+        if tensors[0].is_cuda:
+            return [dist.all_reduce(t[:span], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for t in tensors]
+        works = []
         for t in tensors:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            for j in range(self.world):
+                works.append(dist.reduce(t[j * p:(j + 1) * p], dst=j if self.group is None else dist.get_global_rank(self.group, j),
+                                         op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return works
+
+    def _all_gather(self, tensors: List[torch.Tensor], n: int):
+        p, (a, b) = self.piece(n), self.rows(n)
+        span = p * self.world
+        assert all(t.shape[0] >= span and t.is_contiguous() for t in tensors), (n, span, [tuple(t.shape) for t in tensors])
+        if self.backend == "nccl":
+            with dist._coalescing_manager(group=self.group, async_ops=True) as cm:
+                for t in tensors:
+                    dist.all_gather_into_tensor(t[:span], t[a:b], group=self.group)
+            return [cm]
+        if tensors[0].is_cuda:
+            works = []
+            for t in tensors:
+                t[:a].zero_()
+                t[b:span].zero_()
+                works.append(dist.all_reduce(t[:span], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return works
+        return [dist.all_gather([t[j * p:(j + 1) * p] for j in range(self.world)], t[a:b].clone(), group=self.group, async_op=True)
+                for t in tensors]
+
+    @torch.no_grad()
+    def step(self, grads: Dict[str, torch.Tensor], params: Dict[str, torch.Tensor], n: int,
+             adam_fn: Callable[[tuple, int, int], None]) -> None:
+        """grads / params: the capacity-sized tensors by name; adam_fn(names, row_start, row_stop) updates those rows of the
+        named tensors (parameters and moments) from the already averaged gradient rows."""
+        if self.world == 1:
+            adam_fn(tuple(k for g in self.GROUPS for k in g), 0, n)
+            return
+        a, b = self.rows(n)
+        b = min(b, n)
+        groups = [tuple(k for k in g if k in grads) for g in self.GROUPS]
+        rs = [self._reduce_scatter([grads[k] for k in g], n) for g in groups]
+        ag = []
+        inv = 1.0 / self.world
+        for g, works in zip(groups, rs):
+            for w in works:
+                w.wait()
+            if b > a:
+                torch._foreach_mul_([grads[k][a:b] for k in g], inv)      # mean over the views of all ranks
+                adam_fn(g, a, b)
+            ag += self._all_gather([params[k] for k in g], n)
+        for w in ag:
+            w.wait()
+
+    @torch.no_grad()
+    def gather(self, tensors: List[torch.Tensor], n: int) -> None:
+        if self.world == 1 or not tensors:
+            return
+        for w in self._all_gather(list(tensors), n):
+            w.wait()
 
 
 class ShardedFlatAdam:

@@ -46,7 +46,7 @@ class FusedEngine:
                  attr_dtype: str = "f32", tile_cull: bool = True, binned: bool = True,
                  bin_capacity: Optional[int] = None, fuse_adam: bool = True, device_refine: bool = False,
                  capacity: Optional[int] = None, lean_views: bool = True, flat_multiple: int = 0,
-                 loss_kernels: int = 1):
+                 loss_kernels: int = 1, row_multiple: int = 1):
         """attr_dtype="f16": quaternions, log-scales and SH coefficients are READ from float16 attribute rows
         (include/splat_one_amd.h, so_attr_pack_f16: 112 instead of 224 bytes per Gaussian at SH degree 3); the
         float32 parameters stay the masters Adam updates, and the same Adam launch refreshes the halves."""
@@ -67,6 +67,9 @@ class FusedEngine:
         # in FLAT buffers with the segment layout of the flat gradient, padded to a multiple of `flat_multiple` floats,
         # so that reduce-scatter / sharded Adam / all-gather work on contiguous ranges of all four
         self.flat_multiple = int(flat_multiple)
+        # row_multiple (device_refine in replicated data parallelism, distributed.RowShardedAdam): the capacity is a
+        # multiple of it (world x 16 rows), so that `world` aligned row pieces covering the live rows always exist
+        self.row_multiple = max(1, int(row_multiple))
         assert not (self.flat_multiple and self.device_refine), "flat_multiple and device_refine are separate modes"
         self._capacity_request = capacity
         self._host_stale = False
@@ -125,6 +128,7 @@ class FusedEngine:
         dev = self.device
         n = self.splats["means"].shape[0]
         cap = max(int(cap), n)
+        cap = -(-cap // self.row_multiple) * self.row_multiple       # RowShardedAdam: world row pieces of ceil(N / world) rows fit
         assert cap < (1 << 30), cap
         old = getattr(self, "sets", None)
         self._adam_args_host()                   # lazily-created optimiser state must exist before it is moved
@@ -255,6 +259,24 @@ class FusedEngine:
                                          math.sqrt(1.0 - betas[1] ** t)))
         if not groups:
             return
+        arr = (_lib.AdamGroup * len(groups))(*groups)
+        _lib.call("so_adam_step", len(groups), arr, float(betas[0]), float(betas[1]), float(eps), 0, _lib.stream())
+
+    def adam_on_rows(self, names, a: int, b: int) -> None:
+        """Adam (host-scheduled: so_adam_step) on rows [a, b) of the named tensors of the ACTIVE device-resident set --
+        the row piece this rank owns in a reduce-scattered step (distributed.RowShardedAdam)."""
+        assert self.device_refine and 0 <= a <= b <= self.cap, (a, b, self.cap)
+        if a == b:
+            return
+        act, t = self.sets[self.active], self.steps_done + 1
+        groups, betas, eps = [], None, None
+        for k in names:
+            grp = self.optimizers[k].param_groups[0]
+            betas, eps = grp["betas"], grp["eps"]
+            rows = lambda x: x[a:b]
+            groups.append(_lib.AdamGroup(_lib.ptr(rows(act["p"][k])), _lib.ptr(rows(self.ws["grads"][k])), _lib.ptr(rows(act["m"][k])),
+                                         _lib.ptr(rows(act["v"][k])), 0, rows(act["p"][k]).numel(), 1, grp["lr"] / (1.0 - betas[0] ** t),
+                                         math.sqrt(1.0 - betas[1] ** t)))
         arr = (_lib.AdamGroup * len(groups))(*groups)
         _lib.call("so_adam_step", len(groups), arr, float(betas[0]), float(betas[1]), float(eps), 0, _lib.stream())
 

@@ -614,8 +614,8 @@ class Runner:
             n_floats = sum(int(v.numel()) for v in self.splats.values())
             self._dp_chunks = int(cfg.dp_chunks) if cfg.dp_chunks > 0 else (4 if 4 * n_floats >= (64 << 20) else 1)
             # DefaultStrategy on the device (single GPU, and replicated data parallelism: every rank runs the same
-            # compaction on the all-reduced statistics; the gradient is then all-reduced over the live rows of the
-            # capacity-sized tensors and Adam runs replicated -- a flat reduce-scatter layout would move with N)
+            # compaction on the all-reduced statistics and the gathered moments; the optimiser step is sharded by ROW
+            # pieces of the capacity-sized tensors -- a flat piece layout would move with N)
             dev_refine = (cfg.device_refine and isinstance(s, DefaultStrategy)
                           and cfg.attr_dtype == "f32" and s.refine_scale2d_stop_iter == 0)
             eng = self._engine = FusedEngine(
@@ -629,9 +629,10 @@ class Runner:
                 attr_dtype=cfg.attr_dtype, tile_cull=cfg.tile_cull,
                 binned=cfg.binned, bin_capacity=cfg.bin_capacity,
                 fuse_adam=cfg.fuse_adam, device_refine=dev_refine, capacity=cfg.max_gaussians, loss_kernels=cfg.loss_kernels,
+                row_multiple=self.world_size * sdist.RowShardedAdam.ALIGN_ROWS,
                 flat_multiple=(self._dp_chunks * self.world_size * sdist.ShardedFlatAdam.ALIGN
                                if self.world_size > 1 and not dev_refine else 0))
-            self._sadam = None
+            self._sadam = self._radam = None
             eng.steps_done = step
             eng._step_dev[0] = step
             if self.world_size > 1:
@@ -648,14 +649,16 @@ class Runner:
             eng.set_views(camtoworlds, Ks, pixels, schedule=True)   # the step below always runs the optimiser
             eng.step()
         elif eng.device_refine:
-            # replicated Gaussians, device-resident model: all-reduce (mean) of the live gradient rows, replicated Adam
-            eng.set_views(camtoworlds, Ks, pixels, schedule=True)
+            # replicated Gaussians, device-resident model: the same reduce-scatter / 1/world Adam / all-gather over ROW
+            # pieces of the capacity-sized tensors (distributed.RowShardedAdam); N is the host's copy (sync_host below)
+            eng.set_views(camtoworlds, Ks, pixels, schedule=False)
             eng.fwd_bwd()
             M = eng.M
-            sdist.all_reduce_max_(eng.ws["counters"][2 * M + 2:2 * M + 3])   # a void iteration on one rank is void on all
-            n = eng.n_host                                                   # N as of the last refinement (sync_host below)
-            sdist.all_reduce_mean_list_([eng.ws["grads"][k][:n] for k in eng.ws["grads"]])
-            eng.optimize()
+            sdist.all_reduce_max_(eng.ws["counters"][2 * M + 2:2 * M + 3])   # a void iteration on one rank is raised on all
+            if self._radam is None:
+                self._radam = sdist.RowShardedAdam()
+            self._radam.step(eng.ws["grads"], eng.sets[eng.active]["p"], eng.n_host, eng.adam_on_rows)
+            eng._advance_host_counters()
         else:
             # replicated Gaussians: reduce-scatter of the flat gradient in chunks, Adam on this rank's 1/world of every
             # chunk as it lands, all-gather of the updated parameters (distributed.ShardedFlatAdam)
@@ -689,6 +692,9 @@ class Runner:
                 if self.world_size > 1:      # statistics of all ranks' views, then the same compaction on every rank
                     n = eng.n_host
                     sdist.all_reduce_strategy_state({"grad2d": eng.dstats["grad2d"][:n], "count": eng.dstats["count"][:n]})
+                    if self._radam is not None:      # the compaction rewrites ALL moments: fetch the other owners' rows
+                        act = eng.sets[eng.active]
+                        self._radam.gather([act[q][k] for q in ("m", "v") for k in act[q]], n)
                 eng.refine(s, step, self.scene_scale, seed=cfg.refine_seed)
                 if s.verbose:
                     rep = eng.refine_report()           # (synchronises; verbose runs only)

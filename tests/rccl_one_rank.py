@@ -61,9 +61,15 @@ for c in range(sa.n_chunks):
 torch.cuda.synchronize()
 assert torch.equal(buf, ref)
 sa.gather_moments(buf, buf.clone())
-# the grouped all-reduce of the device-resident model's live gradient rows (torch coalescing manager -> one RCCL group)
-rows = [torch.full((9, 3), 2.0, device=dev), torch.full((9,), 3.0, device=dev), torch.full((9, 15, 3), 4.0, device=dev)]
-sdist._all_reduce_sum_list([t[:6] for t in rows])
+# row pieces of a device-resident model (RowShardedAdam): grouped reduce_scatter_tensor / all_gather_into_tensor through
+# torch's coalescing manager, in place, async handles -- with one rank every collective is a copy onto itself
+ra = sdist.RowShardedAdam()
+assert ra.backend == "nccl" and ra.world == 1 and ra.rows(10) == (0, 16)
+rows = [torch.full((16, 3), 2.0, device=dev), torch.full((16,), 3.0, device=dev), torch.full((16, 15, 3), 4.0, device=dev)]
+for wk in ra._reduce_scatter(rows, 10):
+    wk.wait()
+for wk in ra._all_gather(rows, 10):
+    wk.wait()
 torch.cuda.synchronize()
 assert all(torch.equal(t, torch.full_like(t, v)) for t, v in zip(rows, (2.0, 3.0, 4.0)))
 mx = torch.tensor([3], dtype=torch.int32, device=dev)

@@ -119,3 +119,96 @@ def test_sharded_adam_equals_adam_on_the_mean_gradient(tmp_path, world, n_chunks
         assert torch.allclose(outs[0]["M"][off:off + n], st["exp_avg"], rtol=1e-5, atol=1e-6), k
     padded = outs[0]["P"].numel()
     assert abs(outs[0]["bytes"] - 2 * (world - 1) / world * padded * 4) < 1
+
+
+# ------------------------------------------------------------------------------------------------ row pieces
+def _row_worker(local_rank, world_rank, world_size, args):
+    """RowShardedAdam on capacity-sized tensors: N live rows of CAP, N changing between steps (as after a refinement,
+    with the moments gathered first)."""
+    out_dir, cap, Ns = args
+    from splat_one_amd.distributed import RowShardedAdam
+    ra = RowShardedAdam()
+    g0 = torch.Generator().manual_seed(7)
+    P = {k: torch.randn(cap, rl, generator=g0) for k, rl in ROWS.items()}
+    G = {k: torch.full((cap, rl), float("nan")) for k, rl in ROWS.items()}      # rows beyond N: never read
+    M = {k: torch.zeros(cap, rl) for k, rl in ROWS.items()}
+    V = {k: torch.zeros(cap, rl) for k, rl in ROWS.items()}
+    hyper = _hyper(world_size)
+    t = [0]
+    touched = []
+
+    def adam_fn(names, a, b):
+        touched.append((tuple(names), a, b))
+        for k in names:
+            lr, eps, (b1, b2) = hyper[k]
+            g = G[k][a:b]
+            M[k][a:b].mul_(b1).add_(g, alpha=1 - b1)
+            V[k][a:b].mul_(b2).addcmul_(g, g, value=1 - b2)
+            denom = (V[k][a:b].sqrt() / (1 - b2 ** t[0]) ** 0.5).add_(eps)
+            P[k][a:b].addcdiv_(M[k][a:b], denom, value=-lr / (1 - b1 ** t[0]))
+
+    for step, N in enumerate(Ns):
+        if step and N != Ns[step - 1]:          # "refinement": every rank needs all moments of the old rows first
+            ra.gather([M[k] for k in ROWS] + [V[k] for k in ROWS], Ns[step - 1])
+            for k in ROWS:                      # the new rows start with zero moments, like duplicated / split Gaussians
+                M[k][Ns[step - 1]:].zero_()
+                V[k][Ns[step - 1]:].zero_()
+        for k, rl in ROWS.items():
+            G[k][:N] = _grads(N, world_rank, step)[k].view(N, rl)
+            G[k][N:] = float("nan")             # rows of the last piece beyond N are summed with the rest and never used
+        t[0] = step + 1
+        ra.step(G, P, N, adam_fn)
+        a, b = ra.rows(N)
+        assert all(x[1] == a and x[2] == min(b, N) for x in touched[-2:]) or min(b, N) <= a
+    ra.gather([M[k] for k in ROWS] + [V[k] for k in ROWS], Ns[-1])
+    N = Ns[-1]
+    torch.save({"P": {k: P[k][:N] for k in ROWS}, "M": {k: M[k][:N] for k in ROWS}, "V": {k: V[k][:N] for k in ROWS},
+                "bytes": ra.bytes_per_link_and_step(N)}, os.path.join(out_dir, f"r{world_rank}.pt"))
+
+
+@pytest.mark.parametrize("world,cap,Ns", [(2, 64, (37, 37, 51)), (4, 1024, (777, 1001, 1001)), (8, 2048, (1234, 1234, 3))])
+def test_row_sharded_adam_equals_adam_on_the_mean_gradient(tmp_path, world, cap, Ns):
+    from splat_one_amd import distributed as sdist
+    env_backup = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        sdist.cli(_row_worker, (str(tmp_path), cap, Ns), world_size=world, backend="gloo", port=_free_port())
+    finally:
+        for k, v in env_backup.items():
+            if v is not None:
+                os.environ[k] = v
+    outs = [torch.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(world)]
+    for o in outs[1:]:
+        for q in ("P", "M", "V"):
+            for k in ROWS:
+                assert torch.equal(o[q][k], outs[0][q][k]), (q, k)
+    # single-process reference: torch.optim.Adam per tensor on the mean gradient; a change of N keeps the old rows'
+    # state and gives new rows zero moments (what DefaultStrategy's duplicate / split do)
+    hyper = _hyper(world)
+    g0 = torch.Generator().manual_seed(7)
+    full = {k: torch.randn(cap, rl, generator=g0) for k, rl in ROWS.items()}
+    params, opts = {}, {}
+    for step, N in enumerate(Ns):
+        for k, rl in ROWS.items():
+            if step == 0 or N != Ns[step - 1]:
+                old = params.get(k)
+                new = torch.nn.Parameter(full[k][:N].clone())
+                lr, eps, betas = hyper[k]
+                opt = torch.optim.Adam([new], lr=lr, eps=eps, betas=betas)
+                if old is not None:
+                    n0 = min(N, old.shape[0])
+                    with torch.no_grad():
+                        new[:n0] = old[:n0]
+                    st_old = opts[k].state[old]
+                    st = opt.state[new]
+                    st["step"] = st_old["step"].clone()
+                    st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(new), torch.zeros_like(new)
+                    st["exp_avg"][:n0], st["exp_avg_sq"][:n0] = st_old["exp_avg"][:n0], st_old["exp_avg_sq"][:n0]
+                params[k], opts[k] = new, opt
+            params[k].grad = sum(_grads(N, r, step)[k].view(N, rl) for r in range(world)) / world
+            opts[k].step()
+    for k in ROWS:
+        assert torch.allclose(outs[0]["P"][k], params[k].detach(), rtol=1e-5, atol=1e-7), k
+        assert torch.allclose(outs[0]["M"][k], opts[k].state[params[k]]["exp_avg"], rtol=1e-5, atol=1e-6), k
+    N = Ns[-1]
+    p = -(-N // (16 * world)) * 16
+    assert abs(outs[0]["bytes"] - 2 * (world - 1) / world * p * world * 59 * 4) < 1
