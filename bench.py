@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", type=int, default=100_000)
+    ap.add_argument("--n", "--gaussians", dest="n", type=int, default=100_000)   # (--gaussians: torchrun's own parser trips over "--n")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--regime", default="mcmc", choices=["mcmc", "ref"])
@@ -244,7 +244,10 @@ def main():
             eng = runner._engine
             n_live = eng.sync_host()
             avg = (eng.dstats["grad2d"][:n_live] / eng.dstats["count"][:n_live].clamp_min(1))
-            cfg.strategy.grow_grad2d = float(torch.quantile(avg[torch.randperm(n_live, device=dev)[:1_000_000]], 0.6))
+            thr = torch.quantile(avg[torch.randperm(n_live, device=dev)[:1_000_000]], 0.6).reshape(1)
+            if world > 1:            # replicas must take the same decisions: rank 0's threshold (its own views' statistics)
+                dist.broadcast(thr, src=0)
+            cfg.strategy.grow_grad2d = float(thr)
     torch.cuda.synchronize()
     if not fused:
         prof = _lib.profile_summary()
@@ -330,7 +333,7 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
-        eng.refine(cfg.strategy, runner.step, runner.scene_scale, seed=cfg.refine_seed)
+        runner.refine_on_device(runner.step)          # (with --gpus N: incl. the statistics / moments collectives and the read of N)
         e1.record()
         torch.cuda.synchronize()
         refine_ms = e0.elapsed_time(e1)

@@ -551,6 +551,12 @@ class FusedEngine:
         self._build_workspace()
         self._probe_capacity = False
 
+    def reprobe_capacity(self) -> None:
+        """Measure the per-tile lists again on the next staged view (one forward-only pass and one read) and enlarge the
+        buffers if they are no longer generous -- for callers that cannot afford a void iteration after the model has
+        grown (data-parallel replicas after a refinement: on_overflow == "raise")."""
+        self._probe_capacity = True
+
     def _measure_and_grow(self) -> bool:
         """Forward-only pass on the staged view, read its intersection count (one sync, once per workspace)."""
         d = self._desc()

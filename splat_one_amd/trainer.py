@@ -687,30 +687,7 @@ class Runner:
                       and step % s.reset_every >= s.pause_refine_after_reset)
         reset_now = step < s.refine_stop_iter and step % s.reset_every == 0 and step > 0
         if eng.device_refine:
-            # densification on the device: five launches, nothing read back, the next step replays the other set's graph
-            if refine_now:
-                if self.world_size > 1:      # statistics of all ranks' views, then the same compaction on every rank
-                    n = eng.n_host
-                    sdist.all_reduce_strategy_state({"grad2d": eng.dstats["grad2d"][:n], "count": eng.dstats["count"][:n]})
-                    if self._radam is not None:      # the compaction rewrites ALL moments: fetch the other owners' rows
-                        act = eng.sets[eng.active]
-                        self._radam.gather([act[q][k] for q in ("m", "v") for k in act[q]], n)
-                eng.refine(s, step, self.scene_scale, seed=cfg.refine_seed)
-                if s.verbose:
-                    rep = eng.refine_report()           # (synchronises; verbose runs only)
-                    print(f"Step {step}: {rep['n_dupli']} GSs duplicated, {rep['n_split']} GSs split, {rep['n_prune']} GSs pruned. "
-                          f"Now having {rep['n_new']} GSs.")
-            if reset_now:
-                eng.reset_opacity(s.prune_opa * 2.0)
-            if refine_now and self.world_size > 1:
-                # the collectives of the following steps are sized by N: one read-back per refinement, and a check that
-                # the replicas still agree on it
-                n_new = eng.sync_host()
-                chk = torch.tensor([n_new, -n_new], dtype=torch.int32, device=eng.device)
-                sdist.all_reduce_max_(chk)
-                if int(chk[0]) != n_new or int(chk[1]) != -n_new:
-                    raise RuntimeError(f"replicas diverged: this rank holds {n_new} Gaussians after the refinement of step {step}, "
-                                       f"others between {-int(chk[1])} and {int(chk[0])}")
+            self.refine_on_device(step, refine_now, reset_now)
         elif refine_now or reset_now:
             # torch-level refinement: the tensors of the ParameterDict are replaced one by one -- a render from another
             # thread (Runner.rasterize_splats holds the same lock) must not see half of them
@@ -737,6 +714,37 @@ class Runner:
                           "flatten_ids": eng.ws["flatten_ids"], "means2d": eng.ws["means2d"]}
         self.step += 1
         return eng.loss()[0]
+
+    def refine_on_device(self, step: int, refine_now: bool = True, reset_now: bool = False) -> None:
+        """DefaultStrategy's refinement (and / or opacity reset) of `step` on the device-resident model of the fused engine:
+        five launches, nothing read back, the next step replays the other set's graph.  In replicated data parallelism
+        (a collective call: every rank, same step) the statistics of all ranks' views are summed and the row-sharded
+        moments gathered first, every rank then runs the same compaction, and N -- which sizes the following steps'
+        collectives -- is read back once and compared across ranks."""
+        cfg, s, eng = self.cfg, self.cfg.strategy, self._engine
+        assert eng.device_refine
+        if refine_now:
+            if self.world_size > 1:
+                n = eng.n_host
+                sdist.all_reduce_strategy_state({"grad2d": eng.dstats["grad2d"][:n], "count": eng.dstats["count"][:n]})
+                if self._radam is not None:      # the compaction rewrites ALL moments: fetch the other owners' rows
+                    act = eng.sets[eng.active]
+                    self._radam.gather([act[q][k] for q in ("m", "v") for k in act[q]], n)
+            eng.refine(s, step, self.scene_scale, seed=cfg.refine_seed)
+            if s.verbose:
+                rep = eng.refine_report()           # (synchronises; verbose runs only)
+                print(f"Step {step}: {rep['n_dupli']} GSs duplicated, {rep['n_split']} GSs split, {rep['n_prune']} GSs pruned. "
+                      f"Now having {rep['n_new']} GSs.")
+        if reset_now:
+            eng.reset_opacity(s.prune_opa * 2.0)
+        if refine_now and self.world_size > 1:
+            n_new = eng.sync_host()
+            eng.reprobe_capacity()       # a void iteration cannot be taken back here: size the bins for the grown model
+            chk = torch.tensor([n_new, -n_new], dtype=torch.int32, device=eng.device)
+            sdist.all_reduce_max_(chk)
+            if int(chk[0]) != n_new or int(chk[1]) != -n_new:
+                raise RuntimeError(f"replicas diverged: this rank holds {n_new} Gaussians after the refinement of step {step}, "
+                                   f"others between {-int(chk[1])} and {int(chk[0])}")
 
     def _train_step_sharded(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor) -> Tensor:
         """Gaussian-sharded step (splat_one_amd/sharded.py): camtoworlds / Ks hold the cameras of ALL ranks,
