@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--views", type=int, default=8, help="ring cameras / target images cycled per GPU (the reference draws a new view per step)")
     ap.add_argument("--attr-dtype", default="f32", choices=["f32", "f16"],
                     help="f16: float16 attribute rows (BASELINE.json configs[4]); float32 arithmetic and masters")
+    ap.add_argument("--max-gaussians", type=int, default=None,
+                    help="capacity (rows) of the device-resident model, Config.max_gaussians; default max(2 N, 2^20)")
     ap.add_argument("--loss-kernels", type=int, default=1, choices=[1, 2],
                     help="fused step: 1 = so_ssim_l1_fused (loss and gradient in one launch); 2 = the so_ssim_l1_fwd/bwd pair")
     ap.add_argument("--dp-mode", default="allreduce", choices=["auto", "gaussian_sharded", "allreduce"],
@@ -149,7 +151,7 @@ def main():
         cfg = Config(init_num_pts=N, init_scale=init_scale, init_opa=init_opa, batch_size=1, shN_init_std=0.1,
                      camera_model="pinhole", sh_degree_interval=1,    # SH degree 3 from step 3 on
                      fused=not args.operator_path, dp_mode=dp_mode, attr_dtype=args.attr_dtype,
-                     loss_kernels=args.loss_kernels)
+                     loss_kernels=args.loss_kernels, max_gaussians=args.max_gaussians)
         if args.densify:
             from splat_one_amd.strategy import DefaultStrategy
             cfg.strategy = DefaultStrategy(refine_start_iter=0, refine_every=args.densify, reset_every=3000, verbose=False)

@@ -629,7 +629,7 @@ class Runner:
                 attr_dtype=cfg.attr_dtype, tile_cull=cfg.tile_cull,
                 binned=cfg.binned, bin_capacity=cfg.bin_capacity,
                 fuse_adam=cfg.fuse_adam, device_refine=dev_refine, capacity=cfg.max_gaussians, loss_kernels=cfg.loss_kernels,
-                row_multiple=self.world_size * sdist.RowShardedAdam.ALIGN_ROWS,
+                row_multiple=(self.world_size * sdist.RowShardedAdam.ALIGN_ROWS if self.world_size > 1 else 1),
                 flat_multiple=(self._dp_chunks * self.world_size * sdist.ShardedFlatAdam.ALIGN
                                if self.world_size > 1 and not dev_refine else 0))
             self._sadam = self._radam = None
