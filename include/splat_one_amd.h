@@ -388,6 +388,9 @@ int so_shard_flag_get(int world, int64_t cap, const float *vrec_shard, int32_t *
 int64_t so_attr_rec_stride(int K);
 int so_attr_pack_f16(int64_t N, int K, const float *log_scales, const float *quats, const float *sh0,
                      const float *shN, void *arec, void *stream);
+/* ... of a device-resident model (so_step_desc.n_dev): N is the capacity, rows [0, *n_dev) are packed (n_dev nullable) */
+int so_attr_pack_f16_n(int64_t N, int K, const float *log_scales, const float *quats, const float *sh0,
+                       const float *shN, void *arec, const int32_t *n_dev, void *stream);
 int so_preprocess_fwd_f16(int C, int N, int K, int sh_degree, const float *means, const float *logit_opacities,
                           const void *arec, const float *viewmats, const float *Ks, int width, int height,
                           float eps2d, float near_plane, float far_plane, float radius_clip, int camera_model,
@@ -473,7 +476,8 @@ typedef struct so_step_desc {
   /* Device-resident Gaussian count (nullable): when set, `N` above is the CAPACITY of every per-Gaussian buffer (the
    * parameters, their moments, the per-view arrays with row stride N, rec / vrec, grad2d / count) and the number of
    * live Gaussians is read from *n_dev by the kernels themselves -- so_refine_default changes it on the device and a
-   * captured step follows without re-capture or host read-back.  float32 attributes only. */
+   * captured step follows without re-capture or host read-back.  With attr_rows_f16 the rows follow their masters through
+   * so_attr_pack_f16_n. */
   const int32_t *n_dev;
 } so_step_desc;
 typedef struct so_adam_fuse {

@@ -120,6 +120,7 @@ _SIGS = {
                           ctypes.POINTER(RefineParams), c_ptr, c_ptr, c_ptr],
     "so_reset_opacity": [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr],
     "so_attr_pack_f16": [c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
+    "so_attr_pack_f16_n": [c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
     "so_preprocess_fwd_f16": [c_int] * 4 + [c_ptr] * 5 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_int] + [c_ptr] * 10 + [c_i64, c_ptr, c_int, c_ptr, c_i64, c_ptr, c_ptr],
     "so_preprocess_bwd_f16": [c_int] * 4 + [c_ptr] * 5 + [c_int, c_int, c_f32, c_int, c_int] + [c_ptr] * 3 + [c_f32, c_f32] + [c_ptr] * 9 + [c_int, c_i64, c_ptr, c_ptr, c_ptr],
     "so_step_inputs": [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, ctypes.POINTER(c_f32),

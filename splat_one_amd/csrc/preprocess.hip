@@ -599,7 +599,9 @@ static inline int pp_grid(int64_t total) {
 // float32 SoA -> float16 attribute rows (attr_rec.hpp): one lane per 16-byte chunk, coalesced stores
 __global__ void __launch_bounds__(256)
 k_attr_pack_f16(int64_t N, int K, int stride16, const float *__restrict__ log_scales, const float *__restrict__ quats,
-                const float *__restrict__ sh0, const float *__restrict__ shN, uint4 *__restrict__ arec) {
+                const float *__restrict__ sh0, const float *__restrict__ shN, uint4 *__restrict__ arec,
+                const int32_t *__restrict__ n_dev) {
+  if (n_dev) N = min((int64_t)*n_dev, N);   // device-resident Gaussian count: the grid covers the capacity
   const int64_t total = N * stride16;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t n = i / stride16;
@@ -872,19 +874,53 @@ int preprocess_bwd_n(int C, int N, int K, int sh_degree, const float *means, con
                              nullptr, opacity_reg, scale_reg, v_means, v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN,
                              grad2d, count, vrec, absgrad_stats, 0, skip_flag, skip_out, stream, nullptr, n_dev, rec);
 }
+// the same with float16 attribute rows (so_preprocess_fwd_f16 / so_preprocess_bwd_f16)
+int preprocess_fwd_n_f16(int C, int N, int K, int sh_degree, const float *means, const float *logit_opacities, const void *arec,
+                         const float *viewmats, const float *Ks, int width, int height, float eps2d, float near_plane,
+                         float far_plane, float radius_clip, int camera_model, int antialiased, int tile_size, int32_t *radii,
+                         float *means2d, float *depths, float *conics, float *opacities, float *colors, int32_t *tiles_per_gauss,
+                         int32_t *tile_counts, float *rec, float *vrec, int32_t *tile_slots, int tile_cull, uint64_t *bin_keys,
+                         int64_t bin_cap, int32_t *bin_overflow, const int32_t *n_dev, void *stream) {
+  SO_REQUIRE((int64_t)C * N == 0 || attr_rec_ok(arec), "so_preprocess_fwd_f16: arec must be non-null and 16-byte aligned");
+  const AttrRec attrs{reinterpret_cast<const uint4 *>(arec), attr_rec_stride_bytes(K < 1 ? 1 : K) / 16};
+  return preprocess_fwd_impl("so_preprocess_fwd_f16", C, N, K, sh_degree, means, logit_opacities, attrs, viewmats, Ks, width,
+                             height, eps2d, near_plane, far_plane, radius_clip, camera_model, antialiased, tile_size, radii,
+                             means2d, depths, conics, opacities, colors, tiles_per_gauss, tile_counts, rec, vrec, 0, tile_slots,
+                             tile_cull, bin_keys, bin_cap, bin_overflow, stream, n_dev);
+}
+int preprocess_bwd_n_f16(int C, int N, int K, int sh_degree, const float *means, const float *logit_opacities, const void *arec,
+                         const float *viewmats, const float *Ks, int width, int height, float eps2d, int camera_model,
+                         int antialiased, const int32_t *radii, const float *opacities, const float *colors, float opacity_reg,
+                         float scale_reg, float *v_means, float *v_log_scales, float *v_quats, float *v_logit_opacities,
+                         float *v_sh0, float *v_shN, float *grad2d, float *count, const float *vrec, int absgrad_stats,
+                         const int32_t *skip_flag, float *skip_out, const int32_t *n_dev, void *stream) {
+  SO_REQUIRE(N == 0 || attr_rec_ok(arec), "so_preprocess_bwd_f16: arec must be non-null and 16-byte aligned");
+  SO_REQUIRE(N == 0 || vrec, "so_preprocess_bwd_f16: the gradient records (vrec) are required");
+  const AttrRec attrs{reinterpret_cast<const uint4 *>(arec), attr_rec_stride_bytes(K < 1 ? 1 : K) / 16};
+  return preprocess_bwd_impl("so_preprocess_bwd_f16", C, N, K, sh_degree, means, logit_opacities, attrs, viewmats, Ks, width,
+                             height, eps2d, camera_model, antialiased, radii, opacities, colors, nullptr, nullptr, nullptr,
+                             nullptr, nullptr, nullptr, opacity_reg, scale_reg, v_means, v_log_scales, v_quats,
+                             v_logit_opacities, v_sh0, v_shN, grad2d, count, vrec, absgrad_stats, 0, skip_flag, skip_out, stream,
+                             nullptr, n_dev, nullptr);
+}
 }  // namespace so
 
 extern "C" int64_t so_attr_rec_stride(int K) { return K >= 1 ? so::attr_rec_stride_bytes(K) : 0; }
 
 extern "C" int so_attr_pack_f16(int64_t N, int K, const float *log_scales, const float *quats, const float *sh0,
                                 const float *shN, void *arec, void *stream) {
+  return so_attr_pack_f16_n(N, K, log_scales, quats, sh0, shN, arec, nullptr, stream);
+}
+
+extern "C" int so_attr_pack_f16_n(int64_t N, int K, const float *log_scales, const float *quats, const float *sh0,
+                                  const float *shN, void *arec, const int32_t *n_dev, void *stream) {
   SO_REQUIRE(N >= 0 && K >= 1, "so_attr_pack_f16: bad sizes");
   if (N == 0) return SO_OK;
   SO_REQUIRE(log_scales && quats && sh0 && (shN || K == 1), "so_attr_pack_f16: null pointer");
   SO_REQUIRE(so::attr_rec_ok(arec), "so_attr_pack_f16: arec must be non-null and 16-byte aligned");
   const int stride16 = so::attr_rec_stride_bytes(K) / 16;
   hipLaunchKernelGGL(so::k_attr_pack_f16, dim3(so::pp_grid(N * stride16)), dim3(256), 0, so::as_stream(stream), N, K,
-                     stride16, log_scales, quats, sh0, shN, reinterpret_cast<uint4 *>(arec));
+                     stride16, log_scales, quats, sh0, shN, reinterpret_cast<uint4 *>(arec), n_dev);
   return so::check_launch("so_attr_pack_f16");
 }
 

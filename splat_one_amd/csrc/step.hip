@@ -76,6 +76,18 @@ int preprocess_bwd_n(int C, int N, int K, int sh_degree, const float *means, con
                      float *v_log_scales, float *v_quats, float *v_logit_opacities, float *v_sh0, float *v_shN, float *grad2d,
                      float *count, const float *vrec, int absgrad_stats, const int32_t *skip_flag, float *skip_out,
                      const int32_t *n_dev, const float *rec, void *stream);
+int preprocess_fwd_n_f16(int C, int N, int K, int sh_degree, const float *means, const float *logit_opacities, const void *arec,
+                         const float *viewmats, const float *Ks, int width, int height, float eps2d, float near_plane,
+                         float far_plane, float radius_clip, int camera_model, int antialiased, int tile_size, int32_t *radii,
+                         float *means2d, float *depths, float *conics, float *opacities, float *colors, int32_t *tiles_per_gauss,
+                         int32_t *tile_counts, float *rec, float *vrec, int32_t *tile_slots, int tile_cull, uint64_t *bin_keys,
+                         int64_t bin_cap, int32_t *bin_overflow, const int32_t *n_dev, void *stream);
+int preprocess_bwd_n_f16(int C, int N, int K, int sh_degree, const float *means, const float *logit_opacities, const void *arec,
+                         const float *viewmats, const float *Ks, int width, int height, float eps2d, int camera_model,
+                         int antialiased, const int32_t *radii, const float *opacities, const float *colors, float opacity_reg,
+                         float scale_reg, float *v_means, float *v_log_scales, float *v_quats, float *v_logit_opacities,
+                         float *v_sh0, float *v_shN, float *grad2d, float *count, const float *vrec, int absgrad_stats,
+                         const int32_t *skip_flag, float *skip_out, const int32_t *n_dev, void *stream);
 
 // Per-iteration inputs in one launch (see so_step_inputs in the header).  Workgroup 0 does the small serial
 // pieces (one lane per camera / per Ks entry / per Adam group); every workgroup zeroes its share of the counters.
@@ -215,9 +227,14 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
   SO_REQUIRE(bins == 0 || M * bins < ((int64_t)1 << 31), "so_train_step_fwd_bwd: C*tiles*bin_capacity does not fit 31 bits");
   int32_t *slots = bins ? nullptr : d->tile_slots;
   uint64_t *bin_keys = bins ? d->key_buf : nullptr;
-  SO_REQUIRE(!(d->n_dev && d->attr_rows_f16), "so_train_step_fwd_bwd: n_dev (device-resident N) needs float32 attributes");
   SO_REQUIRE(d->radii || (d->rec && !d->attr_rows_f16 && bins), "so_train_step_fwd_bwd: record-only views (radii == NULL) need rec, float32 attributes and binned lists");
-  if (d->n_dev || !d->radii)
+  if (d->n_dev && d->attr_rows_f16)
+    SO_STAGE(0, so::preprocess_fwd_n_f16(C, N, K, d->sh_degree, d->means, d->logit_opacities, d->attr_rows_f16, d->viewmats, d->Ks,
+                                         W, H, d->eps2d, d->near_plane, d->far_plane, d->radius_clip, d->camera_model,
+                                         d->antialiased, ts, d->radii, d->means2d, d->depths, d->conics, d->opacities, d->colors,
+                                         d->tiles_per_gauss, tile_counts, d->rec, forward_only ? nullptr : d->vrec, slots,
+                                         d->tile_cull, bin_keys, bins, overflow, d->n_dev, stream));
+  else if (d->n_dev || !d->radii)
     SO_STAGE(0, so::preprocess_fwd_n(C, N, K, d->sh_degree, d->means, d->log_scales, d->quats, d->logit_opacities, d->sh0, d->shN,
                                      d->viewmats, d->Ks, W, H, d->eps2d, d->near_plane, d->far_plane, d->radius_clip,
                                      d->camera_model, d->antialiased, ts, d->radii, d->means2d, d->depths, d->conics,
@@ -279,7 +296,13 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
                                               d->shN, d->viewmats, d->Ks, W, H, d->eps2d, d->camera_model, d->antialiased, d->radii,
                                               d->opacities, d->colors, d->opacity_reg, d->scale_reg, d->grad2d, d->count, d->vrec,
                                               d->absgrad, overflow, d->overflow_flag_out, F, stream, d->n_dev, d->rec));
-  } else if (d->n_dev || !d->radii)
+  } else if (d->n_dev && d->attr_rows_f16)
+    SO_STAGE(7, so::preprocess_bwd_n_f16(C, N, K, d->sh_degree, d->means, d->logit_opacities, d->attr_rows_f16, d->viewmats, d->Ks,
+                                         W, H, d->eps2d, d->camera_model, d->antialiased, d->radii, d->opacities, d->colors,
+                                         d->opacity_reg, d->scale_reg, d->v_means, d->v_log_scales, d->v_quats,
+                                         d->v_logit_opacities, d->v_sh0, d->v_shN, d->grad2d, d->count, d->vrec, d->absgrad,
+                                         overflow, d->overflow_flag_out, d->n_dev, stream));
+  else if (d->n_dev || !d->radii)
     SO_STAGE(7, so::preprocess_bwd_n(C, N, K, d->sh_degree, d->means, d->log_scales, d->quats, d->logit_opacities, d->sh0, d->shN,
                                      d->viewmats, d->Ks, W, H, d->eps2d, d->camera_model, d->antialiased, d->radii, d->opacities,
                                      d->colors, d->opacity_reg, d->scale_reg, d->v_means, d->v_log_scales, d->v_quats,

@@ -62,7 +62,6 @@ class FusedEngine:
         # torch.cat, no workspace rebuild, no graph re-capture (one graph per set).  The torch-side handles
         # (ParameterDict, optimiser state, statistics) are re-pointed lazily by `sync_host()`.
         self.device_refine = bool(device_refine)
-        assert not (self.device_refine and attr_dtype != "f32"), "device_refine needs float32 attributes"
         # flat_multiple > 0 (replicated data parallelism, distributed.ShardedFlatAdam): parameters and both moments live
         # in FLAT buffers with the segment layout of the flat gradient, padded to a multiple of `flat_multiple` floats,
         # so that reduce-scatter / sharded Adam / all-gather work on contiguous ranges of all four
@@ -224,6 +223,7 @@ class FusedEngine:
             self.active = dst
             self.refinements += 1
             self._host_stale = True
+            self.refresh_attrs()         # (float16 rows: rebuilt from the compacted masters)
 
     def reset_opacity(self, value: float) -> None:
         """gsplat `reset_opa`: opacity logits clamped to logit(value), their Adam moments zeroed -- in place, on the device."""
@@ -408,6 +408,11 @@ class FusedEngine:
         if self.attr_dtype != "f16":
             return
         s, p = self.splats, _lib.ptr
+        if self.device_refine:      # the active set's capacity-sized masters, live rows only (N on the device)
+            a = self.sets[self.active]["p"]
+            _lib.call("so_attr_pack_f16_n", self.cap, self.K, p(a["scales"]), p(a["quats"]), p(a["sh0"]), p(a["shN"]),
+                      p(self.ws["arec"]), p(self._n_dev[self.active:self.active + 1]), _lib.stream())
+            return
         _lib.call("so_attr_pack_f16", self.N, self.K, p(s["scales"].data), p(s["quats"].data), p(s["sh0"].data),
                   p(s["shN"].data), p(self.ws["arec"]), _lib.stream())
 
@@ -658,6 +663,8 @@ class FusedEngine:
             _lib.call("so_adam_step_dev_n", n, arr, lr0, gam, float(betas[0]), float(betas[1]), float(eps),
                       _lib.ptr(self._step_dev), 0, int(schedule_done), _lib.ptr(ovf), _lib.ptr(self.ws["ovf_f32"]),
                       _lib.ptr(self._n_dev[self.active:self.active + 1]), _lib.stream())
+            if self.attr_dtype == "f16":
+                self.refresh_attrs()     # the float16 rows follow their masters: one coalesced re-pack of the live rows
             return
         _lib.call("so_adam_step_dev_shadow", n, arr, lr0, gam, float(betas[0]), float(betas[1]), float(eps),
                   _lib.ptr(self._step_dev), 0, int(schedule_done), _lib.ptr(ovf), _lib.ptr(self.ws["ovf_f32"]),

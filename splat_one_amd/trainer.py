@@ -616,8 +616,7 @@ class Runner:
             # DefaultStrategy on the device (single GPU, and replicated data parallelism: every rank runs the same
             # compaction on the all-reduced statistics and the gathered moments; the optimiser step is sharded by ROW
             # pieces of the capacity-sized tensors -- a flat piece layout would move with N)
-            dev_refine = (cfg.device_refine and isinstance(s, DefaultStrategy)
-                          and cfg.attr_dtype == "f32" and s.refine_scale2d_stop_iter == 0)
+            dev_refine = cfg.device_refine and isinstance(s, DefaultStrategy) and s.refine_scale2d_stop_iter == 0
             eng = self._engine = FusedEngine(
                 self.splats, self.optimizers, W, H, B, sh_degree=0, camera_model=cfg.camera_model,
                 near_plane=cfg.near_plane, far_plane=cfg.far_plane, antialiased=cfg.antialiased,
@@ -658,6 +657,7 @@ class Runner:
             if self._radam is None:
                 self._radam = sdist.RowShardedAdam()
             self._radam.step(eng.ws["grads"], eng.sets[eng.active]["p"], eng.n_host, eng.adam_on_rows)
+            eng.refresh_attrs()              # float16 attribute rows (if any) follow the gathered masters
             eng._advance_host_counters()
         else:
             # replicated Gaussians: reduce-scatter of the flat gradient in chunks, Adam on this rank's 1/world of every
@@ -669,6 +669,7 @@ class Runner:
             M = eng.M
             sdist.all_reduce_max_(eng.ws["counters"][2 * M + 2:2 * M + 3])   # a void iteration on one rank is raised on all
             self._sadam.step(eng.ws["grads_flat"], eng.ws["params_flat"], eng.adam_on_flat_range)
+            eng.refresh_attrs()              # float16 attribute rows (if any) follow the gathered masters
             eng._advance_host_counters()
         if isinstance(s, MCMCStrategy):
             # lr = the means learning rate after this step's scheduler.step() (gsplat_trainer.py:753-761)

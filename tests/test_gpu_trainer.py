@@ -361,13 +361,13 @@ def test_load_checkpoint_resumes_schedule_and_state(dev, tmp_path):
         assert r2.strategy_state["grad2d"].shape[0] == 1500
 
 
-def _dp_refine_setup(dev, world_rank, world_size, device_refine, batch_size=1):
+def _dp_refine_setup(dev, world_rank, world_size, device_refine, batch_size=1, attr_dtype="f32"):
     from splat_one_amd.strategy import DefaultStrategy
     from splat_one_amd.trainer import Config, Runner
     W, H, N = 128, 96, 3000
     strat = DefaultStrategy(refine_start_iter=4, refine_every=4, reset_every=10, grow_grad2d=5e-5, verbose=False)
     cfg = Config(init_num_pts=N, init_scale=0.3, init_opa=0.3, shN_init_std=0.05, sh_degree_interval=1, fused=True,
-                 dp_mode="allreduce", strategy=strat, device_refine=device_refine, batch_size=batch_size)
+                 dp_mode="allreduce", strategy=strat, device_refine=device_refine, batch_size=batch_size, attr_dtype=attr_dtype)
     r = Runner(0, world_rank, world_size, cfg, scene_scale=1.0 / 1.1)
     with torch.no_grad():
         r.splats["scales"].add_((torch.randn(N, 3, generator=torch.Generator().manual_seed(7)) * 0.4).to(dev))
@@ -376,10 +376,20 @@ def _dp_refine_setup(dev, world_rank, world_size, device_refine, batch_size=1):
     return r, pixels, pinhole_K(W, H)[None].to(dev)
 
 
+def _check_f16_rows(r, attr_dtype):
+    """float16 attribute rows == the half-rounded float32 masters (they are what the kernels read)."""
+    if attr_dtype != "f16":
+        return
+    n = r._engine.sync_host()
+    rows = r._engine.attr_rows()
+    for k in ("quats", "scales", "sh0", "shN"):
+        assert torch.equal(rows[k][:n], r.splats[k].detach().half().float()), k
+
+
 def _dp_refine_worker(local_rank, world_rank, world_size, args):
-    out_dir, device_refine = args
+    out_dir, device_refine, attr_dtype = args
     dev = torch.device("cuda:0")
-    r, pixels, Ks = _dp_refine_setup(dev, world_rank, world_size, device_refine)
+    r, pixels, Ks = _dp_refine_setup(dev, world_rank, world_size, device_refine, attr_dtype=attr_dtype)
     px = pixels(world_rank)
     sizes = []
     for step in range(18):                                   # refinements at 8, 12, 16; opacity reset at 10
@@ -388,25 +398,27 @@ def _dp_refine_worker(local_rank, world_rank, world_size, args):
         sizes.append(len(r.splats["means"]))
     torch.cuda.synchronize()
     assert r._engine.device_refine == device_refine
+    _check_f16_rows(r, attr_dtype)
     st = {k: r.optimizers[k].state[r.splats[k]] for k in r.splats.keys()}
     torch.save({"splats": {k: v.detach().cpu() for k, v in r.splats.items()}, "sizes": sizes,
                 "m": {k: st[k]["exp_avg"].cpu() for k in st}, "step": {k: float(st[k]["step"]) for k in st}},
                os.path.join(out_dir, f"rank{world_rank}.pt"))
 
 
-@pytest.mark.parametrize("device_refine", [True, False])
-def test_replicated_dp_refinement_keeps_the_replicas_identical(dev, tmp_path, device_refine):
+@pytest.mark.parametrize("device_refine,attr_dtype", [(True, "f32"), (False, "f32"), (True, "f16"), (False, "f16")])
+def test_replicated_dp_refinement_keeps_the_replicas_identical(dev, tmp_path, device_refine, attr_dtype):
     """Replicated data parallelism through refinements.  device_refine=False: the statistics are all-reduced, the sharded
     Adam moments gathered, and every rank then duplicates / splits / prunes identically with the torch-level strategy; the
     reduce-scatter / sharded Adam / all-gather step goes on on the new size.  device_refine=True (the default): the model
     stays in the capacity-sized device sets, every rank runs the same compaction kernels on the all-reduced statistics and
     the gathered moments, and the optimiser step is sharded by row pieces (distributed.RowShardedAdam).  Either way the Gaussian sets stay
     bit-identical across ranks while their size changes; the device path is also compared with ONE process that trains
-    on the two ranks' views as a batch of two (same compaction kernels, same seed)."""
+    on the two ranks' views as a batch of two (same compaction kernels, same seed).  attr_dtype="f16": the float16
+    attribute rows the kernels read must follow the masters through the gathered optimiser step and the refinements."""
     from splat_one_amd import distributed as sdist
     env_backup = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     try:
-        sdist.cli(_dp_refine_worker, (str(tmp_path), device_refine), world_size=2, backend="gloo", port=_free_port())
+        sdist.cli(_dp_refine_worker, (str(tmp_path), device_refine, attr_dtype), world_size=2, backend="gloo", port=_free_port())
     finally:
         for k, v in env_backup.items():
             if v is not None:
@@ -419,7 +431,7 @@ def test_replicated_dp_refinement_keeps_the_replicas_identical(dev, tmp_path, de
         assert a["step"][k] == b["step"][k] == 18.0
     if not device_refine:
         return
-    r, pixels, Ks = _dp_refine_setup(dev, 0, 1, True, batch_size=2)
+    r, pixels, Ks = _dp_refine_setup(dev, 0, 1, True, batch_size=2, attr_dtype=attr_dtype)
     px = torch.cat([pixels(0), pixels(1)])
     sizes = []
     for step in range(18):
@@ -428,6 +440,7 @@ def test_replicated_dp_refinement_keeps_the_replicas_identical(dev, tmp_path, de
         sizes.append(r._engine.sync_host())
     # the two runs sum the same per-view gradients and statistics in a different order: decisions at a threshold may
     # differ for a Gaussian or two
+    _check_f16_rows(r, attr_dtype)
     assert abs(sizes[-1] - a["sizes"][-1]) <= 0.01 * sizes[-1] and len(set(sizes)) >= 3, (sizes, a["sizes"])
     if sizes == a["sizes"]:
         for k in a["splats"]:
