@@ -23,7 +23,7 @@ CASES = [("operator dense pinhole", dict(fused=False)),
          ("engine binned", dict(fused=True)),
          ("engine compact lists", dict(fused=True, binned=False)),
          ("engine spherical", dict(fused=True, camera_model="spherical")),
-         ("engine f16 rows (host refinement)", dict(fused=True, attr_dtype="f16")),
+         ("engine f16 rows (device refinement)", dict(fused=True, attr_dtype="f16")),
          ("engine two-kernel Adam", dict(fused=True, fuse_adam=False)),
          ("engine no tile cull", dict(fused=True, tile_cull=False)),
          ("engine antialiased", dict(fused=True, antialiased=True)),

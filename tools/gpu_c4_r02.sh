@@ -8,7 +8,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/c4r02
 mkdir -p $OUT
-ARGS="--n 1000000 --width 2560 --height 1440 --densify 100 --steps 300 --no-cpu-baseline"
+ARGS="--gaussians 1000000 --width 2560 --height 1440 --densify 100 --steps 300 --no-cpu-baseline"
 timeout 600 python3 bench.py $ARGS --kernel-table > $OUT/bench.json 2> $OUT/bench_stderr.txt
 grep -v amdgpu $OUT/bench_stderr.txt | tail -12; cut -c1-1500 $OUT/bench.json
 cd /tmp
