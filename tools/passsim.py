@@ -26,6 +26,7 @@ cnt4=np.zeros((tw*th,4,4),np.int32)   # [tile, quadrant, 4x4 block]
 cnt8=np.zeros((tw*th,4,8),np.int32)   # 2(rows)x4(cols)? use 8 groups of 8 lanes: rows of 8 pixels (1x8)
 cnt2=np.zeros((tw*th,4,2),np.int32)
 cntq=np.zeros((tw*th,4),np.int32)
+half_tb=half_lr=0   # (tile, Gaussian, half) pairs with a valid pixel: 16x8 halves (top/bottom), 8x16 halves (left/right)
 for s in range(0,I,B):
     e=min(I,s+B)
     gg=g[s:e]
@@ -43,6 +44,8 @@ for s in range(0,I,B):
     b4=vq.reshape(-1,4,2,4,2,4).transpose(0,1,2,4,3,5).reshape(-1,4,4,16).any(axis=3)   # [n,quadrant,4 blocks]
     b8=vq.any(axis=3)                                                # [n,quadrant,8 rows of 8 px]
     h2=vq.reshape(-1,4,2,32).any(axis=3)
+    half_tb+=(anyq[:,0]|anyq[:,1]).sum()+(anyq[:,2]|anyq[:,3]).sum()
+    half_lr+=(anyq[:,0]|anyq[:,2]).sum()+(anyq[:,1]|anyq[:,3]).sum()
     np.add.at(cntq,tile_of[s:e],anyq.astype(np.int32))
     np.add.at(cnt4,tile_of[s:e],b4.astype(np.int32))
     np.add.at(cnt8,tile_of[s:e],b8.astype(np.int32))
@@ -50,6 +53,12 @@ for s in range(0,I,B):
 print("regime",regime,"pairs (tile,gaussian) in lists",I,"with any valid pixel",pairs_any,"valid (pixel,gaussian)",valid_px)
 cur=cntq.sum()
 print("current 8x8 passes",cur,"lane util",valid_px/(64*cur))
+# several pixels per lane (VERDICT r1 task 3, third variant): a wave owns a 16x8 / 8x16 half tile (2 pixels per lane) or the
+# whole tile (4 per lane); the per-pass cost that does not depend on the pixel count (cross-lane reduction, atomics, list
+# walk: ~55 of the 143 instructions of a pass) is paid once per pass, the per-pixel part (~88) k times
+S_,P_=55,88
+for name,passes,k in (("8x8 quadrants (now)",cur,1),("16x8 halves",half_tb,2),("8x16 halves",half_lr,2),("16x16 tile",pairs_any,4)):
+    print(f"{name:22s} passes {passes:9d}  instr/pass {S_+P_*k:4d}  issue total {passes*(S_+P_*k)/1e6:8.1f} M  vs now {passes*(S_+P_*k)/(cur*(S_+P_)):.3f}  pixel-slot util {valid_px/(64*k*passes):.3f}")
 for name,c in (("4x4 rows (4 groups of 16)",cnt4),("1x8 rows (8 groups of 8)",cnt8),("4x8 halves (2 groups of 32)",cnt2)):
     it=c.max(axis=2).sum(); su=c.sum()
     print(name,"iterations",it,"ratio vs current",it/cur,"lane util",valid_px/(64*it),"sum of group passes",su, "ideal(avg) iterations",su/c.shape[2]/cur)
