@@ -74,14 +74,14 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 // each side.  Every thread stages element `tid` of the line and (the first 2*kHalf*CH threads only)
 // element `tid + kT`; the others re-read their first element and park the copy in an LDS slot nobody
 // reads, so that no lane-dependent branch is needed.
-template <int CH>
+template <int CH, int T = kT>
 struct StageGeom {
   unsigned off0, off1;   // offset inside an image row, clamped into it
   float cm0, cm1;        // 1 if the float is inside the row
   int slot1;             // LDS slot of the second element
   __device__ __forceinline__ StageGeom(int tid, int f0, int W) {
-    constexpr int E = kT + 2 * kHalf * CH;
-    const int e1 = tid + kT;
+    constexpr int E = T + 2 * kHalf * CH;
+    const int e1 = tid + T;
     const int ff0 = f0 - kHalf * CH + tid, ff1 = f0 - kHalf * CH + e1;
     const bool ok0 = ff0 >= 0 && ff0 < W * CH, ok1 = e1 < E && ff1 >= 0 && ff1 < W * CH;
     off0 = ok0 ? (unsigned)ff0 : 0u;
@@ -91,8 +91,8 @@ struct StageGeom {
     slot1 = e1 < E ? e1 : E + tid;   // dummy slots start at E
   }
 };
-template <int CH>
-constexpr int lds_line_slots() { return 2 * kT + 2 * kHalf * CH; }
+template <int CH, int T = kT>
+constexpr int lds_line_slots() { return 2 * T + 2 * kHalf * CH; }
 
 // wave-uniform pointer to row y (clamped into the image) of ONE image (`img` already points at batch element b;
 // one image is < 2^31 floats, checked on the host, so the row offset is 32-bit scalar arithmetic); rmask: 0/1
@@ -112,8 +112,8 @@ struct FwdStage {
   v2f p0, p1;   // (img1, img2) of the two staged elements, as loaded (not yet masked)
 };
 
-template <int CH>
-__device__ __forceinline__ void fwd_gload(FwdStage<CH> &st, const StageGeom<CH> &g, const float *img1, const float *img2,
+template <int CH, class G>
+__device__ __forceinline__ void fwd_gload(FwdStage<CH> &st, const G &g, const float *img1, const float *img2,
                                           int H, int stride, int y) {
   float rm;
   const float *r1 = row_ptr(img1, H, stride, y, rm);
@@ -135,8 +135,8 @@ __device__ __forceinline__ v4f fwd_record(v2f p, float mask) {   // (x, y, x*x +
 
 // The masks are applied here, when the row goes to LDS, not when it is loaded: touching a loaded value
 // is what makes the wave wait for it, and the loads are issued two steps before this point.
-template <int CH>
-__device__ __forceinline__ void fwd_lstore(const FwdStage<CH> &st, const StageGeom<CH> &g, v4f *line, int tid, int y, int H) {
+template <int CH, class G>
+__device__ __forceinline__ void fwd_lstore(const FwdStage<CH> &st, const G &g, v4f *line, int tid, int y, int H) {
   const float rm = (y >= 0 && y < H) ? 1.f : 0.f;
   line[tid] = fwd_record(st.p0, rm * g.cm0);
   line[g.slot1] = fwd_record(st.p1, rm * g.cm1);
@@ -457,24 +457,33 @@ k_ssim_l1_bwd(int B, int H, int W, const float *__restrict__ img1, const float *
 //   stage 2 = k_ssim_l1_bwd's step on line B (one step later, so that one barrier per step serves both lines):
 //             11 horizontal taps -> second register ring -> vertical taps -> gradient of the row 5 further up.
 // Cost of fusing: an output row needs derivative rows +-5, which need input rows +-10, and the same in columns: a
-// workgroup of kT floats x `rows` rows stages rows+20 input rows and runs stage 1 over rows+10 of them, but emits only
-// kT - 10*CH floats x rows; both rings live in registers (77 values, 244 VGPRs, two waves per SIMD).  `rows` is a
-// run-time argument chosen so that the whole grid is resident at once (57 at 1080p RGB: 26 x 19 workgroups on 512
-// slots).  Measured at 1080p RGB (tools/probes/ssim_bench.hip, profiles/r02_experiments.json): 90 us against
-// 52 + 47 us for the pair; with 45 or 108 rows per workgroup 111 / 131 us.
+// workgroup of kFusedT = 512 floats x `rows` rows (eight waves: one workgroup per CU at two waves per SIMD) stages rows+20
+// input rows and runs stage 1 over rows+10 of them, but emits only 512 - 10*CH floats x rows; both rings live in registers
+// (77 values, 244 VGPRs).  `rows` is a run-time argument chosen so that the whole grid is resident at once (52 at 1080p
+// RGB: 12 x 21 workgroups on 256 CUs).  Measured at 1080p RGB as single launches (tools/probes/ssim_bench.hip,
+// profiles/r02_experiments.json): 87.6 us (256-thread workgroups at 57 rows: 89.8 us) against 52 + 47 us for the pair;
+// with rows that put the grid into a second round (45) or leave it short of waves (108): 111 / 131 us.
+#ifndef SO_FUSED_THREADS
+#define SO_FUSED_THREADS 512
+#endif
 #ifndef SO_FUSED_WAVES
 #define SO_FUSED_WAVES 2
 #endif
 #ifndef SO_FUSED_TAPGROUP
 #define SO_FUSED_TAPGROUP 6
 #endif
+constexpr int kFusedT = SO_FUSED_THREADS;   // floats of a row per workgroup of the fused kernel (8 waves: one workgroup per CU)
 constexpr int kFusedWaves = SO_FUSED_WAVES;
 constexpr int kFusedTapGroup = SO_FUSED_TAPGROUP;
+// make_window()'s weights as compile-time constants (the launcher checks them against the computed ones): eleven scalar
+// registers less to keep alive through a loop that is short of them -- constants are re-materialised, arguments spilled
+constexpr float kFusedW[kWin] = {0x1.0d956cp-10f, 0x1.f1fe02p-8f, 0x1.26eb18p-5f, 0x1.bff0fep-4f, 0x1.b43c4p-3f, 0x1.10656p-2f,
+                                 0x1.b43c4p-3f,   0x1.bff0fep-4f, 0x1.26eb18p-5f, 0x1.f1fe02p-8f, 0x1.0d956cp-10f};
 
 template <int CH>
-constexpr int fused_out_floats() { return kT - 2 * kHalf * CH; }
+constexpr int fused_out_floats() { return kFusedT - 2 * kHalf * CH; }
 template <int CH>
-constexpr int line_b_slots() { return kT + 2 * kHalf * CH; }
+constexpr int line_b_slots() { return kFusedT + 2 * kHalf * CH; }
 
 template <int CH>
 struct FusedState {
@@ -497,9 +506,9 @@ struct FusedOut {
 // y0-15+it (written to line B), reads derivative row y0-16+it from line B, and emits output row y0-21+it.
 template <int CH, int P, int MODE>
 __device__ __forceinline__ void fused_step(FusedState<CH> &S, FwdStage<CH> &preA, FwdStage<CH> &preB,
-                                           v4f (*rowsA)[lds_line_slots<CH>()], v4f (*rowsB)[line_b_slots<CH>()],
-                                           const StageGeom<CH> &g, const FusedOut &o, const float *img1, const float *img2,
-                                           int it, int n_out, int H, int W, int y0, int tid, int valid, const Window &win,
+                                           v4f (*rowsA)[lds_line_slots<CH, kFusedT>()], v4f (*rowsB)[line_b_slots<CH>()],
+                                           const StageGeom<CH, kFusedT> &g, const FusedOut &o, const float *img1, const float *img2,
+                                           int it, int n_out, int H, int W, int y0, int tid, int valid,
                                            float wl1, float wss, float *__restrict__ v_img1) {
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
@@ -529,8 +538,8 @@ __device__ __forceinline__ void fused_step(FusedState<CH> &S, FwdStage<CH> &preA
 #pragma unroll
       for (int j = 0; j < kFusedTapGroup; ++j)
         if (k0 + j < kWin) {
-          m = pk_fma(win.w[k0 + j], v2f{t[j].x, t[j].y}, m);
-          q = pk_fma(win.w[k0 + j], v2f{t[j].z, t[j].w}, q);
+          m = pk_fma(kFusedW[k0 + j], v2f{t[j].x, t[j].y}, m);
+          q = pk_fma(kFusedW[k0 + j], v2f{t[j].z, t[j].w}, q);
           if (k0 + j == kHalf) ctr_abs = fabsf(t[j].x - t[j].y);
         }
       __builtin_amdgcn_sched_barrier(0);
@@ -546,8 +555,8 @@ __device__ __forceinline__ void fused_step(FusedState<CH> &S, FwdStage<CH> &preA
 #pragma unroll
     for (int k = 0; k < kWin; ++k) {
       const int slot = (P + 1 + k) % kWin;
-      mu = pk_fma(win.w[k], S.r1[slot][0], mu);
-      sq = pk_fma(win.w[k], S.r1[slot][1], sq);
+      mu = pk_fma(kFusedW[k], S.r1[slot][0], mu);
+      sq = pk_fma(kFusedW[k], S.r1[slot][1], sq);
     }
     const float mu1 = mu.x, mu2 = mu.y;
     const float musq = fmaf(mu1, mu1, mu2 * mu2), m12 = mu1 * mu2;
@@ -578,8 +587,8 @@ __device__ __forceinline__ void fused_step(FusedState<CH> &S, FwdStage<CH> &preA
 #pragma unroll
       for (int j = 0; j < kFusedTapGroup; ++j)
         if (k0 + j < kWin) {
-          ac = pk_fma(win.w[k0 + j], v2f{t[j].x, t[j].y}, ac);
-          d = fmaf(win.w[k0 + j], t[j].z, d);
+          ac = pk_fma(kFusedW[k0 + j], v2f{t[j].x, t[j].y}, ac);
+          d = fmaf(kFusedW[k0 + j], t[j].z, d);
         }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -592,8 +601,8 @@ __device__ __forceinline__ void fused_step(FusedState<CH> &S, FwdStage<CH> &preA
 #pragma unroll
     for (int k = 0; k < kWin; ++k) {
       const int slot = (P + 1 + k) % kWin;
-      vac = pk_fma(win.w[k], S.r2a[slot], vac);
-      vd = fmaf(win.w[k], S.r2b[slot], vd);
+      vac = pk_fma(kFusedW[k], S.r2a[slot], vac);
+      vd = fmaf(kFusedW[k], S.r2b[slot], vd);
     }
     if (o.store) {
       const float diff = xv - yv;
@@ -604,25 +613,29 @@ __device__ __forceinline__ void fused_step(FusedState<CH> &S, FwdStage<CH> &preA
 }
 
 template <int CH>
-__global__ void __launch_bounds__(kT, kFusedWaves)
+__global__ void __launch_bounds__(kFusedT, kFusedWaves)
 k_ssim_l1_fused(int B, int H, int W, int rows, const float *__restrict__ img1, const float *__restrict__ img2_direct,
-                const float *const *__restrict__ img2_slot, int valid, Window win, float w_l1, float w_ssim,
+                const float *const *__restrict__ img2_slot, int valid, float w_l1, float w_ssim,
                 const float *__restrict__ v_loss, float *__restrict__ sums, float *__restrict__ v_img1,
                 float *__restrict__ loss_out, int32_t *__restrict__ ticket, float c_const) {
+#ifdef SO_FUSED_DBG_DIRECT
+  const float *__restrict__ img2 = img2_direct;
+#else
   const float *__restrict__ img2 = img2_slot ? *img2_slot : img2_direct;
+#endif
   const float up = v_loss ? *v_loss : 1.f;
   const float wl1 = w_l1 * up, wss = w_ssim * up;
-  __shared__ v4f rowsA[2][lds_line_slots<CH>()];
+  __shared__ v4f rowsA[2][lds_line_slots<CH, kFusedT>()];
   __shared__ v4f rowsB[2][line_b_slots<CH>()];
-  __shared__ float red[2][kT / 64];
+  __shared__ float red[2][kFusedT / 64];
   const int tid = threadIdx.x;
   const int f0 = blockIdx.x * fused_out_floats<CH>() - kHalf * CH;   // float of thread 0 (negative in the first strip)
   const int y0 = blockIdx.y * rows, b = blockIdx.z;
   const int n_out = (H - y0) < rows ? (H - y0) : rows;
   const int n_steps = n_out + 4 * kHalf + 1;
-  const StageGeom<CH> g(tid, f0, W);
+  const StageGeom<CH, kFusedT> g(tid, f0, W);
   const int f = f0 + tid;
-  const bool in_row = f >= 0 && f < W * CH, inner = tid >= kHalf * CH && tid < kT - kHalf * CH;
+  const bool in_row = f >= 0 && f < W * CH, inner = tid >= kHalf * CH && tid < kFusedT - kHalf * CH;
   const int x = in_row ? f / CH : 0;
   FusedOut o;
   o.off = in_row ? (unsigned)f : 0u;
@@ -634,7 +647,7 @@ k_ssim_l1_fused(int B, int H, int W, int rows, const float *__restrict__ img1, c
     const int64_t ob = (int64_t)b * H * ((int64_t)W * CH);
     img1 += ob; img2 += ob; v_img1 += ob;
   }
-  for (int i = tid; i < 2 * line_b_slots<CH>(); i += kT) (&rowsB[0][0])[i] = v4f{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < 2 * line_b_slots<CH>(); i += kFusedT) (&rowsB[0][0])[i] = v4f{0.f, 0.f, 0.f, 0.f};
   FwdStage<CH> preA, preB;
   fwd_gload<CH>(preA, g, img1, img2, H, W * CH, y0 - 2 * kHalf);
   fwd_lstore<CH>(preA, g, rowsA[0], tid, y0 - 2 * kHalf, H);
@@ -644,7 +657,7 @@ k_ssim_l1_fused(int B, int H, int W, int rows, const float *__restrict__ img1, c
   S.l1_acc = S.ss_acc = 0.f;
 #pragma unroll
   for (int i = 0; i < kWin; ++i) { S.r1[i][0] = S.r1[i][1] = S.r2a[i] = v2f{0.f, 0.f}; S.r2b[i] = 0.f; }
-#define SO_STEP(P, MODE) fused_step<CH, P, MODE>(S, preA, preB, rowsA, rowsB, g, o, img1, img2, base + P, n_out, H, W, y0, tid, valid, win, wl1, wss, v_img1)
+#define SO_STEP(P, MODE) fused_step<CH, P, MODE>(S, preA, preB, rowsA, rowsB, g, o, img1, img2, base + P, n_out, H, W, y0, tid, valid, wl1, wss, v_img1)
   {
     const int base = 0;
     SO_STEP(0, 0); SO_STEP(1, 0); SO_STEP(2, 0); SO_STEP(3, 0); SO_STEP(4, 0);
@@ -671,7 +684,7 @@ k_ssim_l1_fused(int B, int H, int W, int rows, const float *__restrict__ img1, c
   if (tid == 0) {
     float a = 0.f, c = 0.f;
 #pragma unroll
-    for (int w = 0; w < kT / 64; ++w) { a += red[0][w]; c += red[1][w]; }
+    for (int w = 0; w < kFusedT / 64; ++w) { a += red[0][w]; c += red[1][w]; }
     atomicAdd(sums, a);
     atomicAdd(sums + 1, c);
     if (loss_out) {
@@ -795,20 +808,24 @@ int so::ssim_l1_fused_launch(int B, int H, int W, int CH, const float *img1, con
   SO_REQUIRE(img1 && (img2 || img2_slot) && sums && v_img1, "so_ssim_l1_fused: null pointer");
   SO_REQUIRE(loss_out == nullptr || ticket != nullptr, "so_ssim_l1_fused: loss_out needs a ticket");
   SO_REQUIRE((int64_t)H * W * CH < (int64_t)INT32_MAX, "so_ssim_l1_fused: one image must hold fewer than 2^31 values");
-  const so::Window win = so::make_window();
-  const int out_t = so::kT - 2 * so::kHalf * CH, nx = (W * CH + out_t - 1) / out_t;
+  {
+    const so::Window win = so::make_window();
+    for (int i = 0; i < so::kWin; ++i)
+      SO_REQUIRE(win.w[i] == so::kFusedW[i], "so_ssim_l1_fused: window constant %d differs from the computed weight", i);
+  }
+  const int out_t = so::kFusedT - 2 * so::kHalf * CH, nx = (W * CH + out_t - 1) / out_t;
   if (rows == 0) {
-    const int64_t slots = 256 * so::kFusedWaves * 4 / (so::kT / 64);   // workgroups resident at once on 256 CUs
+    const int64_t slots = 256 * so::kFusedWaves * 4 / (so::kFusedT / 64);   // workgroups resident at once on 256 CUs
     const int64_t ny_max = slots / ((int64_t)nx * B) > 0 ? slots / ((int64_t)nx * B) : 1;
     rows = (int)((H + ny_max - 1) / ny_max);
     if (rows < 24) rows = 24;
   }
   const int ny = (H + rows - 1) / rows;
   SO_REQUIRE(ny <= 65535 && B <= 65535, "so_ssim_l1_fused: grid too large");
-  const dim3 grid(nx, ny, B), block(so::kT);
+  const dim3 grid(nx, ny, B), block(so::kFusedT);
   hipStream_t st = so::as_stream(stream);
 #define SO_LAUNCH_FUSED(CHV) hipLaunchKernelGGL(so::k_ssim_l1_fused<CHV>, grid, block, 0, st, B, H, W, rows, img1, img2, img2_slot, \
-                                                 padding_valid, win, w_l1, w_ssim, v_loss, sums, v_img1, loss_out, ticket, loss_const)
+                                                 padding_valid, w_l1, w_ssim, v_loss, sums, v_img1, loss_out, ticket, loss_const)
   if (CH == 1) SO_LAUNCH_FUSED(1);
   else if (CH == 3) SO_LAUNCH_FUSED(3);
   else SO_LAUNCH_FUSED(4);

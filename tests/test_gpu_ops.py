@@ -685,7 +685,7 @@ def test_photometric_loss_random_sizes(dev, seed):
 @pytest.mark.parametrize("seed", list(range(16)))
 def test_fused_loss_kernel(dev, seed):
     """so_ssim_l1_fused (loss + gradient in one launch, derivative values through LDS) against the float64 oracle and
-    against the forward/backward pair, on random sizes around its strip boundaries (256 - 10 CH floats of a row, any
+    against the forward/backward pair, on random sizes around its strip boundaries (512 - 10 CH floats of a row, any
     number of rows per workgroup), batches, channel counts, both paddings; every launch is repeated on the same work
     buffer (the loss scalars come from the workgroup that draws the last ticket, which must leave the ticket at zero)."""
     import random
@@ -695,7 +695,7 @@ def test_fused_loss_kernel(dev, seed):
     rnd = random.Random(4100 + seed)
     CH = rnd.choice([3, 3, 3, 1, 4])
     B = rnd.choice([1, 1, 2, 3])
-    out_t = 256 - 10 * CH
+    out_t = 512 - 10 * CH           # floats of a row one workgroup emits
     W = rnd.choice([11, 12, 23, out_t // CH, out_t // CH + 1, 2 * out_t // CH, 2 * out_t // CH + 1, rnd.randint(11, 400)])
     H = rnd.choice([11, 13, 24, 25, 47, 48, 49, rnd.randint(11, 200)])
     rows = rnd.choice([0, 0, 1, 5, 11, 24, 57, H])

@@ -4,9 +4,9 @@
 set -e
 cd "$(dirname "$0")/.."
 rm -f tools/probes/ssim_fused_*.bin
-for v in ${FUSED_VARIANTS:-256,2,6 256,2,4 512,2,4}; do
+for v in ${FUSED_VARIANTS:-512,2,4 512,2,6 256,2,6}; do
   IFS=, read -r t w g <<< "$v"
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=fast -Wno-unused-function -DSO_SSIM_THREADS=$t -DSO_FUSED_WAVES=$w -DSO_FUSED_TAPGROUP=$g \
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=fast -Wno-unused-function -DSO_FUSED_THREADS=$t -DSO_FUSED_WAVES=$w -DSO_FUSED_TAPGROUP=$g \
     -Rpass-analysis=kernel-resource-usage splat_one_amd/csrc/loss.hip splat_one_amd/csrc/common.hip tools/probes/ssim_bench.hip \
     -o tools/probes/ssim_fused_t${t}w${w}g${g}.bin 2> /tmp/ssim_fused_t${t}w${w}g${g}.log &
 done
