@@ -788,6 +788,7 @@ int so::ssim_l1_bwd_launch(int B, int H, int W, int CH, const float *img1, const
  * from the workgroup that finishes last; it needs `ticket`, one int32 that is zero before the first launch (the kernel
  * returns it to zero) and is not shared by launches that may overlap.  rows: output rows per workgroup, 0 = chosen so that
  * the grid is resident at once. */
+extern "C" int so_device_cu_count(void);
 namespace so {
 int ssim_l1_fused_launch(int B, int H, int W, int CH, const float *img1, const float *img2, const float *const *img2_slot,
                          int padding_valid, float w_l1, float w_ssim, const float *v_loss, float *sums, float *v_img1,
@@ -815,7 +816,8 @@ int so::ssim_l1_fused_launch(int B, int H, int W, int CH, const float *img1, con
   }
   const int out_t = so::kFusedT - 2 * so::kHalf * CH, nx = (W * CH + out_t - 1) / out_t;
   if (rows == 0) {
-    const int64_t slots = 256 * so::kFusedWaves * 4 / (so::kFusedT / 64);   // workgroups resident at once on 256 CUs
+    static const int cus = so_device_cu_count() > 0 ? so_device_cu_count() : 256;   // 256 on an unpartitioned MI355X
+    const int64_t slots = (int64_t)cus * so::kFusedWaves * 4 / (so::kFusedT / 64);   // workgroups resident at once
     const int64_t ny_max = slots / ((int64_t)nx * B) > 0 ? slots / ((int64_t)nx * B) : 1;
     rows = (int)((H + ny_max - 1) / ny_max);
     if (rows < 24) rows = 24;
