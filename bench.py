@@ -15,7 +15,6 @@ Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
