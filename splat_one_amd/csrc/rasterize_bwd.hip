@@ -26,8 +26,14 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
                 const int32_t *__restrict__ last_ids, const float *__restrict__ v_render_colors,
                 const float *__restrict__ v_render_alphas, float *__restrict__ v_means2d,
                 float *__restrict__ v_means2d_abs, float *__restrict__ v_conics, float *__restrict__ v_colors,
-                float *__restrict__ v_opacities, int wrap_flags) {
+                float *__restrict__ v_opacities, int wrap_flags, const LossFinal fin) {
   constexpr int BLOCK = TS * TS;
+  if (fin.sums && blockIdx.x == 0 && threadIdx.x == 0) {   // (see LossFinal: the loss kernel before this one has completed)
+    const float l1m = fin.sums[0] * fin.a_l1, ssm = fin.sums[1] * fin.b_ss;
+    fin.out[0] = fin.w_l1 / fin.a_l1 * l1m + fin.w_ssim / fin.b_ss * ssm + fin.c_const;
+    fin.out[1] = l1m;
+    fin.out[2] = 1.f - ssm;
+  }
   constexpr int NWAVES = (BLOCK + 63) / 64;
   // staged per Gaussian (same records as the forward): A = (x, y, conic a, conic b),
   // B = (conic c, opacity [, r, g when D == 3]), remaining colour channels in s_col
@@ -259,13 +265,18 @@ static int launch_bwd(int TS, bool abs_, dim3 grid, hipStream_t st, int C, int N
 #define SO_GO(TSV, ABSV)                                                                                         \
   hipLaunchKernelGGL((k_rasterize_bwd<D, TSV, ABSV, false>), grid, dim3(TSV * TSV), 0, st, C, N, W, H, tile_w, tile_h, \
                      m2, conics, colors, opacities, backgrounds, tile_masks, offsets, flatten_ids, n_dev,       \
-                     n_host, ra, last, v_rc, v_ra, v_m, v_abs, v_cn, v_col, v_op, wrap_flags)
+                     n_host, ra, last, v_rc, v_ra, v_m, v_abs, v_cn, v_col, v_op, wrap_flags, LossFinal{})
   if (TS == 16) { if (abs_) SO_GO(16, true); else SO_GO(16, false); }
   else          { if (abs_) SO_GO(8, true);  else SO_GO(8, false); }
 #undef SO_GO
   return check_launch("so_rasterize_bwd");
 }
 
+int rasterize_bwd_packed_launch(int C, int N, int width, int height, int tile_size, const float *rec, const float *backgrounds,
+                                const int32_t *isect_offsets, const int32_t *flatten_ids, const int32_t *n_isects_dev,
+                                int64_t n_isects_host, const float *render_alphas, const int32_t *last_ids,
+                                const float *v_render_colors, const float *v_render_alphas, float *vrec, int absgrad,
+                                const LossFinal &fin, void *stream);
 }  // namespace so
 
 extern "C" int so_rasterize_bwd(int C, int N, int D, int width, int height, int tile_size, const float *means2d,
@@ -313,6 +324,17 @@ extern "C" int so_rasterize_bwd_packed(int C, int N, int width, int height, int 
                                        int64_t n_isects_host, const float *render_alphas, const int32_t *last_ids,
                                        const float *v_render_colors, const float *v_render_alphas, float *vrec,
                                        int absgrad, void *stream) {
+  return so::rasterize_bwd_packed_launch(C, N, width, height, tile_size, rec, backgrounds, isect_offsets, flatten_ids, n_isects_dev,
+                                         n_isects_host, render_alphas, last_ids, v_render_colors, v_render_alphas, vrec, absgrad,
+                                         so::LossFinal{}, stream);
+}
+
+// internal (step.hip): the same launch, with the fused step's loss scalars finalised by its first thread
+int so::rasterize_bwd_packed_launch(int C, int N, int width, int height, int tile_size, const float *rec, const float *backgrounds,
+                                    const int32_t *isect_offsets, const int32_t *flatten_ids, const int32_t *n_isects_dev,
+                                    int64_t n_isects_host, const float *render_alphas, const int32_t *last_ids,
+                                    const float *v_render_colors, const float *v_render_alphas, float *vrec, int absgrad,
+                                    const so::LossFinal &fin, void *stream) {
   SO_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, "so_rasterize_bwd_packed: bad sizes");
   const int wrap_flags = tile_size & ~0xFF;
   tile_size = so::tile_size_of(tile_size);
@@ -331,7 +353,7 @@ extern "C" int so_rasterize_bwd_packed(int C, int N, int width, int height, int 
   hipLaunchKernelGGL((so::k_rasterize_bwd<3, TSV, ABSV, true>), grid, dim3(TSV * TSV), 0, st, C, N, width, height, \
                      tile_w, tile_h, nullptr, nullptr, rec, nullptr, backgrounds, nullptr, isect_offsets,         \
                      flatten_ids, n_isects_dev, n_isects_host, render_alphas, last_ids, v_render_colors,          \
-                     v_render_alphas, nullptr, nullptr, nullptr, vrec, nullptr, wrap_flags)
+                     v_render_alphas, nullptr, nullptr, nullptr, vrec, nullptr, wrap_flags, fin)
   if (tile_size == 16) { if (absgrad) SO_GO(16, true); else SO_GO(16, false); }
   else                 { if (absgrad) SO_GO(8, true);  else SO_GO(8, false); }
 #undef SO_GO

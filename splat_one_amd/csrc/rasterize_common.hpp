@@ -4,6 +4,15 @@
 
 namespace so {
 
+// Loss scalars of the fused training step, finalised by the FIRST thread of the backward rasteriser (the kernel that
+// follows the loss kernel in the step): the loss kernel's own last-workgroup finalisation costs it 4.4 us of tail latency
+// (two memory round trips at the end of every workgroup); here the sums are simply complete.  sums == NULL: nothing to do.
+struct LossFinal {
+  const float *sums;   // [0] sum |x - y|, [1] sum of the SSIM map
+  float *out;          // [0] loss, [1] mean |x - y|, [2] 1 - mean SSIM
+  float w_l1, w_ssim, c_const, a_l1, b_ss;   // loss = w_l1 sums[0] + w_ssim sums[1] + c_const;  means = sums * a_l1 / b_ss
+};
+
 constexpr float kAlphaMax = 0.999f;
 constexpr float kAlphaMin = 1.f / 255.f;
 constexpr float kTStop = 1e-4f;

@@ -7,7 +7,7 @@
 // so_train_step_optimize : :726-742 (all Adam steps + ExponentialLR on the means) with the step
 //   counter, learning-rate schedule and bias corrections evaluated on the device.
 // Between the two the caller may all-reduce the gradients (view-sharded data parallelism).
-#include "so_common.hpp"
+#include "rasterize_common.hpp"   // (LossFinal; includes so_common.hpp)
 
 #include <vector>
 
@@ -51,6 +51,11 @@ int ssim_l1_fwd_launch(int B, int H, int W, int CH, const float *img1, const flo
 int ssim_l1_bwd_launch(int B, int H, int W, int CH, const float *img1, const float *img2, const float *const *img2_slot,
                        const float *dmaps, float w_l1, float w_ssim, const float *v_loss, float *v_img1, const float *sums,
                        float *loss_out, int padding_valid, float loss_const, void *stream);
+int rasterize_bwd_packed_launch(int C, int N, int width, int height, int tile_size, const float *rec, const float *backgrounds,
+                                const int32_t *isect_offsets, const int32_t *flatten_ids, const int32_t *n_isects_dev,
+                                int64_t n_isects_host, const float *render_alphas, const int32_t *last_ids,
+                                const float *v_render_colors, const float *v_render_alphas, float *vrec, int absgrad,
+                                const LossFinal &fin, void *stream);
 int ssim_l1_fused_launch(int B, int H, int W, int CH, const float *img1, const float *img2, const float *const *img2_slot,
                          int padding_valid, float w_l1, float w_ssim, const float *v_loss, float *sums, float *v_img1,
                          float *loss_out, int32_t *ticket, float loss_const, int rows, void *stream);
@@ -266,10 +271,14 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
   if (forward_only) return SO_OK;
   // loss = (1-l) * mean|.| + l * (1 - mean SSIM_valid)
   const float n_l1 = (float)C * H * W * 3.f, n_ss = (float)C * 3.f * (float)(H - 10) * (float)(W - 10);
-  if (!d->dmaps) {   // one kernel, the derivative values never leave the CU
+  so::LossFinal fin{};
+  if (!d->dmaps) {   // one kernel, the derivative values never leave the CU; the loss scalars are written by the first
+                     // thread of the backward rasteriser below (LossFinal), not by this kernel's last workgroup
     SO_STAGE(9, so::ssim_l1_fused_launch(C, H, W, 3, d->render_colors, d->pixels, d->pixels_indirect, 1, (1.f - d->ssim_lambda) / n_l1,
-                          -d->ssim_lambda / n_ss, nullptr, d->loss_sums, d->v_render_colors, d->loss_sums + 2,
-                          reinterpret_cast<int32_t *>(d->loss_sums + 5), d->ssim_lambda, 0, stream));
+                          -d->ssim_lambda / n_ss, nullptr, d->loss_sums, d->v_render_colors, nullptr, nullptr, d->ssim_lambda, 0,
+                          stream));
+    fin = so::LossFinal{d->loss_sums, d->loss_sums + 2, (1.f - d->ssim_lambda) / n_l1, -d->ssim_lambda / n_ss, d->ssim_lambda,
+                        1.f / n_l1, 1.f / n_ss};
   } else {           // the forward / backward pair through dmaps (kept for comparison: bench.py --loss-kernels 2)
     SO_STAGE(4, so::ssim_l1_fwd_launch(C, H, W, 3, d->render_colors, d->pixels, d->pixels_indirect, 1, d->loss_sums, d->dmaps, stream));
     SO_STAGE(5, so::ssim_l1_bwd_launch(C, H, W, 3, d->render_colors, d->pixels, d->pixels_indirect, d->dmaps, (1.f - d->ssim_lambda) / n_l1,
@@ -278,9 +287,9 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
   }
   // gradients of the intermediates accumulate in the 64-byte records vrec[C*N] (zeroed by the
   // forward preprocess kernel): one atomic request per (tile quadrant, Gaussian)
-    SO_STAGE(6, so_rasterize_bwd_packed(C, N, W, H, ts | wrap_flags, d->rec, d->backgrounds, list_off, d->flatten_ids, list_n,
-                                        list_cap, d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
-                                        d->absgrad, stream));
+    SO_STAGE(6, so::rasterize_bwd_packed_launch(C, N, W, H, ts | wrap_flags, d->rec, d->backgrounds, list_off, d->flatten_ids, list_n,
+                                                list_cap, d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
+                                                d->absgrad, fin, stream));
   if (d->fuse_adam) {
     // the optimiser runs inside the backward kernel (gradients never reach HBM); its schedule for this step was
     // evaluated by so_step_inputs into the scratch behind the step counter
