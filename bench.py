@@ -1,7 +1,12 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the MI355X-native 3DGS training path.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N>1: either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or -- when
+no RANK is set -- bench.py starts its own N ranks (one child process per GPU, like `cli(main, cfg)` at
+/root/reference/utils/gsplat_utils/gsplat_trainer.py:998) from a parent that never touches the GPU, forwards rank 0's JSON
+line and exits non-zero if any rank failed.
 
 Workload (BASELINE.json configs[1], "c2"): 100k random Gaussians (reference init, trainer
 `mcmc` preset = trained-like small splats), 1920x1080, SH degree 3, ONE view per GPU per step;
@@ -86,6 +91,73 @@ def cpu_baseline(n, width, height, regime, seconds_budget=20.0):
                       f"{regime} workload: torch fp32 projection/SH/binning/loss/Adam + oracle/c/raster_oracle.c (f32, OpenMP)",
             "forward_mpix_per_s": width * height / fwd / 1e6}
 
+def self_launch(n_ranks, argv):
+    """`python bench.py --gpus N` without a launcher (gsplat_trainer.py:998 `cli(main, cfg)` spawns one process per GPU the
+    same way): start N children of THIS script with torchrun's environment contract, one rank per GPU.  The parent makes
+    no HIP call (it only waits), children inherit stdout / stderr (rank 0 prints the JSON line).  If a rank fails the
+    others are terminated -- by PID -- and its exit code becomes ours."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    base = dict(os.environ)
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                SPLAT_ONE_AMD_SELF_LAUNCHED="1")
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n_ranks)))
+    procs = []
+    for r in range(n_ranks):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    alive = set(range(n_ranks))
+    try:
+        while alive:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 128 - code
+                    print(f"[bench] rank {r} exited with code {code}: stopping the other ranks", file=sys.stderr)
+                    for q in alive:
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+    return rc
+
+
+def rank_report(dist, local_rank, dev_index):
+    """What the process group itself reports, gathered from every rank: backend, world size, and the device each rank
+    drives (index, name, PCI bus id / uuid when torch exposes them) -- config.rccl of the JSON line."""
+    mine = {"rank": dist.get_rank(), "local_rank": local_rank, "pid": os.getpid(), "device_index": dev_index}
+    if torch.cuda.is_available() and dev_index is not None:
+        pr = torch.cuda.get_device_properties(dev_index)
+        mine["device_name"] = pr.name
+        for k in ("uuid", "pci_bus_id", "pci_device_id", "gcnArchName"):
+            v = getattr(pr, k, None)
+            if v is not None:
+                mine[k] = str(v)
+    every = [None] * dist.get_world_size()
+    dist.all_gather_object(every, mine)
+    out = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": every,
+           "self_launched": os.environ.get("SPLAT_ONE_AMD_SELF_LAUNCHED") == "1"}
+    if dist.get_backend() == "nccl":
+        try:
+            out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:   # noqa: BLE001
+            pass
+        out["distinct_devices"] = len({r.get("uuid") or r.get("pci_bus_id") or r["device_index"] for r in every})
+    return out
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -118,7 +190,14 @@ def main():
                          "Gaussians, reduce-scatter / sharded Adam / all-gather of the gradient SoA, BASELINE.json's "
                          "north_star; gaussian_sharded -- the reference's own scheme (projected Gaussians exchanged by "
                          "all-to-all).  The other scheme is timed too and reported in config.other_scheme")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="start the ranks, build the process group, print what it reports (config.rccl) and exit: no kernel "
+                         "runs (the CPU test of the self-launcher; works without a GPU over gloo)")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="--launch-check: this rank exits with code 3 (failure propagation)")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # no launcher: start the N ranks ourselves, before anything in this process touches the GPU
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     if args.densify:      # warm up past the first two refinements: both model sets' graphs are captured before timing
         args.warmup = max(args.warmup, 2 * args.densify + 1)
 
@@ -126,11 +205,31 @@ def main():
     from splat_one_amd.scene import pinhole_K, ring_cameras, front_camera
     from splat_one_amd.trainer import Config, Runner
 
+    n_dev = torch.cuda.device_count()           # (does not initialise HIP)
+    if args.gpus > 1 and n_dev < args.gpus and not os.environ.get("SPLAT_ONE_AMD_BACKEND"):
+        # fewer devices than ranks: RCCL refuses two ranks on one device.  A REHEARSAL of the N-rank flow over gloo, ranks
+        # sharing devices -- flagged in config.rccl.backend; its numbers say nothing about xGMI
+        os.environ["SPLAT_ONE_AMD_BACKEND"] = "gloo"
+        if os.environ.get("RANK", "0") == "0":
+            print(f"[bench] --gpus {args.gpus} on a box with {n_dev} device(s): falling back to the gloo backend "
+                  f"(functional rehearsal, ranks share devices)", file=sys.stderr)
     local_rank, rank, world = sdist.init_from_env()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert world == args.gpus, (f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                                f"--nproc-per-node {args.gpus}, or with no launcher at all")
+    if args.launch_check:
+        if rank == args.fail_rank:
+            sys.exit(3)
+        rep = rank_report(dist, local_rank, local_rank if n_dev else None) if world > 1 else None
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "config": {"rccl": rep}}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path exists for the product)"
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
+    rccl = rank_report(dist, local_rank, local_rank) if world > 1 else None
 
     W, H, N = args.width, args.height, args.n
     init_scale, init_opa = (1.0, 0.1) if args.regime == "ref" else (0.1, 0.5)
@@ -200,6 +299,11 @@ def main():
 
     dp_probe = None
     other_mode = None
+    sdist.COMM_TIMING = world > 1       # phase events around the reduce-scatter / Adam / all-gather of every step (config.comm_ms)
+
+    def comm_objects(r):
+        return [o for o in (getattr(r, "_radam", None), getattr(r, "_sadam", None)) if o is not None and o.timer is not None]
+
     if world == 1:
         cfg, runner, views = make_runner("allreduce")
     else:
@@ -279,12 +383,18 @@ def main():
     # timed region: EXACTLY --steps iterations between barriers
     n_before_timed = runner._engine.sync_host() if (fused and not runner.sharded and getattr(runner._engine, "device_refine", False)) else None
     void0 = getattr(getattr(runner, "_engine", None), "void_steps", 0)
+    for o in comm_objects(runner):
+        o.timer.clear()
     barrier()
     t0 = time.time()
     for _ in range(args.steps):
         step_once()
     barrier()
     elapsed = time.time() - t0
+    comm_ms = None
+    for o in comm_objects(runner):          # mean per step over exactly the timed iterations (this rank's stream)
+        comm_ms = o.comm_ms()
+        o.timer = None
     void_steps = getattr(getattr(runner, "_engine", None), "void_steps", 0) - void0
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -407,8 +517,12 @@ def main():
     out = {
         "metric": ("training iters/sec (100k Gaussians, 1080p, fwd+loss+bwd+Adam)" if (N0, W, H) == (100_000, 1920, 1080)
                    else f"training iters/sec ({N0} Gaussians, {W}x{H}, fwd+loss+bwd+Adam)"),
+        # N = 1: training iterations per second.  N > 1 (weak scaling, one view per GPU and step): every optimiser step
+        # consumes `world` views, so the whole-job aggregate is VIEWS per second (= single-GPU iterations' worth of work per
+        # second, the number to divide by the N = 1 value); optimiser steps per second are reported next to it
         "value": world * args.steps / elapsed,
-        "unit": "it/s",
+        "unit": "it/s" if world == 1 else "views/s",
+        "optimizer_steps_per_s": args.steps / elapsed,
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -434,7 +548,8 @@ def main():
                                                                 if getattr(runner._engine, "device_refine", False) else
                                                                 f", replicated Gaussians: reduce-scatter / 1/{world} Adam / all-gather of the "
                                                                 f"gradient SoA in {getattr(runner, '_dp_chunks', cfg.dp_chunks)} chunk(s) over RCCL")),
-                   "dp_mode_probe_ms_per_step": dp_probe},
+                   "dp_mode_probe_ms_per_step": dp_probe,
+                   "rccl": rccl, "comm_ms": comm_ms},
         "forward_mpix_per_s": None if runner.sharded else world * P / fwd_s / 1e6,
         "hbm_iter_fraction": b_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9),
         "algorithmic_bytes_per_iter": b_iter,

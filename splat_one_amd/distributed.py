@@ -140,6 +140,81 @@ def all_reduce_mean_(flat: torch.Tensor, group=None) -> None:
     flat.mul_(1.0 / dist.get_world_size(group))
 
 
+# Set by bench.py before the runner is built: the sharded optimisers then bracket their phases with events on the compute
+# stream (four records per step) and `comm_ms()` reports the means -- so that the first real multi-GPU run explains itself.
+COMM_TIMING = False
+
+
+class _PhaseTimer:
+    """Events on the CURRENT stream around the phases of one reduce-scatter / Adam / all-gather step.  A `work.wait()` makes
+    the current stream wait for the collective, so the span between two records is the time the compute stream spent in
+    (or blocked on) that phase.  Host tensors (CPU tests) are timed with the wall clock."""
+    PHASES = ("reduce_scatter_wait_ms", "adam_and_issue_ms", "all_gather_wait_ms")
+
+    def __init__(self, keep: int = 512):
+        self.keep, self.marks = keep, []
+
+    def start(self, cuda: bool):
+        self.cur = [self._mark(cuda)]
+
+    def mark(self, cuda: bool):
+        self.cur.append(self._mark(cuda))
+
+    def stop(self):
+        self.marks.append(self.cur)
+        del self.marks[:-self.keep]
+
+    @staticmethod
+    def _mark(cuda: bool):
+        if cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+        import time
+        return time.perf_counter()
+
+    def summary(self) -> Optional[dict]:
+        """Mean milliseconds per step of every phase over the recorded steps (synchronises); None if nothing was timed."""
+        if not self.marks:
+            return None
+        if not isinstance(self.marks[0][0], float):
+            torch.cuda.synchronize()
+        span = lambda a, b: (b - a) * 1e3 if isinstance(a, float) else a.elapsed_time(b)
+        n = len(self.marks)
+        out = {k: sum(span(m[i], m[i + 1]) for m in self.marks) / n for i, k in enumerate(self.PHASES)}
+        out["total_ms"] = sum(span(m[0], m[-1]) for m in self.marks) / n
+        out["steps_timed"] = n
+        return out
+
+    def clear(self):
+        self.marks = []
+
+
+def agree_on_coalescing(probe: Callable[[], None], device, group=None) -> str:
+    """"coalesced" if `probe()` -- one grouped reduce-scatter + all-gather through torch's PRIVATE
+    `dist._coalescing_manager` on scratch tensors -- works on EVERY rank, else "per_tensor" (one async
+    reduce_scatter_tensor / all_gather_into_tensor per tensor, public API).  The decision is collective: every rank
+    contributes 1 / 0 to one all_reduce(MIN), so all ranks take the same branch whatever failed where.
+    SPLAT_ONE_AMD_FORCE_COALESCE_FAIL = "all" | a rank number makes the probe fail there (tests)."""
+    ok, why = 1, ""
+    forced = os.environ.get("SPLAT_ONE_AMD_FORCE_COALESCE_FAIL", "")
+    try:
+        if forced == "all" or (forced.isdigit() and int(forced) == dist.get_rank(group)):
+            raise RuntimeError("forced failure of the coalesced collectives (SPLAT_ONE_AMD_FORCE_COALESCE_FAIL)")
+        probe()
+    except Exception as e:       # noqa: BLE001 -- a private API: anything may have changed
+        ok, why = 0, repr(e)
+    flag = torch.tensor([ok], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    mode = "coalesced" if int(flag.item()) else "per_tensor"
+    if mode == "per_tensor":
+        import warnings
+        warnings.warn("splat_one_amd: grouped collectives (dist._coalescing_manager) are not usable "
+                      + (f"on this rank ({why})" if why else "on another rank")
+                      + "; every rank falls back to one reduce_scatter_tensor / all_gather_into_tensor per tensor", RuntimeWarning)
+    return mode
+
+
 class RowShardedAdam:
     """The same reduce-scatter / sharded Adam / all-gather step for a DEVICE-RESIDENT model (FusedEngine(device_refine=
     True)): parameters, moments and gradients are separate tensors of `capacity` rows of which the first N are live, so no
@@ -167,6 +242,37 @@ class RowShardedAdam:
         self.group = group
         self.rank, self.world = (dist.get_rank(group), dist.get_world_size(group)) if is_initialized() else (0, 1)
         self.backend = dist.get_backend(group) if is_initialized() else "none"
+        # "coalesced": each group of tensors is ONE RCCL launch (torch's private coalescing manager); "per_tensor": one
+        # async collective per tensor (public API).  Agreed on by all ranks at the first step (agree_on_coalescing).
+        self.mode: Optional[str] = None
+        self.timer = _PhaseTimer() if COMM_TIMING else None
+
+    def _ensure_mode(self, device) -> str:
+        if self.mode is None:
+            if self.world == 1:
+                self.mode = "coalesced"
+            else:
+                def probe():
+                    if self.backend != "nccl":
+                        return                      # gloo never groups: nothing that could fail
+                    t = [torch.ones(self.world * self.ALIGN_ROWS, 4, device=device), torch.ones(self.world * self.ALIGN_ROWS, device=device)]
+                    saved, self.mode = self.mode, "coalesced"
+                    try:
+                        for w in self._reduce_scatter(t, self.ALIGN_ROWS * self.world):
+                            w.wait()
+                        for w in self._all_gather(t, self.ALIGN_ROWS * self.world):
+                            w.wait()
+                        torch.cuda.synchronize()
+                    finally:
+                        self.mode = saved
+                self.mode = agree_on_coalescing(probe, device if self.backend == "nccl" else "cpu", self.group)
+        return self.mode
+
+    def comm_ms(self) -> Optional[dict]:
+        out = self.timer.summary() if self.timer is not None else None
+        if out is not None:
+            out["collectives"] = self.mode
+        return out
 
     ALIGN_ROWS = 16   # piece boundaries: 16 rows = 64 bytes of the narrowest tensor (float4 kernels need 16-byte starts)
 
@@ -186,6 +292,9 @@ class RowShardedAdam:
         p, (a, b) = self.piece(n), self.rows(n)
         span = p * self.world
         assert all(t.shape[0] >= span and t.is_contiguous() for t in tensors), (n, span, [tuple(t.shape) for t in tensors])
+        if self.backend == "nccl" and self.mode == "per_tensor":
+            return [dist.reduce_scatter_tensor(t[a:b], t[:span], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    for t in tensors]
         if self.backend == "nccl":
             with dist._coalescing_manager(group=self.group, async_ops=True) as cm:
                 for t in tensors:
@@ -204,6 +313,8 @@ class RowShardedAdam:
         p, (a, b) = self.piece(n), self.rows(n)
         span = p * self.world
         assert all(t.shape[0] >= span and t.is_contiguous() for t in tensors), (n, span, [tuple(t.shape) for t in tensors])
+        if self.backend == "nccl" and self.mode == "per_tensor":
+            return [dist.all_gather_into_tensor(t[:span], t[a:b], group=self.group, async_op=True) for t in tensors]
         if self.backend == "nccl":
             with dist._coalescing_manager(group=self.group, async_ops=True) as cm:
                 for t in tensors:
@@ -230,23 +341,36 @@ class RowShardedAdam:
         a, b = self.rows(n)
         b = min(b, n)
         groups = [tuple(k for k in g if k in grads) for g in self.GROUPS]
+        first = grads[groups[0][0]]
+        self._ensure_mode(first.device)
+        tm, cuda = self.timer, first.is_cuda
+        if tm is not None:
+            tm.start(cuda)
         rs = [self._reduce_scatter([grads[k] for k in g], n) for g in groups]
         ag = []
         inv = 1.0 / self.world
-        for g, works in zip(groups, rs):
+        for i, (g, works) in enumerate(zip(groups, rs)):
             for w in works:
                 w.wait()
+            if tm is not None and i == 0:
+                tm.mark(cuda)                                             # the first reduction has landed
             if b > a:
                 torch._foreach_mul_([grads[k][a:b] for k in g], inv)      # mean over the views of all ranks
                 adam_fn(g, a, b)
             ag += self._all_gather([params[k] for k in g], n)
+        if tm is not None:
+            tm.mark(cuda)                                                 # every Adam launched, every all-gather issued
         for w in ag:
             w.wait()
+        if tm is not None:
+            tm.mark(cuda)
+            tm.stop()
 
     @torch.no_grad()
     def gather(self, tensors: List[torch.Tensor], n: int) -> None:
         if self.world == 1 or not tensors:
             return
+        self._ensure_mode(tensors[0].device)
         for w in self._all_gather(list(tensors), n):
             w.wait()
 
@@ -287,6 +411,13 @@ class ShardedFlatAdam:
         self.total = int(total)
         self.padded_total = self.chunk * self.n_chunks
         self.backend = dist.get_backend(group) if is_initialized() else "none"
+        self.timer = _PhaseTimer() if COMM_TIMING else None
+
+    def comm_ms(self) -> Optional[dict]:
+        out = self.timer.summary() if self.timer is not None else None
+        if out is not None:
+            out["collectives"] = "per_tensor"       # public API only: one collective per chunk
+        return out
 
     def piece_range(self, c: int, r: Optional[int] = None):
         r = self.rank if r is None else r
@@ -334,18 +465,28 @@ class ShardedFlatAdam:
         if self.world == 1:
             adam_fn(0, self.padded_total)
             return
+        tm, cuda = self.timer, grad_flat.is_cuda
+        if tm is not None:
+            tm.start(cuda)
         rs = [self._reduce_scatter(grad_flat, c) for c in range(self.n_chunks)]
         ag = []
         inv = 1.0 / self.world
         for c in range(self.n_chunks):
             for w in rs[c]:
                 w.wait()
+            if tm is not None and c == 0:
+                tm.mark(cuda)                        # the first chunk's reduction has landed
             a, b = self.piece_range(c)
             grad_flat[a:b].mul_(inv)                 # mean over the views of all ranks
             adam_fn(a, b)
             ag.append(self._all_gather(param_flat, c))
+        if tm is not None:
+            tm.mark(cuda)
         for w in ag:
             w.wait()
+        if tm is not None:
+            tm.mark(cuda)
+            tm.stop()
 
     @torch.no_grad()
     def gather_moments(self, *flats: torch.Tensor) -> None:

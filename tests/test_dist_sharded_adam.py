@@ -212,3 +212,53 @@ def test_row_sharded_adam_equals_adam_on_the_mean_gradient(tmp_path, world, cap,
     N = Ns[-1]
     p = -(-N // (16 * world)) * 16
     assert abs(outs[0]["bytes"] - 2 * (world - 1) / world * p * world * 59 * 4) < 1
+
+
+# ------------------------------------------------------------------------------------------------ fallback agreement
+def _fallback_worker(local_rank, world_rank, world_size, args):
+    """The grouped collectives of RowShardedAdam go through a PRIVATE torch API: if it is unusable on ANY rank (forced here
+    on one rank only), every rank must leave it together -- one all_reduce(MIN) decides -- and the step must give the same
+    numbers through the per-tensor collectives.  Phase timers on (bench.py's config.comm_ms)."""
+    out_dir, cap, N, forced = args
+    import warnings
+    from splat_one_amd import distributed as sdist
+    if forced is not None:
+        os.environ["SPLAT_ONE_AMD_FORCE_COALESCE_FAIL"] = forced
+    sdist.COMM_TIMING = True
+    ra = sdist.RowShardedAdam()
+    assert ra.mode is None and ra.timer is not None
+    P = {k: torch.ones(cap, rl) for k, rl in ROWS.items()}
+    G = {k: torch.full((cap, rl), float(world_rank + 1)) for k, rl in ROWS.items()}
+    seen = []
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        for _ in range(2):
+            for k in G:
+                G[k].fill_(float(world_rank + 1))
+            ra.step(G, P, N, lambda names, a, b: [P[k][a:b].sub_(G[k][a:b]) for k in names] and seen.append((a, b)))
+    cm = ra.comm_ms()
+    assert cm["steps_timed"] == 2 and cm["collectives"] == ra.mode and cm["total_ms"] >= 0.0
+    assert set(sdist._PhaseTimer.PHASES) <= set(cm)
+    torch.save({"mode": ra.mode, "P": {k: P[k][:N] for k in ROWS}, "warned": sum("fall" in str(w.message) for w in wlist)},
+               os.path.join(out_dir, f"r{world_rank}.pt"))
+
+
+@pytest.mark.parametrize("forced,want", [(None, "coalesced"), ("1", "per_tensor"), ("all", "per_tensor")])
+def test_collective_fallback_is_agreed_on_by_all_ranks(tmp_path, forced, want):
+    from splat_one_amd import distributed as sdist
+    world, cap, N = 2, 64, 37
+    keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SPLAT_ONE_AMD_FORCE_COALESCE_FAIL")
+    env_backup = {k: os.environ.pop(k, None) for k in keys}
+    try:
+        sdist.cli(_fallback_worker, (str(tmp_path), cap, N, forced), world_size=world, backend="gloo", port=_free_port())
+    finally:
+        for k, v in env_backup.items():
+            if v is not None:
+                os.environ[k] = v
+    outs = [torch.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(world)]
+    assert [o["mode"] for o in outs] == [want] * world          # the rank that did NOT fail follows the one that did
+    assert all(o["warned"] == (1 if want == "per_tensor" else 0) for o in outs)
+    mean_g = sum(r + 1 for r in range(world)) / world
+    for o in outs:
+        for k in ROWS:
+            assert torch.equal(o["P"][k], torch.full_like(o["P"][k], 1.0 - 2 * mean_g)), k
