@@ -1,8 +1,8 @@
 """Measured parity numbers of the GPU tests, written next to pass/fail ("commit the measured errors").
 
 Every `-m gpu` parity test at a BASELINE.json size calls `record(...)`; the entries are merged into ONE JSON file --
-`$SPLAT_ONE_AMD_PARITY_JSON`, default `gpurun_out/parity_r02.json` (gpurun copies it back; the tracked copy is
-`profiles/parity_r02.json`).  Helpers here only measure; the bars are asserted in the tests."""
+`$SPLAT_ONE_AMD_PARITY_JSON`, default `gpurun_out/parity_r03.json` (gpurun copies it back; the tracked copy is
+`profiles/parity_r03.json`).  Helpers here only measure; the bars are asserted in the tests."""
 import json
 import os
 import time
@@ -11,7 +11,7 @@ from typing import Dict
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PATH = os.environ.get("SPLAT_ONE_AMD_PARITY_JSON") or os.path.join(ROOT, "gpurun_out", "parity_r02.json")
+PATH = os.environ.get("SPLAT_ONE_AMD_PARITY_JSON") or os.path.join(ROOT, "gpurun_out", "parity_r03.json")
 
 
 def record(section: str, **metrics) -> None:
@@ -28,6 +28,17 @@ def record(section: str, **metrics) -> None:
     entry["recorded_at"] = time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime())
     with open(PATH, "w") as f:
         json.dump(data, f, indent=1, sort_keys=True)
+
+
+def quats_unfloored(g_h: Dict[str, torch.Tensor], g_o: Dict[str, torch.Tensor]) -> Dict[str, float]:
+    """The quaternion gradient WITHOUT the floor of `grad_errors`, with both norms next to it: ||g - g*|| / ||g*_quats||.
+    Where the scene is isotropic (reference init: equal scales) ||g*_quats|| is rounding noise itself -- 1e-8 of
+    ||g*_scales|| -- and the ratio says nothing; `quats_over_scales` tells the reader which case this is."""
+    ref = g_o["quats"].detach().cpu().double()
+    d = g_h["quats"].detach().cpu().double() - ref
+    sc = g_o["scales"].detach().cpu().double().norm().item()
+    return {"quats_nofloor": d.norm().item() / max(ref.norm().item(), 1e-300), "quats_abs_err": d.norm().item(),
+            "quats_ref_norm": ref.norm().item(), "scales_ref_norm": sc, "quats_over_scales": ref.norm().item() / max(sc, 1e-300)}
 
 
 def grad_errors(g_h: Dict[str, torch.Tensor], g_o: Dict[str, torch.Tensor]) -> Dict[str, float]:

@@ -2,6 +2,7 @@
 sizes x render mode x antialiasing x background x packed x number of cameras x SH degree, small scenes (the oracle
 finishes each in well under a second).  What the fixed-size parity tests do not reach: combinations."""
 import math
+import os
 import random
 
 import pytest
@@ -85,11 +86,10 @@ def test_random_configuration_against_the_oracle(dev, seed):
     assert (ra_h - ra_o).abs().mean().item() <= 1e-4, cfg
     names = ["means", "quats", "scales", "opacities", "sh"]
     ref_scale = g_o[2].norm().item()
-    # the plain float64 oracle takes its own discrete decisions (alpha >= 1/255, T > 1e-4, depth-key ties): in scenes of a
-    # few hundred Gaussians ONE such pixel is worth ~1e-3 of a gradient norm, and the float32 Jacobians of the two
-    # non-linear camera models are the least accurate (tests/test_gpu_configs.py holds those to 1e-3 against the float32
-    # build of the oracle on the device's decisions); 200 further seeds were run once with these bars (tools/dbg_fuzz_report.py)
-    bar = 3e-3 if cfg["model"] in ("spherical", "fisheye") else 1e-3
+    # ONE bar for every camera model (north_star: gradients <= 1e-3 relative).  Rounds 1-2 allowed fisheye / spherical
+    # cases 3e-3; 120 seeds of this test and 120 of the engine test below were run at a uniform 1e-3 on the round-3 library
+    # (tools/gpu_fuzz_bar.sh -> all pass), so the exception is gone.
+    bar = float(os.environ.get("SPLAT_ONE_AMD_FUZZ_BAR", 1e-3))
     for k, a, b in zip(names, g_h, g_o):
         floor = 1e-5 * ref_scale if k == "quats" else 1e-9
         assert (a - b).norm().item() <= bar * b.norm().item() + floor, (cfg, k, (a - b).norm().item(), b.norm().item())
@@ -178,8 +178,7 @@ def test_random_engine_configuration_against_the_oracle(dev, seed):
     assert fwd.mean().item() <= 1e-4, (cfg, "forward L1", fwd.mean().item(), "max", fwd.max().item(), "pixels > 1e-3", int((fwd > 1e-3).sum()))
     assert abs(loss_eng[1].item() - l1_o.item()) < 2e-5 and abs(loss_eng[2].item() - ss_o.item()) < 2e-5, \
         (cfg, "loss", loss_eng.tolist(), l1_o.item(), ss_o.item())
-    # (see the operator-level fuzz above; a camera inside the cloud: the bar of the plain float64 oracle, test_gpu_configs.py)
-    bar = 5e-3 if "spherical" in cfg["models"] else (3e-3 if "fisheye" in cfg["models"] else 1e-3)
+    bar = float(os.environ.get("SPLAT_ONE_AMD_FUZZ_BAR", 1e-3))     # every camera model: the north_star bar
     for k in g_eng:
         ref = p[k].grad
         if ref is None:
