@@ -171,6 +171,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--operator-path", action="store_true",
                     help="time the operator-level autograd path instead of the fused engine")
+    ap.add_argument("--no-operator-path", action="store_true",
+                    help="skip the extra timing of the operator-level autograd path (operator_path_it_s of the N=1 line)")
     ap.add_argument("--kernel-table", action="store_true", help="print per-kernel times to stderr")
     ap.add_argument("--densify", type=int, default=0, metavar="EVERY",
                     help="BASELINE.json configs[3]: DefaultStrategy duplicates / splits / prunes every EVERY iterations "
@@ -590,6 +592,29 @@ def main():
         if ok.item():
             other.update(value=world * args.steps / float(tt.item()), ms_per_step=float(tt.item()) / args.steps * 1e3)
         out["config"]["other_scheme"] = other
+    if world == 1 and fused and not args.densify and not args.no_operator_path:
+        # The same iteration through the reference's own call structure (gsplat_trainer.py:586-742): Runner.rasterize_splats
+        # -> rasterization() [one library call each way] -> photometric_loss -> loss.backward() -> step_all -> strategy
+        # hooks, under torch autograd, no hipGraph -- what a trainer written against gsplat's API gets after the import swap.
+        del runner
+        torch.cuda.empty_cache()
+        args.operator_path = True
+        _cfg_o, r_o, v_o = make_runner("allreduce")
+        st_o = Stepper(r_o, v_o)
+        n_o = min(args.steps, 200)
+        for _ in range(3 * len(v_o)):          # SH ramp, bin probe of every view, allocator warm-up
+            st_o()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(n_o):
+            st_o()
+        torch.cuda.synchronize()
+        dt_o = (time.time() - t0) / n_o
+        out["operator_path_it_s"] = 1.0 / dt_o
+        out["operator_path"] = {"ms_per_step": dt_o * 1e3, "steps": n_o,
+                                "what": "Runner.rasterize_splats -> rasterization() (so_rasterization_fwd/_bwd) -> photometric_loss "
+                                        "-> backward -> step_all -> DefaultStrategy hooks, torch autograd, no hipGraph"}
+        args.operator_path = False
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N0, W, H, args.regime)
     if rank == 0:

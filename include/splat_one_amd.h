@@ -505,6 +505,57 @@ int so_step_inputs(int C, const float *camtoworlds, const float *Ks_src, float *
  * viewer render of gsplat_trainer.py:779-940; pixels, loss and gradient buffers are not touched */
 int so_render_forward(const so_step_desc *desc, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * `gsplat.rendering.rasterization` WHOLE, one call each way.   The reference renders through ONE Python call,
+ *   render_colors, render_alphas, info = rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, height,
+ *       packed=False, absgrad=..., sparse_grad=False, rasterize_mode=..., distributed=False, camera_model=...,
+ *       sh_degree=..., near_plane=..., far_plane=..., render_mode="RGB")              (gsplat_trainer.py:477-494)
+ * and differentiates it with loss.backward() (:655).  For the common shape of that call -- dense layout, SH coefficients
+ * [N,K,3] shared by the cameras, poses without gradient, three colour channels -- so_rasterization_fwd runs projection +
+ * SH colour (+0.5, clamp) + tile binning + per-tile depth sort + rasterisation, and so_rasterization_bwd the backward of
+ * all of them, on the tensors the call is handed:
+ *   activated = 1 (the gsplat call): scales[N,3] = exp(log-scales), opacities[N] = sigmoid(logits), sh0 = colors[N,K,3]
+ *     (ONE coefficient tensor, cat(sh0, shN) at :474; shN unused); gradients come back for exactly these tensors, the
+ *     coefficient gradient in two pieces v_sh0[N,3] | v_shN[N,3(K-1)] (band 0 | bands 1..K-1);
+ *   activated = 0: the raw parameters (log-scales, opacity logits, sh0[N,1,3], shN[N,K-1,3]) -- exp / sigmoid and their
+ *     backward run inside, as in so_preprocess_fwd / _bwd.
+ * Per-call buffers (the caller allocates; the backward needs counters, flatten_ids, rec, vrec, render_alphas, last_ids
+ * of its forward untouched): counters int32[2*C*tiles + 3] (zeroed HERE), flatten_ids int32[C*tiles*bin_capacity],
+ * rec / vrec float[C*N][16] (64-byte aligned; vrec NULL = forward only, nothing saved for a backward).
+ * Scratch that only lives inside the forward: key_buf u64[C*tiles*bin_capacity].
+ * Lists are BINNED (see so_isect_sort_bins): a tile that receives more than bin_capacity Gaussians raises overflow and is
+ * rasterised with its first bin_capacity entries.  status_out (nullable, HOST-MAPPED int32[4]) receives
+ * {fullest tile's count, overflow, seq, intersections} when the forward's last kernel has run: the caller enlarges its
+ * bins from it one call late, without synchronising (and rejects / repeats a call whose overflow flag was set).
+ * Outputs: render_colors[C,H,W,3], render_alphas[C,H,W,1], last_ids[C,H,W]; `info` = strided views of rec:
+ *   {x, y, conic a b c, opacity, r, g, b, depth, radius bits, 0 ...}.
+ * Backward: v_render_colors[C,H,W,3], v_render_alphas[C,H,W,1] (both required) -> v_means[N,3], v_quats[N,4], v_scales[N,3],
+ * v_opacities[N], v_sh0, v_shN (overwritten: one lane owns one Gaussian, sums over the cameras, no atomics) and, when
+ * v_means2d[C,N,2] is given, the screen-space gradient the densification strategy accumulates (`info["means2d"].grad`,
+ * :616-622, :744-752; v_means2d_abs[C,N,2] with absgrad != 0).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct so_raster_desc {
+  int32_t abi_size, C, N, K, width, height, tile_size, sh_degree, camera_model, antialiased, absgrad, tile_cull, activated, seq;
+  float eps2d, near_plane, far_plane, radius_clip;
+  int64_t bin_capacity;
+  /* inputs */
+  const float *means, *quats, *scales, *opacities, *sh0, *shN, *viewmats, *Ks, *backgrounds /* nullable [C,3] */;
+  /* per-call buffers and scratch */
+  int32_t *counters;
+  uint64_t *key_buf;
+  int32_t *flatten_ids;
+  float *rec, *vrec;
+  int32_t *status_out; /* nullable, host-mapped */
+  /* forward outputs (inputs of the backward) */
+  float *render_colors, *render_alphas;
+  int32_t *last_ids;
+  /* backward */
+  const float *v_render_colors, *v_render_alphas;
+  float *v_means, *v_quats, *v_scales, *v_opacities, *v_sh0, *v_shN, *v_means2d /* nullable */, *v_means2d_abs /* nullable */;
+} so_raster_desc;
+int so_rasterization_fwd(const so_raster_desc *desc, void *stream);
+int so_rasterization_bwd(const so_raster_desc *desc, void *stream);
+
 /* Per-stage HIP-event timing of so_train_step_fwd_bwd / so_adam_step_dev on their launch stream
  * (measurement only; the switch and the event log belong to the CALLING THREAD, so another thread's launches are
  * neither timed nor affected; events cannot be recorded inside a hipGraph replay, so profile un-captured launches).
@@ -541,9 +592,11 @@ int so_adam_step_dev_n(int n_groups, const so_adam_group *host_groups, const flo
  *   n_src_dev / n_dst_dev: device int32 (distinct): live rows of src (read), of dst (written);
  *   grad2d / count [capacity]: the densification statistics, zeroed on exit;
  *   scratch: int32[so_refine_scratch_words(capacity)];
- *   report_dev int32[8] (zero-initialised once by the caller): {duplicated, split, pruned, new N, overflow, old N,
- *     refinements so far, 0}.  overflow = the grown set did not fit `capacity`: the rows past it were dropped (the tail
- *     of the output order) -- the caller enlarges its buffers when it next looks.
+ *   report_dev int32[8] (zero-initialised once by the caller; device or HOST-MAPPED memory -- a caller that maps it reads
+ *     it without synchronising, element 6 telling which refinement it describes): {duplicated, split, pruned, new N,
+ *     overflow, old N, refinements so far, rows the refined set needs}.  overflow = the refined set does not fit
+ *     `capacity`: NOTHING is refined then -- dst receives the source rows unchanged (new N = old N), grad2d / count keep
+ *     their sums -- and the caller enlarges its buffers (element 7 says by how much) and calls again.
  * so_reset_opacity: gsplat `reset_opa` -- logits clamped to max_logit, their moments zeroed; n_dev nullable.
  * No entry point here synchronises or reads back; all are hipGraph-capturable.
  * ---------------------------------------------------------------------------------------- */
@@ -572,9 +625,11 @@ int so_reset_opacity(int64_t capacity, const int32_t *n_dev, float *logit_opacit
  *   grad2d[n] += |(v_means2d[c,n].x * sx, v_means2d[c,n].y * sy)|,  count[n] += 1,
  *   radii_state[n] = max(radii_state[n], radii[c,n] * inv_max_wh)   (radii_state nullable)
  * with sx = width / 2 * n_cameras, sy = height / 2 * n_cameras, inv_max_wh = 1 / max(width, height).  (The fused engine
- * accumulates the same inside so_preprocess_bwd.) */
-int so_strategy_update_state(int C, int64_t N, const float *v_means2d, const int32_t *radii, float sx, float sy,
-                             float inv_max_wh, float *grad2d, float *count, float *radii_state, void *stream);
+ * accumulates the same inside so_preprocess_bwd.)
+ * radii_stride: int32 words between consecutive radii (0 or 1: a dense [C,N] array; 16: the radius slot of the 64-byte
+ * records, `info["radii"]` of so_rasterization_fwd). */
+int so_strategy_update_state(int C, int64_t N, const float *v_means2d, const int32_t *radii, int64_t radii_stride, float sx,
+                             float sy, float inv_max_wh, float *grad2d, float *count, float *radii_state, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * MCMC densification strategy (the reference's `mcmc` preset, gsplat_trainer.py:975-983, :753-761).

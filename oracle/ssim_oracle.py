@@ -19,12 +19,17 @@ def ssim_map(img1, img2, dtype=torch.float64):
     """NCHW -> SSIM map [B,C,H,W] with zero 'same' padding."""
     img1, img2 = img1.to(dtype), img2.to(dtype)
     C1, C2 = 0.01 ** 2, 0.03 ** 2
-    CH = img1.shape[1]
     g = gaussian_window(dtype=dtype)
-    k2 = (g[:, None] * g[None, :]).expand(CH, 1, 11, 11)
 
     def blur(x):
-        return F.conv2d(x, k2, padding=5, groups=CH)
+        # the 11x11 window is the outer product g (x) g: rows then columns, each as a sum of shifted slices over the zero
+        # 'same' padding.  Same sum as F.conv2d(x, g[:, None] * g[None, :], padding=5) regrouped (differs by 1e-15 in
+        # float64) -- torch's float64 grouped conv2d on the CPU took 10 s forward + backward per blur at 1080p, this 0.6 s
+        H, W = x.shape[-2:]
+        xp = F.pad(x, (0, 0, 5, 5))
+        y = sum(g[k] * xp[..., k:k + H, :] for k in range(11))
+        yp = F.pad(y, (5, 5, 0, 0))
+        return sum(g[k] * yp[..., k:k + W] for k in range(11))
 
     mu1, mu2 = blur(img1), blur(img2)
     s11 = blur(img1 * img1) - mu1 * mu1

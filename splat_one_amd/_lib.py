@@ -48,6 +48,20 @@ class StepDesc(ctypes.Structure):
            ("n_dev", c_ptr)])
 
 
+class RasterDesc(ctypes.Structure):
+    """Mirror of `so_raster_desc` (so_rasterization_fwd / _bwd: gsplat's `rasterization` whole, one call each way)."""
+    _fields_ = ([(n, ctypes.c_int32) for n in ("abi_size", "C", "N", "K", "width", "height", "tile_size", "sh_degree",
+                                               "camera_model", "antialiased", "absgrad", "tile_cull", "activated", "seq")]
+                + [(n, c_f32) for n in ("eps2d", "near_plane", "far_plane", "radius_clip")]
+                + [("bin_capacity", c_i64)]
+                + [(n, c_ptr) for n in ("means", "quats", "scales", "opacities", "sh0", "shN", "viewmats", "Ks", "backgrounds",
+                                        "counters", "key_buf", "flatten_ids", "rec", "vrec", "status_out",
+                                        "render_colors", "render_alphas", "last_ids",
+                                        "v_render_colors", "v_render_alphas",
+                                        "v_means", "v_quats", "v_scales", "v_opacities", "v_sh0", "v_shN", "v_means2d",
+                                        "v_means2d_abs")])
+
+
 class AdamFuse(ctypes.Structure):
     """Mirror of `so_adam_fuse` (the optimiser fused into the backward kernel)."""
     _fields_ = [("groups", AdamGroup * 6), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double),
@@ -100,13 +114,15 @@ _SIGS = {
     "so_preprocess_bwd": [c_int] * 4 + [c_ptr] * 8 + [c_int, c_int, c_f32, c_int, c_int] + [c_ptr] * 9 + [c_f32, c_f32] + [c_ptr] * 9 + [c_int, c_i64, c_ptr, c_ptr, c_ptr],
     "so_sh_view_colors_fwd": [c_int] * 4 + [c_ptr] * 6,
     "so_sh_view_colors_bwd": [c_int] * 4 + [c_ptr] * 9,
-    "so_strategy_update_state": [c_int, c_i64, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr],
+    "so_strategy_update_state": [c_int, c_i64, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr],
     "so_rec_pack": [c_i64] + [c_ptr] * 7,
     "so_rec_unpack_grads": [c_i64] + [c_ptr] * 7,
     "so_rasterize_fwd_packed": [c_int] * 5 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 4,
     "so_rasterize_bwd_packed": [c_int] * 5 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 5 + [c_int, c_ptr],
     "so_train_step_fwd_bwd": [ctypes.POINTER(StepDesc), c_ptr],
     "so_render_forward": [ctypes.POINTER(StepDesc), c_ptr],
+    "so_rasterization_fwd": [ctypes.POINTER(RasterDesc), c_ptr],
+    "so_rasterization_bwd": [ctypes.POINTER(RasterDesc), c_ptr],
     "so_profile_enable": [c_int],
     "so_profile_read": [ctypes.POINTER(c_f32), ctypes.POINTER(c_int)],
     "so_adam_step_dev": [c_int, ctypes.POINTER(AdamGroup), ctypes.POINTER(c_f32), ctypes.POINTER(c_f32),

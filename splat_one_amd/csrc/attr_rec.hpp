@@ -27,6 +27,7 @@ __device__ __forceinline__ uint32_t pack_h2(float lo, float hi) { return (uint32
 struct AttrSoA {
   const float *log_scales, *quats, *sh0, *shN;
   int K;
+  static constexpr bool kActivated = false;   // log-scales / opacity logits: the kernels apply exp / sigmoid
   template <int DEG> struct Coefs {
     const float *c0, *cN;
     __device__ __forceinline__ void get(int k, float c[3]) const {
@@ -47,9 +48,31 @@ struct AttrSoA {
   }
 };
 
+// AttrAct : what `gsplat.rendering.rasterization` is HANDED at gsplat_trainer.py:477-494 -- post-activation tensors:
+//           scales = exp(log_scales) [N,3], opacities = sigmoid(logits) [N] (passed in the kernels' opacity-logit
+//           argument), quats [N,4], and ONE coefficient tensor colors = cat(sh0, shN) [N,K,3].  The kernels then skip exp /
+//           sigmoid and return the gradients of the activated values; regularisers do not apply (the caller's autograd owns
+//           the activations).
+struct AttrAct {
+  const float *scales, *quats, *coeffs;
+  int K;
+  static constexpr bool kActivated = true;
+  template <int DEG> struct Coefs {
+    const float *c;
+    __device__ __forceinline__ void get(int k, float o[3]) const { o[0] = c[3 * k]; o[1] = c[3 * k + 1]; o[2] = c[3 * k + 2]; }
+  };
+  __device__ __forceinline__ void base(int64_t n, float q[4], float ls[3]) const {
+    const float4 qq = *reinterpret_cast<const float4 *>(quats + 4 * n);
+    q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
+    ls[0] = scales[3 * n]; ls[1] = scales[3 * n + 1]; ls[2] = scales[3 * n + 2];
+  }
+  template <int DEG> __device__ __forceinline__ Coefs<DEG> coefs(int64_t n) const { return Coefs<DEG>{coeffs + n * (int64_t)K * 3}; }
+};
+
 struct AttrRec {
   const uint4 *rec;
   int stride16;   // row stride in 16-byte units
+  static constexpr bool kActivated = false;
   template <int DEG> struct Coefs {
     static constexpr int NH = 3 * (DEG + 1) * (DEG + 1);   // halves used
     static constexpr int NQ = (2 * NH + 15) / 16;           // 16-byte loads

@@ -122,7 +122,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
     const float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
     float q[4], ls[3];
     attrs.base(n, q, ls);
-    const float s[3] = {expf(ls[0]), expf(ls[1]), expf(ls[2])};
+    const float s[3] = {A::kActivated ? ls[0] : expf(ls[0]), A::kActivated ? ls[1] : expf(ls[1]), A::kActivated ? ls[2] : expf(ls[2])};
     ProjOut<float> o;
     project_fwd<float, SPH>(mean, nullptr, q, s, cam.Rw, cam.tw, cam.fx, cam.fy, cam.cx, cam.cy, W, H, eps2d, near_plane,
                        far_plane, radius_clip, cam_model_of(model, c), o);
@@ -135,7 +135,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
       depths[idx] = o.depth;
       conics[3 * idx] = o.conic[0]; conics[3 * idx + 1] = o.conic[1]; conics[3 * idx + 2] = o.conic[2];
     }
-    float op = sigmoidf(logit_opac[n]);
+    float op = A::kActivated ? logit_opac[n] : sigmoidf(logit_opac[n]);
     if (antialiased) op *= o.comp;
     if (radii) opacities[idx] = op;
     float r = 0.f, g = 0.f, b = 0.f;
@@ -352,8 +352,8 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
     const float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
     float q[4], ls[3];
     attrs.base(n, q, ls);
-    const float s[3] = {expf(ls[0]), expf(ls[1]), expf(ls[2])};
-    const float sig = sigmoidf(logit_opac[n]);
+    const float s[3] = {A::kActivated ? ls[0] : expf(ls[0]), A::kActivated ? ls[1] : expf(ls[1]), A::kActivated ? ls[2] : expf(ls[2])};
+    const float sig = A::kActivated ? logit_opac[n] : sigmoidf(logit_opac[n]);
     const auto coef = attrs.template coefs<DEG>(n);
     float vm[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f};
     float v_sig = 0.f, g2 = 0.f, cn = 0.f;
@@ -432,9 +432,11 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
     }
     PPB_STAMP(1);
     // d/d log s = s * d/ds ; scale regulariser: scale_reg * mean|exp(s)| over 3N entries
+    // (AttrAct: the inputs ARE the activated values -- their gradients go out as they are)
     const float sreg = scale_reg / (3.f * (float)N);
-    const float gs[3] = {(vs[0] + sreg) * s[0], (vs[1] + sreg) * s[1], (vs[2] + sreg) * s[2]};
-    const float go = (v_sig + opacity_reg / (float)N) * sig * (1.f - sig);
+    const float gs[3] = {(vs[0] + sreg) * (A::kActivated ? 1.f : s[0]), (vs[1] + sreg) * (A::kActivated ? 1.f : s[1]),
+                         (vs[2] + sreg) * (A::kActivated ? 1.f : s[2])};
+    const float go = (v_sig + opacity_reg / (float)N) * (A::kActivated ? 1.f : sig * (1.f - sig));
     if (ADAM) {
       // Fused optimiser (so_step_desc.fuse_adam): the gradient of this Gaussian is in registers (and, for shN, in
       // its LDS row) -- apply Adam here instead of writing 236 B of gradient for the Adam kernel to read back.
@@ -568,9 +570,11 @@ k_rec_unpack_grads(int64_t n, const float4 *__restrict__ vrec, float2 *__restric
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float4 q0 = vrec[4 * i], q1 = vrec[4 * i + 1], q2 = vrec[4 * i + 2];
     v_means2d[i] = make_float2(q0.x, q0.y);
-    v_conics[3 * i] = q0.z; v_conics[3 * i + 1] = q0.w; v_conics[3 * i + 2] = q1.x;
-    v_colors[3 * i] = q1.y; v_colors[3 * i + 1] = q1.z; v_colors[3 * i + 2] = q1.w;
-    v_opacities[i] = q2.x;
+    if (v_conics) {     // (so_rasterization_bwd wants the screen-space gradient -- the densification statistic -- only)
+      v_conics[3 * i] = q0.z; v_conics[3 * i + 1] = q0.w; v_conics[3 * i + 2] = q1.x;
+      v_colors[3 * i] = q1.y; v_colors[3 * i + 1] = q1.z; v_colors[3 * i + 2] = q1.w;
+      v_opacities[i] = q2.x;
+    }
     if (v_means2d_abs) v_means2d_abs[i] = make_float2(q2.y, q2.z);
   }
 }
@@ -710,6 +714,7 @@ static int preprocess_bwd_impl(const char *what, int C, int N, int K, int sh_deg
   // v_shN rows go through LDS when a workgroup's 256 rows fit the default 64 KB (K <= 22) and the run is 16-byte aligned
   const size_t stage_bytes = (size_t)256 * 3 * (K - 1) * sizeof(float);
   const bool stage = K > 1 && stage_bytes <= 64 * 1024 && (((uintptr_t)v_shN) & 15) == 0;
+  SO_REQUIRE(!(fuse && A::kActivated), "%s: the fused optimiser needs the raw parameters", what);
   if (fuse) {   // the fused optimiser sweeps the staged rows: same conditions, on the parameter / moment tensors
     SO_REQUIRE(K > 1 && stage_bytes <= 64 * 1024, "%s: fused Adam needs 2 <= K <= 22", what);
     uintptr_t bits = 0;
@@ -722,25 +727,22 @@ static int preprocess_bwd_impl(const char *what, int C, int N, int K, int sh_deg
   const bool sph = camera_model_has_spherical(camera_model, C);
 #define SO_LAUNCH(D)                                                                                              \
   if (sph) { SO_LAUNCH_(D, true); } else { SO_LAUNCH_(D, false); }
+#define SO_BWD_ARGS(FUSE)                                                                                         \
+  C, N, K, means, logit_opacities, attrs, viewmats, Ks, width, height, eps2d, camera_model, antialiased, radii,   \
+      opacities, colors, v_means2d, v_means2d_abs, v_depths, v_conics, v_colors, v_opacities, opacity_reg,        \
+      scale_reg, v_means, v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN, grad2d, count, sx, sy,          \
+      reinterpret_cast<const float4 *>(vrec), absgrad_stats, cam_stride, skip_flag, skip_out, FUSE, n_dev,        \
+      reinterpret_cast<const float4 *>(rec)
+  // (the optimiser-fused variant exists for the raw float32 parameters only: activated inputs belong to a caller whose
+  // autograd still has to run the activations' backward)
 #define SO_LAUNCH_(D, S)                                                                                          \
-  if (fuse)                                                                                                       \
-    hipLaunchKernelGGL((k_preprocess_bwd<D, A, true, true, S>), grid, block, stage_bytes, st, C, N, K, means, logit_opacities, attrs, \
-                     viewmats, Ks, width, height, eps2d, camera_model, antialiased, radii, opacities, colors,     \
-                     v_means2d, v_means2d_abs, v_depths, v_conics, v_colors, v_opacities, opacity_reg, scale_reg, \
-                     v_means, v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN, grad2d, count, sx, sy,      \
-                     reinterpret_cast<const float4 *>(vrec), absgrad_stats, cam_stride, skip_flag, skip_out, *fuse, n_dev, reinterpret_cast<const float4 *>(rec)); \
-  else if (stage)                                                                                                 \
-    hipLaunchKernelGGL((k_preprocess_bwd<D, A, true, false, S>), grid, block, stage_bytes, st, C, N, K, means, logit_opacities, attrs, \
-                     viewmats, Ks, width, height, eps2d, camera_model, antialiased, radii, opacities, colors,     \
-                     v_means2d, v_means2d_abs, v_depths, v_conics, v_colors, v_opacities, opacity_reg, scale_reg, \
-                     v_means, v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN, grad2d, count, sx, sy,      \
-                     reinterpret_cast<const float4 *>(vrec), absgrad_stats, cam_stride, skip_flag, skip_out, AdamFuse{}, n_dev, reinterpret_cast<const float4 *>(rec)); \
+  if (fuse) {                                                                                                     \
+    if constexpr (!A::kActivated)                                                                                 \
+      hipLaunchKernelGGL((k_preprocess_bwd<D, A, true, true, S>), grid, block, stage_bytes, st, SO_BWD_ARGS(*fuse)); \
+  } else if (stage)                                                                                               \
+    hipLaunchKernelGGL((k_preprocess_bwd<D, A, true, false, S>), grid, block, stage_bytes, st, SO_BWD_ARGS(AdamFuse{})); \
   else                                                                                                            \
-  hipLaunchKernelGGL((k_preprocess_bwd<D, A, false, false, S>), grid, block, 0, st, C, N, K, means, logit_opacities, attrs, \
-                     viewmats, Ks, width, height, eps2d, camera_model, antialiased, radii, opacities, colors,     \
-                     v_means2d, v_means2d_abs, v_depths, v_conics, v_colors, v_opacities, opacity_reg, scale_reg, \
-                     v_means, v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN, grad2d, count, sx, sy,      \
-                     reinterpret_cast<const float4 *>(vrec), absgrad_stats, cam_stride, skip_flag, skip_out, AdamFuse{}, n_dev, reinterpret_cast<const float4 *>(rec))
+    hipLaunchKernelGGL((k_preprocess_bwd<D, A, false, false, S>), grid, block, 0, st, SO_BWD_ARGS(AdamFuse{}))
   switch (sh_degree) {
     case 0: SO_LAUNCH(0); break;
     case 1: SO_LAUNCH(1); break;
@@ -750,6 +752,7 @@ static int preprocess_bwd_impl(const char *what, int C, int N, int K, int sh_deg
   }
 #undef SO_LAUNCH
 #undef SO_LAUNCH_
+#undef SO_BWD_ARGS
   return check_launch(what);
 }
 
@@ -873,6 +876,43 @@ int preprocess_bwd_n(int C, int N, int K, int sh_degree, const float *means, con
                              eps2d, camera_model, antialiased, radii, opacities, colors, nullptr, nullptr, nullptr, nullptr, nullptr,
                              nullptr, opacity_reg, scale_reg, v_means, v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN,
                              grad2d, count, vrec, absgrad_stats, 0, skip_flag, skip_out, stream, nullptr, n_dev, rec);
+}
+// internal (raster_op.hip): the POST-ACTIVATION inputs of gsplat's rasterization() call (AttrAct): scales [N,3],
+// opacities [N] in (0,1), coeffs [N,K,3]; record-only views; the backward returns the gradients of exactly those
+// tensors (v_sh0 [N,3] and v_shN [N,3(K-1)] apart: the caller concatenates)
+int preprocess_fwd_act(int C, int N, int K, int sh_degree, const float *means, const float *scales, const float *quats,
+                       const float *opacities_in, const float *coeffs, const float *viewmats, const float *Ks, int width,
+                       int height, float eps2d, float near_plane, float far_plane, float radius_clip, int camera_model,
+                       int antialiased, int tile_size, int32_t *tile_counts, float *rec, float *vrec, int tile_cull,
+                       uint64_t *bin_keys, int64_t bin_cap, int32_t *bin_overflow, void *stream) {
+  SO_REQUIRE((int64_t)C * N == 0 || (scales && quats && coeffs), "so_rasterization_fwd: null pointer");
+  const AttrAct attrs{scales, quats, coeffs, K};
+  return preprocess_fwd_impl("so_rasterization_fwd", C, N, K, sh_degree, means, opacities_in, attrs, viewmats, Ks, width, height,
+                             eps2d, near_plane, far_plane, radius_clip, camera_model, antialiased, tile_size, nullptr, nullptr,
+                             nullptr, nullptr, nullptr, nullptr, nullptr, tile_counts, rec, vrec, 0, nullptr, tile_cull,
+                             bin_keys, bin_cap, bin_overflow, stream, nullptr);
+}
+int preprocess_bwd_act(int C, int N, int K, int sh_degree, const float *means, const float *scales, const float *quats,
+                       const float *opacities_in, const float *coeffs, const float *viewmats, const float *Ks, int width,
+                       int height, float eps2d, int camera_model, int antialiased, float *v_means, float *v_scales,
+                       float *v_quats, float *v_opacities, float *v_sh0, float *v_shN, const float *vrec, const float *rec,
+                       void *stream) {
+  SO_REQUIRE(N == 0 || (scales && quats && coeffs), "so_rasterization_bwd: null pointer");
+  const AttrAct attrs{scales, quats, coeffs, K};
+  return preprocess_bwd_impl("so_rasterization_bwd", C, N, K, sh_degree, means, opacities_in, attrs, viewmats, Ks, width, height,
+                             eps2d, camera_model, antialiased, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                             nullptr, nullptr, 0.f, 0.f, v_means, v_scales, v_quats, v_opacities, v_sh0, v_shN, nullptr, nullptr,
+                             vrec, 0, 0, nullptr, nullptr, stream, nullptr, nullptr, rec);
+}
+// internal (raster_op.hip): the screen-space gradients alone out of the gradient records -- contiguous [n,2] arrays for
+// `info["means2d"].grad` / `.absgrad` (v_means2d_abs nullable)
+int rec_unpack_means2d(int64_t n, const float *vrec, float *v_means2d, float *v_means2d_abs, void *stream) {
+  if (n == 0) return SO_OK;
+  SO_REQUIRE(vrec && v_means2d && (((uintptr_t)vrec) & 63) == 0, "so_rasterization_bwd: gradient records missing or misaligned");
+  hipLaunchKernelGGL(k_rec_unpack_grads, dim3(pp_grid(n)), dim3(256), 0, as_stream(stream), n, reinterpret_cast<const float4 *>(vrec),
+                     reinterpret_cast<float2 *>(v_means2d), (float *)nullptr, (float *)nullptr, (float *)nullptr,
+                     reinterpret_cast<float2 *>(v_means2d_abs));
+  return check_launch("so_rasterization_bwd (means2d)");
 }
 // the same with float16 attribute rows (so_preprocess_fwd_f16 / so_preprocess_bwd_f16)
 int preprocess_fwd_n_f16(int C, int N, int K, int sh_degree, const float *means, const float *logit_opacities, const void *arec,

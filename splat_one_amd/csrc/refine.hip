@@ -10,8 +10,9 @@
 //
 //   k_refine_classify   one lane per source Gaussian: the three decisions, packed into a flag byte; per-workgroup
 //                       counts of the rows each output segment receives (wave ballots + popcounts)
-//   k_refine_scan       one workgroup: exclusive scan of the per-workgroup counts, new N (clamped to the capacity),
-//                       the report {duplicated, split, pruned, N, overflow}
+//   k_refine_scan       one workgroup: exclusive scan of the per-workgroup counts, new N, the report {duplicated, split,
+//                       pruned, N, overflow, old N, refinements, rows needed}; a refined set larger than the capacity
+//                       turns the whole refinement into the identity copy (overflow = 1, statistics kept)
 //   k_refine_map        destination of every surviving row (ballot prefix inside the workgroup + scanned offset):
 //                       src_of[dst] = source row | kind << 30
 //   k_refine_gather     one lane per OUTPUT element: parameters, exp_avg, exp_avg_sq of all six tensors copied from the
@@ -136,8 +137,13 @@ k_refine_scan(int nblk, int64_t cap, const int32_t *__restrict__ block_counts, i
     const int64_t n_old = imin64((int64_t)*n_src, cap);
     int64_t n_new = A + B + 2 * Cc;
     const int over = n_new > cap;
-    if (over) n_new = cap;          // rows past the capacity are dropped (k_refine_map); the host enlarges the buffers
-    totals[0] = (int32_t)A; totals[1] = (int32_t)B; totals[2] = (int32_t)Cc;
+    // A refined set that does not fit the capacity is NOT written (round 2 truncated it: the tail of the output order --
+    // split children, duplicates -- was lost while their parents were already gone): the refinement becomes the identity
+    // copy src -> dst with the statistics kept, report[4] tells the host, which enlarges the buffers and refines again.
+    report[7] = (int32_t)imin64(n_new, 0x7fffffff);                      // rows the refined set needs
+    if (over) n_new = n_old;
+    totals[0] = (int32_t)(over ? n_old : A); totals[1] = (int32_t)(over ? 0 : B); totals[2] = (int32_t)(over ? 0 : Cc);
+    totals[3] = over;
     *n_dst = (int32_t)n_new;
     report[0] = (int32_t)n_dup; report[1] = (int32_t)n_split;
     report[2] = (int32_t)(n_old + n_dup + n_split - (A + B + 2 * Cc));   // pruned from the grown set
@@ -152,6 +158,14 @@ k_refine_map(int64_t cap, const int32_t *__restrict__ n_src, const uint8_t *__re
   __shared__ int32_t s_cnt[kRefItems * (kRefBlock / 64)][3];
   __shared__ int32_t s_base[kRefItems * (kRefBlock / 64)][3];
   const int64_t N = imin64((int64_t)*n_src, cap);
+  if (totals[3]) {   // the refined set would not fit (k_refine_scan): identity
+#pragma unroll
+    for (int it = 0; it < kRefItems; ++it) {
+      const int64_t i = (int64_t)blockIdx.x * kRefChunk + it * kRefBlock + threadIdx.x;
+      if (i < N) src_of[i] = (uint32_t)i;
+    }
+    return;
+  }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
   uint32_t f[kRefItems];
@@ -205,11 +219,12 @@ struct ModelSet {
 __global__ void __launch_bounds__(256)
 k_refine_gather(int64_t cap, int K, const ModelSet src, const ModelSet dst, const int32_t *__restrict__ n_dst,
                 const uint32_t *__restrict__ src_of, float *__restrict__ grad2d, float *__restrict__ count,
-                int revised_opacity, uint64_t seed, uint32_t step) {
+                int revised_opacity, uint64_t seed, uint32_t step, const int32_t *__restrict__ totals) {
   const int g = blockIdx.y;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g == 6) {   // the statistics start over after every refinement (gsplat zeroes them)
+    if (totals[3]) return;   // ... unless this one was put off (capacity): it will run again on the same statistics
     for (int64_t i = t0; i < cap; i += stride) { grad2d[i] = 0.f; count[i] = 0.f; }
     return;
   }
@@ -263,13 +278,13 @@ k_reset_opacity(int64_t cap, const int32_t *__restrict__ n_dev, float *__restric
 // statistic inside k_preprocess_bwd): one lane per Gaussian sums over the cameras that see it -- no atomics, no
 // intermediate [C,N] tensors (the torch formulation is a dozen launches).
 __global__ void __launch_bounds__(256)
-k_strategy_update(int C, int64_t N, const float2 *__restrict__ v_means2d, const int32_t *__restrict__ radii, float sx,
-                  float sy, float inv_max_wh, float *__restrict__ grad2d, float *__restrict__ count,
+k_strategy_update(int C, int64_t N, const float2 *__restrict__ v_means2d, const int32_t *__restrict__ radii, int64_t rstride,
+                  float sx, float sy, float inv_max_wh, float *__restrict__ grad2d, float *__restrict__ count,
                   float *__restrict__ radii_state) {
   for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
     float g = 0.f, cn = 0.f, rmax = 0.f;
     for (int c = 0; c < C; ++c) {
-      const int32_t r = radii[(int64_t)c * N + n];
+      const int32_t r = radii[((int64_t)c * N + n) * rstride];
       if (r > 0) {
         const float2 v = v_means2d[(int64_t)c * N + n];
         const float gx = v.x * sx, gy = v.y * sy;
@@ -333,7 +348,7 @@ extern "C" int so_refine_default(int64_t capacity, int K, const so_model_set *sr
   int64_t gx = so::ceil_div(capacity * 3, 256);
   if (gx > 2048) gx = 2048;
   hipLaunchKernelGGL(so::k_refine_gather, dim3((unsigned)gx, 7), dim3(256), 0, st, capacity, K, S, D, n_dst_dev, src_of, grad2d,
-                     count, prm->revised_opacity, prm->seed, (uint32_t)prm->step);
+                     count, prm->revised_opacity, prm->seed, (uint32_t)prm->step, totals);
   return so::check_launch("so_refine_default");
 }
 
@@ -349,14 +364,16 @@ extern "C" int so_reset_opacity(int64_t capacity, const int32_t *n_dev, float *l
   return so::check_launch("so_reset_opacity");
 }
 
-extern "C" int so_strategy_update_state(int C, int64_t N, const float *v_means2d, const int32_t *radii, float sx, float sy,
-                                        float inv_max_wh, float *grad2d, float *count, float *radii_state, void *stream) {
+extern "C" int so_strategy_update_state(int C, int64_t N, const float *v_means2d, const int32_t *radii, int64_t radii_stride,
+                                        float sx, float sy, float inv_max_wh, float *grad2d, float *count, float *radii_state,
+                                        void *stream) {
   SO_REQUIRE(C >= 0 && N >= 0, "so_strategy_update_state: bad sizes");
   if (C == 0 || N == 0) return SO_OK;
   SO_REQUIRE(v_means2d && radii && grad2d && count, "so_strategy_update_state: null pointer");
   int64_t gx = so::ceil_div(N, 256);
   if (gx > 4096) gx = 4096;
   hipLaunchKernelGGL(so::k_strategy_update, dim3((unsigned)gx), dim3(256), 0, so::as_stream(stream), C, N,
-                     reinterpret_cast<const float2 *>(v_means2d), radii, sx, sy, inv_max_wh, grad2d, count, radii_state);
+                     reinterpret_cast<const float2 *>(v_means2d), radii, radii_stride > 0 ? radii_stride : (int64_t)1, sx, sy,
+                     inv_max_wh, grad2d, count, radii_state);
   return so::check_launch("so_strategy_update_state");
 }

@@ -151,7 +151,10 @@ class FusedEngine:
                     stats[q][:n].copy_(self.strategy_state[q])
         self.sets, self.dstats, self.active, self.cap = sets, stats, 0, cap
         self._n_dev = torch.tensor([n, 0], dtype=torch.int32, device=dev)
-        self._report = torch.zeros(8, dtype=torch.int32, device=dev)
+        # the refinement report lives in HOST-MAPPED memory: the kernel writes its eight words across the bus, the host looks
+        # at them one step late without synchronising (element 6 says which refinement they describe)
+        self._report = torch.zeros(8, dtype=torch.int32).pin_memory()
+        self._report_handled = 0
         words = int(_lib.load().so_refine_scratch_words(cap))
         self._refine_scratch = torch.empty(words, dtype=torch.int32, device=dev)
         self._ms = []
@@ -175,14 +178,9 @@ class FusedEngine:
             if not self._host_stale:
                 return self.n_host
             if known_n is None:
-                rep = self._report.cpu()                       # synchronises
-                n = int(self._n_dev[self.active].item())
-                if int(rep[4]):
-                    self._report[4] = 0
-                    import warnings
-                    warnings.warn(f"splat_one_amd: a refinement grew the model past the capacity of {self.cap} Gaussians -- the "
-                                  "rows beyond it were dropped; the buffers are being enlarged (Config.max_gaussians)", RuntimeWarning)
-                    self._grow_after_sync = True
+                n = int(self._n_dev[self.active].item())       # synchronises: the report below is current
+                if int(self._report[4]) and self._report_handled != self.refinements:
+                    self._grow_after_sync = True               # the last refinement was put off: enlarge, refine again (below)
             else:
                 n = known_n
             a = self.sets[self.active]
@@ -203,14 +201,43 @@ class FusedEngine:
             self.n_host, self._host_stale = n, False
             if getattr(self, "_grow_after_sync", False):
                 self._grow_after_sync = False
-                self._build_model_sets(2 * self.cap)
-                self._build_workspace()
+                self._enlarge_and_refine_again()
+                return self.sync_host()
             return n
+
+    def _enlarge_and_refine_again(self) -> None:
+        """The last refinement did not fit the capacity and was put off on the device (so_refine_default: identity copy,
+        statistics kept).  Enlarge both model sets -- to twice the capacity or 1.5x the rows it needs -- and run it again."""
+        import warnings
+        needed = int(self._report[7])
+        new_cap = max(2 * self.cap, int(1.5 * needed))
+        warnings.warn(f"splat_one_amd: a refinement needs {needed} Gaussians, more than the capacity of {self.cap} -- it was put "
+                      f"off (nothing is lost), the buffers grow to {new_cap} rows and it runs again (Config.max_gaussians sizes "
+                      "them up front)", RuntimeWarning)
+        args = self._last_refine
+        self._host_stale = True
+        n = int(self._n_dev[self.active].item())
+        self.sync_host(known_n=n)
+        stats = {q: self.dstats[q][:n].clone() for q in ("grad2d", "count")}
+        self._build_model_sets(new_cap)              # (moves the live rows into set 0 of the new buffers)
+        for q in stats:
+            self.dstats[q][:n].copy_(stats[q])
+        self._build_workspace()
+        self.refine(*args)
+
+    def poll_refine_report(self) -> None:
+        """One step late and without synchronising: did the last refinement fit?  (Called when the next view is staged.)"""
+        if not self.device_refine or self._report_handled == self.refinements or int(self._report[6]) != self.refinements:
+            return
+        if int(self._report[4]):
+            self._enlarge_and_refine_again()
+        self._report_handled = self.refinements
 
     def refine(self, strategy, step: int, scene_scale: float, seed: int = 0) -> None:
         """One DefaultStrategy refinement (duplicate / split / prune) on the device: active set -> other set, which
         becomes the active one.  Statistics are zeroed.  Nothing is read back; `refine_report()` gives the counts."""
         assert self.device_refine
+        self._last_refine = (strategy, step, scene_scale, seed)
         with self._lock:
             src, dst = self.active, 1 - self.active
             prm = _lib.RefineParams(float(strategy.grow_grad2d), float(strategy.grow_scale3d * scene_scale), float(strategy.prune_opa),
@@ -218,7 +245,7 @@ class FusedEngine:
                                     int(bool(strategy.revised_opacity)), int(seed) & 0xFFFFFFFFFFFFFFFF, int(step), 0)
             _lib.call("so_refine_default", self.cap, self.K, ctypes.byref(self._ms[src]), _lib.ptr(self._n_dev[src:src + 1]),
                       ctypes.byref(self._ms[dst]), _lib.ptr(self._n_dev[dst:dst + 1]), _lib.ptr(self.dstats["grad2d"]),
-                      _lib.ptr(self.dstats["count"]), ctypes.byref(prm), _lib.ptr(self._refine_scratch), _lib.ptr(self._report),
+                      _lib.ptr(self.dstats["count"]), ctypes.byref(prm), _lib.ptr(self._refine_scratch), self._report.data_ptr(),
                       _lib.stream())
             self.active = dst
             self.refinements += 1
@@ -236,8 +263,10 @@ class FusedEngine:
 
     def refine_report(self) -> dict:
         """Counts of the last refinement (synchronises): duplicated, split, pruned, N after, capacity overflow, N before."""
-        r = self._report.cpu().tolist()
-        return {"n_dupli": r[0], "n_split": r[1], "n_prune": r[2], "n_new": r[3], "overflow": r[4], "n_old": r[5], "refinements": r[6]}
+        torch.cuda.synchronize()
+        r = self._report.tolist()
+        return {"n_dupli": r[0], "n_split": r[1], "n_prune": r[2], "n_new": r[3], "overflow": r[4], "n_old": r[5], "refinements": r[6],
+                "rows_needed": r[7]}
 
     def adam_on_flat_range(self, a: int, b: int) -> None:
         """Adam (host-scheduled: so_adam_step) on the flat range [a, b) of parameters / moments / gradient -- the piece of
@@ -504,6 +533,7 @@ class FusedEngine:
         same inputs)."""
         if c2w is not None:
             self._check_previous()                   # may rebuild the workspace: before anything is staged
+            self.poll_refine_report()                # (a refinement that did not fit its buffers: enlarge, refine again)
         w, p, dev = self.ws, _lib.ptr, self.device
         n_groups, lr0, gam, betas = 0, None, None, (0.0, 0.0)
         if schedule:

@@ -16,33 +16,44 @@ from ._lib import call, ptr, stream
 
 
 class _L1SSIM(torch.autograd.Function):
-    """a * mean|x-y| + b * mean SSIM(x,y) + c   on channel-last [B,H,W,CH] images."""
+    """a * mean|x-y| + b * mean SSIM(x,y) + c   on channel-last [B,H,W,CH] images.
+
+    When img1 needs a gradient the forward runs `so_ssim_l1_fused`: loss scalars AND d loss / d img1 in one launch (the
+    derivative values of the SSIM map pass through LDS instead of three maps in HBM); the backward then only scales that
+    gradient by the incoming v_loss.  Forward-only calls (eval) run `so_ssim_l1_fwd` without derivative maps."""
 
     @staticmethod
-    def forward(ctx, img1: Tensor, img2: Tensor, a: float, b: float, c: float, valid: bool):
+    def forward(ctx, img1: Tensor, img2: Tensor, a: float, b: float, c: float, valid: bool, one_minus: bool = False):
+        """-> (loss, mean|x-y|, mean SSIM -- or 1 - mean SSIM with `one_minus`, which is what the kernel leaves behind)"""
         B, H, W, CH = img1.shape
-        need_grad = img1.requires_grad
-        sums = torch.zeros(2, dtype=torch.float32, device=img1.device)
-        dmaps = torch.empty(3, B, H, W, CH, dtype=torch.float32, device=img1.device) if need_grad else None
-        call("so_ssim_l1_fwd", B, H, W, CH, ptr(img1), ptr(img2), 1 if valid else 0, ptr(sums), ptr(dmaps), stream())
+        need_grad = ctx.needs_input_grad[0]
         n_l1 = float(B * H * W * CH)
         n_ss = float(B * CH * ((H - 10) * (W - 10) if valid else H * W))
-        l1 = sums[0] / n_l1
-        ssim = sums[1] / n_ss
-        ctx.save_for_backward(img1, img2, dmaps)
-        ctx.w = (a / n_l1, b / n_ss)
+        ctx.set_materialize_grads(False)
+        if need_grad:
+            work = torch.zeros(6, dtype=torch.float32, device=img1.device)     # sums[2] | loss, l1, 1 - ssim | ticket
+            grad = torch.empty_like(img1)
+            call("so_ssim_l1_fused", B, H, W, CH, ptr(img1), ptr(img2), 1 if valid else 0, a / n_l1, b / n_ss, 0, ptr(work), ptr(grad),
+                 ptr(work[2:]), ptr(work[5:]), c, 0, stream())
+            ctx.save_for_backward(grad)
+            loss, l1, ssim = work[2], work[3], (work[4] if one_minus else 1.0 - work[4])
+        else:
+            sums = torch.zeros(2, dtype=torch.float32, device=img1.device)
+            call("so_ssim_l1_fwd", B, H, W, CH, ptr(img1), ptr(img2), 1 if valid else 0, ptr(sums), 0, stream())
+            l1 = sums[0] / n_l1
+            ssim = sums[1] / n_ss
+            loss = a * l1 + b * ssim + c
+            if one_minus:
+                ssim = 1.0 - ssim
         ctx.mark_non_differentiable(l1, ssim)
-        return a * l1 + b * ssim + c, l1, ssim
+        return loss, l1, ssim
 
     @staticmethod
-    def backward(ctx, v_loss, _v_l1, _v_ssim):
-        img1, img2, dmaps = ctx.saved_tensors
-        B, H, W, CH = img1.shape
-        v_img1 = torch.empty_like(img1)
-        v_loss = v_loss.contiguous().to(torch.float32)
-        call("so_ssim_l1_bwd", B, H, W, CH, ptr(img1), ptr(img2), ptr(dmaps), ctx.w[0], ctx.w[1], ptr(v_loss),
-             ptr(v_img1), 0, 0, 0, 0.0, stream())
-        return v_img1, None, None, None, None, None
+    def backward(ctx, v_loss, _v_l1=None, _v_ssim=None):
+        (grad,) = ctx.saved_tensors
+        if v_loss is None:
+            return None, None, None, None, None, None, None
+        return grad * v_loss.to(torch.float32), None, None, None, None, None, None
 
 
 def _prep(x: Tensor) -> Tensor:
@@ -54,9 +65,7 @@ def photometric_loss(colors: Tensor, pixels: Tensor, ssim_lambda: float = 0.2):
     """colors, pixels: [B,H,W,3] in 0..1.  Returns (loss, l1loss, ssimloss) as at gsplat_trainer.py:624-628."""
     assert colors.shape == pixels.shape and colors.dim() == 4, (colors.shape, pixels.shape)
     assert colors.shape[1] > 10 and colors.shape[2] > 10, "image smaller than the 11x11 SSIM window"
-    loss, l1, ssim = _L1SSIM.apply(_prep(colors), _prep(pixels.detach()), 1.0 - ssim_lambda, -ssim_lambda,
-                                   ssim_lambda, True)
-    return loss, l1, 1.0 - ssim
+    return _L1SSIM.apply(_prep(colors), _prep(pixels.detach()), 1.0 - ssim_lambda, -ssim_lambda, ssim_lambda, True, True)
 
 
 def photometric_loss_and_grad(colors: Tensor, pixels: Tensor, ssim_lambda: float = 0.2, *, rows: int = 0):

@@ -70,8 +70,8 @@ def _launch(items: List[tuple], zero_grad: bool) -> None:
             chunk = its[i0:i0 + _lib.SO_ADAM_MAX_GROUPS]
             arr = (_lib.AdamGroup * len(chunk))()
             keep = []
+            torch._foreach_add_([it[2]["step"] for it in chunk], 1)      # (one dispatch for the six host-side step counters)
             for i, (p, g, st, lr, _b, _e, vis) in enumerate(chunk):
-                st["step"] += 1
                 t = float(st["step"])
                 assert p.is_contiguous() and g.is_contiguous(), "parameters and gradients must be contiguous"
                 vptr, row_len = 0, 1

@@ -14,10 +14,67 @@ import torch
 import torch.distributed as dist
 from torch import Tensor
 
+from . import raster_op
 from .ops import (camera_inverse, sh_view_colors, fully_fused_projection, isect_offset_encode, isect_tiles, isect_tiles_static,
                   rasterize_to_pixels, spherical_harmonics)
 
 RENDER_MODES = ("RGB", "D", "ED", "RGB+D", "RGB+ED")
+_PENDING = object()
+LIST_KEYS = ("tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets")
+
+
+class Meta(dict):
+    """The `meta` / `info` dict of `rasterization`.  A plain dict for every key the call computes anyway; the per-tile LISTS
+    (`tiles_per_gauss`, `isect_ids`, `flatten_ids`, `isect_offsets`) are computed when first asked for -- gsplat's own
+    lists, entry for entry (no tile culling, compact layout, global stable order), from the projected centres / radii /
+    depths of this call -- because the kernels work on shorter, differently laid-out lists of their own and the
+    reference's trainer never reads these keys (gsplat_trainer.py:616-622, 707, 722-724, 750)."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._thunks = []
+
+    def set_lazy(self, keys, thunk) -> None:
+        """`thunk()` returns the values of `keys` (a tuple), evaluated when one of them is first read"""
+        self._thunks.append((tuple(keys), thunk))
+        for k in keys:
+            dict.__setitem__(self, k, _PENDING)
+
+    def set_lists(self, thunk) -> None:
+        self.set_lazy(LIST_KEYS, thunk)
+
+    def _resolve(self, key=None) -> None:
+        keep = []
+        for keys, thunk in self._thunks:
+            if key is not None and key not in keys:
+                keep.append((keys, thunk))
+                continue
+            for k, v in zip(keys, thunk()):
+                if dict.__getitem__(self, k) is _PENDING:
+                    dict.__setitem__(self, k, v)
+        self._thunks = keep
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        if v is _PENDING:
+            self._resolve(k)
+            v = dict.__getitem__(self, k)
+        return v
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        self._resolve()
+        return dict.items(self)
+
+    def values(self):
+        self._resolve()
+        return dict.values(self)
+
+    def copy(self):
+        self._resolve()
+        return Meta(dict.copy(self))
 
 
 def _all_to_all_rows(inp: Tensor, send: list, recv: list) -> Tensor:
@@ -98,14 +155,20 @@ def rasterization(
     isect_capacity: Optional[int] = None,
     workspace: Optional[dict] = None,
     tile_cull: bool = True,
+    fused: Optional[bool] = None,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Rasterise N Gaussians to C cameras.  Returns (render_colors[C,H,W,X], render_alphas[C,H,W,1], meta).
 
     Differences from the gsplat call, all explicit:
-      * `tile_cull=True` (default): the per-tile lists leave out (Gaussian, tile) pairs that provably reach no pixel with
-        alpha >= 1/255 (`isect_tiles(conics=, opacities=)`).  Images are bit-identical to the un-culled call and gradients
-        equal up to the order of the float atomics; `meta["tiles_per_gauss"]`, `meta["isect_ids"]`, `meta["flatten_ids"]`
-        and `meta["isect_offsets"]` describe the shorter lists.  `tile_cull=False` reproduces gsplat's lists entry for entry.
+      * `fused` (None = whenever possible): the COMMON SHAPE of the call -- `packed=False`, SH coefficients [N,K,3] shared by
+        the cameras, `render_mode="RGB"`, poses without gradient, no `covars` / `distributed` / `sparse_grad`: exactly what
+        the reference passes at gsplat_trainer.py:478-493 -- runs as ONE library call each way (`splat_one_amd.raster_op`:
+        so_rasterization_fwd / _bwd), with nothing read back to the host.  Any other shape, or `fused=False`, composes the
+        operators of `splat_one_amd.ops` as gsplat composes its own.  Same images, alphas, `meta` and gradients either way.
+      * `tile_cull=True` (default): the kernels' INTERNAL per-tile lists leave out (Gaussian, tile) pairs that provably reach
+        no pixel with alpha >= 1/255.  Images are bit-identical to the un-culled call and gradients equal up to the order of
+        the float atomics.  `meta["tiles_per_gauss"]`, `meta["isect_ids"]`, `meta["flatten_ids"]`, `meta["isect_offsets"]`
+        are gsplat's lists regardless (computed when first read, class `Meta`).
       * `packed=True` (gsplat's default; the reference passes `Config.packed` = False, gsplat_trainer.py:133, 487):
         every per-Gaussian intermediate and `meta` entry has one row per (camera, Gaussian) pair with a positive
         radius, camera-major, with `meta["camera_ids"]` / `meta["gaussian_ids"]` naming the pair; the rasteriser
@@ -123,7 +186,7 @@ def rasterization(
       * `isect_capacity` / `workspace` (extensions): preallocated intersection buffers make the call
         free of host synchronisation (hipGraph-capturable); `meta["n_isects"]` then lives on the device.
     """
-    meta: Dict = {}
+    meta: Dict = Meta()
     N = means.shape[0]
     C = viewmats.shape[0]
     device = means.device
@@ -153,6 +216,30 @@ def rasterization(
         assert (colors.dim() == 3 and colors.shape[0] == N and colors.shape[2] == 3) or (
             colors.dim() == 4 and colors.shape[:2] == (C, N) and colors.shape[3] == 3), colors.shape
         assert (sh_degree + 1) ** 2 <= colors.shape[-2], colors.shape
+
+    tile_width = math.ceil(width / float(tile_size))
+    tile_height = math.ceil(height / float(tile_size))
+    periodic = camera_model == "spherical" and width % tile_size == 0
+
+    def gsplat_lists(means2d_, radii_, depths_, camera_ids_=None, gaussian_ids_=None, n_cam=C):
+        """thunk for Meta: gsplat's un-culled compact lists of this call"""
+        def thunk():
+            with torch.no_grad():
+                return isect_tiles(means2d_.detach().contiguous(), radii_.contiguous(), depths_.detach().contiguous(), tile_size,
+                                   tile_width, tile_height, packed=packed, n_cameras=n_cam, camera_ids=camera_ids_,
+                                   gaussian_ids=gaussian_ids_, return_offsets=True, periodic=periodic)
+        return thunk
+
+    if fused is None or fused:
+        ok = raster_op.usable(means, quats, scales, opacities, colors, viewmats, Ks, sh_degree=sh_degree, packed=packed,
+                              tile_size=tile_size, render_mode=render_mode, sparse_grad=sparse_grad, distributed=distributed,
+                              covars=covars, isect_capacity=isect_capacity, backgrounds=backgrounds, camera_model=camera_model)
+        assert ok or not fused, "rasterization(fused=True): this call does not have the common shape (see the docstring)"
+        if ok:
+            return _one_call(means, quats, scales, opacities, colors, None, viewmats, Ks, width, height, sh_degree=sh_degree,
+                             near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip, eps2d=eps2d, tile_size=tile_size,
+                             backgrounds=backgrounds, absgrad=absgrad, rasterize_mode=rasterize_mode, camera_model=camera_model,
+                             tile_cull=tile_cull)
 
     # K1 projection
     proj = fully_fused_projection(
@@ -240,11 +327,8 @@ def rasterization(
         opacities, colors = rows[..., 7].contiguous(), rows[..., 8:]
 
     # K6-K8 binning + sort + offsets
-    tile_width = math.ceil(width / float(tile_size))
-    tile_height = math.ceil(height / float(tile_size))
     n_isects_dev = None
-    # an equirectangular panorama is periodic in x: footprints continue across the +-pi seam when the tile grid lines up
-    periodic = camera_model == "spherical" and width % tile_size == 0
+    # (periodic: an equirectangular panorama is periodic in x -- footprints continue across the +-pi seam when the tile grid lines up)
     cull_kw = {"conics": conics, "opacities": opacities} if tile_cull else {}
     if isect_capacity is None:
         tiles_per_gauss, isect_ids, flatten_ids, isect_offsets = isect_tiles(
@@ -261,6 +345,10 @@ def rasterization(
     meta.update({"tile_width": tile_width, "tile_height": tile_height, "tiles_per_gauss": tiles_per_gauss,
                  "isect_ids": isect_ids, "flatten_ids": flatten_ids, "isect_offsets": isect_offsets,
                  "width": width, "height": height, "tile_size": tile_size, "n_cameras": C})
+    meta["n_isects_kernel"] = n_isects_dev if n_isects_dev is not None else torch.tensor(flatten_ids.numel(), device=device)
+    if tile_cull and isect_capacity is None:
+        # the rasteriser below walks the culled lists; what `meta` shows are gsplat's (computed if somebody reads them)
+        meta.set_lists(gsplat_lists(means2d, radii, depths, camera_ids, gaussian_ids, C))
 
     # K9 rasterise (channel-chunked like gsplat when D > channel_chunk)
     colors = colors.contiguous()
@@ -286,3 +374,63 @@ def rasterization(
         render_colors = torch.cat(
             [render_colors[..., :-1], render_colors[..., -1:] / render_alphas.clamp(min=1e-10)], dim=-1)
     return render_colors, render_alphas, meta
+
+
+def _one_call(means, quats, scales, opacities, colors, shN, viewmats, Ks, width, height, *, sh_degree, near_plane, far_plane,
+              radius_clip, eps2d, tile_size, backgrounds, absgrad, rasterize_mode, camera_model, tile_cull):
+    """The common shape through `raster_op` (one library call each way) + the `meta` dict around its outputs.  shN given:
+    scales / opacities / colors are the raw parameters (log-scales, logits, sh0)."""
+    C = viewmats.shape[0]
+    tile_width, tile_height = math.ceil(width / float(tile_size)), math.ceil(height / float(tile_size))
+    periodic = camera_model == "spherical" and width % tile_size == 0
+    (render_colors, render_alphas, means2d, radii, depths, conics, opac_v, _rgb, kernel_isects) = raster_op.fused_rasterization(
+        means, quats, scales, opacities, colors, viewmats, Ks, width, height, sh_degree=sh_degree, near_plane=near_plane,
+        far_plane=far_plane, radius_clip=radius_clip, eps2d=eps2d, tile_size=tile_size, backgrounds=backgrounds, absgrad=absgrad,
+        antialiased=(rasterize_mode == "antialiased"), camera_model=camera_model, tile_cull=tile_cull, shN=shN)
+    meta = Meta({"camera_ids": None, "gaussian_ids": None, "radii": radii, "means2d": means2d, "depths": depths,
+                 "conics": conics, "opacities": opac_v, "tile_width": tile_width, "tile_height": tile_height,
+                 "width": width, "height": height, "tile_size": tile_size, "n_cameras": C})
+
+    def gsplat_lists():
+        with torch.no_grad():
+            return isect_tiles(means2d.detach().contiguous(), radii.contiguous(), depths.detach().contiguous(), tile_size, tile_width,
+                               tile_height, packed=False, n_cameras=C, return_offsets=True, periodic=periodic)
+    meta.set_lists(gsplat_lists)
+    # (extension) how many (Gaussian, tile) pairs the kernels' own -- culled, binned -- lists held: a device scalar
+    meta.set_lazy(("n_isects_kernel",), lambda: (kernel_isects(),))
+    return render_colors, render_alphas, meta
+
+
+def rasterization_from_parameters(means: Tensor, quats: Tensor, log_scales: Tensor, logit_opacities: Tensor, sh0: Tensor,
+                                  shN: Tensor, viewmats: Tensor, Ks: Tensor, width: int, height: int, **kw):
+    """What `Runner.rasterize_splats` computes at /root/reference/utils/gsplat_utils/gsplat_trainer.py:456-494,
+
+        rasterization(means, quats, exp(log_scales), sigmoid(logit_opacities), cat([sh0, shN], 1), viewmats, Ks, ...),
+
+    for a caller that HOLDS the raw parameters: when the call has the common shape (see `rasterization`) the activations
+    and the concatenation run inside the kernels -- no exp / sigmoid / cat launches, no autograd nodes for them, the
+    coefficient gradient lands in `sh0.grad` / `shN.grad` without being assembled and split again.  Any other shape (or
+    fused=False) evaluates exactly the expression above.  Same return triple."""
+    fused = kw.pop("fused", None)
+    d = dict(near_plane=0.01, far_plane=1e10, radius_clip=0.0, eps2d=0.3, sh_degree=None, packed=True, tile_size=16, backgrounds=None,
+             render_mode="RGB", sparse_grad=False, absgrad=False, rasterize_mode="classic", distributed=False,
+             camera_model="pinhole", covars=None, isect_capacity=None, tile_cull=True)
+    d.update({k: v for k, v in kw.items() if k in d})
+    ok = (fused is None or fused) and shN.dim() == 3 and sh0.dim() == 3 and sh0.shape[1] == 1 and shN.shape[0] == sh0.shape[0] \
+        and raster_op.usable(means, quats, log_scales, logit_opacities, sh0, viewmats, Ks, sh_degree=d["sh_degree"], packed=d["packed"],
+                             tile_size=d["tile_size"], render_mode=d["render_mode"], sparse_grad=d["sparse_grad"],
+                             distributed=d["distributed"], covars=d["covars"], isect_capacity=d["isect_capacity"],
+                             backgrounds=d["backgrounds"], camera_model=d["camera_model"]) \
+        and shN.dtype == torch.float32 and (d["sh_degree"] + 1) ** 2 <= 1 + shN.shape[1]
+    if not ok:
+        return rasterization(means, quats, torch.exp(log_scales), torch.sigmoid(logit_opacities), torch.cat([sh0, shN], 1),
+                             viewmats, Ks, width, height, fused=fused, **kw)
+    N, C = means.shape[0], viewmats.shape[0]
+    assert means.shape == (N, 3) and quats.shape == (N, 4) and log_scales.shape == (N, 3) and logit_opacities.shape == (N,), \
+        (means.shape, quats.shape, log_scales.shape, logit_opacities.shape)
+    assert viewmats.shape == (C, 4, 4) and Ks.shape == (C, 3, 3), (viewmats.shape, Ks.shape)
+    assert d["rasterize_mode"] in ("classic", "antialiased"), d["rasterize_mode"]
+    return _one_call(means, quats, log_scales, logit_opacities, sh0, shN, viewmats, Ks, width, height, sh_degree=d["sh_degree"],
+                     near_plane=d["near_plane"], far_plane=d["far_plane"], radius_clip=d["radius_clip"], eps2d=d["eps2d"],
+                     tile_size=d["tile_size"], backgrounds=d["backgrounds"], absgrad=d["absgrad"],
+                     rasterize_mode=d["rasterize_mode"], camera_model=d["camera_model"], tile_cull=d["tile_cull"])

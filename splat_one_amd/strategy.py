@@ -344,13 +344,19 @@ class DefaultStrategy(Strategy):
             state["radii"] = torch.zeros(n_gaussian, device=grads.device)
         sx = info["width"] / 2.0 * info["n_cameras"]
         sy = info["height"] / 2.0 * info["n_cameras"]
-        if (not packed and grads.is_cuda and grads.dim() == 3 and grads.dtype == torch.float32 and grads.is_contiguous()
-                and info["radii"].dtype == torch.int32 and info["radii"].is_contiguous()
+        radii = info["radii"]
+        # radii: a dense [C,N] array, or the radius slot of the 64-byte records (`rasterization`'s whole-operator path: a
+        # view with one element every `stride` words)
+        r_stride = radii.stride(-1) if radii.dim() == 2 else 0
+        r_ok = (radii.dtype == torch.int32 and radii.dim() == 2
+                and (radii.is_contiguous() or (r_stride > 1 and radii.stride(0) == radii.shape[1] * r_stride)))
+        if (not packed and grads.is_cuda and grads.dim() == 3 and grads.dtype == torch.float32 and grads.is_contiguous() and r_ok
                 and all(state[k].is_contiguous() and state[k].dtype == torch.float32 for k in ("grad2d", "count"))):
             # dense layout on the device: ONE launch instead of a dozen torch kernels (csrc/refine.hip k_strategy_update)
-            from ._lib import call, ptr, stream
-            C, N = info["radii"].shape
-            call("so_strategy_update_state", C, N, ptr(grads), ptr(info["radii"]), float(sx), float(sy),
+            from ._lib import call, stream
+            ptr = lambda t: 0 if t is None else t.data_ptr()
+            C, N = radii.shape
+            call("so_strategy_update_state", C, N, ptr(grads), ptr(radii), int(r_stride), float(sx), float(sy),
                  1.0 / float(max(info["width"], info["height"])), ptr(state["grad2d"]), ptr(state["count"]),
                  ptr(state["radii"]) if self.refine_scale2d_stop_iter > 0 else 0, stream())
             return

@@ -35,7 +35,7 @@ from torch import Tensor
 from . import distributed as sdist
 from .losses import photometric_loss
 from .optimizers import FusedAdam, SelectiveAdam, step_all
-from .rendering import rasterization
+from .rendering import rasterization, rasterization_from_parameters
 from .ops import camera_inverse
 from .scene import knn, rgb_to_sh, set_random_seed
 from .strategy import DefaultStrategy, MCMCStrategy
@@ -107,7 +107,10 @@ class Config:
     lpips_net: str = "alex"
     # extensions of this build
     isect_capacity: Optional[int] = None   # preallocated intersections -> no host sync in the step
-    fused: bool = False                    # FusedEngine: whole step in two C-ABI calls, hipGraph replay
+    # FusedEngine: the whole training step as hipGraph replays of two C-ABI calls, whenever the step has the shape the
+    # engine covers (Runner._fused_ok: no masks / random background / packed / pose refinement); False: every step goes
+    # through Runner.rasterize_splats -> rasterization() -> photometric_loss -> step_all under torch autograd
+    fused: bool = True
     # multi-GPU scheme (world_size > 1, fused path, one view per rank per step):
     #   "gaussian_sharded"  the reference's own: every rank owns N/world Gaussians, projected Gaussians are
     #                       exchanged (two all-to-alls of ~64 B/Gaussian), per-rank densification / checkpoints;
@@ -136,6 +139,14 @@ class Config:
     #                                        (0 = by size: 4 from 64 MB of gradient on, i.e. ~285k Gaussians at SH degree 3,
     #                                        else 1 -- below that the latency of eight collectives outweighs the overlap)
     shN_init_std: float = 0.0              # >0: noise instead of zeros in the higher SH bands (bench scenes)
+    # Runner.train draws the training views like the reference's DataLoader(shuffle=True) (gsplat_trainer.py:539-546): a
+    # fresh permutation per epoch, seeded from the global torch generator exactly as torch's RandomSampler seeds its own.
+    # False: views in dataset order (deterministic walks for tests)
+    shuffle: bool = True
+    # Runner.rasterize_splats hands the RAW parameters to the library (exp / sigmoid / cat inside the kernels) when the call
+    # has the common shape.  False: the reference's own composition -- torch exp / sigmoid / cat, then rasterization() with
+    # gsplat's signature -- on every call (what a trainer written against gsplat's API executes; bench.py times both)
+    raw_params_call: bool = True
 
     def adjust_steps(self, factor: float):
         """gsplat_trainer.py:184-201"""
@@ -319,6 +330,7 @@ class Runner:
         self._split_gen = torch.Generator(device=self.device)
         self._split_gen.manual_seed(1234)                                 # same on every rank
         self.last_info: Optional[dict] = None
+        self._void_seen = 0
 
     # ------------------------------------------------------------------------------ :308-324
     @staticmethod
@@ -573,23 +585,27 @@ class Runner:
                                              _locked=True, **kwargs)
         kwargs.pop("_locked", None)
         sp = self.full_splats() if self.sharded else self.splats
-        means = sp["means"]
-        quats = sp["quats"]
-        scales = torch.exp(sp["scales"])
-        opacities = torch.sigmoid(sp["opacities"])
         if camera_model is None:
             camera_model = self.cfg.camera_model
         kwargs.pop("image_ids", None)
-        colors = torch.cat([sp["sh0"], sp["shN"]], 1)
         rasterize_mode = "antialiased" if self.cfg.antialiased else "classic"
-        render_colors, render_alphas, info = rasterization(
-            means=means, quats=quats, scales=scales, opacities=opacities, colors=colors,
-            viewmats=camera_inverse(camtoworlds), Ks=Ks, width=width, height=height,
-            packed=self.cfg.packed,
-            absgrad=(self.cfg.strategy.absgrad if isinstance(self.cfg.strategy, DefaultStrategy) else False),
-            sparse_grad=self.cfg.sparse_grad, rasterize_mode=rasterize_mode, distributed=False,
-            camera_model=camera_model, isect_capacity=self.cfg.isect_capacity, workspace=self._workspace,
-            **kwargs)
+        # :456-494 -- exp / sigmoid / cat / inv and the rasterization() call.  This runner holds the raw parameters, so the
+        # activations travel INTO the call (rendering.rasterization_from_parameters: same expression, evaluated inside the
+        # kernels when the call has the common shape, composed exactly as the reference composes it otherwise)
+        common = dict(packed=self.cfg.packed,
+                      absgrad=(self.cfg.strategy.absgrad if isinstance(self.cfg.strategy, DefaultStrategy) else False),
+                      sparse_grad=self.cfg.sparse_grad, rasterize_mode=rasterize_mode, distributed=False,
+                      camera_model=camera_model, isect_capacity=self.cfg.isect_capacity, workspace=self._workspace)
+        viewmats = camera_inverse(camtoworlds)
+        if self.cfg.raw_params_call:
+            render_colors, render_alphas, info = rasterization_from_parameters(
+                sp["means"], sp["quats"], sp["scales"], sp["opacities"], sp["sh0"], sp["shN"], viewmats, Ks, width, height,
+                **common, **kwargs)
+        else:
+            render_colors, render_alphas, info = rasterization(
+                means=sp["means"], quats=sp["quats"], scales=torch.exp(sp["scales"]), opacities=torch.sigmoid(sp["opacities"]),
+                colors=torch.cat([sp["sh0"], sp["shN"]], 1), viewmats=viewmats, Ks=Ks, width=width, height=height,
+                **common, **kwargs)
         if masks is not None:
             render_colors[~masks] = 0
         return render_colors, render_alphas, info
@@ -929,6 +945,24 @@ class Runner:
             reset_opa(params=self.splats, optimizers=self.optimizers, state=self.strategy_state,
                       value=s.prune_opa * 2.0)
 
+    def _epoch_orders(self) -> List[List[int]]:
+        """View indices of one epoch for every rank.  Config.shuffle: the seed is drawn from the global torch generator the
+        way `torch.utils.data.RandomSampler` draws its own (the reference's DataLoader(shuffle=True), gsplat_trainer.py:
+        539-546), then `randperm` on a private generator -- with one rank the order IS the RandomSampler's order for the
+        same global generator state (tests/test_strategy_host.py).  Every rank draws the same seed (all ranks seed 42 and
+        consume the generator alike) and can therefore derive every rank's list."""
+        n, world = len(self.views), self.world_size
+        bases = [list(range(j, n, world)) or [0] for j in range(world)]
+        if not self.cfg.shuffle:
+            return bases
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        out = []
+        for j, base in enumerate(bases):
+            g = torch.Generator()
+            g.manual_seed(seed + j)
+            out.append([base[i] for i in torch.randperm(len(base), generator=g).tolist()])
+        return out
+
     def train(self, max_steps: Optional[int] = None) -> None:
         """Loop over `views` (batch_size per step, rank-strided like a DistributedSampler).
         Decoded views stay resident in HBM after their first use (a 1080p float view is 25 MB; the
@@ -940,7 +974,10 @@ class Runner:
         n = max_steps if max_steps is not None else cfg.max_steps
         B = cfg.batch_size
         dev = self.device
-        order = list(range(self.world_rank, len(self.views), self.world_size)) or [0]
+        # one list of view indices per rank (rank j walks views j, j + world, ...); every rank can derive every rank's
+        # list, so a gaussian_sharded step knows the other ranks' cameras without a collective
+        orders = self._epoch_orders()
+        order = orders[self.world_rank]
         cursor = 0
         resident: Dict[int, Tuple[Tensor, Tensor, Tensor]] = {}
         cache = cfg.patch_size is None
@@ -978,15 +1015,24 @@ class Runner:
             with open(f"{cfg.result_dir.rstrip('/')}/cfg.yml", "w") as f:
                 yaml.safe_dump({k: (v if isinstance(v, (int, float, str, bool, list, type(None))) else repr(v))
                                 for k, v in vars(cfg).items()}, f)
-        for _ in range(n):
+        from collections import deque
+        recent: deque = deque(maxlen=4)          # the last batches: a void iteration (below) is repeated on ITS view
+        done = 0
+        while done < n:
             if self.stop_training:
                 break
-            batch = [fetch(order[(cursor + i) % len(order)]) for i in range(B)]
+            # epoch over: a new permutation (the reference re-iterates its DataLoader, :562-566).  Every rank ends its epoch
+            # on the same step -- after the shortest rank list -- so that all ranks draw the same seeds
+            if cursor + B > min(len(o) for o in orders) and cursor > 0:
+                orders = self._epoch_orders()
+                order, cursor = orders[self.world_rank], 0
+            picked = [order[(cursor + i) % len(order)] for i in range(B)]
+            batch = [fetch(i) for i in picked]
             if self.sharded:
                 # every rank derives the cameras of all ranks from the same sampling rule: no collective
                 cams = []
                 for j in range(self.world_size):
-                    oj = list(range(j, len(self.views), self.world_size)) or [0]
+                    oj = orders[j]
                     cams.append(batch[0][:2] if j == self.world_rank else camera_of(oj[cursor % len(oj)]))
                 c2w = torch.stack([c[0] for c in cams])
                 Ks = torch.stack([c[1] for c in cams])
@@ -996,8 +1042,22 @@ class Runner:
             cursor += B
             pixels = torch.stack([b[2] for b in batch])
             step = self.step
-            ids = torch.tensor([order[(cursor - B + i) % len(order)] for i in range(B)])
+            ids = torch.tensor(picked)
+            recent.append((c2w, Ks, pixels, ids))
             self.train_step(c2w, Ks, pixels, image_ids=ids)
+            done += 1
+            # Void iterations (single GPU, fused engine): a tile's bin overflowed, the optimiser skipped that iteration on
+            # the device and the host learns of it one or two steps late (FusedEngine._check_previous).  The reference never
+            # drops a view: the void iterations' OWN views are trained again now -- two neighbouring views swap places.
+            eng = getattr(self, "_engine", None)
+            void = getattr(eng, "void_steps", 0) - self._void_seen
+            while void > 0 and not self.sharded and self.world_size == 1:
+                self._void_seen += void
+                self.step -= void                                  # those step numbers were never trained
+                todo = [recent[-3]] if void == 1 and len(recent) >= 3 else list(recent)[-3:-1]
+                for args_ in todo[:void]:
+                    self.train_step(args_[0], args_[1], args_[2], image_ids=args_[3])
+                void = getattr(self._engine, "void_steps", 0) - self._void_seen
             if has_data:
                 if step in [i - 1 for i in cfg.save_steps] or step == n - 1:
                     stats = {"mem": torch.cuda.max_memory_allocated() / 1024 ** 3, "ellipse_time": time.time() - global_tic,

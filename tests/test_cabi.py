@@ -75,6 +75,9 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
               "so_adam_group": ["param", "visibility", "numel", "row_len", "lr_step_size", "bc2_sqrt"],
               "so_attr_shadow": ["arec", "stride_bytes", "offset_bytes"],
               "so_model_set": ["p", "m", "v"],
+              "so_raster_desc": ["abi_size", "seq", "eps2d", "radius_clip", "bin_capacity", "means", "shN", "backgrounds", "counters",
+                                 "key_buf", "vrec", "status_out", "render_colors", "last_ids", "v_render_colors", "v_means",
+                                 "v_shN", "v_means2d", "v_means2d_abs"],
               "so_refine_params": ["grow_grad2d", "grow_scale3d", "prune_opa", "prune_scale3d", "prune_big", "revised_opacity",
                                    "seed", "step"]}
     src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
@@ -90,7 +93,7 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
     subprocess.run(["gcc", "-std=c11", "-o", str(exe), str(c)], check=True)
     out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
     mirrors = {"so_step_desc": _lib.StepDesc, "so_adam_group": _lib.AdamGroup, "so_attr_shadow": _lib.AttrShadow,
-               "so_model_set": _lib.ModelSet, "so_refine_params": _lib.RefineParams}
+               "so_model_set": _lib.ModelSet, "so_refine_params": _lib.RefineParams, "so_raster_desc": _lib.RasterDesc}
     for st, fs in fields.items():
         assert int(out[st]) == ctypes.sizeof(mirrors[st]), st
         for f in fs:

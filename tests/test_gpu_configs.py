@@ -3,7 +3,7 @@ c2 100k Gaussians @ 1920x1080 -- the benchmark workload -- through BOTH product 
 `rasterization` and the fused engine); c3's per-GPU share 500k @ 1080p multi-view; c4 1M @ 2560x1440 SH3 forward,
 loss, backward and one refinement; c5 2M Gaussians, mixed pinhole + fisheye batch from float16 attribute rows.
 Bars (north_star): forward <= 1e-4 mean per-pixel L1, gradients <= 1e-3 relative per tensor -- over ALL rows, nothing
-trimmed.  Three comparisons per case, every measured number written to profiles/parity_r02.json (tests/parity_log.py):
+trimmed.  Three comparisons per case, every measured number written to profiles/parity_r03.json (tests/parity_log.py):
 
   same-decisions f64
                  the float64 oracle evaluated on the device's two DISCRETE decisions: (a) the tile-sort keys built
@@ -19,7 +19,15 @@ trimmed.  Three comparisons per case, every measured number written to profiles/
                  depths round a few pairs differently again: kernels contract multiply-adds, torch does not).  <= 1e-4
                  for pinhole views (measured ~2e-6: the device computes what a float32 build of the oracle computes),
                  <= 1e-3 where the restatement's own float32 rounding is larger (fisheye / spherical Jacobians).
-  plain f64      the oracle's own keys and signs.  Recorded; <= 5e-3 (1e-3 holds on the c2 seeds: 8.8e-4).
+  plain f64      the oracle's own keys and its own signs: NOTHING of the device's enters (round 3: run and asserted for
+                 every case).  <= 1e-3 holds at c2 (8.8e-4 / 1.3e-4) and for the panorama batch; at c3 / c4 / c5 the
+                 measured worst tensor is 2.1e-3 (bar there: 3e-3) and the excess over the same-decisions number is made
+                 of the L1 sign ties alone: `explained_by` records them next to the number -- 35..39 pixel channels of
+                 6..12 M whose |render - target| is below the image difference of the two renders, and 0..25 pixels that
+                 the other depth order changes at all (the gradient of a loss against a random-noise target is an
+                 incoherent sum over pixels, so a few dozen flipped signs are 1e-3 of its norm).
+  Quaternions    every case spreads the log-scales (`_anisotropic_`), so ||g*_quats|| ~ 0.7 ||g*_scales|| and the quaternion
+                 gradient is held to the same bars WITHOUT the 0.01 ||g*_scales|| floor of `grad_errors` (both recorded).
 """
 import pytest
 import torch
@@ -104,6 +112,7 @@ def _three_way(section, splats, c2w, Ks, W, H, pixels, dev_depths, dev_radii, rc
                                         l1_signs=signs)
         out["f32_oracle"] = {"fwd_L1": (rc_h - rc_f).abs().mean().item(), "grads": grad_errors(g_h, g_f)}
     out["n_isects_oracle"] = int(sum(m["flatten_ids"].numel() for m in metas_s))
+    out["bars"] = {"same_decisions_f64": 1e-3, "plain_f64": plain_bar if with_plain else None}
     record(section, **out)
     assert out["same_decisions_f64"]["fwd_L1"] <= 1e-4 and out["same_decisions_f64"]["loss_abs_err"] < 1e-5, out["same_decisions_f64"]
     _assert_grads(out["same_decisions_f64"]["grads"], 1e-3, section + " same-decisions f64")
@@ -155,7 +164,7 @@ def test_c2_100k_1080p_both_paths(dev, regime):
     loss, _, _ = photometric_loss(renders, pixels, 0.2)
     loss.backward()
     _, _, metas, _ = _three_way(f"c2_{regime}_operator_path", r.splats, c2w, Ks, W, H, pixels, info["depths"].detach(),
-                                info["radii"], renders, _engine_grads(r), loss.item(),
+                                info["radii"], renders, _engine_grads(r), loss.item(), with_plain=False,   # (plain: the engine below, same inputs)
                                 extra={"N": N, "width": W, "height": H})
     I_o = metas[0]["flatten_ids"].numel()
     # rasterization() culls tiles exactly by default: its lists are the oracle's (gsplat's) minus pairs that reach no pixel
@@ -189,7 +198,7 @@ def test_c3_500k_1080p_two_views(dev):
     assert eng.stats()["overflow"] == 0
     _three_way("c3_500k_1080p_2views", r.splats, c2w, Ks, W, H, pixels, eng.ws["depths"], eng.ws["radii"],
                eng.ws["render_colors"], _engine_grads(r), eng.loss()[0].item(),
-               extra={"N": N, "width": W, "height": H, "views": C})
+               plain_bar=3e-3, extra={"N": N, "width": W, "height": H, "views": C})
 
 
 def test_c4_1m_1440p_forward_backward(dev):
@@ -210,7 +219,7 @@ def test_c4_1m_1440p_forward_backward(dev):
     assert st["overflow"] == 0
     _, _, metas, _ = _three_way("c4_1m_1440p", r.splats, c2w, Ks, W, H, pixels, eng.ws["depths"], eng.ws["radii"],
                                 eng.ws["render_colors"], _engine_grads(r), eng.loss()[0].item(),
-                                extra={"N": N, "width": W, "height": H, "n_isects_engine": st["n_isects"]})
+                                plain_bar=3e-3, extra={"N": N, "width": W, "height": H, "n_isects_engine": st["n_isects"]})
     assert metas[0]["flatten_ids"].numel() > 1_000_000
 
 
@@ -258,7 +267,7 @@ def test_c5_2m_mixed_batch_f16_attributes(dev):
     assert st["overflow"] == 0
     rounded = {k: (v.detach().half().float() if k in ("quats", "scales", "sh0", "shN") else v.detach()) for k, v in r.splats.items()}
     _three_way("c5_2m_1080p_pinhole_fisheye_f16", rounded, c2w, Ks, W, H, pixels, eng.ws["depths"], eng.ws["radii"],
-               eng.ws["render_colors"], _engine_grads(r), eng.loss()[0].item(), models=models, extra={"N": N, "width": W, "height": H, "views": 2, "attr_dtype": "f16",
+               eng.ws["render_colors"], _engine_grads(r), eng.loss()[0].item(), models=models, plain_bar=3e-3, extra={"N": N, "width": W, "height": H, "views": 2, "attr_dtype": "f16",
                                         "n_isects_engine": st["n_isects"], "visible": st["visible"]})
 
 
@@ -280,7 +289,7 @@ def test_c5_mixed_pinhole_fisheye_views(dev):
         eng.set_views(c2w, Ks, pixels)
         eng.fwd_bwd()
         _three_way(f"c5_200k_{model}_f32", r.splats, c2w, Ks, W, H, pixels, eng.ws["depths"], eng.ws["radii"],
-                   eng.ws["render_colors"], _engine_grads(r), eng.loss()[0].item(), models=[model], with_f32=True, with_plain=True)
+                   eng.ws["render_colors"], _engine_grads(r), eng.loss()[0].item(), models=[model], with_f32=True, plain_bar=(3e-3 if model == "fisheye" else 1e-3))
 
 
 def test_camera_model_lists_are_validated():

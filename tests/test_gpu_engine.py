@@ -101,7 +101,7 @@ def test_engine_training_steps_match_runner_and_graph_replay(dev):
     N, W, H = 5000, 128, 96
     outs = []
     for mode in ("runner", "engine", "graph"):
-        r, c2w, Ks, pixels = _make(dev, N, W, H, "mcmc")
+        r, c2w, Ks, pixels = _make(dev, N, W, H, "mcmc", fused=(mode != "runner"))     # "runner": the operator-level step
         r.step = 10
         if mode == "runner":
             for _ in range(5):
@@ -232,7 +232,10 @@ def test_engine_tile_cull_is_exact(dev, regime, C, aa, binned):
                                        torch.cat([sp["sh0"], sp["shN"]], 1), torch.linalg.inv(c2w), Ks, W, H, sh_degree=3,
                                        near_plane=0.01, far_plane=1e8, rasterize_mode="antialiased" if aa else "classic",
                                        packed=False, tile_cull=cull)
-        assert torch.equal(info["flatten_ids"].cpu(), ids)
+        # meta shows gsplat's lists whatever the switch; the kernels' own lists have the engine's length
+        assert int(info["n_isects_kernel"]) == st["n_isects"]
+        if not cull:
+            assert torch.equal(info["flatten_ids"].cpu(), ids)
     a, b = res[False], res[True]
     assert b["n"] < 0.9 * a["n"], (a["n"], b["n"])
     assert torch.equal(a["img"], b["img"]) and torch.equal(a["alpha"], b["alpha"])

@@ -31,14 +31,14 @@ def test_projection_fwd_bwd(dev, camera_model, use_covars):
                       torch.randn(C, N, 3, generator=g), torch.randn(C, N, generator=g))
 
     def run(fn, to, dt, keep=None):
-        m = means.to(to).requires_grad_()
-        V = viewmats.to(to).requires_grad_()
+        m = means.detach().clone().to(to).requires_grad_()
+        V = viewmats.detach().clone().to(to).requires_grad_()
         if use_covars:
             cov = O.quat_scale_to_covar(quats.double(), scales.double()).to(dt).to(to).requires_grad_()
             q = s = None
         else:
             cov = None
-            q, s = quats.to(to).requires_grad_(), scales.to(to).requires_grad_()
+            q, s = quats.detach().clone().to(to).requires_grad_(), scales.detach().clone().to(to).requires_grad_()
         radii, m2, dep, con, comp = fn(m, cov, q, s, V, Ks.to(to), W, H, eps2d=0.3, near_plane=0.01,
                                        far_plane=100.0, calc_compensations=True, camera_model=camera_model)
         k = torch.ones(C, N) if keep is None else keep

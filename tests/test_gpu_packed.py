@@ -43,7 +43,9 @@ def test_packed_rasterization_equals_dense(dev, C, kw):
     kw = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
     splats, viewmats, Ks, W, H = _scene(dev, C)
     N = splats["means"].shape[0]
-    rc_d, ra_d, p_d, m_d = _render(dev, splats, viewmats, Ks, W, H, packed=False, **kw)
+    # (fused=False: the dense call through the same operator composition as the packed one -- this test is about the two
+    # LAYOUTS; the one-call path of the dense common shape is held against it in tests/test_gpu_raster_op.py)
+    rc_d, ra_d, p_d, m_d = _render(dev, splats, viewmats, Ks, W, H, packed=False, fused=False, **kw)
     rc_p, ra_p, p_p, m_p = _render(dev, splats, viewmats, Ks, W, H, packed=True, **kw)
     # layout: the pairs with a positive radius, camera-major
     cam, gid = torch.nonzero(m_d["radii"] > 0, as_tuple=True)

@@ -129,19 +129,49 @@ def test_refine_edge_cases(dev):
     _compare(out, n_new, rep, P1, M1, V1, g1, c1, 700, 1.0, 9)
 
 
-def test_refine_capacity_overflow_is_flagged_and_stays_in_bounds(dev):
+def test_refine_that_does_not_fit_is_put_off_not_truncated(dev):
+    """A refined set larger than the capacity is not written at all (round 2 dropped the tail of the output order
+    -- children whose parents were already removed): the destination receives the source rows unchanged, the statistics
+    keep their sums, the report says overflow and how many rows are needed."""
     N, cap = 3000, 3072
     P, M, V, g2, cn = _random_model(N, seed=2)
     g2[:] = 1.0                                        # everything is "high gradient": the set wants to double
-    out, n_new, rep, _ = _device_refine(dev, P, M, V, g2, cn, cap, 700, 1.0, seed=4, prune_opa=0.0)
-    assert rep[4] == 1 and n_new == cap                # clamped; rows past the capacity were dropped
+    out, n_new, rep, (g2_after, cn_after) = _device_refine(dev, P, M, V, g2, cn, cap, 700, 1.0, seed=4, prune_opa=0.0)
     oP, _, _, orep = RO.refine_default(P, M, V, g2, cn, step=700, scene_scale=1.0, seed=4, prune_opa=0.0)
     assert orep["n_new"] > cap
-    # what fits is the head of gsplat's output order
-    nA = int((~RO.refine_masks_np(g2.astype(np.float64), cn.astype(np.float64), P["scales"].astype(np.float64),
-                                  P["opacities"].astype(np.float64), 700, 1.0, prune_opa=0.0)[1]).sum())
-    assert np.array_equal(out[0]["quats"][:nA], oP["quats"][:nA].astype(np.float32))
-    assert np.isfinite(out[0]["means"]).all()
+    assert rep[4] == 1 and n_new == N and rep[3] == N and rep[5] == N and rep[7] == orep["n_new"]
+    for k in ORDER:                                    # identity: parameters AND moments
+        assert np.array_equal(out[0][k], P[k]) and np.array_equal(out[1][k], M[k]) and np.array_equal(out[2][k], V[k]), k
+    assert np.array_equal(g2_after[:N].numpy(), g2) and np.array_equal(cn_after[:N].numpy(), cn)     # the statistics are still there
+    # with room, the same call refines (the caller's second attempt after enlarging)
+    out2, n2, rep2, _ = _device_refine(dev, P, M, V, g2, cn, 8192, 700, 1.0, seed=4, prune_opa=0.0)
+    assert rep2[4] == 0 and n2 == orep["n_new"]
+
+
+def test_engine_outgrows_its_capacity_without_losing_rows(dev):
+    """Headless single-GPU training never asks for the host's view of the model: the engine must notice by itself, one step
+    late and without synchronising, that a refinement did not fit, enlarge both model sets and run it again."""
+    import warnings
+    from splat_one_amd.scene import front_camera, pinhole_K
+    from splat_one_amd.strategy import DefaultStrategy
+    from splat_one_amd.trainer import Config, Runner
+    W, H, N = 160, 96, 3000
+    strat = DefaultStrategy(refine_start_iter=2, refine_every=4, reset_every=3000, grow_grad2d=0.0, prune_opa=0.0, verbose=False)
+    cfg = Config(init_num_pts=N, init_scale=0.3, init_opa=0.5, strategy=strat, max_gaussians=4096, sh_degree_interval=1)
+    r = Runner(0, 0, 1, cfg, scene_scale=1.0 / 1.1)
+    c2w, Ks = front_camera()[None].to(dev), pinhole_K(W, H)[None].to(dev)
+    px = torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(0)).to(dev)
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        for _ in range(7):                              # refinement at step 4 (every visible Gaussian grows: > 4096 rows)
+            r.train_step(c2w, Ks, px)
+    eng = r._engine
+    assert any("put off" in str(w.message) for w in wl)
+    assert eng.cap >= 8192
+    n = eng.sync_host()
+    vis = int((eng.ws["radii"][0, :N] > 0).sum())
+    assert n >= N + vis - 5 and n > 4096                # every duplicate / both children of every split are there
+    assert torch.isfinite(r.splats["means"]).all() and len(r.splats["means"]) == n
 
 
 def test_refine_equals_the_torch_level_strategy(dev):
@@ -264,19 +294,23 @@ def test_engine_opacity_reset_on_device(dev):
 
 
 def test_engine_capacity_grows_when_exceeded(dev):
+    """max_gaussians too small for the first refinement (step 10): it is put off on the device, the engine notices while it
+    stages step 11 -- nobody asked for the host's view -- enlarges both sets and refines again; no row is lost."""
     W, H, N = 128, 96, 3000
     r = _runner(dev, N, W, H, max_gaussians=3100)
     r.cfg.strategy.grow_grad2d = 0.0                        # everything that was seen is refined
     c2w, Ks = front_camera()[None].to(dev), pinhole_K(W, H)[None].to(dev)
     target = torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(1)).to(dev)
-    for _ in range(11):
+    with pytest.warns(RuntimeWarning, match="put off"):
+        for _ in range(13):
+            r.train_step(c2w, Ks, target)
+    n = len(r.splats["means"])
+    rep = r._engine.refine_report()
+    assert rep["overflow"] == 0 and n == rep["n_new"] and n > 3100 + 2000 and r._engine.cap >= 6200
+    assert n == rep["n_old"] + rep["n_dupli"] + rep["n_split"] - rep["n_prune"]      # gsplat's bookkeeping: nothing dropped
+    for _ in range(8):                                      # the next refinement (step 20) runs in the enlarged buffers
         r.train_step(c2w, Ks, target)
-    with pytest.warns(RuntimeWarning, match="capacity"):
-        n = len(r.splats["means"])
-    assert n == 3100 and r._engine.cap >= 6200
-    for _ in range(6):                                      # the next refinement (step 15) has room again
-        r.train_step(c2w, Ks, target)
-    assert len(r.splats["means"]) > 3100 and torch.isfinite(r.splats["means"]).all()
+    assert len(r.splats["means"]) >= n and torch.isfinite(r.splats["means"]).all()
 
 
 def test_c4_refinement_at_size(dev):

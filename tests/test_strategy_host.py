@@ -141,3 +141,31 @@ def test_duplicate_remove_roundtrip():
     remove(params, opts, state, rm)
     _check_consistent(params, opts, N)
     assert torch.equal(params["means"].detach(), before)
+
+
+def test_training_views_are_drawn_like_the_reference_dataloader():
+    """Runner.train's view order (Config.shuffle, default) == torch's RandomSampler -- what DataLoader(shuffle=True) at
+    /root/reference/utils/gsplat_utils/gsplat_trainer.py:539-546 iterates -- for the same global generator state, epoch
+    after epoch; ranks of a multi-GPU run get disjoint permuted strides that every rank can derive."""
+    from torch.utils.data import RandomSampler
+    from splat_one_amd.trainer import Config, Runner
+
+    class Stub:
+        pass
+
+    r = Stub()
+    r.views, r.world_size, r.cfg = list(range(37)), 1, Config()
+    torch.manual_seed(42)
+    mine = [Runner._epoch_orders(r)[0] for _ in range(3)]
+    torch.manual_seed(42)
+    sampler = RandomSampler(range(37))
+    assert mine == [list(sampler) for _ in range(3)]
+    assert all(sorted(e) == list(range(37)) for e in mine) and mine[0] != mine[1]
+    r.cfg = Config(shuffle=False)
+    assert Runner._epoch_orders(r) == [list(range(37))]
+    r.cfg, r.world_size = Config(), 4
+    torch.manual_seed(7)
+    per_rank = Runner._epoch_orders(r)
+    assert [sorted(o) for o in per_rank] == [list(range(j, 37, 4)) for j in range(4)]
+    torch.manual_seed(7)
+    assert Runner._epoch_orders(r) == per_rank                     # same generator state -> same lists on every rank
