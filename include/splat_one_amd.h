@@ -643,6 +643,38 @@ int so_compute_relocation(int64_t N, const float *opacities, const float *scales
                           const float *binoms, int n_max, float *new_opacities, float *new_scales, void *stream);
 int so_inject_noise(int64_t N, float *means, const float *log_scales, const float *quats,
                     const float *logit_opacities, const float *noise, float scaler, void *stream);
+/* MCMCStrategy on the DEVICE-RESIDENT model (so_step_desc.n_dev): gsplat `relocate` + `sample_add` of one refinement
+ * (gsplat_trainer.py:753-761 every refine_every steps of the `mcmc` preset, :975-983) in place on ONE capacity-sized model
+ * set, with the Gaussian count in device memory -- nothing is read back, nothing re-allocated, a captured step follows.
+ * A draw is a function of (seed, step, phase, sample number): Philox4x32-10 -> uniform -> inverse CDF over a float64
+ * device prefix sum of the opacities (gsplat: torch.multinomial from a host-seeded generator).
+ *   relocate: dead rows (sigmoid(logit) <= min_opacity, ascending) take the place of rows drawn from the ALIVE ones in
+ *     proportion to opacity; a source drawn r times gets (opacity, scale) = so_compute_relocation(., r + 1), clamped to
+ *     [min_opacity, 1 - eps], written back as logit / log, its moments (exp_avg, exp_avg_sq of all six tensors) zeroed; the
+ *     dead row becomes a copy of the updated source.
+ *   sample_add: n_add = min(cap_max, int(1.05 N)) - N rows drawn from ALL rows (after the relocation) the same way, the
+ *     sources updated the same way (their moments kept), the copies appended with zero moments; *n_dev += n_add
+ *     (capacity >= cap_max is the caller's contract; n_add is clamped to the capacity otherwise).
+ *   set: the model (tensor order of so_model_set); binoms[n_max,n_max] as so_compute_relocation takes them;
+ *   scratch: int32[so_mcmc_scratch_words(capacity)], 8-byte aligned, ZERO before the first call (left tidy by every call);
+ *   report_dev int32[8] (device or host-mapped): {relocated, added, 0, new N, 0, old N, refinements so far, 0}.
+ * so_inject_noise_dev: `inject_noise_to_position` of EVERY iteration with the normals drawn on the device from (seed,
+ *   step_counter[0], row) and the scale lr * noise_lr evaluated there too, lr = lr0 * lr_gamma^step_counter[0] (the means'
+ *   ExponentialLR value after this iteration's optimiser step: step_counter is so_adam_step_dev's) -- constant launch
+ *   arguments, hipGraph-capturable behind the optimiser.  n_dev nullable (N = capacity); skip_if_nonzero nullable. */
+typedef struct so_mcmc_params {
+  float min_opacity;
+  int32_t cap_max;
+  uint64_t seed;
+  int32_t step;
+  int32_t reserved; /* 0; bit 0 / bit 1 set: leave out the relocation / the addition (tests look at one phase at a time) */
+} so_mcmc_params;
+int64_t so_mcmc_scratch_words(int64_t capacity);
+int so_mcmc_refine(int64_t capacity, int K, const so_model_set *set, int32_t *n_dev, const float *binoms, int n_max,
+                   const so_mcmc_params *prm, int32_t *scratch, int32_t *report_dev, void *stream);
+int so_inject_noise_dev(int64_t capacity, const int32_t *n_dev, float *means, const float *log_scales, const float *quats,
+                        const float *logit_opacities, uint64_t seed, const int32_t *step_counter, float lr0, float lr_gamma,
+                        float noise_lr, const int32_t *skip_if_nonzero, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Photometric loss.  Replaces F.l1_loss + the CUDA-only `fused_ssim(..., padding="valid")` of

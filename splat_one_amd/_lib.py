@@ -80,6 +80,12 @@ class RefineParams(ctypes.Structure):
                 ("step", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
+class McmcParams(ctypes.Structure):
+    """Mirror of `so_mcmc_params` (device-side MCMCStrategy refinement)."""
+    _fields_ = [("min_opacity", c_f32), ("cap_max", ctypes.c_int32), ("seed", ctypes.c_uint64), ("step", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
 class AttrShadow(ctypes.Structure):
     """Mirror of `so_attr_shadow`: where so_adam_step_dev_shadow keeps the float16 attribute rows current."""
     _fields_ = [("arec", c_ptr), ("stride_bytes", ctypes.c_int32), ("offset_bytes", ctypes.c_int32 * SO_ADAM_MAX_GROUPS)]
@@ -143,6 +149,8 @@ _SIGS = {
                        ctypes.POINTER(c_f32), ctypes.c_double, ctypes.c_double, c_ptr, c_ptr, c_i64, c_int, c_ptr],
     "so_compute_relocation": [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr],
     "so_inject_noise": [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr],
+    "so_mcmc_refine": [c_i64, c_int, ctypes.POINTER(ModelSet), c_ptr, c_ptr, c_int, ctypes.POINTER(McmcParams), c_ptr, c_ptr, c_ptr],
+    "so_inject_noise_dev": [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_uint64, c_ptr, c_f32, c_f32, c_f32, c_ptr, c_ptr],
     "so_adam_step": [c_int, ctypes.POINTER(AdamGroup), ctypes.c_double, ctypes.c_double, ctypes.c_double, c_int, c_ptr],
 }
 
@@ -151,7 +159,7 @@ _lib: Optional[ctypes.CDLL] = None
 
 def exported_symbols():
     return ["so_abi_version", "so_last_error", "so_device_cu_count", "so_profile_num_stages",
-            "so_profile_stage_name", "so_profile_stage_begin_end", "so_attr_rec_stride", "so_refine_scratch_words", "so_projection_packed_blocks"] + list(_SIGS)
+            "so_profile_stage_name", "so_profile_stage_begin_end", "so_attr_rec_stride", "so_refine_scratch_words", "so_mcmc_scratch_words", "so_projection_packed_blocks"] + list(_SIGS)
 
 
 def load() -> ctypes.CDLL:
@@ -175,6 +183,8 @@ def load() -> ctypes.CDLL:
         lib.so_projection_packed_blocks.argtypes = [c_int, c_int]
         lib.so_refine_scratch_words.restype = c_i64
         lib.so_refine_scratch_words.argtypes = [c_i64]
+        lib.so_mcmc_scratch_words.restype = c_i64
+        lib.so_mcmc_scratch_words.argtypes = [c_i64]
         for name, argtypes in _SIGS.items():
             fn = getattr(lib, name)
             fn.argtypes = argtypes

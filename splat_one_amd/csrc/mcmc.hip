@@ -83,3 +83,347 @@ extern "C" int so_inject_noise(int64_t N, float *means, const float *log_scales,
                      quats, logit_opacities, noise, scaler);
   return so::check_launch("so_inject_noise");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// MCMCStrategy ON THE DEVICE (round 3).  gsplat's `relocate` + `sample_add` (the `mcmc` preset's refinement,
+// /root/reference/utils/gsplat_utils/gsplat_trainer.py:975-983, driven at :753-761 every refine_every steps) and the
+// per-iteration position noise on the capacity-sized, device-resident model of the fused engine (so_step_desc.n_dev):
+// nothing is read back, no tensor is re-allocated, a captured step follows the new N by itself.
+//
+// gsplat samples with torch.multinomial from a host-seeded generator and reads two counts back per refinement.  Here a
+// draw is a FUNCTION of (seed, step, phase, sample number) -- Philox4x32-10, so_rng.hpp -- turned into a row by inverse
+// CDF over a device prefix sum (float64) of the opacities; every replica of a data-parallel run draws the same rows.
+//   relocate    dead = sigmoid(logit) <= min_opacity; the j-th dead row (ascending) is teleported onto sample j, drawn
+//               from the alive rows in proportion to their opacity; a source sampled r times gets
+//               (opacity, scale) = compute_relocation(., r + 1), clamped and written back, its moments zeroed; the dead
+//               row becomes a copy of the UPDATED source (its own moments untouched -- gsplat's `relocate`)
+//   sample_add  n_add = min(cap_max, int(1.05 N)) - N samples from ALL rows (after relocation) by opacity; sources updated
+//               the same way (moments kept), copies appended as rows N .. N + n_add - 1 with zero moments; N += n_add
+// Launch sequence per phase: weights + block sums | scan of the block sums, sample count | cdf + dead list | draw + count |
+// new values | apply | tidy.  All grids come from the capacity; the counts live in device memory.
+// ---------------------------------------------------------------------------------------------------------------------
+#include "so_rng.hpp"
+
+namespace so {
+
+constexpr uint32_t kSampleStream = 0x53414D50u;   // "SAMP"
+constexpr uint32_t kNoiseStream = 0x4E4F4953u;    // "NOIS"
+constexpr int kMcBlock = 256, kMcItems = 4, kMcChunk = kMcBlock * kMcItems;
+
+struct McmcSet {
+  float *p[6], *m[6], *v[6];
+};
+
+__device__ __forceinline__ float mc_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+// the relocation formula of k_compute_relocation for one source (float32, same operation order)
+__device__ __forceinline__ void relocation_one(float op, int n, const float *__restrict__ binoms, int n_max, float &new_op, float &coeff) {
+  n = n < 1 ? 1 : (n > n_max ? n_max : n);
+  new_op = 1.f - powf(1.f - op, 1.f / (float)n);
+  float denom = 0.f;
+  for (int a = 1; a <= n; ++a) {
+    float pw = new_op;
+    for (int k = 0; k <= a - 1; ++k) {
+      const float term = ((k & 1) ? -1.f : 1.f) / sqrtf((float)(k + 1)) * pw;
+      denom += binoms[(a - 1) * n_max + k] * term;
+      pw *= new_op;
+    }
+  }
+  coeff = op / denom;
+}
+
+// inclusive scan of (double, int) over a 256-thread workgroup; returns this thread's inclusive values, totals via refs
+__device__ __forceinline__ void block_scan_di(double &w, int &d, double &tot_w, int &tot_d) {
+  __shared__ double s_w[kMcBlock / 64];
+  __shared__ int s_d[kMcBlock / 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double uw = __shfl_up(w, o, 64);
+    const int ud = __shfl_up(d, o, 64);
+    if (lane >= o) { w += uw; d += ud; }
+  }
+  if (lane == 63) { s_w[wv] = w; s_d[wv] = d; }
+  __syncthreads();
+  double bw = 0.0;
+  int bd = 0;
+  tot_w = 0.0; tot_d = 0;
+#pragma unroll
+  for (int k = 0; k < kMcBlock / 64; ++k) {
+    if (k < wv) { bw += s_w[k]; bd += s_d[k]; }
+    tot_w += s_w[k]; tot_d += s_d[k];
+  }
+  w += bw; d += bd;
+  __syncthreads();
+}
+
+// phase 0 (relocate): weight = opacity of ALIVE rows, dead rows counted;  phase 1 (add): weight = opacity of every row
+__global__ void __launch_bounds__(kMcBlock)
+k_mcmc_partial(int64_t cap, const int32_t *__restrict__ n_dev, const float *__restrict__ logit_op, float min_opacity, int phase,
+               float *__restrict__ w_out, double *__restrict__ bsum_w, int32_t *__restrict__ bsum_d) {
+  const int64_t N = min((int64_t)*n_dev, cap);
+  double w = 0.0;
+  int d = 0;
+#pragma unroll
+  for (int it = 0; it < kMcItems; ++it) {
+    const int64_t i = (int64_t)blockIdx.x * kMcChunk + (int64_t)threadIdx.x * kMcItems + it;
+    if (i < N) {
+      const float op = mc_sigmoid(logit_op[i]);
+      const bool dead = phase == 0 && op <= min_opacity;
+      w_out[i] = dead ? 0.f : op;
+      w += dead ? 0.0 : (double)op;
+      d += dead ? 1 : 0;
+    }
+  }
+  double tw; int td;
+  block_scan_di(w, d, tw, td);
+  if (threadIdx.x == 0) { bsum_w[blockIdx.x] = tw; bsum_d[blockIdx.x] = td; }
+}
+
+// one workgroup: exclusive scan of the block sums; totals[0..1] = W (double), tot[2] = n_dead, tot[3] = n_samples, tot[4] = N
+__global__ void __launch_bounds__(kMcBlock)
+k_mcmc_scan(int nblk, int64_t cap, const int32_t *__restrict__ n_dev, const double *__restrict__ bsum_w, const int32_t *__restrict__ bsum_d,
+            double *__restrict__ boff_w, int32_t *__restrict__ boff_d, int32_t *__restrict__ tot, int phase, int cap_max) {
+  double run_w = 0.0;
+  int run_d = 0;
+  for (int b0 = 0; b0 < nblk; b0 += kMcBlock) {
+    const int b = b0 + threadIdx.x;
+    double w = b < nblk ? bsum_w[b] : 0.0;
+    int d = b < nblk ? bsum_d[b] : 0;
+    const double w_in = w;
+    const int d_in = d;
+    double tw; int td;
+    block_scan_di(w, d, tw, td);
+    if (b < nblk) { boff_w[b] = run_w + (w - w_in); boff_d[b] = run_d + (d - d_in); }
+    run_w += tw; run_d += td;
+  }
+  if (threadIdx.x == 0) {
+    const int64_t N = min((int64_t)*n_dev, cap);
+    *reinterpret_cast<double *>(tot) = run_w;
+    tot[2] = run_d;
+    int64_t ns;
+    if (phase == 0) ns = (run_w > 0.0) ? run_d : 0;                      // nothing alive: nothing to relocate onto
+    else {
+      int64_t target = (int64_t)(1.05 * (double)N);                      // Python: min(cap_max, int(1.05 * N))
+      if (target > cap_max) target = cap_max;
+      ns = target - N;
+      if (ns < 0) ns = 0;
+      if (N + ns > cap) ns = cap - N;                                    // (the engine sizes capacity >= cap_max)
+      if (!(run_w > 0.0)) ns = 0;
+    }
+    tot[3] = (int32_t)ns;
+    tot[4] = (int32_t)N;
+  }
+}
+
+__global__ void __launch_bounds__(kMcBlock)
+k_mcmc_cdf(int64_t cap, const int32_t *__restrict__ n_dev, const float *__restrict__ w_in, const double *__restrict__ boff_w,
+           const int32_t *__restrict__ boff_d, int phase, double *__restrict__ cdf, int32_t *__restrict__ dead_list) {
+  const int64_t N = min((int64_t)*n_dev, cap);
+  float wv[kMcItems];
+  double w = 0.0;
+  int d = 0;
+  const int64_t i0 = (int64_t)blockIdx.x * kMcChunk + (int64_t)threadIdx.x * kMcItems;
+#pragma unroll
+  for (int it = 0; it < kMcItems; ++it) {
+    wv[it] = (i0 + it < N) ? w_in[i0 + it] : 0.f;
+    w += (double)wv[it];
+    d += (phase == 0 && i0 + it < N && wv[it] == 0.f) ? 1 : 0;           // (phase 0 wrote 0 for dead rows only: opacity > 0)
+  }
+  const double w_own = w;
+  const int d_own = d;
+  double tw; int td;
+  block_scan_di(w, d, tw, td);
+  double run = boff_w[blockIdx.x] + (w - w_own);
+  int rd = boff_d[blockIdx.x] + (d - d_own);
+#pragma unroll
+  for (int it = 0; it < kMcItems; ++it) {
+    if (i0 + it < N) {
+      run += (double)wv[it];
+      cdf[i0 + it] = run;
+      if (phase == 0 && wv[it] == 0.f) dead_list[rd++] = (int32_t)(i0 + it);
+    }
+  }
+}
+
+// sample j -> row: smallest i with cdf[i] > u W;  counts how often every row was drawn
+__global__ void __launch_bounds__(256)
+k_mcmc_draw(const int32_t *__restrict__ tot, const double *__restrict__ cdf, uint64_t seed, uint32_t step, int phase,
+            int32_t *__restrict__ src, int32_t *__restrict__ cnt) {
+  const int ns = tot[3], N = tot[4];
+  const double W = *reinterpret_cast<const double *>(tot);
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < ns; j += gridDim.x * blockDim.x) {
+    const Philox4 r = philox4x32_10((uint32_t)j, (uint32_t)phase, step, kSampleStream, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const double u = ((double)r.x[0] * 4294967296.0 + (double)r.x[1]) * (1.0 / 18446744073709551616.0);   // [0, 1)
+    const double t = u * W;
+    int lo = 0, hi = N - 1;                          // invariant: the answer is in [lo, hi]
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cdf[mid] > t) hi = mid; else lo = mid + 1;
+    }
+    // t may round up to W itself: step back to the last row that carries weight
+    while (lo > 0 && !(cdf[lo] > cdf[lo - 1])) --lo;
+    src[j] = lo;
+    atomicAdd(cnt + lo, 1);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_mcmc_newvals(const int32_t *__restrict__ tot, const int32_t *__restrict__ src, const int32_t *__restrict__ cnt,
+               const float *__restrict__ logit_op, const float *__restrict__ log_scales, const float *__restrict__ binoms, int n_max,
+               float min_opacity, float *__restrict__ new_logit, float *__restrict__ new_ls) {
+  const int ns = tot[3];
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < ns; j += gridDim.x * blockDim.x) {
+    const int s = src[j];
+    const float op = mc_sigmoid(logit_op[s]);
+    float nop, coeff;
+    relocation_one(op, cnt[s] + 1, binoms, n_max, nop, coeff);
+    nop = fminf(fmaxf(nop, min_opacity), 1.f - 1.1920929e-07f);          // clamp(min_opacity, 1 - eps)
+    new_logit[j] = logf(nop / (1.f - nop));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) new_ls[3 * j + c] = logf(coeff * expf(log_scales[3 * s + c]));
+  }
+}
+
+// grid.y = tensor g; one lane per (sample, element of the row)
+__global__ void __launch_bounds__(256)
+k_mcmc_apply(int K, const McmcSet set, const int32_t *__restrict__ tot, const int32_t *__restrict__ src,
+             const int32_t *__restrict__ dead_list, const float *__restrict__ new_logit, const float *__restrict__ new_ls, int phase) {
+  const int g = blockIdx.y;
+  const int L = (g == 0 || g == 1 || g == 4) ? 3 : (g == 2 ? 4 : (g == 3 ? 1 : 3 * (K - 1)));
+  if (L == 0) return;
+  const int64_t ns = tot[3], N = tot[4];
+  float *__restrict__ P = set.p[g], *__restrict__ M = set.m[g], *__restrict__ V = set.v[g];
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < ns * L; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = e / L;
+    const int c = (int)(e - j * L);
+    const int64_t s = src[j];
+    const int64_t dst = phase == 0 ? (int64_t)dead_list[j] : N + j;
+    float val;
+    if (g == 1) val = new_ls[3 * j + c];
+    else if (g == 3) val = new_logit[j];
+    else val = P[s * L + c];
+    if (g == 1 || g == 3) P[s * L + c] = val;        // (every sample of one source writes the same value)
+    P[dst * L + c] = val;
+    if (phase == 0) { M[s * L + c] = 0.f; V[s * L + c] = 0.f; }          // relocate: the SOURCE's moments start over
+    else { M[dst * L + c] = 0.f; V[dst * L + c] = 0.f; }                 // sample_add: the new rows' moments are zero
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_mcmc_tidy(const int32_t *__restrict__ tot, const int32_t *__restrict__ src, int32_t *__restrict__ cnt, int32_t *__restrict__ n_dev,
+            int32_t *__restrict__ report, int phase) {
+  const int ns = tot[3];
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < ns; j += gridDim.x * blockDim.x) cnt[src[j]] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (phase == 0) { report[0] = ns; report[5] = tot[4]; }
+    else {
+      report[1] = ns;
+      report[3] = tot[4] + ns;
+      *n_dev = tot[4] + ns;
+      __threadfence_system();
+      report[6] += 1;      // written last: refinements done on this model (a host that maps the report reads it unsynchronised)
+    }
+  }
+}
+
+// means += Sigma (z * sigmoid_100((1 - opacity) - 0.995) * lr * noise_lr), z ~ N(0, I) from (seed, optimiser step, row); the
+// learning rate is the means' ExponentialLR value AFTER this iteration's optimiser step: lr0 * gamma^step_counter[0]
+__global__ void __launch_bounds__(256)
+k_inject_noise_dev(int64_t cap, const int32_t *__restrict__ n_dev, float *__restrict__ means, const float *__restrict__ log_scales,
+                   const float *__restrict__ quats, const float *__restrict__ logit_opac, uint64_t seed,
+                   const int32_t *__restrict__ step_counter, float lr0, float lr_gamma, float noise_lr, const int32_t *__restrict__ skip) {
+  if (skip && *skip != 0) return;    // a void iteration (binning overflow) changes nothing
+  const int64_t N = n_dev ? min((int64_t)*n_dev, cap) : cap;
+  const int t = step_counter[0];
+  const float scaler = lr0 * powf(lr_gamma, (float)t) * noise_lr;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const float op = mc_sigmoid(logit_opac[i]);
+    const float gate = 1.f / (1.f + expf(-100.f * ((1.f - op) - 0.995f))) * scaler;
+    const float4 qq = *reinterpret_cast<const float4 *>(quats + 4 * i);
+    const float q[4] = {qq.x, qq.y, qq.z, qq.w};
+    const float s[3] = {expf(log_scales[3 * i]), expf(log_scales[3 * i + 1]), expf(log_scales[3 * i + 2])};
+    float cov[9], Mm[9], Rq[9], qn[4], inv_norm;
+    quat_scale_to_covar<float>(q, s, cov, Mm, Rq, qn, inv_norm);
+    const Philox4 r = philox4x32_10((uint32_t)i, 0u, (uint32_t)t, kNoiseStream, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float two_pi = 6.283185307179586f;
+    const float r0 = sqrtf(-2.f * logf(u24(r.x[0]))), r1 = sqrtf(-2.f * logf(u24(r.x[2])));
+    const float n0 = r0 * cosf(two_pi * u24(r.x[1])) * gate, n1 = r0 * sinf(two_pi * u24(r.x[1])) * gate,
+                n2 = r1 * cosf(two_pi * u24(r.x[3])) * gate;
+    means[3 * i] += cov[0] * n0 + cov[1] * n1 + cov[2] * n2;
+    means[3 * i + 1] += cov[3] * n0 + cov[4] * n1 + cov[5] * n2;
+    means[3 * i + 2] += cov[6] * n0 + cov[7] * n1 + cov[8] * n2;
+  }
+}
+
+static inline int mc_nblk(int64_t cap) { return (int)ceil_div(cap, (int64_t)kMcChunk); }
+
+}  // namespace so
+
+// scratch layout (int32 words): w[cap] | cdf[cap] f64 | dead_list[cap] | src[cap] | cnt[cap] (zero on entry, zero on exit) |
+// new_logit[cap] | new_ls[3 cap] | bsum_w[nblk] f64 | boff_w[nblk] f64 | bsum_d[nblk] | boff_d[nblk] | tot[16]
+extern "C" int64_t so_mcmc_scratch_words(int64_t capacity) {
+  if (capacity <= 0) return 0;
+  const int64_t nblk = so::mc_nblk(capacity);
+  return 10 * capacity + 6 * nblk + 32;
+}
+
+extern "C" int so_mcmc_refine(int64_t capacity, int K, const so_model_set *set, int32_t *n_dev, const float *binoms, int n_max,
+                              const so_mcmc_params *prm, int32_t *scratch, int32_t *report_dev, void *stream) {
+  SO_REQUIRE(capacity > 0 && capacity < ((int64_t)1 << 30) && K >= 1 && n_max >= 1, "so_mcmc_refine: capacity %lld / K %d / n_max %d out of range",
+             (long long)capacity, K, n_max);
+  SO_REQUIRE(set && n_dev && binoms && prm && scratch && report_dev, "so_mcmc_refine: null pointer");
+  SO_REQUIRE((((uintptr_t)scratch) & 7) == 0, "so_mcmc_refine: scratch must be 8-byte aligned");
+  so::McmcSet S{};
+  for (int g = 0; g < 6; ++g) {
+    const bool empty = g == 5 && K == 1;
+    SO_REQUIRE(empty || (set->p[g] && set->m[g] && set->v[g]), "so_mcmc_refine: null tensor in group %d", g);
+    S.p[g] = set->p[g]; S.m[g] = set->m[g]; S.v[g] = set->v[g];
+  }
+  SO_REQUIRE((((uintptr_t)set->p[2]) & 15) == 0, "so_mcmc_refine: quaternions must be 16-byte aligned");
+  const int nblk = so::mc_nblk(capacity);
+  const int64_t cap2 = capacity + (capacity & 1);          // keeps the float64 regions 8-byte aligned
+  float *w = reinterpret_cast<float *>(scratch);
+  double *cdf = reinterpret_cast<double *>(scratch + cap2);
+  int32_t *dead_list = scratch + cap2 + 2 * capacity;
+  int32_t *src = dead_list + capacity;
+  int32_t *cnt = src + capacity;
+  float *new_logit = reinterpret_cast<float *>(cnt + capacity);
+  float *new_ls = new_logit + capacity;
+  int32_t *after = reinterpret_cast<int32_t *>(new_ls + 3 * capacity);
+  after += ((uintptr_t)after & 7) ? 1 : 0;
+  double *bsum_w = reinterpret_cast<double *>(after);
+  double *boff_w = bsum_w + nblk;
+  int32_t *bsum_d = reinterpret_cast<int32_t *>(boff_w + nblk);
+  int32_t *boff_d = bsum_d + nblk;
+  int32_t *tot = boff_d + nblk + ((nblk & 1) ? 1 : 0);
+  SO_REQUIRE(tot + 16 <= scratch + so_mcmc_scratch_words(capacity), "so_mcmc_refine: internal scratch layout error");
+  hipStream_t st = so::as_stream(stream);
+  const int gs = so::mc_grid(capacity);
+  for (int phase = 0; phase < 2; ++phase) {
+    if (prm->reserved & (1 << phase)) continue;      // (tests run one phase at a time and read the scratch in between)
+    hipLaunchKernelGGL(so::k_mcmc_partial, dim3(nblk), dim3(so::kMcBlock), 0, st, capacity, n_dev, S.p[3], prm->min_opacity, phase, w,
+                       bsum_w, bsum_d);
+    hipLaunchKernelGGL(so::k_mcmc_scan, dim3(1), dim3(so::kMcBlock), 0, st, nblk, capacity, n_dev, bsum_w, bsum_d, boff_w, boff_d, tot,
+                       phase, prm->cap_max);
+    hipLaunchKernelGGL(so::k_mcmc_cdf, dim3(nblk), dim3(so::kMcBlock), 0, st, capacity, n_dev, w, boff_w, boff_d, phase, cdf, dead_list);
+    hipLaunchKernelGGL(so::k_mcmc_draw, dim3(gs), dim3(256), 0, st, tot, cdf, prm->seed, (uint32_t)prm->step, phase, src, cnt);
+    hipLaunchKernelGGL(so::k_mcmc_newvals, dim3(gs), dim3(256), 0, st, tot, src, cnt, S.p[3], S.p[1], binoms, n_max, prm->min_opacity,
+                       new_logit, new_ls);
+    hipLaunchKernelGGL(so::k_mcmc_apply, dim3(gs, 6), dim3(256), 0, st, K, S, tot, src, dead_list, new_logit, new_ls, phase);
+    hipLaunchKernelGGL(so::k_mcmc_tidy, dim3(gs), dim3(256), 0, st, tot, src, cnt, n_dev, report_dev, phase);
+  }
+  return so::check_launch("so_mcmc_refine");
+}
+
+extern "C" int so_inject_noise_dev(int64_t capacity, const int32_t *n_dev, float *means, const float *log_scales, const float *quats,
+                                   const float *logit_opacities, uint64_t seed, const int32_t *step_counter, float lr0, float lr_gamma,
+                                   float noise_lr, const int32_t *skip_if_nonzero, void *stream) {
+  SO_REQUIRE(capacity >= 0, "so_inject_noise_dev: bad capacity");
+  if (capacity == 0) return SO_OK;
+  SO_REQUIRE(means && log_scales && quats && logit_opacities && step_counter, "so_inject_noise_dev: null pointer");
+  SO_REQUIRE((((uintptr_t)quats) & 15) == 0, "so_inject_noise_dev: quaternions must be 16-byte aligned");
+  hipLaunchKernelGGL(so::k_inject_noise_dev, dim3(so::mc_grid(capacity)), dim3(256), 0, so::as_stream(stream), capacity, n_dev, means,
+                     log_scales, quats, logit_opacities, seed, step_counter, lr0, lr_gamma, noise_lr, skip_if_nonzero);
+  return so::check_launch("so_inject_noise_dev");
+}

@@ -46,7 +46,7 @@ class FusedEngine:
                  attr_dtype: str = "f32", tile_cull: bool = True, binned: bool = True,
                  bin_capacity: Optional[int] = None, fuse_adam: bool = True, device_refine: bool = False,
                  capacity: Optional[int] = None, lean_views: bool = True, flat_multiple: int = 0,
-                 loss_kernels: int = 1, row_multiple: int = 1):
+                 loss_kernels: int = 1, row_multiple: int = 1, model_sets: int = 2, mcmc_noise: Optional[dict] = None):
         """attr_dtype="f16": quaternions, log-scales and SH coefficients are READ from float16 attribute rows
         (include/splat_one_amd.h, so_attr_pack_f16: 112 instead of 224 bytes per Gaussian at SH degree 3); the
         float32 parameters stay the masters Adam updates, and the same Adam launch refreshes the halves."""
@@ -62,6 +62,11 @@ class FusedEngine:
         # torch.cat, no workspace rebuild, no graph re-capture (one graph per set).  The torch-side handles
         # (ParameterDict, optimiser state, statistics) are re-pointed lazily by `sync_host()`.
         self.device_refine = bool(device_refine)
+        # model_sets: DefaultStrategy's refinement compacts one set into the other (2); MCMCStrategy edits ONE set in place
+        self.model_sets = 2 if int(model_sets) != 1 else 1
+        # mcmc_noise = {"noise_lr", "seed"}: `inject_noise()` draws and applies the position noise of MCMCStrategy on the
+        # device (so_inject_noise_dev) -- the trainer calls it after the step (and after a refinement, as gsplat orders them)
+        self.mcmc_noise = dict(mcmc_noise) if mcmc_noise else None
         # flat_multiple > 0 (replicated data parallelism, distributed.ShardedFlatAdam): parameters and both moments live
         # in FLAT buffers with the segment layout of the flat gradient, padded to a multiple of `flat_multiple` floats,
         # so that reduce-scatter / sharded Adam / all-gather work on contiguous ranges of all four
@@ -132,7 +137,7 @@ class FusedEngine:
         old = getattr(self, "sets", None)
         self._adam_args_host()                   # lazily-created optimiser state must exist before it is moved
         sets = []
-        for _ in range(2):
+        for _ in range(self.model_sets):
             sets.append({kind: {k: torch.zeros((cap,) + tuple(self.splats[k].shape[1:]), dtype=torch.float32, device=dev)
                                 for k in PARAM_ORDER} for kind in ("p", "m", "v")})
         with torch.no_grad():
@@ -155,8 +160,11 @@ class FusedEngine:
         # at them one step late without synchronising (element 6 says which refinement they describe)
         self._report = torch.zeros(8, dtype=torch.int32).pin_memory()
         self._report_handled = 0
-        words = int(_lib.load().so_refine_scratch_words(cap))
-        self._refine_scratch = torch.empty(words, dtype=torch.int32, device=dev)
+        if self.model_sets == 2:
+            words = int(_lib.load().so_refine_scratch_words(cap))
+            self._refine_scratch = torch.empty(words, dtype=torch.int32, device=dev)
+        else:            # MCMCStrategy: zero before the first call, left tidy by every call (include/splat_one_amd.h)
+            self._mcmc_scratch = torch.zeros(int(_lib.load().so_mcmc_scratch_words(cap)), dtype=torch.int32, device=dev)
         self._ms = []
         for sset in sets:
             ms = _lib.ModelSet()
@@ -251,6 +259,46 @@ class FusedEngine:
             self.refinements += 1
             self._host_stale = True
             self.refresh_attrs()         # (float16 rows: rebuilt from the compacted masters)
+
+    def mcmc_refine(self, strategy, step: int, binoms: Tensor, seed: int = 0) -> None:
+        """One MCMCStrategy refinement (gsplat `relocate` + `sample_add`) in place on the device-resident model: dead
+        Gaussians take the place of samples drawn by opacity, 5 % more are added up to cap_max, N changes in device memory.
+        Nothing is read back; `refine_report()` gives the counts."""
+        assert self.device_refine and self.model_sets == 1, "mcmc_refine needs FusedEngine(device_refine=True, model_sets=1)"
+        with self._lock:
+            prm = _lib.McmcParams(float(strategy.min_opacity), int(min(strategy.cap_max, self.cap)), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                  int(step), 0)
+            b = binoms.to(device=self.device, dtype=torch.float32).contiguous()
+            self._binoms = b
+            _lib.call("so_mcmc_refine", self.cap, self.K, ctypes.byref(self._ms[self.active]),
+                      _lib.ptr(self._n_dev[self.active:self.active + 1]), _lib.ptr(b), int(b.shape[0]), ctypes.byref(prm),
+                      _lib.ptr(self._mcmc_scratch), self._report.data_ptr(), _lib.stream())
+            self.refinements += 1
+            self._report_handled = self.refinements        # (no capacity overflow to look for: capacity >= cap_max)
+            self._host_stale = True
+            self.refresh_attrs()
+
+    def inject_noise(self) -> None:
+        """MCMCStrategy's position noise of this iteration (gsplat `inject_noise_to_position`, scaler = lr * noise_lr with
+        the means' learning rate AFTER this iteration's scheduler step): normals and learning rate on the device, constant
+        launch arguments, skipped by itself when the iteration was void."""
+        nz = self.mcmc_noise
+        if nz is None:
+            return
+        if "lr0" not in nz:      # base of the means' ExponentialLR: the optimiser's current lr un-decayed to step 0
+            nz["lr0"] = self.optimizers["means"].param_groups[0]["lr"] / (self.lr_gamma_means ** self.steps_done)
+        p = _lib.ptr
+        ovf = self.ws["counters"][2 * self.M + 2:]
+        if self.device_refine:
+            a = self.sets[self.active]["p"]
+            _lib.call("so_inject_noise_dev", self.cap, p(self._n_dev[self.active:self.active + 1]), p(a["means"]), p(a["scales"]),
+                      p(a["quats"]), p(a["opacities"]), int(nz.get("seed", 0)) & 0xFFFFFFFFFFFFFFFF, p(self._step_dev), float(nz["lr0"]),
+                      float(self.lr_gamma_means), float(nz["noise_lr"]), p(ovf), _lib.stream())
+        else:
+            sp = self.splats
+            _lib.call("so_inject_noise_dev", self.N, 0, p(sp["means"].data), p(sp["scales"].data), p(sp["quats"].data),
+                      p(sp["opacities"].data), int(nz.get("seed", 0)) & 0xFFFFFFFFFFFFFFFF, p(self._step_dev), float(nz["lr0"]),
+                      float(self.lr_gamma_means), float(nz["noise_lr"]), p(ovf), _lib.stream())
 
     def reset_opacity(self, value: float) -> None:
         """gsplat `reset_opa`: opacity logits clamped to logit(value), their Adam moments zeroed -- in place, on the device."""
@@ -852,6 +900,8 @@ class FusedEngine:
         if self.device_refine:
             self.sync_host()
             self._build_model_sets(max(self.cap, 2 * self.splats["means"].shape[0]))
+        if self.mcmc_noise is not None:
+            self.mcmc_noise.pop("lr0", None)
         self._build_workspace()
 
     def bind_strategy_state(self, state: Optional[dict]) -> None:

@@ -632,7 +632,12 @@ class Runner:
             # DefaultStrategy on the device (single GPU, and replicated data parallelism: every rank runs the same
             # compaction on the all-reduced statistics and the gathered moments; the optimiser step is sharded by ROW
             # pieces of the capacity-sized tensors -- a flat piece layout would move with N)
-            dev_refine = cfg.device_refine and isinstance(s, DefaultStrategy) and s.refine_scale2d_stop_iter == 0
+            mcmc = isinstance(s, MCMCStrategy)
+            dev_refine = cfg.device_refine and (mcmc or (isinstance(s, DefaultStrategy) and s.refine_scale2d_stop_iter == 0))
+            capacity = cfg.max_gaussians
+            if mcmc and dev_refine:      # MCMCStrategy grows in place up to cap_max: the ONE model set holds that from the start
+                n0 = len(self._splats["means"])      # (708 B per row at SH degree 3: the default cap_max of 1M is 0.7 GB)
+                capacity = max(capacity or max(2 * n0, 1 << 20), int(s.cap_max), n0)
             eng = self._engine = FusedEngine(
                 self.splats, self.optimizers, W, H, B, sh_degree=0, camera_model=cfg.camera_model,
                 near_plane=cfg.near_plane, far_plane=cfg.far_plane, antialiased=cfg.antialiased,
@@ -643,7 +648,9 @@ class Runner:
                 isect_capacity=cfg.isect_capacity, use_graph=True,
                 attr_dtype=cfg.attr_dtype, tile_cull=cfg.tile_cull,
                 binned=cfg.binned, bin_capacity=cfg.bin_capacity,
-                fuse_adam=cfg.fuse_adam, device_refine=dev_refine, capacity=cfg.max_gaussians, loss_kernels=cfg.loss_kernels,
+                fuse_adam=cfg.fuse_adam, device_refine=dev_refine, capacity=capacity, loss_kernels=cfg.loss_kernels,
+                model_sets=(1 if mcmc else 2),
+                mcmc_noise=({"noise_lr": s.noise_lr, "seed": cfg.refine_seed} if mcmc else None),
                 row_multiple=(self.world_size * sdist.RowShardedAdam.ALIGN_ROWS if self.world_size > 1 else 1),
                 flat_multiple=(self._dp_chunks * self.world_size * sdist.ShardedFlatAdam.ALIGN
                                if self.world_size > 1 and not dev_refine else 0))
@@ -688,14 +695,41 @@ class Runner:
             eng.refresh_attrs()              # float16 attribute rows (if any) follow the gathered masters
             eng._advance_host_counters()
         if isinstance(s, MCMCStrategy):
-            # lr = the means learning rate after this step's scheduler.step() (gsplat_trainer.py:753-761)
-            n_before = len(self.splats["means"])
-            n_rel, n_new = s.step_post_backward(params=self.splats, optimizers=self.optimizers,
-                                                state=self.strategy_state, step=step, info={},
-                                                lr=self.optimizers["means"].param_groups[0]["lr"],
-                                                generator=self._split_gen)
-            if n_rel or n_new:
-                eng.rebuild()
+            refine_now = step < s.refine_stop_iter and step > s.refine_start_iter and step % s.refine_every == 0
+            if eng.device_refine:
+                # MCMCStrategy on the device (gsplat_trainer.py:753-761): relocation + addition in place on the capacity-sized
+                # model, then this iteration's position noise -- no host read, no re-capture.  Replicas (world_size > 1)
+                # draw the same counter-based samples; the row-sharded moments are gathered first because the row pieces
+                # move with N, and N (which sizes the next steps' collectives) is read back once and compared.
+                if refine_now:
+                    if self.world_size > 1 and self._radam is not None:
+                        act = eng.sets[eng.active]
+                        self._radam.gather([act[q][k] for q in ("m", "v") for k in act[q]], eng.n_host)
+                    eng.mcmc_refine(s, step, self._strategy_state["binoms"], seed=cfg.refine_seed)
+                    if s.verbose:
+                        rep = eng.refine_report()
+                        print(f"Step {step}: Relocated {rep['n_dupli']} GSs. Added {rep['n_split']} GSs. Now having {rep['n_new']} GSs.")
+                    if self.world_size > 1:
+                        n_new = eng.sync_host()
+                        eng.reprobe_capacity()
+                        chk = torch.tensor([n_new, -n_new], dtype=torch.int32, device=eng.device)
+                        sdist.all_reduce_max_(chk)
+                        if int(chk[0]) != n_new or int(chk[1]) != -n_new:
+                            raise RuntimeError(f"replicas diverged: this rank holds {n_new} Gaussians after the MCMC refinement of step "
+                                               f"{step}, others between {-int(chk[1])} and {int(chk[0])}")
+                eng.inject_noise()
+            else:
+                # torch-level strategy ops on the host-side handles.  Replicated data parallelism shards the Adam moments by
+                # flat pieces (ShardedFlatAdam): every rank rewrites ALL of them, so the other owners' pieces come first
+                if refine_now and self.world_size > 1 and self._sadam is not None:
+                    self._sadam.gather_moments(eng.ws["m_flat"], eng.ws["v_flat"])
+                # lr = the means learning rate after this step's scheduler.step() (gsplat_trainer.py:753-761)
+                n_rel, n_new = s.step_post_backward(params=self.splats, optimizers=self.optimizers,
+                                                    state=self.strategy_state, step=step, info={},
+                                                    lr=self.optimizers["means"].param_groups[0]["lr"],
+                                                    generator=self._split_gen)
+                if n_rel or n_new:
+                    eng.rebuild()
             self.last_info = {"radii": eng.ws["radii"], "engine": eng,   # eng.stats() / eng.tile_lists(): counts and lists
                               "flatten_ids": eng.ws["flatten_ids"], "means2d": eng.ws["means2d"]}
             self.step += 1

@@ -116,3 +116,157 @@ def test_mcmc_relocate_and_sample_add_semantics(dev):
     assert len(r.splats["means"]) == 525
     st = r.optimizers["shN"].state[r.splats["shN"]]
     assert st["exp_avg"].shape[0] == 525 and st["exp_avg"][500:].abs().max() == 0
+
+
+# ------------------------------------------------------------------------------------------------ MCMCStrategy on the device
+ORDER = ("means", "scales", "quats", "opacities", "sh0", "shN")
+
+
+def _random_model(N, K=16, seed=0, n_dead=0):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    P = {"means": rng.normal(size=(N, 3)), "scales": np.log(rng.uniform(0.01, 0.2, (N, 3))), "quats": rng.normal(size=(N, 4)),
+         "opacities": rng.normal(size=N) * 1.5, "sh0": rng.normal(size=(N, 1, 3)), "shN": rng.normal(size=(N, K - 1, 3))}
+    P = {k: v.astype(np.float32) for k, v in P.items()}
+    if n_dead:
+        P["opacities"][rng.choice(N, n_dead, replace=False)] = -9.0
+    M = {k: rng.normal(size=v.shape).astype(np.float32) for k, v in P.items()}
+    V = {k: rng.uniform(0.1, 1, v.shape).astype(np.float32) for k, v in P.items()}
+    return P, M, V
+
+
+def _device_sets(dev, P, M, V, cap):
+    import numpy as np
+    from splat_one_amd import _lib
+    N = P["means"].shape[0]
+    sets = []
+    for src in (P, M, V):
+        d = {}
+        for k in ORDER:
+            t = torch.full((cap,) + src[k].shape[1:], float("nan"), dtype=torch.float32, device=dev)
+            t[:N] = torch.from_numpy(src[k]).to(dev)
+            d[k] = t
+        sets.append(d)
+    ms = _lib.ModelSet()
+    for i, k in enumerate(ORDER):
+        ms.p[i], ms.m[i], ms.v[i] = (s[k].data_ptr() for s in sets)
+    return sets, ms
+
+
+@pytest.mark.parametrize("N,n_dead,cap_max", [(20_000, 700, 10 ** 6), (5_000, 0, 5_100), (1_000, 990, 10 ** 6), (70_001, 3_000, 72_000)])
+def test_mcmc_refine_on_the_device_equals_the_oracle(dev, N, n_dead, cap_max):
+    """so_mcmc_refine (relocate, then sample_add, one phase per call so that the weights the device formed can be read
+    back) against oracle/mcmc_oracle.py: the SAME rows drawn, parameters of sources / relocated / appended rows, moments."""
+    import ctypes
+    import numpy as np
+    from oracle import mcmc_oracle as MO
+    from splat_one_amd import _lib
+    from splat_one_amd.strategy import MCMCStrategy
+    cap = 1 << 17
+    P, M, V = _random_model(N, seed=N, n_dead=n_dead)
+    sets, ms = _device_sets(dev, P, M, V, cap)
+    n_dev = torch.tensor([N], dtype=torch.int32, device=dev)
+    binoms = MCMCStrategy().initialize_state()["binoms"].to(dev).contiguous()
+    scratch = torch.zeros(int(_lib.load().so_mcmc_scratch_words(cap)), dtype=torch.int32, device=dev)
+    report = torch.zeros(8, dtype=torch.int32, device=dev)
+    seed, step, min_op = 0xABCDEF0123, 700, 0.005
+
+    def run(skip_bits):
+        prm = _lib.McmcParams(min_op, cap_max, seed, step, skip_bits)
+        _lib.call("so_mcmc_refine", cap, 16, ctypes.byref(ms), _lib.ptr(n_dev), _lib.ptr(binoms), 51, ctypes.byref(prm),
+                  _lib.ptr(scratch), _lib.ptr(report), _lib.stream())
+        torch.cuda.synchronize()
+
+    def host(n):
+        return [{k: s[k][:n].cpu().numpy() for k in ORDER} for s in sets]
+
+    # phase 0: relocation
+    run(2)
+    w0 = scratch[:N].view(torch.float32).cpu().numpy().copy()
+    P1o, M1o, V1o, src_o, dead_o = MO.relocate(P, M, V, min_opacity=min_op, seed=seed, step=step, weights=w0)
+    nd = len(dead_o)            # (the planted dead rows plus the odd random logit below logit(min_opacity))
+    assert n_dead <= nd <= n_dead + 20 and int(n_dev) == N and report[0].item() == nd
+    cap2 = cap + (cap & 1)
+    src_d = scratch[cap2 + 3 * cap:cap2 + 3 * cap + nd].cpu().numpy()
+    assert np.array_equal(src_d, src_o)                                   # the same rows drawn
+    P1, M1, V1 = host(N)
+    for k in ORDER:
+        tol = 2e-5 if k in ("scales", "opacities") else 0.0              # (relocation formula in float32 on the device)
+        assert np.allclose(P1[k], P1o[k], rtol=tol, atol=tol), k
+        assert np.array_equal(M1[k], M1o[k]) and np.array_equal(V1[k], V1o[k]), k
+    assert not scratch[cap2 + 4 * cap:cap2 + 5 * cap].any()               # the draw counters are left zero
+    # phase 1: addition, on the relocated model
+    run(1)
+    n_add = max(0, min(cap_max, int(1.05 * N)) - N)
+    assert int(n_dev) == N + n_add and report[1].item() == n_add and report[3].item() == N + n_add
+    w1 = scratch[:N].view(torch.float32).cpu().numpy().copy()
+    P2o, M2o, V2o, src2_o = MO.sample_add(P1, M1, V1, min_opacity=min_op, cap_max=cap_max, seed=seed, step=step, weights=w1)
+    src2_d = scratch[cap2 + 3 * cap:cap2 + 3 * cap + n_add].cpu().numpy()
+    assert np.array_equal(src2_d, src2_o)
+    P2, M2, V2 = host(N + n_add)
+    for k in ORDER:
+        tol = 2e-5 if k in ("scales", "opacities") else 0.0
+        assert P2[k].shape == P2o[k].shape and np.allclose(P2[k], P2o[k], rtol=tol, atol=tol), k
+        assert np.array_equal(M2[k], M2o[k]) and np.array_equal(V2[k], V2o[k]), k
+    if n_add:
+        assert not M2["shN"][N:].any() and np.array_equal(P2["means"][N:], P2["means"][src2_o])
+    # rows beyond the new N were never touched
+    assert torch.isnan(sets[0]["means"][N + n_add:]).all()
+    # without the device's weights the oracle's own float32 opacities give the same draw up to CDF-boundary ties
+    _, _, _, src_own, _ = MO.relocate(P, M, V, min_opacity=min_op, seed=seed, step=step)
+    assert len(src_own) == nd and (src_own != src_o).sum() <= max(1, 2e-3 * max(1, nd))
+
+
+def test_device_noise_matches_the_oracle(dev):
+    """so_inject_noise_dev: normals from (seed, optimiser step, row), scaler = lr0 gamma^step noise_lr evaluated on the device"""
+    import numpy as np
+    from oracle import mcmc_oracle as MO
+    from splat_one_amd import _lib
+    g = torch.Generator().manual_seed(1)
+    N, cap = 3000, 4096
+    means = torch.randn(N, 3, generator=g)
+    ls = torch.log(torch.rand(N, 3, generator=g) * 0.3 + 0.01)
+    quats = torch.randn(N, 4, generator=g)
+    lo = torch.logit(torch.rand(N, generator=g) * 0.02 + 1e-4)
+    lo[::3] = 2.0
+    seed, t, lr0, gamma, noise_lr = 77, 1234, 1.6e-4, 0.99985, 5e5
+    z = torch.from_numpy(MO.noise_normals(seed, t, N))
+    ref = SO.inject_noise(means, ls, quats, lo, z, lr0 * gamma ** t * noise_lr)
+    pad = lambda x: torch.cat([x, torch.full((cap - N,) + x.shape[1:], float("nan"))]).to(dev).contiguous()
+    m, a_ls, a_q, a_lo = pad(means), pad(ls), pad(quats), pad(lo)
+    n_dev = torch.tensor([N], dtype=torch.int32, device=dev)
+    ctr = torch.tensor([t, 0], dtype=torch.int32, device=dev)
+    skip = torch.zeros(1, dtype=torch.int32, device=dev)
+    args = lambda: (cap, _lib.ptr(n_dev), _lib.ptr(m), _lib.ptr(a_ls), _lib.ptr(a_q), _lib.ptr(a_lo), seed, _lib.ptr(ctr), lr0, gamma,
+                    noise_lr, _lib.ptr(skip), _lib.stream())
+    _lib.call("so_inject_noise_dev", *args())
+    got = m[:N].cpu().double() - means.double()
+    assert rel_err(got, ref - means.double()) < 2e-4 and torch.isnan(m[N:]).all()
+    skip.fill_(1)                                    # a void iteration: nothing moves
+    before = m.clone()
+    _lib.call("so_inject_noise_dev", *args())
+    assert torch.equal(m[:N], before[:N])
+
+
+def test_mcmc_engine_refines_without_touching_the_host(dev):
+    """The fused Runner with MCMCStrategy keeps the model on the device: refinements change N there, the captured step
+    follows, and the host's handles are re-pointed only when somebody looks (len(runner.splats[...]))."""
+    W, H = 128, 96
+    r = _mcmc_runner(dev, True)
+    c2w, Ks = ring_cameras(4).to(dev), pinhole_K(W, H)[None].to(dev)
+    target = torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(0)).to(dev)
+    with torch.no_grad():
+        r.splats["opacities"][:150] = -9.0
+    for step in range(25):
+        r.train_step(c2w[step % 4:step % 4 + 1], Ks, target)
+    eng = r._engine
+    assert eng.device_refine and eng.model_sets == 1 and eng.refinements == 1 and eng._host_stale      # nobody looked yet
+    graphs_before = len(eng._graphs)
+    for step in range(25, 45):
+        r.train_step(c2w[step % 4:step % 4 + 1], Ks, target)
+    assert eng.refinements == 3 and len(eng._graphs) == graphs_before                                   # no re-capture
+    rep = eng.refine_report()
+    assert rep["n_new"] == 3400 and len(r.splats["means"]) == 3400 and not eng._host_stale
+    assert (torch.sigmoid(r.splats["opacities"]) >= 0.004).all() and torch.isfinite(r.splats["means"]).all()
+    st = r.optimizers["shN"].state[r.splats["shN"]]
+    assert st["exp_avg"].shape[0] == 3400 and torch.isfinite(st["exp_avg"]).all()
