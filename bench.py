@@ -31,6 +31,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+# VALU issue roof: 256 CUs x 4 SIMD-32 units, one wave64 vector instruction per 2 cycles per SIMD at 2.4 GHz
+# (MI355X_MICROARCH.md, "A wave (64 lanes) ... issues each VALU instruction over 2 cycles"; v_fma_f32 2 cyc throughput)
+VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 2.0
 
 
 def algorithmic_bytes(N, V, I, P, K):
@@ -516,6 +519,27 @@ def main():
     # everything fused into it: Adam inside so_preprocess_bwd, the key writes inside so_preprocess_fwd)
     dom_bytes = by_kernel[dominant]["algorithmic_bytes"] if dominant in by_kernel else ab[dominant]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+    # The other roof of the dominant kernel: vector-instruction issue.  Wave-instructions per launch come from the committed
+    # SQ-counter summary of this workload (profiles/valu.json <- rocprofv3 --pmc SQ_INSTS_VALU, tools/gpu_profiles_r03.sh);
+    # the launch duration is the one measured live above.  `bound` names the roof with the larger fraction.
+    valu = None
+    vpath = os.path.join(ROOT, "profiles", "valu.json")
+    if os.path.exists(vpath) and is_c2_engine:
+        try:
+            vj = json.load(open(vpath))
+            ent = vj.get(dominant)
+            if ent:
+                rate = ent["wave_instructions"] / (dom_ms * 1e-3)
+                valu = {"wave_instructions_per_launch": ent["wave_instructions"], "achieved": rate, "peak": VALU_PEAK_WAVE_INSTR_PER_S,
+                        "unit": "wave64 VALU instructions/s", "frac": rate / VALU_PEAK_WAVE_INSTR_PER_S,
+                        "active_lane_fraction": ent.get("active_lane_fraction"),
+                        "useful_lane_fraction": (vj.get("_useful_lane_fraction_model") or {}).get(dominant),
+                        "source": "profiles/valu.json (SQ counters of this workload, collected at I = 371k-class model states; "
+                                  "useful lanes: tools/passsim.py)"}
+        except Exception:   # noqa: BLE001
+            valu = None
+    hbm_frac = achieved / HBM_PEAK_GBS
+    bound = "valu" if (valu is not None and valu["frac"] > hbm_frac) else "hbm"
     out = {
         "metric": ("training iters/sec (100k Gaussians, 1080p, fwd+loss+bwd+Adam)" if (N0, W, H) == (100_000, 1920, 1080)
                    else f"training iters/sec ({N0} Gaussians, {W}x{H}, fwd+loss+bwd+Adam)"),
@@ -555,10 +579,10 @@ def main():
         "forward_mpix_per_s": None if runner.sharded else world * P / fwd_s / 1e6,
         "hbm_iter_fraction": b_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9),
         "algorithmic_bytes_per_iter": b_iter,
-        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "roofline": {"bound": bound, "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": hbm_frac, "traffic": traffic,
                      "algorithmic_bytes_per_launch": dom_bytes, "mean_launch_us": dom_ms * 1e3,
-                     "launches_timed": dom_calls},
+                     "launches_timed": dom_calls, "valu": valu},
         "roofline_by_kernel": by_kernel,
         "void_steps": void_steps,
     }

@@ -268,8 +268,9 @@ class FusedEngine:
         with self._lock:
             prm = _lib.McmcParams(float(strategy.min_opacity), int(min(strategy.cap_max, self.cap)), int(seed) & 0xFFFFFFFFFFFFFFFF,
                                   int(step), 0)
-            b = binoms.to(device=self.device, dtype=torch.float32).contiguous()
-            self._binoms = b
+            b = getattr(self, "_binoms", None)           # (on the device once: no copy per refinement)
+            if b is None or b.shape != binoms.shape:
+                b = self._binoms = binoms.to(device=self.device, dtype=torch.float32).contiguous()
             _lib.call("so_mcmc_refine", self.cap, self.K, ctypes.byref(self._ms[self.active]),
                       _lib.ptr(self._n_dev[self.active:self.active + 1]), _lib.ptr(b), int(b.shape[0]), ctypes.byref(prm),
                       _lib.ptr(self._mcmc_scratch), self._report.data_ptr(), _lib.stream())

@@ -387,7 +387,18 @@ class Runner:
         if self.world_size > 1 and not self.sharded and self.world_rank != 0:
             return ""
         path = f"{self._result_dirs()['ckpts']}/ckpt_{step}_rank{self.world_rank}.pt"
-        data = {"step": step, "splats": self.splats.state_dict()}
+        # live rows only: with a device-resident model the ParameterDict entries are views [:n] of capacity-sized buffers,
+        # and torch.save serialises the whole storage behind a view (a 100k-Gaussian model became a 250 MB file)
+        data = {"step": step, "splats": {k: v.detach().clone() for k, v in self.splats.state_dict().items()}}
+        # (extension, ignored by the reference's loader :950-957) the Adam moments, so that a resumed run continues with the
+        # optimiser state it had instead of empty moments under late-step bias corrections (a burst of ~10x steps)
+        opt_state = {}
+        for k, opt in self.optimizers.items():
+            st = opt.state.get(self.splats[k], {})
+            if "exp_avg" in st and not st["exp_avg"].is_sparse:
+                opt_state[k] = {"exp_avg": st["exp_avg"].detach().clone(), "exp_avg_sq": st["exp_avg_sq"].detach().clone()}
+        if len(opt_state) == len(self.optimizers):
+            data["adam_moments"] = opt_state
         if self.cfg.pose_opt:
             data["pose_adjust"] = self.pose_adjust.state_dict()                # :693-697
         torch.save(data, path)
@@ -424,8 +435,15 @@ class Runner:
             if isinstance(opt, torch.optim.SparseAdam):
                 continue                      # lazily initialised per row by torch; starts over
             prm = self.splats[k]
-            opt.state[prm] = {"step": torch.tensor(float(self.step)), "exp_avg": torch.zeros_like(prm),
-                              "exp_avg_sq": torch.zeros_like(prm)}
+            if all("adam_moments" in c and k in c["adam_moments"] for c in ckpts):      # written by save_checkpoint above
+                m = torch.cat([c["adam_moments"][k]["exp_avg"] for c in ckpts]).to(self.device).contiguous()
+                v = torch.cat([c["adam_moments"][k]["exp_avg_sq"] for c in ckpts]).to(self.device).contiguous()
+            else:
+                # a checkpoint in the reference's format holds no optimiser state.  (Known consequence: bias corrections of
+                # step `self.step` on empty moments take steps of ~lr / sqrt(1 - beta2^k) for the first k ~ 1000 iterations
+                # after the resume; the reference itself only loads checkpoints to evaluate, :950-966.)
+                m, v = torch.zeros_like(prm), torch.zeros_like(prm)
+            opt.state[prm] = {"step": torch.tensor(float(self.step)), "exp_avg": m, "exp_avg_sq": v}
         return int(ckpts[0]["step"])
 
     # ------------------------------------------------------------------------------ :779-838

@@ -20,6 +20,8 @@ pairs = [(f"{tag}/prof/**/bench_kernel_stats.csv", f"{tag}_engine_kernel_stats.c
          (f"{tag}/pmc/traffic_summary.json", f"{tag}_engine_pmc_traffic.json"),
          (f"{tag}/bench.json", f"{tag}_engine_bench.json"),
          (f"{tag}/other_lines.jsonl", f"{tag}_other_bench_lines.jsonl"),
+         (f"{tag}/pmc/sq_summary.json", f"{tag}_engine_sq_counters.json"),
+         (f"{tag}/hip/hip_api_diff.json", f"{tag}_mcmc_refine_hip_api_calls.json"),
          (f"c4{tag}/bench.json", f"{tag}_c4_densify_bench.json"),
          (f"c4{tag}/**/c4_kernel_stats.csv", f"{tag}_c4_densify_kernel_stats.csv"),
          (f"c4{tag}/hip_api_diff.json", f"{tag}_c4_refine_hip_api_calls.json"),
@@ -50,3 +52,21 @@ out["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools
                 "profiles/%s_engine_pmc_traffic.json" % (tag, tag))
 json.dump(out, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print(out)
+# the VALU side: wave-instructions and exec-mask lane cycles per launch (bench.py roofline.valu)
+sqp = os.path.join(dst, f"{tag}_engine_sq_counters.json")
+if os.path.exists(sqp):
+    sq = json.load(open(sqp))
+    valu = {}
+    for k, v in names.items():
+        c = sq.get(v)
+        if c and "SQ_INSTS_VALU" in c:
+            valu[k] = {"wave_instructions": c["SQ_INSTS_VALU"], "waves": c.get("SQ_WAVES"),
+                       "active_lane_fraction": (c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+                                                if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU") else None)}
+    valu["_note"] = ("rocprofv3 --pmc SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_THREAD_CYCLES_VALU (tools/gpu_profiles_%s.sh), means per launch of the "
+                     "default bench (c2); active_lane_fraction = exec-mask lanes per issued VALU instruction / 64; source profiles/%s_engine_sq_counters.json"
+                     % (tag, tag))
+    # lanes that carry a contributing (pixel, Gaussian) pair in a pass of the rasteriser kernels: tools/passsim.py on the c2 front view
+    valu["_useful_lane_fraction_model"] = {"so_rasterize_bwd": 0.393, "so_rasterize_fwd": 0.393, "source": "tools/passsim.py mcmc (profiles/r02_experiments.json)"}
+    json.dump(valu, open(os.path.join(dst, "valu.json"), "w"), indent=1)
+    print(valu)
