@@ -28,6 +28,13 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
                 float *__restrict__ v_means2d_abs, float *__restrict__ v_conics, float *__restrict__ v_colors,
                 float *__restrict__ v_opacities, int wrap_flags, const LossFinal fin) {
   constexpr int BLOCK = TS * TS;
+  // list entries staged per batch.  SO_BWD_STAGE < BLOCK: less LDS per workgroup (17 KB at 256 entries), so that more
+  // workgroups fit a CU and a new one can start as soon as four wave slots are free (the four waves of a tile finish at
+  // different times); lists longer than the stage take more batches.
+#ifndef SO_BWD_STAGE
+#define SO_BWD_STAGE 256
+#endif
+  constexpr int STAGE = (SO_BWD_STAGE < BLOCK) ? SO_BWD_STAGE : BLOCK;
   if (fin.sums && blockIdx.x == 0 && threadIdx.x == 0) {   // (see LossFinal: the loss kernel before this one has completed)
     const float l1m = fin.sums[0] * fin.a_l1, ssm = fin.sums[1] * fin.b_ss;
     fin.out[0] = fin.w_l1 / fin.a_l1 * l1m + fin.w_ssim / fin.b_ss * ssm + fin.c_const;
@@ -38,12 +45,12 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
   // staged per Gaussian (same records as the forward): A = (x, y, conic a, conic b),
   // B = (conic c, opacity [, r, g when D == 3]), remaining colour channels in s_col
   constexpr int DC = (D == 3) ? 1 : D;
-  __shared__ float4 s_A[BLOCK];
-  __shared__ float4 s_B[BLOCK];
-  __shared__ float4 s_box[BLOCK];
-  __shared__ float s_col[(D == 3) ? 1 : BLOCK * DC];
-  __shared__ float4 s_C[(D == 3) ? BLOCK : 1];   // RGB: blue, 16-byte strided like s_A / s_B (one address register per pass)
-  __shared__ int32_t s_id[BLOCK];
+  __shared__ float4 s_A[STAGE];
+  __shared__ float4 s_B[STAGE];
+  __shared__ float4 s_box[STAGE];
+  __shared__ float s_col[(D == 3) ? 1 : STAGE * DC];
+  __shared__ float4 s_C[(D == 3) ? STAGE : 1];   // RGB: blue, 16-byte strided like s_A / s_B (one address register per pass)
+  __shared__ int32_t s_id[STAGE];
   __shared__ int32_t s_wave_last[NWAVES];
 
   // the host checked C * tile_w * tile_h < 2^31 (32-bit index arithmetic)
@@ -115,10 +122,10 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
     else if (ABS && slot < 11) { out_base = v_means2d_abs + (slot - 9); out_stride = 2; }
   }
 
-  for (int64_t batch_end = block_last; batch_end >= lo; batch_end -= BLOCK) {
+  for (int64_t batch_end = block_last; batch_end >= lo; batch_end -= STAGE) {
     __syncthreads();
     const int64_t idx = batch_end - tid;
-    if (idx >= lo) {
+    if (tid < STAGE && idx >= lo) {
       const int32_t g = flatten_ids[idx];
       s_id[tid] = g;
       if (PACKED) {
@@ -148,7 +155,7 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
       }
     }
     __syncthreads();
-    const int batch_size = (int)((batch_end + 1 - lo) < BLOCK ? (batch_end + 1 - lo) : BLOCK);
+    const int batch_size = (int)((batch_end + 1 - lo) < STAGE ? (batch_end + 1 - lo) : STAGE);
     const int32_t rel_final = (int32_t)(batch_end - bin_final);   // candidate tt contributes to this pixel iff tt >= rel_final
     const int32_t rel_wave = (int32_t)(batch_end - wave_last);
 #pragma unroll 1
