@@ -10,12 +10,18 @@
 // tile's last contributor are never loaded.
 #include "rasterize_common.hpp"
 
+// SO_RASTER_V2 (rasterize_common.hpp, round 3): the D == 3 pass on packed fp32 pairs, the conic applied ONCE per pass --
+// q = Q d serves sigma = 1/2 d.q AND the position gradient v_sigma q.
+#define SO_BWD_V2 SO_RASTER_V2
+
 namespace so {
+
+typedef raster_v2f bwd_v2f;
 
 // PACKED: inputs from the 64-byte records rec[g] (passed through `colors`), gradients into the
 // 64-byte records vrec[g] = {v_x,v_y,v_ca,v_cb,v_cc,v_r,v_g,v_b | v_opac,abs_x,abs_y,..} (passed
 // through `v_colors`): one atomic instruction = one memory-side request per (quadrant, Gaussian).
-template <int D, int TS, bool ABS, bool PACKED>
+template <int D, int TS, bool ABS, bool PACKED, bool SMALL = false>
 __global__ void __launch_bounds__(TS *TS)
 k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2 *__restrict__ means2d,
                 const float *__restrict__ conics, const float *__restrict__ colors,
@@ -134,9 +140,15 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         const float4 q1 = r4[1];   // x,y,ca,cb | cc,opac,r,g
         if (wrap) q0.x -= wrap_w * rintf((q0.x - wrap_cx) / wrap_w);
         s_A[tid] = q0;
-        s_B[tid] = q1;
         s_box[tid] = alpha_bound_box(q0.x, q0.y, q1.y, q0.z, q0.w, q1.x);
+#if SO_BWD_V2
+        // (x, y, ca, cb) | (cb, cc, opacity, blue) | (red, green): (ca, cb) and (cb, cc) are aligned register pairs after the loads
+        s_B[tid] = make_float4(q0.w, q1.x, q1.y, reinterpret_cast<const float *>(r4 + 2)[0]);
+        s_C[tid] = make_float4(q1.z, q1.w, 0.f, 0.f);
+#else
+        s_B[tid] = q1;
         s_C[tid].x = reinterpret_cast<const float *>(r4 + 2)[0];
+#endif
       } else {
         float2 xy = means2d[g];
         if (wrap) xy.x -= wrap_w * rintf((xy.x - wrap_cx) / wrap_w);
@@ -145,8 +157,13 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         s_A[tid] = make_float4(xy.x, xy.y, ca, cb);
         s_box[tid] = alpha_bound_box(xy.x, xy.y, op, ca, cb, cc);
         if (D == 3) {
+#if SO_BWD_V2
+          s_B[tid] = make_float4(cb, cc, op, colors[(int64_t)g * D + 2]);
+          s_C[tid] = make_float4(colors[(int64_t)g * D], colors[(int64_t)g * D + 1], 0.f, 0.f);
+#else
           s_B[tid] = make_float4(cc, op, colors[(int64_t)g * D], colors[(int64_t)g * D + 1]);
           s_C[tid].x = colors[(int64_t)g * D + 2];
+#endif
         } else {
           s_B[tid] = make_float4(cc, op, 0.f, 0.f);
 #pragma unroll
@@ -168,7 +185,8 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         if (hit) {   // bounding boxes overlap: settle it with the exact ellipse-rectangle test
           const float4 a = s_A[cand];
           const float4 bq = s_B[cand];
-          hit = ellipse_hits_rect(a.x, a.y, bq.y, a.z, a.w, bq.x, qx0, qx1, qy0, qy1);
+          if (D == 3 && SO_BWD_V2) hit = ellipse_hits_rect(a.x, a.y, bq.z, a.z, a.w, bq.y, qx0, qx1, qy0, qy1);
+          else hit = ellipse_hits_rect(a.x, a.y, bq.y, a.z, a.w, bq.x, qx0, qx1, qy0, qy1);
         }
       }
       unsigned long long mask = __ballot(hit);
@@ -176,6 +194,59 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         const int bit = __ffsll((long long)mask) - 1;
         mask = clear_bit(mask, bit);
         const int tt = chunk0 + bit;
+#if SO_BWD_V2
+        if constexpr (D == 3) {
+          const float4 a = s_A[tt];            // x, y, ca, cb
+          const float4 b4 = s_B[tt];           // cb, cc, opacity, blue
+          const bwd_v2f d = {a.x - px, a.y - py};
+          // q = Q d = (ca dx + cb dy, cb dx + cc dy):  sigma = 1/2 d.q,  d sigma / d mean = q
+          const bwd_v2f q = conic_times(a.z, a.w, b4.x, b4.y, d);
+          const float s2 = fmaf(q.y, d.y, q.x * d.x);                       // 2 sigma
+          const float vis = gauss_vis(s2);                                  // exp(-sigma), bit for bit the forward's
+          const float ov = b4.z * vis;
+          const float alpha = fminf(kAlphaMax, ov);
+          const bool valid = (tt >= rel_final) && !(s2 < 0.f || alpha < kAlphaMin);
+          if (__ballot(valid) == 0ull) continue;
+          const float alpha_v = valid ? alpha : 0.f;
+          const float ra = __builtin_amdgcn_rcpf(1.f - alpha_v);
+          T *= ra;
+          const float fac = alpha_v * T;
+          const float4 rg4 = s_C[tt];          // red, green
+          const float cv = fmaf(b4.w, v_c[2], fmaf(rg4.y, v_c[1], rg4.x * v_c[0]));
+          const bwd_v2f g01 = bwd_v2f{fac, fac} * bwd_v2f{v_c[0], v_c[1]};
+          const float g2 = fac * v_c[2];
+          const float v_alpha = fmaf(T, cv, ra * (tf_bg - buf_dot));
+          buf_dot = fmaf(fac, cv, buf_dot);
+          const bool grad_on = valid && (ov <= kAlphaMax);
+          const float v_sigma = grad_on ? -ov * v_alpha : 0.f;
+          const float g_op = grad_on ? vis * v_alpha : 0.f;
+          const bwd_v2f vs2 = {v_sigma, v_sigma};
+          const bwd_v2f gxy = vs2 * q;                                      // d L / d mean2d
+          const bwd_v2f t = vs2 * d;
+          const bwd_v2f gcxz = (t * d) * bwd_v2f{0.5f, 0.5f};               // d L / d (ca, cc)
+          const float g_cy = t.x * d.y;                                     // d L / d cb
+          const float v8[8] = {gxy.x, gxy.y, gcxz.x, g_cy, gcxz.y, g01.x, g01.y, g2};
+          float val = row_reduce8_transposed(v8, lane);
+          const float r_op = row_allreduce_sum(g_op);
+          if (l15 == 8) val = r_op;
+          if (ABS) {
+            const float r_ax = row_allreduce_sum(fabsf(gxy.x)), r_ay = row_allreduce_sum(fabsf(gxy.y));
+            if (l15 == 9) val = r_ax;
+            if (l15 == 10) val = r_ay;
+          }
+          val = rows_combine(val);
+          if (lane <= (ABS ? 10 : 8) && val != 0.f) {
+            if constexpr (PACKED && SMALL) {
+              // one 64-byte record per Gaussian: 32-bit byte offset from the uniform base (C N 64 B < 4 GB, checked by the launcher)
+              const unsigned off = (unsigned)s_id[tt] * 64u + (unsigned)slot * 4u;
+              atomicAdd(reinterpret_cast<float *>(reinterpret_cast<char *>(v_colors) + off), val);
+            } else {
+              atomicAdd(out_base + (int64_t)s_id[tt] * out_stride, val);
+            }
+          }
+          continue;
+        }
+#endif
         const float4 a = s_A[tt];
         const float4 bq = s_B[tt];
         const float opac = bq.y;
@@ -356,13 +427,17 @@ int so::rasterize_bwd_packed_launch(int C, int N, int width, int height, int til
              (long long)C * tile_w * tile_h);
   const dim3 grid((unsigned)((int64_t)C * tile_w * tile_h));
   hipStream_t st = so::as_stream(stream);
-#define SO_GO(TSV, ABSV)                                                                                          \
-  hipLaunchKernelGGL((so::k_rasterize_bwd<3, TSV, ABSV, true>), grid, dim3(TSV * TSV), 0, st, C, N, width, height, \
+  // SMALL: every gradient record lies within 4 GB of `vrec` (C N 64 B): the atomic's address is a 32-bit offset from the base
+  const bool small = (int64_t)C * N < ((int64_t)1 << 26);
+#define SO_GO_(TSV, ABSV, SM)                                                                                     \
+  hipLaunchKernelGGL((so::k_rasterize_bwd<3, TSV, ABSV, true, SM>), grid, dim3(TSV * TSV), 0, st, C, N, width, height, \
                      tile_w, tile_h, nullptr, nullptr, rec, nullptr, backgrounds, nullptr, isect_offsets,         \
                      flatten_ids, n_isects_dev, n_isects_host, render_alphas, last_ids, v_render_colors,          \
                      v_render_alphas, nullptr, nullptr, nullptr, vrec, nullptr, wrap_flags, fin)
+#define SO_GO(TSV, ABSV) do { if (small) SO_GO_(TSV, ABSV, true); else SO_GO_(TSV, ABSV, false); } while (0)
   if (tile_size == 16) { if (absgrad) SO_GO(16, true); else SO_GO(16, false); }
   else                 { if (absgrad) SO_GO(8, true);  else SO_GO(8, false); }
 #undef SO_GO
+#undef SO_GO_
   return so::check_launch("so_rasterize_bwd_packed");
 }

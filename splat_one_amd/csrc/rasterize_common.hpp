@@ -13,6 +13,28 @@ struct LossFinal {
   float w_l1, w_ssim, c_const, a_l1, b_ss;   // loss = w_l1 sums[0] + w_ssim sums[1] + c_const;  means = sums * a_l1 / b_ss
 };
 
+// SO_RASTER_V2 (round 3): the RGB passes of both rasteriser kernels on packed fp32 pairs (v_pk_mul / v_pk_fma are the
+// only vector instructions that do two lanes-worth per issue slot on gfx950 -- SQ_ACTIVE_INST_VALU prices every other one
+// of these kernels at ~4 cycles per wave64), staged records laid out so that (ca, cb) and (cb, cc) are register pairs:
+//   s_A = (x, y, ca, cb)   s_B = (cb, cc, opacity, blue)   s_C = (red, green)
+// and ONE statement of the Gaussian's exponent shared by the forward and the backward, so that both take the same
+// alpha >= 1/255 decision bit for bit:  q = Q d,  2 sigma = d . q,  exp(-sigma) = 2^(-(log2 e / 2) 2 sigma).
+#ifndef SO_RASTER_V2
+#define SO_RASTER_V2 1
+#endif
+typedef float raster_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ raster_v2f conic_times(float ca, float cb0, float cb1, float cc, raster_v2f d) {
+  raster_v2f q = raster_v2f{ca, cb0} * raster_v2f{d.x, d.x};
+  return __builtin_elementwise_fma(raster_v2f{cb1, cc}, raster_v2f{d.y, d.y}, q);      // (ca dx + cb dy, cb dx + cc dy)
+}
+__device__ __forceinline__ float gauss_vis(float two_sigma) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_exp2f(two_sigma * -0.72134752044448170368f);
+#else
+  return exp2f(two_sigma * -0.72134752044448170368f);
+#endif
+}
+
 constexpr float kAlphaMax = 0.999f;
 constexpr float kAlphaMin = 1.f / 255.f;
 constexpr float kTStop = 1e-4f;
@@ -125,19 +147,21 @@ __device__ __forceinline__ bool ellipse_hits_rect(float mx, float my, float opac
   float best = __builtin_inff();
   {  // edges x = ax0 / ax1:  sigma(y) = 1/2 (ca x^2 + cc y^2) + cb x y,  y* = -cb x / cc
     const float xs[2] = {ax0, ax1};
+    const float rcc = __builtin_amdgcn_rcpf(cc);   // (1-ulp reciprocal: the test is padded by 1e-3, and a division is 12 instructions)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const float x = xs[i];
-      const float y = fminf(fmaxf(-cb * x / cc, ay0), ay1);
+      const float y = fminf(fmaxf(-cb * x * rcc, ay0), ay1);
       best = fminf(best, 0.5f * (ca * x * x + cc * y * y) + cb * x * y);
     }
   }
   {  // edges y = ay0 / ay1
     const float ys[2] = {ay0, ay1};
+    const float rca = __builtin_amdgcn_rcpf(ca);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const float y = ys[i];
-      const float x = fminf(fmaxf(-cb * y / ca, ax0), ax1);
+      const float x = fminf(fmaxf(-cb * y * rca, ax0), ax1);
       best = fminf(best, 0.5f * (ca * x * x + cc * y * y) + cb * x * y);
     }
   }

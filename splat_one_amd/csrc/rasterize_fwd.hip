@@ -92,9 +92,14 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         const float4 q1 = r4[1];   // x,y,ca,cb | cc,opac,r,g
         if (wrap) q0.x -= wrap_w * rintf((q0.x - wrap_cx) / wrap_w);
         s_A[tid] = q0;
-        s_B[tid] = q1;
         s_box[tid] = alpha_bound_box(q0.x, q0.y, q1.y, q0.z, q0.w, q1.x);
+#if SO_RASTER_V2
+        s_B[tid] = make_float4(q0.w, q1.x, q1.y, reinterpret_cast<const float *>(r4 + 2)[0]);   // cb, cc, opacity, blue
+        s_C[tid] = make_float4(q1.z, q1.w, 0.f, 0.f);                                           // red, green
+#else
+        s_B[tid] = q1;
         s_C[tid].x = reinterpret_cast<const float *>(r4 + 2)[0];
+#endif
       } else {
         float2 xy = means2d[g];
         if (wrap) xy.x -= wrap_w * rintf((xy.x - wrap_cx) / wrap_w);
@@ -103,8 +108,13 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         s_A[tid] = make_float4(xy.x, xy.y, ca, cb);
         s_box[tid] = alpha_bound_box(xy.x, xy.y, op, ca, cb, cc);
         if (D == 3) {
+#if SO_RASTER_V2
+          s_B[tid] = make_float4(cb, cc, op, colors[(int64_t)g * D + 2]);
+          s_C[tid] = make_float4(colors[(int64_t)g * D], colors[(int64_t)g * D + 1], 0.f, 0.f);
+#else
           s_B[tid] = make_float4(cc, op, colors[(int64_t)g * D], colors[(int64_t)g * D + 1]);
           s_C[tid].x = colors[(int64_t)g * D + 2];
+#endif
         } else {
           s_B[tid] = make_float4(cc, op, 0.f, 0.f);
 #pragma unroll
@@ -125,7 +135,8 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         if (hit) {   // bounding boxes overlap: settle it with the exact ellipse-rectangle test
           const float4 a = s_A[cand];
           const float4 bq = s_B[cand];
-          hit = ellipse_hits_rect(a.x, a.y, bq.y, a.z, a.w, bq.x, qx0, qx1, qy0, qy1);
+          if (D == 3 && SO_RASTER_V2) hit = ellipse_hits_rect(a.x, a.y, bq.z, a.z, a.w, bq.y, qx0, qx1, qy0, qy1);
+          else hit = ellipse_hits_rect(a.x, a.y, bq.y, a.z, a.w, bq.x, qx0, qx1, qy0, qy1);
         }
       }
       unsigned long long mask = __ballot(hit);
@@ -134,6 +145,29 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         const int bit = __ffsll((long long)mask) - 1;
         mask = clear_bit(mask, bit);                // one scalar instruction (mask &= mask - 1 is three)
         const int tt = chunk0 + bit;
+#if SO_RASTER_V2
+        if constexpr (D == 3) {
+          const float4 a = s_A[tt];                 // x, y, ca, cb
+          const float4 b4 = s_B[tt];                // cb, cc, opacity, blue
+          const float4 rg4 = s_C[tt];               // red, green (issued with the other two reads, not at its use)
+          const raster_v2f d = {a.x - px, a.y - py};
+          const raster_v2f q = conic_times(a.z, a.w, b4.x, b4.y, d);
+          const float s2 = fmaf(q.y, d.y, q.x * d.x);                       // 2 sigma: the backward recomputes exactly this
+          float alpha = fminf(kAlphaMax, b4.z * gauss_vis(s2));
+          alpha = (s2 < 0.f) ? 0.f : alpha;
+          alpha = (alpha < kAlphaMin) ? 0.f : alpha;
+          const float next_T = T * (1.f - alpha);
+          const bool stop = next_T <= kTStop;
+          T_out += stop ? T : 0.f;
+          const float vis = stop ? 0.f : alpha * T;
+          T = stop ? 0.f : next_T;
+          acc[0] = fmaf(rg4.x, vis, acc[0]);
+          acc[1] = fmaf(rg4.y, vis, acc[1]);
+          acc[2] = fmaf(b4.w, vis, acc[2]);
+          cur_idx = (vis > 0.f) ? batch_base + tt : cur_idx;
+          continue;
+        }
+#endif
         const float4 a = s_A[tt];
         const float4 bq = s_B[tt];
         float blue = 0.f;
