@@ -74,6 +74,8 @@ int so_device_cu_count(void);
 int so_camera_inverse(int C, const float *camtoworlds, float *viewmats, void *stream);
 /* test hook for the wave64 reduction primitives: in[n_waves*64,9] -> out[n_waves,10] */
 int so_debug_wave_reduce(int n_waves, const float *in, float *out, void *stream);
+/* test hook for the rasteriser backward's nine-sum network (round 3): in[n_waves*64,9] -> out[n_waves,9] */
+int so_debug_wave_reduce9(int n_waves, const float *in, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K1/K2  3D -> 2D EWA projection.   Replaces gsplat `fully_fused_projection` (legacy

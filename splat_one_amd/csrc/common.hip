@@ -40,6 +40,27 @@ __global__ void __launch_bounds__(64) k_debug_wave_reduce(const float *__restric
 }
 }  // namespace so
 
+namespace so {
+__global__ void __launch_bounds__(64) k_debug_wave_reduce9(const float *__restrict__ in, float *__restrict__ out) {
+  const int lane = threadIdx.x;
+  const float *row = in + ((int64_t)blockIdx.x * 64 + lane) * 9;
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = row[k];
+  const float w = wave_reduce9_scattered(v, row[8]);
+  // exactly the store pattern of the rasteriser backward: nine lanes, nine distinct slots
+  if ((kReduce9Lanes >> lane) & 1ull) atomicAdd(out + (int64_t)blockIdx.x * 9 + reduce9_slot_of_lane(lane), w);
+}
+}  // namespace so
+
+/* in[n_waves*64, 9] -> out[n_waves, 9] (zeroed by the caller): the 64-lane sums of the nine columns (wave_reduce9_scattered) */
+extern "C" int so_debug_wave_reduce9(int n_waves, const float *in, float *out, void *stream) {
+  SO_REQUIRE(n_waves >= 0 && (n_waves == 0 || (in && out)), "so_debug_wave_reduce9: bad arguments");
+  if (n_waves == 0) return SO_OK;
+  hipLaunchKernelGGL(so::k_debug_wave_reduce9, dim3(n_waves), dim3(64), 0, so::as_stream(stream), in, out);
+  return so::check_launch("so_debug_wave_reduce9");
+}
+
 /* in[n_waves*64, 9] -> out[n_waves, 10] (zeroed by the caller): slots 0..7 += transposing butterfly
  * row sums of columns 0..7, 8 += row sums of column 8, 9 = wave sum of column 8 (row_bcast DPP form). */
 extern "C" int so_debug_wave_reduce(int n_waves, const float *in, float *out, void *stream) {

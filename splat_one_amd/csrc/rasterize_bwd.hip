@@ -128,6 +128,22 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
     else if (ABS && slot < 11) { out_base = v_means2d_abs + (slot - 9); out_stride = 2; }
   }
 
+  // SO_BWD_V2, no absgrad: the nine-sum network's lanes (so_common.hpp::wave_reduce9_scattered)
+  const bool atom_lane = ((kReduce9Lanes >> lane) & 1ull) != 0;
+  const int slot9 = reduce9_slot_of_lane(lane);
+  float *out_base9 = nullptr;
+  int out_stride9 = 0;
+  if (D == 3 && !PACKED) {
+    if (slot9 < 2) { out_base9 = v_means2d + slot9; out_stride9 = 2; }
+    else if (slot9 < 5) { out_base9 = v_conics + (slot9 - 2); out_stride9 = 3; }
+    else if (slot9 < 8) { out_base9 = v_colors + (slot9 - 5); out_stride9 = 3; }
+    else { out_base9 = v_opacities; out_stride9 = 1; }
+  } else if (D == 3) {
+    out_base9 = v_colors + slot9; out_stride9 = 16;
+  }
+  const bwd_v2f pxy = {px, py};
+  float behind = tf_bg;   // tf_bg - buf_dot of the scalar form below
+
   for (int64_t batch_end = block_last; batch_end >= lo; batch_end -= STAGE) {
     __syncthreads();
     const int64_t idx = batch_end - tid;
@@ -142,9 +158,9 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         s_A[tid] = q0;
         s_box[tid] = alpha_bound_box(q0.x, q0.y, q1.y, q0.z, q0.w, q1.x);
 #if SO_BWD_V2
-        // (x, y, ca, cb) | (cb, cc, opacity, blue) | (red, green): (ca, cb) and (cb, cc) are aligned register pairs after the loads
-        s_B[tid] = make_float4(q0.w, q1.x, q1.y, reinterpret_cast<const float *>(r4 + 2)[0]);
-        s_C[tid] = make_float4(q1.z, q1.w, 0.f, 0.f);
+        // (x, y, ca, cb) | (cb, cc, opacity) | (red, green, blue): (ca, cb) and (cb, cc) are aligned register pairs after the loads
+        s_B[tid] = make_float4(q0.w, q1.x, q1.y, 0.f);
+        s_C[tid] = make_float4(q1.z, q1.w, reinterpret_cast<const float *>(r4 + 2)[0], 0.f);
 #else
         s_B[tid] = q1;
         s_C[tid].x = reinterpret_cast<const float *>(r4 + 2)[0];
@@ -158,8 +174,8 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         s_box[tid] = alpha_bound_box(xy.x, xy.y, op, ca, cb, cc);
         if (D == 3) {
 #if SO_BWD_V2
-          s_B[tid] = make_float4(cb, cc, op, colors[(int64_t)g * D + 2]);
-          s_C[tid] = make_float4(colors[(int64_t)g * D], colors[(int64_t)g * D + 1], 0.f, 0.f);
+          s_B[tid] = make_float4(cb, cc, op, 0.f);
+          s_C[tid] = make_float4(colors[(int64_t)g * D], colors[(int64_t)g * D + 1], colors[(int64_t)g * D + 2], 0.f);
 #else
           s_B[tid] = make_float4(cc, op, colors[(int64_t)g * D], colors[(int64_t)g * D + 1]);
           s_C[tid].x = colors[(int64_t)g * D + 2];
@@ -197,8 +213,8 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
 #if SO_BWD_V2
         if constexpr (D == 3) {
           const float4 a = s_A[tt];            // x, y, ca, cb
-          const float4 b4 = s_B[tt];           // cb, cc, opacity, blue
-          const bwd_v2f d = {a.x - px, a.y - py};
+          const float4 b4 = s_B[tt];           // cb, cc, opacity
+          const bwd_v2f d = bwd_v2f{a.x, a.y} - pxy;
           // q = Q d = (ca dx + cb dy, cb dx + cc dy):  sigma = 1/2 d.q,  d sigma / d mean = q
           const bwd_v2f q = conic_times(a.z, a.w, b4.x, b4.y, d);
           const float s2 = fmaf(q.y, d.y, q.x * d.x);                       // 2 sigma
@@ -211,21 +227,35 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
           const float ra = __builtin_amdgcn_rcpf(1.f - alpha_v);
           T *= ra;
           const float fac = alpha_v * T;
-          const float4 rg4 = s_C[tt];          // red, green
-          const float cv = fmaf(b4.w, v_c[2], fmaf(rg4.y, v_c[1], rg4.x * v_c[0]));
+          const float4 c4 = s_C[tt];           // red, green, blue
+          const float cv = fmaf(c4.z, v_c[2], fmaf(c4.y, v_c[1], c4.x * v_c[0]));
           const bwd_v2f g01 = bwd_v2f{fac, fac} * bwd_v2f{v_c[0], v_c[1]};
           const float g2 = fac * v_c[2];
-          const float v_alpha = fmaf(T, cv, ra * (tf_bg - buf_dot));
-          buf_dot = fmaf(fac, cv, buf_dot);
-          const bool grad_on = valid && (ov <= kAlphaMax);
-          const float v_sigma = grad_on ? -ov * v_alpha : 0.f;
-          const float g_op = grad_on ? vis * v_alpha : 0.f;
+          // behind = T_final (v_a - bg.v_c) - sum of the colours behind this Gaussian . v_c, carried as one scalar
+          float v_alpha = fmaf(T, cv, ra * behind);
+          behind = fmaf(-fac, cv, behind);
+          v_alpha = (valid && ov <= kAlphaMax) ? v_alpha : 0.f;             // the clamp at 0.999 has zero slope
+          const float v_sigma = -ov * v_alpha;
+          const float g_op = vis * v_alpha;
           const bwd_v2f vs2 = {v_sigma, v_sigma};
           const bwd_v2f gxy = vs2 * q;                                      // d L / d mean2d
           const bwd_v2f t = vs2 * d;
           const bwd_v2f gcxz = (t * d) * bwd_v2f{0.5f, 0.5f};               // d L / d (ca, cc)
           const float g_cy = t.x * d.y;                                     // d L / d cb
           const float v8[8] = {gxy.x, gxy.y, gcxz.x, g_cy, gcxz.y, g01.x, g01.y, g2};
+          if constexpr (!ABS) {
+            // nine sums over the wave as one network (so_common.hpp): nine lanes, ONE atomic instruction, nine addresses
+            const float val = wave_reduce9_scattered(v8, g_op);
+            if (atom_lane) {
+              if constexpr (PACKED && SMALL) {
+                const unsigned off = (unsigned)s_id[tt] * 64u + (unsigned)slot9 * 4u;
+                atomicAdd(reinterpret_cast<float *>(reinterpret_cast<char *>(v_colors) + off), val);
+              } else {
+                atomicAdd(out_base9 + (int64_t)s_id[tt] * out_stride9, val);
+              }
+            }
+            continue;
+          }
           float val = row_reduce8_transposed(v8, lane);
           const float r_op = row_allreduce_sum(g_op);
           if (l15 == 8) val = r_op;

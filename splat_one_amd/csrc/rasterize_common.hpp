@@ -16,7 +16,7 @@ struct LossFinal {
 // SO_RASTER_V2 (round 3): the RGB passes of both rasteriser kernels on packed fp32 pairs (v_pk_mul / v_pk_fma are the
 // only vector instructions that do two lanes-worth per issue slot on gfx950 -- SQ_ACTIVE_INST_VALU prices every other one
 // of these kernels at ~4 cycles per wave64), staged records laid out so that (ca, cb) and (cb, cc) are register pairs:
-//   s_A = (x, y, ca, cb)   s_B = (cb, cc, opacity, blue)   s_C = (red, green)
+//   s_A = (x, y, ca, cb)   s_B = (cb, cc, opacity, -)   s_C = (red, green, blue, -)
 // and ONE statement of the Gaussian's exponent shared by the forward and the backward, so that both take the same
 // alpha >= 1/255 decision bit for bit:  q = Q d,  2 sigma = d . q,  exp(-sigma) = 2^(-(log2 e / 2) 2 sigma).
 #ifndef SO_RASTER_V2

@@ -80,6 +80,7 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
   for (int k = 0; k < D; ++k) acc[k] = 0.f;
   int32_t cur_idx = 0;
   const int lane = tid & 63;
+  const raster_v2f pxy = {px, py};
 
   for (int64_t batch_start = lo; batch_start < hi; batch_start += BLOCK) {
     if (__syncthreads_and(!(T > 0.f))) break;
@@ -94,8 +95,8 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         s_A[tid] = q0;
         s_box[tid] = alpha_bound_box(q0.x, q0.y, q1.y, q0.z, q0.w, q1.x);
 #if SO_RASTER_V2
-        s_B[tid] = make_float4(q0.w, q1.x, q1.y, reinterpret_cast<const float *>(r4 + 2)[0]);   // cb, cc, opacity, blue
-        s_C[tid] = make_float4(q1.z, q1.w, 0.f, 0.f);                                           // red, green
+        s_B[tid] = make_float4(q0.w, q1.x, q1.y, 0.f);                                          // cb, cc, opacity
+        s_C[tid] = make_float4(q1.z, q1.w, reinterpret_cast<const float *>(r4 + 2)[0], 0.f);    // red, green, blue
 #else
         s_B[tid] = q1;
         s_C[tid].x = reinterpret_cast<const float *>(r4 + 2)[0];
@@ -109,8 +110,8 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         s_box[tid] = alpha_bound_box(xy.x, xy.y, op, ca, cb, cc);
         if (D == 3) {
 #if SO_RASTER_V2
-          s_B[tid] = make_float4(cb, cc, op, colors[(int64_t)g * D + 2]);
-          s_C[tid] = make_float4(colors[(int64_t)g * D], colors[(int64_t)g * D + 1], 0.f, 0.f);
+          s_B[tid] = make_float4(cb, cc, op, 0.f);
+          s_C[tid] = make_float4(colors[(int64_t)g * D], colors[(int64_t)g * D + 1], colors[(int64_t)g * D + 2], 0.f);
 #else
           s_B[tid] = make_float4(cc, op, colors[(int64_t)g * D], colors[(int64_t)g * D + 1]);
           s_C[tid].x = colors[(int64_t)g * D + 2];
@@ -148,9 +149,9 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
 #if SO_RASTER_V2
         if constexpr (D == 3) {
           const float4 a = s_A[tt];                 // x, y, ca, cb
-          const float4 b4 = s_B[tt];                // cb, cc, opacity, blue
-          const float4 rg4 = s_C[tt];               // red, green (issued with the other two reads, not at its use)
-          const raster_v2f d = {a.x - px, a.y - py};
+          const float4 b4 = s_B[tt];                // cb, cc, opacity
+          const float4 c4 = s_C[tt];                // red, green, blue (issued with the other two reads, not at its use)
+          const raster_v2f d = raster_v2f{a.x, a.y} - pxy;
           const raster_v2f q = conic_times(a.z, a.w, b4.x, b4.y, d);
           const float s2 = fmaf(q.y, d.y, q.x * d.x);                       // 2 sigma: the backward recomputes exactly this
           float alpha = fminf(kAlphaMax, b4.z * gauss_vis(s2));
@@ -161,9 +162,9 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
           T_out += stop ? T : 0.f;
           const float vis = stop ? 0.f : alpha * T;
           T = stop ? 0.f : next_T;
-          acc[0] = fmaf(rg4.x, vis, acc[0]);
-          acc[1] = fmaf(rg4.y, vis, acc[1]);
-          acc[2] = fmaf(b4.w, vis, acc[2]);
+          acc[0] = fmaf(c4.x, vis, acc[0]);
+          acc[1] = fmaf(c4.y, vis, acc[1]);
+          acc[2] = fmaf(c4.z, vis, acc[2]);
           cur_idx = (vis > 0.f) ? batch_base + tt : cur_idx;
           continue;
         }

@@ -153,6 +153,78 @@ __device__ __forceinline__ float row_allreduce_sum(float x) {
   return x;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 3: the whole 64-lane reduction of the rasteriser backward's nine sums as ONE transposing network, priced by
+// which lane bits a select is free on.  A transposing stage on lane bit k halves the number of registers: the lanes
+// with bit k clear keep the sum of value A, the others of value B.  On gfx950 the select costs nothing where the
+// hardware has a write mask or a swap:
+//   bit 2 (which quad of a row pair)  DPP bank_mask: row_shl:4 into quads 0,2 / row_shr:4 into quads 1,3 -- 2 per pair
+//   bits 4, 5 (which row)             v_permlane16_swap / v_permlane32_swap ARE a select-exchange of two registers --
+//                                     swap + add = 2 per pair (rows_combine above spends mov + swap + add on ONE)
+//   bits 0, 1 (inside a quad)         no mask: 2 v_cndmask + 1 DPP add per pair -- so these are plain all-reduce steps
+// Eight values: bit 2 (8 instructions) -> 4 registers, bit 4 (4) -> 2, bit 5 (2) -> 1, then plain sums over bits 0, 1, 3
+// (3 DPP adds): 17.  The ninth (opacity) is a plain wave reduction, 4 DPP adds in the row + row_bcast:15 + row_bcast:31
+// (6), whose last instruction writes straight into lanes 56..63 of the result: 23 vector instructions for the nine
+// totals against 33 for row_reduce8_transposed + row_allreduce_sum + select + rows_combine.  Result register: lane
+// 16 r + 4 q holds slot 2 r + q (r = 0..3, q = 0..1), lane 56 holds slot 8 (reduce9_slot_of_lane).  The s_nop's are the
+// wait states between a vector write and a cross-lane read of the same register (inline asm: the compiler adds none);
+// independent instructions fill most of them.  EXEC must be all ones.
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned long long kReduce9Lanes = 0x0111001100110011ull;   // lanes 0,4, 16,20, 32,36, 48,52, 56
+__device__ __forceinline__ int reduce9_slot_of_lane(int lane) {       // meaningful in the lanes of kReduce9Lanes
+  const int row = lane >> 4, quad = (lane >> 2) & 3;
+  return quad < 2 ? 2 * row + quad : 8;
+}
+
+__device__ __forceinline__ float wave_reduce9_scattered(const float (&v)[8], float e) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  float r0, r1, r2, r3;
+  asm volatile(
+      "s_nop 1\n\t"
+      // bit 2: quads 0,2 keep the even value of each pair, quads 1,3 the odd one; opacity's in-row sums ride between
+      "v_add_f32_dpp %0, %5, %5 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %0, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %7, %7 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %1, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %9, %9 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %2, %10, %10 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %4, %4, %4 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %11, %11 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %3, %12, %12 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      // bit 4: rows 0,2 keep r0 (r2), rows 1,3 keep r1 (r3)
+      "s_nop 0\n\t"
+      "v_permlane16_swap_b32 %0, %1\n\t"
+      "v_permlane16_swap_b32 %2, %3\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32 %0, %0, %1\n\t"
+      "v_add_f32 %2, %2, %3\n\t"
+      "v_add_f32_dpp %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      // bit 5: the lower half-wave keeps r0, the upper r2
+      "s_nop 0\n\t"
+      "v_permlane32_swap_b32 %0, %2\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32 %0, %0, %2\n\t"
+      // plain sums over bits 0, 1, 3
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      // opacity: row 3 += lane 31 (rows 0+1), written into quads 2,3 of row 3 of the result
+      "v_add_f32_dpp %0, %4, %4 row_bcast:31 row_mask:0x8 bank_mask:0xc\n\t"
+      "s_nop 1"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "+v"(e)
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+  return r0;
+#else
+  return v[0] + e;
+#endif
+}
+
 // General 4x4 inverse in double (adjugate / determinant) of one camera-to-world matrix.
 __device__ __forceinline__ void camera_inverse_one(const float *__restrict__ src, float *__restrict__ dst) {
   double m[16], inv[16];

@@ -343,6 +343,24 @@ def test_wave_reduction_primitives(dev):
     assert torch.equal(out[:, 8].cpu().double(), ref[:, 8]) and torch.equal(out[:, 9].cpu().double(), ref[:, 8])
 
 
+def test_wave_reduce9_network(dev):
+    """The rasteriser backward's nine 64-lane sums as one transposing network (bank-masked DPP, permlane swaps, row_bcast):
+    every slot against a float64 sum of exact small integers (bitwise in fp32), per-lane patterns that would expose a
+    wrong partner lane (each lane a distinct power-of-two-free integer)."""
+    from splat_one_amd import _lib
+    g = torch.Generator().manual_seed(1)
+    n = 41
+    x = torch.randint(-50, 50, (n * 64, 9), generator=g).float()
+    # first wave: column k of lane l = (k + 1) * (l + 1): a lane left out or counted twice changes the sum
+    lanes = torch.arange(1, 65, dtype=torch.float32)
+    x[:64] = lanes[:, None] * torch.arange(1, 10, dtype=torch.float32)[None]
+    out = torch.zeros(n, 9, device=dev)
+    xd = x.to(dev)
+    _lib.call("so_debug_wave_reduce9", n, _lib.ptr(xd), _lib.ptr(out), _lib.stream())
+    ref = x.reshape(n, 64, 9).double().sum(1)
+    assert torch.equal(out.cpu().double(), ref), (out.cpu()[:2], ref[:2])
+
+
 def test_camera_inverse(dev):
     from splat_one_amd import _lib
     from splat_one_amd.scene import ring_cameras
