@@ -159,7 +159,8 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         s_box[tid] = alpha_bound_box(q0.x, q0.y, q1.y, q0.z, q0.w, q1.x);
 #if SO_BWD_V2
         // (x, y, ca, cb) | (cb, cc, opacity) | (red, green, blue): (ca, cb) and (cb, cc) are aligned register pairs after the loads
-        s_B[tid] = make_float4(q0.w, q1.x, q1.y, 0.f);
+        // s_B.w: the byte offset of this Gaussian's gradient record, so that the atomic's address needs no further LDS read
+        s_B[tid] = make_float4(q0.w, q1.x, q1.y, __uint_as_float((unsigned)g * 64u));
         s_C[tid] = make_float4(q1.z, q1.w, reinterpret_cast<const float *>(r4 + 2)[0], 0.f);
 #else
         s_B[tid] = q1;
@@ -213,7 +214,8 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
 #if SO_BWD_V2
         if constexpr (D == 3) {
           const float4 a = s_A[tt];            // x, y, ca, cb
-          const float4 b4 = s_B[tt];           // cb, cc, opacity
+          const float4 b4 = s_B[tt];           // cb, cc, opacity, record offset
+          const float4 c4 = s_C[tt];           // red, green, blue (issued with the other two: one address register, one wait)
           const bwd_v2f d = bwd_v2f{a.x, a.y} - pxy;
           // q = Q d = (ca dx + cb dy, cb dx + cc dy):  sigma = 1/2 d.q,  d sigma / d mean = q
           const bwd_v2f q = conic_times(a.z, a.w, b4.x, b4.y, d);
@@ -222,12 +224,13 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
           const float ov = b4.z * vis;
           const float alpha = fminf(kAlphaMax, ov);
           const bool valid = (tt >= rel_final) && !(s2 < 0.f || alpha < kAlphaMin);
+          // keeps the colour / offset reads where they are written (hipcc sinks them below the branch, which costs two address moves)
+          asm volatile("" ::"v"(c4.x), "v"(c4.y), "v"(c4.z), "v"(b4.w));
           if (__ballot(valid) == 0ull) continue;
           const float alpha_v = valid ? alpha : 0.f;
           const float ra = __builtin_amdgcn_rcpf(1.f - alpha_v);
           T *= ra;
           const float fac = alpha_v * T;
-          const float4 c4 = s_C[tt];           // red, green, blue
           const float cv = fmaf(c4.z, v_c[2], fmaf(c4.y, v_c[1], c4.x * v_c[0]));
           const bwd_v2f g01 = bwd_v2f{fac, fac} * bwd_v2f{v_c[0], v_c[1]};
           const float g2 = fac * v_c[2];
@@ -248,7 +251,7 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
             const float val = wave_reduce9_scattered(v8, g_op);
             if (atom_lane) {
               if constexpr (PACKED && SMALL) {
-                const unsigned off = (unsigned)s_id[tt] * 64u + (unsigned)slot9 * 4u;
+                const unsigned off = __float_as_uint(b4.w) | ((unsigned)slot9 * 4u);
                 atomicAdd(reinterpret_cast<float *>(reinterpret_cast<char *>(v_colors) + off), val);
               } else {
                 atomicAdd(out_base9 + (int64_t)s_id[tt] * out_stride9, val);

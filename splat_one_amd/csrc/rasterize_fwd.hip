@@ -74,7 +74,11 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
   // Per-pixel state.  A finished pixel (outside the image, or transmittance exhausted) has T == 0, which
   // makes every later contribution vanish arithmetically -- the pass body below has no branches.  T_out
   // keeps the transmittance the pixel stopped at (exactly one of T, T_out is non-zero at the end).
+  // (SO_RASTER_V2, RGB: the same idea with one instruction less per pass -- T_live is the live transmittance or 0, T is never zeroed)
+  constexpr bool V2 = (D == 3) && SO_RASTER_V2;
   float T = inside ? 1.f : 0.f, T_out = 0.f;
+  float T_live = T;
+  int cur_slot = -1;
   float acc[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) acc[k] = 0.f;
@@ -83,7 +87,7 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
   const raster_v2f pxy = {px, py};
 
   for (int64_t batch_start = lo; batch_start < hi; batch_start += BLOCK) {
-    if (__syncthreads_and(!(T > 0.f))) break;
+    if (__syncthreads_and(!((V2 ? T_live : T) > 0.f))) break;
     const int64_t idx = batch_start + tid;
     if (idx < hi) {
       const int32_t g = flatten_ids[idx];
@@ -128,6 +132,9 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
     const int32_t batch_base = (int32_t)batch_start;
 #pragma unroll 1
     for (int chunk0 = 0; chunk0 < batch_size; chunk0 += 64) {
+      if constexpr (V2) {
+        if (__ballot(T_live > 0.f) == 0ull) break;   // (the pass loop tests this itself after every pass, with the compare it has)
+      }
       const int cand = chunk0 + lane;
       bool hit = false;
       if (cand < batch_size) {
@@ -142,7 +149,9 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
       }
       unsigned long long mask = __ballot(hit);
       while (mask) {
-        if (__ballot(T > 0.f) == 0ull) break;
+        if constexpr (!V2) {
+          if (__ballot(T > 0.f) == 0ull) break;
+        }
         const int bit = __ffsll((long long)mask) - 1;
         mask = clear_bit(mask, bit);                // one scalar instruction (mask &= mask - 1 is three)
         const int tt = chunk0 + bit;
@@ -155,17 +164,20 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
           const raster_v2f q = conic_times(a.z, a.w, b4.x, b4.y, d);
           const float s2 = fmaf(q.y, d.y, q.x * d.x);                       // 2 sigma: the backward recomputes exactly this
           float alpha = fminf(kAlphaMax, b4.z * gauss_vis(s2));
-          alpha = (s2 < 0.f) ? 0.f : alpha;
-          alpha = (alpha < kAlphaMin) ? 0.f : alpha;
-          const float next_T = T * (1.f - alpha);
-          const bool stop = next_T <= kTStop;
-          T_out += stop ? T : 0.f;
-          const float vis = stop ? 0.f : alpha * T;
-          T = stop ? 0.f : next_T;
+          alpha = (s2 < 0.f || alpha < kAlphaMin) ? 0.f : alpha;            // skipped Gaussian == zero alpha (one select)
+          // T_live is the transmittance while the pixel is live and 0 afterwards (every later contribution vanishes
+          // arithmetically); T keeps the value the pixel stopped at
+          const float next_T = T_live * (1.f - alpha);
+          const bool stop = next_T <= kTStop;       // also true for pixels already finished (T_live == 0)
+          const float vis = stop ? 0.f : alpha * T_live;
+          T = stop ? T : next_T;
+          T_live = stop ? 0.f : next_T;
           acc[0] = fmaf(c4.x, vis, acc[0]);
           acc[1] = fmaf(c4.y, vis, acc[1]);
           acc[2] = fmaf(c4.z, vis, acc[2]);
-          cur_idx = (vis > 0.f) ? batch_base + tt : cur_idx;
+          // the last contributor as the LDS address the pass already holds in a register; turned into a list index per batch
+          cur_slot = (vis > 0.f) ? tt * 16 : cur_slot;
+          if (__ballot(!stop) == 0ull) break;       // the wave's last live pixel has just stopped
           continue;
         }
 #endif
@@ -193,6 +205,10 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         }
         cur_idx = (vis > 0.f) ? batch_base + tt : cur_idx;
       }
+    }
+    if constexpr (V2) {
+      cur_idx = (cur_slot >= 0) ? batch_base + (cur_slot >> 4) : cur_idx;
+      cur_slot = -1;
     }
   }
   if (inside) {
