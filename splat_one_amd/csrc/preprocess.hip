@@ -13,6 +13,7 @@
 #include "so_common.hpp"
 #include "attr_rec.hpp"
 #include "splat_math.hpp"
+#include "rasterize_common.hpp"   // alpha_bound_box: the rasterisers' cull box, computed once per Gaussian into the record
 
 namespace so {
 
@@ -189,7 +190,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
       rec[4 * idx] = make_float4(o.m2d[0], o.m2d[1], o.conic[0], o.conic[1]);
       rec[4 * idx + 1] = make_float4(o.conic[2], op, r, g);
       rec[4 * idx + 2] = make_float4(b, o.depth, __int_as_float(o.radius), 0.f);
-      rec[4 * idx + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rec[4 * idx + 3] = alpha_bound_box(o.m2d[0], o.m2d[1], op, o.conic[0], o.conic[1], o.conic[2]);
     }
     if (vrec) {  // gradient record, accumulated atomically by the rasteriser backward
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -558,7 +559,7 @@ k_rec_pack(int64_t n, const float2 *__restrict__ means2d, const float *__restric
     rec[4 * i + 1] = make_float4(conics[3 * i + 2], opacities[i], r, g);
     rec[4 * i + 2] = make_float4(b, 0.f, 0.f, 0.f);
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    rec[4 * i + 3] = z;
+    rec[4 * i + 3] = alpha_bound_box(m.x, m.y, opacities[i], conics[3 * i], conics[3 * i + 1], conics[3 * i + 2]);
     if (vrec) { vrec[4 * i] = z; vrec[4 * i + 1] = z; vrec[4 * i + 2] = z; vrec[4 * i + 3] = z; }
   }
 }

@@ -95,9 +95,13 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         const float4 *r4 = reinterpret_cast<const float4 *>(colors) + 4 * (int64_t)g;
         float4 q0 = r4[0];
         const float4 q1 = r4[1];   // x,y,ca,cb | cc,opac,r,g
-        if (wrap) q0.x -= wrap_w * rintf((q0.x - wrap_cx) / wrap_w);
+        float4 bx = r4[3];         // the cull box of this Gaussian, computed once in the kernel that wrote the record
+        if (wrap) {
+          const float shift = wrap_w * rintf((q0.x - wrap_cx) / wrap_w);
+          q0.x -= shift; bx.x -= shift; bx.y -= shift;
+        }
         s_A[tid] = q0;
-        s_box[tid] = alpha_bound_box(q0.x, q0.y, q1.y, q0.z, q0.w, q1.x);
+        s_box[tid] = bx;
 #if SO_RASTER_V2
         s_B[tid] = make_float4(q0.w, q1.x, q1.y, 0.f);                                          // cb, cc, opacity
         s_C[tid] = make_float4(q1.z, q1.w, reinterpret_cast<const float *>(r4 + 2)[0], 0.f);    // red, green, blue
