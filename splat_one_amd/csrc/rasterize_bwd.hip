@@ -478,3 +478,9 @@ int so::rasterize_bwd_packed_launch(int C, int N, int width, int height, int til
 #undef SO_GO_
   return so::check_launch("so_rasterize_bwd_packed");
 }
+
+#ifdef SO_TILE_PERM_EXPERIMENT
+extern "C" int so_debug_tile_perm_bwd(const int32_t *perm) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(so::g_tile_perm), &perm, sizeof(perm)) == hipSuccess ? 0 : 1;
+}
+#endif

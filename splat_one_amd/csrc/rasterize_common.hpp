@@ -51,7 +51,14 @@ constexpr float kTStop = 1e-4f;
 #ifndef SO_TILE_ORDER
 #define SO_TILE_ORDER 2
 #endif
+#ifdef SO_TILE_PERM_EXPERIMENT
+// experiment build (tools/experiments/tile_perm.py): workgroup -> tile through a table the host writes (heaviest tiles first)
+static __device__ const int32_t *g_tile_perm = nullptr;
+#endif
 __device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t n) {
+#ifdef SO_TILE_PERM_EXPERIMENT
+  if (g_tile_perm) return g_tile_perm[b];
+#endif
 #if SO_TILE_ORDER == 1
   return b;
 #elif SO_TILE_ORDER == 2

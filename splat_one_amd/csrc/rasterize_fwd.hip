@@ -304,3 +304,9 @@ extern "C" int so_rasterize_fwd_packed(int C, int N, int width, int height, int 
                        n_isects_host, render_colors, render_alphas, last_ids, wrap_flags);
   return so::check_launch("so_rasterize_fwd_packed");
 }
+
+#ifdef SO_TILE_PERM_EXPERIMENT
+extern "C" int so_debug_tile_perm_fwd(const int32_t *perm) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(so::g_tile_perm), &perm, sizeof(perm)) == hipSuccess ? 0 : 1;
+}
+#endif
