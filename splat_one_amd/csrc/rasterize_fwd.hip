@@ -86,8 +86,20 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
   const int lane = tid & 63;
   const raster_v2f pxy = {px, py};
 
+  // "some pixel of this wave is still live", written by lane 0 of every wave at the end of a batch and read by all after
+  // the barrier that also protects the staged records: one ballot + one LDS word instead of __syncthreads_and (a
+  // 35-instruction DPP reduction), and nothing at all for the single-batch lists that are the rule.
+  __shared__ int s_live[(BLOCK + 63) / 64];
+  const int wid = tid >> 6;
+
   for (int64_t batch_start = lo; batch_start < hi; batch_start += BLOCK) {
-    if (__syncthreads_and(!((V2 ? T_live : T) > 0.f))) break;
+    if (batch_start != lo) {   // uniform
+      __syncthreads();
+      int live = 0;
+#pragma unroll
+      for (int w = 0; w < (BLOCK + 63) / 64; ++w) live |= s_live[w];
+      if (!live) break;        // uniform: every wave read the same words
+    }
     const int64_t idx = batch_start + tid;
     if (idx < hi) {
       const int32_t g = flatten_ids[idx];
@@ -213,6 +225,10 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
     if constexpr (V2) {
       cur_idx = (cur_slot >= 0) ? batch_base + (cur_slot >> 4) : cur_idx;
       cur_slot = -1;
+    }
+    if (batch_start + BLOCK < hi) {   // uniform; read after the next iteration's barrier, overwritten only after the one below it
+      const bool wave_live = __ballot((V2 ? T_live : T) > 0.f) != 0ull;
+      if (lane == 0) s_live[wid] = wave_live ? 1 : 0;
     }
   }
   if (inside) {
