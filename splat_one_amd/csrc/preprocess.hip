@@ -189,7 +189,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
 #endif
       rec[4 * idx] = make_float4(o.m2d[0], o.m2d[1], o.conic[0], o.conic[1]);
       rec[4 * idx + 1] = make_float4(o.conic[2], op, r, g);
-      rec[4 * idx + 2] = make_float4(b, o.depth, __int_as_float(o.radius), 0.f);
+      rec[4 * idx + 2] = make_float4(b, o.depth, __int_as_float(o.radius), cull_tau(op, o.conic[0], o.conic[1], o.conic[2]));
       rec[4 * idx + 3] = alpha_bound_box(o.m2d[0], o.m2d[1], op, o.conic[0], o.conic[1], o.conic[2]);
     }
     if (vrec) {  // gradient record, accumulated atomically by the rasteriser backward
@@ -557,7 +557,7 @@ k_rec_pack(int64_t n, const float2 *__restrict__ means2d, const float *__restric
     float r = 0.f, g = 0.f, b = 0.f;
     if (colors) { r = colors[3 * i]; g = colors[3 * i + 1]; b = colors[3 * i + 2]; }
     rec[4 * i + 1] = make_float4(conics[3 * i + 2], opacities[i], r, g);
-    rec[4 * i + 2] = make_float4(b, 0.f, 0.f, 0.f);
+    rec[4 * i + 2] = make_float4(b, 0.f, 0.f, cull_tau(opacities[i], conics[3 * i], conics[3 * i + 1], conics[3 * i + 2]));
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     rec[4 * i + 3] = alpha_bound_box(m.x, m.y, opacities[i], conics[3 * i], conics[3 * i + 1], conics[3 * i + 2]);
     if (vrec) { vrec[4 * i] = z; vrec[4 * i + 1] = z; vrec[4 * i + 2] = z; vrec[4 * i + 3] = z; }

@@ -163,12 +163,13 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         s_box[tid] = bx;
 #if SO_BWD_V2
         // (x, y, ca, cb) | (cb, cc, opacity) | (red, green, blue): (ca, cb) and (cb, cc) are aligned register pairs after the loads
-        // s_B.w: the byte offset of this Gaussian's gradient record, so that the atomic's address needs no further LDS read
-        s_B[tid] = make_float4(q0.w, q1.x, q1.y, __uint_as_float((unsigned)g * 64u));
-        s_C[tid] = make_float4(q1.z, q1.w, reinterpret_cast<const float *>(r4 + 2)[0], 0.f);
+        // s_C.w: the byte offset of this Gaussian's gradient record, so that the atomic's address needs no further LDS read
+        const float4 q2 = r4[2];                                    // blue, depth, radius, cull threshold
+        s_B[tid] = make_float4(q0.w, q1.x, q1.y, q2.w);
+        s_C[tid] = make_float4(q1.z, q1.w, q2.x, __uint_as_float((unsigned)g * 64u));
 #else
         s_B[tid] = q1;
-        s_C[tid].x = reinterpret_cast<const float *>(r4 + 2)[0];
+        s_C[tid] = make_float4(r4[2].x, r4[2].w, 0.f, 0.f);         // blue, cull threshold
 #endif
       } else {
         float2 xy = means2d[g];
@@ -179,14 +180,14 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         s_box[tid] = alpha_bound_box(xy.x, xy.y, op, ca, cb, cc);
         if (D == 3) {
 #if SO_BWD_V2
-          s_B[tid] = make_float4(cb, cc, op, 0.f);
+          s_B[tid] = make_float4(cb, cc, op, cull_tau(op, ca, cb, cc));
           s_C[tid] = make_float4(colors[(int64_t)g * D], colors[(int64_t)g * D + 1], colors[(int64_t)g * D + 2], 0.f);
 #else
           s_B[tid] = make_float4(cc, op, colors[(int64_t)g * D], colors[(int64_t)g * D + 1]);
-          s_C[tid].x = colors[(int64_t)g * D + 2];
+          s_C[tid] = make_float4(colors[(int64_t)g * D + 2], cull_tau(op, ca, cb, cc), 0.f, 0.f);
 #endif
         } else {
-          s_B[tid] = make_float4(cc, op, 0.f, 0.f);
+          s_B[tid] = make_float4(cc, op, cull_tau(op, ca, cb, cc), 0.f);
 #pragma unroll
           for (int k = 0; k < D; ++k) s_col[tid * DC + k] = colors[(int64_t)g * D + k];
         }
@@ -206,8 +207,10 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         if (hit) {   // bounding boxes overlap: settle it with the exact ellipse-rectangle test
           const float4 a = s_A[cand];
           const float4 bq = s_B[cand];
-          if (D == 3 && SO_BWD_V2) hit = ellipse_hits_rect(a.x, a.y, bq.z, a.z, a.w, bq.y, qx0, qx1, qy0, qy1);
-          else hit = ellipse_hits_rect(a.x, a.y, bq.y, a.z, a.w, bq.x, qx0, qx1, qy0, qy1);
+          // (x, y, cull threshold of this Gaussian, conic) against this wave's quadrant
+          if (D == 3 && SO_BWD_V2) hit = ellipse_hits_rect(a.x, a.y, bq.w, a.z, a.w, bq.y, qx0, qx1, qy0, qy1);
+          else if (D == 3) hit = ellipse_hits_rect(a.x, a.y, s_C[cand].y, a.z, a.w, bq.x, qx0, qx1, qy0, qy1);
+          else hit = ellipse_hits_rect(a.x, a.y, bq.z, a.z, a.w, bq.x, qx0, qx1, qy0, qy1);
         }
       }
       unsigned long long mask = __ballot(hit);
@@ -218,8 +221,8 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
 #if SO_BWD_V2
         if constexpr (D == 3) {
           const float4 a = s_A[tt];            // x, y, ca, cb
-          const float4 b4 = s_B[tt];           // cb, cc, opacity, record offset
-          const float4 c4 = s_C[tt];           // red, green, blue (issued with the other two: one address register, one wait)
+          const float4 b4 = s_B[tt];           // cb, cc, opacity, (cull threshold)
+          const float4 c4 = s_C[tt];           // red, green, blue, record offset (issued with the other two: one address register, one wait)
           const bwd_v2f d = bwd_v2f{a.x, a.y} - pxy;
           // q = Q d = (ca dx + cb dy, cb dx + cc dy):  sigma = 1/2 d.q,  d sigma / d mean = q
           const bwd_v2f q = conic_times(a.z, a.w, b4.x, b4.y, d);
@@ -229,7 +232,7 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
           const float alpha = fminf(kAlphaMax, ov);
           const bool valid = (tt >= rel_final) && !(s2 < 0.f || alpha < kAlphaMin);
           // keeps the colour / offset reads where they are written (hipcc sinks them below the branch, which costs two address moves)
-          asm volatile("" ::"v"(c4.x), "v"(c4.y), "v"(c4.z), "v"(b4.w));
+          asm volatile("" ::"v"(c4.x), "v"(c4.y), "v"(c4.z), "v"(c4.w));
           if (__ballot(valid) == 0ull) continue;
           const float alpha_v = valid ? alpha : 0.f;
           const float ra = __builtin_amdgcn_rcpf(1.f - alpha_v);
@@ -255,7 +258,7 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
             const float val = wave_reduce9_scattered(v8, g_op);
             if (atom_lane) {
               if constexpr (PACKED && SMALL) {
-                const unsigned off = __float_as_uint(b4.w) | ((unsigned)slot9 * 4u);
+                const unsigned off = __float_as_uint(c4.w) | ((unsigned)slot9 * 4u);
                 atomicAdd(reinterpret_cast<float *>(reinterpret_cast<char *>(v_colors) + off), val);
               } else {
                 atomicAdd(out_base9 + (int64_t)s_id[tt] * out_stride9, val);

@@ -16,7 +16,7 @@ struct LossFinal {
 // SO_RASTER_V2 (round 3): the RGB passes of both rasteriser kernels on packed fp32 pairs (v_pk_mul / v_pk_fma are the
 // only vector instructions that do two lanes-worth per issue slot on gfx950 -- SQ_ACTIVE_INST_VALU prices every other one
 // of these kernels at ~4 cycles per wave64), staged records laid out so that (ca, cb) and (cb, cc) are register pairs:
-//   s_A = (x, y, ca, cb)   s_B = (cb, cc, opacity, -)   s_C = (red, green, blue, -)
+//   s_A = (x, y, ca, cb)   s_B = (cb, cc, opacity, cull threshold)   s_C = (red, green, blue, record offset [bwd])
 // and ONE statement of the Gaussian's exponent shared by the forward and the backward, so that both take the same
 // alpha >= 1/255 decision bit for bit:  q = Q d,  2 sigma = d . q,  exp(-sigma) = 2^(-(log2 e / 2) 2 sigma).
 #ifndef SO_RASTER_V2
@@ -143,15 +143,22 @@ __device__ __forceinline__ float4 alpha_bound_box(float x, float y, float opac, 
 // tau = ln(255 opac), with the same conservative padding as alpha_bound_box.  Evaluated by ONE lane
 // per candidate Gaussian in the ballot phase (so its cost is amortised over 64 pixels); culls the
 // bounding-box corners the box test lets through.
-__device__ __forceinline__ bool ellipse_hits_rect(float mx, float my, float opac, float ca, float cb, float cc,
-                                                  float x0, float x1, float y0, float y1) {
-  if (!(opac * 255.f >= 0.999f)) return false;
+// Split in two since round 3: what depends on the Gaussian alone (the threshold, and the two answers that need no geometry)
+// is computed once per Gaussian -- by the kernel that writes the 64-byte record, or when the list entry is staged -- and
+// what depends on the rectangle runs per (wave, candidate).
+__device__ __forceinline__ float cull_tau(float opac, float ca, float cb, float cc) {
+  const float inf = __builtin_inff();
+  if (!(opac * 255.f >= 0.999f)) return -inf;                      // can never contribute: no rectangle is hit
   const float det = ca * cc - cb * cb;
-  if (!(det > 0.f) || !(ca > 0.f) || !(cc > 0.f)) return true;   // degenerate conic: never cull
+  if (!(det > 0.f) || !(ca > 0.f) || !(cc > 0.f)) return inf;      // degenerate conic: never cull
   const float tau = fmaxf(__logf(opac * 255.f), 0.f) * 1.0001f + 1e-4f;
+  return tau * 1.0005f + 1e-3f;
+}
+
+__device__ __forceinline__ bool ellipse_hits_rect(float mx, float my, float tau, float ca, float cb, float cc,
+                                                  float x0, float x1, float y0, float y1) {
   // translate so the Gaussian centre is the origin; pad the rectangle by 0.01 px
   const float ax0 = x0 - mx - 0.01f, ax1 = x1 - mx + 0.01f, ay0 = y0 - my - 0.01f, ay1 = y1 - my + 0.01f;
-  if (ax0 <= 0.f && ax1 >= 0.f && ay0 <= 0.f && ay1 >= 0.f) return true;   // centre inside
   // minimum over each edge of the convex quadratic: 1-D parabola, clamp the unconstrained minimiser
   float best = __builtin_inff();
   {  // edges x = ax0 / ax1:  sigma(y) = 1/2 (ca x^2 + cc y^2) + cb x y,  y* = -cb x / cc
@@ -174,7 +181,8 @@ __device__ __forceinline__ bool ellipse_hits_rect(float mx, float my, float opac
       best = fminf(best, 0.5f * (ca * x * x + cc * y * y) + cb * x * y);
     }
   }
-  return best <= tau * 1.0005f + 1e-3f;
+  if (ax0 <= 0.f && ax1 >= 0.f && ay0 <= 0.f && ay1 >= 0.f) best = 0.f;   // centre inside
+  return best <= tau;                                                      // (+inf: always, -inf: never)
 }
 
 }  // namespace so

@@ -115,11 +115,12 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         s_A[tid] = q0;
         s_box[tid] = bx;
 #if SO_RASTER_V2
-        s_B[tid] = make_float4(q0.w, q1.x, q1.y, 0.f);                                          // cb, cc, opacity
-        s_C[tid] = make_float4(q1.z, q1.w, reinterpret_cast<const float *>(r4 + 2)[0], 0.f);    // red, green, blue
+        const float4 q2 = r4[2];                                    // blue, depth, radius, cull threshold
+        s_B[tid] = make_float4(q0.w, q1.x, q1.y, q2.w);             // cb, cc, opacity, cull threshold
+        s_C[tid] = make_float4(q1.z, q1.w, q2.x, 0.f);              // red, green, blue
 #else
         s_B[tid] = q1;
-        s_C[tid].x = reinterpret_cast<const float *>(r4 + 2)[0];
+        s_C[tid] = make_float4(r4[2].x, r4[2].w, 0.f, 0.f);         // blue, cull threshold
 #endif
       } else {
         float2 xy = means2d[g];
@@ -130,14 +131,14 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         s_box[tid] = alpha_bound_box(xy.x, xy.y, op, ca, cb, cc);
         if (D == 3) {
 #if SO_RASTER_V2
-          s_B[tid] = make_float4(cb, cc, op, 0.f);
+          s_B[tid] = make_float4(cb, cc, op, cull_tau(op, ca, cb, cc));
           s_C[tid] = make_float4(colors[(int64_t)g * D], colors[(int64_t)g * D + 1], colors[(int64_t)g * D + 2], 0.f);
 #else
           s_B[tid] = make_float4(cc, op, colors[(int64_t)g * D], colors[(int64_t)g * D + 1]);
-          s_C[tid].x = colors[(int64_t)g * D + 2];
+          s_C[tid] = make_float4(colors[(int64_t)g * D + 2], cull_tau(op, ca, cb, cc), 0.f, 0.f);
 #endif
         } else {
-          s_B[tid] = make_float4(cc, op, 0.f, 0.f);
+          s_B[tid] = make_float4(cc, op, cull_tau(op, ca, cb, cc), 0.f);
 #pragma unroll
           for (int k = 0; k < D; ++k) s_col[tid * DC + k] = colors[(int64_t)g * D + k];
         }
@@ -159,8 +160,10 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         if (hit) {   // bounding boxes overlap: settle it with the exact ellipse-rectangle test
           const float4 a = s_A[cand];
           const float4 bq = s_B[cand];
-          if (D == 3 && SO_RASTER_V2) hit = ellipse_hits_rect(a.x, a.y, bq.z, a.z, a.w, bq.y, qx0, qx1, qy0, qy1);
-          else hit = ellipse_hits_rect(a.x, a.y, bq.y, a.z, a.w, bq.x, qx0, qx1, qy0, qy1);
+          // (x, y, cull threshold of this Gaussian, conic) against this wave's quadrant
+          if (D == 3 && SO_RASTER_V2) hit = ellipse_hits_rect(a.x, a.y, bq.w, a.z, a.w, bq.y, qx0, qx1, qy0, qy1);
+          else if (D == 3) hit = ellipse_hits_rect(a.x, a.y, s_C[cand].y, a.z, a.w, bq.x, qx0, qx1, qy0, qy1);
+          else hit = ellipse_hits_rect(a.x, a.y, bq.z, a.z, a.w, bq.x, qx0, qx1, qy0, qy1);
         }
       }
       unsigned long long mask = __ballot(hit);
