@@ -103,9 +103,7 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
   int32_t bin_final = (int32_t)lo - 1;
   if (inside && T_final < 1.f) bin_final = last_ids[pix];
   // wave / block maxima
-  int32_t wave_last = bin_final;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, d, 64));
+  const int32_t wave_last = wave_max_i32(bin_final);   // wave-uniform (scalar)
   if (lane == 0) s_wave_last[wid] = wave_last;
   __syncthreads();
   int32_t block_last = s_wave_last[0];

@@ -63,6 +63,23 @@ __device__ __forceinline__ float dpp_mov(float old, float v) {
 #endif
 }
 
+// Maximum of an int over the 64 lanes as a wave-uniform value (scalar register): four rotations inside the rows, then the
+// four row results read from lanes 0 / 16 / 32 / 48 -- 8 vector instructions and no LDS hardware, against 36 + six
+// ds_bpermute for the __shfl_xor ladder hipcc builds.  EXEC must be all ones.
+__device__ __forceinline__ int wave_max_i32(int x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false));    // quad_perm:[1,0,3,2]
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false));    // quad_perm:[2,3,0,1]
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x124, 0xf, 0xf, false));   // row_ror:4
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, 0xf, false));   // row_ror:8
+  const int a = __builtin_amdgcn_readlane(x, 0), b = __builtin_amdgcn_readlane(x, 16);
+  const int c = __builtin_amdgcn_readlane(x, 32), d = __builtin_amdgcn_readlane(x, 48);
+  return max(max(a, b), max(c, d));
+#else
+  return x;
+#endif
+}
+
 // Sum over the 64 lanes; the total lands in lane 63.
 __device__ __forceinline__ float wave_reduce_sum_to_last(float v) {
   // row_shr:1,2,3 within rows of 16 (classic GCN reduction), then row_shr:4 / 8, then row_bcast

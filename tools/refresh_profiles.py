@@ -40,7 +40,7 @@ for a, b in pairs:
     else:
         print("MISSING", a)
 d = json.load(open(os.path.join(dst, f"{tag}_engine_pmc_traffic.json")))
-names = {"so_rasterize_bwd": "void so::k_rasterize_bwd<3, 16, false, true>", "so_rasterize_fwd": "void so::k_rasterize_fwd<3, 16, true>",
+names = {"so_rasterize_bwd": "void so::k_rasterize_bwd<3, 16, false, true, true>", "so_rasterize_fwd": "void so::k_rasterize_fwd<3, 16, true>",
          "so_adam_step_dev": "so::k_adam_dev", "so_ssim_l1_fwd": "void so::k_ssim_l1_fwd<3>", "so_ssim_l1_bwd": "void so::k_ssim_l1_bwd<3>",
          "so_ssim_l1_fused": "void so::k_ssim_l1_fused<3>",
          "so_preprocess_fwd": "void so::k_preprocess_fwd<3, so::AttrSoA, false>",
