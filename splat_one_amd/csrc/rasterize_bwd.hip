@@ -456,6 +456,9 @@ int so::rasterize_bwd_packed_launch(int C, int N, int width, int height, int til
   tile_size = so::tile_size_of(tile_size);
   SO_REQUIRE(tile_size == 16 || tile_size == 8, "so_rasterize_bwd_packed: tile_size %d not in {8,16}", tile_size);
   SO_REQUIRE(!wrap_flags || width % tile_size == 0, "so_rasterize_bwd_packed: SO_TILE_WRAP_* needs width %% tile_size == 0");
+  // the fused step's loss scalars are written by this kernel's first thread: a skipped launch would leave the previous
+  // iteration's values behind (so_train_step_fwd_bwd rejects empty problems before it gets here; keep it that way)
+  SO_REQUIRE(!fin.sums || (C > 0 && N > 0), "so_rasterize_bwd_packed: the loss scalars need a launch (C = %d, N = %d)", C, N);
   if (C == 0 || N == 0) return SO_OK;
   SO_REQUIRE(rec && isect_offsets && render_alphas && last_ids && v_render_colors && v_render_alphas && vrec,
              "so_rasterize_bwd_packed: null pointer");
