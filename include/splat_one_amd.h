@@ -325,8 +325,11 @@ int so_adam_step_dev_shadow(int n_groups, const so_adam_group *host_groups, cons
  * Backward overwrites v_means, v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN and adds
  * to grad2d[N] / count[N] (nullable pair).  v_means2d_abs / v_depths nullable.
  * Packed records (64-byte aligned, nullable): the forward also writes rec[C*N][16] =
- *   {x, y, conic a, b, c, opacity, r, g, b, depth, radius bits, 0...} (one cache line per Gaussian
- *   for the rasteriser's gathers) and zeroes vrec[C*N][16]; so_rasterize_bwd_packed accumulates
+ *   {x, y, conic a, b, c, opacity, r, g, b, depth, radius bits, cull threshold, cull box xmin, xmax, ymin, ymax}
+ *   (one cache line per Gaussian for the rasteriser's gathers; slots 11..15, round 3, are the rasterisers' own culling
+ *   data -- the threshold of the exact quadrant test and the box of the alpha >= 1/255 region, computed once per
+ *   Gaussian here or by so_rec_pack: records for the packed rasterisers must come from one of these two) and zeroes
+ *   vrec[C*N][16]; so_rasterize_bwd_packed accumulates
  *   {v_x, v_y, v_ca, v_cb, v_cc, v_r, v_g, v_b, v_opacity, abs_x, abs_y, 0...} there and the backward
  *   reads them from `vrec` instead of the five separate v_* arrays.
  * cam_stride (0 = N): row stride between cameras of every per-view array and of rec / vrec -- lets a
