@@ -76,6 +76,9 @@ int so_camera_inverse(int C, const float *camtoworlds, float *viewmats, void *st
 int so_debug_wave_reduce(int n_waves, const float *in, float *out, void *stream);
 /* test hook for the rasteriser backward's nine-sum network (round 3): in[n_waves*64,9] -> out[n_waves,9] */
 int so_debug_wave_reduce9(int n_waves, const float *in, float *out, void *stream);
+/* test hook for the rasterisers' per-quadrant culling: in[n][10] = {mx, my, opacity, conic a, b, c, x0, x1, y0, y1}
+ * -> out[n][2] = {box test, exact test} as 0 / 1 */
+int so_debug_cull(int64_t n, const float *in, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K1/K2  3D -> 2D EWA projection.   Replaces gsplat `fully_fused_projection` (legacy

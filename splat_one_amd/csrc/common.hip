@@ -1,5 +1,6 @@
 // common.hip -- error channel and device queries of libsplat_one_amd.so
 #include "so_common.hpp"
+#include "rasterize_common.hpp"
 
 namespace so {
 static thread_local char g_err[512] = "";
@@ -59,6 +60,29 @@ extern "C" int so_debug_wave_reduce9(int n_waves, const float *in, float *out, v
   if (n_waves == 0) return SO_OK;
   hipLaunchKernelGGL(so::k_debug_wave_reduce9, dim3(n_waves), dim3(64), 0, so::as_stream(stream), in, out);
   return so::check_launch("so_debug_wave_reduce9");
+}
+
+namespace so {
+__global__ void k_debug_cull(int64_t n, const float *__restrict__ in, float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float *p = in + 10 * i;   // mx, my, opacity, ca, cb, cc, x0, x1, y0, y1
+  const float tau = cull_tau(p[2], p[3], p[4], p[5]);
+  const float4 box = alpha_bound_box(p[0], p[1], p[2], p[3], p[4], p[5]);
+  const bool box_hit = !(box.y < p[6] || box.x > p[7] || box.w < p[8] || box.z > p[9]);
+  out[2 * i] = box_hit ? 1.f : 0.f;
+  out[2 * i + 1] = ellipse_hits_rect(p[0], p[1], tau, p[3], p[4], p[5], p[6], p[7], p[8], p[9]) ? 1.f : 0.f;
+}
+}  // namespace so
+
+/* test hook for the rasterisers' per-quadrant culling: in[n][10] = {mx, my, opacity, conic a, b, c, rectangle x0, x1, y0, y1}
+ * (pixel centres) -> out[n][2] = {the box test, the exact test} as 0 / 1 (tests/test_gpu_ops.py checks both against a
+ * float64 minimisation: neither may miss a rectangle in which alpha reaches 1/255) */
+extern "C" int so_debug_cull(int64_t n, const float *in, float *out, void *stream) {
+  SO_REQUIRE(n >= 0 && (n == 0 || (in && out)), "so_debug_cull: bad arguments");
+  if (n == 0) return SO_OK;
+  hipLaunchKernelGGL(so::k_debug_cull, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, so::as_stream(stream), n, in, out);
+  return so::check_launch("so_debug_cull");
 }
 
 /* in[n_waves*64, 9] -> out[n_waves, 10] (zeroed by the caller): slots 0..7 += transposing butterfly

@@ -159,30 +159,29 @@ __device__ __forceinline__ bool ellipse_hits_rect(float mx, float my, float tau,
                                                   float x0, float x1, float y0, float y1) {
   // translate so the Gaussian centre is the origin; pad the rectangle by 0.01 px
   const float ax0 = x0 - mx - 0.01f, ax1 = x1 - mx + 0.01f, ay0 = y0 - my - 0.01f, ay1 = y1 - my + 0.01f;
-  // minimum over each edge of the convex quadratic: 1-D parabola, clamp the unconstrained minimiser
-  float best = __builtin_inff();
-  {  // edges x = ax0 / ax1:  sigma(y) = 1/2 (ca x^2 + cc y^2) + cb x y,  y* = -cb x / cc
-    const float xs[2] = {ax0, ax1};
+  // The minimum over the rectangle of a convex quadratic whose own minimum (the centre, sigma = 0) lies outside it is on an
+  // edge the centre can see -- sigma grows along every ray from the centre, so the first point of the rectangle a ray meets
+  // beats everything behind it: at most ONE vertical and ONE horizontal edge (round 3; all four were evaluated before).
+  // On an edge: 1-D parabola, clamp the unconstrained minimiser.
+  const float inf = __builtin_inff();
+  const bool in_x = ax0 <= 0.f && ax1 >= 0.f, in_y = ay0 <= 0.f && ay1 >= 0.f;
+  float best;
+  {  // edge x = xe:  sigma(y) = 1/2 (ca xe^2 + cc y^2) + cb xe y,  y* = -cb xe / cc
+    const float xe = ax0 > 0.f ? ax0 : ax1;
     const float rcc = __builtin_amdgcn_rcpf(cc);   // (1-ulp reciprocal: the test is padded by 1e-3, and a division is 12 instructions)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float x = xs[i];
-      const float y = fminf(fmaxf(-cb * x * rcc, ay0), ay1);
-      best = fminf(best, 0.5f * (ca * x * x + cc * y * y) + cb * x * y);
-    }
+    const float y = fminf(fmaxf(-cb * xe * rcc, ay0), ay1);
+    const float sv = 0.5f * (ca * xe * xe + cc * y * y) + cb * xe * y;
+    best = in_x ? inf : sv;
   }
-  {  // edges y = ay0 / ay1
-    const float ys[2] = {ay0, ay1};
+  {  // edge y = ye
+    const float ye = ay0 > 0.f ? ay0 : ay1;
     const float rca = __builtin_amdgcn_rcpf(ca);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float y = ys[i];
-      const float x = fminf(fmaxf(-cb * y * rca, ax0), ax1);
-      best = fminf(best, 0.5f * (ca * x * x + cc * y * y) + cb * x * y);
-    }
+    const float x = fminf(fmaxf(-cb * ye * rca, ax0), ax1);
+    const float sh = 0.5f * (ca * x * x + cc * ye * ye) + cb * x * ye;
+    best = fminf(best, in_y ? inf : sh);
   }
-  if (ax0 <= 0.f && ax1 >= 0.f && ay0 <= 0.f && ay1 >= 0.f) best = 0.f;   // centre inside
-  return best <= tau;                                                      // (+inf: always, -inf: never)
+  if (in_x && in_y) best = 0.f;   // centre inside
+  return !(best > tau);   // (+inf: always, -inf: never; a NaN -- non-finite conic -- is never culled, as before the split)
 }
 
 }  // namespace so

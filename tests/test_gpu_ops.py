@@ -361,6 +361,60 @@ def test_wave_reduce9_network(dev):
     assert torch.equal(out.cpu().double(), ref), (out.cpu()[:2], ref[:2])
 
 
+def test_quadrant_cull_never_misses(dev):
+    """The rasterisers' per-(wave, candidate) culling -- the box of the alpha >= 1/255 region, then the exact test (minimum of
+    sigma over the quadrant's pixel-centre rectangle on the ONE vertical and ONE horizontal edge the centre can see) --
+    against a float64 minimisation over all four edges plus a dense sample of the rectangle: neither test may reject a
+    rectangle in which alpha reaches 1/255 (a miss would silently drop a contribution), and the exact test must not
+    accept rectangles that are clearly outside (it would only cost passes, but then it is not doing its job)."""
+    import numpy as np
+    from splat_one_amd import _lib
+    rng = np.random.default_rng(5)
+    n = 200_000
+    # conics of random ellipses (radii 0.3 .. 40 px, any orientation), centres around an 8x8-pixel rectangle
+    r1, r2 = np.exp(rng.uniform(np.log(0.3), np.log(40.0), (2, n)))
+    th = rng.uniform(0, np.pi, n)
+    c, s_ = np.cos(th), np.sin(th)
+    ia, ib = 1.0 / r1 ** 2, 1.0 / r2 ** 2
+    ca, cb, cc = c * c * ia + s_ * s_ * ib, c * s_ * (ia - ib), s_ * s_ * ia + c * c * ib
+    op = np.where(rng.random(n) < 0.1, rng.uniform(0.0, 0.01, n), rng.uniform(0.004, 1.0, n))
+    x0 = rng.integers(0, 200, n) + 0.5
+    y0 = rng.integers(0, 200, n) + 0.5
+    x1, y1 = x0 + 7.0, y0 + 7.0
+    reach = np.maximum(r1, r2) * 4 + 12
+    mx = x0 + 3.5 + rng.uniform(-1, 1, n) * reach
+    my = y0 + 3.5 + rng.uniform(-1, 1, n) * reach
+    rows = np.stack([mx, my, op, ca, cb, cc, x0, x1, y0, y1], 1).astype(np.float32)
+    inp = torch.from_numpy(rows).to(dev)
+    out = torch.empty(n, 2, device=dev)
+    _lib.call("so_debug_cull", n, _lib.ptr(inp), _lib.ptr(out), _lib.stream())
+    box_hit, exact_hit = (out[:, 0] > 0).cpu().numpy(), (out[:, 1] > 0).cpu().numpy()
+    # float64 truth on the float32 inputs: minimum of sigma over the rectangle
+    mx, my, op, ca, cb, cc, x0, x1, y0, y1 = rows.astype(np.float64).T
+    ax0, ax1, ay0, ay1 = x0 - mx, x1 - mx, y0 - my, y1 - my
+
+    def sig(x, y):
+        return 0.5 * (ca * x * x + cc * y * y) + cb * x * y
+    best = np.full(n, np.inf)
+    for xe in (ax0, ax1):
+        best = np.minimum(best, sig(xe, np.clip(-cb * xe / cc, ay0, ay1)))
+    for ye in (ay0, ay1):
+        best = np.minimum(best, sig(np.clip(-cb * ye / ca, ax0, ax1), ye))
+    best = np.where((ax0 <= 0) & (ax1 >= 0) & (ay0 <= 0) & (ay1 >= 0), 0.0, best)
+    for fx in np.linspace(0, 1, 8):          # the pixel centres themselves: what the rasteriser evaluates
+        for fy in np.linspace(0, 1, 8):
+            assert (sig(ax0 + 7 * fx, ay0 + 7 * fy) >= best * (1 - 1e-12) - 1e-12).all()
+    with np.errstate(divide="ignore"):
+        tau = np.log(255.0 * op)             # alpha >= 1/255  <=>  sigma <= tau
+    reaches = (op * 255.0 >= 1.0) & (best <= tau)
+    assert reaches.sum() > 20_000 and (~reaches).sum() > 20_000
+    assert not (reaches & ~box_hit).any(), "the box test rejected a rectangle that is hit"
+    assert not (reaches & ~exact_hit).any(), "the exact test rejected a rectangle that is hit"
+    clearly_out = (op * 255.0 < 0.99) | (best > tau * 1.01 + 0.05)
+    assert not (clearly_out & exact_hit).any(), "the exact test accepted a rectangle that is clearly missed"
+    assert (box_hit & ~exact_hit).sum() > 1000      # it does remove what the box lets through
+
+
 def test_camera_inverse(dev):
     from splat_one_amd import _lib
     from splat_one_amd.scene import ring_cameras
