@@ -139,6 +139,10 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
   } else if (D == 3) {
     out_base9 = v_colors + slot9; out_stride9 = 16;
   }
+  // what undoes the units of the staged conic on the reduced sums: 2 ln 2 on the mean2d slots (and their absolute
+  // values), the 1/2 of dL/d(ca, cc) -- by slot, for the lanes of either reduction
+  const float unscale9 = slot9 < 2 ? kConicUnscale : ((slot9 == 2 || slot9 == 4) ? 0.5f : 1.f);
+  const float unscale = (slot < 2 || slot == 9 || slot == 10) ? kConicUnscale : ((slot == 2 || slot == 4) ? 0.5f : 1.f);
   const bwd_v2f pxy = {px, py};
   float behind = tf_bg;   // tf_bg - buf_dot of the scalar form below
 
@@ -157,15 +161,17 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
           const float shift = wrap_w * rintf((q0.x - wrap_cx) / wrap_w);
           q0.x -= shift; bx.x -= shift; bx.y -= shift;
         }
-        s_A[tid] = q0;
         s_box[tid] = bx;
 #if SO_BWD_V2
         // (x, y, ca, cb) | (cb, cc, opacity) | (red, green, blue): (ca, cb) and (cb, cc) are aligned register pairs after the loads
         // s_C.w: the byte offset of this Gaussian's gradient record, so that the atomic's address needs no further LDS read
         const float4 q2 = r4[2];                                    // blue, depth, radius, cull threshold
-        s_B[tid] = make_float4(q0.w, q1.x, q1.y, q2.w);
+        q0.z *= kConicScale; q0.w *= kConicScale;                   // conic and threshold in units of the exponent of 2 (as the forward)
+        s_A[tid] = q0;
+        s_B[tid] = make_float4(q0.w, q1.x * kConicScale, q1.y, q2.w * kConicScale);
         s_C[tid] = make_float4(q1.z, q1.w, q2.x, __uint_as_float((unsigned)g * 64u));
 #else
+        s_A[tid] = q0;
         s_B[tid] = q1;
         s_C[tid] = make_float4(r4[2].x, r4[2].w, 0.f, 0.f);         // blue, cull threshold
 #endif
@@ -174,11 +180,11 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         if (wrap) xy.x -= wrap_w * rintf((xy.x - wrap_cx) / wrap_w);
         const float op = opacities[g];
         const float ca = conics[3 * (int64_t)g], cb = conics[3 * (int64_t)g + 1], cc = conics[3 * (int64_t)g + 2];
-        s_A[tid] = make_float4(xy.x, xy.y, ca, cb);
+        s_A[tid] = (D == 3 && SO_BWD_V2) ? make_float4(xy.x, xy.y, ca * kConicScale, cb * kConicScale) : make_float4(xy.x, xy.y, ca, cb);
         s_box[tid] = alpha_bound_box(xy.x, xy.y, op, ca, cb, cc);
         if (D == 3) {
 #if SO_BWD_V2
-          s_B[tid] = make_float4(cb, cc, op, cull_tau(op, ca, cb, cc));
+          s_B[tid] = make_float4(cb * kConicScale, cc * kConicScale, op, cull_tau(op, ca, cb, cc) * kConicScale);
           s_C[tid] = make_float4(colors[(int64_t)g * D], colors[(int64_t)g * D + 1], colors[(int64_t)g * D + 2], 0.f);
 #else
           s_B[tid] = make_float4(cc, op, colors[(int64_t)g * D], colors[(int64_t)g * D + 1]);
@@ -224,7 +230,7 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
           const bwd_v2f d = bwd_v2f{a.x, a.y} - pxy;
           // q = Q d = (ca dx + cb dy, cb dx + cc dy):  sigma = 1/2 d.q,  d sigma / d mean = q
           const bwd_v2f q = conic_times(a.z, a.w, b4.x, b4.y, d);
-          const float s2 = fmaf(q.y, d.y, q.x * d.x);                       // 2 sigma
+          const float s2 = fmaf(q.y, d.y, q.x * d.x);                       // sigma log2(e): the staged conic is pre-scaled
           const float vis = gauss_vis(s2);                                  // exp(-sigma), bit for bit the forward's
           const float ov = b4.z * vis;
           const float alpha = fminf(kAlphaMax, ov);
@@ -246,14 +252,15 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
           const float v_sigma = -ov * v_alpha;
           const float g_op = vis * v_alpha;
           const bwd_v2f vs2 = {v_sigma, v_sigma};
-          const bwd_v2f gxy = vs2 * q;                                      // d L / d mean2d
+          // per pixel in the staged units, put right once per pass on the reduced sums (unscale9 / unscale below)
+          const bwd_v2f gxy = vs2 * q;                                      // k d L / d mean2d
           const bwd_v2f t = vs2 * d;
-          const bwd_v2f gcxz = (t * d) * bwd_v2f{0.5f, 0.5f};               // d L / d (ca, cc)
+          const bwd_v2f gcxz = t * d;                                       // 2 d L / d (ca, cc)
           const float g_cy = t.x * d.y;                                     // d L / d cb
           const float v8[8] = {gxy.x, gxy.y, gcxz.x, g_cy, gcxz.y, g01.x, g01.y, g2};
           if constexpr (!ABS) {
             // nine sums over the wave as one network (so_common.hpp): nine lanes, ONE atomic instruction, nine addresses
-            const float val = wave_reduce9_scattered(v8, g_op);
+            const float val = wave_reduce9_scattered(v8, g_op) * unscale9;
             if (atom_lane) {
               if constexpr (PACKED && SMALL) {
                 const unsigned off = __float_as_uint(c4.w) | ((unsigned)slot9 * 4u);
@@ -272,7 +279,7 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
             if (l15 == 9) val = r_ax;
             if (l15 == 10) val = r_ay;
           }
-          val = rows_combine(val);
+          val = rows_combine(val) * unscale;
           if (lane <= (ABS ? 10 : 8) && val != 0.f) {
             if constexpr (PACKED && SMALL) {
               // one 64-byte record per Gaussian: 32-bit byte offset from the uniform base (C N 64 B < 4 GB, checked by the launcher)

@@ -18,7 +18,7 @@ struct LossFinal {
 // of these kernels at ~4 cycles per wave64), staged records laid out so that (ca, cb) and (cb, cc) are register pairs:
 //   s_A = (x, y, ca, cb)   s_B = (cb, cc, opacity, cull threshold)   s_C = (red, green, blue, record offset [bwd])
 // and ONE statement of the Gaussian's exponent shared by the forward and the backward, so that both take the same
-// alpha >= 1/255 decision bit for bit:  q = Q d,  2 sigma = d . q,  exp(-sigma) = 2^(-(log2 e / 2) 2 sigma).
+// alpha >= 1/255 decision bit for bit:  q = (k Q) d,  s = d . q,  exp(-sigma) = 2^(-s)  (k = log2 e / 2, see kConicScale).
 #ifndef SO_RASTER_V2
 #define SO_RASTER_V2 1
 #endif
@@ -27,11 +27,16 @@ __device__ __forceinline__ raster_v2f conic_times(float ca, float cb0, float cb1
   raster_v2f q = raster_v2f{ca, cb0} * raster_v2f{d.x, d.x};
   return __builtin_elementwise_fma(raster_v2f{cb1, cc}, raster_v2f{d.y, d.y}, q);      // (ca dx + cb dy, cb dx + cc dy)
 }
-__device__ __forceinline__ float gauss_vis(float two_sigma) {
+// The staged conic and cull threshold of the RGB passes are pre-multiplied by log2(e) / 2 (round 3): d . (k Q) d is the
+// exponent of 2 directly -- one multiplication less per pass in both kernels -- and the backward undoes the factor once per
+// pass on the nine reduced sums (k on the mean2d slots; the 1/2 of dL/d(ca, cc) rides on the same multiplication).
+constexpr float kConicScale = 0.72134752044448170368f;        // log2(e) / 2
+constexpr float kConicUnscale = 1.38629436111989061883f;      // 2 ln 2
+__device__ __forceinline__ float gauss_vis(float scaled_two_sigma) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return __builtin_amdgcn_exp2f(two_sigma * -0.72134752044448170368f);
+  return __builtin_amdgcn_exp2f(-scaled_two_sigma);
 #else
-  return exp2f(two_sigma * -0.72134752044448170368f);
+  return exp2f(-scaled_two_sigma);
 #endif
 }
 

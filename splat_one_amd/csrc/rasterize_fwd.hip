@@ -112,13 +112,15 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
           const float shift = wrap_w * rintf((q0.x - wrap_cx) / wrap_w);
           q0.x -= shift; bx.x -= shift; bx.y -= shift;
         }
-        s_A[tid] = q0;
         s_box[tid] = bx;
 #if SO_RASTER_V2
         const float4 q2 = r4[2];                                    // blue, depth, radius, cull threshold
-        s_B[tid] = make_float4(q0.w, q1.x, q1.y, q2.w);             // cb, cc, opacity, cull threshold
+        q0.z *= kConicScale; q0.w *= kConicScale;                   // conic and threshold in units of the exponent of 2
+        s_A[tid] = q0;
+        s_B[tid] = make_float4(q0.w, q1.x * kConicScale, q1.y, q2.w * kConicScale);   // cb, cc, opacity, cull threshold
         s_C[tid] = make_float4(q1.z, q1.w, q2.x, 0.f);              // red, green, blue
 #else
+        s_A[tid] = q0;
         s_B[tid] = q1;
         s_C[tid] = make_float4(r4[2].x, r4[2].w, 0.f, 0.f);         // blue, cull threshold
 #endif
@@ -127,11 +129,11 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         if (wrap) xy.x -= wrap_w * rintf((xy.x - wrap_cx) / wrap_w);
         const float op = opacities[g];
         const float ca = conics[3 * (int64_t)g], cb = conics[3 * (int64_t)g + 1], cc = conics[3 * (int64_t)g + 2];
-        s_A[tid] = make_float4(xy.x, xy.y, ca, cb);
+        s_A[tid] = (D == 3 && SO_RASTER_V2) ? make_float4(xy.x, xy.y, ca * kConicScale, cb * kConicScale) : make_float4(xy.x, xy.y, ca, cb);
         s_box[tid] = alpha_bound_box(xy.x, xy.y, op, ca, cb, cc);
         if (D == 3) {
 #if SO_RASTER_V2
-          s_B[tid] = make_float4(cb, cc, op, cull_tau(op, ca, cb, cc));
+          s_B[tid] = make_float4(cb * kConicScale, cc * kConicScale, op, cull_tau(op, ca, cb, cc) * kConicScale);
           s_C[tid] = make_float4(colors[(int64_t)g * D], colors[(int64_t)g * D + 1], colors[(int64_t)g * D + 2], 0.f);
 #else
           s_B[tid] = make_float4(cc, op, colors[(int64_t)g * D], colors[(int64_t)g * D + 1]);
@@ -181,7 +183,7 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
           const float4 c4 = s_C[tt];                // red, green, blue (issued with the other two reads, not at its use)
           const raster_v2f d = raster_v2f{a.x, a.y} - pxy;
           const raster_v2f q = conic_times(a.z, a.w, b4.x, b4.y, d);
-          const float s2 = fmaf(q.y, d.y, q.x * d.x);                       // 2 sigma: the backward recomputes exactly this
+          const float s2 = fmaf(q.y, d.y, q.x * d.x);                       // sigma log2(e) (pre-scaled conic): the backward recomputes exactly this
           float alpha = fminf(kAlphaMax, b4.z * gauss_vis(s2));
           alpha = (s2 < 0.f || alpha < kAlphaMin) ? 0.f : alpha;            // skipped Gaussian == zero alpha (one select)
           // T_live is the transmittance while the pixel is live and 0 afterwards (every later contribution vanishes
