@@ -105,8 +105,11 @@ k_step_inputs(int C, const float *__restrict__ c2w, const float *__restrict__ Ks
   // (n_isects, overflow), read by one thread before that pair is zeroed, so no other workgroup races it
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += (int64_t)gridDim.x * blockDim.x)
     if (!status_out || (i != status_at && i != status_at + 1)) counters[i] = 0u;
-  if (blockIdx.x != 0) return;
-  if (status_out && threadIdx.x == 0) {
+  // three independent jobs on three workgroups (when the grid has them), so that the kernel lasts as long as the longest of
+  // them and not as long as their sum: the status report waits for its stores to reach host memory, the schedule runs
+  // three double-precision pow() per group
+  const unsigned b_status = gridDim.x > 1 ? 1u : 0u, b_sched = gridDim.x > 2 ? 2u : 0u;
+  if (blockIdx.x == b_status && status_out && threadIdx.x == 0) {
     const int32_t n_prev = (int32_t)counters[status_at], ov_prev = (int32_t)counters[status_at + 1];
     if (status_at < n_zero) counters[status_at] = 0u;
     if (status_at + 1 < n_zero) counters[status_at + 1] = 0u;
@@ -115,11 +118,14 @@ k_step_inputs(int C, const float *__restrict__ c2w, const float *__restrict__ Ks
     __threadfence_system();
     status_out[2] = seq;      // written last: the host trusts [0], [1] once it sees its own sequence number here
   }
-  for (int c = threadIdx.x; c < C; c += blockDim.x) camera_inverse_one(c2w + 16 * c, w2c + 16 * c);
-  if (Ks_dst)
-    for (int i = threadIdx.x; i < 9 * C; i += blockDim.x) Ks_dst[i] = Ks_src[i];
-  if (pixels_slot && threadIdx.x == 0) *pixels_slot = pixels;
-  if (n_groups > 0) adam_schedule_block(sch.lr0, sch.lr_gamma, n_groups, beta1, beta2, step_ptr, reinterpret_cast<float2 *>(step_ptr + 2));
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) camera_inverse_one(c2w + 16 * c, w2c + 16 * c);
+    if (Ks_dst)
+      for (int i = threadIdx.x; i < 9 * C; i += blockDim.x) Ks_dst[i] = Ks_src[i];
+    if (pixels_slot && threadIdx.x == 0) *pixels_slot = pixels;
+  }
+  if (blockIdx.x == b_sched && n_groups > 0)   // (block-uniform: adam_schedule_block has a barrier)
+    adam_schedule_block(sch.lr0, sch.lr_gamma, n_groups, beta1, beta2, step_ptr, reinterpret_cast<float2 *>(step_ptr + 2));
 }
 
 static inline void zero_async(void *p, int64_t n_words, hipStream_t st) {
