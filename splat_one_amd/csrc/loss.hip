@@ -491,6 +491,7 @@ struct FusedState {
   v2f r2a[kWin];     // stage 2: blur_x of (g_mu, dm_dE) per derivative row
   float r2b[kWin];   //          blur_x of dm_dB2
   float l1_acc, ss_acc;
+  float xo, yo;      // the two images at this thread's float of the row the CURRENT step emits, loaded during the previous step
 };
 
 struct FusedOut {
@@ -517,12 +518,23 @@ __device__ __forceinline__ void fused_step(FusedState<CH> &S, FwdStage<CH> &preA
     preA = preB;
     fwd_gload<CH>(preB, g, img1, img2, H, W * CH, y0 - 2 * kHalf + it + 3);
   }
-  float xv = 0.f, yv = 0.f;
+  // The output row's own pixel values (the gradient needs x and y at the centre) are requested ONE STEP AHEAD and carried
+  // in the state: requested in the step that uses them, hipcc sinks the loads into the `if (o.store)` block at the end of
+  // the step, right in front of their use, and every step then waits a full L2 round trip there (round 3: that wait was
+  // most of the 1.03 us a wave needs per step with a SIMD to itself).  A load cannot sink past the next step's barrier.
+  float xv = 0.f, yv = 0.f, xn = 0.f, yn = 0.f;
   unsigned orow = 0;
   if constexpr (MODE == 3) {
     orow = (unsigned)((y0 + it - 21) * (W * CH));
-    xv = (img1 + orow)[o.off];
-    yv = (img2 + orow)[o.off];
+    xv = S.xo;
+    yv = S.yo;
+  }
+  if constexpr (MODE >= 2) {
+    int yr = y0 + it - 20;                        // the row the NEXT step emits, clamped into the image
+    yr = yr < 0 ? 0 : (yr >= H ? H - 1 : yr);
+    const unsigned orow_n = (unsigned)(yr * (W * CH));
+    xn = (img1 + orow_n)[o.off];
+    yn = (img2 + orow_n)[o.off];
   }
   // ---- stage 1, horizontal
   {
@@ -610,6 +622,7 @@ __device__ __forceinline__ void fused_step(FusedState<CH> &S, FwdStage<CH> &preA
       (v_img1 + orow)[o.off] = wl1 * sgn + wss * (vac.x + 2.f * xv * vac.y + yv * vd);
     }
   }
+  if constexpr (MODE >= 2) { S.xo = xn; S.yo = yn; }
 }
 
 template <int CH>
@@ -655,6 +668,7 @@ k_ssim_l1_fused(int B, int H, int W, int rows, const float *__restrict__ img1, c
   fwd_gload<CH>(preB, g, img1, img2, H, W * CH, y0 - 2 * kHalf + 2);
   FusedState<CH> S;
   S.l1_acc = S.ss_acc = 0.f;
+  S.xo = S.yo = 0.f;
 #pragma unroll
   for (int i = 0; i < kWin; ++i) { S.r1[i][0] = S.r1[i][1] = S.r2a[i] = v2f{0.f, 0.f}; S.r2b[i] = 0.f; }
 #define SO_STEP(P, MODE) fused_step<CH, P, MODE>(S, preA, preB, rowsA, rowsB, g, o, img1, img2, base + P, n_out, H, W, y0, tid, valid, wl1, wss, v_img1)
