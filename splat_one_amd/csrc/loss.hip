@@ -69,6 +69,17 @@ __device__ __forceinline__ v2f pk_fma(float w, v2f x, v2f acc) {
   return __builtin_elementwise_fma(ww, x, acc);
 }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// A load through a pointer that was itself read from memory (the target image's slot, so_step_inputs) is a FLAT load for the
+// compiler -- it cannot know the address space -- and a flat load counts in lgkmcnt as well as vmcnt: the first
+// `s_waitcnt lgkmcnt(0)` for an LDS read after it also waits for the global round trip.  Every load of the target goes
+// through this cast (round 3: the row prefetch two steps ahead was being waited for in the step that issued it).
+__device__ __forceinline__ float gload(const float *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return *reinterpret_cast<const __attribute__((address_space(1))) float *>(reinterpret_cast<uintptr_t>(p));
+#else
+  return *p;
+#endif
+}
 
 // Per-thread staging geometry: a staged line is the workgroup's kT floats plus kHalf*CH halo floats on
 // each side.  Every thread stages element `tid` of the line and (the first 2*kHalf*CH threads only)
@@ -123,8 +134,8 @@ __device__ __forceinline__ void fwd_gload(FwdStage<CH> &st, const G &g, const fl
   st.p1 = v2f{(float)g.off1, (float)y};
   (void)r1; (void)r2;
 #else
-  st.p0 = v2f{r1[g.off0], r2[g.off0]};
-  st.p1 = v2f{r1[g.off1], r2[g.off1]};
+  st.p0 = v2f{r1[g.off0], gload(r2 + g.off0)};
+  st.p1 = v2f{r1[g.off1], gload(r2 + g.off1)};
 #endif
 }
 
@@ -163,7 +174,7 @@ __device__ __forceinline__ void ssim_fwd_step(SsimFwdState<CH> &S, FwdStage<CH> 
                                               int it, int n_out, int b, int H, int W, int y0, int tid, int valid,
                                               const Window &win, float *__restrict__ dmaps, int64_t map_stride) {
   __builtin_amdgcn_sched_barrier(0);   // keep the unrolled steps apart: overlapping them only costs registers
-  __syncthreads();
+  lds_barrier();
   {   // stage row it+1 (loaded two steps ago), fetch row it+3; both harmless past the end
     fwd_lstore<CH>(preA, g, rows[(it + 1) & 1], tid, y0 - kHalf + it + 1, H);
     preA = preB;
@@ -345,7 +356,7 @@ __device__ __forceinline__ void ssim_bwd_step(SsimBwdState<CH> &S, BwdStage<CH> 
                                               int H, int W, int y0, int tid, const Window &win, float wl1, float wss,
                                               float *__restrict__ v_img1) {
   __builtin_amdgcn_sched_barrier(0);
-  __syncthreads();
+  lds_barrier();
   {
     bwd_lstore<CH>(preA, g, rows[(it + 1) & 1], tid, y0 - kHalf + it + 1, H);
     preA = preB;
@@ -356,7 +367,7 @@ __device__ __forceinline__ void ssim_bwd_step(SsimBwdState<CH> &S, BwdStage<CH> 
   if constexpr (OUT) {   // issue the two pixel loads early; consumed after the vertical sums
     orow = (unsigned)((y0 + it - 2 * kHalf) * (W * CH));
     xv = (img1 + orow)[o.off];
-    yv = (img2 + orow)[o.off];
+    yv = gload(img2 + orow + o.off);
   }
   const v4f *R = rows[it & 1] + tid;
   v2f ac = {0.f, 0.f};
@@ -512,7 +523,7 @@ __device__ __forceinline__ void fused_step(FusedState<CH> &S, FwdStage<CH> &preA
                                            int it, int n_out, int H, int W, int y0, int tid, int valid,
                                            float wl1, float wss, float *__restrict__ v_img1) {
   __builtin_amdgcn_sched_barrier(0);
-  __syncthreads();
+  lds_barrier();
   {
     fwd_lstore<CH>(preA, g, rowsA[(it + 1) & 1], tid, y0 - 2 * kHalf + it + 1, H);
     preA = preB;
@@ -534,7 +545,7 @@ __device__ __forceinline__ void fused_step(FusedState<CH> &S, FwdStage<CH> &preA
     yr = yr < 0 ? 0 : (yr >= H ? H - 1 : yr);
     const unsigned orow_n = (unsigned)(yr * (W * CH));
     xn = (img1 + orow_n)[o.off];
-    yn = (img2 + orow_n)[o.off];
+    yn = gload(img2 + orow_n + o.off);
   }
   // ---- stage 1, horizontal
   {

@@ -147,7 +147,7 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
   float behind = tf_bg;   // tf_bg - buf_dot of the scalar form below
 
   for (int64_t batch_end = block_last; batch_end >= lo; batch_end -= STAGE) {
-    __syncthreads();
+    lds_barrier();
     const int64_t idx = batch_end - tid;
     if (tid < STAGE && idx >= lo) {
       const int32_t g = flatten_ids[idx];
@@ -197,7 +197,7 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     const int batch_size = (int)((batch_end + 1 - lo) < STAGE ? (batch_end + 1 - lo) : STAGE);
     const int32_t rel_final = (int32_t)(batch_end - bin_final);   // candidate tt contributes to this pixel iff tt >= rel_final
     const int32_t rel_wave = (int32_t)(batch_end - wave_last);

@@ -94,7 +94,7 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
 
   for (int64_t batch_start = lo; batch_start < hi; batch_start += BLOCK) {
     if (batch_start != lo) {   // uniform
-      __syncthreads();
+      lds_barrier();
       int live = 0;
 #pragma unroll
       for (int w = 0; w < (BLOCK + 63) / 64; ++w) live |= s_live[w];
@@ -146,7 +146,7 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     const int batch_size = (int)((hi - batch_start) < BLOCK ? (hi - batch_start) : BLOCK);
     const int32_t batch_base = (int32_t)batch_start;
 #pragma unroll 1

@@ -63,6 +63,19 @@ __device__ __forceinline__ float dpp_mov(float old, float v) {
 #endif
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a fence over ALL address spaces: in front of its
+// s_barrier hipcc waits for every outstanding global store / atomic of the wave (s_waitcnt vmcnt(0) -- stores and
+// no-return atomics count in vmcnt on gfx9), i.e. a full L2 round trip per barrier wherever a kernel stores or adds to
+// global memory between barriers and exchanges data through LDS alone (the fused SSIM step stores its output row right
+// before the barrier; the rasteriser backward has its gradient atomics in flight at the batch boundary).
+__device__ __forceinline__ void lds_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#endif
+}
+
 // Maximum of an int over the 64 lanes as a wave-uniform value (scalar register): four rotations inside the rows, then the
 // four row results read from lanes 0 / 16 / 32 / 48 -- 8 vector instructions and no LDS hardware, against 36 + six
 // ds_bpermute for the __shfl_xor ladder hipcc builds.  EXEC must be all ones.
