@@ -107,14 +107,17 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         const float4 *r4 = reinterpret_cast<const float4 *>(colors) + 4 * (int64_t)g;
         float4 q0 = r4[0];
         const float4 q1 = r4[1];   // x,y,ca,cb | cc,opac,r,g
+        const float4 q2 = r4[2];   // blue, depth, radius, cull threshold
         float4 bx = r4[3];         // the cull box of this Gaussian, computed once in the kernel that wrote the record
+        // (all four quarters of the record requested together: left to itself hipcc requests the two words it needs of the
+        // third quarter only after the first two have arrived -- one more round trip per staged batch)
+        asm volatile("" ::"v"(q2.x), "v"(q2.w));
         if (wrap) {
           const float shift = wrap_w * rintf((q0.x - wrap_cx) / wrap_w);
           q0.x -= shift; bx.x -= shift; bx.y -= shift;
         }
         s_box[tid] = bx;
 #if SO_RASTER_V2
-        const float4 q2 = r4[2];                                    // blue, depth, radius, cull threshold
         q0.z *= kConicScale; q0.w *= kConicScale;                   // conic and threshold in units of the exponent of 2
         s_A[tid] = q0;
         s_B[tid] = make_float4(q0.w, q1.x * kConicScale, q1.y, q2.w * kConicScale);   // cb, cc, opacity, cull threshold
@@ -122,7 +125,7 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
 #else
         s_A[tid] = q0;
         s_B[tid] = q1;
-        s_C[tid] = make_float4(r4[2].x, r4[2].w, 0.f, 0.f);         // blue, cull threshold
+        s_C[tid] = make_float4(q2.x, q2.w, 0.f, 0.f);               // blue, cull threshold
 #endif
       } else {
         float2 xy = means2d[g];
