@@ -491,6 +491,29 @@ constexpr int kFusedTapGroup = SO_FUSED_TAPGROUP;
 constexpr float kFusedW[kWin] = {0x1.0d956cp-10f, 0x1.f1fe02p-8f, 0x1.26eb18p-5f, 0x1.bff0fep-4f, 0x1.b43c4p-3f, 0x1.10656p-2f,
                                  0x1.b43c4p-3f,   0x1.bff0fep-4f, 0x1.26eb18p-5f, 0x1.f1fe02p-8f, 0x1.0d956cp-10f};
 
+// SO_FUSED_XY8 (round 3, default): line A holds (x, y) only -- 8-byte records, half the LDS bytes of stage 1's eleven
+// taps -- and the two products are formed per tap (one packed multiply + one fma) instead of once per staged element.
+// The step was within 8 % of its instruction-issue bound and STILL gained 3.6 us (74.3 -> 70.7): eight waves reading
+// 22 x 1 KB per step is most of what a CU's LDS delivers, so bytes count there, not only instructions.
+#ifndef SO_FUSED_XY8
+#define SO_FUSED_XY8 1
+#endif
+#if SO_FUSED_XY8
+typedef v2f fusedA_t;
+#else
+typedef v4f fusedA_t;
+#endif
+template <int CH, class G>
+__device__ __forceinline__ void fused_lstore(const FwdStage<CH> &st, const G &g, fusedA_t *line, int tid, int y, int H) {
+#if SO_FUSED_XY8
+  const float rm = (y >= 0 && y < H) ? 1.f : 0.f;
+  const float m0 = rm * g.cm0, m1 = rm * g.cm1;
+  line[tid] = st.p0 * v2f{m0, m0};
+  line[g.slot1] = st.p1 * v2f{m1, m1};
+#else
+  fwd_lstore<CH>(st, g, line, tid, y, H);
+#endif
+}
 template <int CH>
 constexpr int fused_out_floats() { return kFusedT - 2 * kHalf * CH; }
 template <int CH>
@@ -518,14 +541,14 @@ struct FusedOut {
 // y0-15+it (written to line B), reads derivative row y0-16+it from line B, and emits output row y0-21+it.
 template <int CH, int P, int MODE>
 __device__ __forceinline__ void fused_step(FusedState<CH> &S, FwdStage<CH> &preA, FwdStage<CH> &preB,
-                                           v4f (*rowsA)[lds_line_slots<CH, kFusedT>()], v4f (*rowsB)[line_b_slots<CH>()],
+                                           fusedA_t (*rowsA)[lds_line_slots<CH, kFusedT>()], v4f (*rowsB)[line_b_slots<CH>()],
                                            const StageGeom<CH, kFusedT> &g, const FusedOut &o, const float *img1, const float *img2,
                                            int it, int n_out, int H, int W, int y0, int tid, int valid,
                                            float wl1, float wss, float *__restrict__ v_img1) {
   __builtin_amdgcn_sched_barrier(0);
   lds_barrier();
   {
-    fwd_lstore<CH>(preA, g, rowsA[(it + 1) & 1], tid, y0 - 2 * kHalf + it + 1, H);
+    fused_lstore<CH>(preA, g, rowsA[(it + 1) & 1], tid, y0 - 2 * kHalf + it + 1, H);
     preA = preB;
     fwd_gload<CH>(preB, g, img1, img2, H, W * CH, y0 - 2 * kHalf + it + 3);
   }
@@ -549,12 +572,12 @@ __device__ __forceinline__ void fused_step(FusedState<CH> &S, FwdStage<CH> &preA
   }
   // ---- stage 1, horizontal
   {
-    const v4f *R = rowsA[it & 1] + tid;
+    const fusedA_t *R = rowsA[it & 1] + tid;
     v2f m = {0.f, 0.f}, q = {0.f, 0.f};
     float ctr_abs = 0.f;
 #pragma unroll
     for (int k0 = 0; k0 < kWin; k0 += kFusedTapGroup) {
-      v4f t[kFusedTapGroup];
+      fusedA_t t[kFusedTapGroup];
 #pragma unroll
       for (int j = 0; j < kFusedTapGroup; ++j)
         if (k0 + j < kWin) t[j] = R[(k0 + j) * CH];
@@ -562,7 +585,12 @@ __device__ __forceinline__ void fused_step(FusedState<CH> &S, FwdStage<CH> &preA
       for (int j = 0; j < kFusedTapGroup; ++j)
         if (k0 + j < kWin) {
           m = pk_fma(kFusedW[k0 + j], v2f{t[j].x, t[j].y}, m);
+#if SO_FUSED_XY8
+          const v2f xx = v2f{t[j].x, t[j].x} * v2f{t[j].x, t[j].y};          // (x^2, x y)
+          q = pk_fma(kFusedW[k0 + j], v2f{fmaf(t[j].y, t[j].y, xx.x), xx.y}, q);
+#else
           q = pk_fma(kFusedW[k0 + j], v2f{t[j].z, t[j].w}, q);
+#endif
           if (k0 + j == kHalf) ctr_abs = fabsf(t[j].x - t[j].y);
         }
       __builtin_amdgcn_sched_barrier(0);
@@ -649,7 +677,7 @@ k_ssim_l1_fused(int B, int H, int W, int rows, const float *__restrict__ img1, c
 #endif
   const float up = v_loss ? *v_loss : 1.f;
   const float wl1 = w_l1 * up, wss = w_ssim * up;
-  __shared__ v4f rowsA[2][lds_line_slots<CH, kFusedT>()];
+  __shared__ fusedA_t rowsA[2][lds_line_slots<CH, kFusedT>()];
   __shared__ v4f rowsB[2][line_b_slots<CH>()];
   __shared__ float red[2][kFusedT / 64];
   const int tid = threadIdx.x;
@@ -674,7 +702,7 @@ k_ssim_l1_fused(int B, int H, int W, int rows, const float *__restrict__ img1, c
   for (int i = tid; i < 2 * line_b_slots<CH>(); i += kFusedT) (&rowsB[0][0])[i] = v4f{0.f, 0.f, 0.f, 0.f};
   FwdStage<CH> preA, preB;
   fwd_gload<CH>(preA, g, img1, img2, H, W * CH, y0 - 2 * kHalf);
-  fwd_lstore<CH>(preA, g, rowsA[0], tid, y0 - 2 * kHalf, H);
+  fused_lstore<CH>(preA, g, rowsA[0], tid, y0 - 2 * kHalf, H);
   fwd_gload<CH>(preA, g, img1, img2, H, W * CH, y0 - 2 * kHalf + 1);
   fwd_gload<CH>(preB, g, img1, img2, H, W * CH, y0 - 2 * kHalf + 2);
   FusedState<CH> S;
