@@ -490,7 +490,10 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
           for (int k = 0; k < 3 * (NB - 1); ++k) my_row[k] = 0.f;
         for (int k = 3 * (NB - 1); k < R; ++k) my_row[k] = 0.f;
       }
-      __syncthreads();
+      // (a wave sweeps the 64 rows its own lanes wrote: the exchange is inside the wave, so a wave-local LDS fence is all
+      // it takes -- __syncthreads() also made every wave wait for the slowest one of the workgroup and for its own stores
+      // of the small tensors above to be acknowledged, vmcnt(0))
+      wave_lds_sync();
       PPB_STAMP(3);
       const int64_t w0 = n0 + (int64_t)wv * 64;            // first Gaussian of this wave: a multiple of 64 -> 16-byte aligned run
       const int64_t rows = N - w0 < 64 ? N - w0 : 64;
@@ -522,7 +525,7 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
         }
       }
       PPB_STAMP(4);
-      __syncthreads();
+      wave_lds_sync();   // the rows are rewritten by the next grid-stride trip of the same wave
     }
   }
 }

@@ -76,6 +76,16 @@ __device__ __forceinline__ void lds_barrier() {
 #endif
 }
 
+// The same for data that only travels between the lanes of ONE wave through LDS (no other wave reads it): order the wave's
+// own LDS writes before its LDS reads, nothing else.
+__device__ __forceinline__ void wave_lds_sync() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+#endif
+}
+
 // Maximum of an int over the 64 lanes as a wave-uniform value (scalar register): four rotations inside the rows, then the
 // four row results read from lanes 0 / 16 / 32 / 48 -- 8 vector instructions and no LDS hardware, against 36 + six
 // ds_bpermute for the __shfl_xor ladder hipcc builds.  EXEC must be all ones.
