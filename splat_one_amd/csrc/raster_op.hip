@@ -159,9 +159,13 @@ extern "C" int so_rasterization_bwd(const so_raster_desc *d, void *stream) {
   SO_REQUIRE(d->v_means && d->v_quats && d->v_scales && d->v_opacities && d->v_sh0 && (d->v_shN || d->K == 1),
              "so_rasterization_bwd: null gradient output");
   const int wrap = so::wrap_flags_of(d->camera_model, C, W, ts);
+  // counters: tile_counts[M] | sort scratch [M + 1] | n_isects (unused) | overflow of the forward's binning pass
+  const int64_t M = (int64_t)C * ((W + ts - 1) / ts) * ((H + ts - 1) / ts);
+  so::LossFinal fin{};
+  fin.skip = d->counters + 2 * M + 2;
   rc = so::rasterize_bwd_packed_launch(C, N, W, H, ts | wrap, d->rec, d->backgrounds, d->counters, d->flatten_ids, nullptr,
                                        -d->bin_capacity, d->render_alphas, d->last_ids, d->v_render_colors, d->v_render_alphas,
-                                       d->vrec, d->absgrad, so::LossFinal{}, stream);
+                                       d->vrec, d->absgrad, fin, stream);
   if (rc != SO_OK) return rc;
   if (d->activated)
     rc = so::preprocess_bwd_act(C, N, d->K, d->sh_degree, d->means, d->scales, d->quats, d->opacities, d->sh0, d->viewmats, d->Ks, W, H,

@@ -47,6 +47,7 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
     fin.out[1] = l1m;
     fin.out[2] = 1.f - ssm;
   }
+  if (fin.skip && *fin.skip != 0) return;   // uniform over the grid
   constexpr int NWAVES = (BLOCK + 63) / 64;
   // staged per Gaussian (same records as the forward): A = (x, y, conic a, conic b),
   // B = (conic c, opacity [, r, g when D == 3]), remaining colour channels in s_col

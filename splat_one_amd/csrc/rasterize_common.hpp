@@ -11,6 +11,9 @@ struct LossFinal {
   const float *sums;   // [0] sum |x - y|, [1] sum of the SSIM map
   float *out;          // [0] loss, [1] mean |x - y|, [2] 1 - mean SSIM
   float w_l1, w_ssim, c_const, a_l1, b_ss;   // loss = w_l1 sums[0] + w_ssim sums[1] + c_const;  means = sums * a_l1 / b_ss
+  // skip (nullable; so_rasterization_bwd): the forward's binning pass cut a list (its overflow counter) -> this backward
+  // leaves the gradient records at the zeros the forward wrote: a cut image teaches nothing (raster_op.py)
+  const int32_t *skip = nullptr;
 };
 
 // SO_RASTER_V2 (round 3): the RGB passes of both rasteriser kernels on packed fp32 pairs (v_pk_mul / v_pk_fma are the

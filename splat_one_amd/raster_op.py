@@ -12,12 +12,20 @@ What the call returns is what gsplat returns: images, alphas and `info` with `me
 `.absgrad` the densification strategy reads after the backward (gsplat_trainer.py:616-622, 744-752).
 
 Per-tile lists are BINNED (fixed slots per tile, include/splat_one_amd.h so_isect_sort_bins).  The slot count is measured
-on the first call of a (device, stream, tile grid) -- one synchronisation, once -- as 8x the fullest tile, and followed
+-- one synchronisation -- as 8x the fullest tile on the first call of a (device, stream, tile grid) and again whenever the
+call's Gaussian count has grown 1.5x past the last measurement (a denser checkpoint at the same resolution), and followed
 from then on through a host-mapped status word each forward publishes {fullest tile, overflow}: the next call reads it
-without synchronising and enlarges the bins while they are still half empty.  A call that overflows nevertheless (the
-fullest tile more than doubled from one call to the next) rasterises that tile with its first `slots` Gaussians; it is
-reported with a RuntimeWarning by the following call -- never silently -- and `SPLAT_ONE_AMD_EXACT_LISTS=1` (or
-`rasterization(..., fused=False)`) selects the exact-size operator path instead.
+without synchronising and enlarges the bins while they are still half empty.  What an overflow can do:
+  * a call that needs NO gradient (eval, viewer frames, `torch.no_grad()`) waits for its own status word and runs again on
+    larger bins: it never returns an image rendered from cut lists;
+  * a call that will be differentiated does not wait (the host keeps running ahead of the GPU).  If the fullest tile more
+    than doubled since the previous call, that tile is rendered from the `slots` entries that arrived first (arrival order:
+    NOT the front-most ones), and the backward of that call returns EXACTLY ZERO gradients -- the rasteriser's backward
+    kernel reads the overflow flag on the device (so_raster_desc, LossFinal.skip) -- so nothing is learnt from the cut
+    image; the following call reports it with a RuntimeWarning and enlarges the bins, `pending_overflow()` lets a training
+    loop ask after its last call;
+  * `SPLAT_ONE_AMD_EXACT_LISTS=1` (or `rasterization(..., fused=False)`) selects the exact-size operator path (gsplat's own
+    shape: one host read per call).
 """
 from __future__ import annotations
 
@@ -52,6 +60,7 @@ class _Bins:
         self.status_ptr = self.status.data_ptr()
         self.seq = 0
         self.probed = False
+        self.n_probe = 0                             # Gaussians per view of the call the bins were last measured on
         self.zero_alphas: Dict[Tuple[int, int, int], Tensor] = {}
         self.overflows = 0
 
@@ -75,8 +84,9 @@ class _Bins:
         if overflow:
             self.overflows += 1
             warnings.warn(f"splat_one_amd.rasterization: the previous call put {fullest} Gaussians over one tile, more than its "
-                          f"{self.slots} list slots -- that tile was rendered from its first {self.slots} entries; the bins are "
-                          "enlarged now (SPLAT_ONE_AMD_EXACT_LISTS=1 selects exact-size lists at the price of one host "
+                          f"{self.slots} list slots -- that tile was rendered from the {self.slots} entries that arrived first "
+                          "and the call's backward returned zero gradients (nothing was learnt from the cut image); the bins "
+                          "are enlarged now (SPLAT_ONE_AMD_EXACT_LISTS=1 selects exact-size lists at the price of one host "
                           "synchronisation per call)", RuntimeWarning)
             if self.slots >= self.limit:
                 raise RuntimeError(f"{fullest} Gaussians over one tile exceed the largest bin this image size allows "
@@ -88,6 +98,20 @@ class _Bins:
 
 _BINS: Dict[tuple, _Bins] = {}
 _BINS_LOCK = threading.Lock()
+
+
+def pending_overflow(synchronize: bool = True) -> int:
+    """How many of the LAST calls on any tile grid cut a list (0 or more)?  A differentiated call reports its overflow
+    through the call that follows; a training loop asks here after its last iteration.  Synchronises the device by
+    default (the status words are written by the forward's last kernel)."""
+    if synchronize and torch.cuda.is_available():
+        torch.cuda.synchronize()
+    n = 0
+    for b in list(_BINS.values()):
+        st = b.status_np
+        if b.seq and int(st[2]) == b.seq and int(st[1]):
+            n += 1
+    return n
 
 
 def _bins_for(device: torch.device, M: int) -> _Bins:
@@ -186,14 +210,19 @@ class _Rasterization(torch.autograd.Function):
                 d.bin_capacity, d.seq = bins.slots, bins.seq
                 d.key_buf, d.flatten_ids = bins.keys().data_ptr(), flatten_ids.data_ptr()
                 _lib.call("so_rasterization_fwd", ctypes.byref(d), _lib.stream())
-                if bins.probed:
+                # measure (ONE synchronisation): the first call on this tile grid, a model 1.5x denser than the one the bins
+                # were sized on, and every call that needs no gradient (eval / viewer: exact, see the module docstring)
+                measure = (not bins.probed) or N > 1.5 * bins.n_probe
+                if not (measure or not need_bwd):
                     break
-                # first call on this tile grid: measure the fullest tile (ONE synchronisation, once) and size the bins 8x
                 torch.cuda.current_stream().synchronize()
                 fullest, overflow = int(bins.status_np[0]), int(bins.status_np[1])
-                bins.probed = True
-                if overflow or 8 * fullest > bins.slots:
-                    bins.grow_to(fullest, 8)
+                if measure:
+                    bins.probed, bins.n_probe = True, N
+                    if overflow or 8 * fullest > bins.slots:
+                        bins.grow_to(fullest, 8)
+                elif overflow or 2 * fullest > bins.slots:
+                    bins.grow_to(fullest, 4)
                 if not overflow:
                     break
                 if bins.slots < fullest:

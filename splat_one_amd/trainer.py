@@ -331,6 +331,7 @@ class Runner:
         self._split_gen.manual_seed(1234)                                 # same on every rank
         self.last_info: Optional[dict] = None
         self._void_seen = 0
+        self._replaying = False          # Runner.train is training a void iteration's view again (no second refinement)
 
     # ------------------------------------------------------------------------------ :308-324
     @staticmethod
@@ -713,7 +714,8 @@ class Runner:
             eng.refresh_attrs()              # float16 attribute rows (if any) follow the gathered masters
             eng._advance_host_counters()
         if isinstance(s, MCMCStrategy):
-            refine_now = step < s.refine_stop_iter and step > s.refine_start_iter and step % s.refine_every == 0
+            refine_now = (step < s.refine_stop_iter and step > s.refine_start_iter and step % s.refine_every == 0
+                          and not self._replaying)
             if eng.device_refine:
                 # MCMCStrategy on the device (gsplat_trainer.py:753-761): relocation + addition in place on the capacity-sized
                 # model, then this iteration's position noise -- no host read, no re-capture.  Replicas (world_size > 1)
@@ -742,8 +744,9 @@ class Runner:
                 if refine_now and self.world_size > 1 and self._sadam is not None:
                     self._sadam.gather_moments(eng.ws["m_flat"], eng.ws["v_flat"])
                 # lr = the means learning rate after this step's scheduler.step() (gsplat_trainer.py:753-761)
+                # (a replayed void iteration: a label outside the refinement window -- the noise is drawn, nothing is relocated)
                 n_rel, n_new = s.step_post_backward(params=self.splats, optimizers=self.optimizers,
-                                                    state=self.strategy_state, step=step, info={},
+                                                    state=self.strategy_state, step=(-1 if self._replaying else step), info={},
                                                     lr=self.optimizers["means"].param_groups[0]["lr"],
                                                     generator=self._split_gen)
                 if n_rel or n_new:
@@ -753,8 +756,8 @@ class Runner:
             self.step += 1
             return eng.loss()[0]
         refine_now = (step < s.refine_stop_iter and step > s.refine_start_iter and step % s.refine_every == 0
-                      and step % s.reset_every >= s.pause_refine_after_reset)
-        reset_now = step < s.refine_stop_iter and step % s.reset_every == 0 and step > 0
+                      and step % s.reset_every >= s.pause_refine_after_reset and not self._replaying)
+        reset_now = step < s.refine_stop_iter and step % s.reset_every == 0 and step > 0 and not self._replaying
         if eng.device_refine:
             self.refine_on_device(step, refine_now, reset_now)
         elif refine_now or reset_now:
@@ -1105,10 +1108,17 @@ class Runner:
             void = getattr(eng, "void_steps", 0) - self._void_seen
             while void > 0 and not self.sharded and self.world_size == 1:
                 self._void_seen += void
-                self.step -= void                                  # those step numbers were never trained
-                todo = [recent[-3]] if void == 1 and len(recent) >= 3 else list(recent)[-3:-1]
-                for args_ in todo[:void]:
-                    self.train_step(args_[0], args_[1], args_[2], image_ids=args_[3])
+                todo = ([recent[-3]] if void == 1 and len(recent) >= 3 else list(recent)[-3:-1])[:void]
+                # rewind by what IS replayed (at most two views are remembered), and do not run the strategy a
+                # second time at a repeated label -- its refinement / opacity reset already happened when the label was
+                # first seen (MCMC: a second relocate-and-add would grow N by 1.05 twice)
+                self.step -= len(todo)
+                self._replaying = True
+                try:
+                    for args_ in todo:
+                        self.train_step(args_[0], args_[1], args_[2], image_ids=args_[3])
+                finally:
+                    self._replaying = False
                 void = getattr(self._engine, "void_steps", 0) - self._void_seen
             if has_data:
                 if step in [i - 1 for i in cfg.save_steps] or step == n - 1:

@@ -1,8 +1,8 @@
 """Measured parity numbers of the GPU tests, written next to pass/fail ("commit the measured errors").
 
 Every `-m gpu` parity test at a BASELINE.json size calls `record(...)`; the entries are merged into ONE JSON file --
-`$SPLAT_ONE_AMD_PARITY_JSON`, default `gpurun_out/parity_r03.json` (gpurun copies it back; the tracked copy is
-`profiles/parity_r03.json`).  Helpers here only measure; the bars are asserted in the tests."""
+`$SPLAT_ONE_AMD_PARITY_JSON`, default `gpurun_out/parity_r04.json` (gpurun copies it back; the tracked copy is
+`profiles/parity_r04.json`).  Helpers here only measure; the bars are asserted in the tests."""
 import json
 import os
 import time
@@ -11,7 +11,7 @@ from typing import Dict
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PATH = os.environ.get("SPLAT_ONE_AMD_PARITY_JSON") or os.path.join(ROOT, "gpurun_out", "parity_r03.json")
+PATH = os.environ.get("SPLAT_ONE_AMD_PARITY_JSON") or os.path.join(ROOT, "gpurun_out", "parity_r04.json")
 
 
 def record(section: str, **metrics) -> None:

@@ -173,9 +173,11 @@ def test_no_grad_and_threads(dev):
 
 
 def test_bins_follow_the_scene_without_host_reads(dev, monkeypatch):
-    """The slot count per tile is measured once (first call on a tile grid) and then followed through the host-mapped
-    status word: a scene that grows is met by larger bins before a tile overflows; an overflow that does happen (bins
-    forced small here) is announced by the NEXT call and repaired."""
+    """The slot count per tile is measured on the first call of a tile grid (and again when the model has grown 1.5x) and
+    then followed through the host-mapped status word.  What an overflow can do (raster_op.py docstring): a call
+    without gradient waits for its own status and runs again -- never an image from cut lists; a differentiated call does
+    not wait: its backward returns EXACTLY zero gradients (decided on the device), `pending_overflow()` and the next call
+    say so, and the bins are repaired."""
     from splat_one_amd import raster_op, rasterization
     W, H = 112, 80                     # a tile grid no other test uses: fresh bin state
     raster_op._BINS.clear()
@@ -192,37 +194,47 @@ def test_bins_follow_the_scene_without_host_reads(dev, monkeypatch):
     ref = im.clone()
     slow = rasterization(*args, vm, Kd, W, H, sh_degree=3, packed=False, fused=False)[0]
     (bins,) = [b for k, b in raster_op._BINS.items() if k[2] == 7 * 5]
-    assert bins.probed and bins.slots > 32 and (im - slow).abs().mean().item() <= 5e-7
-    # overflow, late detection: shrink the bins behind the module's back
+    assert bins.probed and bins.n_probe == 3000 and bins.slots > 32 and (im - slow).abs().mean().item() <= 5e-7
     torch.cuda.synchronize()
     fullest = int(bins.status[0])
+    # (1) no gradient wanted: bins shrunk behind the module's back -> the call notices by itself and returns the exact image
     bins.slots = max(16, fullest // 4)
     bins.status[2] = -1                # (as if the previous call were still in flight: nothing to look at before this one)
-    cut = render(args)
+    assert torch.equal(render(args), ref) and bins.slots >= fullest and raster_op.pending_overflow() == 0
+    # (2) a differentiated call on bins that are too small: not waited for; zero gradients, announced afterwards
+    leaves, gargs = _inputs(splats, dev, grad=True)
+    bins.slots = max(16, fullest // 4)
+    bins.status[2] = -1
+    rc, _ra, info = rasterization(*gargs, vm, Kd, W, H, sh_degree=3, packed=False)
+    info["means2d"].retain_grad()
+    (rc * rc).sum().backward()
     torch.cuda.synchronize()
-    assert int(bins.status[1]) == 1 and (cut - ref).abs().max().item() > 1e-3      # that call WAS truncated ...
+    assert int(bins.status[1]) == 1 and (rc.detach() - ref).abs().max().item() > 1e-3       # that image WAS cut ...
+    for t in leaves.values():                                                                # ... and taught nothing
+        assert t.grad is not None and float(t.grad.abs().max()) == 0.0
+    assert float(info["means2d"].grad.abs().max()) == 0.0
+    assert raster_op.pending_overflow() == 1
     with warnings.catch_warnings(record=True) as wl:
         warnings.simplefilter("always")
-        again = render(args)
-    assert any("list slots" in str(w.message) for w in wl)                          # ... and the next one says so
-    assert bins.slots >= 4 * fullest and torch.equal(again, ref)
-    # growth without overflow: three times the Gaussians -> fuller tiles -> the bins are enlarged from the status word
+        for t in leaves.values():
+            t.grad = None
+        rc2, _, _ = rasterization(*gargs, vm, Kd, W, H, sh_degree=3, packed=False)
+        (rc2 * rc2).sum().backward()
+    assert any("list slots" in str(w.message) for w in wl)                                   # the next call says so ...
+    assert bins.slots >= 4 * fullest and torch.equal(rc2.detach(), ref)                      # ... on repaired bins
+    assert all(float(t.grad.abs().max()) > 0.0 for t in leaves.values()) and raster_op.pending_overflow() == 0
+    # (3) growth without overflow: three times the Gaussians at the same resolution -> measured again at once (N > 1.5x)
     big, _, _ = make_scene(9000, W, H, regime="ref")
-    _, args_big = _inputs(big, dev, grad=False)
+    leaves_big, args_big = _inputs(big, dev, grad=True)
     bins.slots = int(1.5 * fullest)    # tight but sufficient for the small scene ...
     bins.status[2] = -1
     assert torch.equal(render(args), ref)
+    out_big, _, _ = rasterization(*args_big, vm, Kd, W, H, sh_degree=3, packed=False)       # ... the big one is re-probed
     torch.cuda.synchronize()
-    full_big = []
-    for _ in range(2):                 # ... the big scene's first call may overflow it (announced), its second must not
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            out_big = render(args_big)
-        torch.cuda.synchronize()
-        full_big.append(int(bins.status[0]))
-    assert int(bins.status[1]) == 0 and bins.slots >= 2 * full_big[-1]
-    slow_big = rasterization(*args_big, vm, Kd, W, H, sh_degree=3, packed=False, fused=False)[0]
-    assert (out_big - slow_big).abs().mean().item() <= 5e-7
+    assert bins.n_probe == 9000 and int(bins.status[1]) == 0 and bins.slots >= 2 * int(bins.status[0])
+    with torch.no_grad():
+        slow_big = rasterization(*args_big, vm, Kd, W, H, sh_degree=3, packed=False, fused=False)[0]
+    assert (out_big.detach() - slow_big).abs().mean().item() <= 5e-7
 
 
 def test_raw_parameter_call_equals_the_composed_call(dev):
