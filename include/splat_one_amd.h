@@ -289,6 +289,13 @@ typedef struct so_adam_group {
 } so_adam_group;
 int so_adam_step(int n_groups, const so_adam_group *host_groups, double beta1, double beta2, double eps,
                  int zero_grad, void *stream);
+/* The same step for a row / flat piece of a data-parallel replica (one view per GPU, gradients reduce-scattered:
+ * SURVEY.md section 8e; the reference scales its hyper-parameters for that batch at gsplat_trainer.py:266-278):
+ *   grad_scale  multiplies the gradient on the fly (1 / world: the reduce-scatter delivers the SUM over the ranks);
+ *   skip_f32    (nullable, device) a float the same reduce-scatter has summed over the ranks -- non-zero: some rank's
+ *               binning pass overflowed, the iteration is void on EVERY rank, nothing is written. */
+int so_adam_step_scaled(int n_groups, const so_adam_group *host_groups, double beta1, double beta2, double eps,
+                        int zero_grad, const float *skip_f32, float grad_scale, void *stream);
 
 /* Device-scheduled variant for hipGraph replay: `step_counter` is a device int32[2 + 4*SO_ADAM_MAX_GROUPS]
  * scratch whose element 0 is the number of optimiser steps done so far (the rest holds the per-group
@@ -494,6 +501,17 @@ typedef struct so_adam_fuse {
   int32_t *step_counter;   /* the device scratch of so_adam_step_dev */
 } so_adam_fuse;
 int so_train_step_fwd_bwd(const so_step_desc *desc, void *stream);
+/* The same iteration cut in two for data-parallel replicas (one view per GPU, `cli(main, cfg)` gsplat_trainer.py:998;
+ * gradient exchange instead of the reference's Gaussian sharding: SURVEY.md section 8e), so that the exchange starts
+ * before the backward has finished:
+ *   so_train_step_head      forward, loss, rasteriser backward -- the per-view gradient records vrec are complete;
+ *   so_train_step_bwd_rows  the per-Gaussian backward (projection / SH / activations, regularisers, densification
+ *                           statistics) for rows [row_begin, row_end) of every gradient tensor; row_begin a multiple of
+ *                           64.  One lane per Gaussian, no dependence between rows: the caller launches it chunk by chunk
+ *                           and starts the reduce-scatter of chunk i while chunk i + 1 runs.
+ * head + rows [0, N) == so_train_step_fwd_bwd bit for bit.  Needs desc->n_dev or record-only views; not with fuse_adam. */
+int so_train_step_head(const so_step_desc *desc, void *stream);
+int so_train_step_bwd_rows(const so_step_desc *desc, int64_t row_begin, int64_t row_end, void *stream);
 /* Everything that changes from one iteration to the next, in ONE launch, so that a captured step needs
  * neither copies nor re-capture (the reference does `inv(camtoworlds)`, `.to(device)` and the scheduler
  * arithmetic on the host each iteration, gsplat_trainer.py:586-603, :483, :749-751):

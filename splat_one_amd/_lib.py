@@ -128,6 +128,8 @@ _SIGS = {
     "so_rasterize_fwd_packed": [c_int] * 5 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 4,
     "so_rasterize_bwd_packed": [c_int] * 5 + [c_ptr] * 5 + [c_i64] + [c_ptr] * 5 + [c_int, c_ptr],
     "so_train_step_fwd_bwd": [ctypes.POINTER(StepDesc), c_ptr],
+    "so_train_step_head": [ctypes.POINTER(StepDesc), c_ptr],
+    "so_train_step_bwd_rows": [ctypes.POINTER(StepDesc), ctypes.c_int64, ctypes.c_int64, c_ptr],
     "so_render_forward": [ctypes.POINTER(StepDesc), c_ptr],
     "so_rasterization_fwd": [ctypes.POINTER(RasterDesc), c_ptr],
     "so_rasterization_bwd": [ctypes.POINTER(RasterDesc), c_ptr],
@@ -154,6 +156,8 @@ _SIGS = {
     "so_mcmc_refine": [c_i64, c_int, ctypes.POINTER(ModelSet), c_ptr, c_ptr, c_int, ctypes.POINTER(McmcParams), c_ptr, c_ptr, c_ptr],
     "so_inject_noise_dev": [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_uint64, c_ptr, c_f32, c_f32, c_f32, c_ptr, c_ptr],
     "so_adam_step": [c_int, ctypes.POINTER(AdamGroup), ctypes.c_double, ctypes.c_double, ctypes.c_double, c_int, c_ptr],
+    "so_adam_step_scaled": [c_int, ctypes.POINTER(AdamGroup), ctypes.c_double, ctypes.c_double, ctypes.c_double, c_int, c_ptr,
+                            c_f32, c_ptr],
 }
 
 _lib: Optional[ctypes.CDLL] = None

@@ -14,8 +14,12 @@ struct AdamGroups {
   so_adam_group g[SO_ADAM_MAX_GROUPS];
 };
 
+// skip (nullable): a float some collective has summed over the ranks -- non-zero: this iteration is void on every rank,
+// parameters and moments stay as they are.  gscale: the gradient is multiplied by it on the fly (1 / world: the
+// reduce-scatter delivered the SUM over the ranks' views).
 __global__ void __launch_bounds__(256)
-k_adam(AdamGroups groups, AdamHyper h, int zero_grad) {
+k_adam(AdamGroups groups, AdamHyper h, int zero_grad, const float *__restrict__ skip, float gscale) {
+  if (skip && *skip != 0.f) return;
   const so_adam_group G = groups.g[blockIdx.y];
   const int64_t n4 = (G.row_len % 4 == 0 || !G.visibility) ? G.numel / 4 : 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -30,10 +34,10 @@ k_adam(AdamGroups groups, AdamHyper h, int zero_grad) {
       continue;
     }
     float4 p = p4[i], g = ld_nt(g4 + i), m = ld_nt(m4 + i), v = ld_nt(v4 + i);
-    adam_one(p.x, g.x, m.x, v.x, h, G.lr_step_size, G.bc2_sqrt);
-    adam_one(p.y, g.y, m.y, v.y, h, G.lr_step_size, G.bc2_sqrt);
-    adam_one(p.z, g.z, m.z, v.z, h, G.lr_step_size, G.bc2_sqrt);
-    adam_one(p.w, g.w, m.w, v.w, h, G.lr_step_size, G.bc2_sqrt);
+    adam_one(p.x, g.x * gscale, m.x, v.x, h, G.lr_step_size, G.bc2_sqrt);
+    adam_one(p.y, g.y * gscale, m.y, v.y, h, G.lr_step_size, G.bc2_sqrt);
+    adam_one(p.z, g.z * gscale, m.z, v.z, h, G.lr_step_size, G.bc2_sqrt);
+    adam_one(p.w, g.w * gscale, m.w, v.w, h, G.lr_step_size, G.bc2_sqrt);
     p4[i] = p; st_nt(m4 + i, m); st_nt(v4 + i, v);
     if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -43,7 +47,7 @@ k_adam(AdamGroups groups, AdamHyper h, int zero_grad) {
       continue;
     }
     float p = G.param[i], m = G.exp_avg[i], v = G.exp_avg_sq[i];
-    adam_one(p, G.grad[i], m, v, h, G.lr_step_size, G.bc2_sqrt);
+    adam_one(p, G.grad[i] * gscale, m, v, h, G.lr_step_size, G.bc2_sqrt);
     G.param[i] = p; G.exp_avg[i] = m; G.exp_avg_sq[i] = v;
     if (zero_grad) G.grad[i] = 0.f;
   }
@@ -248,8 +252,18 @@ extern "C" int so_adam_step_dev(int n_groups, const so_adam_group *host_groups, 
                                  zero_grad, schedule_done, skip_i32, skip_f32, nullptr, stream);
 }
 
+static int adam_step_impl(int n_groups, const so_adam_group *host_groups, double beta1, double beta2, double eps, int zero_grad,
+                          const float *skip, float gscale, void *stream);
 extern "C" int so_adam_step(int n_groups, const so_adam_group *host_groups, double beta1, double beta2, double eps,
                             int zero_grad, void *stream) {
+  return adam_step_impl(n_groups, host_groups, beta1, beta2, eps, zero_grad, nullptr, 1.f, stream);
+}
+extern "C" int so_adam_step_scaled(int n_groups, const so_adam_group *host_groups, double beta1, double beta2, double eps,
+                                   int zero_grad, const float *skip_f32, float grad_scale, void *stream) {
+  return adam_step_impl(n_groups, host_groups, beta1, beta2, eps, zero_grad, skip_f32, grad_scale, stream);
+}
+static int adam_step_impl(int n_groups, const so_adam_group *host_groups, double beta1, double beta2, double eps, int zero_grad,
+                          const float *skip, float gscale, void *stream) {
   SO_REQUIRE(n_groups >= 0 && n_groups <= SO_ADAM_MAX_GROUPS, "so_adam_step: n_groups %d not in [0,%d]", n_groups, SO_ADAM_MAX_GROUPS);
   if (n_groups == 0) return SO_OK;
   SO_REQUIRE(host_groups, "so_adam_step: null groups");
@@ -270,6 +284,6 @@ extern "C" int so_adam_step(int n_groups, const so_adam_group *host_groups, doub
   if (gx < 1) gx = 1;
   const so::AdamHyper H{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps};
   hipLaunchKernelGGL(so::k_adam, dim3((unsigned)gx, (unsigned)n_groups), dim3(256), 0, so::as_stream(stream), G, H,
-                     zero_grad);
+                     zero_grad, skip, gscale);
   return so::check_launch("so_adam_step");
 }

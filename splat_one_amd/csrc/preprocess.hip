@@ -321,9 +321,13 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
                  float *__restrict__ grad2d, float *__restrict__ count, float stat_sx, float stat_sy,
                  const float4 *__restrict__ vrec, int use_abs_stats, int64_t cam_stride,
                  const int32_t *__restrict__ skip_flag, float *__restrict__ skip_out, const AdamFuse af,
-                 const int32_t *__restrict__ n_dev, const float4 *__restrict__ rec) {
+                 const int32_t *__restrict__ n_dev, const float4 *__restrict__ rec, int64_t row_begin, int64_t row_end) {
   constexpr int NB = (DEG + 1) * (DEG + 1);
   if (n_dev) N = min(*n_dev, N);   // device-resident Gaussian count (see k_preprocess_fwd); the grid covers the capacity
+  // rows [row_begin, row_end) only (row_end <= 0: to the end; row_begin a multiple of 64): data-parallel steps cut the
+  // backward into row chunks so that the reduce-scatter of chunk i runs under chunk i + 1 (so_train_step_bwd_rows).
+  // N stays the live count (the regularisers are means over all Gaussians).
+  const int64_t n_hi = (row_end > 0 && row_end < (int64_t)N) ? row_end : (int64_t)N;
   static_assert(!ADAM || STAGE, "the fused optimiser works on the staged shN rows");
   // skip_flag (nullable): the binning pass overflowed its buffers -> this iteration is void: leave gradients and
   // densification statistics alone (the optimiser step skips too); skip_out (nullable) publishes the flag as a
@@ -338,11 +342,11 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
   extern __shared__ __attribute__((aligned(16))) float s_stage[];
   const int R = 3 * (K - 1);
   // the trip count is uniform over the workgroup (the staged write-out is cooperative)
-  for (int64_t n0 = (int64_t)blockIdx.x * blockDim.x; n0 < N; n0 += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t n0 = row_begin + (int64_t)blockIdx.x * blockDim.x; n0 < n_hi; n0 += (int64_t)gridDim.x * blockDim.x) {
     const int64_t n = n0 + threadIdx.x;
-    const bool active = n < N;
+    const bool active = n < n_hi;
 #ifdef PP_STAMPS
-    const bool first_trip = n0 == (int64_t)blockIdx.x * blockDim.x;
+    const bool first_trip = n0 == row_begin + (int64_t)blockIdx.x * blockDim.x;
 #endif
     PPB_STAMP(0);
     float acc[NB][3];
@@ -496,7 +500,7 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
       wave_lds_sync();
       PPB_STAMP(3);
       const int64_t w0 = n0 + (int64_t)wv * 64;            // first Gaussian of this wave: a multiple of 64 -> 16-byte aligned run
-      const int64_t rows = N - w0 < 64 ? N - w0 : 64;
+      const int64_t rows = n_hi - w0 < 64 ? n_hi - w0 : 64;
       if (rows > 0) {
         const int total = (int)rows * R;
         const float4 *src4 = reinterpret_cast<const float4 *>(mine);
@@ -693,7 +697,7 @@ static int preprocess_bwd_impl(const char *what, int C, int N, int K, int sh_deg
                                float *v_logit_opacities, float *v_sh0, float *v_shN, float *grad2d, float *count,
                                const float *vrec, int absgrad_stats, int64_t cam_stride, const int32_t *skip_flag,
                                float *skip_out, void *stream, const AdamFuse *fuse = nullptr, const int32_t *n_dev = nullptr,
-                               const float *rec = nullptr) {
+                               const float *rec = nullptr, int64_t row_begin = 0, int64_t row_end = 0) {
   SO_REQUIRE(C >= 0 && N >= 0 && K >= 1 && width > 0 && height > 0, "%s: bad sizes", what);
   SO_REQUIRE(sh_degree >= 0 && sh_degree <= 4 && (sh_degree + 1) * (sh_degree + 1) <= K,
              "%s: sh_degree %d does not fit K=%d", what, sh_degree, K);
@@ -712,7 +716,11 @@ static int preprocess_bwd_impl(const char *what, int C, int N, int K, int sh_deg
   SO_REQUIRE(cam_stride >= N, "%s: cam_stride %lld < N %d", what, (long long)cam_stride, N);
   if (!vrec && v_means2d_abs) absgrad_stats = 1;
   SO_REQUIRE((grad2d == nullptr) == (count == nullptr), "%s: grad2d and count go together", what);
-  const dim3 grid(pp_grid(N)), block(256);
+  SO_REQUIRE(row_begin >= 0 && row_begin % 64 == 0 && (row_end <= 0 || row_end >= row_begin) && !(fuse && (row_begin || row_end > 0)),
+             "%s: row range [%lld, %lld) must start at a multiple of 64 (and is not available with the fused optimiser)", what,
+             (long long)row_begin, (long long)row_end);
+  if (row_begin >= N || (row_end > 0 && row_end == row_begin)) return SO_OK;
+  const dim3 grid(pp_grid((row_end > 0 && row_end < N ? row_end : (int64_t)N) - row_begin)), block(256);
   hipStream_t st = as_stream(stream);
   const float sx = 0.5f * (float)width * (float)C, sy = 0.5f * (float)height * (float)C;
   // v_shN rows go through LDS when a workgroup's 256 rows fit the default 64 KB (K <= 22) and the run is 16-byte aligned
@@ -736,7 +744,7 @@ static int preprocess_bwd_impl(const char *what, int C, int N, int K, int sh_deg
       opacities, colors, v_means2d, v_means2d_abs, v_depths, v_conics, v_colors, v_opacities, opacity_reg,        \
       scale_reg, v_means, v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN, grad2d, count, sx, sy,          \
       reinterpret_cast<const float4 *>(vrec), absgrad_stats, cam_stride, skip_flag, skip_out, FUSE, n_dev,        \
-      reinterpret_cast<const float4 *>(rec)
+      reinterpret_cast<const float4 *>(rec), row_begin, row_end
   // (the optimiser-fused variant exists for the raw float32 parameters only: activated inputs belong to a caller whose
   // autograd still has to run the activations' backward)
 #define SO_LAUNCH_(D, S)                                                                                          \
@@ -873,13 +881,13 @@ int preprocess_bwd_n(int C, int N, int K, int sh_degree, const float *means, con
                      const float *opacities, const float *colors, float opacity_reg, float scale_reg, float *v_means,
                      float *v_log_scales, float *v_quats, float *v_logit_opacities, float *v_sh0, float *v_shN, float *grad2d,
                      float *count, const float *vrec, int absgrad_stats, const int32_t *skip_flag, float *skip_out,
-                     const int32_t *n_dev, const float *rec, void *stream) {
+                     const int32_t *n_dev, const float *rec, void *stream, int64_t row_begin, int64_t row_end) {
   SO_REQUIRE(N == 0 || (log_scales && quats && sh0 && (shN || K == 1)), "so_preprocess_bwd: null pointer");
   const AttrSoA attrs{log_scales, quats, sh0, shN, K};
   return preprocess_bwd_impl("so_preprocess_bwd", C, N, K, sh_degree, means, logit_opacities, attrs, viewmats, Ks, width, height,
                              eps2d, camera_model, antialiased, radii, opacities, colors, nullptr, nullptr, nullptr, nullptr, nullptr,
                              nullptr, opacity_reg, scale_reg, v_means, v_log_scales, v_quats, v_logit_opacities, v_sh0, v_shN,
-                             grad2d, count, vrec, absgrad_stats, 0, skip_flag, skip_out, stream, nullptr, n_dev, rec);
+                             grad2d, count, vrec, absgrad_stats, 0, skip_flag, skip_out, stream, nullptr, n_dev, rec, row_begin, row_end);
 }
 // internal (raster_op.hip): the POST-ACTIVATION inputs of gsplat's rasterization() call (AttrAct): scales [N,3],
 // opacities [N] in (0,1), coeffs [N,K,3]; record-only views; the backward returns the gradients of exactly those
@@ -937,7 +945,8 @@ int preprocess_bwd_n_f16(int C, int N, int K, int sh_degree, const float *means,
                          int antialiased, const int32_t *radii, const float *opacities, const float *colors, float opacity_reg,
                          float scale_reg, float *v_means, float *v_log_scales, float *v_quats, float *v_logit_opacities,
                          float *v_sh0, float *v_shN, float *grad2d, float *count, const float *vrec, int absgrad_stats,
-                         const int32_t *skip_flag, float *skip_out, const int32_t *n_dev, void *stream) {
+                         const int32_t *skip_flag, float *skip_out, const int32_t *n_dev, void *stream, int64_t row_begin,
+                         int64_t row_end) {
   SO_REQUIRE(N == 0 || attr_rec_ok(arec), "so_preprocess_bwd_f16: arec must be non-null and 16-byte aligned");
   SO_REQUIRE(N == 0 || vrec, "so_preprocess_bwd_f16: the gradient records (vrec) are required");
   const AttrRec attrs{reinterpret_cast<const uint4 *>(arec), attr_rec_stride_bytes(K < 1 ? 1 : K) / 16};
@@ -945,7 +954,7 @@ int preprocess_bwd_n_f16(int C, int N, int K, int sh_degree, const float *means,
                              height, eps2d, camera_model, antialiased, radii, opacities, colors, nullptr, nullptr, nullptr,
                              nullptr, nullptr, nullptr, opacity_reg, scale_reg, v_means, v_log_scales, v_quats,
                              v_logit_opacities, v_sh0, v_shN, grad2d, count, vrec, absgrad_stats, 0, skip_flag, skip_out, stream,
-                             nullptr, n_dev, nullptr);
+                             nullptr, n_dev, nullptr, row_begin, row_end);
 }
 }  // namespace so
 

@@ -40,7 +40,7 @@ int preprocess_bwd_n(int C, int N, int K, int sh_degree, const float *means, con
                      const float *opacities, const float *colors, float opacity_reg, float scale_reg, float *v_means,
                      float *v_log_scales, float *v_quats, float *v_logit_opacities, float *v_sh0, float *v_shN, float *grad2d,
                      float *count, const float *vrec, int absgrad_stats, const int32_t *skip_flag, float *skip_out,
-                     const int32_t *n_dev, const float *rec, void *stream);
+                     const int32_t *n_dev, const float *rec, void *stream, int64_t row_begin = 0, int64_t row_end = 0);
 int rasterize_bwd_packed_launch(int C, int N, int width, int height, int tile_size, const float *rec, const float *backgrounds,
                                 const int32_t *isect_offsets, const int32_t *flatten_ids, const int32_t *n_isects_dev,
                                 int64_t n_isects_host, const float *render_alphas, const int32_t *last_ids,

@@ -261,8 +261,17 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
           const float v8[8] = {gxy.x, gxy.y, gcxz.x, g_cy, gcxz.y, g01.x, g01.y, g2};
           if constexpr (!ABS) {
             // nine sums over the wave as one network (so_common.hpp): nine lanes, ONE atomic instruction, nine addresses
+#if defined(SO_ABL_NORED)    // ablation (tools/gpu_bwd_ablate.sh): no cross-lane reduction -- WRONG gradients, timing only
+            const float val = (v8[0] + v8[1] + v8[2] + v8[3] + v8[4] + v8[5] + v8[6] + v8[7] + g_op) * unscale9;
+#else
             const float val = wave_reduce9_scattered(v8, g_op) * unscale9;
+#endif
+#if defined(SO_ABL_NOATOM)   // ablation: the reduced value is kept alive but never added -- ZERO gradients, timing only
+            asm volatile("" ::"v"(val));
+            if (false) {
+#else
             if (atom_lane) {
+#endif
               if constexpr (PACKED && SMALL) {
                 const unsigned off = __float_as_uint(c4.w) | ((unsigned)slot9 * 4u);
                 atomicAdd(reinterpret_cast<float *>(reinterpret_cast<char *>(v_colors) + off), val);

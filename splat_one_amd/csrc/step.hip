@@ -80,7 +80,7 @@ int preprocess_bwd_n(int C, int N, int K, int sh_degree, const float *means, con
                      const float *opacities, const float *colors, float opacity_reg, float scale_reg, float *v_means,
                      float *v_log_scales, float *v_quats, float *v_logit_opacities, float *v_sh0, float *v_shN, float *grad2d,
                      float *count, const float *vrec, int absgrad_stats, const int32_t *skip_flag, float *skip_out,
-                     const int32_t *n_dev, const float *rec, void *stream);
+                     const int32_t *n_dev, const float *rec, void *stream, int64_t row_begin = 0, int64_t row_end = 0);
 int preprocess_fwd_n_f16(int C, int N, int K, int sh_degree, const float *means, const float *logit_opacities, const void *arec,
                          const float *viewmats, const float *Ks, int width, int height, float eps2d, float near_plane,
                          float far_plane, float radius_clip, int camera_model, int antialiased, int tile_size, int32_t *radii,
@@ -92,7 +92,8 @@ int preprocess_bwd_n_f16(int C, int N, int K, int sh_degree, const float *means,
                          int antialiased, const int32_t *radii, const float *opacities, const float *colors, float opacity_reg,
                          float scale_reg, float *v_means, float *v_log_scales, float *v_quats, float *v_logit_opacities,
                          float *v_sh0, float *v_shN, float *grad2d, float *count, const float *vrec, int absgrad_stats,
-                         const int32_t *skip_flag, float *skip_out, const int32_t *n_dev, void *stream);
+                         const int32_t *skip_flag, float *skip_out, const int32_t *n_dev, void *stream, int64_t row_begin = 0,
+                         int64_t row_end = 0);
 
 // Per-iteration inputs in one launch (see so_step_inputs in the header).  Workgroup 0 does the small serial
 // pieces (one lane per camera / per Ks entry / per Adam group); every workgroup zeroes its share of the counters.
@@ -168,9 +169,26 @@ extern "C" void so_profile_stage_begin_end(int stage, int begin, void *stream) {
   else if (cur) { delete cur; cur = nullptr; }
 }
 
-static int step_impl(const so_step_desc *d, void *stream, bool forward_only);
+// what of the iteration one call runs: all of it; the forward only (eval / viewer); everything but the last stage (HEAD);
+// the last stage -- the backward of projection / SH / activations -- on a row range of the Gaussians (TAIL)
+enum StepPart { STEP_ALL = 0, STEP_FORWARD = 1, STEP_HEAD = 2, STEP_TAIL = 3 };
+static int step_impl(const so_step_desc *d, void *stream, StepPart part, int64_t row_begin = 0, int64_t row_end = 0);
 
-extern "C" int so_train_step_fwd_bwd(const so_step_desc *d, void *stream) { return step_impl(d, stream, false); }
+extern "C" int so_train_step_fwd_bwd(const so_step_desc *d, void *stream) { return step_impl(d, stream, STEP_ALL); }
+
+// Data-parallel replicas (gsplat_trainer.py:266-278 scales the hyper-parameters for them): the same
+// iteration as so_train_step_fwd_bwd cut in two so that the gradient exchange can start before the backward has finished.
+//   so_train_step_head      forward, loss, rasteriser backward (the per-view gradient records are complete)
+//   so_train_step_bwd_rows  the per-Gaussian backward for rows [row_begin, row_end) of every gradient tensor (row_begin a
+//                           multiple of 64; one lane per Gaussian, no dependence between rows): the caller launches it chunk
+//                           by chunk and starts the reduce-scatter of chunk i while chunk i + 1 runs
+// head + rows [0, N) == so_train_step_fwd_bwd bit for bit (tests/test_gpu_engine.py).  Not with fuse_adam.
+extern "C" int so_train_step_head(const so_step_desc *d, void *stream) { return step_impl(d, stream, STEP_HEAD); }
+extern "C" int so_train_step_bwd_rows(const so_step_desc *d, int64_t row_begin, int64_t row_end, void *stream) {
+  SO_REQUIRE(row_begin >= 0 && row_begin % 64 == 0 && row_end > row_begin, "so_train_step_bwd_rows: bad row range [%lld, %lld)",
+             (long long)row_begin, (long long)row_end);
+  return step_impl(d, stream, STEP_TAIL, row_begin, row_end);
+}
 
 extern "C" int so_step_inputs(int C, const float *camtoworlds, const float *Ks_src, float *viewmats, float *Ks_dst,
                               const float *pixels, const float **pixels_slot, int32_t *counters, int64_t n_zero,
@@ -196,9 +214,10 @@ extern "C" int so_step_inputs(int C, const float *camtoworlds, const float *Ks_s
 
 // Forward only (render_colors / render_alphas / last_ids of the current views): the eval / viewer
 // path of gsplat_trainer.py:779-940 on the same static buffers, also hipGraph-capturable.
-extern "C" int so_render_forward(const so_step_desc *d, void *stream) { return step_impl(d, stream, true); }
+extern "C" int so_render_forward(const so_step_desc *d, void *stream) { return step_impl(d, stream, STEP_FORWARD); }
 
-static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
+static int step_impl(const so_step_desc *d, void *stream, StepPart part, int64_t row_begin, int64_t row_end) {
+  const bool forward_only = part == STEP_FORWARD;
   SO_REQUIRE(d != nullptr, "so_train_step_fwd_bwd: null descriptor");
   SO_REQUIRE(d->abi_size == (int32_t)sizeof(so_step_desc), "so_train_step_fwd_bwd: descriptor size %d != %d (ABI mismatch)",
              d->abi_size, (int)sizeof(so_step_desc));
@@ -211,7 +230,10 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
   // counters: tile_counts[M] | cursor[M] | long-list length | n_isects | overflow     loss_sums: l1, ssim
   int32_t *tile_counts = d->counters, *cursor = d->counters + M, *n_isects = d->counters + 2 * M + 1,
           *overflow = d->counters + 2 * M + 2;
-  if (d->inputs_staged) {
+  SO_REQUIRE(part == STEP_ALL || part == STEP_FORWARD || !d->fuse_adam, "so_train_step_head / _bwd_rows: not with fuse_adam");
+  if (part == STEP_TAIL) {
+    // (the head of this iteration has run: counters, records and gradient records are in place)
+  } else if (d->inputs_staged) {
     // so_step_inputs zeroed the counters (and the loss sums behind them) for this iteration
   } else if (reinterpret_cast<int32_t *>(d->loss_sums) == d->counters + 2 * M + 3) {
     so::zero_async(d->counters, 2 * M + 5, st);   // loss sums packed right behind the counters: one launch
@@ -224,6 +246,7 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
   // binned lists: every tile owns bin_capacity slots of key_buf / flatten_ids; the forward kernel's returning atomics
   // place the keys, so the scan and the scatter pass do not exist (tile_counts doubles as the per-tile list length)
   const int64_t bins = d->bin_capacity;
+  if (part != STEP_TAIL) {
   SO_REQUIRE(d->raster_impl == 0, "so_train_step_fwd_bwd: raster_impl must be 0");
   SO_REQUIRE(bins >= 0, "so_train_step_fwd_bwd: bad bin_capacity");
   // periodic views: spherical cameras, when the tile grid lines up across the seam (so_preprocess_fwd derives the same
@@ -296,6 +319,10 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
     SO_STAGE(6, so::rasterize_bwd_packed_launch(C, N, W, H, ts | wrap_flags, d->rec, d->backgrounds, list_off, d->flatten_ids, list_n,
                                                 list_cap, d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
                                                 d->absgrad, fin, stream));
+  }   // part != STEP_TAIL
+  if (part == STEP_HEAD) return SO_OK;
+  SO_REQUIRE(part != STEP_TAIL || d->n_dev || !d->radii,
+             "so_train_step_bwd_rows: needs the device-resident row count (n_dev) or record-only views (radii == NULL)");
   if (d->fuse_adam) {
     // the optimiser runs inside the backward kernel (gradients never reach HBM); its schedule for this step was
     // evaluated by so_step_inputs into the scratch behind the step counter
@@ -316,13 +343,13 @@ static int step_impl(const so_step_desc *d, void *stream, bool forward_only) {
                                          W, H, d->eps2d, d->camera_model, d->antialiased, d->radii, d->opacities, d->colors,
                                          d->opacity_reg, d->scale_reg, d->v_means, d->v_log_scales, d->v_quats,
                                          d->v_logit_opacities, d->v_sh0, d->v_shN, d->grad2d, d->count, d->vrec, d->absgrad,
-                                         overflow, d->overflow_flag_out, d->n_dev, stream));
+                                         overflow, d->overflow_flag_out, d->n_dev, stream, row_begin, row_end));
   else if (d->n_dev || !d->radii)
     SO_STAGE(7, so::preprocess_bwd_n(C, N, K, d->sh_degree, d->means, d->log_scales, d->quats, d->logit_opacities, d->sh0, d->shN,
                                      d->viewmats, d->Ks, W, H, d->eps2d, d->camera_model, d->antialiased, d->radii, d->opacities,
                                      d->colors, d->opacity_reg, d->scale_reg, d->v_means, d->v_log_scales, d->v_quats,
                                      d->v_logit_opacities, d->v_sh0, d->v_shN, d->grad2d, d->count, d->vrec, d->absgrad,
-                                     overflow, d->overflow_flag_out, d->n_dev, d->rec, stream));
+                                     overflow, d->overflow_flag_out, d->n_dev, d->rec, stream, row_begin, row_end));
   else if (d->attr_rows_f16)
     SO_STAGE(7, so_preprocess_bwd_f16(C, N, K, d->sh_degree, d->means, d->logit_opacities, d->attr_rows_f16, d->viewmats, d->Ks,
                                       W, H, d->eps2d, d->camera_model, d->antialiased, d->radii, d->opacities, d->colors,

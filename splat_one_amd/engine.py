@@ -109,6 +109,7 @@ class FusedEngine:
         self._graph: Optional[torch.cuda.CUDAGraph] = None
         self._graph_key = None
         self._graphs, self._graphs_fb = {}, {}       # captured steps by (N, SH degree, workspace, statistics on, model set)
+        self._graphs_head, self._rows_desc = {}, None
         self._graph_fb: Optional[torch.cuda.CUDAGraph] = None
         self._graph_opt: Optional[torch.cuda.CUDAGraph] = None
         self._graph_fb_key = None
@@ -119,7 +120,10 @@ class FusedEngine:
         self._seq = 0
         self._status_event: Optional[torch.cuda.Event] = None
         self._last_launch = self._status_kind = None   # "train" | "render": what last ran on the counters
-        self.on_overflow = "grow"        # "grow": void iteration, larger buffers, continue;  "raise": RuntimeError
+        # "grow": void iteration, larger buffers, continue;  "raise": RuntimeError;  "defer": data-parallel replicas -- the
+        # caller decides from the flag summed over all ranks and calls take_back() on every rank (Runner._dp_check_void)
+        self.on_overflow = "grow"
+        self._local_overflow_seen = 0
         self.void_steps = 0              # iterations discarded because the binning pass overflowed
         if self.device_refine:
             self._build_model_sets(int(capacity) if capacity else max(2 * splats["means"].shape[0], 1 << 20))
@@ -317,7 +321,7 @@ class FusedEngine:
         return {"n_dupli": r[0], "n_split": r[1], "n_prune": r[2], "n_new": r[3], "overflow": r[4], "n_old": r[5], "refinements": r[6],
                 "rows_needed": r[7]}
 
-    def adam_on_flat_range(self, a: int, b: int) -> None:
+    def adam_on_flat_range(self, a: int, b: int, skip: Optional[Tensor] = None, grad_scale: float = 1.0) -> None:
         """Adam (host-scheduled: so_adam_step) on the flat range [a, b) of parameters / moments / gradient -- the piece of
         the model this rank owns in a reduce-scattered step (distributed.ShardedFlatAdam).  The range is cut at the
         tensor boundaries: every tensor keeps its own learning rate (gsplat_trainer.py:246-257, :266-278)."""
@@ -338,11 +342,14 @@ class FusedEngine:
         if not groups:
             return
         arr = (_lib.AdamGroup * len(groups))(*groups)
-        _lib.call("so_adam_step", len(groups), arr, float(betas[0]), float(betas[1]), float(eps), 0, _lib.stream())
+        _lib.call("so_adam_step_scaled", len(groups), arr, float(betas[0]), float(betas[1]), float(eps), 0,
+                  _lib.ptr(skip) if skip is not None else 0, float(grad_scale), _lib.stream())
 
-    def adam_on_rows(self, names, a: int, b: int) -> None:
-        """Adam (host-scheduled: so_adam_step) on rows [a, b) of the named tensors of the ACTIVE device-resident set --
-        the row piece this rank owns in a reduce-scattered step (distributed.RowShardedAdam)."""
+    def adam_on_rows(self, names, a: int, b: int, skip: Optional[Tensor] = None, grad_scale: float = 1.0) -> None:
+        """Adam (host-scheduled: so_adam_step_scaled) on rows [a, b) of the named tensors of the ACTIVE device-resident set --
+        a row piece this rank owns in a reduce-scattered step (distributed.RowShardedAdam).  skip: one device float the
+        reduce-scatter summed over the ranks (non-zero: the iteration is void everywhere, nothing is written);
+        grad_scale: 1 / world, applied to the summed gradient on the fly."""
         assert self.device_refine and 0 <= a <= b <= self.cap, (a, b, self.cap)
         if a == b:
             return
@@ -356,7 +363,8 @@ class FusedEngine:
                                          _lib.ptr(rows(act["v"][k])), 0, rows(act["p"][k]).numel(), 1, grp["lr"] / (1.0 - betas[0] ** t),
                                          math.sqrt(1.0 - betas[1] ** t)))
         arr = (_lib.AdamGroup * len(groups))(*groups)
-        _lib.call("so_adam_step", len(groups), arr, float(betas[0]), float(betas[1]), float(eps), 0, _lib.stream())
+        _lib.call("so_adam_step_scaled", len(groups), arr, float(betas[0]), float(betas[1]), float(eps), 0,
+                  _lib.ptr(skip) if skip is not None else 0, float(grad_scale), _lib.stream())
 
     def _adam_args_host(self) -> None:
         for k in PARAM_ORDER:
@@ -478,7 +486,7 @@ class FusedEngine:
                     self.strategy_state[k] = torch.zeros(N, device=dev)
         self._graph = None
         self._graph_fb = self._graph_opt = None
-        self._graphs, self._graphs_fb = {}, {}
+        self._graphs, self._graphs_fb, self._graphs_head, self._rows_desc = {}, {}, {}, None
 
     def refresh_attrs(self) -> None:
         """Rebuild the float16 attribute rows from the float32 masters (after anything but the engine's own
@@ -628,8 +636,8 @@ class FusedEngine:
         return int(self.ws["counters"][:self.M].max().item())
 
     def _grow(self, needed: int) -> None:
-        if self.binned:                              # `needed`: Gaussians over the fullest tile
-            self._bin_hint = -(-int(2 * needed + 16) // 256) * 256
+        if self.binned:                              # `needed`: Gaussians over the fullest tile (bins never shrink)
+            self._bin_hint = max(int(self.bin_capacity), -(-int(2 * needed + 16) // 256) * 256)
         else:
             self._capacity_hint = int(1.5 * needed) + 4096
         self._build_workspace()
@@ -684,7 +692,33 @@ class FusedEngine:
         if self.on_overflow == "raise":
             raise RuntimeError(f"tile-intersection buffers overflowed ({max(n_prev, n_last)} > capacity {self.capacity}); "
                                "the affected iterations were skipped on the device -- raise Config.isect_capacity")
-        void = 1 + (1 if ov_last else 0)
+        if self.on_overflow == "defer":
+            # data-parallel replicas: whether an iteration was void is decided by the flag the gradient reduce-scatter summed
+            # over ALL ranks (Runner._dp_check_void -> take_back on every rank alike); what this rank saw locally only sizes
+            # its own bins then
+            self._local_overflow_seen = max(self._local_overflow_seen, n_prev, n_last, self.bin_capacity if self.binned else 0)
+            return
+        self.take_back(1 + (1 if ov_last else 0), max(n_prev, n_last))
+
+    def local_overflow_recent(self):
+        """(did one of the last two training iterations overflow THIS rank's buffers, entries needed) -- for replicas, whose
+        void iterations are decided by the flag summed over all ranks.  Call after a device-wide synchronisation."""
+        c, M = self.ws["counters"], self.M
+        ov_last = int(c[2 * M + 2].item())
+        ov_prev = int(self._status[1]) if int(self._status[2]) == self._seq else 0      # published by the last staging
+        seen = bool(ov_last or ov_prev or self._local_overflow_seen)
+        needed = self._fullest_tile() if self.binned else int(c[2 * M + 1].item())
+        needed = max(needed, int(self._local_overflow_seen), int(self._status[0]) if (ov_prev and not self.binned) else 0)
+        if seen and self.binned:
+            needed = max(needed, self.bin_capacity)          # at least double the bins that were too small
+        self._local_overflow_seen = 0
+        self._status_event = None                            # (what _check_previous would have looked at is handled)
+        return seen, needed
+
+    def take_back(self, void: int, needed: int, grow: bool = True) -> None:
+        """`void` training iterations never happened (the optimiser skipped them on the device): undo the host-side step
+        bookkeeping, enlarge the intersection buffers for `needed` entries (binned: Gaussians over the fullest tile) and
+        say so."""
         self.void_steps += void
         for _ in range(void):                        # undo _advance_host_counters for iterations that never happened
             self.steps_done -= 1
@@ -693,10 +727,14 @@ class FusedEngine:
             self.optimizers["means"].param_groups[0]["lr"] /= self.lr_gamma_means
         self._step_dev[0] = self.steps_done
         import warnings
-        what = (f"{max(n_prev, n_last)} Gaussians over one tile exceeded its bin of {self.bin_capacity} slots" if self.binned else
-                f"{max(n_prev, n_last)} tile intersections exceeded the buffer capacity {self.capacity}")
+        what = (f"{needed} Gaussians over one tile exceeded its bin of {self.bin_capacity} slots" if self.binned else
+                f"{needed} tile intersections exceeded the buffer capacity {self.capacity}")
+        if not grow:      # (a replica whose own buffers held: another rank's view overflowed)
+            warnings.warn(f"splat_one_amd: {void} training iteration(s) skipped on every replica -- another rank's "
+                          "tile-intersection buffers overflowed", RuntimeWarning)
+            return
         warnings.warn(f"splat_one_amd: {void} training iteration(s) skipped -- {what}; buffers enlarged", RuntimeWarning)
-        self._grow(max(n_prev, n_last))
+        self._grow(needed)
 
     def set_views(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor, schedule: bool = False) -> None:
         """Stage this step's cameras and target images.  camtoworlds[C,4,4] (inverted on the device),
@@ -788,6 +826,38 @@ class FusedEngine:
         self._graph_opt = self._graph_opt or None
         self._consume_staging()
         self._graph_fb.replay()
+
+    def fwd_bwd_head(self) -> None:
+        """Data-parallel replicas: forward, loss and rasteriser backward of the staged views (so_train_step_head) -- the
+        per-view gradient records are complete, the per-Gaussian backward follows chunk by chunk (`bwd_rows`) so that the
+        reduce-scatter of one chunk runs under the next.  A hipGraph replay when `use_graph`."""
+        self._last_launch = "train"
+        if not self.use_graph:
+            self._consume_staging()
+            d = self._desc()
+            _lib.call("so_train_step_head", ctypes.byref(d), _lib.stream())
+            return
+        key = (self.N, self.cfg["sh_degree"], id(self.ws), self.strategy_state is not None, self.active if self.device_refine else 0)
+        if key not in self._graphs_head:
+            if not self._staged:
+                self._stage(None, None, None, False)
+            self._warm_fwd_bwd()
+            with CAPTURE_LOCK:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    d = self._desc()
+                    _lib.call("so_train_step_head", ctypes.byref(d), _lib.stream())
+            self._graphs_head[key] = g
+        self._consume_staging()
+        self._graphs_head[key].replay()
+
+    def bwd_rows(self, a: int, b: int) -> None:
+        """The per-Gaussian backward for rows [a, b) (a multiple of 64) of every gradient tensor: so_train_step_bwd_rows on
+        the current stream, after `fwd_bwd_head`."""
+        key = (id(self.ws), self.cfg["sh_degree"], self.strategy_state is not None, self.active if self.device_refine else 0)
+        if self._rows_desc is None or self._rows_desc[0] != key:
+            self._rows_desc = (key, self._desc())
+        _lib.call("so_train_step_bwd_rows", ctypes.byref(self._rows_desc[1]), int(a), int(b), _lib.stream())
 
     def optimize(self) -> None:
         sched, self._sched_staged = self._sched_staged, False
@@ -894,7 +964,7 @@ class FusedEngine:
             self.cfg["sh_degree"] = deg
             self._graph = None
             self._graph_fb = self._graph_opt = None
-            self._graphs, self._graphs_fb = {}, {}
+            self._graphs, self._graphs_fb, self._graphs_head, self._rows_desc = {}, {}, {}, None
 
     def rebuild(self) -> None:
         """Call after the Gaussian set changed on the HOST side (a torch-level strategy rewrote params / optimiser state)."""

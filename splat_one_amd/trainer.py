@@ -332,6 +332,10 @@ class Runner:
         self.last_info: Optional[dict] = None
         self._void_seen = 0
         self._replaying = False          # Runner.train is training a void iteration's view again (no second refinement)
+        from collections import deque
+        self._dp_hist: deque = deque(maxlen=2)   # [pinned flag, event, looked at] of the last two replicated iterations
+        self._dp_pinned, self._dp_slot = None, 0
+        self._no_refine_before = 0       # step labels below this were seen before void iterations were taken back
 
     # ------------------------------------------------------------------------------ :308-324
     @staticmethod
@@ -642,9 +646,11 @@ class Runner:
 
     def _train_step_fused(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor) -> Tensor:
         from .engine import FusedEngine
+        eng = getattr(self, "_engine", None)
+        if self.world_size > 1 and eng is not None:
+            self._dp_check_void(eng)             # may take void iterations (and their step labels) back
         cfg, step, s = self.cfg, self.step, self.cfg.strategy
         B, H, W = pixels.shape[0], pixels.shape[1], pixels.shape[2]
-        eng = getattr(self, "_engine", None)
         if eng is None or (eng.C, eng.H, eng.W) != (B, H, W):
             n_floats = sum(int(v.numel()) for v in self.splats.values())
             self._dp_chunks = int(cfg.dp_chunks) if cfg.dp_chunks > 0 else (4 if 4 * n_floats >= (64 << 20) else 1)
@@ -670,17 +676,19 @@ class Runner:
                 fuse_adam=cfg.fuse_adam, device_refine=dev_refine, capacity=capacity, loss_kernels=cfg.loss_kernels,
                 model_sets=(1 if mcmc else 2),
                 mcmc_noise=({"noise_lr": s.noise_lr, "seed": cfg.refine_seed} if mcmc else None),
-                row_multiple=(self.world_size * sdist.RowShardedAdam.ALIGN_ROWS if self.world_size > 1 else 1),
+                row_multiple=(self._dp_chunks * self.world_size * sdist.RowShardedAdam.ALIGN_ROWS if self.world_size > 1 else 1),
                 flat_multiple=(self._dp_chunks * self.world_size * sdist.ShardedFlatAdam.ALIGN
                                if self.world_size > 1 and not dev_refine else 0))
             self._sadam = self._radam = None
             eng.steps_done = step
             eng._step_dev[0] = step
             if self.world_size > 1:
-                # replicas must not diverge: an overflow (of a tile's bin, or of the compact buffers) is flagged on every rank
-                # (all_reduce_max below) and stops the run instead of growing buffers per rank -- the sharded Adam that follows
-                # the reduce-scatter is scheduled by the host and cannot take an iteration back
-                eng.on_overflow = "raise"
+                # replicas must not diverge: "this rank's binning pass overflowed" is summed over the ranks by the gradient
+                # reduce-scatter itself (distributed.RowShardedAdam.flags), every rank's Adam launches skip on the sum on the
+                # device, and every rank's host takes the same iterations back one step late (_dp_check_void) -- the engine
+                # must not act on what it saw locally
+                eng.on_overflow = "defer"
+                self._dp_hist.clear()
         eng.set_sh_degree(min(step // cfg.sh_degree_interval, cfg.sh_degree))
         # densification statistics are accumulated inside the backward kernel while refinement is active
         stats_on = isinstance(s, DefaultStrategy) and step < s.refine_stop_iter
@@ -690,32 +698,40 @@ class Runner:
             eng.set_views(camtoworlds, Ks, pixels, schedule=True)   # the step below always runs the optimiser
             eng.step()
         elif eng.device_refine:
-            # replicated Gaussians, device-resident model: the same reduce-scatter / 1/world Adam / all-gather over ROW
-            # pieces of the capacity-sized tensors (distributed.RowShardedAdam); N is the host's copy (sync_host below)
+            # replicated Gaussians, device-resident model: reduce-scatter / 1/world Adam / all-gather over ROW pieces of the
+            # capacity-sized tensors (distributed.RowShardedAdam), the per-Gaussian backward cut into Config.dp_chunks row
+            # chunks so that the reduce-scatter of chunk c runs on RCCL's stream under the kernel of chunk c + 1; no
+            # collective besides those (the void flag rides in chunk 0).  N is the host's copy (sync_host below)
             eng.set_views(camtoworlds, Ks, pixels, schedule=False)
-            eng.fwd_bwd()
-            M = eng.M
-            sdist.all_reduce_max_(eng.ws["counters"][2 * M + 2:2 * M + 3])   # a void iteration on one rank is raised on all
             if self._radam is None:
-                self._radam = sdist.RowShardedAdam()
-            self._radam.step(eng.ws["grads"], eng.sets[eng.active]["p"], eng.n_host, eng.adam_on_rows)
+                self._radam = sdist.RowShardedAdam(n_chunks=self._dp_chunks)
+            ra, n = self._radam, eng.n_host
+            grads, params = eng.ws["grads"], eng.sets[eng.active]["p"]
+            eng.fwd_bwd_head()
+            ra.begin(n, eng.device, True)
+            for c in range(ra.n_chunks):
+                lo, hi = ra.chunk_range(n, c)
+                eng.bwd_rows(lo, hi)                                       # (rows past the live count: the kernel clamps)
+                ra.reduce_chunk(c, grads, eng.ws["ovf_f32"])
+            ra.finish(grads, params, eng.adam_on_rows)
+            self._dp_note_void(ra.void_flag())
             eng.refresh_attrs()              # float16 attribute rows (if any) follow the gathered masters
             eng._advance_host_counters()
         else:
-            # replicated Gaussians: reduce-scatter of the flat gradient in chunks, Adam on this rank's 1/world of every
-            # chunk as it lands, all-gather of the updated parameters (distributed.ShardedFlatAdam)
+            # replicated Gaussians, torch-level refinement: reduce-scatter of the FLAT gradient in chunks, Adam on this
+            # rank's 1/world of every chunk as it lands, all-gather of the updated parameters (distributed.ShardedFlatAdam);
+            # the void flags travel in a 64-byte-per-rank reduce-scatter of their own, issued with the first chunk
             eng.set_views(camtoworlds, Ks, pixels, schedule=False)
             eng.fwd_bwd()
             if self._sadam is None or self._sadam.total != eng.flat_total:
                 self._sadam = sdist.ShardedFlatAdam(eng.flat_total, n_chunks=self._dp_chunks)
-            M = eng.M
-            sdist.all_reduce_max_(eng.ws["counters"][2 * M + 2:2 * M + 3])   # a void iteration on one rank is raised on all
-            self._sadam.step(eng.ws["grads_flat"], eng.ws["params_flat"], eng.adam_on_flat_range)
+            self._sadam.step(eng.ws["grads_flat"], eng.ws["params_flat"], eng.adam_on_flat_range, void_src=eng.ws["ovf_f32"])
+            self._dp_note_void(self._sadam.void_flag())
             eng.refresh_attrs()              # float16 attribute rows (if any) follow the gathered masters
             eng._advance_host_counters()
         if isinstance(s, MCMCStrategy):
             refine_now = (step < s.refine_stop_iter and step > s.refine_start_iter and step % s.refine_every == 0
-                          and not self._replaying)
+                          and not self._replaying and step >= self._no_refine_before)
             if eng.device_refine:
                 # MCMCStrategy on the device (gsplat_trainer.py:753-761): relocation + addition in place on the capacity-sized
                 # model, then this iteration's position noise -- no host read, no re-capture.  Replicas (world_size > 1)
@@ -746,7 +762,8 @@ class Runner:
                 # lr = the means learning rate after this step's scheduler.step() (gsplat_trainer.py:753-761)
                 # (a replayed void iteration: a label outside the refinement window -- the noise is drawn, nothing is relocated)
                 n_rel, n_new = s.step_post_backward(params=self.splats, optimizers=self.optimizers,
-                                                    state=self.strategy_state, step=(-1 if self._replaying else step), info={},
+                                                    state=self.strategy_state,
+                                                    step=(-1 if (self._replaying or step < self._no_refine_before) else step), info={},
                                                     lr=self.optimizers["means"].param_groups[0]["lr"],
                                                     generator=self._split_gen)
                 if n_rel or n_new:
@@ -756,8 +773,10 @@ class Runner:
             self.step += 1
             return eng.loss()[0]
         refine_now = (step < s.refine_stop_iter and step > s.refine_start_iter and step % s.refine_every == 0
-                      and step % s.reset_every >= s.pause_refine_after_reset and not self._replaying)
-        reset_now = step < s.refine_stop_iter and step % s.reset_every == 0 and step > 0 and not self._replaying
+                      and step % s.reset_every >= s.pause_refine_after_reset and not self._replaying
+                      and step >= self._no_refine_before)
+        reset_now = (step < s.refine_stop_iter and step % s.reset_every == 0 and step > 0 and not self._replaying
+                     and step >= self._no_refine_before)
         if eng.device_refine:
             self.refine_on_device(step, refine_now, reset_now)
         elif refine_now or reset_now:
@@ -786,6 +805,45 @@ class Runner:
                           "flatten_ids": eng.ws["flatten_ids"], "means2d": eng.ws["means2d"]}
         self.step += 1
         return eng.loss()[0]
+
+    # ---- data-parallel replicas: void iterations (a view's binning pass overflowed on SOME rank)
+    def _dp_note_void(self, flag: Optional[Tensor]) -> None:
+        """Remember this iteration's void flag -- the sum over all ranks the reduce-scatter left in this rank's piece, the
+        same number everywhere -- for the host: an asynchronous 4-byte copy into pinned memory and an event, no wait."""
+        if flag is None:
+            return
+        if self._dp_pinned is None:
+            self._dp_pinned = [torch.zeros(1, dtype=torch.float32).pin_memory() for _ in range(4)]
+        slot = self._dp_pinned[self._dp_slot % len(self._dp_pinned)]
+        self._dp_slot += 1
+        slot.copy_(flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._dp_hist.append([slot, ev, False])
+
+    def _dp_check_void(self, eng) -> None:
+        """One step late and without a device-wide wait (FusedEngine._check_previous for replicas): was the iteration before
+        the last one void?  Every rank reads the same summed flag, so every rank takes the same iterations back (step counter,
+        Adam bias correction, lr schedule) -- the Adam launches skipped them on the device already -- and a rank that saw
+        its own bins overflow enlarges them.  The views of void iterations are not trained again here."""
+        h = self._dp_hist
+        if len(h) < 2 or h[-2][2]:
+            return
+        old, new = h[-2], h[-1]
+        old[1].synchronize()
+        old[2] = True
+        if float(old[0][0]) == 0.0:
+            return
+        torch.cuda.synchronize()                 # rare path: the last iteration's flag is needed too
+        void = 1 + (1 if float(new[0][0]) != 0.0 else 0)
+        h.clear()
+        seen, needed = eng.local_overflow_recent()
+        eng.take_back(void, needed, grow=seen)
+        # the step LABELS go back with the optimiser steps (SH-degree ramp, lr schedule and refinement calendar follow the
+        # number of steps actually taken, as on one GPU); what the strategy did at the labels that are now repeated is not
+        # done a second time
+        self._no_refine_before = max(self._no_refine_before, self.step)
+        self.step -= void
 
     def refine_on_device(self, step: int, refine_now: bool = True, reset_now: bool = False) -> None:
         """DefaultStrategy's refinement (and / or opacity reset) of `step` on the device-resident model of the fused engine:

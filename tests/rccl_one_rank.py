@@ -63,15 +63,27 @@ assert torch.equal(buf, ref)
 sa.gather_moments(buf, buf.clone())
 # row pieces of a device-resident model (RowShardedAdam): grouped reduce_scatter_tensor / all_gather_into_tensor through
 # torch's coalescing manager, in place, async handles -- with one rank every collective is a copy onto itself
-ra = sdist.RowShardedAdam()
-assert ra.backend == "nccl" and ra.world == 1 and ra.rows(10) == (0, 16)
-rows = [torch.full((16, 3), 2.0, device=dev), torch.full((16,), 3.0, device=dev), torch.full((16, 15, 3), 4.0, device=dev)]
-for wk in ra._reduce_scatter(rows, 10):
-    wk.wait()
-for wk in ra._all_gather(rows, 10):
+ra = sdist.RowShardedAdam(n_chunks=2)
+assert ra.backend == "nccl" and ra.world == 1 and ra.rows(100, 0) == (0, 64) and ra.rows(100, 1) == (64, 128) and ra.span(100) == 128
+ra.mode = "coalesced"                # (one rank: step() short-cuts -- drive the chunk collectives and the flag reduce-scatter directly)
+rows = [torch.full((128, 3), 2.0, device=dev), torch.full((128,), 3.0, device=dev), torch.full((128, 15, 3), 4.0, device=dev)]
+for mode in ("coalesced", "per_tensor"):
+    ra.mode = mode
+    for c in range(ra.n_chunks):
+        for wk in ra._reduce_scatter(rows, 100, c):
+            wk.wait()
+        for wk in ra._all_gather(rows, 100, c):
+            wk.wait()
+ra.flags = torch.full((ra.world * ra.FLAG_STRIDE,), 5.0, device=dev)
+for wk in ra._reduce_scatter_flags():
     wk.wait()
 torch.cuda.synchronize()
-assert all(torch.equal(t, torch.full_like(t, v)) for t, v in zip(rows, (2.0, 3.0, 4.0)))
+assert all(torch.equal(t, torch.full_like(t, v)) for t, v in zip(rows, (2.0, 3.0, 4.0))) and float(ra.void_flag()[0]) == 5.0
+sdist.probe_coalescing_locally()     # the rank-local half of the fallback vote: the private API exists and can be entered empty
+for wk in sa._reduce_scatter_flags(torch.tensor([1.0], device=dev), dev):
+    wk.wait()
+torch.cuda.synchronize()
+assert float(sa.void_flag()[0]) == 1.0
 mx = torch.tensor([3], dtype=torch.int32, device=dev)
 sdist.all_reduce_max_(mx)
 assert int(mx) == 3

@@ -42,7 +42,7 @@ def _hyper(world):
 
 
 def _worker(local_rank, world_rank, world_size, args):
-    out_dir, N, n_chunks, steps = args
+    out_dir, N, n_chunks, steps, void_at = args
     from splat_one_amd.distributed import ShardedFlatAdam
     segs, total = _layout(N)
     sa = ShardedFlatAdam(total, n_chunks=n_chunks)
@@ -57,25 +57,35 @@ def _worker(local_rank, world_rank, world_size, args):
     hyper = _hyper(world_size)
     t = [0]
 
-    def adam_fn(a, b):
-        # torch restatement of so_adam_step on the flat range [a, b): one group per tensor segment it intersects
+    def adam_fn(a, b, skip, gscale):
+        # torch restatement of so_adam_step_scaled on the flat range [a, b): one group per tensor segment it intersects;
+        # the SUMMED gradient times gscale (1 / world); nothing happens when the summed void flag is non-zero
+        assert gscale == 1.0 / world_size and skip is not None
+        if float(skip[0]) != 0.0:
+            return
         for k, (off, n) in segs.items():
             lo, hi = max(a, off), min(b, off + n)
             if lo >= hi:
                 continue
             lr, eps, (b1, b2) = hyper[k]
-            g = G[lo:hi]
+            g = G[lo:hi] * gscale
             M[lo:hi].mul_(b1).add_(g, alpha=1 - b1)
             V[lo:hi].mul_(b2).addcmul_(g, g, value=1 - b2)
             denom = (V[lo:hi].sqrt() / (1 - b2 ** t[0]) ** 0.5).add_(eps)
             P[lo:hi].addcdiv_(M[lo:hi], denom, value=-lr / (1 - b1 ** t[0]))
 
+    done = 0
     for step in range(steps):
         G.zero_()
         for k, (off, n) in segs.items():
             G[off:off + n] = _grads(N, world_rank, step)[k]
-        t[0] = step + 1
-        sa.step(G, P, adam_fn)
+        t[0] = done + 1
+        # iteration `void_at`: the LAST rank's binning pass "overflowed" -- every rank must skip it (the flag is summed by
+        # a reduce-scatter, not by a collective the host waits for) and every rank reads the same sum afterwards
+        mine = torch.tensor([1.0 if (step == void_at and world_rank == world_size - 1) else 0.0])
+        sa.step(G, P, adam_fn, void_src=mine)
+        assert float(sa.void_flag()[0]) == (1.0 if step == void_at else 0.0)
+        done += 0 if step == void_at else 1       # (the host takes a void iteration's step count back)
     m_own = M.clone()
     sa.gather_moments(M, V)
     mine = torch.zeros(sa.padded_total, dtype=torch.bool)
@@ -85,13 +95,13 @@ def _worker(local_rank, world_rank, world_size, args):
     torch.save({"P": P, "M": M, "V": V, "bytes": sa.bytes_per_link_and_step()}, os.path.join(out_dir, f"r{world_rank}.pt"))
 
 
-@pytest.mark.parametrize("world,n_chunks,N", [(2, 4, 1001), (4, 4, 777), (8, 5, 1234)])
-def test_sharded_adam_equals_adam_on_the_mean_gradient(tmp_path, world, n_chunks, N):
+@pytest.mark.parametrize("world,n_chunks,N,void_at", [(2, 4, 1001, -1), (4, 4, 777, 1), (8, 5, 1234, -1)])
+def test_sharded_adam_equals_adam_on_the_mean_gradient(tmp_path, world, n_chunks, N, void_at):
     from splat_one_amd import distributed as sdist
-    steps = 3
+    steps = 3 if void_at < 0 else 4
     env_backup = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     try:
-        sdist.cli(_worker, (str(tmp_path), N, n_chunks, steps), world_size=world, backend="gloo", port=_free_port())
+        sdist.cli(_worker, (str(tmp_path), N, n_chunks, steps, void_at), world_size=world, backend="gloo", port=_free_port())
     finally:
         for k, v in env_backup.items():
             if v is not None:
@@ -109,6 +119,8 @@ def test_sharded_adam_equals_adam_on_the_mean_gradient(tmp_path, world, n_chunks
         lr, eps, betas = hyper[k]
         opts[k] = torch.optim.Adam([params[k]], lr=lr, eps=eps, betas=betas)
     for step in range(steps):
+        if step == void_at:                      # the void iteration never happened
+            continue
         for k in ROWS:
             params[k].grad = sum(_grads(N, r, step)[k] for r in range(world)) / world
             opts[k].step()
@@ -125,9 +137,10 @@ def test_sharded_adam_equals_adam_on_the_mean_gradient(tmp_path, world, n_chunks
 def _row_worker(local_rank, world_rank, world_size, args):
     """RowShardedAdam on capacity-sized tensors: N live rows of CAP, N changing between steps (as after a refinement,
     with the moments gathered first)."""
-    out_dir, cap, Ns = args
+    out_dir, cap, Ns, n_chunks, void_at = args
     from splat_one_amd.distributed import RowShardedAdam
-    ra = RowShardedAdam()
+    ra = RowShardedAdam(n_chunks=n_chunks)
+    assert all(ra.span(N) <= cap and ra.chunk_rows(N) % (world_size * 64) == 0 for N in Ns)
     g0 = torch.Generator().manual_seed(7)
     P = {k: torch.randn(cap, rl, generator=g0) for k, rl in ROWS.items()}
     G = {k: torch.full((cap, rl), float("nan")) for k, rl in ROWS.items()}      # rows beyond N: never read
@@ -137,16 +150,20 @@ def _row_worker(local_rank, world_rank, world_size, args):
     t = [0]
     touched = []
 
-    def adam_fn(names, a, b):
+    def adam_fn(names, a, b, skip, gscale):
         touched.append((tuple(names), a, b))
+        assert gscale == 1.0 / world_size and skip is not None
+        if float(skip[0]) != 0.0:                # the void flags of all ranks, summed by chunk 0's reduce-scatter
+            return
         for k in names:
             lr, eps, (b1, b2) = hyper[k]
-            g = G[k][a:b]
+            g = G[k][a:b] * gscale
             M[k][a:b].mul_(b1).add_(g, alpha=1 - b1)
             V[k][a:b].mul_(b2).addcmul_(g, g, value=1 - b2)
             denom = (V[k][a:b].sqrt() / (1 - b2 ** t[0]) ** 0.5).add_(eps)
             P[k][a:b].addcdiv_(M[k][a:b], denom, value=-lr / (1 - b1 ** t[0]))
 
+    done = 0
     for step, N in enumerate(Ns):
         if step and N != Ns[step - 1]:          # "refinement": every rank needs all moments of the old rows first
             ra.gather([M[k] for k in ROWS] + [V[k] for k in ROWS], Ns[step - 1])
@@ -156,22 +173,34 @@ def _row_worker(local_rank, world_rank, world_size, args):
         for k, rl in ROWS.items():
             G[k][:N] = _grads(N, world_rank, step)[k].view(N, rl)
             G[k][N:] = float("nan")             # rows of the last piece beyond N are summed with the rest and never used
-        t[0] = step + 1
-        ra.step(G, P, N, adam_fn)
-        a, b = ra.rows(N)
-        assert all(x[1] == a and x[2] == min(b, N) for x in touched[-2:]) or min(b, N) <= a
+        t[0] = done + 1
+        mine = torch.tensor([2.0 if (step == void_at and world_rank == 0) else 0.0])
+        before = len(touched)
+        if step % 2 == 0:                        # the whole step at once ...
+            ra.step(G, P, N, adam_fn, void_src=mine)
+        else:                                    # ... or chunk by chunk, as the trainer drives it under the backward kernels
+            ra.begin(N, "cpu", False)
+            for c in range(ra.n_chunks):
+                ra.reduce_chunk(c, G, mine)
+            ra.finish(G, P, adam_fn)
+        assert float(ra.void_flag()[0]) == (2.0 if step == void_at else 0.0)
+        done += 0 if step == void_at else 1
+        own = ra.owned(N)
+        assert sorted({(x[1], x[2]) for x in touched[before:]}) == sorted(own), (touched[before:], own)
+        assert sum(b - a for r in range(world_size) for a, b in ra.owned(N, r)) == N        # the pieces tile the live rows
     ra.gather([M[k] for k in ROWS] + [V[k] for k in ROWS], Ns[-1])
     N = Ns[-1]
     torch.save({"P": {k: P[k][:N] for k in ROWS}, "M": {k: M[k][:N] for k in ROWS}, "V": {k: V[k][:N] for k in ROWS},
                 "bytes": ra.bytes_per_link_and_step(N)}, os.path.join(out_dir, f"r{world_rank}.pt"))
 
 
-@pytest.mark.parametrize("world,cap,Ns", [(2, 64, (37, 37, 51)), (4, 1024, (777, 1001, 1001)), (8, 2048, (1234, 1234, 3))])
-def test_row_sharded_adam_equals_adam_on_the_mean_gradient(tmp_path, world, cap, Ns):
+@pytest.mark.parametrize("world,cap,Ns,n_chunks,void_at", [(2, 128, (37, 37, 51), 1, -1), (4, 1024, (777, 1001, 1001, 1001), 2, 2),
+                                                            (8, 2048, (1234, 1234, 3), 3, -1), (2, 1024, (700, 700, 300), 4, 0)])
+def test_row_sharded_adam_equals_adam_on_the_mean_gradient(tmp_path, world, cap, Ns, n_chunks, void_at):
     from splat_one_amd import distributed as sdist
     env_backup = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     try:
-        sdist.cli(_row_worker, (str(tmp_path), cap, Ns), world_size=world, backend="gloo", port=_free_port())
+        sdist.cli(_row_worker, (str(tmp_path), cap, Ns, n_chunks, void_at), world_size=world, backend="gloo", port=_free_port())
     finally:
         for k, v in env_backup.items():
             if v is not None:
@@ -204,14 +233,16 @@ def test_row_sharded_adam_equals_adam_on_the_mean_gradient(tmp_path, world, cap,
                     st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(new), torch.zeros_like(new)
                     st["exp_avg"][:n0], st["exp_avg_sq"][:n0] = st_old["exp_avg"][:n0], st_old["exp_avg_sq"][:n0]
                 params[k], opts[k] = new, opt
-            params[k].grad = sum(_grads(N, r, step)[k].view(N, rl) for r in range(world)) / world
-            opts[k].step()
+            if step != void_at:                  # the void iteration never happened (its refinement bookkeeping did)
+                params[k].grad = sum(_grads(N, r, step)[k].view(N, rl) for r in range(world)) / world
+                opts[k].step()
     for k in ROWS:
         assert torch.allclose(outs[0]["P"][k], params[k].detach(), rtol=1e-5, atol=1e-7), k
         assert torch.allclose(outs[0]["M"][k], opts[k].state[params[k]]["exp_avg"], rtol=1e-5, atol=1e-6), k
     N = Ns[-1]
-    p = -(-N // (16 * world)) * 16
-    assert abs(outs[0]["bytes"] - 2 * (world - 1) / world * p * world * 59 * 4) < 1
+    q = 64 * world
+    span = -(-N // (n_chunks * q)) * q * n_chunks
+    assert abs(outs[0]["bytes"] - 2 * (world - 1) / world * span * 59 * 4) < 1
 
 
 # ------------------------------------------------------------------------------------------------ fallback agreement
@@ -235,7 +266,7 @@ def _fallback_worker(local_rank, world_rank, world_size, args):
         for _ in range(2):
             for k in G:
                 G[k].fill_(float(world_rank + 1))
-            ra.step(G, P, N, lambda names, a, b: [P[k][a:b].sub_(G[k][a:b]) for k in names] and seen.append((a, b)))
+            ra.step(G, P, N, lambda names, a, b, skip, gs: [P[k][a:b].sub_(G[k][a:b] * gs) for k in names] and seen.append((a, b)))
     cm = ra.comm_ms()
     assert cm["steps_timed"] == 2 and cm["collectives"] == ra.mode and cm["total_ms"] >= 0.0
     assert set(sdist._PhaseTimer.PHASES) <= set(cm)
@@ -246,7 +277,7 @@ def _fallback_worker(local_rank, world_rank, world_size, args):
 @pytest.mark.parametrize("forced,want", [(None, "coalesced"), ("1", "per_tensor"), ("all", "per_tensor")])
 def test_collective_fallback_is_agreed_on_by_all_ranks(tmp_path, forced, want):
     from splat_one_amd import distributed as sdist
-    world, cap, N = 2, 64, 37
+    world, cap, N = 2, 128, 37
     keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SPLAT_ONE_AMD_FORCE_COALESCE_FAIL")
     env_backup = {k: os.environ.pop(k, None) for k in keys}
     try:

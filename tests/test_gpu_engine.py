@@ -306,3 +306,53 @@ def test_engine_fused_adam_equals_the_two_kernel_step(dev, use_graph):
         assert not torch.equal(pb[k], _make(dev, N, W, H, "mcmc", 2)[0].splats[k].detach()), k     # it did train
     assert rel_err(g2a, g2b) < 1e-4 and torch.equal(cna, cnb) and (la - lb).abs().max().item() < 1e-5
 
+
+
+@pytest.mark.parametrize("use_graph,attr_dtype,device_refine", [(False, "f32", False), (True, "f32", True), (False, "f16", True)])
+def test_head_plus_row_chunks_equal_the_whole_step(dev, use_graph, attr_dtype, device_refine):
+    """Data-parallel replicas run the iteration as so_train_step_head + so_train_step_bwd_rows per row chunk (so that a
+    chunk's reduce-scatter runs under the next chunk's kernel).  On ONE set of gradient records the chunked backward equals
+    the backward over all rows BIT FOR BIT (gradients, regulariser terms, densification statistics), whatever the cut
+    (uneven chunks, a chunk past the live rows); against the one-call step of a second engine it agrees up to the order of
+    the rasteriser's atomic adds."""
+    from splat_one_amd.engine import FusedEngine
+    N, W, H, C = 5000, 160, 96, 2
+    res = {}
+    for split in (False, True):
+        r, c2w, Ks, pixels = _make(dev, N, W, H, "mcmc", C, opacity_reg=0.01, scale_reg=0.01)
+        st = r.cfg.strategy.initialize_state(1.0)
+        eng = FusedEngine(r.splats, r.optimizers, W, H, C, sh_degree=3, strategy_state=st, use_graph=use_graph, attr_dtype=attr_dtype,
+                          opacity_reg=0.01, scale_reg=0.01, device_refine=device_refine, capacity=(8192 if device_refine else None))
+        rows = 8192 if device_refine else N
+        stats = eng.dstats if device_refine else st
+        snap = lambda: ({k: v[:N].clone() for k, v in eng.ws["grads"].items()}, stats["grad2d"][:N].clone(), stats["count"][:N].clone())
+        if not split:
+            eng.set_views(c2w, Ks, pixels)
+            eng.fwd_bwd()
+            torch.cuda.synchronize()
+            res[split] = snap() + (eng.loss().clone(),)
+            continue
+        for it in range(2):          # twice: the second pass replays the captured head graph
+            eng.set_views(c2w, Ks, pixels)
+            eng.fwd_bwd_head()
+        for k in ("grad2d", "count"):
+            stats[k].zero_()
+        eng.bwd_rows(0, rows)                                     # all rows in one launch ...
+        torch.cuda.synchronize()
+        whole = snap()
+        for v in eng.ws["grads"].values():
+            v.fill_(float("nan"))
+        for k in ("grad2d", "count"):
+            stats[k].zero_()
+        for a, b in ((0, 1024), (1024, 1088), (1088, 4992), (4992, rows)):     # ... and cut into chunks, on the same records
+            eng.bwd_rows(a, b)
+        torch.cuda.synchronize()
+        cut = snap()
+        for k in whole[0]:
+            assert torch.equal(whole[0][k], cut[0][k]) and whole[0][k].abs().sum() > 0, k
+        assert torch.equal(whole[1], cut[1]) and torch.equal(whole[2], cut[2]) and float(cut[2].sum()) > 0
+        res[split] = cut + (eng.loss().clone(),)
+    for k in res[False][0]:
+        assert rel_err(res[True][0][k], res[False][0][k]) < 1e-5, k
+    assert rel_err(res[True][1], res[False][1]) < 1e-5 and torch.equal(res[True][2], res[False][2])
+    assert torch.allclose(res[True][3], res[False][3], rtol=1e-6, atol=0)

@@ -282,6 +282,76 @@ def test_gaussian_sharded_overflow_voids_and_grows_on_every_rank(dev, tmp_path):
             assert v < 2e-4, (k, v, o)
 
 
+def _replicated_overflow_worker(local_rank, world_rank, world_size, args):
+    import warnings
+    out_dir, device_refine = args
+    from splat_one_amd.trainer import Config, Runner
+    dev = torch.device("cuda:0")
+    W, H, N = 128, 96, 3000
+
+    def make(bin_capacity):
+        cfg = Config(init_num_pts=N, init_scale=0.3, init_opa=0.3, shN_init_std=0.05, sh_degree_interval=1, fused=True,
+                     dp_mode="allreduce", device_refine=device_refine, dp_chunks=3, bin_capacity=bin_capacity)
+        r = Runner(0, world_rank, world_size, cfg, scene_scale=1.0 / 1.1)
+        with torch.no_grad():
+            r.splats["scales"].add_((torch.randn(N, 3, generator=torch.Generator().manual_seed(7)) * 0.4).to(dev))
+        return r
+
+    c2w = ring_cameras(8)[world_rank:world_rank + 1].to(dev)
+    Ks = pinhole_K(W, H)[None].to(dev)
+    pixels = torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(100 + world_rank)).to(dev)
+    a = make(4096)                                   # ample bins on both ranks: the run to reproduce
+    a.train_step(c2w, Ks, pixels)
+    fullest = a._engine._fullest_tile()
+    for _ in range(4):
+        a.train_step(c2w, Ks, pixels)
+    assert a._engine.void_steps == 0
+    # bins too small on the LAST rank only: its view voids the iteration on EVERY rank (the flag is summed by the gradient
+    # reduce-scatter: no collective of its own), both take the same iterations back, only that rank enlarges its bins
+    b = make(max(16, fullest // 2) if world_rank == world_size - 1 else 4096)
+    calls = 0
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        while getattr(b, "_engine", None) is None or b._engine.steps_done < 5:
+            b.train_step(c2w, Ks, pixels)
+            calls += 1
+            assert calls < 16, "the replicas do not recover from the overflow"
+    torch.cuda.synchronize()
+    assert b._engine.on_overflow == "defer" and (b._radam if device_refine else b._sadam).n_chunks == 3
+    rel = {k: ((b.splats[k] - a.splats[k]).norm() / a.splats[k].norm().clamp_min(1e-12)).item() for k in a.splats.keys()}
+    torch.save({"fullest": fullest, "calls": calls, "void": b._engine.void_steps, "bins": b._engine.bin_capacity, "rel": rel,
+                "warned_here": sum(1 for w in caught if "buffers enlarged" in str(w.message)),
+                "warned_other": sum(1 for w in caught if "another rank" in str(w.message)),
+                "splats": {k: v.detach().cpu() for k, v in b.splats.items()},
+                "opt_step": float(b.optimizers["means"].state[b.splats["means"]]["step"])},
+               os.path.join(out_dir, f"rovf{world_rank}.pt"))
+
+
+@pytest.mark.parametrize("device_refine", [True, False])
+def test_replicated_dp_overflow_is_void_on_every_rank_and_training_goes_on(dev, tmp_path, device_refine):
+    """replicas no longer raise on an overflow.  One rank's bins are too small: the iteration is void on
+    BOTH ranks (flag summed by the reduce-scatter, Adam skips on the device), both hosts take the same two iterations back
+    one step late, the rank that overflowed enlarges its bins, and the run ends where the run with ample bins ends --
+    with the backward cut into three row chunks (so_train_step_head / so_train_step_bwd_rows) under the reduce-scatters."""
+    from splat_one_amd import distributed as sdist
+    env_backup = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        sdist.cli(_replicated_overflow_worker, (str(tmp_path), device_refine), world_size=2, backend="gloo", port=_free_port())
+    finally:
+        for k, v in env_backup.items():
+            if v is not None:
+                os.environ[k] = v
+    out = [torch.load(os.path.join(tmp_path, f"rovf{i}.pt")) for i in range(2)]
+    for i, o in enumerate(out):
+        assert o["void"] == 2 and o["calls"] == 7 and o["opt_step"] == 5.0, o["void"]     # found one step late: two void iterations
+        assert (o["warned_here"], o["warned_other"]) == ((1, 0) if i == 1 else (0, 1)), (i, o["warned_here"], o["warned_other"])
+        for k, v in o["rel"].items():
+            assert v < 2e-4, (k, v)
+        for k in o["splats"]:
+            assert torch.equal(o["splats"][k], out[0]["splats"][k]), k
+    assert out[0]["bins"] == 4096 and out[1]["bins"] >= 2 * max(16, out[1]["fullest"] // 2)
+
+
 def _replicated_operator_worker(local_rank, world_rank, world_size, args):
     """Operator-level path (Config.fused=False) with replicated Gaussians: visible_adam / packed + sparse_grad, a
     narrow view per rank so that the two ranks SEE DIFFERENT Gaussians, with densification inside the run."""
