@@ -162,6 +162,30 @@ def rank_report(dist, local_rank, dev_index):
     return out
 
 
+XGMI_GBS_PER_LINK_DIRECTION = 76.8      # 153.6 GB/s per link, both directions together; 7 links per GPU, fully connected
+XGMI_EFFICIENCY = 0.8                   # what a large RCCL transfer is assumed to reach of it
+RCCL_LAUNCH_US = 15.0                   # per grouped collective launch (latency floor), assumed
+
+
+def comm_model(N, K, n_chunks):
+    """Predicted reduce-scatter / all-gather time per optimiser step of the replicated scheme at 2 / 4 / 8 ranks, from bytes
+    per xGMI link and direction -- printed next to the measured config.comm_ms so that the first
+    multi-GPU run explains itself.  Direct exchange on the fully connected mesh: piece j of every rank's rows goes straight
+    to rank j, so a link carries rows x 4 (11 + 3 K) bytes / world per phase and direction."""
+    floats_per_row = 11 + 3 * K
+    out = {"assumptions": {"xgmi_GBs_per_link_direction": XGMI_GBS_PER_LINK_DIRECTION, "efficiency": XGMI_EFFICIENCY,
+                           "launch_us_per_grouped_collective": RCCL_LAUNCH_US, "pattern": "direct (piece j -> rank j), all links busy",
+                           "collectives_per_phase": 2 * n_chunks}, "by_world": {}}
+    for w in (2, 4, 8):
+        q = w * 64 * n_chunks
+        span = -(-N // q) * q
+        per_link = span * floats_per_row * 4.0 / w
+        ms = per_link / (XGMI_GBS_PER_LINK_DIRECTION * XGMI_EFFICIENCY * 1e9) * 1e3 + 2 * n_chunks * RCCL_LAUNCH_US * 1e-3
+        out["by_world"][str(w)] = {"rows_exchanged": span, "bytes_per_link_and_direction_per_phase": per_link,
+                                   "reduce_scatter_ms": ms, "all_gather_ms": ms, "ring_bytes_per_link_per_phase": per_link * (w - 1)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -487,15 +511,42 @@ def main():
                                  "so_rasterize_bwd", "so_sh_bwd", "so_projection_bwd", "so_adam_step"))
     dominant = dominant.replace("_packed", "")          # the packed-record entry points share the byte model
     traffic = None
+    profile_notes = {}
+
+    def collected_near(j, what):
+        """A committed counter summary applies to this run only if it was collected at (nearly) the same workload state: the
+        passes walk tile lists, and their number follows the tile intersections I."""
+        at = (j.get("_collected_at") or {}).get("tile_intersections")
+        if not at:
+            profile_notes[what] = "refused: the summary in profiles/ does not say at which tile-intersection count it was collected"
+            return False
+        if abs(I - at) > 0.05 * at:
+            profile_notes[what] = f"refused: collected at I = {at}, this run has I = {I} (> 5 % apart)"
+            return False
+        profile_notes[what] = f"collected at I = {at} (this run: I = {I})"
+        return True
+
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     # the PMC traffic in profiles/ was collected on c2 with the fused engine: it says nothing about another workload
     is_c2_engine = ((N0, W, H, args.densify, world, len(views)) == (100_000, 1920, 1080, 0, 1, 8) and fused and args.attr_dtype == "f32"
                     and args.regime == "mcmc" and args.cloud_scale == 1.0)
     if os.path.exists(tpath) and is_c2_engine:
         try:
-            traffic = json.load(open(tpath)).get(dominant)
+            tj = json.load(open(tpath))
+            traffic = tj.get(dominant) if collected_near(tj, "traffic") else None
         except Exception:
             traffic = None
+    # rocprofv3's own average for the dominant kernel (profiles/kernel_us.json <- the committed --kernel-trace --stats summary
+    # of this command), next to the live stage timer
+    kernel_us_rocprof = None
+    kpath = os.path.join(ROOT, "profiles", "kernel_us.json")
+    if os.path.exists(kpath) and is_c2_engine:
+        try:
+            kj = json.load(open(kpath))
+            if dominant in kj:
+                kernel_us_rocprof = {"us": kj[dominant], "source": kj.get("_note"), "collected_at": kj.get("_collected_at")}
+        except Exception:   # noqa: BLE001
+            kernel_us_rocprof = None
 
     # every timed stage against the HBM roofline (the table of DESIGN.md section 4): which kernels stream at the
     # roofline and which are bound by instruction issue
@@ -527,15 +578,14 @@ def main():
     if os.path.exists(vpath) and is_c2_engine:
         try:
             vj = json.load(open(vpath))
-            ent = vj.get(dominant)
+            ent = vj.get(dominant) if collected_near(vj, "valu") else None
             if ent:
                 rate = ent["wave_instructions"] / (dom_ms * 1e-3)
                 valu = {"wave_instructions_per_launch": ent["wave_instructions"], "achieved": rate, "peak": VALU_PEAK_WAVE_INSTR_PER_S,
                         "unit": "wave64 VALU instructions/s", "frac": rate / VALU_PEAK_WAVE_INSTR_PER_S,
                         "active_lane_fraction": ent.get("active_lane_fraction"),
                         "useful_lane_fraction": (vj.get("_useful_lane_fraction_model") or {}).get(dominant),
-                        "source": "profiles/valu.json (SQ counters of this workload, collected at I = 371k-class model states; "
-                                  "useful lanes: tools/passsim.py)"}
+                        "source": "profiles/valu.json (SQ counters of this workload; useful lanes: tools/passsim.py)"}
         except Exception:   # noqa: BLE001
             valu = None
     hbm_frac = achieved / HBM_PEAK_GBS
@@ -575,14 +625,20 @@ def main():
                                                                 f", replicated Gaussians: reduce-scatter / 1/{world} Adam / all-gather of the "
                                                                 f"gradient SoA in {getattr(runner, '_dp_chunks', cfg.dp_chunks)} chunk(s) over RCCL")),
                    "dp_mode_probe_ms_per_step": dp_probe,
-                   "rccl": rccl, "comm_ms": comm_ms},
+                   "rccl": rccl, "comm_ms": comm_ms, "comm_model": comm_model(N, K, getattr(runner, "_dp_chunks", 1) or 1)},
         "forward_mpix_per_s": None if runner.sharded else world * P / fwd_s / 1e6,
         "hbm_iter_fraction": b_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9),
         "algorithmic_bytes_per_iter": b_iter,
         "roofline": {"bound": bound, "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": hbm_frac, "traffic": traffic,
                      "algorithmic_bytes_per_launch": dom_bytes, "mean_launch_us": dom_ms * 1e3,
-                     "launches_timed": dom_calls, "valu": valu},
+                     "launches_timed": dom_calls, "valu": valu, "kernel_us_rocprof": kernel_us_rocprof,
+                     "profile_notes": profile_notes},
+        # BASELINE.json north_star: >= 1000 it/s at c2 on one MI355X AND >= 40 % of the HBM roofline
+        "target": {"it_s": 1000, "hbm_frac": 0.40, "it_s_met": bool(world * args.steps / elapsed >= 1000 * world),
+                   "hbm_iter_fraction": b_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9),
+                   "hbm_frac_met": bool(b_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9) >= 0.40),
+                   "dominant_kernel_hbm_frac": hbm_frac},
         "roofline_by_kernel": by_kernel,
         "void_steps": void_steps,
     }

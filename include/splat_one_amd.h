@@ -456,7 +456,9 @@ typedef struct so_step_desc {
   float *grad2d, *count;
   int64_t isect_capacity;
   int32_t abi_size, C, N, K, width, height, tile_size, sh_degree, camera_model, antialiased, absgrad;
-  int32_t raster_impl; /* must be 0 (the wave-per-quadrant kernels of round 1 moved to tools/experiments/) */
+  int32_t raster_impl; /* backward rasteriser mapping: 0 one wave per 8x8 quadrant (default); 1 one wave per 16x16 tile -- one
+                        * reduction and one atomic per (tile, Gaussian) instead of per (quadrant, Gaussian): faster from ~250
+                        * list entries per tile on (16x16 tiles, no absgrad; otherwise 0 is used) */
   float eps2d, near_plane, far_plane, radius_clip, ssim_lambda, opacity_reg, scale_reg;
   /* Inputs staged by so_step_inputs (both optional, zero = off):
    *   pixels_indirect  device slot holding the address of this iteration's target image [C,H,W,3]; when set it

@@ -71,3 +71,30 @@ def l1_sign_report(colors_oracle, colors_device, pixels):
     flip = torch.sign(xo - y) != torch.sign(xd - y)
     return {"flips": int(flip.sum()), "max_abs_diff_at_flips": float((xo - y).abs()[flip].max()) if flip.any() else 0.0,
             "pixel_channels": int(flip.numel())}
+
+
+def disparity_loss(depths, points, depths_gt, width, height, dtype=torch.float64):
+    """The depth-supervision term of /root/reference/utils/gsplat_utils/gsplat_trainer.py:629-644, without the scene scale
+    and depth_lambda factors the caller applies (:644-645): the rendered expected depth [B,H,W,1] (render_mode "RGB+ED",
+    :595) bilinearly sampled at the SfM points [B,M,2] in pixel coordinates (grid_sample, align_corners=True), disparity
+    1/d where d > 0 and 0 elsewhere, mean |disp - 1/depths_gt| over all B x M points.  Restated with explicit bilinear
+    weights (no grid_sample): x = px (W-1)/(W-1) = px, so the sample is the 2x2 neighbourhood of (px, py), zero outside."""
+    d, p, g = depths.to(dtype)[..., 0], points.to(dtype), depths_gt.to(dtype)
+    B, H, W = d.shape
+    assert (W, H) == (width, height)
+    x, y = p[..., 0], p[..., 1]
+    x0, y0 = torch.floor(x), torch.floor(y)
+    out = torch.zeros_like(x)
+    bi = torch.arange(B)[:, None].expand_as(x)
+    for dx in (0, 1):
+        for dy in (0, 1):
+            xi, yi = x0 + dx, y0 + dy
+            w = (1 - (x - xi).abs()) * (1 - (y - yi).abs())
+            ok = (xi >= 0) & (xi <= W - 1) & (yi >= 0) & (yi <= H - 1)
+            v = d[bi, yi.clamp(0, H - 1).long(), xi.clamp(0, W - 1).long()]
+            out = out + torch.where(ok, w * v, torch.zeros_like(v))
+    # value of where(d > 0, 1 / d, 0) (:641); the inner where only keeps autograd from forming 0 * inf at d = 0 exactly (a
+    # point over an empty pixel), where the reference's own expression differentiates to NaN
+    pos = out > 0
+    disp = torch.where(pos, 1.0 / torch.where(pos, out, torch.ones_like(out)), torch.zeros_like(out))
+    return (disp - 1.0 / g).abs().mean()

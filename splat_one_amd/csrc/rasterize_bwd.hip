@@ -410,6 +410,11 @@ int rasterize_bwd_packed_launch(int C, int N, int width, int height, int tile_si
                                 int64_t n_isects_host, const float *render_alphas, const int32_t *last_ids,
                                 const float *v_render_colors, const float *v_render_alphas, float *vrec, int absgrad,
                                 const LossFinal &fin, void *stream);
+int rasterize_bwd_tile_launch(int C, int N, int width, int height, int tile_w, int tile_h, const float *rec,
+                              const float *backgrounds, const int32_t *isect_offsets, const int32_t *flatten_ids,
+                              const int32_t *n_isects_dev, int64_t n_isects_host, const float *render_alphas,
+                              const int32_t *last_ids, const float *v_render_colors, const float *v_render_alphas,
+                              float *vrec, int wrap_flags, const LossFinal &fin, hipStream_t st);
 }  // namespace so
 
 extern "C" int so_rasterize_bwd(int C, int N, int D, int width, int height, int tile_size, const float *means2d,
@@ -485,6 +490,16 @@ int so::rasterize_bwd_packed_launch(int C, int N, int width, int height, int til
              (long long)C * tile_w * tile_h);
   const dim3 grid((unsigned)((int64_t)C * tile_w * tile_h));
   hipStream_t st = so::as_stream(stream);
+  // 16x16 tiles without absgrad, on request: one wave per tile, one reduction and one atomic per (tile, Gaussian) --
+  // rasterize_bwd_tile.hip.  Measured (profiles/r04_experiments.json: rasterize_bwd_tile_waves): 22 % fewer vector
+  // instructions, but a tile is then one wave's serial chain -- 957 -> 803 us on the dense regime's 520-entry lists, 73 ->
+  // 76 us on c2's 31-entry lists, 177 -> 204 us at 106 entries.  The fused engine asks for it when its probe finds >= 256
+  // entries per tile (so_step_desc.raster_impl = 1); SPLAT_ONE_AMD_BWD_TILE=1 / 0 sets the default of every other caller.
+  static const bool env_tile = [] { const char *e = getenv("SPLAT_ONE_AMD_BWD_TILE"); return e && e[0] == '1'; }();
+  const bool tile_waves = fin.tile_waves < 0 ? env_tile : fin.tile_waves != 0;
+  if (tile_size == 16 && !absgrad && tile_waves)
+    return so::rasterize_bwd_tile_launch(C, N, width, height, tile_w, tile_h, rec, backgrounds, isect_offsets, flatten_ids, n_isects_dev,
+                                         n_isects_host, render_alphas, last_ids, v_render_colors, v_render_alphas, vrec, wrap_flags, fin, st);
   // SMALL: every gradient record lies within 4 GB of `vrec` (C N 64 B): the atomic's address is a 32-bit offset from the base
   const bool small = (int64_t)C * N < ((int64_t)1 << 26);
 #define SO_GO_(TSV, ABSV, SM)                                                                                     \

@@ -14,6 +14,10 @@ struct LossFinal {
   // skip (nullable; so_rasterization_bwd): the forward's binning pass cut a list (its overflow counter) -> this backward
   // leaves the gradient records at the zeros the forward wrote: a cut image teaches nothing (raster_op.py)
   const int32_t *skip = nullptr;
+  // which mapping the packed RGB backward uses (rasterize_bwd.hip): 0 one wave per 8x8 quadrant, 1 one wave per 16x16 tile
+  // (rasterize_bwd_tile.hip: fewer instructions, longer per-tile chains -- faster from ~250 list entries per tile on),
+  // -1 the process default (SPLAT_ONE_AMD_BWD_TILE, else 0)
+  int tile_waves = -1;
 };
 
 // SO_RASTER_V2 (round 3): the RGB passes of both rasteriser kernels on packed fp32 pairs (v_pk_mul / v_pk_fma are the

@@ -247,7 +247,8 @@ static int step_impl(const so_step_desc *d, void *stream, StepPart part, int64_t
   // place the keys, so the scan and the scatter pass do not exist (tile_counts doubles as the per-tile list length)
   const int64_t bins = d->bin_capacity;
   if (part != STEP_TAIL) {
-  SO_REQUIRE(d->raster_impl == 0, "so_train_step_fwd_bwd: raster_impl must be 0");
+  SO_REQUIRE(d->raster_impl == 0 || d->raster_impl == 1, "so_train_step_fwd_bwd: raster_impl must be 0 (a wave per 8x8 quadrant) or 1 "
+             "(backward: a wave per 16x16 tile)");
   SO_REQUIRE(bins >= 0, "so_train_step_fwd_bwd: bad bin_capacity");
   // periodic views: spherical cameras, when the tile grid lines up across the seam (so_preprocess_fwd derives the same
   // from camera_model; the fill pass and the rasteriser take it as flags in their tile_size argument)
@@ -315,7 +316,8 @@ static int step_impl(const so_step_desc *d, void *stream, StepPart part, int64_t
                           d->ssim_lambda, stream));
   }
   // gradients of the intermediates accumulate in the 64-byte records vrec[C*N] (zeroed by the
-  // forward preprocess kernel): one atomic request per (tile quadrant, Gaussian)
+  // forward preprocess kernel): one atomic request per (tile quadrant, Gaussian), or per (tile, Gaussian) with raster_impl 1
+  fin.tile_waves = d->raster_impl == 1 ? 1 : 0;
     SO_STAGE(6, so::rasterize_bwd_packed_launch(C, N, W, H, ts | wrap_flags, d->rec, d->backgrounds, list_off, d->flatten_ids, list_n,
                                                 list_cap, d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
                                                 d->absgrad, fin, stream));

