@@ -19,15 +19,22 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS = {}
 
 
+# SPLAT_ONE_AMD_SANITIZE=1 (tests/test_sanitizers.py, in a child process started with LD_PRELOAD=libasan): load the
+# -fsanitize=address,undefined builds of the same source
+_SAN = os.environ.get("SPLAT_ONE_AMD_SANITIZE") == "1"
+
+
 def build(quiet: bool = True) -> None:
-    subprocess.run(["make", "-C", _HERE] + (["-s"] if quiet else []), check=True)
+    subprocess.run(["make", "-C", _HERE] + (["sanitize"] if _SAN else []) + (["-s"] if quiet else []), check=True)
 
 
 def _lib(dtype: torch.dtype):
     name = {torch.float64: "liboracle_f64.so", torch.float32: "liboracle_f32.so"}[dtype]
+    if _SAN:
+        name = name.replace(".so", "_san.so")
     if name not in _LIBS:
         path = os.path.join(_HERE, "_build", name)
-        if not os.path.exists(path):
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(_HERE, "c", "raster_oracle.c")):
             build()
         lib = ctypes.CDLL(path)
         assert lib.oracle_real_size() == torch.empty(0, dtype=dtype).element_size()

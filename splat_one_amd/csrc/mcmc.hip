@@ -396,7 +396,13 @@ extern "C" int so_mcmc_refine(int64_t capacity, int K, const so_model_set *set, 
   double *boff_w = bsum_w + nblk;
   int32_t *bsum_d = reinterpret_cast<int32_t *>(boff_w + nblk);
   int32_t *boff_d = bsum_d + nblk;
-  int32_t *tot = boff_d + nblk + ((nblk & 1) ? 1 : 0);
+  // `tot` is read and written as doubles (k_mcmc_scan / k_mcmc_draw): keep it 8-byte aligned.  bsum_d is (follows two
+  // double arrays behind an aligned start) and boff_d + nblk = bsum_d + 2 nblk words is again -- ADVICE r3: the former
+  // "+ (nblk & 1)" pad MISaligned it for odd nblk; round up explicitly and check
+  int32_t *tot = boff_d + nblk;
+  tot += ((uintptr_t)tot & 7) ? 1 : 0;
+  SO_REQUIRE(((uintptr_t)tot & 7) == 0 && ((uintptr_t)bsum_w & 7) == 0 && ((uintptr_t)cdf & 7) == 0,
+             "so_mcmc_refine: the float64 regions of the scratch must be 8-byte aligned (scratch itself: 8 bytes)");
   SO_REQUIRE(tot + 16 <= scratch + so_mcmc_scratch_words(capacity), "so_mcmc_refine: internal scratch layout error");
   hipStream_t st = so::as_stream(stream);
   const int gs = so::mc_grid(capacity);

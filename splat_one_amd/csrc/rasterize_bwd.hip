@@ -10,9 +10,8 @@
 // tile's last contributor are never loaded.
 #include "rasterize_common.hpp"
 
-// SO_RASTER_V2 (rasterize_common.hpp, round 3): the D == 3 pass on packed fp32 pairs, the conic applied ONCE per pass --
+// The D == 3 pass works on packed fp32 pairs with the conic applied ONCE per pass (rasterize_common.hpp, round 3):
 // q = Q d serves sigma = 1/2 d.q AND the position gradient v_sigma q.
-#define SO_BWD_V2 SO_RASTER_V2
 
 namespace so {
 
@@ -127,15 +126,16 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
     else if (ABS && slot < 11) { out_base = v_means2d_abs + (slot - 9); out_stride = 2; }
   }
 
-  // SO_BWD_V2, no absgrad: the nine-sum network's lanes (so_common.hpp::wave_reduce9_scattered)
+  // the nine-sum network's lanes (so_common.hpp::wave_reduce9_scattered): RGB without absgrad, and -- round 4 -- the first
+  // three channels + geometry of every D >= 4 call (RGB+ED, what the depth-supervision loss renders: gsplat_trainer.py:595)
   const bool atom_lane = ((kReduce9Lanes >> lane) & 1ull) != 0;
   const int slot9 = reduce9_slot_of_lane(lane);
   float *out_base9 = nullptr;
   int out_stride9 = 0;
-  if (D == 3 && !PACKED) {
+  if (D >= 3 && !PACKED) {
     if (slot9 < 2) { out_base9 = v_means2d + slot9; out_stride9 = 2; }
     else if (slot9 < 5) { out_base9 = v_conics + (slot9 - 2); out_stride9 = 3; }
-    else if (slot9 < 8) { out_base9 = v_colors + (slot9 - 5); out_stride9 = 3; }
+    else if (slot9 < 8) { out_base9 = v_colors + (slot9 - 5); out_stride9 = D; }
     else { out_base9 = v_opacities; out_stride9 = 1; }
   } else if (D == 3) {
     out_base9 = v_colors + slot9; out_stride9 = 16;
@@ -163,7 +163,6 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
           q0.x -= shift; bx.x -= shift; bx.y -= shift;
         }
         s_box[tid] = bx;
-#if SO_BWD_V2
         // (x, y, ca, cb) | (cb, cc, opacity) | (red, green, blue): (ca, cb) and (cb, cc) are aligned register pairs after the loads
         // s_C.w: the byte offset of this Gaussian's gradient record, so that the atomic's address needs no further LDS read
         const float4 q2 = r4[2];                                    // blue, depth, radius, cull threshold
@@ -171,26 +170,16 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         s_A[tid] = q0;
         s_B[tid] = make_float4(q0.w, q1.x * kConicScale, q1.y, q2.w * kConicScale);
         s_C[tid] = make_float4(q1.z, q1.w, q2.x, __uint_as_float((unsigned)g * 64u));
-#else
-        s_A[tid] = q0;
-        s_B[tid] = q1;
-        s_C[tid] = make_float4(r4[2].x, r4[2].w, 0.f, 0.f);         // blue, cull threshold
-#endif
       } else {
         float2 xy = means2d[g];
         if (wrap) xy.x -= wrap_w * rintf((xy.x - wrap_cx) / wrap_w);
         const float op = opacities[g];
         const float ca = conics[3 * (int64_t)g], cb = conics[3 * (int64_t)g + 1], cc = conics[3 * (int64_t)g + 2];
-        s_A[tid] = (D == 3 && SO_BWD_V2) ? make_float4(xy.x, xy.y, ca * kConicScale, cb * kConicScale) : make_float4(xy.x, xy.y, ca, cb);
+        s_A[tid] = (D == 3) ? make_float4(xy.x, xy.y, ca * kConicScale, cb * kConicScale) : make_float4(xy.x, xy.y, ca, cb);
         s_box[tid] = alpha_bound_box(xy.x, xy.y, op, ca, cb, cc);
         if (D == 3) {
-#if SO_BWD_V2
           s_B[tid] = make_float4(cb * kConicScale, cc * kConicScale, op, cull_tau(op, ca, cb, cc) * kConicScale);
           s_C[tid] = make_float4(colors[(int64_t)g * D], colors[(int64_t)g * D + 1], colors[(int64_t)g * D + 2], 0.f);
-#else
-          s_B[tid] = make_float4(cc, op, colors[(int64_t)g * D], colors[(int64_t)g * D + 1]);
-          s_C[tid] = make_float4(colors[(int64_t)g * D + 2], cull_tau(op, ca, cb, cc), 0.f, 0.f);
-#endif
         } else {
           s_B[tid] = make_float4(cc, op, cull_tau(op, ca, cb, cc), 0.f);
 #pragma unroll
@@ -213,8 +202,7 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
           const float4 a = s_A[cand];
           const float4 bq = s_B[cand];
           // (x, y, cull threshold of this Gaussian, conic) against this wave's quadrant
-          if (D == 3 && SO_BWD_V2) hit = ellipse_hits_rect(a.x, a.y, bq.w, a.z, a.w, bq.y, qx0, qx1, qy0, qy1);
-          else if (D == 3) hit = ellipse_hits_rect(a.x, a.y, s_C[cand].y, a.z, a.w, bq.x, qx0, qx1, qy0, qy1);
+          if (D == 3) hit = ellipse_hits_rect(a.x, a.y, bq.w, a.z, a.w, bq.y, qx0, qx1, qy0, qy1);
           else hit = ellipse_hits_rect(a.x, a.y, bq.z, a.z, a.w, bq.x, qx0, qx1, qy0, qy1);
         }
       }
@@ -223,7 +211,6 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         const int bit = __ffsll((long long)mask) - 1;
         mask = clear_bit(mask, bit);
         const int tt = chunk0 + bit;
-#if SO_BWD_V2
         if constexpr (D == 3) {
           const float4 a = s_A[tt];            // x, y, ca, cb
           const float4 b4 = s_B[tt];           // cb, cc, opacity, (cull threshold)
@@ -300,8 +287,8 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
             }
           }
           continue;
-        }
-#endif
+        } else {
+        // ---- D != 3 (depth channel, N-D features): the scalar pass
         const float4 a = s_A[tt];
         const float4 bq = s_B[tt];
         const float opac = bq.y;
@@ -321,16 +308,10 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         const float fac = alpha_v * T;
         float g_col[D];
         float cv = 0.f;                          // sum_k colour[k] * v_c[k]
-        if constexpr (D == 3) {
-          cv = fmaf(s_C[tt].x, v_c[2], fmaf(bq.w, v_c[1], bq.z * v_c[0]));
 #pragma unroll
-          for (int k = 0; k < 3; ++k) g_col[k] = fac * v_c[k];
-        } else {
-#pragma unroll
-          for (int k = 0; k < D; ++k) {
-            cv = fmaf(s_col[tt * DC + k], v_c[k], cv);
-            g_col[k] = fac * v_c[k];
-          }
+        for (int k = 0; k < D; ++k) {
+          cv = fmaf(s_col[tt * DC + k], v_c[k], cv);
+          g_col[k] = fac * v_c[k];
         }
         // v_alpha = sum_k (c_k T - buffer_k ra) v_c[k] + T_final ra (v_a - bg . v_c)
         const float v_alpha = fmaf(T, cv, ra * (tf_bg - buf_dot));
@@ -343,23 +324,24 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         const float g_x = fmaf(a.z, t1, a.w * t2), g_y = fmaf(a.w, t1, bq.x * t2);
         float g_ax = 0.f, g_ay = 0.f;
         if (ABS) { g_ax = fabsf(g_x); g_ay = fabsf(g_y); }
-        if (D == 3) {
-          const float v8[8] = {g_x, g_y, g_cx, g_cy, g_cz, g_col[0], g_col[1 % D], g_col[2 % D]};
-          float val = row_reduce8_transposed(v8, lane);
-          const float r_op = row_allreduce_sum(g_op);
-          if (l15 == 8) val = r_op;
-          if (ABS) {
-            const float r_ax = row_allreduce_sum(g_ax), r_ay = row_allreduce_sum(g_ay);
-            if (l15 == 9) val = r_ax;
-            if (l15 == 10) val = r_ay;
+        if constexpr (D >= 4 && !ABS) {
+          // geometry + the first three channels through the nine-sum network (ONE atomic instruction, nine addresses);
+          // the channels beyond (the depth of RGB+ED, N-D features) as plain wave sums into lane 63.  Until round 3 all
+          // 6 + D sums went the second way: 10 single-lane atomics per pass for RGB+ED.  (With absgrad the old form stays:
+          // |gradient| sums and gradient sums are then added in the SAME order, so absgrad >= |grad| holds to the last bit.)
+          const float v8[8] = {g_x, g_y, g_cx, g_cy, g_cz, g_col[0], g_col[1], g_col[2]};
+          const float val9 = wave_reduce9_scattered(v8, g_op);
+#pragma unroll
+          for (int k = 3; k < D; ++k) g_col[k] = wave_reduce_sum_to_last(g_col[k]);
+          const int64_t g = s_id[tt];
+          if (atom_lane) atomicAdd(out_base9 + g * out_stride9, val9);
+          if (lane == 63) {
+#pragma unroll
+            for (int k = 3; k < D; ++k) atomicAdd(v_colors + g * D + k, g_col[k]);
           }
-          // combine the four rows, then ONE atomic instruction with 9 (11) distinct addresses
-          // (one 64-byte record when PACKED)
-          val = rows_combine(val);
-          if (lane <= (ABS ? 10 : 8) && val != 0.f) atomicAdd(out_base + (int64_t)s_id[tt] * out_stride, val);
           continue;
         }
-        // generic channel counts: wave sums land in lane 63
+        // one or two channels: wave sums land in lane 63
 #pragma unroll
         for (int k = 0; k < D; ++k) g_col[k] = wave_reduce_sum_to_last(g_col[k]);
         const float w_cx = wave_reduce_sum_to_last(g_cx), w_cy = wave_reduce_sum_to_last(g_cy);
@@ -382,6 +364,7 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
           }
           atomicAdd(v_opacities + g, w_op);
         }
+        }   // D != 3
       }
     }
   }

@@ -20,15 +20,13 @@ struct LossFinal {
   int tile_waves = -1;
 };
 
-// SO_RASTER_V2 (round 3): the RGB passes of both rasteriser kernels on packed fp32 pairs (v_pk_mul / v_pk_fma are the
+// Round 3: the RGB passes of both rasteriser kernels work on packed fp32 pairs (v_pk_mul / v_pk_fma are the
 // only vector instructions that do two lanes-worth per issue slot on gfx950 -- SQ_ACTIVE_INST_VALU prices every other one
 // of these kernels at ~4 cycles per wave64), staged records laid out so that (ca, cb) and (cb, cc) are register pairs:
 //   s_A = (x, y, ca, cb)   s_B = (cb, cc, opacity, cull threshold)   s_C = (red, green, blue, record offset [bwd])
 // and ONE statement of the Gaussian's exponent shared by the forward and the backward, so that both take the same
 // alpha >= 1/255 decision bit for bit:  q = (k Q) d,  s = d . q,  exp(-sigma) = 2^(-s)  (k = log2 e / 2, see kConicScale).
-#ifndef SO_RASTER_V2
-#define SO_RASTER_V2 1
-#endif
+// (The round-2 scalar form of the RGB pass, kept behind SO_RASTER_V2=0 through round 3, is gone: it was built by no test.)
 typedef float raster_v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ raster_v2f conic_times(float ca, float cb0, float cb1, float cc, raster_v2f d) {
   raster_v2f q = raster_v2f{ca, cb0} * raster_v2f{d.x, d.x};

@@ -74,8 +74,8 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
   // Per-pixel state.  A finished pixel (outside the image, or transmittance exhausted) has T == 0, which
   // makes every later contribution vanish arithmetically -- the pass body below has no branches.  T_out
   // keeps the transmittance the pixel stopped at (exactly one of T, T_out is non-zero at the end).
-  // (SO_RASTER_V2, RGB: the same idea with one instruction less per pass -- T_live is the live transmittance or 0, T is never zeroed)
-  constexpr bool V2 = (D == 3) && SO_RASTER_V2;
+  // (RGB, round 3: the same idea with one instruction less per pass -- T_live is the live transmittance or 0, T is never zeroed)
+  constexpr bool V2 = (D == 3);
   float T = inside ? 1.f : 0.f, T_out = 0.f;
   float T_live = T;
   int cur_slot = -1;
@@ -117,31 +117,20 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
           q0.x -= shift; bx.x -= shift; bx.y -= shift;
         }
         s_box[tid] = bx;
-#if SO_RASTER_V2
         q0.z *= kConicScale; q0.w *= kConicScale;                   // conic and threshold in units of the exponent of 2
         s_A[tid] = q0;
         s_B[tid] = make_float4(q0.w, q1.x * kConicScale, q1.y, q2.w * kConicScale);   // cb, cc, opacity, cull threshold
         s_C[tid] = make_float4(q1.z, q1.w, q2.x, 0.f);              // red, green, blue
-#else
-        s_A[tid] = q0;
-        s_B[tid] = q1;
-        s_C[tid] = make_float4(q2.x, q2.w, 0.f, 0.f);               // blue, cull threshold
-#endif
       } else {
         float2 xy = means2d[g];
         if (wrap) xy.x -= wrap_w * rintf((xy.x - wrap_cx) / wrap_w);
         const float op = opacities[g];
         const float ca = conics[3 * (int64_t)g], cb = conics[3 * (int64_t)g + 1], cc = conics[3 * (int64_t)g + 2];
-        s_A[tid] = (D == 3 && SO_RASTER_V2) ? make_float4(xy.x, xy.y, ca * kConicScale, cb * kConicScale) : make_float4(xy.x, xy.y, ca, cb);
+        s_A[tid] = (D == 3) ? make_float4(xy.x, xy.y, ca * kConicScale, cb * kConicScale) : make_float4(xy.x, xy.y, ca, cb);
         s_box[tid] = alpha_bound_box(xy.x, xy.y, op, ca, cb, cc);
         if (D == 3) {
-#if SO_RASTER_V2
           s_B[tid] = make_float4(cb * kConicScale, cc * kConicScale, op, cull_tau(op, ca, cb, cc) * kConicScale);
           s_C[tid] = make_float4(colors[(int64_t)g * D], colors[(int64_t)g * D + 1], colors[(int64_t)g * D + 2], 0.f);
-#else
-          s_B[tid] = make_float4(cc, op, colors[(int64_t)g * D], colors[(int64_t)g * D + 1]);
-          s_C[tid] = make_float4(colors[(int64_t)g * D + 2], cull_tau(op, ca, cb, cc), 0.f, 0.f);
-#endif
         } else {
           s_B[tid] = make_float4(cc, op, cull_tau(op, ca, cb, cc), 0.f);
 #pragma unroll
@@ -166,8 +155,7 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
           const float4 a = s_A[cand];
           const float4 bq = s_B[cand];
           // (x, y, cull threshold of this Gaussian, conic) against this wave's quadrant
-          if (D == 3 && SO_RASTER_V2) hit = ellipse_hits_rect(a.x, a.y, bq.w, a.z, a.w, bq.y, qx0, qx1, qy0, qy1);
-          else if (D == 3) hit = ellipse_hits_rect(a.x, a.y, s_C[cand].y, a.z, a.w, bq.x, qx0, qx1, qy0, qy1);
+          if (D == 3) hit = ellipse_hits_rect(a.x, a.y, bq.w, a.z, a.w, bq.y, qx0, qx1, qy0, qy1);
           else hit = ellipse_hits_rect(a.x, a.y, bq.z, a.z, a.w, bq.x, qx0, qx1, qy0, qy1);
         }
       }
@@ -179,7 +167,6 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         const int bit = __ffsll((long long)mask) - 1;
         mask = clear_bit(mask, bit);                // one scalar instruction (mask &= mask - 1 is three)
         const int tt = chunk0 + bit;
-#if SO_RASTER_V2
         if constexpr (D == 3) {
           const float4 a = s_A[tt];                 // x, y, ca, cb
           const float4 b4 = s_B[tt];                // cb, cc, opacity
@@ -203,12 +190,10 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
           cur_slot = (vis > 0.f) ? tt * 16 : cur_slot;
           if (__ballot(!stop) == 0ull) break;       // the wave's last live pixel has just stopped
           continue;
-        }
-#endif
+        } else {
+        // ---- D != 3 (depth channel, N-D features): the scalar pass
         const float4 a = s_A[tt];
         const float4 bq = s_B[tt];
-        float blue = 0.f;
-        if constexpr (D == 3) blue = s_C[tt].x;     // issued with the other two reads, not at its use
         const float dx = a.x - px, dy = a.y - py;
         const float sigma = 0.5f * (a.z * dx * dx + bq.x * dy * dy) + a.w * dx * dy;
         float alpha = fminf(kAlphaMax, bq.y * __expf(-sigma));
@@ -219,15 +204,10 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
         T_out += stop ? T : 0.f;
         const float vis = stop ? 0.f : alpha * T;
         T = stop ? 0.f : next_T;
-        if constexpr (D == 3) {
-          acc[0] = fmaf(bq.z, vis, acc[0]);
-          acc[1] = fmaf(bq.w, vis, acc[1]);
-          acc[2] = fmaf(blue, vis, acc[2]);
-        } else {
 #pragma unroll
-          for (int k = 0; k < D; ++k) acc[k] = fmaf(s_col[tt * DC + k], vis, acc[k]);
-        }
+        for (int k = 0; k < D; ++k) acc[k] = fmaf(s_col[tt * DC + k], vis, acc[k]);
         cur_idx = (vis > 0.f) ? batch_base + tt : cur_idx;
+        }   // D != 3
       }
     }
     if constexpr (V2) {

@@ -148,6 +148,9 @@ k_refine_scan(int nblk, int64_t cap, const int32_t *__restrict__ block_counts, i
     report[0] = (int32_t)n_dup; report[1] = (int32_t)n_split;
     report[2] = (int32_t)(n_old + n_dup + n_split - (A + B + 2 * Cc));   // pruned from the grown set
     report[3] = (int32_t)n_new; report[4] = over; report[5] = (int32_t)n_old;
+    // the report lives in host-mapped memory and is polled without a synchronisation (FusedEngine.poll_refine_report): the
+    // sequence word goes out LAST, behind a system-scope fence, so that a host that sees it sees report[4] / [7] too
+    __threadfence_system();
     report[6] += 1;                 // refinements done on these buffers (the host's view of N is stale when it differs)
   }
 }

@@ -241,7 +241,10 @@ class FusedEngine:
         """One step late and without synchronising: did the last refinement fit?  (Called when the next view is staged.)"""
         if not self.device_refine or self._report_handled == self.refinements or int(self._report[6]) != self.refinements:
             return
-        if int(self._report[4]):
+        over = int(self._report[4])
+        if int(self._report[6]) != self.refinements:      # (re-read behind the sequence word: the kernel fences before it)
+            return
+        if over or int(self._report[4]):
             self._enlarge_and_refine_again()
         self._report_handled = self.refinements
 

@@ -153,8 +153,12 @@ def _device_sets(dev, P, M, V, cap):
     return sets, ms
 
 
-@pytest.mark.parametrize("N,n_dead,cap_max", [(20_000, 700, 10 ** 6), (5_000, 0, 5_100), (1_000, 990, 10 ** 6), (70_001, 3_000, 72_000)])
-def test_mcmc_refine_on_the_device_equals_the_oracle(dev, N, n_dead, cap_max):
+@pytest.mark.parametrize("N,n_dead,cap_max,cap", [(20_000, 700, 10 ** 6, 1 << 17), (5_000, 0, 5_100, 1 << 17), (1_000, 990, 10 ** 6, 1 << 17),
+                                                  (70_001, 3_000, 72_000, 1 << 17),
+                                                  # an ODD capacity and an ODD number of scan blocks (73): the float64 regions of
+                                                  # the scratch must stay 8-byte aligned (`tot` was not)
+                                                  (70_001, 3_000, 72_000, 74_751)])
+def test_mcmc_refine_on_the_device_equals_the_oracle(dev, N, n_dead, cap_max, cap):
     """so_mcmc_refine (relocate, then sample_add, one phase per call so that the weights the device formed can be read
     back) against oracle/mcmc_oracle.py: the SAME rows drawn, parameters of sources / relocated / appended rows, moments."""
     import ctypes
@@ -162,7 +166,6 @@ def test_mcmc_refine_on_the_device_equals_the_oracle(dev, N, n_dead, cap_max):
     from oracle import mcmc_oracle as MO
     from splat_one_amd import _lib
     from splat_one_amd.strategy import MCMCStrategy
-    cap = 1 << 17
     P, M, V = _random_model(N, seed=N, n_dead=n_dead)
     sets, ms = _device_sets(dev, P, M, V, cap)
     n_dev = torch.tensor([N], dtype=torch.int32, device=dev)
