@@ -616,6 +616,13 @@ def main():
                    "visible_gaussians_per_view": Vs, "tile_intersections_per_view": Is,
                    "tile_cull": bool(cfg.tile_cull and fused),   # I counts what is left after exact tile culling
                    "binned_lists": bool(fused and not runner.sharded and runner._engine.binned),
+                   # per-tile bins: slots per tile, their memory, and whether a skewed view made the engine fall back to the
+                   # compact slotted lists (FusedEngine.bin_budget_bytes)
+                   "bin_capacity": (int(runner._engine.bin_capacity) if fused and not runner.sharded else None),
+                   "bin_memory_mb": (12.0 * runner._engine.M * runner._engine.bin_capacity / 1e6 if fused and not runner.sharded and runner._engine.binned else None),
+                   "fell_back_to_compact_lists": bool(fused and not runner.sharded and getattr(runner._engine, "fell_back_to_compact", False)),
+                   "backward_rasteriser": ("one wave per 16x16 tile" if fused and not runner.sharded and runner._engine.cfg.get("raster_impl") == 1
+                                           else "one wave per 8x8 quadrant"),
                    "parallelism": (f"gaussian-sharded dp{world}: one view per GPU, N/{world} Gaussians per GPU, "
                                    "projected Gaussians exchanged by all-to-all" if runner.sharded else
                                    f"view-sharded dp{world}" + ("" if world == 1 else

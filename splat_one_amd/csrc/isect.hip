@@ -342,6 +342,50 @@ __device__ __forceinline__ void wave_sort_list(const uint64_t *__restrict__ key_
     if (lane + 64 * e < L) write_sorted(v[e], lo + lane + 64 * e, t, n_tiles, tile_bits, flatten_ids, isect_ids);
 }
 
+// Medium lists (256 < L <= CAP, CAP a multiple of 256) by the whole workgroup (round 4; until then the barrier-per-step
+// bitonic network in LDS: 45 barriers for 512 keys, 66 for 2048 -- 188 us per iteration on the 1M-Gaussian / 1440p run, where
+// most tiles hold 300-500 keys).  Chunks of 256 keys are sorted by ONE wave each in registers (the short-list path), parked
+// in LDS, and after ONE barrier every key finds its final place by itself: its index in its own chunk plus, for every other
+// chunk, the number of keys below it (a branch-free 8-step binary search in LDS) -- keys are distinct (the id is in the low
+// word), so that is the rank.  512 keys: two register sorts side by side + 8 LDS reads per key; 2048: 8 sorts on 4 waves +
+// 56 reads per key.  Same order as any correct sort of the distinct 64-bit keys: bit-identical lists.
+template <int THREADS>
+__device__ __forceinline__ void sort_mid_chunks(uint64_t *s_keys, const uint64_t *__restrict__ key_buf, int64_t lo, int L, int64_t t,
+                                                int n_tiles, int tile_bits, int32_t *flatten_ids, int64_t *isect_ids) {
+  constexpr int WAVES = THREADS / 64;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nch = (L + 255) >> 8;
+  for (int c = wave; c < nch; c += WAVES) {
+    uint64_t v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = 256 * c + lane + 64 * e;
+      v[e] = i < L ? key_buf[lo + i] : ~0ull;          // the last chunk's tail: +inf, sorts behind every key
+    }
+    wave_bitonic_sort<4>(v, lane);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s_keys[256 * c + lane + 64 * e] = v[e];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 256 * nch; i += THREADS) {
+    const uint64_t key = s_keys[i];
+    if (key == ~0ull) continue;                          // padding
+    const int ci = i >> 8;
+    int rank = i & 255;
+    for (int c = 0; c < nch; ++c) {
+      if (c == ci) continue;
+      const uint64_t *ch = s_keys + 256 * c;
+      int pos = 0;
+#pragma unroll
+      for (int step = 128; step >= 1; step >>= 1) pos += (ch[pos + step - 1] < key) ? step : 0;
+      rank += pos;                                        // keys of chunk c below this one (255 at most counted: the 256th
+      rank += (pos == 255 && ch[255] < key) ? 1 : 0;     // needs its own look)
+    }
+    write_sorted(key, lo + rank, t, n_tiles, tile_bits, flatten_ids, isect_ids);
+  }
+  __syncthreads();
+}
+
 // LDS sort for lists with L <= CAP (CAP keys of 8 B in LDS); longer lists are appended to the
 // work list (long_list[0..*long_count)) for k_tile_sort_long.
 template <int THREADS, int CAP>
@@ -370,11 +414,7 @@ k_tile_sort_lds(int64_t M, int n_tiles, int tile_bits, const int32_t *__restrict
       }
       continue;
     }
-    for (int i = threadIdx.x; i < L; i += THREADS) s_keys[i] = key_buf[lo + i];
-    __syncthreads();
-    bitonic_sort_shared<THREADS>(s_keys, (int)L);
-    for (int i = threadIdx.x; i < L; i += THREADS) write_sorted(s_keys[i], lo + i, t, n_tiles, tile_bits, flatten_ids, isect_ids);
-    __syncthreads();
+    sort_mid_chunks<THREADS>(s_keys, key_buf, lo, (int)L, t, n_tiles, tile_bits, flatten_ids, isect_ids);
   }
 }
 
@@ -414,11 +454,7 @@ k_tile_sort_waves(int64_t M, int n_tiles, int tile_bits, const int32_t *__restri
       int64_t mlo, mhi;
       tile_range(tm, M, offsets, n_isects, capacity, mlo, mhi);
       const int64_t ML = mhi - mlo;
-      for (int i = threadIdx.x; i < ML; i += THREADS) s_keys[i] = key_buf[mlo + i];
-      __syncthreads();
-      bitonic_sort_shared<THREADS>(s_keys, (int)ML);
-      for (int i = threadIdx.x; i < ML; i += THREADS) write_sorted(s_keys[i], mlo + i, tm, n_tiles, tile_bits, flatten_ids, isect_ids);
-      __syncthreads();
+      sort_mid_chunks<THREADS>(s_keys, key_buf, mlo, (int)ML, tm, n_tiles, tile_bits, flatten_ids, isect_ids);
     }
     __syncthreads();                              // s_mid is rewritten by the next group
   }

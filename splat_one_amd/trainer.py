@@ -133,6 +133,8 @@ class Config:
     fuse_adam: bool = True                 # single-GPU fused step: Adam inside the backward kernel (no gradient round trip)
     loss_kernels: int = 1                  # fused step: 1 = loss and its gradient in one launch; 2 = forward/backward pair
     bin_capacity: Optional[int] = None     # slots per tile; None: 8x the fullest tile of the first view, >= 1024
+    bin_budget_gb: float = 4.0             # memory the per-tile bins may take; a view that needs more (a cloud gathered in a few
+                                           # tiles) switches the engine to the compact slotted lists by itself, with a warning
     # single-GPU fused step with DefaultStrategy: the refinement (duplicate / split / prune / opacity reset) runs as a
     # stream compaction ON THE DEVICE (so_refine_default): capacity-preallocated parameters + Adam moments, N in device
     # memory, counter-based split noise, no host read-back, no graph re-capture.  False: the torch-level strategy ops.
@@ -689,7 +691,7 @@ class Runner:
                 lr_gamma_means=self.lr_gamma,
                 isect_capacity=cfg.isect_capacity, use_graph=True,
                 attr_dtype=cfg.attr_dtype, tile_cull=cfg.tile_cull,
-                binned=cfg.binned, bin_capacity=cfg.bin_capacity,
+                binned=cfg.binned, bin_capacity=cfg.bin_capacity, bin_budget_bytes=int(cfg.bin_budget_gb * 2 ** 30),
                 fuse_adam=cfg.fuse_adam, device_refine=dev_refine, capacity=capacity, loss_kernels=cfg.loss_kernels,
                 model_sets=(1 if mcmc else 2),
                 mcmc_noise=({"noise_lr": s.noise_lr, "seed": cfg.refine_seed} if mcmc else None),

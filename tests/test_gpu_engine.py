@@ -389,3 +389,37 @@ def test_tile_wave_backward_equals_the_quadrant_wave_backward(dev, regime, C, mo
     for k, v in p.items():
         floor = 1e-5 * p["scales"].grad.norm() if k == "quats" else 0.0
         assert ((grads[1][k].cpu().double() - v.grad).norm() / (v.grad.norm() + floor)).item() <= 1e-3, k
+
+
+def test_skewed_cloud_falls_back_to_compact_lists_instead_of_raising(dev):
+    """A cloud gathered in a few tiles (what real captures look like next to the uniform benchmark cube): bins sized for the
+    fullest tile would exceed the memory budget.  The engine switches to the compact slotted lists at its capacity probe --
+    one warning, no void iteration, no RuntimeError -- and trains like an engine built with
+    binned=False."""
+    import warnings
+    from splat_one_amd.engine import FusedEngine
+    N, W, H = 20_000, 320, 192
+    res = {}
+    for mode in ("budget", "compact"):
+        r, c2w, Ks, pixels = _make(dev, N, W, H, "mcmc")
+        with torch.no_grad():
+            r.splats["means"].mul_(0.08)                      # everything lands in the middle of the image
+        M = (W // 16) * (H // 16)
+        kw = dict(bin_budget_bytes=12 * M * 96) if mode == "budget" else dict(binned=False)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            eng = FusedEngine(r.splats, r.optimizers, W, H, 1, sh_degree=3, use_graph=True, **kw)
+            for _ in range(4):
+                eng.set_views(c2w, Ks, pixels, schedule=True)
+                eng.step()
+            torch.cuda.synchronize()
+        st = eng.stats()
+        assert st["overflow"] == 0 and eng.void_steps == 0 and eng.steps_done == 4 and not eng.binned
+        if mode == "budget":
+            assert eng.fell_back_to_compact and sum("falling back to the compact" in str(w.message) for w in caught) == 1
+            fullest = int(torch.bincount(eng.tile_lists()[1].new_tensor(
+                [i for i, (a, b) in enumerate(zip(eng.tile_lists()[0][:-1], eng.tile_lists()[0][1:])) for _ in range(b - a)])).max())
+            assert 2 * fullest > 96                            # bins with headroom really did not fit the budget
+        res[mode] = {k: v.detach().clone() for k, v in r.splats.items()}
+    for k in res["budget"]:
+        assert rel_err(res["budget"][k], res["compact"][k]) < 1e-4, k
