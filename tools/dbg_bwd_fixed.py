@@ -17,7 +17,10 @@ Ks = pinhole_K(W, H)[None].to(dev)
 tg = [torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(100 + v)).to(dev) for v in range(8)]
 eng = FusedEngine(r.splats, r.optimizers, W, H, 1, sh_degree=3, use_graph=False)
 for i in range(3):          # warm-up (module load, bin probe)
-    eng.set_views(ring[i:i + 1], Ks, tg[i]); eng.fwd_bwd()
+    eng.set_views(ring[i:i + 1], Ks, tg[i])
+    if os.environ.get("SPLAT_ONE_AMD_BWD_TILE") in ("0", "1"):      # override the engine's choice of backward rasteriser
+        eng.cfg["raster_impl"] = int(os.environ["SPLAT_ONE_AMD_BWD_TILE"])
+    eng.fwd_bwd()
 torch.cuda.synchronize()
 _lib.call("so_profile_enable", 1)
 for rep in range(5):
