@@ -285,9 +285,26 @@ def test_gaussian_sharded_overflow_voids_and_grows_on_every_rank(dev, tmp_path):
 def _replicated_overflow_worker(local_rank, world_rank, world_size, args):
     import warnings
     out_dir, device_refine = args
+    import torch.distributed as dist
+    from splat_one_amd import distributed as sdist
     from splat_one_amd.trainer import Config, Runner
     dev = torch.device("cuda:0")
     W, H, N = 128, 96, 3000
+    # no collective besides the reduce-scatters / all-gathers of the step: the per-step all_reduce(MAX) of rounds 2-3 is gone
+    # (under gloo a reduce-scatter of HIP tensors IS an all_reduce(SUM): count the MAX ones and the helper that issued them)
+    n_max = {"max": 0}
+    real_all_reduce, real_helper = dist.all_reduce, sdist.all_reduce_max_
+
+    def counting_all_reduce(t, op=dist.ReduceOp.SUM, *a, **k):
+        if op == dist.ReduceOp.MAX:
+            n_max["max"] += 1
+        return real_all_reduce(t, op, *a, **k)
+
+    def counting_helper(*a, **k):
+        n_max["max"] += 1
+        return real_helper(*a, **k)
+
+    dist.all_reduce, sdist.all_reduce_max_ = counting_all_reduce, counting_helper
 
     def make(bin_capacity):
         cfg = Config(init_num_pts=N, init_scale=0.3, init_opa=0.3, shN_init_std=0.05, sh_degree_interval=1, fused=True,
@@ -319,6 +336,7 @@ def _replicated_overflow_worker(local_rank, world_rank, world_size, args):
     torch.cuda.synchronize()
     assert b._engine.on_overflow == "defer" and (b._radam if device_refine else b._sadam).n_chunks == 3
     rel = {k: ((b.splats[k] - a.splats[k]).norm() / a.splats[k].norm().clamp_min(1e-12)).item() for k in a.splats.keys()}
+    assert n_max["max"] == 0, n_max
     torch.save({"fullest": fullest, "calls": calls, "void": b._engine.void_steps, "bins": b._engine.bin_capacity, "rel": rel,
                 "warned_here": sum(1 for w in caught if "buffers enlarged" in str(w.message)),
                 "warned_other": sum(1 for w in caught if "another rank" in str(w.message)),
