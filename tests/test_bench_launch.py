@@ -90,3 +90,25 @@ def test_bench_two_ranks_without_launcher(dev):
     rep = out["config"]["rccl"]
     assert rep["world_size"] == 2 and rep["self_launched"] is True and len(rep["ranks"]) == 2
     assert "comm_ms" in out["config"]
+
+
+def test_comm_model_counts_the_bytes_the_row_pieces_move():
+    """bench.py's predicted reduce-scatter / all-gather time (config.comm_model) uses the layout of distributed.RowShardedAdam:
+    rows rounded up to chunks x world x 64, 236 bytes per row at SH degree 3, 1 / world of them per link and direction."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from splat_one_amd.distributed import RowShardedAdam
+    m = bench.comm_model(100_000, 16, 1)
+    for w in (2, 4, 8):
+        e = m["by_world"][str(w)]
+        ra = RowShardedAdam.__new__(RowShardedAdam)
+        ra.world, ra.n_chunks = w, 1
+        assert e["rows_exchanged"] == ra.span(100_000)
+        assert abs(e["bytes_per_link_and_direction_per_phase"] - ra.span(100_000) * 236.0 / w) < 1e-6
+        # what every rank sends per phase over its w - 1 links == RowShardedAdam's own count (both phases: x 2)
+        assert abs(2 * (w - 1) * e["bytes_per_link_and_direction_per_phase"] - ra.bytes_per_link_and_step(100_000)) < 1e-3
+        assert e["reduce_scatter_ms"] > 0 and e["reduce_scatter_ms"] == e["all_gather_ms"]
+    m4 = bench.comm_model(500_000, 16, 4)
+    assert m4["assumptions"]["collectives_per_phase"] == 8 and m4["by_world"]["8"]["rows_exchanged"] % (4 * 8 * 64) == 0
