@@ -323,18 +323,25 @@ class RowShardedAdam:
         return 2.0 * (self.world - 1) / max(1, self.world) * self.span(n) * floats_per_row * 4.0
 
     # ---- collectives on one chunk
-    def _reduce_scatter(self, tensors: List[torch.Tensor], n: int, c: int):
+    def _reduce_scatter(self, tensors: List[torch.Tensor], n: int, c: int, with_flags: bool = False):
+        """with_flags: the void flags join THIS group -- on RCCL in coalesced mode inside the same grouped launch (no
+        collective of their own), otherwise as one more asynchronous collective behind it."""
         (lo, hi), (a, b) = self.chunk_range(n, c), self.rows(n, c)
         p = self.piece(n)
         assert all(t.shape[0] >= hi and t.is_contiguous() for t in tensors), (n, hi, [tuple(t.shape) for t in tensors])
         if self.backend == "nccl" and self.mode == "per_tensor":
             return [dist.reduce_scatter_tensor(t[a:b], t[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                    for t in tensors]
+                    for t in tensors] + (self._reduce_scatter_flags() if with_flags else [])
         if self.backend == "nccl":
+            f, st, r = self.flags, self.FLAG_STRIDE, self.rank
             with dist._coalescing_manager(group=self.group, async_ops=True) as cm:
                 for t in tensors:
                     dist.reduce_scatter_tensor(t[a:b], t[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+                if with_flags:
+                    dist.reduce_scatter_tensor(f[r * st:(r + 1) * st], f, op=dist.ReduceOp.SUM, group=self.group)
             return [cm]
+        if with_flags:
+            return self._reduce_scatter(tensors, n, c) + self._reduce_scatter_flags()
         if tensors[0].is_cuda:
             return [dist.all_reduce(t[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for t in tensors]
         works = []
@@ -393,10 +400,7 @@ class RowShardedAdam:
                 self.flags.zero_()
         works = []
         for gi, ts in enumerate(groups):
-            w = self._reduce_scatter(ts, self._n, c)
-            if c == 0 and gi == len(groups) - 1:
-                w = w + self._reduce_scatter_flags()
-            works.append(w)
+            works.append(self._reduce_scatter(ts, self._n, c, with_flags=(c == 0 and gi == len(groups) - 1)))
         self._rs[c] = works
 
     def _reduce_scatter_flags(self):

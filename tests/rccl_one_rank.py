@@ -75,6 +75,10 @@ for mode in ("coalesced", "per_tensor"):
         for wk in ra._all_gather(rows, 100, c):
             wk.wait()
 ra.flags = torch.full((ra.world * ra.FLAG_STRIDE,), 5.0, device=dev)
+for mode in ("coalesced", "per_tensor"):          # the void flags inside the grouped launch / as one more collective
+    ra.mode = mode
+    for wk in ra._reduce_scatter(rows, 100, 0, with_flags=True):
+        wk.wait()
 for wk in ra._reduce_scatter_flags():
     wk.wait()
 torch.cuda.synchronize()
