@@ -564,6 +564,8 @@ int so_render_forward(const so_step_desc *desc, void *stream);
  * ---------------------------------------------------------------------------------------- */
 typedef struct so_raster_desc {
   int32_t abi_size, C, N, K, width, height, tile_size, sh_degree, camera_model, antialiased, absgrad, tile_cull, activated, seq;
+  int32_t raster_impl; /* backward only: 0 one wave per 8x8 quadrant, 1 one wave per 16x16 tile (as so_step_desc.raster_impl:
+                        * faster from ~250 list entries per tile on), -1 the process default (SPLAT_ONE_AMD_BWD_TILE) */
   float eps2d, near_plane, far_plane, radius_clip;
   int64_t bin_capacity;
   /* inputs */

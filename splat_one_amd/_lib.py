@@ -51,7 +51,7 @@ class StepDesc(ctypes.Structure):
 class RasterDesc(ctypes.Structure):
     """Mirror of `so_raster_desc` (so_rasterization_fwd / _bwd: gsplat's `rasterization` whole, one call each way)."""
     _fields_ = ([(n, ctypes.c_int32) for n in ("abi_size", "C", "N", "K", "width", "height", "tile_size", "sh_degree",
-                                               "camera_model", "antialiased", "absgrad", "tile_cull", "activated", "seq")]
+                                               "camera_model", "antialiased", "absgrad", "tile_cull", "activated", "seq", "raster_impl")]
                 + [(n, c_f32) for n in ("eps2d", "near_plane", "far_plane", "radius_clip")]
                 + [("bin_capacity", c_i64)]
                 + [(n, c_ptr) for n in ("means", "quats", "scales", "opacities", "sh0", "shN", "viewmats", "Ks", "backgrounds",

@@ -163,6 +163,7 @@ extern "C" int so_rasterization_bwd(const so_raster_desc *d, void *stream) {
   const int64_t M = (int64_t)C * ((W + ts - 1) / ts) * ((H + ts - 1) / ts);
   so::LossFinal fin{};
   fin.skip = d->counters + 2 * M + 2;
+  fin.tile_waves = d->raster_impl;           // (-1: the process default; rasterize_bwd.hip)
   rc = so::rasterize_bwd_packed_launch(C, N, W, H, ts | wrap, d->rec, d->backgrounds, d->counters, d->flatten_ids, nullptr,
                                        -d->bin_capacity, d->render_alphas, d->last_ids, d->v_render_colors, d->v_render_alphas,
                                        d->vrec, d->absgrad, fin, stream);

@@ -75,7 +75,7 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
               "so_adam_group": ["param", "visibility", "numel", "row_len", "lr_step_size", "bc2_sqrt"],
               "so_attr_shadow": ["arec", "stride_bytes", "offset_bytes"],
               "so_model_set": ["p", "m", "v"],
-              "so_raster_desc": ["abi_size", "seq", "eps2d", "radius_clip", "bin_capacity", "means", "shN", "backgrounds", "counters",
+              "so_raster_desc": ["abi_size", "seq", "raster_impl", "eps2d", "radius_clip", "bin_capacity", "means", "shN", "backgrounds", "counters",
                                  "key_buf", "vrec", "status_out", "render_colors", "last_ids", "v_render_colors", "v_means",
                                  "v_shN", "v_means2d", "v_means2d_abs"],
               "so_refine_params": ["grow_grad2d", "grow_scale3d", "prune_opa", "prune_scale3d", "prune_big", "revised_opacity",

@@ -274,3 +274,27 @@ def test_raw_parameter_call_equals_the_composed_call(dev):
         b = rasterization(splats["means"].to(dev), splats["quats"].to(dev), splats["scales"].to(dev).exp(), splats["opacities"].to(dev).sigmoid(),
                           torch.cat([splats["sh0"], splats["shN"]], 1).to(dev), vm, Kd, W, H, sh_degree=3, packed=True)[0]
     assert torch.equal(a, b)
+
+
+def test_dense_lists_take_the_tile_wave_backward(dev):
+    """Long tile lists (dense initialisations): `rasterization()` switches its backward to the one-wave-per-tile kernel
+    (so_raster_desc.raster_impl = 1) from the mean list length its bins' status word reports -- no host read -- and the
+    gradients stay those of the operator composition."""
+    from splat_one_amd import raster_op, rasterization
+    W, H, N = 144, 112, 40_000                    # a tile grid no other test uses: 9 x 7 tiles, several hundred entries each
+    splats, c2w, Ks = make_scene(N, W, H, regime="ref")
+    vm, Kd = torch.linalg.inv(c2w).to(dev), Ks.to(dev)
+    g = torch.Generator().manual_seed(4)
+    splats = {k: v.detach().clone() for k, v in splats.items()}
+    splats["scales"] = splats["scales"] + torch.randn(N, 3, generator=g) * 0.4      # anisotropic: the quaternion gradient is a signal
+    w_rgb, w_a = torch.rand(1, H, W, 3, generator=g), torch.rand(1, H, W, 1, generator=g)
+    ref = _step(rasterization, splats, vm, Kd, W, H, w_rgb, w_a, dev, sh_degree=3, fused=False)
+    out = None
+    for _ in range(2):                             # the second call has looked at the first one's status word
+        out = _step(rasterization, splats, vm, Kd, W, H, w_rgb, w_a, dev, sh_degree=3)
+    (bins,) = [b for k, b in raster_op._BINS.items() if k[2] == 9 * 7]
+    assert bins.mean_list >= 256.0, bins.mean_list
+    assert (out[0] - ref[0]).abs().max().item() <= 2e-6
+    for k in ref[2]:
+        floor = 1e-5 * ref[2]["scales"].norm() if k == "quats" else 0.0
+        assert ((out[2][k] - ref[2][k]).norm() / (ref[2][k].norm() + floor)).item() <= 2e-5, k
