@@ -627,7 +627,7 @@ def main():
                                    "projected Gaussians exchanged by all-to-all" if runner.sharded else
                                    f"view-sharded dp{world}" + ("" if world == 1 else
                                                                 f", replicated device-resident Gaussians (device-side refinement): reduce-scatter / 1/{world} Adam / "
-                                                                "all-gather over row pieces of the capacity-sized tensors, two grouped RCCL launches each"
+                                                                f"all-gather over row pieces of the capacity-sized tensors in {getattr(runner, '_dp_chunks', 1)} row chunk(s), two grouped RCCL launches per chunk and phase, each chunk's reduce-scatter under the next chunk's backward kernel"
                                                                 if getattr(runner._engine, "device_refine", False) else
                                                                 f", replicated Gaussians: reduce-scatter / 1/{world} Adam / all-gather of the "
                                                                 f"gradient SoA in {getattr(runner, '_dp_chunks', cfg.dp_chunks)} chunk(s) over RCCL")),
