@@ -582,3 +582,53 @@ def test_depth_loss_term_matches_the_oracle_and_is_never_silently_dropped(dev):
     r.train_step(c2w, Ks, pixels, points=points, depths_gt=depths_gt)
     torch.cuda.synchronize()
     assert abs(float(r.last_depthloss) - dlo.item()) <= 1e-5 * abs(dlo.item()) and not torch.equal(before, r.splats["means"].detach())
+
+
+def _dp_mcmc_worker(local_rank, world_rank, world_size, out_dir):
+    from splat_one_amd.strategy import MCMCStrategy
+    from splat_one_amd.trainer import Config, Runner
+    dev = torch.device("cuda:0")
+    W, H, N = 128, 96, 3000
+    strat = MCMCStrategy(refine_start_iter=4, refine_every=5, refine_stop_iter=1000, cap_max=4000, verbose=False)
+    cfg = Config(init_num_pts=N, init_scale=0.3, init_opa=0.3, shN_init_std=0.05, sh_degree_interval=1, fused=True,
+                 dp_mode="allreduce", strategy=strat, dp_chunks=2, opacity_reg=0.01, scale_reg=0.01)
+    r = Runner(0, world_rank, world_size, cfg, scene_scale=1.0 / 1.1)
+    with torch.no_grad():
+        r.splats["scales"].add_((torch.randn(N, 3, generator=torch.Generator().manual_seed(7)) * 0.4).to(dev))
+    Ks = pinhole_K(W, H)[None].to(dev)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
+    px = torch.stack([(xx + 0.2 * world_rank) % 1, yy, 0.5 * (xx + yy)], -1)[None].to(dev).contiguous()
+    sizes = []
+    for step in range(17):                                   # refinements (relocate + 5 % more rows) at 5, 10, 15
+        v = (2 * step + world_rank) % 8
+        r.train_step(ring_cameras(8)[v:v + 1].to(dev), Ks, px)
+        sizes.append(r._engine.sync_host())
+    torch.cuda.synchronize()
+    eng = r._engine
+    assert eng.device_refine and eng.model_sets == 1 and r._radam is not None and r._radam.n_chunks == 2
+    n = sizes[-1]
+    act = eng.sets[eng.active]
+    r._radam.gather([act[q][k] for q in ("m", "v") for k in act[q]], n)     # every rank's copy of ALL moments
+    torch.cuda.synchronize()
+    torch.save({"sizes": sizes, "p": {k: act["p"][k][:n].detach().cpu() for k in act["p"]},
+                "m": {k: act["m"][k][:n].detach().cpu() for k in act["m"]}}, os.path.join(out_dir, f"mcmc{world_rank}.pt"))
+
+
+def test_replicated_dp_mcmc_on_the_device_keeps_the_replicas_identical(dev, tmp_path):
+    """MCMCStrategy on the device-resident model in replicated data parallelism, through the row-CHUNKED optimiser step of
+    round 4: relocation and addition draw the same counter-based samples on every rank, the row-sharded moments are gathered
+    before each refinement (their pieces move with N), replicas stay bit-identical while N grows 5 % per refinement."""
+    from splat_one_amd import distributed as sdist
+    env_backup = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        sdist.cli(_dp_mcmc_worker, str(tmp_path), world_size=2, backend="gloo", port=_free_port())
+    finally:
+        for k, v in env_backup.items():
+            if v is not None:
+                os.environ[k] = v
+    a, b = (torch.load(os.path.join(tmp_path, f"mcmc{i}.pt")) for i in range(2))
+    assert a["sizes"] == b["sizes"] and a["sizes"][0] == 3000 and a["sizes"][-1] > 3000 * 1.05 ** 2, a["sizes"]
+    for q in ("p", "m"):
+        for k in a[q]:
+            assert torch.equal(a[q][k], b[q][k]) and torch.isfinite(a[q][k]).all(), (q, k)
+    assert a["m"]["means"].abs().sum() > 0
