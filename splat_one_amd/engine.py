@@ -226,7 +226,10 @@ class FusedEngine:
 
     def _enlarge_and_refine_again(self) -> None:
         """The last refinement did not fit the capacity and was put off on the device (so_refine_default: identity copy,
-        statistics kept).  Enlarge both model sets -- to twice the capacity or 1.5x the rows it needs -- and run it again."""
+        statistics kept).  Enlarge both model sets -- to twice the capacity or 1.5x the rows it needs -- and run it again.
+        (It runs one iteration LATE: with the step label it was asked for -- the split noise is keyed by it, so every replica
+        and every rerun draws the same children -- and with statistics that include the one iteration trained in between:
+        `grad2d / count` are running means over >= refine_every views, one more view moves them by ~1 / refine_every.)"""
         import warnings
         needed = int(self._report[7])
         new_cap = max(2 * self.cap, int(1.5 * needed))
