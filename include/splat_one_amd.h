@@ -488,7 +488,9 @@ typedef struct so_step_desc {
   /* Optimiser fused into the backward (nullable): the last kernel of the step applies Adam to the six parameter
    * tensors itself -- the 236 B/Gaussian of gradient never travel to HBM and back and so_adam_step_dev is not called.
    * The v_* gradient outputs are then NOT written.  Single-GPU steps only (a data-parallel step needs the gradients
-   * for its all-reduce); the schedule of this step must have been evaluated by so_step_inputs (n_groups = 6). */
+   * for its all-reduce); the schedule of this step must have been evaluated by so_step_inputs (n_groups = 6).
+   * With attr_rows_f16 (K <= 18) the same kernel re-packs the rows of the Gaussians it updates from their new float32
+   * values (round to nearest even, as so_attr_pack_f16): the rows stay == half(masters) without a further pass. */
   const struct so_adam_fuse *fuse_adam;
   /* Device-resident Gaussian count (nullable): when set, `N` above is the CAPACITY of every per-Gaussian buffer (the
    * parameters, their moments, the per-view arrays with row stride N, rec / vrec, grad2d / count) and the number of

@@ -28,6 +28,7 @@ struct AttrSoA {
   const float *log_scales, *quats, *sh0, *shN;
   int K;
   static constexpr bool kActivated = false;   // log-scales / opacity logits: the kernels apply exp / sigmoid
+  static constexpr bool kHalfRows = false;
   template <int DEG> struct Coefs {
     const float *c0, *cN;
     __device__ __forceinline__ void get(int k, float c[3]) const {
@@ -57,6 +58,7 @@ struct AttrAct {
   const float *scales, *quats, *coeffs;
   int K;
   static constexpr bool kActivated = true;
+  static constexpr bool kHalfRows = false;
   template <int DEG> struct Coefs {
     const float *c;
     __device__ __forceinline__ void get(int k, float o[3]) const { o[0] = c[3 * k]; o[1] = c[3 * k + 1]; o[2] = c[3 * k + 2]; }
@@ -73,6 +75,7 @@ struct AttrRec {
   const uint4 *rec;
   int stride16;   // row stride in 16-byte units
   static constexpr bool kActivated = false;
+  static constexpr bool kHalfRows = true;     // a fused optimiser step re-packs the rows it read (AdamFuse::half_rows)
   template <int DEG> struct Coefs {
     static constexpr int NH = 3 * (DEG + 1) * (DEG + 1);   // halves used
     static constexpr int NQ = (2 * NH + 15) / 16;           // 16-byte loads

@@ -304,10 +304,14 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
   }
 }
 
+// LDS floats per Gaussian for the float16 row header (quat 4, log-scale 3, sh0 3) when the fused optimiser also re-packs the
+// rows; odd, so that lanes writing their own header do not share banks
+constexpr int kHalfHdr = 11;
+
 // (One wave per SIMD: 256 VGPRs + AGPRs.  Forcing two with __launch_bounds__(256, 2) spills 49 registers
 // and measured slower, 23.1 vs 20.5 us at 100k Gaussians.)
 template <int DEG, class A, bool STAGE, bool ADAM, bool SPH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (ADAM && A::kHalfRows) ? 2 : 1)
 k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const float *__restrict__ logit_opac,
                  const A attrs, const float *__restrict__ viewmats,
                  const float *__restrict__ Ks, int W, int H, float eps2d, int model, int antialiased,
@@ -470,6 +474,13 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (j < kLen[g]) { af.p[g][at[g] + j] = pv[g][j]; af.m[g][at[g] + j] = mv[g][j]; af.v[g][at[g] + j] = vv[g][j]; }
+      if (A::kHalfRows && af.half_rows) {   // float16 rows: the new quaternion, log-scale and sh0 wait in LDS for the wave's row sweep below
+        float *hd = s_stage + (size_t)blockDim.x * R + (size_t)threadIdx.x * kHalfHdr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hd[j] = pv[2][j];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { hd[4 + j] = pv[1][j]; hd[7 + j] = pv[4][j]; }
+      }
     } else {
       v_means[3 * n] = vm[0]; v_means[3 * n + 1] = vm[1]; v_means[3 * n + 2] = vm[2];
       *reinterpret_cast<float4 *>(v_quats + 4 * n) = make_float4(vq[0], vq[1], vq[2], vq[3]);
@@ -504,6 +515,7 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
       if (rows > 0) {
         const int total = (int)rows * R;
         const float4 *src4 = reinterpret_cast<const float4 *>(mine);
+        float4 *const upd4 = reinterpret_cast<float4 *>(mine);   // float16 rows: the updated shN replaces its gradient in LDS
         if (ADAM) {   // the wave's 64 rows of shN, its moments and (in LDS) its gradient: one coalesced sweep
           const float2 hy = af.hyper[5];
           float4 *p4 = reinterpret_cast<float4 *>(af.p[5] + w0 * R), *m4 = reinterpret_cast<float4 *>(af.m[5] + w0 * R),
@@ -516,11 +528,39 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
             adam_one(pp.z, g.z, mm.z, vv.z, af.h, hy.x, hy.y);
             adam_one(pp.w, g.w, mm.w, vv.w, af.h, hy.x, hy.y);
             p4[i] = pp; st_nt(m4 + i, mm); st_nt(v4 + i, vv);
+            if (A::kHalfRows && af.half_rows) upd4[i] = pp;
           }
           for (int i = (total & ~3) + lane; i < total; i += 64) {
             float pj = af.p[5][w0 * R + i], mj = af.m[5][w0 * R + i], vj = af.v[5][w0 * R + i];
             adam_one(pj, mine[i], mj, vj, af.h, hy.x, hy.y);
             af.p[5][w0 * R + i] = pj; af.m[5][w0 * R + i] = mj; af.v[5][w0 * R + i] = vj;
+            if (A::kHalfRows && af.half_rows) mine[i] = pj;
+          }
+          if (A::kHalfRows && af.half_rows) {
+            // The wave's 64 float16 rows are one contiguous run (row stride == row size): written as whole 16-byte pieces,
+            // eight halves each, from the float32 values now in LDS -- the same round-to-nearest-even as so_attr_pack_f16,
+            // so the rows equal masters.half() bit for bit.  (The scatter of 2-byte stores from inside the Adam kernel
+            // cost 350 us at 2M Gaussians and the separate re-pack pass re-reads 224 B per Gaussian; this adds no read.)
+            wave_lds_sync();
+            const int parts = af.half_stride16;
+            uint4 *out = reinterpret_cast<uint4 *>(af.half_rows) + w0 * parts;
+            const float *hdr = s_stage + (size_t)blockDim.x * R + (size_t)wv * 64 * kHalfHdr;
+            for (int q = lane; q < (int)rows * parts; q += 64) {
+              const int r = q / parts, part = q - r * parts;
+              float hv[8];
+              if (part == 0) {
+#pragma unroll
+                for (int j = 0; j < 7; ++j) hv[j] = hdr[r * kHalfHdr + j];
+                hv[7] = 0.f;
+              } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  const int e = (part - 1) * 8 + j;
+                  hv[j] = e < 3 ? hdr[r * kHalfHdr + 7 + e] : (e < 3 * K ? mine[r * R + (e - 3)] : 0.f);
+                }
+              }
+              out[q] = make_uint4(pack_h2(hv[0], hv[1]), pack_h2(hv[2], hv[3]), pack_h2(hv[4], hv[5]), pack_h2(hv[6], hv[7]));
+            }
           }
         } else {
           float4 *dst4 = reinterpret_cast<float4 *>(v_shN + w0 * R);
@@ -735,7 +775,12 @@ static int preprocess_bwd_impl(const char *what, int C, int N, int K, int sh_deg
       bits |= (uintptr_t)fuse->p[g] | (uintptr_t)fuse->m[g] | (uintptr_t)fuse->v[g];
     }
     SO_REQUIRE((bits & 15) == 0 && fuse->hyper, "%s: fused Adam: tensors must be 16-byte aligned, hyper non-null", what);
+    SO_REQUIRE(!fuse->half_rows || (A::kHalfRows && (((uintptr_t)fuse->half_rows) & 15) == 0 && fuse->half_stride16 == attr_rec_stride_bytes(K) / 16 &&
+                                    stage_bytes + (size_t)256 * kHalfHdr * sizeof(float) <= 64 * 1024),
+               "%s: fused Adam with float16 rows: rows 16-byte aligned, stride of K, and K <= 18", what);
   }
+  // (float16 rows re-packed by the fused optimiser: 11 more floats of LDS per Gaussian for the row header)
+  const size_t lds_bytes = stage_bytes + ((fuse && fuse->half_rows) ? (size_t)256 * kHalfHdr * sizeof(float) : 0);
   const bool sph = camera_model_has_spherical(camera_model, C);
 #define SO_LAUNCH(D)                                                                                              \
   if (sph) { SO_LAUNCH_(D, true); } else { SO_LAUNCH_(D, false); }
@@ -750,7 +795,7 @@ static int preprocess_bwd_impl(const char *what, int C, int N, int K, int sh_deg
 #define SO_LAUNCH_(D, S)                                                                                          \
   if (fuse) {                                                                                                     \
     if constexpr (!A::kActivated)                                                                                 \
-      hipLaunchKernelGGL((k_preprocess_bwd<D, A, true, true, S>), grid, block, stage_bytes, st, SO_BWD_ARGS(*fuse)); \
+      hipLaunchKernelGGL((k_preprocess_bwd<D, A, true, true, S>), grid, block, lds_bytes, st, SO_BWD_ARGS(*fuse)); \
   } else if (stage)                                                                                               \
     hipLaunchKernelGGL((k_preprocess_bwd<D, A, true, false, S>), grid, block, stage_bytes, st, SO_BWD_ARGS(AdamFuse{})); \
   else                                                                                                            \
@@ -843,8 +888,23 @@ extern "C" int so_preprocess_bwd_f16(int C, int N, int K, int sh_degree, const f
                                  absgrad_stats, cam_stride, skip_flag, skip_out, stream);
 }
 
-// internal (step.hip): the float32-attribute backward with the optimiser fused in
+// internal (step.hip): the backward with the optimiser fused in (float32 attributes, or float16 rows that the same
+// kernel re-packs: fuse.half_rows)
 namespace so {
+int preprocess_bwd_fused_adam_f16(int C, int N, int K, int sh_degree, const float *means, const float *logit_opacities,
+                                  const void *arec, const float *viewmats, const float *Ks, int width, int height, float eps2d,
+                                  int camera_model, int antialiased, const int32_t *radii, const float *opacities,
+                                  const float *colors, float opacity_reg, float scale_reg, float *grad2d, float *count,
+                                  const float *vrec, int absgrad_stats, const int32_t *skip_flag, float *skip_out,
+                                  const AdamFuse &fuse, void *stream, const int32_t *n_dev, const float *rec) {
+  SO_REQUIRE(attr_rec_ok(arec) && fuse.half_rows == arec, "so_train_step_fwd_bwd (fused Adam, float16 rows): the rows read and the rows re-packed must be the same 16-byte aligned buffer");
+  const AttrRec attrs{reinterpret_cast<const uint4 *>(arec), attr_rec_stride_bytes(K < 1 ? 1 : K) / 16};
+  float *dummy = fuse.p[0];
+  return preprocess_bwd_impl("so_train_step_fwd_bwd (fused Adam, float16 rows)", C, N, K, sh_degree, means, logit_opacities, attrs,
+                             viewmats, Ks, width, height, eps2d, camera_model, antialiased, radii, opacities, colors, nullptr,
+                             nullptr, nullptr, nullptr, nullptr, nullptr, opacity_reg, scale_reg, dummy, dummy, dummy, dummy, dummy,
+                             fuse.p[5], grad2d, count, vrec, absgrad_stats, 0, skip_flag, skip_out, stream, &fuse, n_dev, rec);
+}
 int preprocess_bwd_fused_adam(int C, int N, int K, int sh_degree, const float *means, const float *log_scales, const float *quats,
                               const float *logit_opacities, const float *sh0, const float *shN, const float *viewmats,
                               const float *Ks, int width, int height, float eps2d, int camera_model, int antialiased,

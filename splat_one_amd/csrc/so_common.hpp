@@ -343,6 +343,10 @@ struct AdamFuse {
   float *p[6], *m[6], *v[6];
   const float2 *hyper;
   AdamHyper h;
+  // float16 attribute rows (attr_rec.hpp; nullable): the kernel that applies the update also re-packs the rows of the
+  // Gaussians it owns from the new float32 values, so the next forward reads what so_attr_pack_f16 would have written
+  void *half_rows = nullptr;
+  int half_stride16 = 0;   // row stride in 16-byte units
 };
 
 __device__ __forceinline__ int lane_id() {

@@ -8,6 +8,7 @@
 //   counter, learning-rate schedule and bias corrections evaluated on the device.
 // Between the two the caller may all-reduce the gradients (view-sharded data parallelism).
 #include "rasterize_common.hpp"   // (LossFinal; includes so_common.hpp)
+#include "attr_rec.hpp"           // (attr_rec_stride_bytes)
 
 #include <vector>
 
@@ -67,6 +68,12 @@ int preprocess_bwd_fused_adam(int C, int N, int K, int sh_degree, const float *m
                               float scale_reg, float *grad2d, float *count, const float *vrec, int absgrad_stats,
                               const int32_t *skip_flag, float *skip_out, const AdamFuse &fuse, void *stream,
                               const int32_t *n_dev, const float *rec);
+int preprocess_bwd_fused_adam_f16(int C, int N, int K, int sh_degree, const float *means, const float *logit_opacities,
+                                  const void *arec, const float *viewmats, const float *Ks, int width, int height, float eps2d,
+                                  int camera_model, int antialiased, const int32_t *radii, const float *opacities,
+                                  const float *colors, float opacity_reg, float scale_reg, float *grad2d, float *count,
+                                  const float *vrec, int absgrad_stats, const int32_t *skip_flag, float *skip_out,
+                                  const AdamFuse &fuse, void *stream, const int32_t *n_dev, const float *rec);
 int preprocess_fwd_n(int C, int N, int K, int sh_degree, const float *means, const float *log_scales, const float *quats,
                      const float *logit_opacities, const float *sh0, const float *shN, const float *viewmats, const float *Ks,
                      int width, int height, float eps2d, float near_plane, float far_plane, float radius_clip, int camera_model,
@@ -329,13 +336,21 @@ static int step_impl(const so_step_desc *d, void *stream, StepPart part, int64_t
     // the optimiser runs inside the backward kernel (gradients never reach HBM); its schedule for this step was
     // evaluated by so_step_inputs into the scratch behind the step counter
     const so_adam_fuse *f = d->fuse_adam;
-    SO_REQUIRE(!d->attr_rows_f16 && f->step_counter, "so_train_step_fwd_bwd: fuse_adam needs float32 attributes and the step counter");
+    SO_REQUIRE(f->step_counter, "so_train_step_fwd_bwd: fuse_adam needs the step counter");
     so::AdamFuse F{};
     for (int g = 0; g < 6; ++g) { F.p[g] = f->groups[g].param; F.m[g] = f->groups[g].exp_avg; F.v[g] = f->groups[g].exp_avg_sq; }
     SO_REQUIRE(F.p[0] == d->means && F.p[1] == d->log_scales && F.p[2] == d->quats && F.p[3] == d->logit_opacities &&
                    F.p[4] == d->sh0 && F.p[5] == d->shN, "so_train_step_fwd_bwd: fuse_adam groups must be the descriptor's six parameter tensors, in order");
     F.hyper = reinterpret_cast<const float2 *>(f->step_counter + 2);
     F.h = so::AdamHyper{(float)(1.0 - f->beta1), (float)f->beta2, (float)(1.0 - f->beta2), (float)f->eps};
+    if (d->attr_rows_f16) {   // the rows are read by this kernel and re-packed by it from the updated masters
+      F.half_rows = const_cast<void *>(d->attr_rows_f16);
+      F.half_stride16 = so::attr_rec_stride_bytes(K) / 16;
+      SO_STAGE(7, so::preprocess_bwd_fused_adam_f16(C, N, K, d->sh_degree, d->means, d->logit_opacities, d->attr_rows_f16, d->viewmats,
+                                                    d->Ks, W, H, d->eps2d, d->camera_model, d->antialiased, d->radii, d->opacities,
+                                                    d->colors, d->opacity_reg, d->scale_reg, d->grad2d, d->count, d->vrec, d->absgrad,
+                                                    overflow, d->overflow_flag_out, F, stream, d->n_dev, d->rec));
+    } else
     SO_STAGE(7, so::preprocess_bwd_fused_adam(C, N, K, d->sh_degree, d->means, d->log_scales, d->quats, d->logit_opacities, d->sh0,
                                               d->shN, d->viewmats, d->Ks, W, H, d->eps2d, d->camera_model, d->antialiased, d->radii,
                                               d->opacities, d->colors, d->opacity_reg, d->scale_reg, d->grad2d, d->count, d->vrec,

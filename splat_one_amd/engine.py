@@ -87,7 +87,7 @@ class FusedEngine:
         # tile, at least 1024 slots), enlarged after an overflow like the compact buffers.
         # step(): Adam runs inside the backward kernel (so_step_desc.fuse_adam) -- the gradients of a single-GPU step
         # never reach HBM.  fwd_bwd() + optimize() (data-parallel steps, gradient inspection) keep the two kernels.
-        self.fuse_adam = bool(fuse_adam) and attr_dtype == "f32"
+        self.fuse_adam = bool(fuse_adam)
         self.binned = bool(binned)
         self._bin_hint = bin_capacity
         # memory the per-tile bins may take (12 bytes per slot, every tile the same slot count): a view whose fullest tile
@@ -518,7 +518,7 @@ class FusedEngine:
     def attr_rows(self) -> Dict[str, Tensor]:
         """The float16 rows decoded to float32 tensors shaped like the parameters (tests, inspection)."""
         assert self.attr_dtype == "f16"
-        h = self.ws["arec"].view(torch.float16).view(self.N, self.attr_stride // 2)
+        h = self.ws["arec"].view(torch.float16).view(-1, self.attr_stride // 2)[:self.N]
         K = self.K
         return {"quats": h[:, 0:4].float(), "scales": h[:, 4:7].float(), "sh0": h[:, 8:11].float().view(self.N, 1, 3),
                 "shN": h[:, 11:8 + 3 * K].float().reshape(self.N, K - 1, 3)}
@@ -798,7 +798,7 @@ class FusedEngine:
     def _fusable(self, sched: bool) -> bool:
         """The fused optimiser needs this step's schedule staged (set_views(schedule=True)), SH coefficients beyond
         degree 0 (its sweep works on the staged shN rows) and rows that fit the 64 KB stage."""
-        return self.fuse_adam and sched and 2 <= self.K <= 22
+        return self.fuse_adam and sched and 2 <= self.K <= (22 if self.attr_dtype == "f32" else 18)
 
     def _launch_fwd_bwd(self, fused_adam: bool = False) -> None:
         d = self._desc()

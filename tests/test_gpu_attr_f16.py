@@ -99,18 +99,20 @@ def test_engine_f16_attributes_match_oracle_at_rounded_values(dev, C, kw):
         assert (v.grad.cpu().double() - g_eng[k]).norm().item() <= 1e-5 * g_eng[k].norm().item() + 1e-12, k
 
 
-@pytest.mark.parametrize("use_graph,repack", [(False, True), (True, True), (True, False)])
-def test_engine_f16_rows_follow_the_optimiser(dev, use_graph, repack):
+@pytest.mark.parametrize("use_graph,how", [(False, "fused"), (True, "fused"), (False, "repack"), (True, "repack"), (True, "scatter")])
+def test_engine_f16_rows_follow_the_optimiser(dev, use_graph, how):
     """Adam updates the float32 masters exactly as in float32 storage given the same gradients, and the step leaves
-    rows == masters.half() bit for bit -- through the coalesced re-pack that follows the Adam launch (default) and
-    through the scatter inside it (f16_repack = False); training makes progress; a rebuild repacks."""
+    rows == masters.half() bit for bit -- written by the backward kernel that applies the update (the fused optimiser, default),
+    by the coalesced re-pack that follows a separate Adam launch (fuse_adam=False), or by the scatter inside that launch
+    (f16_repack = False); training makes progress; a rebuild repacks."""
     from splat_one_amd.engine import FusedEngine
-    N, W, H = 5000, 128, 96
+    N, W, H = 5000, 128, 96                        # 5000 = 78 x 64 + 8: a partial last wave in the row sweep
     r, c2w, Ks, pixels = _make(dev, N, W, H, "mcmc")
     r.step = 10
     eng = FusedEngine(r.splats, r.optimizers, W, H, 1, sh_degree=3, lr_gamma_means=r.lr_gamma, use_graph=use_graph,
-                      attr_dtype="f16")
-    eng.f16_repack = repack
+                      attr_dtype="f16", fuse_adam=(how == "fused"))
+    eng.f16_repack = how != "scatter"
+    assert eng._fusable(True) == (how == "fused")
     losses = []
     for _ in range(12):
         eng.set_views(c2w, Ks, pixels, schedule=True)
@@ -128,6 +130,46 @@ def test_engine_f16_rows_follow_the_optimiser(dev, use_graph, repack):
     assert not torch.equal(eng.attr_rows()["shN"], r.splats["shN"].detach().half().float())
     eng.rebuild()
     assert torch.equal(eng.attr_rows()["shN"], r.splats["shN"].detach().half().float())
+
+
+@pytest.mark.parametrize("use_graph,device_refine", [(False, False), (True, True)])
+def test_engine_f16_fused_optimiser_equals_the_two_kernel_step(dev, use_graph, device_refine):
+    """With float16 rows the optimiser fused into the backward (which also re-packs the rows it owns) gives the parameters,
+    moments and rows of backward + so_adam_step_dev + so_attr_pack_f16 -- through the SH ramp (columns of shN that have
+    no gradient yet still decay their moments and are re-packed), with two views, regularisers and densification statistics;
+    the padding halves of every row stay zero."""
+    from splat_one_amd.engine import FusedEngine
+    N, W, H = 5003, 128, 96
+    out = {}
+    for fuse in (False, True):
+        r, c2w, Ks, pixels = _make(dev, N, W, H, "mcmc", 2, opacity_reg=0.01, scale_reg=0.01)
+        st = r.cfg.strategy.initialize_state(1.0)
+        eng = FusedEngine(r.splats, r.optimizers, W, H, 2, sh_degree=0, strategy_state=st, lr_gamma_means=r.lr_gamma,
+                          use_graph=use_graph, fuse_adam=fuse, opacity_reg=0.01, scale_reg=0.01, attr_dtype="f16",
+                          device_refine=device_refine, capacity=(8192 if device_refine else None))
+        for it in range(6):
+            eng.set_sh_degree(min(it, 3))
+            eng.set_views(c2w, Ks, pixels, schedule=True)
+            eng.step()
+        torch.cuda.synchronize()
+        eng.sync_host() if device_refine else None
+        assert eng.stats()["overflow"] == 0 and eng.steps_done == 6
+        rows = eng.attr_rows()
+        for k in F16_KEYS:
+            assert torch.equal(rows[k][:N], eng.splats[k].detach()[:N].half().float()), (fuse, k)
+        raw = eng.ws["arec"].view(torch.int16).view(-1, eng.attr_stride // 2)[:N]
+        assert int(raw[:, 7].abs().max()) == 0                      # K = 16: 8 + 48 halves fill the 112-byte row exactly
+        stats = eng.dstats if device_refine else st
+        out[fuse] = ({k: v.detach()[:N].clone() for k, v in eng.splats.items()},
+                     {k: (eng.optimizers[k].state[eng.splats[k]]["exp_avg"][:N].clone(),
+                          eng.optimizers[k].state[eng.splats[k]]["exp_avg_sq"][:N].clone()) for k in eng.splats.keys()},
+                     stats["grad2d"][:N].clone(), stats["count"][:N].clone(), eng.loss().clone())
+    (pa, ma, g2a, cna, la), (pb, mb, g2b, cnb, lb) = out[False], out[True]
+    rel = lambda a, b: (a - b).norm().item() / (a.norm().item() + 1e-30)
+    for k in pa:
+        assert rel(pa[k], pb[k]) < 2e-5, k
+        assert rel(ma[k][0], mb[k][0]) < 1e-4 and rel(ma[k][1], mb[k][1]) < 1e-4, k
+    assert rel(g2a, g2b) < 1e-4 and torch.equal(cna, cnb) and (la - lb).abs().max().item() < 1e-5
 
 
 def test_engine_f16_sh_degree_ramp_and_degree0_only(dev):
