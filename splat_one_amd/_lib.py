@@ -165,7 +165,7 @@ _lib: Optional[ctypes.CDLL] = None
 
 def exported_symbols():
     return ["so_abi_version", "so_last_error", "so_device_cu_count", "so_profile_num_stages",
-            "so_profile_stage_name", "so_profile_stage_begin_end", "so_attr_rec_stride", "so_refine_scratch_words", "so_mcmc_scratch_words", "so_projection_packed_blocks"] + list(_SIGS)
+            "so_profile_stage_name", "so_profile_stage_begin_end", "so_attr_rec_stride", "so_bin_counter_index", "so_refine_scratch_words", "so_mcmc_scratch_words", "so_projection_packed_blocks"] + list(_SIGS)
 
 
 def load() -> ctypes.CDLL:
@@ -185,6 +185,8 @@ def load() -> ctypes.CDLL:
         lib.so_profile_stage_name.argtypes = [c_int]
         lib.so_attr_rec_stride.restype = c_i64
         lib.so_attr_rec_stride.argtypes = [c_int]
+        lib.so_bin_counter_index.restype = c_i64
+        lib.so_bin_counter_index.argtypes = [c_i64, c_i64]
         lib.so_projection_packed_blocks.restype = c_i64
         lib.so_projection_packed_blocks.argtypes = [c_int, c_int]
         lib.so_refine_scratch_words.restype = c_i64

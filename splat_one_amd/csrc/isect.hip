@@ -265,7 +265,7 @@ __device__ __forceinline__ void bitonic_sort_shared(uint64_t *keys, int n) {
 __device__ __forceinline__ void tile_range(int64_t t, int64_t M, const int32_t *offsets, const int32_t *n_isects,
                                            int64_t capacity, int64_t &lo, int64_t &hi) {
   if (!n_isects && capacity < 0) {   // binned lists: cap = -capacity slots per tile, `offsets` holds the per-tile counts
-    const int64_t cap = -capacity, cnt = offsets[t];
+    const int64_t cap = -capacity, cnt = offsets[bin_counter_index(t, M)];
     lo = t * cap;
     hi = lo + (cnt < cap ? cnt : cap);
     return;

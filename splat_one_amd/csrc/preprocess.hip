@@ -230,7 +230,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
             got[i] = -1;
             if (i < cnt) {
               if (!tile_cull || tile_touches(cmx, cmy, cqa, cqb, cqc, ctau, x, y, tile_size))
-                got[i] = atomicAdd(tile_counts + ((int64_t)c * n_tiles + y * tile_w + wrapx(x, tile_w)), 1);
+                got[i] = atomicAdd(tile_counts + bin_counter_index((int64_t)c * n_tiles + y * tile_w + wrapx(x, tile_w), (int64_t)C * n_tiles), 1);
               if (++x == bx1) { x = bx0; ++y; }
             }
           }
@@ -291,7 +291,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
             if (!tile_cull || tile_touches(smx, smy, sqa, sqb, sqc, stau, x, y, tile_size)) {
               if (bin_keys) {
                 const int64_t t = srow + y * tile_w + wrapx(x, tile_w);
-                const int32_t s = atomicAdd(tile_counts + t, 1);
+                const int32_t s = atomicAdd(tile_counts + bin_counter_index(t, (int64_t)C * n_tiles), 1);
                 if (s < bin_cap) bin_keys[t * bin_cap + s] = skey;
                 else *bin_overflow = 1;
               } else {
@@ -1019,6 +1019,7 @@ int preprocess_bwd_n_f16(int C, int N, int K, int sh_degree, const float *means,
 }  // namespace so
 
 extern "C" int64_t so_attr_rec_stride(int K) { return K >= 1 ? so::attr_rec_stride_bytes(K) : 0; }
+extern "C" int64_t so_bin_counter_index(int64_t t, int64_t M) { return so::bin_counter_index(t, M); }
 
 extern "C" int so_attr_pack_f16(int64_t N, int K, const float *log_scales, const float *quats, const float *sh0,
                                 const float *shN, void *arec, void *stream) {

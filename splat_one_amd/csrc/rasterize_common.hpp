@@ -118,7 +118,7 @@ __device__ __forceinline__ unsigned long long clear_bit(unsigned long long mask,
 __device__ __forceinline__ void tile_list_range(int64_t ct, int64_t M, const int32_t *__restrict__ offsets,
                                                 const int32_t *__restrict__ n_dev, int64_t n_host, int64_t &lo, int64_t &hi) {
   if (!n_dev && n_host < 0) {
-    const int64_t cap = -n_host, cnt = offsets[ct];
+    const int64_t cap = -n_host, cnt = offsets[bin_counter_index(ct, M)];
     lo = ct * cap;
     hi = lo + (cnt < cap ? cnt : cap);
     return;

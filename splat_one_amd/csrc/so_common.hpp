@@ -360,6 +360,36 @@ __device__ __forceinline__ int lane_id() {
 
 
 // ---------------------------------------------------------------------------------------------
+// Where the counter of a binned list lives (round 4).  The binning atomics of so_preprocess_fwd are memory-side returning
+// atomics; with the counters of neighbouring tiles next to each other a scene whose splats gather in one image region sends
+// most of them to the few 64-byte lines that hold those counters (tools/probes/atomic_skew.hip: 246k adds into 340
+// neighbouring counters 55 us, into the same counters 4 KB apart 21 us; spread evenly over all counters 12.6 us either way).
+// So RUNS of two neighbouring tiles are dealt over the array: run g of G = M / 2 keeps its two counts at run (g * 1031) mod G
+// -- a bijection (1031 is prime; 1033 when it divides G), neighbouring runs 4 KB apart -- in every kernel that reads or bumps
+// a BINNED count; the key slots themselves stay at t * bin_cap.  Compact lists (offsets = exclusive scan) are not touched.
+// Why runs and not single counters: a large splat is binned by one wave whose 64 lanes bump an 8 x 8 block of neighbouring
+// tiles, 8 lines per instruction in plain order and 64 when every counter is on its own.  Measured (tools/gpu_skew_r04.sh,
+// so_preprocess_fwd, us; plain / single / runs of 2 / 4 / 8): c2 37.5 / 34.2 / 34.1 / 34.4 / 34.8; dense `ref` regime 135 /
+// 186 / 152 / 149 / 147; 100k splats in a fifth of the cube (--cloud-scale 0.2) 96 / 57 / 66 / 73 / 89; 2M there 1014 / 332 /
+// 452 / 578 / 842; 400k at 0.4: 126 / 76 / 75 / 78 / 85.
+// ---------------------------------------------------------------------------------------------
+#ifndef SO_BIN_GROUP_LOG2
+#define SO_BIN_GROUP_LOG2 1      // runs of 2^k neighbouring counters stay together and the runs are spread; < 0: plain order
+#endif
+__host__ __device__ __forceinline__ int64_t bin_counter_index(int64_t t, int64_t M) {
+#if SO_BIN_GROUP_LOG2 < 0
+  return t;
+#else
+  const int64_t G = M >> SO_BIN_GROUP_LOG2;                 // whole runs; a ragged tail keeps its place
+  if (G < 2 || G >= ((int64_t)1 << 21) || t >= (G << SO_BIN_GROUP_LOG2)) return t;   // (g * 1033 stays below 2^32)
+  const uint32_t m = (uint32_t)G, k = (m % 1031u) ? 1031u : 1033u;
+  if (m % k == 0u) return t;
+  const uint32_t g = (uint32_t)(t >> SO_BIN_GROUP_LOG2);
+  return ((int64_t)((g * k) % m) << SO_BIN_GROUP_LOG2) | (t & ((1 << SO_BIN_GROUP_LOG2) - 1));
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
 // Exact tile culling.  gsplat bins a Gaussian into every tile of the square of half-width ceil(3 sqrt(lambda_max))
 // around its centre, but the rasteriser drops a (pixel, Gaussian) pair whose
 // alpha = opacity * exp(-sigma) is below 1/255 -- i.e. outside the ellipse sigma(d) <= tau = ln(255 * opacity).  A tile

@@ -1056,7 +1056,11 @@ class FusedEngine:
         if not self.binned:
             n = int(c[2 * M + 1].item())
             return self.ws["isect_offsets"].reshape(-1).cpu().tolist() + [n], self.ws["flatten_ids"][:n].clone()
-        cnt = c[:M].clamp(max=self.bin_capacity).to(torch.int64)
+        # tile t keeps its count at so_bin_counter_index(t, M) (include/splat_one_amd.h: neighbouring counters 4 KB apart)
+        if getattr(self, "_count_at", None) is None or self._count_at.numel() != M:
+            f = _lib.load().so_bin_counter_index
+            self._count_at = torch.tensor([f(t, M) for t in range(M)], dtype=torch.int64, device=self.device)
+        cnt = c[:M][self._count_at].clamp(max=self.bin_capacity).to(torch.int64)
         offs = [0] + torch.cumsum(cnt, 0).cpu().tolist()
         ids = self.ws["flatten_ids"].view(M, self.bin_capacity)
         keep = torch.arange(self.bin_capacity, device=self.device)[None, :] < cnt[:, None]

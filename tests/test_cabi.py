@@ -126,3 +126,19 @@ def test_per_view_camera_models_and_f16_rows_validate_without_a_gpu():
     with pytest.raises(RuntimeError, match="tile_slots"):
         _lib.call("so_preprocess_fwd", 1, 4, 16, 3, *([1] * 8), 16, 16, 0.3, 0.01, 1e8, 0.0, 0, 0, 16,
                   *([1] * 7), 0, 0, 0, 0, 1, 0, 0, 0, 0, 0)
+
+
+def test_bin_counter_placement_is_a_bijection_that_separates_neighbouring_runs():
+    """so_bin_counter_index (include/splat_one_amd.h): where tile t of M keeps its binned count.  A bijection of [0, M) for
+    every M (any tile grid, any number of views; odd M leaves its last tile in place; a tile count that 1031 divides takes
+    the other multiplier), runs of two neighbouring tiles stay together, neighbouring runs land >= 1 KB apart."""
+    f = _lib.load().so_bin_counter_index
+    for M in (1, 2, 3, 4, 16, 17, 510, 8160, 8161, 2 * 1031, 2 * 1031 * 1033 // 1033 * 3, 14400, 65280, 4 * 8160 + 1):
+        idx = [f(t, M) for t in range(M)]
+        assert sorted(idx) == list(range(M)), M
+        for t in range(0, M - 1, 2):
+            assert idx[t + 1] == idx[t] + 1 and idx[t] % 2 == 0, (M, t)
+    idx = [f(t, 8160) for t in range(8160)]
+    gaps = [abs(idx[t + 2] - idx[t]) * 4 for t in range(0, 8158, 2)]
+    assert min(gaps) >= 1024, min(gaps)
+    assert f(5, 1 << 23) == 5                     # beyond 2^21 runs: plain order (the 32-bit product would wrap)
