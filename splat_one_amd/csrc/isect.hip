@@ -231,37 +231,10 @@ k_isect_scatter(int C, int N, const float *__restrict__ means2d, const int32_t *
   }
 }
 
-// Bitonic network with every comparison ascending ("flip" then "disperse" steps): elements past
-// n behave as +inf and never move, so ragged sizes need no padding.
-template <int THREADS>
-__device__ __forceinline__ void bitonic_sort_shared(uint64_t *keys, int n) {
-  int np2 = 1;
-  while (np2 < n) np2 <<= 1;
-  const int half = np2 >> 1;
-  for (int k = 2; k <= np2; k <<= 1) {
-    const int hk = k >> 1;
-    for (int i = threadIdx.x; i < half; i += THREADS) {  // flip
-      const int blk = i / hk, off = i - blk * hk;
-      const int a = blk * k + off, b = blk * k + k - 1 - off;
-      if (b < n) {
-        const uint64_t ka = keys[a], kb = keys[b];
-        if (ka > kb) { keys[a] = kb; keys[b] = ka; }
-      }
-    }
-    __syncthreads();
-    for (int j = hk >> 1; j >= 1; j >>= 1) {  // disperse
-      for (int i = threadIdx.x; i < half; i += THREADS) {
-        const int a = (i / j) * 2 * j + (i % j), b = a + j;
-        if (b < n) {
-          const uint64_t ka = keys[a], kb = keys[b];
-          if (ka > kb) { keys[a] = kb; keys[b] = ka; }
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
-
+// The merge network used for lists beyond the register sort (bitonic_merge_runs_shared below) has every comparison ascending
+// ("flip" then "disperse" steps): elements past n behave as +inf and never move, so ragged sizes need no padding.  Index
+// arithmetic in shifts and masks: with `i / hk`, `i / j`, `i % j` on run-time values the compiler emitted three integer
+// divisions per compare-exchange, ~100 instructions for 10 of work (round 4).
 __device__ __forceinline__ void tile_range(int64_t t, int64_t M, const int32_t *offsets, const int32_t *n_isects,
                                            int64_t capacity, int64_t &lo, int64_t &hi) {
   if (!n_isects && capacity < 0) {   // binned lists: cap = -capacity slots per tile, `offsets` holds the per-tile counts
@@ -327,6 +300,76 @@ __device__ __forceinline__ void wave_bitonic_sort(uint64_t (&v)[E], int lane) {
         }
       }
     }
+  }
+}
+
+// The last eight steps of a merge level (partner distances 128 ... 1, every comparison ascending: the flip-form network)
+// on 256 consecutive keys held by one wave, element index = lane + 64 e: two steps between registers
+// of the same lane, six on shuffles.
+__device__ __forceinline__ void wave_merge_tail_256(uint64_t (&v)[4], int lane) {
+#pragma unroll
+  for (int je = 2; je >= 1; je >>= 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if ((e & je) == 0) {
+        const uint64_t x = v[e], y = v[e | je];
+        v[e] = x < y ? x : y;
+        v[e | je] = x < y ? y : x;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 32; j >= 1; j >>= 1) {
+    const bool upper = (lane & j) != 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint64_t o = shfl_xor_u64(v[e], j);
+      v[e] = upper ? (v[e] < o ? o : v[e]) : (v[e] < o ? v[e] : o);
+    }
+  }
+}
+
+// Merge levels 512 ... of the flip-form network over n keys in LDS (n a multiple of 256, the keys standing in sorted runs
+// of 256): per level the flip step and the steps with partner distance >= 256 run in LDS, one barrier each, and the eight
+// steps below that in registers, each wave taking whole 256-key blocks -- 21 LDS steps + 6 register tails for 16384 keys
+// instead of 69 LDS steps (of which the 30 with partner distances below 32 were bank-conflicted).
+template <int THREADS>
+__device__ __forceinline__ void bitonic_merge_runs_shared(uint64_t *keys, int n) {
+  int lnp2 = 0;
+  while ((1 << lnp2) < n) ++lnp2;
+  const int half = (1 << lnp2) >> 1;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int lk = 9; lk <= lnp2; ++lk) {
+    const int k = 1 << lk, hk = k >> 1;
+    for (int i = threadIdx.x; i < half; i += THREADS) {  // flip
+      const int blk = i >> (lk - 1), off = i & (hk - 1);
+      const int a = (blk << lk) + off, b = (blk << lk) + k - 1 - off;
+      if (b < n) {
+        const uint64_t ka = keys[a], kb = keys[b];
+        if (ka > kb) { keys[a] = kb; keys[b] = ka; }
+      }
+    }
+    __syncthreads();
+    for (int lj = lk - 2; lj >= 8; --lj) {  // disperse, partner distance >= 256
+      const int j = 1 << lj;
+      for (int i = threadIdx.x; i < half; i += THREADS) {
+        const int a = ((i >> lj) << (lj + 1)) + (i & (j - 1)), b = a + j;
+        if (b < n) {
+          const uint64_t ka = keys[a], kb = keys[b];
+          if (ka > kb) { keys[a] = kb; keys[b] = ka; }
+        }
+      }
+      __syncthreads();
+    }
+    for (int c = wave; c < (n >> 8); c += THREADS / 64) {
+      uint64_t v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = keys[256 * c + lane + 64 * e];
+      wave_merge_tail_256(v, lane);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) keys[256 * c + lane + 64 * e] = v[e];
+    }
+    __syncthreads();
   }
 }
 
@@ -460,60 +503,127 @@ k_tile_sort_waves(int64_t M, int n_tiles, int tile_bits, const int32_t *__restri
   }
 }
 
-// Long lists (work list built by k_tile_sort_lds): a small fixed grid walks the list, so the launch
-// costs nothing when no tile is long.  <= CAP keys: the same network in 128 KiB of LDS; longer
-// (pathological: > 16384 Gaussians over one tile): the network runs on the global key buffer.
-template <int THREADS, int CAP>
+// Long lists (work list built by k_tile_sort_lds): a fixed grid walks the list, so the launches cost next to nothing when no
+// tile is long.  The unit of work is a SECTION of CAP keys of a long tile, sections dealt round-robin over the workgroups
+// (round 4: until then a workgroup took a whole tile, and the one tile with 40k keys of a gathered cloud kept one CU busy
+// for 400 us after all others had finished):
+//   pass 1 (MERGE = false)  a section's runs of 256 keys are sorted in registers, merged by the network in 128 KiB of LDS;
+//                           the only section of a tile (<= CAP keys) goes straight to flatten_ids, otherwise the sorted
+//                           keys are written back in place;
+//   pass 2 (MERGE = true)   tiles of two or more sections: every key of a section finds its final place by itself -- its
+//                           index in its own section plus, for each other section, the number of keys below it (a
+//                           branch-free binary search, the sections being L2-resident; until round 4 the whole network ran
+//                           on the global key buffer, ~120 barrier-separated passes for 30k keys).  Keys are distinct (the
+//                           id is the low word), so that is the rank: the same order as any correct sort.
+// The kernel boundary is the only synchronisation between the passes.
+template <int THREADS, int CAP, bool MERGE>
 __global__ void __launch_bounds__(THREADS)
 k_tile_sort_long(int64_t M, int n_tiles, int tile_bits, const int32_t *__restrict__ offsets,
                  const int32_t *__restrict__ n_isects, int64_t capacity, uint64_t *__restrict__ key_buf,
                  int32_t *__restrict__ flatten_ids, int64_t *__restrict__ isect_ids,
                  const int32_t *__restrict__ long_list, const int32_t *__restrict__ long_count) {
   extern __shared__ __attribute__((aligned(16))) uint64_t s_keys[];
+  static_assert(CAP % 256 == 0 && THREADS % 64 == 0 && THREADS <= 1024, "whole runs, whole waves");
+  __shared__ int32_t s_wave_sums[THREADS / 64];
+  __shared__ int32_t s_pick[2];
   const int n_long = *long_count;
-  for (int w = blockIdx.x; w < n_long; w += gridDim.x) {
-    const int64_t t = long_list[w];
-    int64_t lo, hi;
-    tile_range(t, M, offsets, n_isects, capacity, lo, hi);
-    const int64_t n = hi - lo;
-    if (n <= CAP) {
-      for (int i = threadIdx.x; i < n; i += THREADS) s_keys[i] = key_buf[lo + i];
-      __syncthreads();
-      bitonic_sort_shared<THREADS>(s_keys, (int)n);
-      for (int i = threadIdx.x; i < n; i += THREADS) write_sorted(s_keys[i], lo + i, t, n_tiles, tile_bits, flatten_ids, isect_ids);
-      __syncthreads();
-      continue;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  int first = (int)blockIdx.x;          // this workgroup's first section of the current batch of THREADS long tiles
+  for (int w0 = 0; w0 < n_long; w0 += THREADS) {
+    // every thread looks at one long tile: how many sections?  then a block-wide exclusive scan numbers the sections
+    int32_t nsec = 0;
+    if (w0 + tid < n_long) {
+      int64_t lo, hi;
+      tile_range(long_list[w0 + tid], M, offsets, n_isects, capacity, lo, hi);
+      nsec = (int32_t)((hi - lo + CAP - 1) / CAP);
+      if (MERGE && nsec == 1) nsec = 0;
     }
-    uint64_t *keys = key_buf + lo;
-    int64_t np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    const int64_t half = np2 >> 1;
-    for (int64_t k = 2; k <= np2; k <<= 1) {
-      const int64_t hk = k >> 1;
-      for (int64_t i = threadIdx.x; i < half; i += THREADS) {
-        const int64_t blk = i / hk, off = i - blk * hk;
-        const int64_t a = blk * k + off, b = blk * k + k - 1 - off;
-        if (b < n) {
-          const uint64_t ka = keys[a], kb = keys[b];
-          if (ka > kb) { keys[a] = kb; keys[b] = ka; }
-        }
-      }
-      __threadfence_block();
-      __syncthreads();
-      for (int64_t j = hk >> 1; j >= 1; j >>= 1) {
-        for (int64_t i = threadIdx.x; i < half; i += THREADS) {
-          const int64_t a = (i / j) * 2 * j + (i % j), b = a + j;
-          if (b < n) {
-            const uint64_t ka = keys[a], kb = keys[b];
-            if (ka > kb) { keys[a] = kb; keys[b] = ka; }
-          }
-        }
-        __threadfence_block();
-        __syncthreads();
-      }
+    int32_t sc = nsec;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int32_t o = __shfl_up(sc, d, 64);
+      if (lane >= d) sc += o;
     }
-    for (int64_t i = threadIdx.x; i < n; i += THREADS) write_sorted(keys[i], lo + i, t, n_tiles, tile_bits, flatten_ids, isect_ids);
+    if (lane == 63) s_wave_sums[wave] = sc;
     __syncthreads();
+    int32_t wave_off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; ++w) {
+      const int32_t ws = s_wave_sums[w];
+      wave_off += w < wave ? ws : 0;
+      total += ws;
+    }
+    const int32_t p0 = wave_off + sc - nsec;
+    int q = first;
+    for (; q < total; q += (int)gridDim.x) {
+      if (p0 <= q && q < p0 + nsec) { s_pick[0] = w0 + tid; s_pick[1] = q - p0; }
+      __syncthreads();
+      const int64_t t = long_list[s_pick[0]];
+      const int sec = s_pick[1];
+      __syncthreads();
+      int64_t lo, hi;
+      tile_range(t, M, offsets, n_isects, capacity, lo, hi);
+      const int64_t n = hi - lo;
+      const int nsec_t = (int)((n + CAP - 1) / CAP);
+      uint64_t *keys = key_buf + lo;
+      const int64_t s0 = (int64_t)sec * CAP;
+      const int sn = (int)(n - s0 < CAP ? n - s0 : CAP);
+      if constexpr (!MERGE) {
+        const int nch = (sn + 255) >> 8;
+        for (int c = wave; c < nch; c += THREADS / 64) {
+          uint64_t v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int i = 256 * c + lane + 64 * e;
+            v[e] = i < sn ? keys[s0 + i] : ~0ull;          // the last run's tail: +inf, sorts behind every key
+          }
+          wave_bitonic_sort<4>(v, lane);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s_keys[256 * c + lane + 64 * e] = v[e];
+        }
+        __syncthreads();
+        bitonic_merge_runs_shared<THREADS>(s_keys, 256 * nch);
+        if (nsec_t == 1) {
+          for (int i = tid; i < sn; i += THREADS) write_sorted(s_keys[i], lo + i, t, n_tiles, tile_bits, flatten_ids, isect_ids);
+        } else {
+          for (int i = tid; i < sn; i += THREADS) keys[s0 + i] = s_keys[i];
+        }
+        __syncthreads();
+      } else {
+        constexpr int U = 4;                               // searches in flight per thread
+        for (int i0 = tid * U; i0 < sn; i0 += THREADS * U) {
+          uint64_t key[U];
+          int64_t rank[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            key[u] = i0 + u < sn ? keys[s0 + i0 + u] : ~0ull;
+            rank[u] = i0 + u;
+          }
+          for (int other = 0; other < nsec_t; ++other) {
+            if (other == sec) continue;
+            const uint64_t *ch = keys + (int64_t)other * CAP;
+            const int len = (int)(n - (int64_t)other * CAP < CAP ? n - (int64_t)other * CAP : CAP);
+            int pos[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) pos[u] = 0;
+            for (int step = CAP; step >= 1; step >>= 1) {
+#pragma unroll
+              for (int u = 0; u < U; ++u) {
+                const int p = pos[u] + step;
+                if (p <= len && ch[p - 1] < key[u]) pos[u] = p;
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) rank[u] += pos[u];
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (i0 + u < sn) write_sorted(key[u], lo + rank[u], t, n_tiles, tile_bits, flatten_ids, isect_ids);
+        }
+      }
+    }
+    first = q - total;                   // where this workgroup's round-robin turn falls in the next batch
+    __syncthreads();                     // s_wave_sums is rewritten by the next batch
   }
 }
 
@@ -588,7 +698,7 @@ static void launch_tile_sorts(int64_t M, int n_tiles, int tb, const int32_t *ise
   const int gridW = (int)(groups < 65535 * 8 ? groups : 65535 * 8);
   static bool lds_attr_set = false;  // 128 KiB of dynamic LDS needs an explicit opt-in
   if (!lds_attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sort_long<1024, 16384>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sort_long<1024, 16384, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8) != hipSuccess) {
       (void)hipGetLastError();
     }
@@ -602,11 +712,15 @@ static void launch_tile_sorts(int64_t M, int n_tiles, int tb, const int32_t *ise
   else
     hipLaunchKernelGGL((k_tile_sort_lds<256, 2048>), dim3(gridM), dim3(256), 2048 * 8, st, M, n_tiles, tb,
                        isect_offsets, n_isects, capacity, key_buf, flatten_ids, isect_ids, long_list, long_count);
-  // longer lists: one workgroup per CU (128 KiB of LDS each) over the work list -- the grid is fixed at launch,
-  // the list length is only known on the device
-  // (binned lists whose bins hold no more than the first kernel sorts cannot have a long tile: nothing to launch)
-  if (!n_isects && capacity < 0 && -capacity <= 2048) return;
-  hipLaunchKernelGGL((k_tile_sort_long<1024, 16384>), dim3(256), dim3(1024), 16384 * 8, st, M, n_tiles, tb,
+  // longer lists: one workgroup per CU (128 KiB of LDS each) over the sections of the work list -- the grid is fixed at
+  // launch, the list length is only known on the device
+  // (binned lists whose bins hold no more than the first kernel sorts cannot have a long tile: nothing to launch; bins of
+  // no more than one section need no merge pass)
+  if (binned && -capacity <= 2048) return;
+  hipLaunchKernelGGL((k_tile_sort_long<1024, 16384, false>), dim3(256), dim3(1024), 16384 * 8, st, M, n_tiles, tb,
+                     isect_offsets, n_isects, capacity, key_buf, flatten_ids, isect_ids, long_list, long_count);
+  if (binned && -capacity <= 16384) return;
+  hipLaunchKernelGGL((k_tile_sort_long<1024, 16384, true>), dim3(256), dim3(1024), 0, st, M, n_tiles, tb,
                      isect_offsets, n_isects, capacity, key_buf, flatten_ids, isect_ids, long_list, long_count);
 }
 }  // namespace so

@@ -176,10 +176,11 @@ def test_isect_every_sort_path_boundary(dev):
 
 
 def test_isect_long_lists(dev):
-    """Lists longer than the small (1024) and the large (16384) LDS sort capacities."""
+    """Lists longer than the small (2048) and the large (16384) LDS sort capacities: one section of the long-list kernel,
+    exactly one, one key more, two and three sections (sorted in LDS section by section, merged by rank)."""
     from splat_one_amd.ops import isect_tiles
     g = torch.Generator().manual_seed(0)
-    for N in (3000, 20000):
+    for N in (3000, 16384, 16385, 20000, 40000):
         m2 = torch.rand(1, N, 2, generator=g) * 8 + 4          # all inside tile (0,0) of a 16x16 image
         radii = torch.ones(1, N, dtype=torch.int32)
         dep = torch.rand(1, N, generator=g) + 0.5
