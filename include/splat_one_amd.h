@@ -532,11 +532,15 @@ int so_train_step_bwd_rows(const so_step_desc *desc, int64_t row_begin, int64_t 
  *   written behind the counter, counter advanced) -- pass schedule_done = 1 to so_adam_step_dev then;
  *   status_out (nullable, host-mapped int32[3]): before zeroing, counters[status_at] and [status_at+1]
  *   (n_isects and overflow of the PREVIOUS iteration on these buffers) are published as
- *   {n_isects, overflow, seq} -- the host learns of a void iteration one step late, without a device sync. */
+ *   {n_isects, overflow, seq} -- the host learns of a void iteration one step late, without a device sync;
+ *   lists_stat (nullable, device int32[4], zero before the first call; with status_out, which is then int32[5]): the
+ *   first n_lists counters are per-tile list lengths (binned lists) -- their maximum and sum are gathered while they are
+ *   zeroed and published by the NEXT call as status_out[3], [4] (written before seq): the host follows the growth of the
+ *   lists -- larger bins before a tile overflows, the backward rasteriser that suits the length -- without reading the device. */
 int so_step_inputs(int C, const float *camtoworlds, const float *Ks_src, float *viewmats, float *Ks_dst,
                    const float *pixels, const float **pixels_slot, int32_t *counters, int64_t n_zero, int n_groups,
                    const float *lr0, const float *lr_gamma, double beta1, double beta2, int32_t *step_counter,
-                   int32_t *status_out, int64_t status_at, int32_t seq, void *stream);
+                   int32_t *status_out, int64_t status_at, int32_t seq, int64_t n_lists, int32_t *lists_stat, void *stream);
 /* the forward stages only (preprocess, binning, sort, rasterise) on the same descriptor: the eval /
  * viewer render of gsplat_trainer.py:779-940; pixels, loss and gradient buffers are not touched */
 int so_render_forward(const so_step_desc *desc, void *stream);

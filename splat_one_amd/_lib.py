@@ -150,7 +150,7 @@ _SIGS = {
     "so_preprocess_fwd_f16": [c_int] * 4 + [c_ptr] * 5 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_int] + [c_ptr] * 10 + [c_i64, c_ptr, c_int, c_ptr, c_i64, c_ptr, c_ptr],
     "so_preprocess_bwd_f16": [c_int] * 4 + [c_ptr] * 5 + [c_int, c_int, c_f32, c_int, c_int] + [c_ptr] * 3 + [c_f32, c_f32] + [c_ptr] * 9 + [c_int, c_i64, c_ptr, c_ptr, c_ptr],
     "so_step_inputs": [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, ctypes.POINTER(c_f32),
-                       ctypes.POINTER(c_f32), ctypes.c_double, ctypes.c_double, c_ptr, c_ptr, c_i64, c_int, c_ptr],
+                       ctypes.POINTER(c_f32), ctypes.c_double, ctypes.c_double, c_ptr, c_ptr, c_i64, c_int, c_i64, c_ptr, c_ptr],
     "so_compute_relocation": [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr],
     "so_inject_noise": [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr],
     "so_mcmc_refine": [c_i64, c_int, ctypes.POINTER(ModelSet), c_ptr, c_ptr, c_int, ctypes.POINTER(McmcParams), c_ptr, c_ptr, c_ptr],

@@ -108,11 +108,32 @@ __global__ void __launch_bounds__(256)
 k_step_inputs(int C, const float *__restrict__ c2w, const float *__restrict__ Ks_src, float *__restrict__ w2c,
               float *__restrict__ Ks_dst, const float *pixels, const float **pixels_slot, uint32_t *__restrict__ counters,
               int64_t n_zero, AdamSched sch, int n_groups, double beta1, double beta2, int32_t *__restrict__ step_ptr,
-              int32_t *status_out, int64_t status_at, int32_t seq) {
+              int32_t *status_out, int64_t status_at, int32_t seq, int64_t n_lists, int32_t *__restrict__ lists_stat) {
   // status_out (host-mapped, nullable): what the PREVIOUS iteration left in counters[status_at], [status_at+1]
   // (n_isects, overflow), read by one thread before that pair is zeroed, so no other workgroup races it
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += (int64_t)gridDim.x * blockDim.x)
+  // lists_stat (device, int32[4], nullable; with status_out): the first n_lists counters are the per-tile list lengths of the
+  // previous iteration (binned lists) -- their maximum and sum are gathered while they are zeroed, into the pair
+  // lists_stat[2 (seq & 1)], and the pair the previous launch completed is published as status_out[3], [4]: the host follows
+  // the growth of the lists (bins, choice of the backward rasteriser) without ever reading the device
+  uint32_t l_max = 0u, l_sum = 0u;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += (int64_t)gridDim.x * blockDim.x) {
+    if (lists_stat && status_out && i < n_lists) {
+      const uint32_t v = counters[i];
+      l_max = v > l_max ? v : l_max;
+      l_sum += v;
+    }
     if (!status_out || (i != status_at && i != status_at + 1)) counters[i] = 0u;
+  }
+  if (lists_stat && status_out && n_lists > 0) {
+    const int32_t w_max = wave_max_i32((int32_t)l_max);
+    uint32_t w_sum = l_sum;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) w_sum += (uint32_t)__shfl_xor((int)w_sum, d, 64);
+    if ((threadIdx.x & 63) == 0 && w_sum) {
+      atomicMax(lists_stat + 2 * (seq & 1), w_max);
+      atomicAdd(lists_stat + 2 * (seq & 1) + 1, (int32_t)w_sum);
+    }
+  }
   // three independent jobs on three workgroups (when the grid has them), so that the kernel lasts as long as the longest of
   // them and not as long as their sum: the status report waits for its stores to reach host memory, the schedule runs
   // three double-precision pow() per group
@@ -123,6 +144,13 @@ k_step_inputs(int C, const float *__restrict__ c2w, const float *__restrict__ Ks
     if (status_at + 1 < n_zero) counters[status_at + 1] = 0u;
     status_out[0] = n_prev;
     status_out[1] = ov_prev;
+    if (lists_stat) {   // the pair of the launch before this one: complete, and free again for the launch after this one
+      int32_t *done = lists_stat + 2 * ((seq + 1) & 1);
+      status_out[3] = done[0];
+      status_out[4] = done[1];
+      done[0] = 0;
+      done[1] = 0;
+    }
     __threadfence_system();
     status_out[2] = seq;      // written last: the host trusts [0], [1] once it sees its own sequence number here
   }
@@ -200,7 +228,8 @@ extern "C" int so_train_step_bwd_rows(const so_step_desc *d, int64_t row_begin, 
 extern "C" int so_step_inputs(int C, const float *camtoworlds, const float *Ks_src, float *viewmats, float *Ks_dst,
                               const float *pixels, const float **pixels_slot, int32_t *counters, int64_t n_zero,
                               int n_groups, const float *lr0, const float *lr_gamma, double beta1, double beta2,
-                              int32_t *step_counter, int32_t *status_out, int64_t status_at, int32_t seq, void *stream) {
+                              int32_t *step_counter, int32_t *status_out, int64_t status_at, int32_t seq, int64_t n_lists,
+                              int32_t *lists_stat, void *stream) {
   SO_REQUIRE(C >= 0 && n_zero >= 0 && n_groups >= 0 && n_groups <= SO_ADAM_MAX_GROUPS, "so_step_inputs: bad sizes");
   SO_REQUIRE(C == 0 || (camtoworlds && viewmats), "so_step_inputs: null camera pointers");
   SO_REQUIRE((Ks_src == nullptr) == (Ks_dst == nullptr), "so_step_inputs: Ks_src and Ks_dst go together");
@@ -208,6 +237,7 @@ extern "C" int so_step_inputs(int C, const float *camtoworlds, const float *Ks_s
   SO_REQUIRE(n_zero == 0 || counters, "so_step_inputs: null counters");
   SO_REQUIRE(n_groups == 0 || (lr0 && lr_gamma && step_counter), "so_step_inputs: null schedule pointers");
   SO_REQUIRE(status_out == nullptr || (counters && status_at >= 0), "so_step_inputs: status_out needs counters and status_at");
+  SO_REQUIRE(lists_stat == nullptr || (status_out && n_lists >= 0 && n_lists <= status_at), "so_step_inputs: lists_stat needs status_out and n_lists <= status_at");
   so::AdamSched S{};
   for (int i = 0; i < n_groups; ++i) { S.lr0[i] = lr0[i]; S.lr_gamma[i] = lr_gamma[i]; }
   int64_t g = (n_zero + 1023) / 1024;
@@ -215,7 +245,7 @@ extern "C" int so_step_inputs(int C, const float *camtoworlds, const float *Ks_s
   if (g > 1024) g = 1024;
   hipLaunchKernelGGL(so::k_step_inputs, dim3((unsigned)g), dim3(256), 0, so::as_stream(stream), C, camtoworlds, Ks_src, viewmats,
                      Ks_dst, pixels, pixels_slot, reinterpret_cast<uint32_t *>(counters), n_zero, S, n_groups, beta1, beta2,
-                     step_counter, status_out, status_at, seq);
+                     step_counter, status_out, status_at, seq, n_lists, lists_stat);
   return so::check_launch("so_step_inputs");
 }
 

@@ -122,7 +122,11 @@ class FusedEngine:
         self.steps_done = 0
         self._step_dev = torch.zeros(2 + 4 * _lib.SO_ADAM_MAX_GROUPS, dtype=torch.int32, device=self.device)
         # host-mapped status words {n_isects, overflow, seq} of the previous iteration (so_step_inputs)
-        self._status = torch.zeros(4, dtype=torch.int32).pin_memory()
+        self._status = torch.zeros(8, dtype=torch.int32).pin_memory()
+        # {max, sum} of the per-tile list lengths, gathered by so_step_inputs while it zeroes the counters and published one
+        # call later as _status[3], [4]: the bins and the choice of the backward rasteriser follow a growing model (device-side
+        # refinements) without a read-back
+        self._lists_stat = torch.zeros(4, dtype=torch.int32, device=self.device)
         self._seq = 0
         self._status_event: Optional[torch.cuda.Event] = None
         self._last_launch = self._status_kind = None   # "train" | "render": what last ran on the counters
@@ -627,15 +631,20 @@ class FusedEngine:
         _lib.call("so_step_inputs", self.C if c2w is not None else 0, p(c2w), p(Ks), p(w["viewmats"]), p(w["Ks"]) if c2w is not None else 0,
                   p(px), p(w["pixels_slot"]) if px is not None else 0, p(w["counters"]), 2 * self.M + 5, n_groups, lr0, gam,
                   float(betas[0]), float(betas[1]), _lib.ptr(self._step_dev),
-                  self._status.data_ptr() if publish else 0, 2 * self.M + 1, self._seq, _lib.stream())
+                  self._status.data_ptr() if publish else 0, 2 * self.M + 1, self._seq,
+                  self.M if (publish and self.binned) else 0, p(self._lists_stat) if (publish and self.binned) else 0, _lib.stream())
         if publish:
             self._status_event = torch.cuda.Event()
             self._status_event.record()
         self._staged = True
         self._sched_staged = bool(schedule)
-        if publish and self._probe_capacity:
-            self._probe_capacity = False
-            if self._measure_and_grow():             # buffers were too small for this view: stage again on the new ones
+        if publish and (self._probe_capacity or getattr(self, "_remeasure", False)):
+            # (first sizing: 8x headroom over this view's fullest tile; after a refinement changed the model: measured again --
+            # one forward pass and one read per refinement -- so that lists that have grown get larger bins BEFORE they overflow
+            # and the backward rasteriser that suits their length; bins are rebuilt only when their headroom has fallen below 2x)
+            first = self._probe_capacity
+            self._probe_capacity = self._remeasure = False
+            if self._measure_and_grow(8 if first else 2):   # buffers were too small for this view: stage again on the new ones
                 self._status_event = None            # (the previous iteration's status has been looked at already)
                 self._step_dev[0] = self.steps_done  # the schedule above advanced the device counter: undo
                 self._stage(c2w, Ks, pixels, schedule)
@@ -674,12 +683,13 @@ class FusedEngine:
 
     def reprobe_capacity(self) -> None:
         """Measure the per-tile lists again on the next staged view (one forward-only pass and one read) and enlarge the
-        buffers if they are no longer generous -- for callers that cannot afford a void iteration after the model has
-        grown (data-parallel replicas after a refinement: on_overflow == "raise")."""
-        self._probe_capacity = True
+        buffers if they are no longer generous (less than 2x the fullest tile) -- what the engine does by itself after
+        every device-side refinement; for callers that change the model in other ways and cannot afford a void iteration."""
+        self._remeasure = True
 
-    def _measure_and_grow(self) -> bool:
-        """Forward-only pass on the staged view, read its intersection count (one sync, once per workspace)."""
+    def _measure_and_grow(self, headroom: int = 8) -> bool:
+        """Forward-only pass on the staged view, read its intersection count (one sync, once per workspace and once per
+        refinement).  Bins are rebuilt (at 8x the fullest tile) when they hold less than `headroom` times that tile."""
         d = self._desc()
         _lib.call("so_render_forward", ctypes.byref(d), _lib.stream())
         if self.binned:
@@ -692,7 +702,7 @@ class FusedEngine:
             if impl != self.cfg["raster_impl"]:
                 self.cfg["raster_impl"] = impl
                 self._graphs, self._graphs_fb, self._graphs_head, self._rows_desc = {}, {}, {}, None
-            if 8 * mx > self.bin_capacity:           # other views / later iterations may fill a tile far more than this one
+            if headroom * mx > self.bin_capacity:    # other views / later iterations may fill a tile far more than this one
                 if 2 * mx > self._bin_limit:         # bins with any headroom do not fit the budget: compact lists instead
                     self._fall_back_to_compact_lists(mx)
                     return True
@@ -707,6 +717,28 @@ class FusedEngine:
             return True
         return False
 
+    def _follow_lists(self, fullest: int, total: int) -> None:
+        """The list lengths of an iteration two calls back (so_step_inputs gathers them on the device, no read-back): keep the
+        bins at >= 2x the fullest tile -- rebuilt at 8x before a tile overflows, a model that device-side refinements grow
+        from 1M to 1.8M Gaussians multiplies its lists -- and the backward rasteriser that suits the mean length (one wave
+        per tile from 256 entries per tile, back to one per quadrant below 192)."""
+        if fullest <= 0:
+            return
+        mean_list = total / max(self.M, 1)
+        impl = self.cfg["raster_impl"]
+        if self.cfg["tile_size"] == 16 and not self.cfg["absgrad"]:
+            impl = 1 if mean_list >= 256.0 else (0 if mean_list < 192.0 else impl)
+        if impl != self.cfg["raster_impl"]:
+            self.cfg["raster_impl"] = impl
+            self._graph = None
+            self._graph_fb = self._graph_opt = None
+            self._graphs, self._graphs_fb, self._graphs_head, self._rows_desc = {}, {}, {}, None
+        if 2 * fullest > self.bin_capacity and self.bin_capacity < self._bin_limit and fullest <= self.bin_capacity:
+            # (a tile beyond the capacity has overflowed: that is _check_previous' business -- void iteration, take back)
+            self._bin_hint = min(-(-8 * fullest // 256) * 256, self._bin_limit)
+            self._build_workspace()
+            self._probe_capacity = False
+
     def _check_previous(self) -> None:
         """One step late and without a device-wide sync: did the iteration before the last one overflow its
         intersection buffers?  (The kernels stay in bounds and the optimiser skipped it; here the buffers grow
@@ -716,6 +748,8 @@ class FusedEngine:
             return
         ev.synchronize()
         n_prev, ov_prev, seq = (int(v) for v in self._status[:3])
+        if seq == self._seq and not ov_prev and self.binned and self._status_kind == "train":
+            self._follow_lists(int(self._status[3]), int(self._status[4]))
         if seq != self._seq or not ov_prev:
             return
         torch.cuda.synchronize()

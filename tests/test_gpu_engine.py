@@ -391,6 +391,59 @@ def test_tile_wave_backward_equals_the_quadrant_wave_backward(dev, regime, C, mo
         assert ((grads[1][k].cpu().double() - v.grad).norm() / (v.grad.norm() + floor)).item() <= 1e-3, k
 
 
+def test_bins_and_backward_rasteriser_follow_growing_lists_without_a_read_back(dev):
+    """A device-side refinement can multiply the per-tile lists (BASELINE configs[3]: 1M -> 1.8M Gaussians over the timed
+    region, 145 -> 337 entries per tile).  so_step_inputs gathers the maximum and the sum of the list lengths while it zeroes
+    the counters and publishes them to host-mapped memory one call later; from those the engine rebuilds its bins at 8x the
+    fullest tile as soon as they hold less than 2x of it -- BEFORE a tile overflows: no void iteration -- and moves the
+    backward to one wave per tile once the mean list reaches 256 entries.  No synchronising call in the steps that only look
+    (torch's sync debug mode); `reprobe_capacity()` is the explicit, synchronising form."""
+    from splat_one_amd.engine import FusedEngine
+    N, W, H = 6000, 176, 112
+    r, c2w, Ks, pixels = _make(dev, N, W, H, "mcmc")
+    st = r.cfg.strategy.initialize_state(1.0)
+    eng = FusedEngine(r.splats, r.optimizers, W, H, 1, sh_degree=3, use_graph=True, device_refine=True, capacity=16384,
+                      strategy_state=st, bin_capacity=512)
+
+    def steps(n, no_sync=False):
+        if no_sync:
+            torch.cuda.set_sync_debug_mode("error")
+        try:
+            for _ in range(n):
+                eng.set_views(c2w, Ks, pixels, schedule=True)
+                eng.step()
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        torch.cuda.synchronize()
+
+    steps(4)
+    ws0, fullest0 = eng.ws, eng._fullest_tile()
+    assert eng.cfg["raster_impl"] == 0 and eng.void_steps == 0 and eng.bin_capacity == 512 and 2 * fullest0 < 512
+    steps(4, no_sync=True)                                   # lists with >= 2x headroom: looked at, left alone, no sync
+    # (what the host sees is two iterations old and the model trains: close to the current lists, not equal)
+    assert eng.ws is ws0 and abs(int(eng._status[3]) - eng._fullest_tile()) <= 8
+    assert abs(int(eng._status[4]) - eng.stats()["n_isects"]) <= 0.02 * eng.stats()["n_isects"]
+    # the splats swell a little (what a split / duplicate round does to the lists, as one edit of the active set): the
+    # fullest tile passes HALF the bin -- not the bin
+    with torch.no_grad():
+        eng.sets[eng.active]["p"]["scales"][:N] += 0.9
+    steps(5)
+    fullest1 = eng._fullest_tile()
+    assert 256 < fullest1 <= 512, fullest1
+    assert eng.void_steps == 0 and eng.stats()["overflow"] == 0 and eng.bin_capacity >= 8 * fullest1 > 512 and eng.ws is not ws0
+    # and further: still inside the new bins; the mean list passes 256 entries -> one wave per tile in the backward
+    with torch.no_grad():
+        eng.sets[eng.active]["p"]["scales"][:N] += 1.6
+    steps(5)
+    assert eng.void_steps == 0 and eng.stats()["overflow"] == 0
+    assert eng.stats()["n_isects"] / eng.M >= 256 and eng.cfg["raster_impl"] == 1
+    # the explicit form: one forward pass and one read, at once
+    eng.cfg["raster_impl"] = 0
+    eng.reprobe_capacity()
+    steps(1)
+    assert eng.cfg["raster_impl"] == 1
+
+
 def test_skewed_cloud_falls_back_to_compact_lists_instead_of_raising(dev):
     """A cloud gathered in a few tiles (what real captures look like next to the uniform benchmark cube): bins sized for the
     fullest tile would exceed the memory budget.  The engine switches to the compact slotted lists at its capacity probe --

@@ -218,7 +218,10 @@ def test_engine_refinement_without_host_sync_equals_the_oracle(dev):
     next steps replay captured graphs on the other model set, and the Gaussian set after the refinement equals the
     oracle's on the state the device held before it."""
     W, H, N = 160, 120, 4000
-    r = _runner(dev, N, W, H)
+    # (bins given up front with room for the six refinements below: the engine follows growing lists by itself and would
+    # rebuild its bins -- allocations, a re-capture -- inside the window that must not synchronise; that path has its own test,
+    # test_bins_and_backward_rasteriser_follow_growing_lists_without_a_read_back)
+    r = _runner(dev, N, W, H, bin_capacity=8192)
     c2w = ring_cameras(4).to(dev)
     Ks = pinhole_K(W, H)[None].to(dev)
     yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
