@@ -515,16 +515,21 @@ def main():
 
     def collected_near(j, what):
         """A committed counter summary applies to this run only if it was collected at (nearly) the same workload state: the
-        passes walk tile lists, and their number follows the tile intersections I."""
-        at = (j.get("_collected_at") or {}).get("tile_intersections")
-        if not at:
-            profile_notes[what] = "refused: the summary in profiles/ does not say at which tile-intersection count it was collected"
-            return False
-        if abs(I - at) > 0.05 * at:
-            profile_notes[what] = f"refused: collected at I = {at}, this run has I = {I} (> 5 % apart)"
-            return False
-        profile_notes[what] = f"collected at I = {at} (this run: I = {I})"
-        return True
+        passes walk tile lists, and their number follows the tile intersections I.  profiles/*.json hold
+        the collection of the default command and, under "_also", the one made at the round-end driver's command line
+        (--steps 20 --warmup 5): returns the collection within 5 % of this run's I, or None."""
+        seen = []
+        for col in [j] + list(j.get("_also") or []):
+            at = (col.get("_collected_at") or {}).get("tile_intersections")
+            if not at:
+                continue
+            seen.append(at)
+            if abs(I - at) <= 0.05 * at:
+                profile_notes[what] = f"collected at I = {at} (this run: I = {I})"
+                return col
+        profile_notes[what] = ("refused: the summary in profiles/ does not say at which tile-intersection count it was collected" if not seen
+                               else f"refused: collected at I = {seen}, this run has I = {I} (> 5 % apart)")
+        return None
 
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     # the PMC traffic in profiles/ was collected on c2 with the fused engine: it says nothing about another workload
@@ -532,8 +537,8 @@ def main():
                     and args.regime == "mcmc" and args.cloud_scale == 1.0)
     if os.path.exists(tpath) and is_c2_engine:
         try:
-            tj = json.load(open(tpath))
-            traffic = tj.get(dominant) if collected_near(tj, "traffic") else None
+            tj = collected_near(json.load(open(tpath)), "traffic")
+            traffic = tj.get(dominant) if tj else None
         except Exception:
             traffic = None
     # rocprofv3's own average for the dominant kernel (profiles/kernel_us.json <- the committed --kernel-trace --stats summary
@@ -542,7 +547,7 @@ def main():
     kpath = os.path.join(ROOT, "profiles", "kernel_us.json")
     if os.path.exists(kpath) and is_c2_engine:
         try:
-            kj = json.load(open(kpath))
+            kj = collected_near(json.load(open(kpath)), "kernel_us") or {}
             if dominant in kj:
                 kernel_us_rocprof = {"us": kj[dominant], "source": kj.get("_note"), "collected_at": kj.get("_collected_at")}
         except Exception:   # noqa: BLE001
@@ -577,8 +582,8 @@ def main():
     vpath = os.path.join(ROOT, "profiles", "valu.json")
     if os.path.exists(vpath) and is_c2_engine:
         try:
-            vj = json.load(open(vpath))
-            ent = vj.get(dominant) if collected_near(vj, "valu") else None
+            vj = collected_near(json.load(open(vpath)), "valu") or {}
+            ent = vj.get(dominant)
             if ent:
                 rate = ent["wave_instructions"] / (dom_ms * 1e-3)
                 valu = {"wave_instructions_per_launch": ent["wave_instructions"], "achieved": rate, "peak": VALU_PEAK_WAVE_INSTR_PER_S,

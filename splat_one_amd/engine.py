@@ -697,8 +697,11 @@ class FusedEngine:
             # which backward rasteriser: long lists (the dense initialisation regime, >= 256 entries per tile on average)
             # run faster with one wave per tile -- 22 % fewer instructions -- short ones with one wave per 8x8 quadrant (a
             # tile is then not one wave's serial chain); measured crossover ~250 entries (profiles/r04_experiments.json)
+            # ... and only when the lists are long EVERYWHERE: a cloud gathered in 250 tiles of 12 000 entries has a mean of 390
+            # over the 8160 tiles too, but one wave per tile then leaves three quarters of the SIMDs idle (2M Gaussians at
+            # --cloud-scale 0.2: 1050 us against 372 with the four waves per tile of the other kernel)
             mean_list = float(self.ws["counters"][:self.M].clamp(max=self.bin_capacity).float().mean().item())
-            impl = 1 if (mean_list >= 256.0 and self.cfg["tile_size"] == 16 and not self.cfg["absgrad"]) else 0
+            impl = self._pick_raster_impl(self.cfg["raster_impl"], mean_list, mx, first=True)
             if impl != self.cfg["raster_impl"]:
                 self.cfg["raster_impl"] = impl
                 self._graphs, self._graphs_fb, self._graphs_head, self._rows_desc = {}, {}, {}, None
@@ -717,17 +720,24 @@ class FusedEngine:
             return True
         return False
 
+    def _pick_raster_impl(self, now: int, mean_list: float, fullest: int, first: bool = False) -> int:
+        """One wave per tile (1) for lists that are long everywhere -- mean >= 256 entries per tile and the fullest tile
+        within 6x of the mean -- else one wave per 8x8 quadrant (0); with hysteresis once running (back at < 192 or > 8x)."""
+        if self.cfg["tile_size"] != 16 or self.cfg["absgrad"]:
+            return 0
+        if mean_list >= 256.0 and fullest <= 6.0 * mean_list:
+            return 1
+        if first or mean_list < 192.0 or fullest > 8.0 * mean_list:
+            return 0
+        return now
+
     def _follow_lists(self, fullest: int, total: int) -> None:
         """The list lengths of an iteration two calls back (so_step_inputs gathers them on the device, no read-back): keep the
         bins at >= 2x the fullest tile -- rebuilt at 8x before a tile overflows, a model that device-side refinements grow
-        from 1M to 1.8M Gaussians multiplies its lists -- and the backward rasteriser that suits the mean length (one wave
-        per tile from 256 entries per tile, back to one per quadrant below 192)."""
+        from 1M to 1.8M Gaussians multiplies its lists -- and the backward rasteriser that suits them (_pick_raster_impl)."""
         if fullest <= 0:
             return
-        mean_list = total / max(self.M, 1)
-        impl = self.cfg["raster_impl"]
-        if self.cfg["tile_size"] == 16 and not self.cfg["absgrad"]:
-            impl = 1 if mean_list >= 256.0 else (0 if mean_list < 192.0 else impl)
+        impl = self._pick_raster_impl(self.cfg["raster_impl"], total / max(self.M, 1), fullest)
         if impl != self.cfg["raster_impl"]:
             self.cfg["raster_impl"] = impl
             self._graph = None

@@ -64,6 +64,7 @@ class _Bins:
         self.zero_alphas: Dict[Tuple[int, int, int], Tensor] = {}
         self.overflows = 0
         self.mean_list = 0.0                         # list entries per tile of the last forward whose status has been looked at
+        self.fullest = 0                             # ... and its fullest tile
 
     def keys(self) -> Tensor:
         n = self.M * self.slots
@@ -82,7 +83,7 @@ class _Bins:
         if self.seq == 0 or int(st[2]) != self.seq:
             return
         fullest, overflow = int(st[0]), int(st[1])
-        self.mean_list = float(int(st[3])) / self.M
+        self.mean_list, self.fullest = float(int(st[3])) / self.M, fullest
         if overflow:
             self.overflows += 1
             warnings.warn(f"splat_one_amd.rasterization: the previous call put {fullest} Gaussians over one tile, more than its "
@@ -219,7 +220,7 @@ class _Rasterization(torch.autograd.Function):
                     break
                 torch.cuda.current_stream().synchronize()
                 fullest, overflow = int(bins.status_np[0]), int(bins.status_np[1])
-                bins.mean_list = float(int(bins.status_np[3])) / M
+                bins.mean_list, bins.fullest = float(int(bins.status_np[3])) / M, fullest
                 if measure:
                     bins.probed, bins.n_probe = True, N
                     if overflow or 8 * fullest > bins.slots:
@@ -267,7 +268,10 @@ class _Rasterization(torch.autograd.Function):
         d.bin_capacity = ctx.slots
         # long lists (dense initialisations: >= 256 entries per tile, as the fused engine decides): the backward rasteriser
         # as one wave per tile; the mean is the one the last looked-at status word of these bins reported -- no read here
-        d.raster_impl = 1 if (bins.mean_list >= 256.0 and cfg["tile_size"] == 16 and not cfg["absgrad"]) else -1
+        # (long EVERYWHERE -- the fullest tile within 6x of the mean: a cloud gathered in a few hundred tiles has too few tiles
+        # for one wave each, FusedEngine._pick_raster_impl)
+        d.raster_impl = 1 if (bins.mean_list >= 256.0 and bins.fullest <= 6.0 * bins.mean_list and cfg["tile_size"] == 16
+                              and not cfg["absgrad"]) else -1
         d.means, d.quats, d.scales, d.opacities, d.sh0, d.shN = (means.data_ptr(), quats.data_ptr(), scales.data_ptr(),
                                                                    opacities.data_ptr(), sh0.data_ptr(), _p(shN))
         d.viewmats, d.Ks, d.backgrounds = viewmats.data_ptr(), Ks.data_ptr(), _p(backgrounds)

@@ -8,27 +8,32 @@
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r04
+export RTAG
+# RTAG=r04d BARGS="--steps 20 --warmup 5": the same counter passes at the state the round-end driver benches (its command
+# line: 25 iterations in all, ~308k tile intersections instead of ~372k) -- bench.py picks the collection that matches its run
+RTAG=${RTAG:-r04}
+BARGS=${BARGS:-}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$RTAG
 mkdir -p $OUT/prof $OUT/pmc $OUT/hip
 if [ "${PART:-A}" = "A" ]; then
-timeout 600 python3 bench.py --kernel-table > $OUT/bench.json 2> $OUT/bench_stderr.txt || exit 1
+timeout 600 python3 bench.py --kernel-table $BARGS > $OUT/bench.json 2> $OUT/bench_stderr.txt || exit 1
 cut -c1-600 $OUT/bench.json
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-operator-path > $OUT/prof/stdout.txt 2> $OUT/prof/stderr.txt || exit 1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-operator-path $BARGS > $OUT/prof/stdout.txt 2> $OUT/prof/stderr.txt || exit 1
 for CTR in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d $OUT/pmc -o pmc_$CTR -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-operator-path > $OUT/pmc/stdout_$CTR.txt 2> $OUT/pmc/stderr_$CTR.txt || exit 1
+  timeout 600 rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d $OUT/pmc -o pmc_$CTR -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-operator-path $BARGS > $OUT/pmc/stdout_$CTR.txt 2> $OUT/pmc/stderr_$CTR.txt || exit 1
 done
 for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU"; do
   tag=$(echo $SET | cut -d' ' -f1)
-  timeout 600 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/pmc -o sq_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-operator-path > $OUT/pmc/stdout_$tag.txt 2> $OUT/pmc/stderr_$tag.txt || exit 1
+  timeout 600 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/pmc -o sq_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-operator-path $BARGS > $OUT/pmc/stdout_$tag.txt 2> $OUT/pmc/stderr_$tag.txt || exit 1
 done
-for S in 150 250; do
+for S in $( [ -z "$BARGS" ] && echo 150 250 ); do
   timeout 600 rocprofv3 --hip-trace --stats --output-format csv -d $OUT/hip -o hip$S -- python3 $GRAFT_REPO_ROOT/tools/dbg_refine_sync.py --strategy mcmc --n 100000 --width 1920 --height 1080 --steps $S > $OUT/hip/hip${S}_stdout.txt 2> $OUT/hip/hip${S}_stderr.txt || exit 1
   tail -1 $OUT/hip/hip${S}_stdout.txt
 done
 python3 - <<'PY'
 import csv, glob, os, json, collections
-out=os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/r04"
+out=os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/"+os.environ.get("RTAG","r04")
 for f in glob.glob(out+"/prof/**/bench_kernel_stats.csv", recursive=True):
     for r in list(csv.DictReader(open(f)))[:14]:
         print(f"{r['Name'][:80]:80s} calls {r['Calls']:>6s} avg_us {float(r['AverageNs'])/1e3:10.1f} pct {r['Percentage']}")

@@ -39,18 +39,18 @@ for a, b in pairs:
         print("copied", os.path.relpath(p, ROOT), "->", b)
     else:
         print("MISSING", a)
-d = json.load(open(os.path.join(dst, f"{tag}_engine_pmc_traffic.json")))
 names = {"so_rasterize_bwd": "void so::k_rasterize_bwd<3, 16, false, true, true>", "so_rasterize_fwd": "void so::k_rasterize_fwd<3, 16, true>",
          "so_adam_step_dev": "so::k_adam_dev", "so_ssim_l1_fwd": "void so::k_ssim_l1_fwd<3>", "so_ssim_l1_bwd": "void so::k_ssim_l1_bwd<3>",
          "so_ssim_l1_fused": "void so::k_ssim_l1_fused<3>",
          "so_preprocess_fwd": "void so::k_preprocess_fwd<3, so::AttrSoA, false>",
          "so_preprocess_bwd": "void so::k_preprocess_bwd<3, so::AttrSoA, true, true, false>",
          "so_isect_fill": "void so::k_tile_sort_waves<256, 2048>"}
-out = {k: d[v]["hbm_bytes_per_launch_corrected"] for k, v in names.items() if v in d}
-def collected_at(kind):
+
+
+def collected_at(run, kind):
     """tile intersections of the profiled bench command itself (its JSON line is in the pass's stdout file)"""
     vals = []
-    for f in glob.glob(os.path.join(src, tag, kind, "stdout*.txt")):
+    for f in glob.glob(os.path.join(src, run, kind, "stdout*.txt")):
         for line in open(f):
             if line.startswith("{") and "tile_intersections" in line:
                 try:
@@ -63,39 +63,66 @@ def collected_at(kind):
     return {"tile_intersections": int(sum(v[0] for v in vals) / len(vals)), "steps": vals[0][1], "warmup": vals[0][2], "runs": len(vals)}
 
 
-out["_collected_at"] = collected_at("pmc")
-out["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profiles_%s.sh) of the default bench (c2, 8 ring views "
-                "cycled), KB -> bytes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; source "
-                "profiles/%s_engine_pmc_traffic.json" % (tag, tag))
-json.dump(out, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
-print(out)
-# the VALU side: wave-instructions and exec-mask lane cycles per launch (bench.py roofline.valu)
-sqp = os.path.join(dst, f"{tag}_engine_sq_counters.json")
-if os.path.exists(sqp):
-    sq = json.load(open(sqp))
-    valu = {}
-    for k, v in names.items():
-        c = sq.get(v)
-        if c and "SQ_INSTS_VALU" in c:
-            valu[k] = {"wave_instructions": c["SQ_INSTS_VALU"], "waves": c.get("SQ_WAVES"),
-                       "active_lane_fraction": (c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
-                                                if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU") else None)}
-    valu["_collected_at"] = collected_at("pmc")
-    valu["_note"] = ("rocprofv3 --pmc SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_THREAD_CYCLES_VALU (tools/gpu_profiles_%s.sh), means per launch of the "
-                     "default bench (c2); active_lane_fraction = exec-mask lanes per issued VALU instruction / 64; source profiles/%s_engine_sq_counters.json"
-                     % (tag, tag))
-    # lanes that carry a contributing (pixel, Gaussian) pair in a pass of the rasteriser kernels: tools/passsim.py on the c2 front view
-    valu["_useful_lane_fraction_model"] = {"so_rasterize_bwd": 0.393, "so_rasterize_fwd": 0.393, "source": "tools/passsim.py mcmc (profiles/r02_experiments.json)"}
-    json.dump(valu, open(os.path.join(dst, "valu.json"), "w"), indent=1)
-    print(valu)
+def collections(run, label):
+    """(traffic, valu, kernel_us) of one counter collection: `run` = its directory under gpurun_out/, `label` = the prefix of
+    its copies in profiles/"""
+    import csv
+    traffic = valu = ku = None
+    tp = os.path.join(dst, f"{label}_engine_pmc_traffic.json")
+    if os.path.exists(tp):
+        d = json.load(open(tp))
+        traffic = {k: d[v]["hbm_bytes_per_launch_corrected"] for k, v in names.items() if v in d}
+        traffic["_collected_at"] = collected_at(run, "pmc")
+        traffic["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profiles_%s.sh) of the bench command (c2, 8 ring "
+                            "views cycled), KB -> bytes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; source "
+                            "profiles/%s_engine_pmc_traffic.json" % (tag, label))
+    # the VALU side: wave-instructions and exec-mask lane cycles per launch (bench.py roofline.valu)
+    sqp = os.path.join(dst, f"{label}_engine_sq_counters.json")
+    if os.path.exists(sqp):
+        sq = json.load(open(sqp))
+        valu = {}
+        for k, v in names.items():
+            c = sq.get(v)
+            if c and "SQ_INSTS_VALU" in c:
+                valu[k] = {"wave_instructions": c["SQ_INSTS_VALU"], "waves": c.get("SQ_WAVES"),
+                           "active_lane_fraction": (c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+                                                    if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU") else None)}
+        valu["_collected_at"] = collected_at(run, "pmc")
+        valu["_note"] = ("rocprofv3 --pmc SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_THREAD_CYCLES_VALU (tools/gpu_profiles_%s.sh), means per launch of the "
+                         "bench command (c2); active_lane_fraction = exec-mask lanes per issued VALU instruction / 64; source "
+                         "profiles/%s_engine_sq_counters.json" % (tag, label))
+        # lanes that carry a contributing (pixel, Gaussian) pair in a pass of the rasteriser kernels: tools/passsim.py on the c2 front view
+        valu["_useful_lane_fraction_model"] = {"so_rasterize_bwd": 0.393, "so_rasterize_fwd": 0.393, "source": "tools/passsim.py mcmc (profiles/r02_experiments.json)"}
+    # rocprofv3's per-kernel averages of the bench command, keyed by entry point (bench.py roofline.kernel_us_rocprof)
+    ks = os.path.join(dst, f"{label}_engine_kernel_stats.csv")
+    if os.path.exists(ks):
+        rows = {r["Name"].split("(")[0]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(ks))}
+        ku = {k: round(rows[v], 2) for k, v in names.items() if v in rows}
+        ku["_collected_at"] = collected_at(run, "prof")
+        ku["_note"] = "rocprofv3 --kernel-trace --stats of the bench command, AverageNs per kernel; source profiles/%s_engine_kernel_stats.csv" % label
+    return traffic, valu, ku
 
-# rocprofv3's per-kernel averages of the bench command, keyed by entry point (bench.py roofline.kernel_us_rocprof)
-import csv
-ks = os.path.join(dst, f"{tag}_engine_kernel_stats.csv")
-if os.path.exists(ks):
-    rows = {r["Name"].split("(")[0]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(ks))}
-    ku = {k: round(rows[v], 2) for k, v in names.items() if v in rows}
-    ku["_collected_at"] = collected_at("prof")
-    ku["_note"] = "rocprofv3 --kernel-trace --stats of the default bench command, AverageNs per kernel; source profiles/%s_engine_kernel_stats.csv" % tag
-    json.dump(ku, open(os.path.join(dst, "kernel_us.json"), "w"), indent=1)
-    print(ku)
+
+main = collections(tag, tag)
+# a second collection at the round-end driver's command line (`--steps 20 --warmup 5`: RTAG=<tag>d tools/gpu_profiles_<tag>.sh):
+# kept under "_also"; bench.py uses whichever collection was made at (nearly) its own tile-intersection count
+also = None
+if os.path.isdir(os.path.join(src, tag + "d")):
+    for a, b in [(f"{tag}d/prof/**/bench_kernel_stats.csv", f"{tag}d_engine_kernel_stats.csv"),
+                 (f"{tag}d/pmc/traffic_summary.json", f"{tag}d_engine_pmc_traffic.json"),
+                 (f"{tag}d/pmc/sq_summary.json", f"{tag}d_engine_sq_counters.json"),
+                 (f"{tag}d/bench.json", f"{tag}d_engine_bench.json")]:
+        p = first(a)
+        if p:
+            shutil.copy(p, os.path.join(dst, b))
+            print("copied", os.path.relpath(p, ROOT), "->", b)
+    also = collections(tag + "d", tag + "d")
+for i, fname in enumerate(("traffic.json", "valu.json", "kernel_us.json")):
+    if main[i] is None:
+        continue
+    out = dict(main[i])
+    if also is not None and also[i] is not None:
+        out["_also"] = [also[i]]
+    json.dump(out, open(os.path.join(dst, fname), "w"), indent=1)
+    print(fname, {k: v for k, v in out.items() if not k.startswith("_")}, out.get("_collected_at"),
+          [c.get("_collected_at") for c in out.get("_also", [])])
