@@ -79,6 +79,8 @@ int so_debug_wave_reduce9(int n_waves, const float *in, float *out, void *stream
 /* test hook for the rasterisers' per-quadrant culling: in[n][10] = {mx, my, opacity, conic a, b, c, x0, x1, y0, y1}
  * -> out[n][2] = {box test, exact test} as 0 / 1 */
 int so_debug_cull(int64_t n, const float *in, float *out, void *stream);
+/* test hook: out[t] = so_bin_counter_index(t, M) as the DEVICE code evaluates it (t = 0 .. M-1) */
+int so_debug_bin_counter_index(int64_t M, int64_t *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * K1/K2  3D -> 2D EWA projection.   Replaces gsplat `fully_fused_projection` (legacy

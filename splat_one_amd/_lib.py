@@ -113,6 +113,7 @@ _SIGS = {
     "so_debug_wave_reduce": [c_int, c_ptr, c_ptr, c_ptr],
     "so_debug_wave_reduce9": [c_int, c_ptr, c_ptr, c_ptr],
     "so_debug_cull": [c_i64, c_ptr, c_ptr, c_ptr],
+    "so_debug_bin_counter_index": [c_i64, c_ptr, c_ptr],
     "so_isect_scan": [c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr],
     "so_preprocess_fwd": [c_int] * 4 + [c_ptr] * 8 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_int] + [c_ptr] * 10 + [c_i64, c_ptr, c_int, c_ptr, c_i64, c_ptr, c_ptr],
     "so_isect_sort_bins": [c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr],

@@ -85,6 +85,22 @@ extern "C" int so_debug_cull(int64_t n, const float *in, float *out, void *strea
   return so::check_launch("so_debug_cull");
 }
 
+namespace so {
+__global__ void k_debug_bin_counter_index(int64_t M, int64_t *__restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < M) out[t] = bin_counter_index(t, M);
+}
+}  // namespace so
+
+/* test hook: out[t] = where the DEVICE code keeps the binned count of tile t of M (so_common.hpp bin_counter_index: a float32
+ * quotient estimate put right exactly) -- must equal the host's so_bin_counter_index(t, M) for every t */
+extern "C" int so_debug_bin_counter_index(int64_t M, int64_t *out, void *stream) {
+  SO_REQUIRE(M >= 0 && (M == 0 || out), "so_debug_bin_counter_index: bad arguments");
+  if (M == 0) return SO_OK;
+  hipLaunchKernelGGL(so::k_debug_bin_counter_index, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, so::as_stream(stream), M, out);
+  return so::check_launch("so_debug_bin_counter_index");
+}
+
 /* in[n_waves*64, 9] -> out[n_waves, 10] (zeroed by the caller): slots 0..7 += transposing butterfly
  * row sums of columns 0..7, 8 += row sums of column 8, 9 = wave sum of column 8 (row_bcast DPP form). */
 extern "C" int so_debug_wave_reduce(int n_waves, const float *in, float *out, void *stream) {

@@ -175,6 +175,24 @@ def test_isect_every_sort_path_boundary(dev):
         assert torch.equal(ids_h.cpu(), ids_o), N
 
 
+def test_bin_counter_placement_device_equals_host(dev):
+    """The device evaluates (run * 1031) mod runs with a float32 quotient estimate and an exact correction
+    (so_common.hpp bin_counter_index); the host with integer arithmetic (so_bin_counter_index).  Equal for every tile of
+    every grid tried -- tiny, odd, the 1080p / 1440p / 4K grids, several views, a run count that 1031 divides, the largest
+    the spread applies to."""
+    from splat_one_amd import _lib
+    f = _lib.load().so_bin_counter_index
+    for M in (1, 2, 3, 7, 64, 77, 510, 2062, 8160, 8161, 14400, 32400, 8 * 8160, 2 * 1031 * 7, (1 << 22) - 2, (1 << 22) + 6):
+        out = torch.empty(M, dtype=torch.int64, device=dev)
+        _lib.call("so_debug_bin_counter_index", M, _lib.ptr(out), _lib.stream())
+        got = out.cpu()
+        step = max(1, M // 50_000)                                  # (the host side is a Python loop: sample the largest grids)
+        ts = list(range(0, M, step)) + [M - 1]
+        want = torch.tensor([f(t, M) for t in ts])
+        assert torch.equal(got[ts], want), M
+        assert torch.equal(torch.sort(got).values, torch.arange(M)), M      # a bijection on the device too
+
+
 def test_isect_long_lists(dev):
     """Lists longer than the small (2048) and the large (16384) LDS sort capacities: one section of the long-list kernel,
     exactly one, one key more, two and three sections (sorted in LDS section by section, merged by rank)."""
