@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SO_ABI_VERSION 1
+#define SO_ABI_VERSION 2
 
 enum so_status {
   SO_OK = 0,

@@ -161,6 +161,10 @@ _SIGS = {
                             c_f32, c_ptr],
 }
 
+# include/splat_one_amd.h SO_ABI_VERSION: raised whenever an entry point's signature changes (2: so_step_inputs gained
+# n_lists / lists_stat), so that a stale library against newer bindings fails at load instead of shifting arguments
+ABI_VERSION = 2
+
 _lib: Optional[ctypes.CDLL] = None
 
 
@@ -198,7 +202,8 @@ def load() -> ctypes.CDLL:
             fn = getattr(lib, name)
             fn.argtypes = argtypes
             fn.restype = c_int
-        assert lib.so_abi_version() == 1, "ABI version mismatch"
+        assert lib.so_abi_version() == ABI_VERSION, (f"{LIB_PATH} has ABI version {lib.so_abi_version()}, these bindings are written for "
+                                                      f"{ABI_VERSION}: rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
         _lib = lib
     return _lib
 

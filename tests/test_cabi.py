@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_channel():
     lib = _lib.load()
-    assert lib.so_abi_version() == 1
+    assert lib.so_abi_version() == _lib.ABI_VERSION == 2
     # invalid arguments are rejected before any HIP call (works without a GPU)
     with pytest.raises(RuntimeError, match="degrees_to_use"):
         _lib.call("so_sh_fwd", 1, 4, 16, 9, 0, 0, 0, 0, 0, 0)
