@@ -262,9 +262,54 @@ __device__ __forceinline__ void write_sorted(uint64_t key, int64_t pos, int64_t 
 // tail), the classic xor-partner bitonic network runs on ds_bpermute shuffles -- no LDS array, no
 // barrier.  Short lists dominate trained-like scenes (mean ~40 keys per tile on the c2 workload, ~150 at
 // 1M Gaussians / 1440p).
+// The value lane (l ^ J) holds, without the LDS crossbar (end of round 4; until then __shfl_xor = ds_bpermute: 1 200 of them in
+// the long-list kernel, each a round trip through LDS that a wave sorting ONE list has nothing to hide behind).  J = 1, 2, 8:
+// one DPP move (quad_perm, row_ror:8 -- a rotation by half a row IS the exchange of its halves); J = 4: two DPP moves with
+// bank masks (quads 0, 2 take lane + 4, quads 1, 3 take lane - 4); J = 16, 32: v_permlane16/32_swap of two copies leaves the
+// even rows (lower half-wave) of the value in one register and the odd ones in the other, twice each -- `upper` = (l & J) != 0
+// picks.  Inline asm for the swaps (so_common.hpp rows_combine: the builtin's struct return is miscompiled; the s_nop's are
+// the wait states around a cross-lane read).  EXEC must be all ones: every caller runs whole waves.
+template <int J>
+__device__ __forceinline__ uint32_t lane_xor_u32(uint32_t x, bool upper) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (J == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xf, 0xf, true);          // quad_perm:[1,0,3,2]
+  else if constexpr (J == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xf, 0xf, true);     // quad_perm:[2,3,0,1]
+  else if constexpr (J == 4) {
+    const int r = __builtin_amdgcn_update_dpp((int)x, (int)x, 0x104, 0xf, 0x5, false);                       // row_shl:4 into quads 0, 2
+    return (uint32_t)__builtin_amdgcn_update_dpp(r, (int)x, 0x114, 0xf, 0xa, false);                         // row_shr:4 into quads 1, 3
+  } else if constexpr (J == 8) return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x128, 0xf, 0xf, true);   // row_ror:8
+  else {
+    uint32_t a = x, b = x;
+    if constexpr (J == 16) asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    else asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return upper ? a : b;
+  }
+#else
+  (void)upper;
+  return x;
+#endif
+}
+// m in {1, 2, 4, 8, 16, 32}, a constant wherever the sort networks call it (their loops are fully unrolled)
 __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
-  const uint32_t lo = __shfl_xor((uint32_t)v, m, 64), hi = __shfl_xor((uint32_t)(v >> 32), m, 64);
-  return ((uint64_t)hi << 32) | lo;
+  const int lane = lane_id();
+  const bool upper = (lane & m) != 0;
+  const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  uint32_t olo, ohi;
+  switch (m) {
+    case 1: olo = lane_xor_u32<1>(lo, upper); ohi = lane_xor_u32<1>(hi, upper); break;
+    case 2: olo = lane_xor_u32<2>(lo, upper); ohi = lane_xor_u32<2>(hi, upper); break;
+    case 4: olo = lane_xor_u32<4>(lo, upper); ohi = lane_xor_u32<4>(hi, upper); break;
+    case 8: olo = lane_xor_u32<8>(lo, upper); ohi = lane_xor_u32<8>(hi, upper); break;
+#if defined(SO_SORT_PERMLANE)
+    case 16: olo = lane_xor_u32<16>(lo, upper); ohi = lane_xor_u32<16>(hi, upper); break;
+    default: olo = lane_xor_u32<32>(lo, upper); ohi = lane_xor_u32<32>(hi, upper); break;
+#else
+    // across rows the crossbar stays: the swap form costs two copies, the swap, its wait states and a select per half --
+    // five vector instructions where ds_bpermute is one LDS instruction (measured: dense regime sort 72 -> 75.5 us with it)
+    default: olo = (uint32_t)__shfl_xor((int)lo, m, 64); ohi = (uint32_t)__shfl_xor((int)hi, m, 64); break;
+#endif
+  }
+  return ((uint64_t)ohi << 32) | olo;
 }
 
 // E elements per lane (element index = lane + 64 e): up to 64 E keys sorted by ONE wave in registers.  Steps with
@@ -373,6 +418,26 @@ __device__ __forceinline__ void bitonic_merge_runs_shared(uint64_t *keys, int n)
   }
 }
 
+// Four INDEPENDENT sequences of up to 64 keys, one per register element (element e of lane l = key l of sequence e), sorted
+// side by side: the 21 shuffle steps of the 64-key network, each issued for the four sequences back to back so that their
+// ds_bpermute round trips overlap (one sequence at a time, a wave waits out every round trip on its own).
+__device__ __forceinline__ void wave_bitonic_sort_4x64(uint64_t (&v)[4], int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j >= 1; j >>= 1) {
+      const bool upper = (lane & j) != 0;
+      const bool asc = (lane & k) == 0 || k == 64;
+      const bool take_min = (asc != upper);
+      uint64_t o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = shfl_xor_u64(v[e], j);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = take_min ? (v[e] < o[e] ? v[e] : o[e]) : (v[e] < o[e] ? o[e] : v[e]);
+    }
+  }
+}
+
 template <int E>
 __device__ __forceinline__ void wave_sort_list(const uint64_t *__restrict__ key_buf, int64_t lo, int L, int lane, int64_t t,
                                                int n_tiles, int tile_bits, int32_t *flatten_ids, int64_t *isect_ids) {
@@ -429,6 +494,16 @@ __device__ __forceinline__ void sort_mid_chunks(uint64_t *s_keys, const uint64_t
   __syncthreads();
 }
 
+// The work list of long tiles: *long_count = number of entries in bits 0..29; bit 30 = "some tile holds more than one section
+// of kLongSection keys" -- only then has the rank-merge pass of k_tile_sort_long anything to do, and it costs 28 us just to
+// walk the list and find that out.
+constexpr int kLongSection = 16384;
+constexpr int32_t kLongMerge = 1 << 30;
+__device__ __forceinline__ void push_long_tile(int32_t *long_list, int32_t *long_count, int64_t t, int64_t L) {
+  long_list[atomicAdd(long_count, 1) & (kLongMerge - 1)] = (int32_t)t;
+  if (L > kLongSection) atomicOr(long_count, kLongMerge);
+}
+
 // LDS sort for lists with L <= CAP (CAP keys of 8 B in LDS); longer lists are appended to the
 // work list (long_list[0..*long_count)) for k_tile_sort_long.
 template <int THREADS, int CAP>
@@ -443,7 +518,7 @@ k_tile_sort_lds(int64_t M, int n_tiles, int tile_bits, const int32_t *__restrict
     tile_range(t, M, offsets, n_isects, capacity, lo, hi);
     const int64_t L = hi - lo;
     if (L > CAP) {
-      if (threadIdx.x == 0) long_list[atomicAdd(long_count, 1)] = (int32_t)t;
+      if (threadIdx.x == 0) push_long_tile(long_list, long_count, t, L);
       continue;
     }
     if (L <= 0) continue;
@@ -483,7 +558,7 @@ k_tile_sort_waves(int64_t M, int n_tiles, int tile_bits, const int32_t *__restri
     const int64_t L = hi - lo;
     if (lane == 0) s_mid[wave] = (L > 256 && L <= CAP) ? 1 : 0;
     if (L > CAP) {
-      if (lane == 0) long_list[atomicAdd(long_count, 1)] = (int32_t)t;
+      if (lane == 0) push_long_tile(long_list, long_count, t, L);
     } else if (L > 0 && L <= 256) {
       if (L <= 64) wave_sort_list<1>(key_buf, lo, (int)L, lane, t, n_tiles, tile_bits, flatten_ids, isect_ids);
       else if (L <= 128) wave_sort_list<2>(key_buf, lo, (int)L, lane, t, n_tiles, tile_bits, flatten_ids, isect_ids);
@@ -501,6 +576,199 @@ k_tile_sort_waves(int64_t M, int n_tiles, int tile_bits, const int32_t *__restri
     }
     __syncthreads();                              // s_mid is rewritten by the next group
   }
+}
+
+// The flip-form network on n keys of an LDS sub-array, in place, any n (keys past n behave as +inf): the fall-back for one
+// oversized bucket of sort_section_buckets (every thread of the workgroup calls it).
+template <int THREADS>
+__device__ __forceinline__ void bitonic_sort_ragged_shared(uint64_t *keys, int n) {
+  int lnp2 = 0;
+  while ((1 << lnp2) < n) ++lnp2;
+  const int half = (1 << lnp2) >> 1;
+  for (int lk = 1; lk <= lnp2; ++lk) {
+    const int k = 1 << lk, hk = k >> 1;
+    for (int i = threadIdx.x; i < half; i += THREADS) {  // flip
+      const int blk = i >> (lk - 1), off = i & (hk - 1);
+      const int a = (blk << lk) + off, b = (blk << lk) + k - 1 - off;
+      if (b < n) {
+        const uint64_t ka = keys[a], kb = keys[b];
+        if (ka > kb) { keys[a] = kb; keys[b] = ka; }
+      }
+    }
+    __syncthreads();
+    for (int lj = lk - 2; lj >= 0; --lj) {  // disperse
+      const int j = 1 << lj;
+      for (int i = threadIdx.x; i < half; i += THREADS) {
+        const int a = ((i >> lj) << (lj + 1)) + (i & (j - 1)), b = a + j;
+        if (b < n) {
+          const uint64_t ka = keys[a], kb = keys[b];
+          if (ka > kb) { keys[a] = kb; keys[b] = ka; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// One section (<= 16384 keys) of a long list, sorted by DEPTH BUCKETS (end of round 4).  The merge network spends n log^2 n
+// 64-bit compare-exchanges (a 12 500-key section: ~125 us, issue-bound); here the keys are dealt into up to 448 buckets by a
+// monotone map of the depth word (same depth -> same bucket, larger -> same or later bucket), each bucket -- ~42 keys -- is
+// sorted by ONE wave in registers on the full 64-bit key, and the buckets are already in order: ~5x fewer instructions.
+//   A  minimum / maximum depth of the section                       (keys read from global memory; they are L2-resident)
+//   B  histogram of the buckets (LDS atomics)          C  exclusive scan (one wave)
+//   D  keys re-read and scattered to their bucket's range of s_keys (returning LDS atomics: order inside a bucket is arbitrary)
+//   E  every wave sorts four buckets at a time side by side in registers (a bucket of 65 .. 256 keys: on its own, two or four
+//      registers per lane) and emits them at bucket base + rank
+//   F  a bucket with more than 256 keys (many equal depths, a depth distribution with a spike): the ragged network on its
+//      range of s_keys, by the whole workgroup, then emitted
+// Same result as any correct sort of the distinct 64-bit keys.  emit(position in the section, key).
+constexpr int kSortBuckets = 512;
+template <int THREADS, class Emit>
+__device__ __forceinline__ void sort_section_buckets(uint64_t *s_keys, const uint64_t *keys, int sn, Emit emit) {
+  __shared__ int32_t s_cnt[kSortBuckets], s_base[kSortBuckets], s_cur[kSortBuckets];
+  __shared__ uint32_t s_lohi[2][THREADS / 64];
+  __shared__ int32_t s_big[kSortBuckets], s_nbig;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // ~42 keys per bucket on average (a multiple of 64 buckets, 448 at most): the 64-lane sequences of the register sort are
+  // two thirds full and a Poisson-like fill passes 64 in one bucket of 10^3
+  const int nb = 64 * ((sn + 64 * 42 - 1) / (64 * 42));
+  // A (the section's keys stay in registers for B and D: sixteen loads per thread in flight at once, not three walks over
+  // global memory with a round trip per key)
+  static_assert(THREADS * 16 >= 16384, "sixteen keys per thread cover a section");
+  uint64_t kreg[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) kreg[j] = tid + THREADS * j < sn ? keys[tid + THREADS * j] : ~0ull;
+  uint32_t dlo = 0xffffffffu, dhi = 0u;
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (tid + THREADS * j < sn) {
+      const uint32_t d = (uint32_t)(kreg[j] >> 32);
+      dlo = d < dlo ? d : dlo;
+      dhi = d > dhi ? d : dhi;
+    }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const uint32_t ol = (uint32_t)__shfl_xor((int)dlo, m, 64), oh = (uint32_t)__shfl_xor((int)dhi, m, 64);
+    dlo = ol < dlo ? ol : dlo;
+    dhi = oh > dhi ? oh : dhi;
+  }
+  if (lane == 0) { s_lohi[0][wave] = dlo; s_lohi[1][wave] = dhi; }
+  for (int i = tid; i < kSortBuckets; i += THREADS) s_cnt[i] = 0;
+  if (tid == 0) s_nbig = 0;
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < THREADS / 64; ++w) {
+    dlo = s_lohi[0][w] < dlo ? s_lohi[0][w] : dlo;
+    dhi = s_lohi[1][w] > dhi ? s_lohi[1][w] : dhi;
+  }
+  // the order wanted is that of the 64-bit keys, i.e. of the depth's BIT PATTERN as an unsigned integer: the map works on
+  // that integer (difference to the minimum -> float -> scaled -> truncated: every step monotone, whatever its rounding)
+  const float scale = dhi > dlo ? (float)nb / (float)(dhi - dlo) : 0.f;
+  auto bucket_of = [&](uint64_t key) {
+    const int b = (int)((float)((uint32_t)(key >> 32) - dlo) * scale);
+    return b >= nb ? nb - 1 : b;
+  };
+  // B
+#if defined(SO_SORT_ABL) && SO_SORT_ABL >= 3
+  if (false)
+#endif
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (tid + THREADS * j < sn) atomicAdd(&s_cnt[bucket_of(kreg[j])], 1);
+  __syncthreads();
+  // C (one wave: nb / 64 counts per lane)
+  if (wave == 0) {
+    const int per = nb >> 6;                       // 1 .. 6
+    int mine = 0;
+    for (int j = 0; j < per; ++j) mine += s_cnt[lane * per + j];
+    int sc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(sc, d, 64);
+      if (lane >= d) sc += o;
+    }
+    int run = sc - mine;
+    for (int j = 0; j < per; ++j) {
+      const int b = lane * per + j;
+      s_base[b] = run;
+      s_cur[b] = run;
+      run += s_cnt[b];
+    }
+  }
+  __syncthreads();
+  // D
+#if defined(SO_SORT_ABL) && SO_SORT_ABL >= 2
+  if (false)
+#endif
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (tid + THREADS * j < sn) s_keys[atomicAdd(&s_cur[bucket_of(kreg[j])], 1)] = kreg[j];
+  __syncthreads();
+  // E (a wave takes four neighbouring buckets at a time: all four small -- the rule -- go through the side-by-side sort.
+  // Joining neighbouring buckets into fuller 64-key segments first -- buckets are in key order, so that is allowed -- was
+  // tried: the greedy cut is a serial walk over the bucket counts, 25 us per section for one lane, more than it saves.)
+  const int nseg = nb;
+  const int32_t *s_seg = s_base, *s_seglen = s_cnt;
+#if defined(SO_SORT_ABL) && SO_SORT_ABL >= 1   // ablation builds (timing only, WRONG lists): 1 = no bucket sorts, 2 = no scatter either, 3 = nothing
+  if (false)
+#endif
+  for (int g0 = 4 * wave; g0 < nseg; g0 += 4 * (THREADS / 64)) {
+    int cnt4[4], base4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { cnt4[e] = g0 + e < nseg ? s_seglen[g0 + e] : 0; base4[e] = g0 + e < nseg ? s_seg[g0 + e] : 0; }
+    if (cnt4[0] <= 64 && cnt4[1] <= 64 && cnt4[2] <= 64 && cnt4[3] <= 64) {
+      uint64_t v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = lane < cnt4[e] ? s_keys[base4[e] + lane] : ~0ull;
+#if !defined(SO_SORT_SKIP_SORT4)
+      wave_bitonic_sort_4x64(v, lane);
+#endif
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (lane < cnt4[e]) emit(base4[e] + lane, v[e]);
+      continue;
+    }
+    for (int e4 = 0; e4 < 4; ++e4) {
+      const int cnt = cnt4[e4], base = base4[e4];
+      if (cnt == 0) continue;
+      if (cnt <= 64) {
+        uint64_t v[1] = {lane < cnt ? s_keys[base + lane] : ~0ull};
+        wave_bitonic_sort<1>(v, lane);
+        if (lane < cnt) emit(base + lane, v[0]);
+      } else if (cnt <= 128) {
+        uint64_t v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) v[e] = lane + 64 * e < cnt ? s_keys[base + lane + 64 * e] : ~0ull;
+        wave_bitonic_sort<2>(v, lane);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          if (lane + 64 * e < cnt) emit(base + lane + 64 * e, v[e]);
+      } else if (cnt <= 256) {
+        uint64_t v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = lane + 64 * e < cnt ? s_keys[base + lane + 64 * e] : ~0ull;
+        wave_bitonic_sort<4>(v, lane);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (lane + 64 * e < cnt) emit(base + lane + 64 * e, v[e]);
+      } else if (lane == 0) {
+        s_big[atomicAdd(&s_nbig, 1)] = g0 + e4;
+      }
+    }
+  }
+  __syncthreads();
+  // F
+#if defined(SO_SORT_SKIP_F)
+  const int nbig = 0;
+#else
+  const int nbig = s_nbig;
+#endif
+  for (int k = 0; k < nbig; ++k) {
+    const int g = s_big[k], cnt = s_seglen[g], base = s_seg[g];
+    bitonic_sort_ragged_shared<THREADS>(s_keys + base, cnt);
+    for (int i = tid; i < cnt; i += THREADS) emit(base + i, s_keys[base + i]);
+  }
+  __syncthreads();                                  // s_keys and the bucket tables are rewritten by the next section
 }
 
 // Long lists (work list built by k_tile_sort_lds): a fixed grid walks the list, so the launches cost next to nothing when no
@@ -526,7 +794,10 @@ k_tile_sort_long(int64_t M, int n_tiles, int tile_bits, const int32_t *__restric
   static_assert(CAP % 256 == 0 && THREADS % 64 == 0 && THREADS <= 1024, "whole runs, whole waves");
   __shared__ int32_t s_wave_sums[THREADS / 64];
   __shared__ int32_t s_pick[2];
-  const int n_long = *long_count;
+  static_assert(CAP == kLongSection, "the merge flag is set against kLongSection");
+  const int32_t packed = *long_count;
+  const int n_long = packed & (kLongMerge - 1);
+  if (MERGE && !(packed & kLongMerge)) return;     // no tile of several sections: nothing to merge
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   int first = (int)blockIdx.x;          // this workgroup's first section of the current batch of THREADS long tiles
   for (int w0 = 0; w0 < n_long; w0 += THREADS) {
@@ -569,26 +840,13 @@ k_tile_sort_long(int64_t M, int n_tiles, int tile_bits, const int32_t *__restric
       const int64_t s0 = (int64_t)sec * CAP;
       const int sn = (int)(n - s0 < CAP ? n - s0 : CAP);
       if constexpr (!MERGE) {
-        const int nch = (sn + 255) >> 8;
-        for (int c = wave; c < nch; c += THREADS / 64) {
-          uint64_t v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int i = 256 * c + lane + 64 * e;
-            v[e] = i < sn ? keys[s0 + i] : ~0ull;          // the last run's tail: +inf, sorts behind every key
-          }
-          wave_bitonic_sort<4>(v, lane);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) s_keys[256 * c + lane + 64 * e] = v[e];
-        }
-        __syncthreads();
-        bitonic_merge_runs_shared<THREADS>(s_keys, 256 * nch);
-        if (nsec_t == 1) {
-          for (int i = tid; i < sn; i += THREADS) write_sorted(s_keys[i], lo + i, t, n_tiles, tile_bits, flatten_ids, isect_ids);
-        } else {
-          for (int i = tid; i < sn; i += THREADS) keys[s0 + i] = s_keys[i];
-        }
-        __syncthreads();
+        // (until the end of round 4: runs of 256 keys sorted in registers + bitonic_merge_runs_shared over the section)
+        if (nsec_t == 1)
+          sort_section_buckets<THREADS>(s_keys, keys + s0, sn, [&](int pos, uint64_t key) {
+            write_sorted(key, lo + pos, t, n_tiles, tile_bits, flatten_ids, isect_ids);
+          });
+        else
+          sort_section_buckets<THREADS>(s_keys, keys + s0, sn, [&](int pos, uint64_t key) { keys[s0 + pos] = key; });
       } else {
         constexpr int U = 4;                               // searches in flight per thread
         for (int i0 = tid * U; i0 < sn; i0 += THREADS * U) {

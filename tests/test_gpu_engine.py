@@ -198,6 +198,30 @@ def test_engine_survives_intersection_overflow(dev, binned):
     assert e_auto.void_steps == 0 and (e_auto.bin_capacity > 16 if binned else e_auto.capacity > 1024)
 
 
+def test_engine_long_binned_lists_equal_the_operator_lists(dev):
+    """Tiles with thousands of Gaussians (gathered clouds, large scenes): the engine's binned lists -- keys in arrival order,
+    sorted by the long-list kernel's depth buckets -- equal the operator path's compact lists of the same scene entry for
+    entry (gsplat's order: depth, then Gaussian id), and the step trains without a void iteration."""
+    from splat_one_amd.engine import FusedEngine
+    from splat_one_amd.rendering import rasterization
+    N, W, H = 14000, 48, 48
+    r, c2w, Ks, pixels = _make(dev, N, W, H, "ref")
+    eng = FusedEngine(r.splats, r.optimizers, W, H, 1, sh_degree=3, use_graph=False, tile_cull=False)
+    eng.set_views(c2w, Ks, pixels)
+    eng.fwd_bwd()
+    st = eng.stats()
+    offs, ids = eng.tile_lists()
+    lens = [b - a for a, b in zip(offs[:-1], offs[1:])]
+    assert st["overflow"] == 0 and max(lens) > 4096 and sum(1 for n in lens if n > 2048) >= 4, lens
+    sp = r.splats
+    with torch.no_grad():
+        _, _, info = rasterization(sp["means"], sp["quats"], torch.exp(sp["scales"]), torch.sigmoid(sp["opacities"]),
+                                   torch.cat([sp["sh0"], sp["shN"]], 1), torch.linalg.inv(c2w), Ks, W, H, sh_degree=3,
+                                   near_plane=0.01, far_plane=1e8, packed=False, tile_cull=False)
+    assert torch.equal(info["flatten_ids"].cpu(), ids.cpu())
+    assert info["isect_offsets"].reshape(-1).cpu().tolist() == offs[:-1]
+
+
 @pytest.mark.parametrize("regime,C,aa,binned", [("ref", 1, False, True), ("mcmc", 2, True, True), ("ref", 1, False, False)])
 def test_engine_tile_cull_is_exact(dev, regime, C, aa, binned):
     """Exact tile culling drops (Gaussian, tile) pairs that cannot reach alpha = 1/255 at any pixel of the tile:

@@ -210,6 +210,38 @@ def test_isect_long_lists(dev):
         assert torch.equal(ids_h.cpu(), ids_o), N
 
 
+@pytest.mark.parametrize("dist", ["uniform", "all_equal", "two_values", "spike", "heavy_tail", "tiny_range"])
+def test_isect_long_lists_by_depth_buckets(dev, dist):
+    """The long-list kernel deals a section's keys into depth buckets, sorts each bucket in registers and falls back to a
+    network for a bucket of more than 256 keys: bit-identical lists whatever the depths look like -- evenly spread, ALL equal
+    (one bucket holds the whole section: the order is by Gaussian id alone), two values, a spike of equal depths inside a
+    spread, a heavy tail (most buckets empty), a range of a few ulps -- at sizes on both sides of the bucket-count steps
+    (4096 / 8192), of one section (16384) and with a ragged second section."""
+    from splat_one_amd.ops import isect_tiles
+    g = torch.Generator().manual_seed(11)
+    for N in (2049, 4096, 4097, 8192, 8200, 16384, 21000):
+        m2 = torch.rand(1, N, 2, generator=g) * 8 + 4          # all inside tile (0,0) of a 16x16 image
+        radii = torch.ones(1, N, dtype=torch.int32)
+        u = torch.rand(1, N, generator=g)
+        if dist == "uniform":
+            dep = 0.5 + 7.0 * u
+        elif dist == "all_equal":
+            dep = torch.full((1, N), 3.25)
+        elif dist == "two_values":
+            dep = torch.where(u < 0.3, torch.tensor(2.0), torch.tensor(9.5))
+        elif dist == "spike":
+            dep = torch.where(u < 0.4, torch.tensor(4.0), 0.5 + 7.0 * torch.rand(1, N, generator=g))
+        elif dist == "heavy_tail":
+            dep = 0.2 + torch.exp(12.0 * u * u * u)
+        else:
+            dep = 5.0 + (torch.randint(0, 9, (1, N), generator=g).float() * 4.76837158203125e-07)   # 9 neighbouring float32 values
+        _, ids_o, flat_o = O.isect_tiles(m2, radii, dep, 16, 1, 1)
+        _, ids_h, flat_h = isect_tiles(m2.to(dev), radii.to(dev), dep.to(dev), 16, 1, 1)
+        assert ids_o.numel() == N
+        assert torch.equal(flat_h.cpu(), flat_o), (dist, N)
+        assert torch.equal(ids_h.cpu(), ids_o), (dist, N)
+
+
 @pytest.mark.parametrize("tile_size,D,with_bg,W,H,scale", [
     (16, 3, False, 200, 120, 0.25), (16, 3, True, 70, 50, 1.0), (16, 4, True, 64, 64, 0.5),
     (8, 3, False, 100, 60, 0.2), (16, 1, False, 64, 48, 0.5), (16, 7, True, 48, 48, 0.5)])
