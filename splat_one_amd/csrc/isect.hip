@@ -841,12 +841,12 @@ k_tile_sort_long(int64_t M, int n_tiles, int tile_bits, const int32_t *__restric
       const int sn = (int)(n - s0 < CAP ? n - s0 : CAP);
       if constexpr (!MERGE) {
         // (until the end of round 4: runs of 256 keys sorted in registers + bitonic_merge_runs_shared over the section)
-        if (nsec_t == 1)
-          sort_section_buckets<THREADS>(s_keys, keys + s0, sn, [&](int pos, uint64_t key) {
-            write_sorted(key, lo + pos, t, n_tiles, tile_bits, flatten_ids, isect_ids);
-          });
-        else
-          sort_section_buckets<THREADS>(s_keys, keys + s0, sn, [&](int pos, uint64_t key) { keys[s0 + pos] = key; });
+        // (ONE instantiation for both destinations: the function's bucket tables are static LDS arrays)
+        const bool only_section = nsec_t == 1;
+        sort_section_buckets<THREADS>(s_keys, keys + s0, sn, [&](int pos, uint64_t key) {
+          if (only_section) write_sorted(key, lo + pos, t, n_tiles, tile_bits, flatten_ids, isect_ids);
+          else keys[s0 + pos] = key;
+        });
       } else {
         constexpr int U = 4;                               // searches in flight per thread
         for (int i0 = tid * U; i0 < sn; i0 += THREADS * U) {
