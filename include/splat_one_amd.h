@@ -705,7 +705,9 @@ int so_inject_noise(int64_t N, float *means, const float *log_scales, const floa
  * so_inject_noise_dev: `inject_noise_to_position` of EVERY iteration with the normals drawn on the device from (seed,
  *   step_counter[0], row) and the scale lr * noise_lr evaluated there too, lr = lr0 * lr_gamma^step_counter[0] (the means'
  *   ExponentialLR value after this iteration's optimiser step: step_counter is so_adam_step_dev's) -- constant launch
- *   arguments, hipGraph-capturable behind the optimiser.  n_dev nullable (N = capacity); skip_if_nonzero nullable. */
+ *   arguments, hipGraph-capturable behind the optimiser.  n_dev nullable (N = capacity); skip_if_nonzero nullable: ONE
+ *   4-byte device word tested for any set bit -- an int32 flag, or the float32 void flag a gradient reduce-scatter summed
+ *   over the ranks (+0.0f is all-zero bits; a sum of 0 / 1 flags is never -0.0f). */
 typedef struct so_mcmc_params {
   float min_opacity;
   int32_t cap_max;

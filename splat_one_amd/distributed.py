@@ -190,7 +190,7 @@ class _PhaseTimer:
         self.marks = []
 
 
-def agree_on_coalescing(probe: Callable[[], None], device, group=None) -> str:
+def agree_on_coalescing(probe: Callable[[], None], device, group=None, trial: Optional[Callable[[], None]] = None) -> str:
     """"coalesced" if `probe()` succeeds on EVERY rank, else "per_tensor" (one async reduce_scatter_tensor /
     all_gather_into_tensor per tensor, public API).  `probe` looks at rank-LOCAL things only -- does torch's PRIVATE
     `dist._coalescing_manager` exist, can it be entered and left with nothing inside -- and must NOT issue a collective
@@ -209,6 +209,21 @@ def agree_on_coalescing(probe: Callable[[], None], device, group=None) -> str:
     flag = torch.tensor([ok], dtype=torch.int32, device=device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
     mode = "coalesced" if int(flag.item()) else "per_tensor"
+    if mode == "coalesced" and trial is not None:
+        # Second phase: every rank is known to be here, in step.  ONE tiny grouped reduce-scatter + all-gather on
+        # scratch tensors -- including the in-place `reduce_scatter_tensor(f[r], f)` form the void flags use -- so that a torch /
+        # RCCL build that cannot group these calls is found out NOW and not in the middle of the first step's grouped
+        # collective over the gradient buffers; then a second all_reduce(MIN).  (A build that cannot raises when the call is
+        # made, on every rank alike; the forced failure of the tests raises before the rank has joined anything.)
+        try:
+            if forced == "trial" or (forced.startswith("trial:") and int(forced[6:]) == dist.get_rank(group)):
+                raise RuntimeError("forced failure of the trial grouped collective (SPLAT_ONE_AMD_FORCE_COALESCE_FAIL)")
+            trial()
+        except Exception as e:   # noqa: BLE001
+            ok, why = 0, repr(e)
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        mode = "coalesced" if int(flag.item()) else "per_tensor"
     if mode == "per_tensor":
         import warnings
         warnings.warn("splat_one_amd: grouped collectives (dist._coalescing_manager) are not usable "
@@ -225,6 +240,30 @@ def probe_coalescing_locally(group=None) -> None:
         raise RuntimeError("torch.distributed._coalescing_manager does not exist in this torch")
     with cm(group=group, async_ops=True):
         pass
+
+
+def trial_grouped_collectives(device, group=None) -> None:
+    """Second half of `agree_on_coalescing` (RCCL only; called by every rank after the first vote said "coalesced"): one
+    grouped reduce-scatter (two tensors, the second one in place inside its own input as the void flags are) and one grouped
+    all-gather on 64-float scratch pieces, waited for and checked.  Raises if this torch / RCCL build cannot do that."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    a = torch.full((world * 16,), 1.0, dtype=torch.float32, device=device)
+    f = torch.full((world * 16,), 2.0, dtype=torch.float32, device=device)
+    out = torch.zeros(16, dtype=torch.float32, device=device)
+    with dist._coalescing_manager(group=group, async_ops=True) as cm:
+        dist.reduce_scatter_tensor(out, a, op=dist.ReduceOp.SUM, group=group)
+        dist.reduce_scatter_tensor(f[rank * 16:(rank + 1) * 16], f, op=dist.ReduceOp.SUM, group=group)
+    cm.wait()
+    g = torch.zeros(world * 16, dtype=torch.float32, device=device)
+    g[rank * 16:(rank + 1) * 16] = float(rank + 1)
+    with dist._coalescing_manager(group=group, async_ops=True) as cm:
+        dist.all_gather_into_tensor(g, g[rank * 16:(rank + 1) * 16], group=group)
+        dist.all_gather_into_tensor(a, out, group=group)
+    cm.wait()
+    want = torch.arange(1, world + 1, dtype=torch.float32, device=device).repeat_interleave(16)
+    if not (torch.equal(g, want) and bool((out == float(world)).all()) and bool((f[rank * 16:(rank + 1) * 16] == 2.0 * world).all())
+            and bool((a == float(world)).all())):
+        raise RuntimeError("grouped reduce_scatter_tensor / all_gather_into_tensor returned wrong values")
 
 
 class RowShardedAdam:
@@ -277,7 +316,8 @@ class RowShardedAdam:
                 self.mode = "coalesced"
             else:
                 probe = (lambda: probe_coalescing_locally(self.group)) if self.backend == "nccl" else (lambda: None)
-                self.mode = agree_on_coalescing(probe, device if self.backend == "nccl" else "cpu", self.group)
+                trial = (lambda: trial_grouped_collectives(device, self.group)) if self.backend == "nccl" else None
+                self.mode = agree_on_coalescing(probe, device if self.backend == "nccl" else "cpu", self.group, trial)
         return self.mode
 
     def comm_ms(self) -> Optional[dict]:

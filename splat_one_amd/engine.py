@@ -134,6 +134,7 @@ class FusedEngine:
         # caller decides from the flag summed over all ranks and calls take_back() on every rank (Runner._dp_check_void)
         self.on_overflow = "grow"
         self._local_overflow_seen = 0
+        self._compact_pending = False    # a deferred overflow happened with the bins at their limit: take_back falls back to compact lists
         self.void_steps = 0              # iterations discarded because the binning pass overflowed
         self.fell_back_to_compact = False
         if self.device_refine:
@@ -300,17 +301,21 @@ class FusedEngine:
             self._host_stale = True
             self.refresh_attrs()
 
-    def inject_noise(self) -> None:
+    def inject_noise(self, skip: Optional[Tensor] = None) -> None:
         """MCMCStrategy's position noise of this iteration (gsplat `inject_noise_to_position`, scaler = lr * noise_lr with
         the means' learning rate AFTER this iteration's scheduler step): normals and learning rate on the device, constant
-        launch arguments, skipped by itself when the iteration was void."""
+        launch arguments, skipped by itself when the iteration was void.  `skip`: the 4-byte device word that says so -- by
+        default this engine's own overflow counter; data-parallel replicas pass the float32 flag their gradient
+        reduce-scatter SUMMED over the ranks (so_inject_noise_dev tests the word's bits: 0.0f is all-zero bits), so that every
+        replica skips or adds alike."""
         nz = self.mcmc_noise
         if nz is None:
             return
         if "lr0" not in nz:      # base of the means' ExponentialLR: the optimiser's current lr un-decayed to step 0
             nz["lr0"] = self.optimizers["means"].param_groups[0]["lr"] / (self.lr_gamma_means ** self.steps_done)
         p = _lib.ptr
-        ovf = self.ws["counters"][2 * self.M + 2:]
+        ovf = self.ws["counters"][2 * self.M + 2:] if skip is None else skip
+        assert ovf.element_size() == 4 and ovf.device == self.device, "inject_noise: skip must be a 4-byte word on the engine's device"
         if self.device_refine:
             a = self.sets[self.active]["p"]
             _lib.call("so_inject_noise_dev", self.cap, p(self._n_dev[self.active:self.active + 1]), p(a["means"]), p(a["scales"]),
@@ -765,33 +770,30 @@ class FusedEngine:
         torch.cuda.synchronize()
         c = self.ws["counters"]
         n_last, ov_last = int(c[2 * self.M + 1].item()), int(c[2 * self.M + 2].item())
+        at_limit = False
         if self.binned:                              # what overflowed is one tile's bin: size by the fullest tile
             n_prev = n_last = self._fullest_tile()
-            if self.bin_capacity >= self._bin_limit:     # the bins cannot grow any further: compact lists from here on
-                if self._status_kind == "train" and self.on_overflow == "grow":
-                    void = 1 + (1 if ov_last else 0)
-                    self.void_steps += void
-                    for _ in range(void):
-                        self.steps_done -= 1
-                        for k in PARAM_ORDER:
-                            self.optimizers[k].state[self.splats[k]]["step"] -= 1
-                        self.optimizers["means"].param_groups[0]["lr"] /= self.lr_gamma_means
-                    self._step_dev[0] = self.steps_done
-                self._fall_back_to_compact_lists(n_last)
-                return
+            at_limit = self.bin_capacity >= self._bin_limit     # the bins cannot grow any further: compact lists from here on
         if self._status_kind != "train":             # a forward-only render overflowed: no iteration to take back
-            self._grow(max(n_prev, n_last))
+            if at_limit:
+                self._fall_back_to_compact_lists(n_last)
+            else:
+                self._grow(max(n_prev, n_last))
             return
+        # the overflow policy comes BEFORE any change of layout: the compact-list fall-back used to return ahead of it,
+        # so that "raise" no longer raised and "defer" lost what this rank had seen
         if self.on_overflow == "raise":
             raise RuntimeError(f"tile-intersection buffers overflowed ({max(n_prev, n_last)} > capacity {self.capacity}); "
-                               "the affected iterations were skipped on the device -- raise Config.isect_capacity")
+                               "the affected iterations were skipped on the device -- raise Config.isect_capacity"
+                               + (" (the per-tile bins are at bin_budget_bytes: Config.binned = False selects the compact lists)" if at_limit else ""))
         if self.on_overflow == "defer":
             # data-parallel replicas: whether an iteration was void is decided by the flag the gradient reduce-scatter summed
             # over ALL ranks (Runner._dp_check_void -> take_back on every rank alike); what this rank saw locally only sizes
-            # its own bins then
+            # its own bins then -- or, with the bins at their limit, makes take_back switch this rank to the compact lists
             self._local_overflow_seen = max(self._local_overflow_seen, n_prev, n_last, self.bin_capacity if self.binned else 0)
+            self._compact_pending = self._compact_pending or at_limit
             return
-        self.take_back(1 + (1 if ov_last else 0), max(n_prev, n_last))
+        self.take_back(1 + (1 if ov_last else 0), max(n_prev, n_last), compact=at_limit)
 
     def local_overflow_recent(self):
         """(did one of the last two training iterations overflow THIS rank's buffers, entries needed) -- for replicas, whose
@@ -808,10 +810,10 @@ class FusedEngine:
         self._status_event = None                            # (what _check_previous would have looked at is handled)
         return seen, needed
 
-    def take_back(self, void: int, needed: int, grow: bool = True) -> None:
+    def take_back(self, void: int, needed: int, grow: bool = True, compact: bool = False) -> None:
         """`void` training iterations never happened (the optimiser skipped them on the device): undo the host-side step
         bookkeeping, enlarge the intersection buffers for `needed` entries (binned: Gaussians over the fullest tile) and
-        say so."""
+        say so.  compact (or a deferred overflow at the bin limit): the bins cannot grow -- switch to the compact lists."""
         self.void_steps += void
         for _ in range(void):                        # undo _advance_host_counters for iterations that never happened
             self.steps_done -= 1
@@ -825,6 +827,13 @@ class FusedEngine:
         if not grow:      # (a replica whose own buffers held: another rank's view overflowed)
             warnings.warn(f"splat_one_amd: {void} training iteration(s) skipped on every replica -- another rank's "
                           "tile-intersection buffers overflowed", RuntimeWarning)
+            return
+        compact = self.binned and (compact or self._compact_pending or self.bin_capacity >= self._bin_limit)
+        self._compact_pending = False
+        if compact:
+            warnings.warn(f"splat_one_amd: {void} training iteration(s) skipped -- {what}, and the bins are at their memory budget",
+                          RuntimeWarning)
+            self._fall_back_to_compact_lists(needed)
             return
         warnings.warn(f"splat_one_amd: {void} training iteration(s) skipped -- {what}; buffers enlarged", RuntimeWarning)
         self._grow(needed)

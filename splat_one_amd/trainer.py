@@ -772,7 +772,16 @@ class Runner:
                         if int(chk[0]) != n_new or int(chk[1]) != -n_new:
                             raise RuntimeError(f"replicas diverged: this rank holds {n_new} Gaussians after the MCMC refinement of step "
                                                f"{step}, others between {-int(chk[1])} and {int(chk[0])}")
-                eng.inject_noise()
+                if self.world_size > 1:
+                    # replicas: the noise kernel reads the optimiser step from device memory (Philox counter, lr decay) -- the
+                    # data-parallel steps run Adam with host-side schedules and never advance it -- and must skip on the flag
+                    # SUMMED over the ranks, as the Adam launches did: a rank-local overflow word would let the other
+                    # replicas add noise the overflowing one leaves out
+                    eng._step_dev[0] = eng.steps_done
+                    flag = self._radam.void_flag() if self._radam is not None else (self._sadam.void_flag() if self._sadam is not None else None)
+                    eng.inject_noise(skip=flag)
+                else:
+                    eng.inject_noise()
             else:
                 # torch-level strategy ops on the host-side handles.  Replicated data parallelism shards the Adam moments by
                 # flat pieces (ShardedFlatAdam): every rank rewrites ALL of them, so the other owners' pieces come first

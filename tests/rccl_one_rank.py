@@ -84,6 +84,10 @@ for wk in ra._reduce_scatter_flags():
 torch.cuda.synchronize()
 assert all(torch.equal(t, torch.full_like(t, v)) for t, v in zip(rows, (2.0, 3.0, 4.0))) and float(ra.void_flag()[0]) == 5.0
 sdist.probe_coalescing_locally()     # the rank-local half of the fallback vote: the private API exists and can be entered empty
+# ... and the second half: one tiny GROUPED reduce-scatter (one of them in place, as the void flags are) + all-gather
+# through this torch / RCCL build, values checked; then the two-phase vote itself
+sdist.trial_grouped_collectives(dev)
+assert sdist.agree_on_coalescing(sdist.probe_coalescing_locally, dev, None, lambda: sdist.trial_grouped_collectives(dev)) == "coalesced"
 for wk in sa._reduce_scatter_flags(torch.tensor([1.0], device=dev), dev):
     wk.wait()
 torch.cuda.synchronize()

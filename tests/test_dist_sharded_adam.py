@@ -293,3 +293,36 @@ def test_collective_fallback_is_agreed_on_by_all_ranks(tmp_path, forced, want):
     for o in outs:
         for k in ROWS:
             assert torch.equal(o["P"][k], torch.full_like(o["P"][k], 1.0 - 2 * mean_g)), k
+
+
+def _trial_vote_worker(local_rank, world_rank, world_size, args):
+    out_dir, forced = args
+    import warnings
+    from splat_one_amd import distributed as sdist
+    if forced is not None:
+        os.environ["SPLAT_ONE_AMD_FORCE_COALESCE_FAIL"] = forced
+    ran = []
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        mode = sdist.agree_on_coalescing(lambda: None, "cpu", None, trial=lambda: ran.append(world_rank))
+    torch.save({"mode": mode, "ran": ran, "warned": sum("fall" in str(w.message) for w in wlist)}, os.path.join(out_dir, f"t{world_rank}.pt"))
+
+
+@pytest.mark.parametrize("forced,want,trial_ran", [(None, "coalesced", [True, True]), ("trial:1", "per_tensor", [True, False]),
+                                                   ("0", "per_tensor", [False, False])])
+def test_collective_vote_has_a_trial_phase_every_rank_follows(tmp_path, forced, want, trial_ran):
+    """ADVICE r4: after the rank-local vote says "coalesced", every rank runs ONE trial grouped collective and votes again;
+    a rank whose trial fails takes all ranks to "per_tensor"; a rank whose FIRST vote fails keeps every rank out of the trial."""
+    from splat_one_amd import distributed as sdist
+    keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SPLAT_ONE_AMD_FORCE_COALESCE_FAIL")
+    env_backup = {k: os.environ.pop(k, None) for k in keys}
+    try:
+        sdist.cli(_trial_vote_worker, (str(tmp_path), forced), world_size=2, backend="gloo", port=_free_port())
+    finally:
+        for k, v in env_backup.items():
+            if v is not None:
+                os.environ[k] = v
+    outs = [torch.load(os.path.join(tmp_path, f"t{r}.pt")) for r in range(2)]
+    assert [o["mode"] for o in outs] == [want] * 2
+    assert [bool(o["ran"]) for o in outs] == trial_ran
+    assert all(o["warned"] == (1 if want == "per_tensor" else 0) for o in outs)

@@ -500,3 +500,54 @@ def test_skewed_cloud_falls_back_to_compact_lists_instead_of_raising(dev):
         res[mode] = {k: v.detach().clone() for k, v in r.splats.items()}
     for k in res["budget"]:
         assert rel_err(res["budget"][k], res["compact"][k]) < 1e-4, k
+
+
+@pytest.mark.parametrize("policy", ["grow", "raise", "defer"])
+def test_overflow_policy_is_honoured_when_the_bins_are_at_their_budget(dev, policy):
+    """with the bins already at `bin_budget_bytes` an overflow used to fall back to the compact lists BEFORE
+    looking at `on_overflow` -- "raise" did not raise (and the host's step count drifted from the device's), "defer" forgot
+    what the rank had seen.  Bins fixed at 16 slots = the budget, a view whose fullest tile needs more:
+    grow: the void iterations are taken back, compact lists from then on, the run continues;  raise: RuntimeError;
+    defer: nothing changes until the caller -- Runner._dp_check_void -- calls take_back, which then falls back."""
+    import warnings
+    from splat_one_amd.engine import FusedEngine
+    N, W, H = 6000, 160, 96
+    r, c2w, Ks, pixels = _make(dev, N, W, H, "mcmc")
+    with torch.no_grad():
+        r.splats["means"].mul_(0.3)
+    M = (W // 16) * (H // 16)
+    eng = FusedEngine(r.splats, r.optimizers, W, H, 1, sh_degree=3, use_graph=True, bin_capacity=16, bin_budget_bytes=12 * M * 16)
+    assert eng.bin_capacity == 16 and eng._bin_limit == 16
+    eng.on_overflow = policy
+
+    def steps(n):
+        for _ in range(n):
+            eng.set_views(c2w, Ks, pixels, schedule=True)
+            eng.step()
+
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        if policy == "raise":
+            with pytest.raises(RuntimeError, match="overflowed"):
+                steps(4)
+            return
+        steps(4)
+        torch.cuda.synchronize()
+        if policy == "defer":
+            assert eng.binned and eng.void_steps == 0 and eng._compact_pending and eng._local_overflow_seen > 16
+            assert eng.steps_done == 4                       # nothing taken back yet: that is the caller's (collective) decision
+            seen, needed = eng.local_overflow_recent()
+            assert seen and needed > 16
+            eng.take_back(4, needed, grow=seen)              # (every iteration so far was void on the device)
+        assert not eng.binned and eng.fell_back_to_compact
+        assert sum("falling back to the compact" in str(w.message) for w in caught) == 1
+        void = eng.void_steps
+        assert void >= 2 and eng.steps_done == 4 - void
+        assert float(r.optimizers["means"].state[r.splats["means"]]["step"]) == float(eng.steps_done)
+        assert int(eng._step_dev[0].item()) == eng.steps_done
+        steps(3)
+        eng.set_views(c2w, Ks, pixels)
+        torch.cuda.synchronize()
+    assert eng.void_steps == void and eng.steps_done == 4 - void + 3 and eng.stats()["overflow"] == 0
+    assert int(eng._step_dev[0].item()) == eng.steps_done
+    assert all(torch.isfinite(v).all() for v in r.splats.values())

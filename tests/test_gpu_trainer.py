@@ -584,14 +584,17 @@ def test_depth_loss_term_matches_the_oracle_and_is_never_silently_dropped(dev):
     assert abs(float(r.last_depthloss) - dlo.item()) <= 1e-5 * abs(dlo.item()) and not torch.equal(before, r.splats["means"].detach())
 
 
-def _dp_mcmc_worker(local_rank, world_rank, world_size, out_dir):
+def _dp_mcmc_worker(local_rank, world_rank, world_size, args):
+    out_dir, small_bins = args if isinstance(args, tuple) else (args, False)
     from splat_one_amd.strategy import MCMCStrategy
     from splat_one_amd.trainer import Config, Runner
     dev = torch.device("cuda:0")
     W, H, N = 128, 96, 3000
     strat = MCMCStrategy(refine_start_iter=4, refine_every=5, refine_stop_iter=1000, cap_max=4000, verbose=False)
+    # small_bins: the LAST rank's per-tile bins are too small for its views -- its overflow voids iterations on every rank
     cfg = Config(init_num_pts=N, init_scale=0.3, init_opa=0.3, shN_init_std=0.05, sh_degree_interval=1, fused=True,
-                 dp_mode="allreduce", strategy=strat, dp_chunks=2, opacity_reg=0.01, scale_reg=0.01)
+                 dp_mode="allreduce", strategy=strat, dp_chunks=2, opacity_reg=0.01, scale_reg=0.01,
+                 bin_capacity=(16 if (small_bins and world_rank == world_size - 1) else (4096 if small_bins else None)))
     r = Runner(0, world_rank, world_size, cfg, scene_scale=1.0 / 1.1)
     with torch.no_grad():
         r.splats["scales"].add_((torch.randn(N, 3, generator=torch.Generator().manual_seed(7)) * 0.4).to(dev))
@@ -611,7 +614,8 @@ def _dp_mcmc_worker(local_rank, world_rank, world_size, out_dir):
     r._radam.gather([act[q][k] for q in ("m", "v") for k in act[q]], n)     # every rank's copy of ALL moments
     torch.cuda.synchronize()
     torch.save({"sizes": sizes, "p": {k: act["p"][k][:n].detach().cpu() for k in act["p"]},
-                "m": {k: act["m"][k][:n].detach().cpu() for k in act["m"]}}, os.path.join(out_dir, f"mcmc{world_rank}.pt"))
+                "m": {k: act["m"][k][:n].detach().cpu() for k in act["m"]}, "void": eng.void_steps, "steps_done": eng.steps_done,
+                "step_dev": int(eng._step_dev[0].item()), "bins": eng.bin_capacity}, os.path.join(out_dir, f"mcmc{world_rank}.pt"))
 
 
 def test_replicated_dp_mcmc_on_the_device_keeps_the_replicas_identical(dev, tmp_path):
@@ -632,3 +636,29 @@ def test_replicated_dp_mcmc_on_the_device_keeps_the_replicas_identical(dev, tmp_
         for k in a[q]:
             assert torch.equal(a[q][k], b[q][k]) and torch.isfinite(a[q][k]).all(), (q, k)
     assert a["m"]["means"].abs().sum() > 0
+
+
+def test_replicated_dp_mcmc_overflow_on_one_rank_keeps_the_noise_in_step(dev, tmp_path):
+    """with device-side MCMC in replicated data parallelism the position noise must skip on the void flag SUMMED
+    over the ranks (the rank-local overflow word let the rank that did not overflow add noise the other one left out) and
+    must read the optimiser step the data-parallel path keeps on the host.  One rank starts with 16-slot bins: its overflow
+    voids iterations on both ranks, both take them back, and the replicas -- noise included -- stay bit-identical."""
+    import warnings
+    from splat_one_amd import distributed as sdist
+    env_backup = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sdist.cli(_dp_mcmc_worker, (str(tmp_path), True), world_size=2, backend="gloo", port=_free_port())
+    finally:
+        for k, v in env_backup.items():
+            if v is not None:
+                os.environ[k] = v
+    a, b = (torch.load(os.path.join(tmp_path, f"mcmc{i}.pt")) for i in range(2))
+    assert a["void"] == b["void"] and a["void"] >= 1, (a["void"], b["void"])
+    assert a["steps_done"] == b["steps_done"] == a["step_dev"] == b["step_dev"], (a["steps_done"], a["step_dev"], b["step_dev"])
+    assert a["bins"] == 4096 and b["bins"] > 16
+    assert a["sizes"] == b["sizes"]
+    for q in ("p", "m"):
+        for k in a[q]:
+            assert torch.equal(a[q][k], b[q][k]) and torch.isfinite(a[q][k]).all(), (q, k)
