@@ -94,6 +94,51 @@ def cpu_baseline(n, width, height, regime, seconds_budget=20.0):
                       f"{regime} workload: torch fp32 projection/SH/binning/loss/Adam + oracle/c/raster_oracle.c (f32, OpenMP)",
             "forward_mpix_per_s": width * height / fwd / 1e6}
 
+OTHER_CONFIGS = {
+    # key: (flags, what)
+    "ref": (["--regime", "ref", "--steps", "30", "--warmup", "5"],
+            "c2 in the reference's default preset (init_scale 1.0, init_opa 0.1)"),
+    "c3_share": (["--gaussians", "500000", "--steps", "30", "--warmup", "5"],
+                 "configs[2], one GPU's share: 500k Gaussians, 1080p, one view per step"),
+    "c4_densify": (["--gaussians", "1000000", "--width", "2560", "--height", "1440", "--densify", "100", "--steps", "100"],
+                   "configs[3]: 1M Gaussians, 1440p, DefaultStrategy refining every 100 iterations on the device"),
+    "c5_share_f16": (["--gaussians", "2000000", "--attr-dtype", "f16", "--steps", "20", "--warmup", "5"],
+                     "configs[4], one GPU's share: 2M Gaussians, float16 attribute rows, pinhole view"),
+}
+
+
+def other_configs(timeout_s=300):
+    """Compact sub-results of the other BASELINE configurations: {key: {it_s, ms_per_step, hbm_iter_fraction, dominant kernel and
+    its HBM fraction, ...}}, each from one child process `python bench.py <flags> --no-cpu-baseline --no-operator-path
+    --no-other-configs` (started by PID-less subprocess.run: the parent waits; the GPU is shared sequentially)."""
+    import subprocess
+    res = {}
+    for key, (flags, what) in OTHER_CONFIGS.items():
+        cmd = [sys.executable, os.path.abspath(__file__)] + flags + ["--no-cpu-baseline", "--no-operator-path", "--no-other-configs"]
+        t0 = time.time()
+        try:
+            pr = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+            line = next((l for l in reversed(pr.stdout.splitlines()) if l.startswith("{")), None)
+            if pr.returncode != 0 or line is None:
+                res[key] = {"what": what, "error": f"exit code {pr.returncode}: {pr.stderr.strip().splitlines()[-1:] or ''}"}
+                continue
+            j = json.loads(line)
+            rf = j["roofline"]
+            res[key] = {"what": what, "flags": " ".join(flags), "it_s": j["value"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
+                        "hbm_iter_fraction": j["hbm_iter_fraction"], "dominant_kernel": rf["kernel"],
+                        "dominant_kernel_us": rf["mean_launch_us"], "dominant_hbm_frac": rf["frac"], "bound": rf["bound"],
+                        "traffic": rf.get("traffic"), "valu_frac": (rf.get("valu") or {}).get("frac"),
+                        "tile_intersections": j["config"]["tile_intersections"], "visible_gaussians": j["config"]["visible_gaussians"],
+                        "backward_rasteriser": j["config"]["backward_rasteriser"], "void_steps": j["void_steps"],
+                        "gaussians_after": (j.get("densify") or {}).get("gaussians_after"),
+                        "wall_s": round(time.time() - t0, 1)}
+        except subprocess.TimeoutExpired:
+            res[key] = {"what": what, "error": f"timed out after {timeout_s} s"}
+        except Exception as e:   # noqa: BLE001
+            res[key] = {"what": what, "error": repr(e)}
+    return res
+
+
 def self_launch(n_ranks, argv):
     """`python bench.py --gpus N` without a launcher (gsplat_trainer.py:998 `cli(main, cfg)` spawns one process per GPU the
     same way): start N children of THIS script with torchrun's environment contract, one rank per GPU.  The parent makes
@@ -219,6 +264,15 @@ def main():
                          "Gaussians, reduce-scatter / sharded Adam / all-gather of the gradient SoA, BASELINE.json's "
                          "north_star; gaussian_sharded -- the reference's own scheme (projected Gaussians exchanged by "
                          "all-to-all).  The other scheme is timed too and reported in config.other_scheme")
+    ap.add_argument("--targets", default="teacher", choices=["teacher", "noise"],
+                    help="teacher (default): the target images are renders of the frozen INITIAL model at the ring views and the "
+                         "student starts from the same geometry with re-drawn colours -- full-size coherent gradients, and a "
+                         "workload (tile intersections) that stays put however many steps are run; noise: seeded U[0,1) images "
+                         "(rounds 1-4: the splats grow against them, I drifts ~20 %% over 200 steps)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N = 1, default workload only: skip the compact sub-results of the other BASELINE configurations "
+                         "(other_configs: ref, c3_share, c4_densify, c5_share_f16 -- each a child process of this script)")
+    ap.add_argument("--step-trace", action="store_true", help="diagnostic: an event per timed step, gaps printed to stderr")
     ap.add_argument("--launch-check", action="store_true",
                     help="start the ranks, build the process group, print what it reports (config.rccl) and exit: no kernel "
                          "runs (the CPU test of the self-launcher; works without a GPU over gloo)")
@@ -266,13 +320,36 @@ def main():
     NV = max(1, args.views)
     ring = ring_cameras(NV * world) if NV * world > 1 else front_camera()[None]
     g = torch.Generator().manual_seed(100 + rank)
+    teacher = args.targets == "teacher" and not args.densify
     if args.densify:      # a smooth target (a shifted colour ramp per view): gradients that make densification grow the set
         yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
         targets = [torch.stack([(xx + 0.1 * v) % 1.0, (yy + 0.07 * v) % 1.0, 0.5 * (xx + yy)], -1)[None].contiguous().to(dev)
                    for v in range(NV)]
+    elif teacher:
+        targets = None    # rendered from the runner's own initial model (make_runner)
     else:
         targets = [torch.rand(1, H, W, 3, generator=g).to(dev) for _ in range(NV)]
     K1 = pinhole_K(W, H)[None]
+
+    def teacher_targets(r):
+        """A STATIONARY workload: the targets are renders of the frozen initial model at this rank's ring
+        views; the student keeps that geometry and gets its colours re-drawn (sh0 + N(0, 0.5^2), shN ~ N(0, 0.1^2), other seed),
+        so the loss has full-size, coherent gradients, its optimum keeps the splats where they are, and the tile-intersection
+        count no longer depends on how many steps ran before or inside the timed region."""
+        out = []
+        with torch.no_grad():
+            for v in range(NV):
+                cam = ring[v * world + rank:v * world + rank + 1].contiguous().to(dev)
+                rc, _, _ = r.rasterize_splats(camtoworlds=cam, Ks=K1.to(dev), width=W, height=H, sh_degree=3,
+                                              near_plane=r.cfg.near_plane, far_plane=r.cfg.far_plane)
+                out.append(rc[..., :3].detach().clone().contiguous())
+            gs = torch.Generator().manual_seed(4242 + (rank if r.sharded else 0))
+            r.splats["sh0"].add_((torch.randn(r.splats["sh0"].shape, generator=gs) * 0.5).to(dev))
+            r.splats["shN"].copy_((torch.randn(r.splats["shN"].shape, generator=gs) * 0.1).to(dev))
+        torch.cuda.synchronize()
+        r._workspace.clear()         # (the operator path's buffers of these renders are not kept)
+        torch.cuda.empty_cache()
+        return out
 
     def make_runner(dp_mode):
         cfg = Config(init_num_pts=N, init_scale=init_scale, init_opa=init_opa, batch_size=1, shN_init_std=0.1,
@@ -286,10 +363,11 @@ def main():
         if args.cloud_scale != 1.0:
             with torch.no_grad():
                 r.splats["means"].mul_(args.cloud_scale)
+        tg = teacher_targets(r) if teacher else targets
         if r.sharded:      # the step takes the cameras of every rank (rank r renders camera r of the step's group)
-            views = [(ring[v * world:(v + 1) * world].contiguous().to(dev), K1.repeat(world, 1, 1).to(dev), targets[v]) for v in range(NV)]
+            views = [(ring[v * world:(v + 1) * world].contiguous().to(dev), K1.repeat(world, 1, 1).to(dev), tg[v]) for v in range(NV)]
         else:
-            views = [(ring[v * world + rank:v * world + rank + 1].contiguous().to(dev), K1.to(dev), targets[v]) for v in range(NV)]
+            views = [(ring[v * world + rank:v * world + rank + 1].contiguous().to(dev), K1.to(dev), tg[v]) for v in range(NV)]
         return cfg, r, views
 
     class Stepper:
@@ -364,9 +442,49 @@ def main():
     # preparation (untimed, before the W warm-up steps and whatever W is): two cycles over the views, so that the SH-degree
     # ramp is over, every hipGraph the timed region replays is captured and the per-tile bins have seen every view -- the
     # counterpart of a compile step; a small --warmup then times steady-state iterations, not captures
+    preparation_steps = 0
     if world == 1 and not args.densify:
-        for _ in range(2 * len(views)):
+        preparation_steps = 2 * len(views)
+        for _ in range(preparation_steps):
             step_once()
+    def measure_forward():
+        """forward-only rate: the eval / viewer render (projection + SH + binning + sort + rasterise), seconds per render"""
+        if getattr(runner, "_engine", None) is None and fused:
+            step_once()                       # (the engine is built by the first training step)
+        if runner.sharded:
+            fwd_call = lambda: None           # a render needs every shard on one rank: not a per-step quantity here
+        elif fused:
+            fwd_call = runner._engine.render
+        else:
+            def fwd_call():
+                with torch.no_grad():
+                    runner.rasterize_splats(c2w, Ks, W, H, sh_degree=3, near_plane=cfg.near_plane, far_plane=cfg.far_plane)
+        for _ in range(5):
+            fwd_call()
+        barrier()
+        t0_ = time.time()
+        for _ in range(50):
+            fwd_call()
+        barrier()
+        _lib.profile_summary()  # discard
+        return (time.time() - t0_) / 50
+
+    def last_I():
+        """tile intersections of the last iteration (synchronises; outside the timed region)"""
+        info = getattr(runner, "last_info", None) or {}
+        if "engine" in info:
+            return info["engine"].stats()["n_isects"]
+        if "n_isects" in info:
+            return int(info["n_isects"].item())
+        return int(info["flatten_ids"].numel()) if "flatten_ids" in info else None
+
+    # Everything that idles the GPU or reads it back -- the forward-only timing, the workload counters before the timed region --
+    # happens BEFORE the warm-up, so that the W warm-up steps run straight into the barrier of the timed region (round 5,
+    # bench.py --step-trace: after an idle gap the first ~30 iterations run 5 % slower, 278 against 263 us).  Runs with
+    # densification measure the forward after their warm-up refinements instead (the model it renders is the grown one).
+    fwd_s = None if args.densify else measure_forward()
+    I_start = None if args.densify else last_I()
+
     # warm-up
     if not fused:
         _lib.PROFILE = "all"     # operator path: per-entry-point HIP events from Python
@@ -389,37 +507,37 @@ def main():
                        key=lambda kv: kv[1][0] * kv[1][1])[0]
         _lib.PROFILE = {dominant}
 
-    # forward-only rate: the eval / viewer render (projection + SH + binning + sort + rasterise)
-    if runner.sharded:
-        fwd_call = lambda: None           # a render needs every shard on one rank: not a per-step quantity here
-    elif fused:
-        eng = runner._engine
-        fwd_call = eng.render
-    else:
-        def fwd_call():
-            with torch.no_grad():
-                runner.rasterize_splats(c2w, Ks, W, H, sh_degree=3, near_plane=cfg.near_plane, far_plane=cfg.far_plane)
-    for _ in range(5):
-        fwd_call()
-    barrier()
-    t0 = time.time()
-    for _ in range(50):
-        fwd_call()
-    barrier()
-    fwd_s = (time.time() - t0) / 50
-    _lib.profile_summary()  # discard
-
     # timed region: EXACTLY --steps iterations between barriers
     n_before_timed = runner._engine.sync_host() if (fused and not runner.sharded and getattr(runner._engine, "device_refine", False)) else None
     void0 = getattr(getattr(runner, "_engine", None), "void_steps", 0)
+
+    if args.densify:
+        fwd_s = measure_forward()
+        I_start = last_I()
     for o in comm_objects(runner):
         o.timer.clear()
     barrier()
     t0 = time.time()
-    for _ in range(args.steps):
-        step_once()
+    if args.step_trace:      # (diagnostic: one event per step -- where inside the timed region does the time go?)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        host_t = []
+        evs[0].record()
+        for i in range(args.steps):
+            step_once()
+            evs[i + 1].record()
+            host_t.append(time.time() - t0)
+    else:
+        for _ in range(args.steps):
+            step_once()
     barrier()
     elapsed = time.time() - t0
+    if args.step_trace and rank == 0:
+        gaps = [evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(args.steps)]
+        print("[step-trace] us between consecutive step-end events:", [round(g_, 1) for g_ in gaps[:24]], "... mean of the rest",
+              round(sum(gaps[24:]) / max(1, len(gaps[24:])), 1), file=sys.stderr)
+        print("[step-trace] host time at which step i had been issued (us):", [round(h * 1e6) for h in host_t[:24]],
+              " whole region (us):", round(elapsed * 1e6), file=sys.stderr)
+    I_end = last_I()
     comm_ms = None
     for o in comm_objects(runner):          # mean per step over exactly the timed iterations (this rank's stream)
         comm_ms = o.comm_ms()
@@ -504,6 +622,7 @@ def main():
     ab["so_preprocess_bwd"] = ab["so_projection_bwd"] + ab["so_sh_bwd"]                    # fused K2+K5
     ab["so_adam_step_dev"] = ab["so_adam_step"]
     ab["so_isect_scan"] = 8 * (W // 16 + 1) * (H // 16 + 1)
+    ab["so_tile_order"] = 8 * (W // 16 + 1) * (H // 16 + 1)        # list lengths read, workgroup -> tile table written
     ab["so_ssim_l1_fwd"] = 24 * P + 36 * P
     ab["so_ssim_l1_bwd"] = 60 * P + 12 * P
     ab["so_ssim_l1_fused"] = 24 * P + 12 * P          # two images in, one gradient image out
@@ -513,7 +632,7 @@ def main():
     traffic = None
     profile_notes = {}
 
-    def collected_near(j, what):
+    def collected_near(j, what, tol=0.05):
         """A committed counter summary applies to this run only if it was collected at (nearly) the same workload state: the
         passes walk tile lists, and their number follows the tile intersections I.  profiles/*.json hold
         the collection of the default command and, under "_also", the one made at the round-end driver's command line
@@ -524,20 +643,39 @@ def main():
             if not at:
                 continue
             seen.append(at)
-            if abs(I - at) <= 0.05 * at:
+            if abs(I - at) <= tol * at:
                 profile_notes[what] = f"collected at I = {at} (this run: I = {I})"
                 return col
         profile_notes[what] = ("refused: the summary in profiles/ does not say at which tile-intersection count it was collected" if not seen
-                               else f"refused: collected at I = {seen}, this run has I = {I} (> 5 % apart)")
+                               else f"refused: collected at I = {seen}, this run has I = {I} (> {tol:.0%} apart)")
         return None
 
+    def collection_for(j, what):
+        """c2: the root collection (or one of its "_also"); any other named workload: j["_by_workload"][key] -- collected by
+        tools/gpu_profiles_r05.sh at that workload's own command line (15 % on I: densification moves it inside a run)."""
+        if wl_short == "c2":
+            return collected_near(j, what)
+        col = (j.get("_by_workload") or {}).get(wl_short)
+        if col is None:
+            profile_notes[what] = f"no counter collection for workload '{wl_short}' in profiles/"
+            return None
+        return collected_near(col, what, tol=0.15)
+
+    # which BASELINE configuration this is (profiles/*.json keep one counter collection per key under "_by_workload")
+    wl = (N0, W, H, bool(args.densify), args.regime, args.attr_dtype, args.cloud_scale)
+    workload_key = {(100_000, 1920, 1080, False, "mcmc", "f32", 1.0): "c2",
+                    (100_000, 1920, 1080, False, "ref", "f32", 1.0): "c2-ref (the reference's default preset)",
+                    (500_000, 1920, 1080, False, "mcmc", "f32", 1.0): "c3 (per-GPU share: 500k Gaussians, one view)",
+                    (1_000_000, 2560, 1440, True, "mcmc", "f32", 1.0): "c4",
+                    (2_000_000, 1920, 1080, False, "mcmc", "f16", 1.0): "c5 (per-GPU share: 2M Gaussians, float16 rows, pinhole view)",
+                    (2_000_000, 1920, 1080, False, "mcmc", "f32", 1.0): "2M-f32"}.get(wl, "custom")
+    wl_short = workload_key.split(" ")[0]
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    # the PMC traffic in profiles/ was collected on c2 with the fused engine: it says nothing about another workload
-    is_c2_engine = ((N0, W, H, args.densify, world, len(views)) == (100_000, 1920, 1080, 0, 1, 8) and fused and args.attr_dtype == "f32"
-                    and args.regime == "mcmc" and args.cloud_scale == 1.0)
+    # the PMC collections in profiles/ are keyed by workload (c2 at the root; c2-ref, c4, 2M-f32, ... under "_by_workload")
+    is_c2_engine = workload_key != "custom" and world == 1 and len(views) == 8 and fused     # (a named workload with a collection of its own)
     if os.path.exists(tpath) and is_c2_engine:
         try:
-            tj = collected_near(json.load(open(tpath)), "traffic")
+            tj = collection_for(json.load(open(tpath)), "traffic")
             traffic = tj.get(dominant) if tj else None
         except Exception:
             traffic = None
@@ -547,7 +685,7 @@ def main():
     kpath = os.path.join(ROOT, "profiles", "kernel_us.json")
     if os.path.exists(kpath) and is_c2_engine:
         try:
-            kj = collected_near(json.load(open(kpath)), "kernel_us") or {}
+            kj = collection_for(json.load(open(kpath)), "kernel_us") or {}
             if dominant in kj:
                 kernel_us_rocprof = {"us": kj[dominant], "source": kj.get("_note"), "collected_at": kj.get("_collected_at")}
         except Exception:   # noqa: BLE001
@@ -582,7 +720,7 @@ def main():
     vpath = os.path.join(ROOT, "profiles", "valu.json")
     if os.path.exists(vpath) and is_c2_engine:
         try:
-            vj = collected_near(json.load(open(vpath)), "valu") or {}
+            vj = collection_for(json.load(open(vpath)), "valu") or {}
             ent = vj.get(dominant)
             if ent:
                 rate = ent["wave_instructions"] / (dom_ms * 1e-3)
@@ -610,13 +748,18 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "path": ("sharded engine (C-ABI launches + 2 all-to-all)" if runner.sharded else
                  "fused engine (hipGraph replay)" if fused else "operator-level autograd path"),
-        "config": {"workload": f"{'c2' if (N0, W, H, args.densify, args.cloud_scale) == (100_000, 1920, 1080, 0, 1.0) else 'custom'}: {N0} Gaussians "
+        "config": {"workload": f"{workload_key}: {N0} Gaussians "
                                f"(reference random init, '{args.regime}' preset), "
                                f"{W}x{H}, SH degree 3, 1 view per GPU per step ({len(views)} ring cameras and targets cycled), pinhole"
                                + (f", DefaultStrategy refining every {args.densify} iterations ({n_before_timed or N0} -> {N} Gaussians "
                                   f"over the timed region and the stage-timer pass)" if args.densify else "")
                                + (", float16 attribute rows" if args.attr_dtype == "f16" else "")
-                               + (f", initial positions scaled by {args.cloud_scale}" if args.cloud_scale != 1.0 else ""),
+                               + (f", initial positions scaled by {args.cloud_scale}" if args.cloud_scale != 1.0 else "")
+                               + (", targets = renders of the frozen initial model (student: same geometry, re-drawn colours)" if teacher else
+                                  (", smooth ramp targets" if args.densify else ", random-noise targets")),
+                   "workload_key": workload_key, "targets": ("teacher" if teacher else ("ramp" if args.densify else "noise")),
+                   "preparation_steps": preparation_steps,      # untimed, before --warmup: SH ramp, graph captures, bin probes of all views
+                   "tile_intersections_timed_region": {("before_first_step" if args.densify else "before_the_warmup_steps"): I_start, "after_last_step": I_end},
                    "views_per_step": world, "views_cycled": len(views), "visible_gaussians": V, "tile_intersections": I,
                    "visible_gaussians_per_view": Vs, "tile_intersections_per_view": Is,
                    "tile_cull": bool(cfg.tile_cull and fused),   # I counts what is left after exact tile culling
@@ -628,6 +771,8 @@ def main():
                    "fell_back_to_compact_lists": bool(fused and not runner.sharded and getattr(runner._engine, "fell_back_to_compact", False)),
                    "backward_rasteriser": ("one wave per 16x16 tile" if fused and not runner.sharded and runner._engine.cfg.get("raster_impl") == 1
                                            else "one wave per 8x8 quadrant"),
+                   "tile_order": ("longest list first (device-built table, one launch per step)" if fused and not runner.sharded and getattr(runner._engine, "_lpt", False)
+                                  and getattr(runner._engine, "tile_order_lpt", False) else "XCD-local runs of 8 tiles"),
                    "parallelism": (f"gaussian-sharded dp{world}: one view per GPU, N/{world} Gaussians per GPU, "
                                    "projected Gaussians exchanged by all-to-all" if runner.sharded else
                                    f"view-sharded dp{world}" + ("" if world == 1 else
@@ -688,7 +833,7 @@ def main():
         # The same iteration through the reference's own call structure (gsplat_trainer.py:586-742): Runner.rasterize_splats
         # -> rasterization() [one library call each way] -> photometric_loss -> loss.backward() -> step_all -> strategy
         # hooks, under torch autograd, no hipGraph -- what a trainer written against gsplat's API gets after the import swap.
-        del runner
+        runner = None
         torch.cuda.empty_cache()
         args.operator_path = True
         _cfg_o, r_o, v_o = make_runner("allreduce")
@@ -707,6 +852,20 @@ def main():
                                 "what": "Runner.rasterize_splats -> rasterization() (so_rasterization_fwd/_bwd) -> photometric_loss "
                                         "-> backward -> step_all -> DefaultStrategy hooks, torch autograd, no hipGraph"}
         args.operator_path = False
+    if world == 1 and workload_key == "c2" and fused and not args.no_other_configs:
+        # The other BASELINE configurations next to the headline, each timed by a CHILD of this script
+        # (its own process: a failure there cannot take the headline line with it) with the driver's own clock around it:
+        # >= 20 timed steps, no CPU baseline, no operator path.
+        runner = r_o = st_o = step_once = None        # free the device memory of this process's runners for the children
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["other_configs"] = other_configs()
+        ref = out["other_configs"].get("ref") or {}
+        out["ref_regime"] = {k: ref.get(k) for k in ("it_s", "ms_per_step", "dominant_kernel", "dominant_kernel_us", "dominant_hbm_frac",
+                                                     "valu_frac", "backward_rasteriser", "tile_intersections", "error") if k in ref}
+        out["ref_regime"]["what"] = ("the reference's DEFAULT preset (init_scale 1.0, init_opa 0.1: gsplat_trainer.py:117-119, what "
+                                     "app/gsplat_manager.py:43-49 runs): ~520 list entries per tile")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N0, W, H, args.regime)
     if rank == 0:

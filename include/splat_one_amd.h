@@ -506,6 +506,11 @@ typedef struct so_step_desc {
    * captured step follows without re-capture or host read-back.  With attr_rows_f16 the rows follow their masters through
    * so_attr_pack_f16_n. */
   const int32_t *n_dev;
+  /* int32[C*tiles] scratch (nullable): when set, the step builds a workgroup -> tile table by descending list length (one
+   * small launch behind the per-tile sort) and BOTH rasterisers take their tiles in that order, longest list first.  For
+   * long-list regimes (raster_impl == 1: a tile is one wave's serial chain, so the kernel cannot end before its longest
+   * tile does -- started last, that tile runs on alone).  Speed only: any tile order gives the same images and gradients. */
+  int32_t *tile_order;
 } so_step_desc;
 typedef struct so_adam_fuse {
   so_adam_group groups[6]; /* means, log_scales, quats, logit_opacities, sh0, shN: param / exp_avg / exp_avg_sq (grad unused) */

@@ -15,6 +15,9 @@
 #include "splat_math.hpp"
 #include "rasterize_common.hpp"   // alpha_bound_box: the rasterisers' cull box, computed once per Gaussian into the record
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace so {
 
 struct CamP {
@@ -87,7 +90,37 @@ __device__ unsigned long long g_ppb_stamps[16384 * 8];
 #define PPB_STAMP(k) do { } while (0)
 #endif
 
-template <int DEG, class A, bool SPH>
+// shN rows of a wave read as ONE contiguous run (COOP).  A lane owns one 3 (K - 1)-float row of shN
+// (180 bytes at SH degree 3): read lane by lane, every load instruction touches 64 different lines and a wave pulls its 11.5 KB
+// through the vector cache in 64-byte crumbs (k_preprocess_bwd had the mirror problem for its WRITES and solved it the same
+// way).  Here the wave's 64 rows -- contiguous in memory, row stride == row size -- come in as whole 1 KB pieces by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, lane l of piece i lands at byte 1024 i + 16 l of the wave's LDS region) and
+// every lane then reads ITS row from LDS (row stride 45 floats: odd, no bank conflicts).  Only full waves inside one camera
+// whose first row is 16-byte aligned take this path; the others (the last wave of the live rows, camera seams of a batch with
+// N % 64 != 0) read lane by lane as before.  The coefficients are the same floats either way: results are bit-identical.
+__device__ __forceinline__ unsigned lds_byte_address(const void *p) {   // generic -> LDS address (an addrspacecast)
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (unsigned)(uintptr_t)((const __attribute__((address_space(3))) char *)p);
+#else
+  return 0u;
+#endif
+}
+struct CoefsLdsRow {
+  const float *c0;      // sh0 of this Gaussian (global)
+  unsigned row;         // byte address of this lane's shN row in LDS
+  __device__ __forceinline__ void get(int k, float c[3]) const {
+    if (k == 0) { c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; return; }
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __attribute__((address_space(3))) float *r =
+        reinterpret_cast<const __attribute__((address_space(3))) float *>(static_cast<uintptr_t>(row)) + 3 * (k - 1);
+    c[0] = r[0]; c[1] = r[1]; c[2] = r[2];
+#else
+    c[0] = c[1] = c[2] = 0.f;
+#endif
+  }
+};
+
+template <int DEG, class A, bool SPH, bool COOP>
 __global__ void __launch_bounds__(256)
 k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__restrict__ logit_opac, const A attrs,
                  const float *__restrict__ viewmats,
@@ -111,6 +144,34 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
     const bool first_trip = lin0 == (int64_t)blockIdx.x * blockDim.x;
 #endif
     PP_STAMP(0);
+    bool staged = false;          // wave-uniform: this wave's 64 shN rows are (being) staged in its LDS region
+    unsigned my_lds_row = 0;
+    if constexpr (COOP) {
+      extern __shared__ __attribute__((aligned(16))) float s_rows[];
+      const int R = 3 * (attrs.K - 1);
+      const int wv = threadIdx.x >> 6, lane = lane_id();
+      const int64_t lin_w = lin0 + (int64_t)wv * 64;                 // lin of lane 0 (wave-uniform)
+      const int64_t c_w = lin_w / N, n_w = lin_w - c_w * N;
+      // full wave, one camera, live rows only, and the run 16-byte aligned (R odd: first row a multiple of 4)
+      staged = lin_w + 64 <= total && n_w + 64 <= (int64_t)n_live && ((n_w * R) & 3) == 0;
+      staged = __builtin_amdgcn_readfirstlane((int)staged) != 0;
+      float *mine = s_rows + (size_t)wv * 64 * R;
+      if (staged) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        wave_lds_sync();                                             // the previous trip's row reads are done
+        const float4 *src = reinterpret_cast<const float4 *>(attrs.shN + n_w * R);
+        const int total4 = 16 * R;                                   // 64 R floats = 16 R float4 (R = 45: 720 = 11.25 pieces)
+        for (int i = 0; i * 64 < total4; ++i) {                      // (uniform trip count; the last piece is lane-masked)
+          const int q = i * 64 + lane;
+          if (q < total4)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) void *>(reinterpret_cast<uintptr_t>(src + q)),
+                                             reinterpret_cast<__attribute__((address_space(3))) void *>(static_cast<uintptr_t>(lds_byte_address(mine) + (unsigned)i * 1024u)),
+                                             16, 0, 0);
+        }
+#endif
+      }
+      my_lds_row = lds_byte_address(mine) + (unsigned)lane * (unsigned)R * 4u;
+    }
     int cnt = 0, bx0 = 0, bx1 = 0, by0 = 0, by1 = 0, c = 0;
     float cmx = 0.f, cmy = 0.f, cqa = 0.f, cqb = 0.f, cqc = 0.f, ctau = 0.f;   // what the exact tile test needs
     float cdepth = 0.f;
@@ -144,16 +205,37 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
     if (o.radius == -12345) r = 1.f;      // (keeps the projection ahead of the stamp)
 #endif
     PP_STAMP(1);
+    if constexpr (COOP) {
+      // the rows must have landed before any lane reads its own -- and before the NEXT trip's DMA may overwrite them, so this
+      // wait is taken by every staged wave, whether or not one of its Gaussians is visible (an LDS-DMA is a pending write on
+      // the VM counter; staged waves are full, so all 64 lanes are here)
+      if (staged) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_lds_sync();
+#endif
+      }
+    }
     if (o.radius > 0) {
       float dx = mean[0] - cam.pos[0], dy = mean[1] - cam.pos[1], dz = mean[2] - cam.pos[2];
       const float inorm = rsqrtf(dx * dx + dy * dy + dz * dz);
       dx *= inorm; dy *= inorm; dz *= inorm;
-      const auto coef = attrs.template coefs<DEG>(n);
-      sh_eval<float>(DEG, dx, dy, dz, [&](int k, float yk, float, float, float) {
-        float cf[3];
-        coef.get(k, cf);
-        r += yk * cf[0]; g += yk * cf[1]; b += yk * cf[2];
-      });
+      auto colour_from = [&](const auto &coef) {
+        sh_eval<float>(DEG, dx, dy, dz, [&](int k, float yk, float, float, float) {
+          float cf[3];
+          coef.get(k, cf);
+          r += yk * cf[0]; g += yk * cf[1]; b += yk * cf[2];
+        });
+      };
+      if constexpr (COOP) {
+        if (staged) {      // (wave-uniform)
+          colour_from(CoefsLdsRow{attrs.sh0 + 3 * n, my_lds_row});
+        } else {
+          colour_from(attrs.template coefs<DEG>(n));
+        }
+      } else {
+        colour_from(attrs.template coefs<DEG>(n));
+      }
       r = fmaxf(r + 0.5f, 0.f); g = fmaxf(g + 0.5f, 0.f); b = fmaxf(b + 0.5f, 0.f);
       // first binning pass (same float arithmetic as isect.hip::tile_box)
       const float tile_r = (float)o.radius / tile_size;
@@ -304,6 +386,9 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
   }
 }
 
+#ifndef SO_PP_SWEEP_BATCH
+#define SO_PP_SWEEP_BATCH 12
+#endif
 // LDS floats per Gaussian for the float16 row header (quat 4, log-scale 3, sh0 3) when the fused optimiser also re-packs the
 // rows; odd, so that lanes writing their own header do not share banks
 constexpr int kHalfHdr = 11;
@@ -520,15 +605,36 @@ k_preprocess_bwd(int C, int N, int K, const float *__restrict__ means, const flo
           const float2 hy = af.hyper[5];
           float4 *p4 = reinterpret_cast<float4 *>(af.p[5] + w0 * R), *m4 = reinterpret_cast<float4 *>(af.m[5] + w0 * R),
                  *v4 = reinterpret_cast<float4 *>(af.v[5] + w0 * R);
-          for (int i = lane; i < total / 4; i += 64) {   // (unrolling by 4 measured slower: 50 -> 52 us)
-            float4 pp = p4[i], mm = ld_nt(m4 + i), vv = ld_nt(v4 + i);
-            const float4 g = src4[i];
-            adam_one(pp.x, g.x, mm.x, vv.x, af.h, hy.x, hy.y);
-            adam_one(pp.y, g.y, mm.y, vv.y, af.h, hy.x, hy.y);
-            adam_one(pp.z, g.z, mm.z, vv.z, af.h, hy.x, hy.y);
-            adam_one(pp.w, g.w, mm.w, vv.w, af.h, hy.x, hy.y);
-            p4[i] = pp; st_nt(m4 + i, mm); st_nt(v4 + i, vv);
-            if (A::kHalfRows && af.half_rows) upd4[i] = pp;
+          // The sweep in batches of kSweep float4 per lane: ALL loads of a batch (parameter + two moments: 3 kSweep requests per
+          // lane, at clamped addresses, no exec-masked blocks) leave before the first value is used, then the updates and the
+          // stores follow -- two memory round trips for a wave's 11.25 float4 per lane instead of twelve (round 5; a plain loop
+          // waits load -> update -> store per trip at 1.5 waves per SIMD, and `#pragma unroll 4` of it gained nothing in round 2
+          // because the stores of trip i may alias the loads of trip i + 1 for all the compiler knows).  The registers are free
+          // here: the projection state is dead.
+          // (12 float4 per lane = a full wave's rows in ONE round trip: c2 43.6 -> 41.0 us with 12, 41.6 with 6, 43.4 with 3,
+          // profiles/r05_experiments.json; the float16-row variant is short of registers already and takes 4)
+          constexpr int kSweep = A::kHalfRows ? 4 : SO_PP_SWEEP_BATCH;
+          const int n4 = total / 4;
+          for (int i0 = 0; i0 < n4; i0 += 64 * kSweep) {   // (uniform)
+            float4 pp[kSweep], mm[kSweep], vv[kSweep];
+#pragma unroll
+            for (int u = 0; u < kSweep; ++u) {
+              const int ic = min(i0 + u * 64 + lane, n4 - 1);
+              pp[u] = p4[ic]; mm[u] = ld_nt(m4 + ic); vv[u] = ld_nt(v4 + ic);
+            }
+#pragma unroll
+            for (int u = 0; u < kSweep; ++u) {
+              const int i = i0 + u * 64 + lane;
+              if (i < n4) {
+                const float4 g = src4[i];
+                adam_one(pp[u].x, g.x, mm[u].x, vv[u].x, af.h, hy.x, hy.y);
+                adam_one(pp[u].y, g.y, mm[u].y, vv[u].y, af.h, hy.x, hy.y);
+                adam_one(pp[u].z, g.z, mm[u].z, vv[u].z, af.h, hy.x, hy.y);
+                adam_one(pp[u].w, g.w, mm[u].w, vv[u].w, af.h, hy.x, hy.y);
+                p4[i] = pp[u]; st_nt(m4 + i, mm[u]); st_nt(v4 + i, vv[u]);
+                if (A::kHalfRows && af.half_rows) upd4[i] = pp[u];
+              }
+            }
           }
           for (int i = (total & ~3) + lane; i < total; i += 64) {
             float pj = af.p[5][w0 * R + i], mj = af.m[5][w0 * R + i], vj = af.v[5][w0 * R + i];
@@ -706,10 +812,20 @@ static int preprocess_fwd_impl(const char *what, int C, int N, int K, int sh_deg
   const dim3 grid(pp_grid((int64_t)C * N)), block(256);
   hipStream_t st = as_stream(stream);
   const bool sph = camera_model_has_spherical(camera_model, C);
+  // shN rows through LDS (COOP, see CoefsLdsRow): float32 SoA attributes, SH degree >= 1, a workgroup's 256 rows within the
+  // default 64 KB of dynamic LDS (K <= 22) and a 16-byte aligned tensor.  SPLAT_ONE_AMD_PP_COOP=0 keeps the lane-by-lane reads.
+  static const bool coop_env = [] { const char *e = getenv("SPLAT_ONE_AMD_PP_COOP"); return !(e && e[0] == '0'); }();
+  size_t coop_bytes = 0;
+  if constexpr (std::is_same<A, AttrSoA>::value) {
+    const size_t b = (size_t)256 * 3 * (K - 1) * sizeof(float);
+    if (coop_env && sh_degree >= 1 && K > 1 && b <= 64 * 1024 && (((uintptr_t)attrs.shN) & 15) == 0) coop_bytes = b;
+  }
 #define SO_LAUNCH(D)                                                                                               \
   if (sph) SO_LAUNCH_(D, true); else SO_LAUNCH_(D, false)
 #define SO_LAUNCH_(D, S)                                                                                           \
-  hipLaunchKernelGGL((k_preprocess_fwd<D, A, S>), grid, block, 0, st, C, N, means, logit_opacities, attrs, viewmats,  \
+  if (coop_bytes) SO_LAUNCH__(D, S, true, coop_bytes); else SO_LAUNCH__(D, S, false, 0)
+#define SO_LAUNCH__(D, S, CO, LDS)                                                                                 \
+  hipLaunchKernelGGL((k_preprocess_fwd<D, A, S, (CO && std::is_same<A, AttrSoA>::value && D >= 1)>), grid, block, LDS, st, C, N, means, logit_opacities, attrs, viewmats,  \
                      Ks, width, height, eps2d, near_plane, far_plane, radius_clip, camera_model, antialiased,      \
                      (float)tile_size, tile_w, tile_h, radii, means2d, depths, conics, opacities, colors,          \
                      tiles_per_gauss, tile_counts, reinterpret_cast<float4 *>(rec), reinterpret_cast<float4 *>(vrec), \
@@ -723,6 +839,7 @@ static int preprocess_fwd_impl(const char *what, int C, int N, int K, int sh_deg
   }
 #undef SO_LAUNCH
 #undef SO_LAUNCH_
+#undef SO_LAUNCH__
   return check_launch(what);
 }
 

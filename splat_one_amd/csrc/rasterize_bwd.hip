@@ -62,7 +62,7 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
   // the host checked C * tile_w * tile_h < 2^31 (32-bit index arithmetic)
   const int n_tiles = tile_w * tile_h;
   const int M = C * n_tiles;
-  const int ct = (int)xcd_remap(blockIdx.x, M);
+  const int ct = fin.tile_order ? fin.tile_order[blockIdx.x] : (int)xcd_remap(blockIdx.x, M);   // (LossFinal::tile_order: longest list first)
   if (tile_masks && !tile_masks[ct]) return;
   const int c = ct / n_tiles;
   const int t = ct - c * n_tiles;

@@ -47,7 +47,7 @@ k_rasterize_bwd_tile(int C, int N, int W, int H, int tile_w, int tile_h, const f
   const int n_tiles = tile_w * tile_h;
   const int M = C * n_tiles;
   const int lane = threadIdx.x;
-  const int ct = (int)xcd_remap(blockIdx.x, M);
+  const int ct = fin.tile_order ? fin.tile_order[blockIdx.x] : (int)xcd_remap(blockIdx.x, M);
   const int c = ct / n_tiles;
   const int t = ct - c * n_tiles;
   const int ty = t / tile_w, tx = t - ty * tile_w;
@@ -201,6 +201,70 @@ k_rasterize_bwd_tile(int C, int N, int W, int H, int tile_w, int tile_h, const f
 #pragma unroll
     for (int q = 0; q < 4; ++q) rel[q] -= STAGE;      // the next batch ends STAGE entries earlier
   }
+}
+
+// Workgroup -> tile table, longest list first (so_step_desc.tile_order): ONE workgroup, a counting sort of the C x tiles list
+// lengths over 256 length classes (class = length scaled by the longest list; the order inside a class is the arrival order of
+// LDS atomics -- any bijection gives the same images and gradients, rasterize_common.hpp::xcd_remap).  Consecutive workgroups
+// are dispatched round-robin over the XCDs, so every XCD receives its share of the long tiles first.
+constexpr int kOrderThreads = 1024, kOrderClasses = 256, kOrderCache = 15360;   // list lengths kept in LDS (60 KB): one global read pass
+__global__ void __launch_bounds__(kOrderThreads)
+k_tile_order(int M, const int32_t *__restrict__ offsets, const int32_t *__restrict__ n_isects_dev, int64_t n_isects_host,
+             int32_t *__restrict__ order) {
+  __shared__ int s_cls[kOrderClasses];
+  __shared__ int s_wmax[kOrderThreads / 64];
+  __shared__ int s_len[kOrderCache];
+  const int tid = threadIdx.x;
+  auto length = [&](int t) {
+    int64_t lo, hi;
+    tile_list_range(t, M, offsets, n_isects_dev, n_isects_host, lo, hi);
+    return (int)(hi - lo);
+  };
+  auto cached = [&](int t) { return t < kOrderCache ? s_len[t] : length(t); };
+  int mx = 0;
+  for (int t = tid; t < M; t += kOrderThreads) {
+    const int len = length(t);
+    if (t < kOrderCache) s_len[t] = len;
+    mx = max(mx, len);
+  }
+  mx = wave_max_i32(mx);
+  if ((tid & 63) == 0) s_wmax[tid >> 6] = mx;
+  if (tid < kOrderClasses) s_cls[tid] = 0;
+  __syncthreads();
+  mx = 0;
+#pragma unroll
+  for (int w = 0; w < kOrderThreads / 64; ++w) mx = max(mx, s_wmax[w]);
+  const float scale = (float)kOrderClasses / (float)(mx + 1);
+  auto cls_of = [&](int len) {                       // class 0 = the longest lists
+    const int k = (int)((float)len * scale);
+    return kOrderClasses - 1 - (k < kOrderClasses ? k : kOrderClasses - 1);
+  };
+  for (int t = tid; t < M; t += kOrderThreads) atomicAdd(&s_cls[cls_of(cached(t))], 1);
+  __syncthreads();
+  if (tid < 64) {                                    // exclusive scan of the 256 class counts by one wave: 4 per lane
+    int v[4], run = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = s_cls[4 * tid + j]; run += v[j]; }
+    int inc = run;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(inc, d, 64);
+      if (tid >= d) inc += o;
+    }
+    int base = inc - run;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s_cls[4 * tid + j] = base; base += v[j]; }
+  }
+  __syncthreads();
+  for (int t = tid; t < M; t += kOrderThreads) order[atomicAdd(&s_cls[cls_of(cached(t))], 1)] = t;
+}
+
+int tile_order_launch(int C, int tile_w, int tile_h, const int32_t *offsets, const int32_t *n_isects_dev, int64_t n_isects_host,
+                      int32_t *order, hipStream_t st) {
+  const int64_t M = (int64_t)C * tile_w * tile_h;
+  SO_REQUIRE(order && offsets && M > 0 && M < ((int64_t)1 << 31), "so_train_step_fwd_bwd: tile_order needs the tile lists and C*tiles < 2^31");
+  hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(kOrderThreads), 0, st, (int)M, offsets, n_isects_dev, n_isects_host, order);
+  return check_launch("so_train_step_fwd_bwd (tile order)");
 }
 
 // internal (rasterize_bwd.hip::rasterize_bwd_packed_launch): 16x16 tiles, no absgrad

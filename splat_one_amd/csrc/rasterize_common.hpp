@@ -18,6 +18,10 @@ struct LossFinal {
   // (rasterize_bwd_tile.hip: fewer instructions, longer per-tile chains -- faster from ~250 list entries per tile on),
   // -1 the process default (SPLAT_ONE_AMD_BWD_TILE, else 0)
   int tile_waves = -1;
+  // workgroup -> tile table (nullable; so_step_desc.tile_order, built by so::tile_order_launch): longest list first, for the
+  // one-wave-per-tile backward -- a tile there is ONE wave's serial chain, so the kernel ends when its longest tile does;
+  // started last, a long tile runs on alone over an emptying machine (round 4: 2.5 resident waves per SIMD of 5)
+  const int32_t *tile_order = nullptr;
 };
 
 // Round 3: the RGB passes of both rasteriser kernels work on packed fp32 pairs (v_pk_mul / v_pk_fma are the

@@ -24,7 +24,7 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
                 const uint8_t *__restrict__ tile_masks, const int32_t *__restrict__ offsets,
                 const int32_t *__restrict__ flatten_ids, const int32_t *__restrict__ n_isects_dev,
                 int64_t n_isects_host, float *__restrict__ render_colors, float *__restrict__ render_alphas,
-                int32_t *__restrict__ last_ids, int wrap_flags) {
+                int32_t *__restrict__ last_ids, int wrap_flags, const int32_t *__restrict__ tile_order) {
   constexpr int BLOCK = TS * TS;
   // staged per Gaussian: A = (x, y, conic a, conic b), B = (conic c, opacity [, r, g when D == 3]),
   // remaining colour channels in s_col -- two 16-byte broadcast reads + one 4-byte read per pass for RGB
@@ -39,7 +39,9 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
   // the host checked C * tile_w * tile_h < 2^31: 32-bit index arithmetic (a 64-bit division is ~100 instructions)
   const int n_tiles = tile_w * tile_h;
   const int M = C * n_tiles;
-  const int ct = (int)xcd_remap(blockIdx.x, M);
+  // tile_order (nullable; LossFinal::tile_order): longest list first -- long-list regimes, where a tile's walk is long
+  // against the pixel loads the XCD-local order saves
+  const int ct = tile_order ? tile_order[blockIdx.x] : (int)xcd_remap(blockIdx.x, M);
   const int c = ct / n_tiles;
   const int t = ct - c * n_tiles;
   const int ty = t / tile_w, tx = t - ty * tile_w;
@@ -237,10 +239,10 @@ static int launch_fwd(int TS, dim3 grid, hipStream_t st, int C, int N, int W, in
   const float2 *m2 = reinterpret_cast<const float2 *>(means2d);
   if (TS == 16)
     hipLaunchKernelGGL((k_rasterize_fwd<D, 16, false>), grid, dim3(256), 0, st, C, N, W, H, tile_w, tile_h, m2, conics, colors,
-                       opacities, backgrounds, tile_masks, offsets, flatten_ids, n_dev, n_host, rc, ra, last, wrap_flags);
+                       opacities, backgrounds, tile_masks, offsets, flatten_ids, n_dev, n_host, rc, ra, last, wrap_flags, (const int32_t *)nullptr);
   else
     hipLaunchKernelGGL((k_rasterize_fwd<D, 8, false>), grid, dim3(64), 0, st, C, N, W, H, tile_w, tile_h, m2, conics, colors,
-                       opacities, backgrounds, tile_masks, offsets, flatten_ids, n_dev, n_host, rc, ra, last, wrap_flags);
+                       opacities, backgrounds, tile_masks, offsets, flatten_ids, n_dev, n_host, rc, ra, last, wrap_flags, (const int32_t *)nullptr);
   return check_launch("so_rasterize_fwd");
 }
 
@@ -280,11 +282,25 @@ extern "C" int so_rasterize_fwd(int C, int N, int D, int width, int height, int 
 #undef SO_CASE
 }
 
+namespace so {
+int rasterize_fwd_packed_launch(int C, int N, int width, int height, int tile_size, const float *rec, const float *backgrounds,
+                                const int32_t *isect_offsets, const int32_t *flatten_ids, const int32_t *n_isects_dev,
+                                int64_t n_isects_host, float *render_colors, float *render_alphas, int32_t *last_ids,
+                                const int32_t *tile_order, void *stream);
+}
 extern "C" int so_rasterize_fwd_packed(int C, int N, int width, int height, int tile_size, const float *rec,
                                        const float *backgrounds, const int32_t *isect_offsets,
                                        const int32_t *flatten_ids, const int32_t *n_isects_dev,
                                        int64_t n_isects_host, float *render_colors, float *render_alphas,
                                        int32_t *last_ids, void *stream) {
+  return so::rasterize_fwd_packed_launch(C, N, width, height, tile_size, rec, backgrounds, isect_offsets, flatten_ids, n_isects_dev,
+                                         n_isects_host, render_colors, render_alphas, last_ids, nullptr, stream);
+}
+// internal (step.hip): the same with a workgroup -> tile table (so_step_desc.tile_order; nullable)
+int so::rasterize_fwd_packed_launch(int C, int N, int width, int height, int tile_size, const float *rec, const float *backgrounds,
+                                    const int32_t *isect_offsets, const int32_t *flatten_ids, const int32_t *n_isects_dev,
+                                    int64_t n_isects_host, float *render_colors, float *render_alphas, int32_t *last_ids,
+                                    const int32_t *tile_order, void *stream) {
   SO_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, "so_rasterize_fwd_packed: bad sizes");
   const int wrap_flags = tile_size & ~0xFF;
   tile_size = so::tile_size_of(tile_size);
@@ -301,11 +317,11 @@ extern "C" int so_rasterize_fwd_packed(int C, int N, int width, int height, int 
   if (tile_size == 16)
     hipLaunchKernelGGL((so::k_rasterize_fwd<3, 16, true>), grid, dim3(256), 0, st, C, N, width, height, tile_w, tile_h,
                        nullptr, nullptr, rec, nullptr, backgrounds, nullptr, isect_offsets, flatten_ids, n_isects_dev,
-                       n_isects_host, render_colors, render_alphas, last_ids, wrap_flags);
+                       n_isects_host, render_colors, render_alphas, last_ids, wrap_flags, tile_order);
   else
     hipLaunchKernelGGL((so::k_rasterize_fwd<3, 8, true>), grid, dim3(64), 0, st, C, N, width, height, tile_w, tile_h,
                        nullptr, nullptr, rec, nullptr, backgrounds, nullptr, isect_offsets, flatten_ids, n_isects_dev,
-                       n_isects_host, render_colors, render_alphas, last_ids, wrap_flags);
+                       n_isects_host, render_colors, render_alphas, last_ids, wrap_flags, tile_order);
   return so::check_launch("so_rasterize_fwd_packed");
 }
 

@@ -16,8 +16,8 @@ namespace so {
 // Optional per-stage timing with HIP events on the launch stream (bench.py's roofline leg).
 static const char *kStageNames[] = {"so_preprocess_fwd", "so_isect_scan", "so_isect_fill", "so_rasterize_fwd",
                                     "so_ssim_l1_fwd", "so_ssim_l1_bwd", "so_rasterize_bwd", "so_preprocess_bwd",
-                                    "so_adam_step_dev", "so_ssim_l1_fused"};
-constexpr int kNumStages = 10;
+                                    "so_adam_step_dev", "so_ssim_l1_fused", "so_tile_order"};
+constexpr int kNumStages = 11;
 // per calling thread: the trainer thread's timers neither see nor are switched by a viewer thread's renders
 static thread_local bool g_prof_on = false;
 static thread_local std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events[kNumStages];
@@ -57,6 +57,12 @@ int rasterize_bwd_packed_launch(int C, int N, int width, int height, int tile_si
                                 int64_t n_isects_host, const float *render_alphas, const int32_t *last_ids,
                                 const float *v_render_colors, const float *v_render_alphas, float *vrec, int absgrad,
                                 const LossFinal &fin, void *stream);
+int rasterize_fwd_packed_launch(int C, int N, int width, int height, int tile_size, const float *rec, const float *backgrounds,
+                                const int32_t *isect_offsets, const int32_t *flatten_ids, const int32_t *n_isects_dev,
+                                int64_t n_isects_host, float *render_colors, float *render_alphas, int32_t *last_ids,
+                                const int32_t *tile_order, void *stream);
+int tile_order_launch(int C, int tile_w, int tile_h, const int32_t *offsets, const int32_t *n_isects_dev, int64_t n_isects_host,
+                      int32_t *order, hipStream_t st);
 int ssim_l1_fused_launch(int B, int H, int W, int CH, const float *img1, const float *img2, const float *const *img2_slot,
                          int padding_valid, float w_l1, float w_ssim, const float *v_loss, float *sums, float *v_img1,
                          float *loss_out, int32_t *ticket, float loss_const, int rows, void *stream);
@@ -333,8 +339,10 @@ static int step_impl(const so_step_desc *d, void *stream, StepPart part, int64_t
   const int32_t *list_off = bins ? tile_counts : d->isect_offsets;
   const int32_t *list_n = bins ? nullptr : n_isects;
   const int64_t list_cap = bins ? -bins : d->isect_capacity;
-    SO_STAGE(3, so_rasterize_fwd_packed(C, N, W, H, ts | wrap_flags, d->rec, d->backgrounds, list_off, d->flatten_ids, list_n,
-                                        list_cap, d->render_colors, d->render_alphas, d->last_ids, stream));
+  if (d->tile_order)   // longest list first (both rasterisers)
+    SO_STAGE(10, so::tile_order_launch(C, tile_w, tile_h, list_off, list_n, list_cap, d->tile_order, st));
+    SO_STAGE(3, so::rasterize_fwd_packed_launch(C, N, W, H, ts | wrap_flags, d->rec, d->backgrounds, list_off, d->flatten_ids, list_n,
+                                                list_cap, d->render_colors, d->render_alphas, d->last_ids, d->tile_order, stream));
   if (forward_only) return SO_OK;
   // loss = (1-l) * mean|.| + l * (1 - mean SSIM_valid)
   const float n_l1 = (float)C * H * W * 3.f, n_ss = (float)C * 3.f * (float)(H - 10) * (float)(W - 10);
@@ -355,6 +363,7 @@ static int step_impl(const so_step_desc *d, void *stream, StepPart part, int64_t
   // gradients of the intermediates accumulate in the 64-byte records vrec[C*N] (zeroed by the
   // forward preprocess kernel): one atomic request per (tile quadrant, Gaussian), or per (tile, Gaussian) with raster_impl 1
   fin.tile_waves = d->raster_impl == 1 ? 1 : 0;
+  fin.tile_order = d->tile_order;
     SO_STAGE(6, so::rasterize_bwd_packed_launch(C, N, W, H, ts | wrap_flags, d->rec, d->backgrounds, list_off, d->flatten_ids, list_n,
                                                 list_cap, d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
                                                 d->absgrad, fin, stream));

@@ -137,6 +137,9 @@ class FusedEngine:
         self._compact_pending = False    # a deferred overflow happened with the bins at their limit: take_back falls back to compact lists
         self.void_steps = 0              # iterations discarded because the binning pass overflowed
         self.fell_back_to_compact = False
+        import os
+        self.tile_order_lpt = os.environ.get("SPLAT_ONE_AMD_TILE_ORDER", "1") != "0"   # (0: keep the XCD-local order, for A/B runs)
+        self._lpt = False                # the rasterisers take their tiles longest list first (_pick_tile_order)
         if self.device_refine:
             self._build_model_sets(int(capacity) if capacity else max(2 * splats["means"].shape[0], 1 << 20))
         self._build_workspace()
@@ -443,6 +446,9 @@ class FusedEngine:
         w["flatten_ids"] = e(cap, dtype=i32)
         w["render_colors"], w["render_alphas"] = e(C, H, W, 3), e(C, H, W, 1)
         w["last_ids"] = e(C, H, W, dtype=i32)
+        # workgroup -> tile table of the rasterisers, longest list first: built on the device every step while the one-wave-
+        # per-tile backward is selected (so_step_desc.tile_order; long lists everywhere -- see _pick_raster_impl)
+        w["tile_order"] = torch.zeros(M, dtype=i32, device=dev)
         w["loss_sums"] = w["counters"][2 * M + 3:2 * M + 9].view(torch.float32)
         w["dmaps"] = e(3, C, H, W, 3) if self.loss_kernels == 2 else None
         w["v_render_colors"] = e(C, H, W, 3)
@@ -571,6 +577,7 @@ class FusedEngine:
         d.tile_slots = p(w["tile_slots"])
         d.tile_cull = int(self.tile_cull)
         d.bin_capacity = self.bin_capacity
+        d.tile_order = p(w["tile_order"]) if (self._lpt and self.tile_order_lpt) else 0
         return d
 
     def _adam_args(self):
@@ -682,6 +689,7 @@ class FusedEngine:
         self.binned = False
         self.lean = False
         self.cfg["raster_impl"] = 0
+        self._lpt = True                 # (a view that does not fit binned lists is a skewed one: longest tile first)
         self.fell_back_to_compact = True
         self._capacity_hint = None
         self._build_workspace()              # (probe flag set: the next staged view is measured and the buffers sized 2x its count)
@@ -707,8 +715,9 @@ class FusedEngine:
             # --cloud-scale 0.2: 1050 us against 372 with the four waves per tile of the other kernel)
             mean_list = float(self.ws["counters"][:self.M].clamp(max=self.bin_capacity).float().mean().item())
             impl = self._pick_raster_impl(self.cfg["raster_impl"], mean_list, mx, first=True)
-            if impl != self.cfg["raster_impl"]:
-                self.cfg["raster_impl"] = impl
+            lpt = self._pick_tile_order(False, impl, mean_list, mx)
+            if impl != self.cfg["raster_impl"] or lpt != self._lpt:
+                self.cfg["raster_impl"], self._lpt = impl, lpt
                 self._graphs, self._graphs_fb, self._graphs_head, self._rows_desc = {}, {}, {}, None
             if headroom * mx > self.bin_capacity:    # other views / later iterations may fill a tile far more than this one
                 if 2 * mx > self._bin_limit:         # bins with any headroom do not fit the budget: compact lists instead
@@ -722,6 +731,18 @@ class FusedEngine:
         n = int(self.ws["counters"][2 * self.M + 1].item())
         if 1.25 * n > self.capacity:
             self._grow(2 * n)
+            return True
+        return False
+
+    def _pick_tile_order(self, now: bool, impl: int, mean_list: float, fullest: int) -> bool:
+        """Longest list first (so_step_desc.tile_order: one small launch per step) where the kernel's end is its longest tile:
+        with one wave per tile (impl 1) always; with four waves per tile when the lists are SKEWED -- a fullest tile of >= 512
+        entries and > 8x the mean: a cloud gathered in a few tiles, as real captures are -- with hysteresis (off below 6x / 384)."""
+        if impl == 1:
+            return True
+        if fullest >= 512 and fullest > 8.0 * max(mean_list, 1.0):
+            return True
+        if now and fullest >= 384 and fullest > 6.0 * max(mean_list, 1.0):
             return True
         return False
 
@@ -743,8 +764,9 @@ class FusedEngine:
         if fullest <= 0:
             return
         impl = self._pick_raster_impl(self.cfg["raster_impl"], total / max(self.M, 1), fullest)
-        if impl != self.cfg["raster_impl"]:
-            self.cfg["raster_impl"] = impl
+        lpt = self._pick_tile_order(self._lpt, impl, total / max(self.M, 1), fullest)
+        if impl != self.cfg["raster_impl"] or lpt != self._lpt:
+            self.cfg["raster_impl"], self._lpt = impl, lpt
             self._graph = None
             self._graph_fb = self._graph_opt = None
             self._graphs, self._graphs_fb, self._graphs_head, self._rows_desc = {}, {}, {}, None
