@@ -18,6 +18,10 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef SO_PP_EARLY_ATOMICS
+#define SO_PP_EARLY_ATOMICS 1   // k_preprocess_fwd: the binning atomics of small rectangles leave before the colour is evaluated
+#endif
+
 namespace so {
 
 struct CamP {
@@ -106,7 +110,8 @@ __device__ __forceinline__ unsigned lds_byte_address(const void *p) {   // gener
 #endif
 }
 struct CoefsLdsRow {
-  const float *c0;      // sh0 of this Gaussian (global)
+  float c0[3];          // sh0 of this Gaussian, loaded with the other per-Gaussian values (before the binning atomics leave: a
+                        // global load behind them would have to wait for them -- the vector memory counter is in order)
   unsigned row;         // byte address of this lane's shN row in LDS
   __device__ __forceinline__ void get(int k, float c[3]) const {
     if (k == 0) { c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; return; }
@@ -176,6 +181,8 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
     float cmx = 0.f, cmy = 0.f, cqa = 0.f, cqb = 0.f, cqc = 0.f, ctau = 0.f;   // what the exact tile test needs
     float cdepth = 0.f;
     int64_t idx = 0;
+    int32_t got[SO_TILE_SLOTS];   // binned lists: the slots the returning atomics of a small rectangle hand out (issued EARLY, below)
+    bool early = false;
     if (lin < total && (lin - (lin / N) * N) < n_live) {
     c = (int)(lin / N);
     const int64_t n = lin - (int64_t)c * N;
@@ -201,42 +208,13 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
     if (antialiased) op *= o.comp;
     if (radii) opacities[idx] = op;
     float r = 0.f, g = 0.f, b = 0.f;
+    float sh0v[3] = {0.f, 0.f, 0.f};
+    if constexpr (COOP) { sh0v[0] = attrs.sh0[3 * n]; sh0v[1] = attrs.sh0[3 * n + 1]; sh0v[2] = attrs.sh0[3 * n + 2]; }
 #ifdef PP_STAMPS
     if (o.radius == -12345) r = 1.f;      // (keeps the projection ahead of the stamp)
 #endif
     PP_STAMP(1);
-    if constexpr (COOP) {
-      // the rows must have landed before any lane reads its own -- and before the NEXT trip's DMA may overwrite them, so this
-      // wait is taken by every staged wave, whether or not one of its Gaussians is visible (an LDS-DMA is a pending write on
-      // the VM counter; staged waves are full, so all 64 lanes are here)
-      if (staged) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wave_lds_sync();
-#endif
-      }
-    }
     if (o.radius > 0) {
-      float dx = mean[0] - cam.pos[0], dy = mean[1] - cam.pos[1], dz = mean[2] - cam.pos[2];
-      const float inorm = rsqrtf(dx * dx + dy * dy + dz * dz);
-      dx *= inorm; dy *= inorm; dz *= inorm;
-      auto colour_from = [&](const auto &coef) {
-        sh_eval<float>(DEG, dx, dy, dz, [&](int k, float yk, float, float, float) {
-          float cf[3];
-          coef.get(k, cf);
-          r += yk * cf[0]; g += yk * cf[1]; b += yk * cf[2];
-        });
-      };
-      if constexpr (COOP) {
-        if (staged) {      // (wave-uniform)
-          colour_from(CoefsLdsRow{attrs.sh0 + 3 * n, my_lds_row});
-        } else {
-          colour_from(attrs.template coefs<DEG>(n));
-        }
-      } else {
-        colour_from(attrs.template coefs<DEG>(n));
-      }
-      r = fmaxf(r + 0.5f, 0.f); g = fmaxf(g + 0.5f, 0.f); b = fmaxf(b + 0.5f, 0.f);
       // first binning pass (same float arithmetic as isect.hip::tile_box)
       const float tile_r = (float)o.radius / tile_size;
       const float tx = o.m2d[0] / tile_size, ty = o.m2d[1] / tile_size;
@@ -255,6 +233,55 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
       cmx = o.m2d[0]; cmy = o.m2d[1]; cqa = o.conic[0]; cqb = o.conic[1]; cqc = o.conic[2];
       ctau = cull_tau(op);
       cdepth = o.depth;
+    }
+    if constexpr (COOP) {
+      // the rows must have landed before any lane reads its own -- and before the NEXT trip's DMA may overwrite them, so this
+      // wait is taken by every staged wave, whether or not one of its Gaussians is visible (an LDS-DMA is a pending write on
+      // the VM counter; staged waves are full, so all 64 lanes are here)
+      if (staged) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_lds_sync();
+#endif
+      }
+    }
+    if (SO_PP_EARLY_ATOMICS && bin_keys && tile_counts && cnt > 0 && cnt <= SO_TILE_SLOTS) {
+      // Binned lists, small rectangle: the returning atomics leave NOW -- behind the last global load this lane needs (the shN rows
+      // are in LDS, sh0 in registers) -- and are waited for after the colour has been evaluated and the records stored: the
+      // ~12 us a wave spent waiting for its slots (s_memrealtime stamps, round 2) run under ~6 us of its own work (round 5).
+      early = true;
+      int x = bx0, y = by0;
+#pragma unroll
+      for (int i = 0; i < SO_TILE_SLOTS; ++i) {
+        got[i] = -1;
+        if (i < cnt) {
+          if (!tile_cull || tile_touches(cmx, cmy, cqa, cqb, cqc, ctau, x, y, tile_size))
+            got[i] = atomicAdd(tile_counts + bin_counter_index((int64_t)c * n_tiles + y * tile_w + wrapx(x, tile_w), (int64_t)C * n_tiles), 1);
+          if (++x == bx1) { x = bx0; ++y; }
+        }
+      }
+    }
+    if (o.radius > 0) {
+      float dx = mean[0] - cam.pos[0], dy = mean[1] - cam.pos[1], dz = mean[2] - cam.pos[2];
+      const float inorm = rsqrtf(dx * dx + dy * dy + dz * dz);
+      dx *= inorm; dy *= inorm; dz *= inorm;
+      auto colour_from = [&](const auto &coef) {
+        sh_eval<float>(DEG, dx, dy, dz, [&](int k, float yk, float, float, float) {
+          float cf[3];
+          coef.get(k, cf);
+          r += yk * cf[0]; g += yk * cf[1]; b += yk * cf[2];
+        });
+      };
+      if constexpr (COOP) {
+        if (staged) {      // (wave-uniform)
+          colour_from(CoefsLdsRow{{sh0v[0], sh0v[1], sh0v[2]}, my_lds_row});
+        } else {
+          colour_from(attrs.template coefs<DEG>(n));
+        }
+      } else {
+        colour_from(attrs.template coefs<DEG>(n));
+      }
+      r = fmaxf(r + 0.5f, 0.f); g = fmaxf(g + 0.5f, 0.f); b = fmaxf(b + 0.5f, 0.f);
     }
     if (radii) {
       colors[3 * idx] = r; colors[3 * idx + 1] = g; colors[3 * idx + 2] = b;
@@ -305,15 +332,16 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
           // section is 15.0 -> 11.6 of a wave's 23.5 -> 21.6 us; what remains is the throughput of the memory-side atomic
           // units with every wave of the launch in this section at once (357k returning atomics in ~12 us).
           const uint64_t key = ((uint64_t)__float_as_uint(cdepth) << 32) | (uint64_t)(uint32_t)idx;
-          int32_t got[kOwn];
           int x = bx0, y = by0;
+          if (!early) {
 #pragma unroll
-          for (int i = 0; i < kOwn; ++i) {
-            got[i] = -1;
-            if (i < cnt) {
-              if (!tile_cull || tile_touches(cmx, cmy, cqa, cqb, cqc, ctau, x, y, tile_size))
-                got[i] = atomicAdd(tile_counts + bin_counter_index((int64_t)c * n_tiles + y * tile_w + wrapx(x, tile_w), (int64_t)C * n_tiles), 1);
-              if (++x == bx1) { x = bx0; ++y; }
+            for (int i = 0; i < kOwn; ++i) {
+              got[i] = -1;
+              if (i < cnt) {
+                if (!tile_cull || tile_touches(cmx, cmy, cqa, cqb, cqc, ctau, x, y, tile_size))
+                  got[i] = atomicAdd(tile_counts + bin_counter_index((int64_t)c * n_tiles + y * tile_w + wrapx(x, tile_w), (int64_t)C * n_tiles), 1);
+                if (++x == bx1) { x = bx0; ++y; }
+              }
             }
           }
           x = bx0; y = by0;

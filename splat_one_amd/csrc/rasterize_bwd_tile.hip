@@ -239,7 +239,16 @@ k_tile_order(int M, const int32_t *__restrict__ offsets, const int32_t *__restri
     const int k = (int)((float)len * scale);
     return kOrderClasses - 1 - (k < kOrderClasses ? k : kOrderClasses - 1);
   };
-  for (int t = tid; t < M; t += kOrderThreads) atomicAdd(&s_cls[cls_of(cached(t))], 1);
+  // (empty tiles -- most of a skewed view's -- are counted and placed once per WAVE: thousands of LDS atomics on one address
+  // cost the first version 21 us on a cloud gathered in a ninth of the image)
+  const int n_trips = (M + kOrderThreads - 1) / kOrderThreads;
+  for (int trip = 0; trip < n_trips; ++trip) {
+    const int t = trip * kOrderThreads + tid;
+    const int len = t < M ? cached(t) : -1;
+    const unsigned long long zmask = __ballot(len == 0);
+    if (len > 0) atomicAdd(&s_cls[cls_of(len)], 1);
+    else if (len == 0 && (zmask & ((1ull << (tid & 63)) - 1ull)) == 0ull) atomicAdd(&s_cls[kOrderClasses - 1], __popcll(zmask));
+  }
   __syncthreads();
   if (tid < 64) {                                    // exclusive scan of the 256 class counts by one wave: 4 per lane
     int v[4], run = 0;
@@ -256,7 +265,17 @@ k_tile_order(int M, const int32_t *__restrict__ offsets, const int32_t *__restri
     for (int j = 0; j < 4; ++j) { s_cls[4 * tid + j] = base; base += v[j]; }
   }
   __syncthreads();
-  for (int t = tid; t < M; t += kOrderThreads) order[atomicAdd(&s_cls[cls_of(cached(t))], 1)] = t;
+  for (int trip = 0; trip < n_trips; ++trip) {
+    const int t = trip * kOrderThreads + tid;
+    const int len = t < M ? cached(t) : -1;
+    const unsigned long long zmask = __ballot(len == 0);
+    const unsigned long long below = zmask & ((1ull << (tid & 63)) - 1ull);
+    int zbase = 0;
+    if (len == 0 && below == 0ull) zbase = atomicAdd(&s_cls[kOrderClasses - 1], __popcll(zmask));
+    if (zmask) zbase = __shfl(zbase, __ffsll((long long)zmask) - 1, 64);      // the leader's base, to every lane of the wave
+    if (len > 0) order[atomicAdd(&s_cls[cls_of(len)], 1)] = t;
+    else if (len == 0) order[zbase + __popcll(below)] = t;
+  }
 }
 
 int tile_order_launch(int C, int tile_w, int tile_h, const int32_t *offsets, const int32_t *n_isects_dev, int64_t n_isects_host,

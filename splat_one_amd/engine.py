@@ -24,7 +24,7 @@ from typing import Dict, Optional
 import torch
 from torch import Tensor
 
-from . import _lib
+from . import _lib, list_policy
 from .ops import camera_model_code
 
 PARAM_ORDER = ("means", "scales", "quats", "opacities", "sh0", "shN")
@@ -700,81 +700,69 @@ class FusedEngine:
         every device-side refinement; for callers that change the model in other ways and cannot afford a void iteration."""
         self._remeasure = True
 
+    def _list_state(self) -> "list_policy.ListState":
+        return list_policy.ListState(binned=self.binned, bin_capacity=int(self.bin_capacity), bin_limit=int(getattr(self, "_bin_limit", 0)),
+                                     capacity=int(self.capacity), raster_impl=int(self.cfg["raster_impl"]), lpt=bool(self._lpt),
+                                     on_overflow=self.on_overflow, tile16=self.cfg["tile_size"] == 16, absgrad=bool(self.cfg["absgrad"]),
+                                     compact_pending=bool(self._compact_pending), local_overflow_seen=int(self._local_overflow_seen))
+
+    def _apply(self, actions) -> bool:
+        """Execute what list_policy decided.  Returns True when the workspace changed under a staged view
+        ("restage")."""
+        restage = False
+        for act in actions:
+            kind = act[0]
+            if kind == "set_kernels":
+                self.cfg["raster_impl"], self._lpt = int(act[1]), bool(act[2])
+                self._graph = None
+                self._graph_fb = self._graph_opt = None
+                self._graphs, self._graphs_fb, self._graphs_head, self._rows_desc = {}, {}, {}, None
+            elif kind == "rebuild_bins":
+                self._bin_hint = int(act[1])
+                self._build_workspace()
+                self._probe_capacity = False
+            elif kind == "grow":
+                self._grow(int(act[1]))
+            elif kind == "fall_back_to_compact":
+                self._fall_back_to_compact_lists(int(act[1]))
+            elif kind == "take_back":
+                self.take_back(int(act[1]), int(act[2]), compact=bool(act[3]))
+            elif kind == "defer":
+                self._local_overflow_seen = int(act[1])
+                self._compact_pending = self._compact_pending or bool(act[2])
+            elif kind == "raise":
+                raise RuntimeError(act[1] + " -- raise Config.isect_capacity"
+                                   + (" (the per-tile bins are at bin_budget_bytes: Config.binned = False selects the compact lists)"
+                                      if self.binned and self.bin_capacity >= self._bin_limit else ""))
+            elif kind == "void":
+                self._void(int(act[1]))
+            elif kind == "restage":
+                restage = True
+            else:
+                raise AssertionError(f"unknown list-policy action {act!r}")
+        return restage
+
     def _measure_and_grow(self, headroom: int = 8) -> bool:
-        """Forward-only pass on the staged view, read its intersection count (one sync, once per workspace and once per
-        refinement).  Bins are rebuilt (at 8x the fullest tile) when they hold less than `headroom` times that tile."""
+        """Forward-only pass on the staged view, read its list lengths (one sync, once per workspace and once per refinement);
+        list_policy.on_probe decides: which backward rasteriser / tile order suits them (long lists everywhere: one wave per
+        tile -- 22 % fewer instructions, but a tile is then one wave's serial chain; measured crossover ~250 entries per tile,
+        profiles/r04_experiments.json -- and only where they are long EVERYWHERE: a cloud gathered in 250 tiles of 12 000 entries
+        has a mean of 390 too and leaves three quarters of the SIMDs idle with one wave per tile), and whether the bins hold
+        `headroom` times the fullest tile (else: rebuilt at 8x, or -- past the memory budget -- the compact lists)."""
         d = self._desc()
         _lib.call("so_render_forward", ctypes.byref(d), _lib.stream())
         if self.binned:
             mx = self._fullest_tile()
-            # which backward rasteriser: long lists (the dense initialisation regime, >= 256 entries per tile on average)
-            # run faster with one wave per tile -- 22 % fewer instructions -- short ones with one wave per 8x8 quadrant (a
-            # tile is then not one wave's serial chain); measured crossover ~250 entries (profiles/r04_experiments.json)
-            # ... and only when the lists are long EVERYWHERE: a cloud gathered in 250 tiles of 12 000 entries has a mean of 390
-            # over the 8160 tiles too, but one wave per tile then leaves three quarters of the SIMDs idle (2M Gaussians at
-            # --cloud-scale 0.2: 1050 us against 372 with the four waves per tile of the other kernel)
             mean_list = float(self.ws["counters"][:self.M].clamp(max=self.bin_capacity).float().mean().item())
-            impl = self._pick_raster_impl(self.cfg["raster_impl"], mean_list, mx, first=True)
-            lpt = self._pick_tile_order(False, impl, mean_list, mx)
-            if impl != self.cfg["raster_impl"] or lpt != self._lpt:
-                self.cfg["raster_impl"], self._lpt = impl, lpt
-                self._graphs, self._graphs_fb, self._graphs_head, self._rows_desc = {}, {}, {}, None
-            if headroom * mx > self.bin_capacity:    # other views / later iterations may fill a tile far more than this one
-                if 2 * mx > self._bin_limit:         # bins with any headroom do not fit the budget: compact lists instead
-                    self._fall_back_to_compact_lists(mx)
-                    return True
-                self._bin_hint = min(-(-8 * mx // 256) * 256, self._bin_limit)
-                self._build_workspace()
-                self._probe_capacity = False
-                return True
-            return False
+            return self._apply(list_policy.on_probe(self._list_state(), mx, mean_list, 0, headroom))
         n = int(self.ws["counters"][2 * self.M + 1].item())
-        if 1.25 * n > self.capacity:
-            self._grow(2 * n)
-            return True
-        return False
-
-    def _pick_tile_order(self, now: bool, impl: int, mean_list: float, fullest: int) -> bool:
-        """Longest list first (so_step_desc.tile_order: one small launch per step) where the kernel's end is its longest tile:
-        with one wave per tile (impl 1) always; with four waves per tile when the lists are SKEWED -- a fullest tile of >= 512
-        entries and > 8x the mean: a cloud gathered in a few tiles, as real captures are -- with hysteresis (off below 6x / 384)."""
-        if impl == 1:
-            return True
-        if fullest >= 512 and fullest > 8.0 * max(mean_list, 1.0):
-            return True
-        if now and fullest >= 384 and fullest > 6.0 * max(mean_list, 1.0):
-            return True
-        return False
-
-    def _pick_raster_impl(self, now: int, mean_list: float, fullest: int, first: bool = False) -> int:
-        """One wave per tile (1) for lists that are long everywhere -- mean >= 256 entries per tile and the fullest tile
-        within 6x of the mean -- else one wave per 8x8 quadrant (0); with hysteresis once running (back at < 192 or > 8x)."""
-        if self.cfg["tile_size"] != 16 or self.cfg["absgrad"]:
-            return 0
-        if mean_list >= 256.0 and fullest <= 6.0 * mean_list:
-            return 1
-        if first or mean_list < 192.0 or fullest > 8.0 * mean_list:
-            return 0
-        return now
+        return self._apply(list_policy.on_probe(self._list_state(), 0, 0.0, n, headroom))
 
     def _follow_lists(self, fullest: int, total: int) -> None:
         """The list lengths of an iteration two calls back (so_step_inputs gathers them on the device, no read-back): keep the
         bins at >= 2x the fullest tile -- rebuilt at 8x before a tile overflows, a model that device-side refinements grow
-        from 1M to 1.8M Gaussians multiplies its lists -- and the backward rasteriser that suits them (_pick_raster_impl)."""
-        if fullest <= 0:
-            return
-        impl = self._pick_raster_impl(self.cfg["raster_impl"], total / max(self.M, 1), fullest)
-        lpt = self._pick_tile_order(self._lpt, impl, total / max(self.M, 1), fullest)
-        if impl != self.cfg["raster_impl"] or lpt != self._lpt:
-            self.cfg["raster_impl"], self._lpt = impl, lpt
-            self._graph = None
-            self._graph_fb = self._graph_opt = None
-            self._graphs, self._graphs_fb, self._graphs_head, self._rows_desc = {}, {}, {}, None
-        if 2 * fullest > self.bin_capacity and self.bin_capacity < self._bin_limit and fullest <= self.bin_capacity:
-            # (a tile beyond the capacity has overflowed: that is _check_previous' business -- void iteration, take back)
-            self._bin_hint = min(-(-8 * fullest // 256) * 256, self._bin_limit)
-            self._build_workspace()
-            self._probe_capacity = False
+        from 1M to 1.8M Gaussians multiplies its lists -- and the kernels that suit them (list_policy.on_lists)."""
+        self._apply(list_policy.on_lists(self._list_state(), int(fullest), int(total), self.M))
 
     def _check_previous(self) -> None:
         """One step late and without a device-wide sync: did the iteration before the last one overflow its
@@ -792,30 +780,10 @@ class FusedEngine:
         torch.cuda.synchronize()
         c = self.ws["counters"]
         n_last, ov_last = int(c[2 * self.M + 1].item()), int(c[2 * self.M + 2].item())
-        at_limit = False
         if self.binned:                              # what overflowed is one tile's bin: size by the fullest tile
             n_prev = n_last = self._fullest_tile()
-            at_limit = self.bin_capacity >= self._bin_limit     # the bins cannot grow any further: compact lists from here on
-        if self._status_kind != "train":             # a forward-only render overflowed: no iteration to take back
-            if at_limit:
-                self._fall_back_to_compact_lists(n_last)
-            else:
-                self._grow(max(n_prev, n_last))
-            return
-        # the overflow policy comes BEFORE any change of layout: the compact-list fall-back used to return ahead of it,
-        # so that "raise" no longer raised and "defer" lost what this rank had seen
-        if self.on_overflow == "raise":
-            raise RuntimeError(f"tile-intersection buffers overflowed ({max(n_prev, n_last)} > capacity {self.capacity}); "
-                               "the affected iterations were skipped on the device -- raise Config.isect_capacity"
-                               + (" (the per-tile bins are at bin_budget_bytes: Config.binned = False selects the compact lists)" if at_limit else ""))
-        if self.on_overflow == "defer":
-            # data-parallel replicas: whether an iteration was void is decided by the flag the gradient reduce-scatter summed
-            # over ALL ranks (Runner._dp_check_void -> take_back on every rank alike); what this rank saw locally only sizes
-            # its own bins then -- or, with the bins at their limit, makes take_back switch this rank to the compact lists
-            self._local_overflow_seen = max(self._local_overflow_seen, n_prev, n_last, self.bin_capacity if self.binned else 0)
-            self._compact_pending = self._compact_pending or at_limit
-            return
-        self.take_back(1 + (1 if ov_last else 0), max(n_prev, n_last), compact=at_limit)
+        # the overflow policy comes BEFORE any change of layout: list_policy.on_overflow
+        self._apply(list_policy.on_overflow(self._list_state(), self._status_kind or "render", n_prev, n_last, bool(ov_last)))
 
     def local_overflow_recent(self):
         """(did one of the last two training iterations overflow THIS rank's buffers, entries needed) -- for replicas, whose
@@ -832,10 +800,8 @@ class FusedEngine:
         self._status_event = None                            # (what _check_previous would have looked at is handled)
         return seen, needed
 
-    def take_back(self, void: int, needed: int, grow: bool = True, compact: bool = False) -> None:
-        """`void` training iterations never happened (the optimiser skipped them on the device): undo the host-side step
-        bookkeeping, enlarge the intersection buffers for `needed` entries (binned: Gaussians over the fullest tile) and
-        say so.  compact (or a deferred overflow at the bin limit): the bins cannot grow -- switch to the compact lists."""
+    def _void(self, void: int) -> None:
+        """`void` training iterations never happened (the optimiser skipped them on the device): undo the host-side bookkeeping."""
         self.void_steps += void
         for _ in range(void):                        # undo _advance_host_counters for iterations that never happened
             self.steps_done -= 1
@@ -843,22 +809,25 @@ class FusedEngine:
                 self.optimizers[k].state[self.splats[k]]["step"] -= 1
             self.optimizers["means"].param_groups[0]["lr"] /= self.lr_gamma_means
         self._step_dev[0] = self.steps_done
+
+    def take_back(self, void: int, needed: int, grow: bool = True, compact: bool = False) -> None:
+        """`void` training iterations never happened: undo the host-side step bookkeeping, enlarge the intersection buffers for
+        `needed` entries (binned: Gaussians over the fullest tile) and say so.  compact (or a deferred overflow at the bin
+        limit): the bins cannot grow -- switch to the compact lists (list_policy.on_take_back)."""
         import warnings
         what = (f"{needed} Gaussians over one tile exceeded its bin of {self.bin_capacity} slots" if self.binned else
                 f"{needed} tile intersections exceeded the buffer capacity {self.capacity}")
+        actions = list_policy.on_take_back(self._list_state(), int(void), int(needed), bool(grow), bool(compact))
+        self._compact_pending = False
         if not grow:      # (a replica whose own buffers held: another rank's view overflowed)
             warnings.warn(f"splat_one_amd: {void} training iteration(s) skipped on every replica -- another rank's "
                           "tile-intersection buffers overflowed", RuntimeWarning)
-            return
-        compact = self.binned and (compact or self._compact_pending or self.bin_capacity >= self._bin_limit)
-        self._compact_pending = False
-        if compact:
+        elif any(a[0] == "fall_back_to_compact" for a in actions):
             warnings.warn(f"splat_one_amd: {void} training iteration(s) skipped -- {what}, and the bins are at their memory budget",
                           RuntimeWarning)
-            self._fall_back_to_compact_lists(needed)
-            return
-        warnings.warn(f"splat_one_amd: {void} training iteration(s) skipped -- {what}; buffers enlarged", RuntimeWarning)
-        self._grow(needed)
+        else:
+            warnings.warn(f"splat_one_amd: {void} training iteration(s) skipped -- {what}; buffers enlarged", RuntimeWarning)
+        self._apply(actions)
 
     def set_views(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor, schedule: bool = False) -> None:
         """Stage this step's cameras and target images.  camtoworlds[C,4,4] (inverted on the device),

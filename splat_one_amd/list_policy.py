@@ -1,0 +1,129 @@
+"""The fused engine's decisions about its tile lists, as ONE pure function per event (no torch, no device).
+
+`FusedEngine` owns buffers, graphs and the device; this module owns the POLICY: given what the engine knows (the state below) and
+an event (the capacity probe of a new workspace, the list statistics the device publishes one call late, an overflow found one
+step late, the caller's take-back), it returns the list of actions the engine then executes.  DESIGN.md section 5 prints the same
+table; tests/test_list_policy.py walks every (state, event) row of it against these functions, tests/test_gpu_engine.py runs the
+engine through the rows that need a device.
+
+Actions (tuples, executed in order by FusedEngine._apply):
+    ("set_kernels", raster_impl, lpt)   which backward rasteriser / tile order; drops every captured graph when it changes
+    ("rebuild_bins", slots)             new workspace with `slots` per tile (binned layout; the list-following path: 8x the fullest tile)
+    ("grow", needed)                    FusedEngine._grow: bins of >= 2 needed + 16 slots / compact buffers of 1.5 needed + 4096 entries
+    ("fall_back_to_compact", fullest)   leave the binned layout for good (bins at their memory budget), warn once
+    ("take_back", void, needed, compact) FusedEngine.take_back -> on_take_back below
+    ("void", n)                         n iterations never happened: undo the host-side step bookkeeping (step count, Adam step, lr)
+    ("defer", seen, at_limit)           replicas: remember what this rank saw; the caller decides from the summed flag
+    ("raise", message)                  RuntimeError
+    ("restage",)                        the probe changed the workspace: stage the view again on the new buffers
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Tuple
+
+Action = Tuple
+
+
+@dataclass
+class ListState:
+    binned: bool                 # per-tile bins (True) or gsplat's compact lists (False)
+    bin_capacity: int            # slots per tile (binned)
+    bin_limit: int               # most slots per tile the memory budget allows (binned)
+    capacity: int                # intersection entries of the compact buffers
+    raster_impl: int             # 0: one wave per 8x8 quadrant, 1: one wave per 16x16 tile (backward)
+    lpt: bool                    # rasterisers take their tiles longest list first
+    on_overflow: str             # "grow" | "raise" | "defer"
+    tile16: bool = True          # 16x16 tiles (the one-wave-per-tile kernel exists for them only)
+    absgrad: bool = False
+    compact_pending: bool = False      # a deferred overflow happened with the bins at their limit
+    local_overflow_seen: int = 0       # replicas: entries this rank saw overflow since the last take-back
+
+
+def _round_up(x: int, m: int) -> int:
+    return -(-int(x) // m) * m
+
+
+def pick_raster_impl(now: int, mean_list: float, fullest: int, tile16: bool, absgrad: bool, first: bool = False) -> int:
+    """One wave per tile (1) for lists that are long EVERYWHERE -- mean >= 256 entries per tile and the fullest tile within 6x
+    of the mean -- else one wave per 8x8 quadrant (0); hysteresis once running (back to 0 below 192 entries or beyond 8x)."""
+    if not tile16 or absgrad:
+        return 0
+    if mean_list >= 256.0 and fullest <= 6.0 * mean_list:
+        return 1
+    if first or mean_list < 192.0 or fullest > 8.0 * mean_list:
+        return 0
+    return now
+
+
+def pick_tile_order(now: bool, impl: int, mean_list: float, fullest: int) -> bool:
+    """Longest list first where a kernel's end is its longest tile: always with one wave per tile; with four waves per tile
+    when the lists are SKEWED (fullest tile >= 512 entries and > 8x the mean), with hysteresis (off below 384 / 6x)."""
+    m = max(mean_list, 1.0)
+    if impl == 1:
+        return True
+    if fullest >= 512 and fullest > 8.0 * m:
+        return True
+    return bool(now and fullest >= 384 and fullest > 6.0 * m)
+
+
+def on_probe(s: ListState, fullest: int, mean_list: float, n_isects: int, headroom: int) -> List[Action]:
+    """A forward-only pass on the first view of a workspace (headroom 8) or after a refinement (headroom 2) measured the lists."""
+    acts: List[Action] = []
+    if s.binned:
+        impl = pick_raster_impl(s.raster_impl, mean_list, fullest, s.tile16, s.absgrad, first=True)
+        lpt = pick_tile_order(False, impl, mean_list, fullest)
+        if (impl, lpt) != (s.raster_impl, s.lpt):
+            acts.append(("set_kernels", impl, lpt))
+        if headroom * fullest > s.bin_capacity:
+            if 2 * fullest > s.bin_limit:
+                return acts + [("fall_back_to_compact", fullest), ("restage",)]
+            return acts + [("rebuild_bins", min(_round_up(8 * fullest, 256), s.bin_limit)), ("restage",)]
+        return acts
+    if 1.25 * n_isects > s.capacity:
+        return [("grow", 2 * n_isects), ("restage",)]
+    return acts
+
+
+def on_lists(s: ListState, fullest: int, total: int, n_tiles: int) -> List[Action]:
+    """{max, sum} of the per-tile list lengths of a training iteration two calls back (gathered on the device, published through
+    host-mapped status words: no read-back).  Binned layout only."""
+    if not s.binned or fullest <= 0:
+        return []
+    acts: List[Action] = []
+    mean = total / max(n_tiles, 1)
+    impl = pick_raster_impl(s.raster_impl, mean, fullest, s.tile16, s.absgrad)
+    lpt = pick_tile_order(s.lpt, impl, mean, fullest)
+    if (impl, lpt) != (s.raster_impl, s.lpt):
+        acts.append(("set_kernels", impl, lpt))
+    # bins kept at >= 2x the fullest tile, rebuilt at 8x BEFORE a tile overflows (a tile beyond the capacity HAS overflowed:
+    # that is on_overflow's business)
+    if 2 * fullest > s.bin_capacity and s.bin_capacity < s.bin_limit and fullest <= s.bin_capacity:
+        acts.append(("rebuild_bins", min(_round_up(8 * fullest, 256), s.bin_limit)))
+    return acts
+
+
+def on_overflow(s: ListState, kind: str, n_prev: int, n_last: int, ov_last: bool) -> List[Action]:
+    """The iteration before the last one overflowed its lists (found one step late; the device skipped its optimiser step).
+    kind: what ran on the counters -- "train" or "render".  n_prev / n_last: entries needed by the two iterations in flight
+    (binned: Gaussians over the fullest tile).  ov_last: the last iteration overflowed too."""
+    needed = max(n_prev, n_last)
+    at_limit = s.binned and s.bin_capacity >= s.bin_limit
+    if kind != "train":                  # a forward-only render: no iteration to take back
+        return [("fall_back_to_compact", n_last)] if at_limit else [("grow", needed)]
+    if s.on_overflow == "raise":
+        return [("raise", f"tile-intersection buffers overflowed ({needed} > capacity); the affected iterations were skipped on the device")]
+    if s.on_overflow == "defer":
+        return [("defer", max(s.local_overflow_seen, needed, s.bin_capacity if s.binned else 0), at_limit)]
+    return [("take_back", 1 + (1 if ov_last else 0), needed, at_limit)]
+
+
+def on_take_back(s: ListState, void: int, needed: int, grow: bool, compact: bool) -> List[Action]:
+    """`void` iterations are taken back (single GPU: from on_overflow; replicas: Runner._dp_check_void from the summed flag).
+    grow False: another rank's view overflowed, this rank's buffers held."""
+    acts: List[Action] = [("void", void)]
+    if not grow:
+        return acts
+    if s.binned and (compact or s.compact_pending or s.bin_capacity >= s.bin_limit):
+        return acts + [("fall_back_to_compact", needed)]
+    return acts + [("grow", needed)]
