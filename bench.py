@@ -159,6 +159,7 @@ def self_launch(n_ranks, argv):
     for r in range(n_ranks):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    print("[bench] started ranks: pids " + " ".join(str(p.pid) for p in procs), file=sys.stderr)
     rc = 0
     alive = set(range(n_ranks))
     try:
@@ -212,22 +213,36 @@ XGMI_EFFICIENCY = 0.8                   # what a large RCCL transfer is assumed 
 RCCL_LAUNCH_US = 15.0                   # per grouped collective launch (latency floor), assumed
 
 
-def comm_model(N, K, n_chunks):
+def comm_model(N, K, n_chunks, t_step_ms=None, t_bwd_rows_ms=None, t_stage_ms=0.005):
     """Predicted reduce-scatter / all-gather time per optimiser step of the replicated scheme at 2 / 4 / 8 ranks, from bytes
     per xGMI link and direction -- printed next to the measured config.comm_ms so that the first
     multi-GPU run explains itself.  Direct exchange on the fully connected mesh: piece j of every rank's rows goes straight
-    to rank j, so a link carries rows x 4 (11 + 3 K) bytes / world per phase and direction."""
+    to rank j, so a link carries rows x 4 (11 + 3 K) bytes / world per phase and direction.
+    With t_step_ms (one GPU's step) and t_bwd_rows_ms (its per-Gaussian backward, the kernel the reduce-scatters run under):
+    what stays EXPOSED -- the last chunk's reduce-scatter plus whatever of the others the backward chunks cannot cover; the
+    all-gather minus the next iteration's staging launch (its tail runs under so_step_inputs: `RowShardedAdam.finish(
+    defer_gather_wait=True)`) -- the extra HBM round trip of the un-fused gradients (2 x 4 (11 + 3 K) N bytes at ~4 TB/s), and
+    `scaling_efficiency_predicted` = t_step / (t_step + exposed + un-fused)."""
     floats_per_row = 11 + 3 * K
     out = {"assumptions": {"xgmi_GBs_per_link_direction": XGMI_GBS_PER_LINK_DIRECTION, "efficiency": XGMI_EFFICIENCY,
                            "launch_us_per_grouped_collective": RCCL_LAUNCH_US, "pattern": "direct (piece j -> rank j), all links busy",
-                           "collectives_per_phase": 2 * n_chunks}, "by_world": {}}
+                           "collectives_per_phase": 2 * n_chunks, "one_gpu_step_ms": t_step_ms, "backward_rows_ms": t_bwd_rows_ms,
+                           "staging_ms_the_gather_tail_runs_under": t_stage_ms, "unfused_gradient_round_trip_TBs": 4.0}, "by_world": {}}
     for w in (2, 4, 8):
         q = w * 64 * n_chunks
         span = -(-N // q) * q
         per_link = span * floats_per_row * 4.0 / w
         ms = per_link / (XGMI_GBS_PER_LINK_DIRECTION * XGMI_EFFICIENCY * 1e9) * 1e3 + 2 * n_chunks * RCCL_LAUNCH_US * 1e-3
-        out["by_world"][str(w)] = {"rows_exchanged": span, "bytes_per_link_and_direction_per_phase": per_link,
-                                   "reduce_scatter_ms": ms, "all_gather_ms": ms, "ring_bytes_per_link_per_phase": per_link * (w - 1)}
+        e = {"rows_exchanged": span, "bytes_per_link_and_direction_per_phase": per_link,
+             "reduce_scatter_ms": ms, "all_gather_ms": ms, "ring_bytes_per_link_per_phase": per_link * (w - 1)}
+        if t_step_ms:
+            cover = (t_bwd_rows_ms or 0.0) * (n_chunks - 1) / n_chunks          # backward chunks 1 .. n-1 run over reductions 0 .. n-2
+            rs_exposed = ms / n_chunks + max(0.0, ms * (n_chunks - 1) / n_chunks - cover)
+            ag_exposed = max(0.0, ms - t_stage_ms)
+            unfused = 2.0 * N * floats_per_row * 4.0 / 4.0e12 * 1e3
+            e.update(reduce_scatter_exposed_ms=rs_exposed, all_gather_exposed_ms=ag_exposed, unfused_gradient_ms=unfused,
+                     scaling_efficiency_predicted=t_step_ms / (t_step_ms + rs_exposed + ag_exposed + unfused))
+        out["by_world"][str(w)] = e
     return out
 
 
@@ -277,6 +292,9 @@ def main():
                     help="start the ranks, build the process group, print what it reports (config.rccl) and exit: no kernel "
                          "runs (the CPU test of the self-launcher; works without a GPU over gloo)")
     ap.add_argument("--fail-rank", type=int, default=-1, help="--launch-check: this rank exits with code 3 (failure propagation)")
+    ap.add_argument("--fail-late", action="store_true",
+                    help="--launch-check --fail-rank R: rank R fails AFTER the group is up and has run its first collectives "
+                         "(the others are then inside a barrier it never joins)")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         # no launcher: start the N ranks ourselves, before anything in this process touches the GPU
@@ -300,10 +318,15 @@ def main():
     assert world == args.gpus, (f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
                                 f"--nproc-per-node {args.gpus}, or with no launcher at all")
     if args.launch_check:
-        if rank == args.fail_rank:
+        if rank == args.fail_rank and not args.fail_late:
             sys.exit(3)
         rep = rank_report(dist, local_rank, local_rank if n_dev else None) if world > 1 else None
-        if rank == 0:
+        if world > 1 and args.fail_late and args.fail_rank >= 0:
+            dist.barrier()                       # the group is up and has worked
+            if rank == args.fail_rank:
+                os._exit(3)                      # dies without leaving the group: the others wait in the barrier below
+            time.sleep(0.5)
+        if rank == 0 and not (args.fail_late and args.fail_rank >= 0):
             print(json.dumps({"launch_check": True, "n_gpus": world, "config": {"rccl": rep}}))
         if world > 1:
             dist.barrier()
@@ -782,7 +805,10 @@ def main():
                                                                 f", replicated Gaussians: reduce-scatter / 1/{world} Adam / all-gather of the "
                                                                 f"gradient SoA in {getattr(runner, '_dp_chunks', cfg.dp_chunks)} chunk(s) over RCCL")),
                    "dp_mode_probe_ms_per_step": dp_probe,
-                   "rccl": rccl, "comm_ms": comm_ms, "comm_model": comm_model(N, K, getattr(runner, "_dp_chunks", 1) or 1)},
+                   "rccl": rccl, "comm_ms": comm_ms,
+                   "comm_model": comm_model(N, K, getattr(runner, "_dp_chunks", 1) or 1,
+                                            t_step_ms=(elapsed / args.steps * 1e3 if world == 1 else None),
+                                            t_bwd_rows_ms=((prof.get("so_preprocess_bwd") or (0, 0.0))[1] if world == 1 else None))},
         "forward_mpix_per_s": None if runner.sharded else world * P / fwd_s / 1e6,
         "hbm_iter_fraction": b_iter / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9),
         "algorithmic_bytes_per_iter": b_iter,
@@ -799,6 +825,14 @@ def main():
         "roofline_by_kernel": by_kernel,
         "void_steps": void_steps,
     }
+    if world > 1:
+        # what config.comm_model expects of this world size, from THIS run's own compute time (step minus the measured waits)
+        waits = ((comm_ms or {}).get("reduce_scatter_wait_ms") or 0.0) + ((comm_ms or {}).get("all_gather_wait_ms") or 0.0)
+        t_comp = max(elapsed / args.steps * 1e3 - waits, 1e-6)
+        cm = comm_model(N, K, getattr(runner, "_dp_chunks", 1) or 1, t_step_ms=t_comp,
+                        t_bwd_rows_ms=(prof.get("so_preprocess_bwd") or (0, 0.0))[1])["by_world"].get(str(world))
+        out["scaling_efficiency_predicted"] = (cm or {}).get("scaling_efficiency_predicted")
+        out["scaling_efficiency_predicted_from"] = {"compute_ms_per_step_this_run": t_comp, "measured_waits_ms": waits, "model": cm}
     if args.densify:
         out["densify"] = {"every": args.densify, "gaussians_before_timed_region": n_before_timed, "gaussians_after": N,
                           "device_side": bool(fused and getattr(runner._engine, "device_refine", False)),

@@ -309,6 +309,8 @@ class RowShardedAdam:
         self.flags: Optional[torch.Tensor] = None
         self._rs: List[list] = []
         self._n = 0
+        self._pending_ag: list = []              # all-gathers of the last finish(defer_gather_wait=True)
+        self._pending_tm = None
 
     def _ensure_mode(self, device) -> str:
         if self.mode is None:
@@ -416,6 +418,7 @@ class RowShardedAdam:
     @torch.no_grad()
     def begin(self, n: int, device, cuda: bool) -> None:
         """Start a step over n live rows.  (world == 1: nothing to exchange.)"""
+        self.wait_gathers()                       # (a deferred gather of the previous step: the rows are about to be reused)
         self._n, self._rs, self._void_src = int(n), [None] * self.n_chunks, None
         if self.world == 1:
             return
@@ -460,11 +463,28 @@ class RowShardedAdam:
         return self.flags[self.rank * self.FLAG_STRIDE:self.rank * self.FLAG_STRIDE + 1]
 
     @torch.no_grad()
+    def wait_gathers(self) -> None:
+        """The parameter all-gathers of the last `finish(defer_gather_wait=True)`: make the current stream (CPU tensors: the host)
+        wait for them.  Idempotent and cheap; called before anything reads or writes the parameters (FusedEngine calls it in
+        front of every launch that does, Runner before handing out `splats`)."""
+        ag, self._pending_ag = getattr(self, "_pending_ag", None) or [], []
+        if not ag:
+            return
+        for w in ag:
+            w.wait()
+        tm, self._pending_tm = getattr(self, "_pending_tm", None), None
+        if tm is not None:
+            tm[0].mark(tm[1])
+            tm[0].stop()
+
+    @torch.no_grad()
     def finish(self, grads: Dict[str, torch.Tensor], params: Dict[str, torch.Tensor],
-               adam_fn: Callable[..., None]) -> None:
+               adam_fn: Callable[..., None], defer_gather_wait: bool = False) -> None:
         """Wait for the reductions chunk by chunk, run adam_fn(names, row_start, row_stop, skip, grad_scale) on the own live
         rows of each, all-gather the parameter rows.  skip = this rank's summed void flag (device float), grad_scale =
-        1 / world (mean over the views of all ranks)."""
+        1 / world (mean over the views of all ranks).  defer_gather_wait: return with the all-gathers in flight -- the caller
+        stages the next iteration (so_step_inputs, a target upload: nothing there touches the parameters) and calls
+        `wait_gathers()` before the first kernel that does, so the gathers' tail runs under that staging."""
         n = self._n
         groups = [tuple(k for k in g if k in grads) for g in self.GROUPS]
         if self.world == 1:
@@ -489,11 +509,9 @@ class RowShardedAdam:
                 ag += self._all_gather([params[k] for k in g], n, c)
         if tm is not None:
             tm.mark(cuda)                                                 # every Adam launched, every all-gather issued
-        for w in ag:
-            w.wait()
-        if tm is not None:
-            tm.mark(cuda)
-            tm.stop()
+        self._pending_ag, self._pending_tm = ag, ((tm, cuda) if tm is not None else None)
+        if not defer_gather_wait:
+            self.wait_gathers()
 
     @torch.no_grad()
     def step(self, grads: Dict[str, torch.Tensor], params: Dict[str, torch.Tensor], n: int,
@@ -507,6 +525,7 @@ class RowShardedAdam:
 
     @torch.no_grad()
     def gather(self, tensors: List[torch.Tensor], n: int) -> None:
+        self.wait_gathers()
         if self.world == 1 or not tensors:
             return
         self._ensure_mode(tensors[0].device)

@@ -139,7 +139,8 @@ class FusedEngine:
         self.fell_back_to_compact = False
         import os
         self.tile_order_lpt = os.environ.get("SPLAT_ONE_AMD_TILE_ORDER", "1") != "0"   # (0: keep the XCD-local order, for A/B runs)
-        self._lpt = False                # the rasterisers take their tiles longest list first (_pick_tile_order)
+        self._lpt = False                # the rasterisers take their tiles longest list first (list_policy.pick_tile_order)
+        self.before_param_access = None  # replicas: RowShardedAdam.wait_gathers (see _params_ready)
         if self.device_refine:
             self._build_model_sets(int(capacity) if capacity else max(2 * splats["means"].shape[0], 1 << 20))
         self._build_workspace()
@@ -269,6 +270,7 @@ class FusedEngine:
     def refine(self, strategy, step: int, scene_scale: float, seed: int = 0) -> None:
         """One DefaultStrategy refinement (duplicate / split / prune) on the device: active set -> other set, which
         becomes the active one.  Statistics are zeroed.  Nothing is read back; `refine_report()` gives the counts."""
+        self._params_ready()
         assert self.device_refine
         self._last_refine = (strategy, step, scene_scale, seed)
         with self._lock:
@@ -289,6 +291,7 @@ class FusedEngine:
         """One MCMCStrategy refinement (gsplat `relocate` + `sample_add`) in place on the device-resident model: dead
         Gaussians take the place of samples drawn by opacity, 5 % more are added up to cap_max, N changes in device memory.
         Nothing is read back; `refine_report()` gives the counts."""
+        self._params_ready()
         assert self.device_refine and self.model_sets == 1, "mcmc_refine needs FusedEngine(device_refine=True, model_sets=1)"
         with self._lock:
             prm = _lib.McmcParams(float(strategy.min_opacity), int(min(strategy.cap_max, self.cap)), int(seed) & 0xFFFFFFFFFFFFFFFF,
@@ -314,6 +317,7 @@ class FusedEngine:
         nz = self.mcmc_noise
         if nz is None:
             return
+        self._params_ready()
         if "lr0" not in nz:      # base of the means' ExponentialLR: the optimiser's current lr un-decayed to step 0
             nz["lr0"] = self.optimizers["means"].param_groups[0]["lr"] / (self.lr_gamma_means ** self.steps_done)
         p = _lib.ptr
@@ -332,6 +336,7 @@ class FusedEngine:
 
     def reset_opacity(self, value: float) -> None:
         """gsplat `reset_opa`: opacity logits clamped to logit(value), their Adam moments zeroed -- in place, on the device."""
+        self._params_ready()
         assert self.device_refine
         with self._lock:
             a = self.sets[self.active]
@@ -519,6 +524,7 @@ class FusedEngine:
     def refresh_attrs(self) -> None:
         """Rebuild the float16 attribute rows from the float32 masters (after anything but the engine's own
         optimiser step wrote quats / scales / sh0 / shN: densification, relocation, a loaded checkpoint)."""
+        self._params_ready()
         if self.attr_dtype != "f16":
             return
         s, p = self.splats, _lib.ptr
@@ -707,7 +713,7 @@ class FusedEngine:
                                      compact_pending=bool(self._compact_pending), local_overflow_seen=int(self._local_overflow_seen))
 
     def _apply(self, actions) -> bool:
-        """Execute what list_policy decided (DESIGN.md section 5).  Returns True when the workspace changed under a staged view
+        """Execute what list_policy decided (DESIGN.md section 4.3).  Returns True when the workspace changed under a staged view
         ("restage")."""
         restage = False
         for act in actions:
@@ -887,12 +893,21 @@ class FusedEngine:
         assert camtoworlds.shape == (self.C, 4, 4) and Ks.shape == (self.C, 3, 3), (camtoworlds.shape, Ks.shape)
         self._stage(camtoworlds, Ks, None, False)
 
+    def _params_ready(self) -> None:
+        """Replicas: the parameter all-gathers of the previous optimiser step may still be in flight
+        (distributed.RowShardedAdam.finish(defer_gather_wait=True)): whatever reads or writes the parameters waits for them
+        first.  `before_param_access` is set by the trainer; None on one GPU."""
+        hook = self.before_param_access
+        if hook is not None:
+            hook()
+
     def _consume_staging(self) -> None:
         """Every launch of the step needs zeroed counters: re-stage (zero only) when the caller repeats a
         launch on the same inputs."""
         if not self._staged:
             self._stage(None, None, None, False)
         self._staged = False
+        self._params_ready()
 
     def render(self):
         """Forward only on the current cameras: returns (render_colors[C,H,W,3], render_alphas[C,H,W,1])

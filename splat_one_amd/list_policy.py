@@ -2,7 +2,7 @@
 
 `FusedEngine` owns buffers, graphs and the device; this module owns the POLICY: given what the engine knows (the state below) and
 an event (the capacity probe of a new workspace, the list statistics the device publishes one call late, an overflow found one
-step late, the caller's take-back), it returns the list of actions the engine then executes.  DESIGN.md section 5 prints the same
+step late, the caller's take-back), it returns the list of actions the engine then executes.  DESIGN.md section 4.3 prints the same
 table; tests/test_list_policy.py walks every (state, event) row of it against these functions, tests/test_gpu_engine.py runs the
 engine through the rows that need a device.
 

@@ -248,6 +248,8 @@ class Runner:
     # (one device->host read of N after a refinement, none otherwise) -- the training step itself never touches them.
     def _fresh(self):
         eng = self.__dict__.get("_engine")
+        if eng is not None and getattr(eng, "before_param_access", None) is not None:
+            eng.before_param_access()            # (replicas: parameter all-gathers still in flight)
         if eng is not None and getattr(eng, "_host_stale", False):
             eng.sync_host()
 
@@ -732,7 +734,10 @@ class Runner:
                 lo, hi = ra.chunk_range(n, c)
                 eng.bwd_rows(lo, hi)                                       # (rows past the live count: the kernel clamps)
                 ra.reduce_chunk(c, grads, eng.ws["ovf_f32"])
-            ra.finish(grads, params, eng.adam_on_rows)
+            # the parameter all-gathers stay in flight: the next iteration's staging (so_step_inputs, a target upload) runs under
+            # their tail, the engine waits for them in front of the first launch that touches the parameters
+            eng.before_param_access = ra.wait_gathers
+            ra.finish(grads, params, eng.adam_on_rows, defer_gather_wait=True)
             self._dp_note_void(ra.void_flag())
             eng.refresh_attrs()              # float16 attribute rows (if any) follow the gathered masters
             eng._advance_host_counters()

@@ -49,6 +49,28 @@ def test_failed_rank_gives_nonzero_exit():
     assert "rank 1 exited with code 3" in r.stderr
 
 
+def test_a_rank_that_dies_late_ends_all_eight_ranks_and_leaves_no_orphans():
+    """`bench.py --gpus 8` (what the driver's scaling run starts): the process group comes up, works, and THEN one rank dies
+    while the seven others wait in a collective it never joins.  The parent must notice, stop the others -- by PID -- and exit
+    non-zero; none of the eight children may outlive it."""
+    import re
+    import time
+    import psutil
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--launch-check", "--fail-rank", "5", "--fail-late"], env=_clean_env(),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert "rank 5 exited with code 3" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    m = re.search(r"started ranks: pids ([0-9 ]+)", r.stderr)
+    assert m, r.stderr[-2000:]
+    pids = [int(x) for x in m.group(1).split()]
+    assert len(pids) == 8
+    time.sleep(0.5)
+    alive = [p for p in pids if psutil.pid_exists(p) and psutil.Process(p).status() != psutil.STATUS_ZOMBIE]
+    assert not alive, alive
+    assert time.time() - t0 < 300            # stopped by the parent, not by a collective's timeout
+
+
 def test_under_a_launcher_no_second_spawn():
     """RANK in the environment (torch.distributed.run's contract): bench.py adopts the rank it was given."""
     import socket

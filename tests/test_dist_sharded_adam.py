@@ -182,7 +182,14 @@ def _row_worker(local_rank, world_rank, world_size, args):
             ra.begin(N, "cpu", False)
             for c in range(ra.n_chunks):
                 ra.reduce_chunk(c, G, mine)
-            ra.finish(G, P, adam_fn)
+            # ... with the parameter all-gathers left in flight (round 5: their tail runs under the next iteration's staging);
+            # the next begin() / gather() / an explicit wait_gathers() collects them
+            ra.finish(G, P, adam_fn, defer_gather_wait=(step % 4 == 1))
+            if step % 4 == 1 and world_size > 1:
+                assert ra._pending_ag
+                if step == len(Ns) - 1:
+                    ra.wait_gathers()
+                    assert not ra._pending_ag
         assert float(ra.void_flag()[0]) == (2.0 if step == void_at else 0.0)
         done += 0 if step == void_at else 1
         own = ra.owned(N)

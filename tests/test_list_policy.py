@@ -1,7 +1,7 @@
-"""The fused engine's list-policy state machine (DESIGN.md section 5), row by row, on the CPU.
+"""The fused engine's list-policy state machine (DESIGN.md section 4.3), row by row, on the CPU.
 
 splat_one_amd/list_policy.py holds the decisions as pure functions; `FusedEngine._apply` executes the actions they return.
-TABLE below IS the table of DESIGN.md section 5 (one row per (state, event) pair that behaves differently); the first test
+TABLE below IS the table of DESIGN.md section 4.3 (one row per (state, event) pair that behaves differently); the first test
 walks it against the functions, the second drives `FusedEngine._apply` / `take_back` with a stubbed engine (no library, no device)
 and checks that every action kind reaches the method that implements it, in order."""
 import types

@@ -51,6 +51,25 @@ def collected_at(run_dir, kind):
             "runs": len(vals), "workload": vals[0][3]}
 
 
+COMPLEMENTARY = ("so_isect_fill",)      # stages whose kernels ALL run in one iteration (sum); elsewhere they are alternatives (mean)
+
+
+def aggregate(per_kernel, calls):
+    """{stage: value per launch} from {kernel: mean per launch} and {kernel: launches}: the per-tile sort launches up to four
+    kernels per iteration (their means add, weighted by how often each ran); every other stage is ONE kernel per iteration out
+    of several variants (SH-degree instantiations of the first steps, the two backward rasterisers): launch-weighted mean."""
+    by_stage = {}
+    for k, v in per_kernel.items():
+        st = stage_of(k)
+        if st and calls.get(k):
+            by_stage.setdefault(st, []).append((calls[k], v))
+    out = {}
+    for st, lst in by_stage.items():
+        tot = sum(c * v for c, v in lst)
+        out[st] = tot / (max(c for c, _ in lst) if st in COMPLEMENTARY else sum(c for c, _ in lst))
+    return out
+
+
 def one(wl):
     run = os.path.join(SRC, "r05_" + wl)
     if not os.path.isdir(run):
@@ -63,51 +82,55 @@ def one(wl):
             shutil.copy(os.path.join(run, a), os.path.join(DST, b))
     ks = sorted(glob.glob(os.path.join(run, "prof", "**", "bench_kernel_stats.csv"), recursive=True))
     traffic = valu = ku = None
+    calls = {}
     if ks:
         shutil.copy(ks[0], os.path.join(DST, f"{tag}_kernel_stats.csv"))
         rows = list(csv.DictReader(open(ks[0])))
-        by_stage = {}
+        calls = {r["Name"].split("(")[0]: int(r["Calls"]) for r in rows}
+        ku = {st: round(v, 2) for st, v in aggregate({r["Name"].split("(")[0]: float(r["AverageNs"]) / 1e3 for r in rows}, calls).items()}
+        ku["_kernels"] = {}
         for r in rows:
             st = stage_of(r["Name"])
             if st:
-                by_stage.setdefault(st, []).append((int(r["Calls"]), float(r["AverageNs"]) / 1e3, r["Name"].split("(")[0]))
-        ku = {}
-        for st, lst in by_stage.items():
-            primary = max(c for c, _, _ in lst)
-            ku[st] = round(sum(c * us for c, us, _ in lst) / primary, 2)
-        ku["_kernels"] = {st: [n for _, _, n in lst] for st, lst in by_stage.items()}
+                ku["_kernels"].setdefault(st, []).append({"kernel": r["Name"].split("(")[0], "calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 2)})
         ku["_collected_at"] = collected_at(run, "prof")
-        ku["_note"] = (f"rocprofv3 --kernel-trace --stats of the bench command of workload {wl}: per stage, sum over its kernels of "
-                       f"AverageNs x Calls / calls of the stage's most-launched kernel; source profiles/{tag}_kernel_stats.csv")
+        ku["_note"] = (f"rocprofv3 --kernel-trace --stats of the bench command of workload {wl}: per stage the launch-weighted mean of its kernel "
+                       f"variants (the per-tile sort: the sum of its kernels); source profiles/{tag}_kernel_stats.csv")
     tp = os.path.join(run, "pmc", "traffic_summary.json")
     if os.path.exists(tp):
-        d = json.load(open(tp)).get("_per_stage", {})
-        traffic = {st: v["hbm_bytes_per_launch_corrected"] for st, v in d.items()}
+        d = {k: v for k, v in json.load(open(tp)).items() if not k.startswith("_")}
+        c2 = {k: v["launches"] for k, v in d.items()}
+        traffic = aggregate({k: v["hbm_bytes_per_launch_corrected"] for k, v in d.items()}, c2)
         traffic["_collected_at"] = collected_at(run, "pmc")
         traffic["_note"] = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_profiles_r05.sh WL={wl}), KB -> bytes, FETCH_SIZE doubled "
-                            f"as MI355X_MICROARCH.md prescribes for gfx950, per launch of each stage's primary kernel; source profiles/{tag}_pmc_traffic.json")
+                            f"as MI355X_MICROARCH.md prescribes for gfx950, per launch (launch-weighted over a stage's kernel variants; the sort: summed); "
+                            f"source profiles/{tag}_pmc_traffic.json")
     sp = os.path.join(run, "pmc", "sq_summary.json")
     if os.path.exists(sp):
-        d = json.load(open(sp)).get("_per_stage", {})
+        d = {k: v for k, v in json.load(open(sp)).items() if not k.startswith("_")}
+        names = sorted({c for v in d.values() for c in v})
+        per = {c: aggregate({k: v[c] for k, v in d.items() if c in v}, calls) for c in names}
         valu = {}
-        for st, c in d.items():
-            if "SQ_INSTS_VALU" not in c:
-                continue
-            valu[st] = {"wave_instructions": c["SQ_INSTS_VALU"], "waves": c.get("SQ_WAVES"),
-                        "active_lane_fraction": (c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
-                                                 if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU") else None),
-                        # share of the kernel's SIMD-cycles in which a VALU instruction was executing: SQ_ACTIVE_INST_VALU counts
-                        # quad-cycles (x 4) over SQ_BUSY_CYCLES per SE ... reported as measured, see profiles/README.md
-                        "valu_active_quad_cycles": c.get("SQ_ACTIVE_INST_VALU"), "busy_cycles": c.get("SQ_BUSY_CYCLES"),
-                        "wave_cycles": c.get("SQ_WAVE_CYCLES"), "wait_inst_any": c.get("SQ_WAIT_INST_ANY")}
+        for st in per.get("SQ_INSTS_VALU", {}):
+            g = lambda c: per.get(c, {}).get(st)
+            valu[st] = {"wave_instructions": round(g("SQ_INSTS_VALU")), "waves": g("SQ_WAVES"),
+                        "active_lane_fraction": (g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU"))
+                                                 if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU") else None),
+                        "valu_active_quad_cycles": g("SQ_ACTIVE_INST_VALU"), "busy_cycles": g("SQ_BUSY_CYCLES"),
+                        "wave_quad_cycles": g("SQ_WAVE_CYCLES"), "wait_inst_any": g("SQ_WAIT_INST_ANY")}
+            us = (ku or {}).get(st)
+            if us and g("SQ_ACTIVE_INST_VALU") and g("SQ_WAVE_CYCLES"):
+                simd_cycles = us * 1e-6 * 2.4e9 * 1024            # 1024 SIMDs at 2.4 GHz over the kernel's rocprofv3 duration
+                valu[st]["vector_pipe_busy"] = round(4.0 * g("SQ_ACTIVE_INST_VALU") / simd_cycles, 3)
+                valu[st]["resident_waves_per_simd"] = round(4.0 * g("SQ_WAVE_CYCLES") / simd_cycles, 2)
         valu["_collected_at"] = collected_at(run, "pmc")
-        valu["_note"] = (f"rocprofv3 --pmc SQ_* (two passes, tools/gpu_profiles_r05.sh WL={wl}), per launch of each stage's primary kernel; "
-                         f"active_lane_fraction = exec-mask lanes per issued VALU instruction / 64; source profiles/{tag}_sq_counters.json")
+        valu["_note"] = (f"rocprofv3 --pmc SQ_* (two passes, tools/gpu_profiles_r05.sh WL={wl}), per launch; active_lane_fraction = exec-mask lanes per "
+                         f"issued VALU instruction / 64; vector_pipe_busy = 4 x SQ_ACTIVE_INST_VALU (quad-cycles) / (1024 SIMDs x 2.4 GHz x the kernel's "
+                         f"rocprofv3 duration), resident_waves_per_simd = 4 x SQ_WAVE_CYCLES over the same; source profiles/{tag}_sq_counters.json")
         if wl in ("c2", "c2d"):
             valu["_useful_lane_fraction_model"] = {"so_rasterize_bwd": 0.393, "so_rasterize_fwd": 0.393,
                                                    "source": "tools/passsim.py mcmc (profiles/r02_experiments.json)"}
-    print(wl, "->", {k: (v if not isinstance(v, dict) else "...") for k, v in (ku or {}).items() if not k.startswith("_")},
-          (traffic or {}).get("_collected_at"))
+    print(wl, "->", {k: v for k, v in (ku or {}).items() if not k.startswith("_")}, (traffic or {}).get("_collected_at"))
     return traffic, valu, ku
 
 
