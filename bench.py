@@ -507,6 +507,12 @@ def main():
     # densification measure the forward after their warm-up refinements instead (the model it renders is the grown one).
     fwd_s = None if args.densify else measure_forward()
     I_start = None if args.densify else last_I()
+    if preparation_steps:
+        # ... and the GPU gets its load back before the W warm-up steps: after the read-backs above it runs ~5 % slower for its
+        # next ~30 iterations (--step-trace), more than a small --warmup covers.  Untimed, named in the line.
+        for _ in range(2 * len(views)):
+            step_once()
+        preparation_steps += 2 * len(views)
 
     # warm-up
     if not fused:
