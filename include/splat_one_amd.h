@@ -511,6 +511,11 @@ typedef struct so_step_desc {
    * long-list regimes (raster_impl == 1: a tile is one wave's serial chain, so the kernel cannot end before its longest
    * tile does -- started last, that tile runs on alone).  Speed only: any tile order gives the same images and gradients. */
   int32_t *tile_order;
+  /* != 0 (binned lists, 16x16 tiles): the per-tile sort is NOT launched; the forward rasteriser's workgroup sorts the list of
+   * its own tile before it walks it (<= 256 keys: one wave, in registers; <= 2048: the workgroup; longer: a slow scratch-free
+   * rank sort) and writes flatten_ids for the backward.  One launch and one pass over the keys fewer where lists are short
+   * everywhere; the same lists, images and gradients either way. */
+  int32_t sort_in_rasteriser;
 } so_step_desc;
 typedef struct so_adam_fuse {
   so_adam_group groups[6]; /* means, log_scales, quats, logit_opacities, sh0, shN: param / exp_avg / exp_avg_sq (grad unused) */

@@ -10,13 +10,20 @@
 // Gaussians that cannot reach alpha >= 1/255 anywhere in the quadrant cost one lane-compare
 // instead of 64 pixel evaluations.  The cull is exact: it never changes a pixel.
 #include "rasterize_common.hpp"
+#include "wave_sort.hpp"          // the prologue sort (SORT): wave_sort_list, sort_mid_chunks, rank_sort_global
 
 namespace so {
 
 // PACKED: the four per-Gaussian inputs come from ONE 64-byte record rec[g] = {x,y,ca,cb | cc,opac,r,g |
 // b,..} written by so_preprocess_fwd (one cache line per gathered Gaussian instead of four); passed
 // through the `colors` pointer, D must be 3.
-template <int D, int TS, bool PACKED>
+// SORT (round 5; PACKED, binned lists, so_step_desc.sort_in_rasteriser): `flatten_ids` is NOT sorted yet -- the tile's keys
+// {depth bits, id} stand in `sort_keys` as the binning pass left them, and this workgroup sorts its own list before it walks
+// it: <= 256 keys by wave 0 in registers (ids to global memory for the backward AND to LDS for the first batch here, so no
+// global round trip), <= 2048 by the whole workgroup (register-sorted chunks + rank search in the 16 KB the staging arrays
+// occupy later), longer by the scratch-free rank sort.  One launch and one pass over the keys fewer per iteration where the
+// lists are short (c2: the sort kernel's 8.4 us + a launch boundary against ~3 us more in here).
+template <int D, int TS, bool PACKED, bool SORT = false>
 __global__ void __launch_bounds__(TS *TS)
 k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2 *__restrict__ means2d,
                 const float *__restrict__ conics, const float *__restrict__ colors,
@@ -24,17 +31,21 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
                 const uint8_t *__restrict__ tile_masks, const int32_t *__restrict__ offsets,
                 const int32_t *__restrict__ flatten_ids, const int32_t *__restrict__ n_isects_dev,
                 int64_t n_isects_host, float *__restrict__ render_colors, float *__restrict__ render_alphas,
-                int32_t *__restrict__ last_ids, int wrap_flags, const int32_t *__restrict__ tile_order) {
+                int32_t *__restrict__ last_ids, int wrap_flags, const int32_t *__restrict__ tile_order,
+                const uint64_t *__restrict__ sort_keys = nullptr) {
+  static_assert(!SORT || (PACKED && D == 3 && TS == 16), "the prologue sort exists for the packed RGB 16x16 kernel");
   constexpr int BLOCK = TS * TS;
   // staged per Gaussian: A = (x, y, conic a, conic b), B = (conic c, opacity [, r, g when D == 3]),
   // remaining colour channels in s_col -- two 16-byte broadcast reads + one 4-byte read per pass for RGB
   constexpr int DC = (D == 3) ? 1 : D;   // channels kept in s_col
-  __shared__ float4 s_A[BLOCK];
-  __shared__ float4 s_B[BLOCK];
-  __shared__ float4 s_box[BLOCK];   // xmin, xmax, ymin, ymax of the alpha>=1/255 region
+  // (one array carved in four: with SORT the medium-list sort parks its 2048 keys in the same 16 KB before the staging starts)
+  __shared__ float4 s_raw[((D == 3) ? 4 : 3) * BLOCK + ((D == 3) ? 0 : 1)];
+  float4 *const s_A = s_raw, *const s_B = s_raw + BLOCK;
+  float4 *const s_box = s_raw + 2 * BLOCK;   // xmin, xmax, ymin, ymax of the alpha>=1/255 region
   __shared__ float s_col[(D == 3) ? 1 : BLOCK * DC];
   // RGB: blue sits in a third 16-byte-strided array, so one address register (tt * 16) serves all three reads of a pass
-  __shared__ float4 s_C[(D == 3) ? BLOCK : 1];
+  float4 *const s_C = s_raw + 3 * BLOCK;
+  __shared__ int32_t s_ids[SORT ? BLOCK : 1];
 
   // the host checked C * tile_w * tile_h < 2^31: 32-bit index arithmetic (a 64-bit division is ~100 instructions)
   const int n_tiles = tile_w * tile_h;
@@ -72,6 +83,26 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
 
   int64_t lo, hi;
   tile_list_range(ct, M, offsets, n_isects_dev, n_isects_host, lo, hi);
+  bool ids_in_lds = false;
+  if constexpr (SORT) {
+    const int L = (int)(hi - lo);
+    if (L > 0) {       // (uniform over the workgroup)
+      int32_t *ids_out = const_cast<int32_t *>(flatten_ids);
+      if (L <= 256) {
+        if (tid < 64) {
+          if (L <= 64) wave_sort_list<1>(sort_keys, lo, L, tid, ct, n_tiles, 0, ids_out, nullptr, s_ids);
+          else if (L <= 128) wave_sort_list<2>(sort_keys, lo, L, tid, ct, n_tiles, 0, ids_out, nullptr, s_ids);
+          else wave_sort_list<4>(sort_keys, lo, L, tid, ct, n_tiles, 0, ids_out, nullptr, s_ids);
+        }
+        ids_in_lds = true;
+      } else if (L <= 2048) {
+        sort_mid_chunks<BLOCK>(reinterpret_cast<uint64_t *>(s_raw), sort_keys, lo, L, ct, n_tiles, 0, ids_out, nullptr);
+      } else {
+        rank_sort_global(sort_keys, lo, L, ct, n_tiles, 0, ids_out, nullptr);
+      }
+      __syncthreads();   // the ids (LDS, or global memory written by this workgroup) before anybody stages them
+    }
+  }
 
   // Per-pixel state.  A finished pixel (outside the image, or transmittance exhausted) has T == 0, which
   // makes every later contribution vanish arithmetically -- the pass body below has no branches.  T_out
@@ -104,7 +135,7 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
     }
     const int64_t idx = batch_start + tid;
     if (idx < hi) {
-      const int32_t g = flatten_ids[idx];
+      const int32_t g = (SORT && ids_in_lds) ? s_ids[tid] : flatten_ids[idx];
       if (PACKED) {
         const float4 *r4 = reinterpret_cast<const float4 *>(colors) + 4 * (int64_t)g;
         float4 q0 = r4[0];
@@ -239,10 +270,12 @@ static int launch_fwd(int TS, dim3 grid, hipStream_t st, int C, int N, int W, in
   const float2 *m2 = reinterpret_cast<const float2 *>(means2d);
   if (TS == 16)
     hipLaunchKernelGGL((k_rasterize_fwd<D, 16, false>), grid, dim3(256), 0, st, C, N, W, H, tile_w, tile_h, m2, conics, colors,
-                       opacities, backgrounds, tile_masks, offsets, flatten_ids, n_dev, n_host, rc, ra, last, wrap_flags, (const int32_t *)nullptr);
+                       opacities, backgrounds, tile_masks, offsets, flatten_ids, n_dev, n_host, rc, ra, last, wrap_flags, (const int32_t *)nullptr,
+                       (const uint64_t *)nullptr);
   else
     hipLaunchKernelGGL((k_rasterize_fwd<D, 8, false>), grid, dim3(64), 0, st, C, N, W, H, tile_w, tile_h, m2, conics, colors,
-                       opacities, backgrounds, tile_masks, offsets, flatten_ids, n_dev, n_host, rc, ra, last, wrap_flags, (const int32_t *)nullptr);
+                       opacities, backgrounds, tile_masks, offsets, flatten_ids, n_dev, n_host, rc, ra, last, wrap_flags, (const int32_t *)nullptr,
+                       (const uint64_t *)nullptr);
   return check_launch("so_rasterize_fwd");
 }
 
@@ -286,7 +319,7 @@ namespace so {
 int rasterize_fwd_packed_launch(int C, int N, int width, int height, int tile_size, const float *rec, const float *backgrounds,
                                 const int32_t *isect_offsets, const int32_t *flatten_ids, const int32_t *n_isects_dev,
                                 int64_t n_isects_host, float *render_colors, float *render_alphas, int32_t *last_ids,
-                                const int32_t *tile_order, void *stream);
+                                const int32_t *tile_order, void *stream, const uint64_t *sort_keys = nullptr);
 }
 extern "C" int so_rasterize_fwd_packed(int C, int N, int width, int height, int tile_size, const float *rec,
                                        const float *backgrounds, const int32_t *isect_offsets,
@@ -300,8 +333,11 @@ extern "C" int so_rasterize_fwd_packed(int C, int N, int width, int height, int 
 int so::rasterize_fwd_packed_launch(int C, int N, int width, int height, int tile_size, const float *rec, const float *backgrounds,
                                     const int32_t *isect_offsets, const int32_t *flatten_ids, const int32_t *n_isects_dev,
                                     int64_t n_isects_host, float *render_colors, float *render_alphas, int32_t *last_ids,
-                                    const int32_t *tile_order, void *stream) {
+                                    const int32_t *tile_order, void *stream, const uint64_t *sort_keys) {
   SO_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, "so_rasterize_fwd_packed: bad sizes");
+  // sort_keys (so_step_desc.sort_in_rasteriser): binned lists only (n_isects_dev == NULL, n_isects_host = -slots), 16x16 tiles
+  SO_REQUIRE(!sort_keys || (!n_isects_dev && n_isects_host < 0 && so::tile_size_of(tile_size) == 16 && flatten_ids),
+             "so_rasterize_fwd_packed: the prologue sort needs binned lists and 16x16 tiles");
   const int wrap_flags = tile_size & ~0xFF;
   tile_size = so::tile_size_of(tile_size);
   SO_REQUIRE(tile_size == 16 || tile_size == 8, "so_rasterize_fwd_packed: tile_size %d not in {8,16}", tile_size);
@@ -314,14 +350,18 @@ int so::rasterize_fwd_packed_launch(int C, int N, int width, int height, int til
              (long long)C * tile_w * tile_h);
   const dim3 grid((unsigned)((int64_t)C * tile_w * tile_h));
   hipStream_t st = so::as_stream(stream);
-  if (tile_size == 16)
+  if (tile_size == 16 && sort_keys)
+    hipLaunchKernelGGL((so::k_rasterize_fwd<3, 16, true, true>), grid, dim3(256), 0, st, C, N, width, height, tile_w, tile_h,
+                       nullptr, nullptr, rec, nullptr, backgrounds, nullptr, isect_offsets, flatten_ids, n_isects_dev,
+                       n_isects_host, render_colors, render_alphas, last_ids, wrap_flags, tile_order, sort_keys);
+  else if (tile_size == 16)
     hipLaunchKernelGGL((so::k_rasterize_fwd<3, 16, true>), grid, dim3(256), 0, st, C, N, width, height, tile_w, tile_h,
                        nullptr, nullptr, rec, nullptr, backgrounds, nullptr, isect_offsets, flatten_ids, n_isects_dev,
-                       n_isects_host, render_colors, render_alphas, last_ids, wrap_flags, tile_order);
+                       n_isects_host, render_colors, render_alphas, last_ids, wrap_flags, tile_order, (const uint64_t *)nullptr);
   else
     hipLaunchKernelGGL((so::k_rasterize_fwd<3, 8, true>), grid, dim3(64), 0, st, C, N, width, height, tile_w, tile_h,
                        nullptr, nullptr, rec, nullptr, backgrounds, nullptr, isect_offsets, flatten_ids, n_isects_dev,
-                       n_isects_host, render_colors, render_alphas, last_ids, wrap_flags, tile_order);
+                       n_isects_host, render_colors, render_alphas, last_ids, wrap_flags, tile_order, (const uint64_t *)nullptr);
   return so::check_launch("so_rasterize_fwd_packed");
 }
 

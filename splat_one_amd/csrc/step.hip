@@ -60,7 +60,7 @@ int rasterize_bwd_packed_launch(int C, int N, int width, int height, int tile_si
 int rasterize_fwd_packed_launch(int C, int N, int width, int height, int tile_size, const float *rec, const float *backgrounds,
                                 const int32_t *isect_offsets, const int32_t *flatten_ids, const int32_t *n_isects_dev,
                                 int64_t n_isects_host, float *render_colors, float *render_alphas, int32_t *last_ids,
-                                const int32_t *tile_order, void *stream);
+                                const int32_t *tile_order, void *stream, const uint64_t *sort_keys = nullptr);
 int tile_order_launch(int C, int tile_w, int tile_h, const int32_t *offsets, const int32_t *n_isects_dev, int64_t n_isects_host,
                       int32_t *order, hipStream_t st);
 int ssim_l1_fused_launch(int B, int H, int W, int CH, const float *img1, const float *img2, const float *const *img2_slot,
@@ -328,7 +328,10 @@ static int step_impl(const so_step_desc *d, void *stream, StepPart part, int64_t
                            d->viewmats, d->Ks, W, H, d->eps2d, d->near_plane, d->far_plane, d->radius_clip,
                            d->camera_model, d->antialiased, ts, d->radii, d->means2d, d->depths, d->conics,
                            d->opacities, d->colors, d->tiles_per_gauss, tile_counts, d->rec, forward_only ? nullptr : d->vrec, 0, slots, d->tile_cull, bin_keys, bins, overflow, stream));
-  if (bins) {
+  // sort_in_rasteriser: the forward rasteriser's workgroups sort their own lists (binned lists, 16x16 tiles; short lists)
+  const bool fold_sort = bins && d->sort_in_rasteriser && ts == 16;
+  if (fold_sort) {
+  } else if (bins) {
     SO_STAGE(2, so_isect_sort_bins(C, tile_w, tile_h, tile_counts, bins, d->key_buf, d->flatten_ids, cursor, stream));
   } else {
     SO_STAGE(1, so_isect_scan(C, tile_w, tile_h, tile_counts, slots ? cursor : nullptr, d->isect_offsets, n_isects, stream));
@@ -342,7 +345,8 @@ static int step_impl(const so_step_desc *d, void *stream, StepPart part, int64_t
   if (d->tile_order)   // longest list first (both rasterisers)
     SO_STAGE(10, so::tile_order_launch(C, tile_w, tile_h, list_off, list_n, list_cap, d->tile_order, st));
     SO_STAGE(3, so::rasterize_fwd_packed_launch(C, N, W, H, ts | wrap_flags, d->rec, d->backgrounds, list_off, d->flatten_ids, list_n,
-                                                list_cap, d->render_colors, d->render_alphas, d->last_ids, d->tile_order, stream));
+                                                list_cap, d->render_colors, d->render_alphas, d->last_ids, d->tile_order, stream,
+                                                fold_sort ? d->key_buf : nullptr));
   if (forward_only) return SO_OK;
   // loss = (1-l) * mean|.| + l * (1 - mean SSIM_valid)
   const float n_l1 = (float)C * H * W * 3.f, n_ss = (float)C * 3.f * (float)(H - 10) * (float)(W - 10);

@@ -141,6 +141,11 @@ class FusedEngine:
         self.tile_order_lpt = os.environ.get("SPLAT_ONE_AMD_TILE_ORDER", "1") != "0"   # (0: keep the XCD-local order, for A/B runs)
         self._lpt = False                # the rasterisers take their tiles longest list first (list_policy.pick_tile_order)
         self.before_param_access = None  # replicas: RowShardedAdam.wait_gathers (see _params_ready)
+        self._fold = False               # the per-tile sort runs in the forward rasteriser's prologue (list_policy.pick_sort_fold)
+        # Measured equal (profiles/r05_experiments.json: c2 3 926-3 930 it/s folded against 3 912-3 931; the forward rasteriser takes
+        # the sort kernel's time over, 36.9 -> 45 us, because every workgroup of a round sorts at the same moment and three of its four
+        # waves wait): OFF unless SPLAT_ONE_AMD_SORT_FOLD=1 -- kept because it is one launch fewer for callers that count launches
+        self.sort_fold_ok = os.environ.get("SPLAT_ONE_AMD_SORT_FOLD", "0") == "1"
         if self.device_refine:
             self._build_model_sets(int(capacity) if capacity else max(2 * splats["means"].shape[0], 1 << 20))
         self._build_workspace()
@@ -584,6 +589,7 @@ class FusedEngine:
         d.tile_cull = int(self.tile_cull)
         d.bin_capacity = self.bin_capacity
         d.tile_order = p(w["tile_order"]) if (self._lpt and self.tile_order_lpt) else 0
+        d.sort_in_rasteriser = int(bool(self._fold and self.sort_fold_ok and self.binned and c["tile_size"] == 16))
         return d
 
     def _adam_args(self):
@@ -695,6 +701,7 @@ class FusedEngine:
         self.binned = False
         self.lean = False
         self.cfg["raster_impl"] = 0
+        self._fold = False
         self._lpt = True                 # (a view that does not fit binned lists is a skewed one: longest tile first)
         self.fell_back_to_compact = True
         self._capacity_hint = None
@@ -708,7 +715,7 @@ class FusedEngine:
 
     def _list_state(self) -> "list_policy.ListState":
         return list_policy.ListState(binned=self.binned, bin_capacity=int(self.bin_capacity), bin_limit=int(getattr(self, "_bin_limit", 0)),
-                                     capacity=int(self.capacity), raster_impl=int(self.cfg["raster_impl"]), lpt=bool(self._lpt),
+                                     capacity=int(self.capacity), raster_impl=int(self.cfg["raster_impl"]), lpt=bool(self._lpt), fold=bool(self._fold),
                                      on_overflow=self.on_overflow, tile16=self.cfg["tile_size"] == 16, absgrad=bool(self.cfg["absgrad"]),
                                      compact_pending=bool(self._compact_pending), local_overflow_seen=int(self._local_overflow_seen))
 
@@ -719,7 +726,7 @@ class FusedEngine:
         for act in actions:
             kind = act[0]
             if kind == "set_kernels":
-                self.cfg["raster_impl"], self._lpt = int(act[1]), bool(act[2])
+                self.cfg["raster_impl"], self._lpt, self._fold = int(act[1]), bool(act[2]), bool(act[3])
                 self._graph = None
                 self._graph_fb = self._graph_opt = None
                 self._graphs, self._graphs_fb, self._graphs_head, self._rows_desc = {}, {}, {}, None

@@ -7,7 +7,8 @@ table; tests/test_list_policy.py walks every (state, event) row of it against th
 engine through the rows that need a device.
 
 Actions (tuples, executed in order by FusedEngine._apply):
-    ("set_kernels", raster_impl, lpt)   which backward rasteriser / tile order; drops every captured graph when it changes
+    ("set_kernels", raster_impl, lpt, fold)  which backward rasteriser / tile order / where the per-tile sort runs; drops every
+                                        captured graph when it changes
     ("rebuild_bins", slots)             new workspace with `slots` per tile (binned layout; the list-following path: 8x the fullest tile)
     ("grow", needed)                    FusedEngine._grow: bins of >= 2 needed + 16 slots / compact buffers of 1.5 needed + 4096 entries
     ("fall_back_to_compact", fullest)   leave the binned layout for good (bins at their memory budget), warn once
@@ -34,6 +35,7 @@ class ListState:
     raster_impl: int             # 0: one wave per 8x8 quadrant, 1: one wave per 16x16 tile (backward)
     lpt: bool                    # rasterisers take their tiles longest list first
     on_overflow: str             # "grow" | "raise" | "defer"
+    fold: bool = False           # the per-tile sort runs in the forward rasteriser's prologue (no sort launch)
     tile16: bool = True          # 16x16 tiles (the one-wave-per-tile kernel exists for them only)
     absgrad: bool = False
     compact_pending: bool = False      # a deferred overflow happened with the bins at their limit
@@ -67,14 +69,25 @@ def pick_tile_order(now: bool, impl: int, mean_list: float, fullest: int) -> boo
     return bool(now and fullest >= 384 and fullest > 6.0 * m)
 
 
+def pick_sort_fold(now: bool, binned: bool, tile16: bool, fullest: int) -> bool:
+    """The per-tile sort inside the forward rasteriser (one launch fewer) where lists are short EVERYWHERE: fullest tile <= 256
+    entries, i.e. every workgroup sorts its list with ONE wave in registers; with hysteresis (back to the sort kernels above
+    384).  Longer lists that turn up in between are still sorted correctly in there (<= 2048 by the whole workgroup; beyond
+    that a slow scratch-free rank sort)."""
+    if not binned or not tile16:
+        return False
+    return fullest <= (384 if now else 256)
+
+
 def on_probe(s: ListState, fullest: int, mean_list: float, n_isects: int, headroom: int) -> List[Action]:
     """A forward-only pass on the first view of a workspace (headroom 8) or after a refinement (headroom 2) measured the lists."""
     acts: List[Action] = []
     if s.binned:
         impl = pick_raster_impl(s.raster_impl, mean_list, fullest, s.tile16, s.absgrad, first=True)
         lpt = pick_tile_order(False, impl, mean_list, fullest)
-        if (impl, lpt) != (s.raster_impl, s.lpt):
-            acts.append(("set_kernels", impl, lpt))
+        fold = pick_sort_fold(False, s.binned, s.tile16, fullest)
+        if (impl, lpt, fold) != (s.raster_impl, s.lpt, s.fold):
+            acts.append(("set_kernels", impl, lpt, fold))
         if headroom * fullest > s.bin_capacity:
             if 2 * fullest > s.bin_limit:
                 return acts + [("fall_back_to_compact", fullest), ("restage",)]
@@ -94,8 +107,9 @@ def on_lists(s: ListState, fullest: int, total: int, n_tiles: int) -> List[Actio
     mean = total / max(n_tiles, 1)
     impl = pick_raster_impl(s.raster_impl, mean, fullest, s.tile16, s.absgrad)
     lpt = pick_tile_order(s.lpt, impl, mean, fullest)
-    if (impl, lpt) != (s.raster_impl, s.lpt):
-        acts.append(("set_kernels", impl, lpt))
+    fold = pick_sort_fold(s.fold, s.binned, s.tile16, fullest)
+    if (impl, lpt, fold) != (s.raster_impl, s.lpt, s.fold):
+        acts.append(("set_kernels", impl, lpt, fold))
     # bins kept at >= 2x the fullest tile, rebuilt at 8x BEFORE a tile overflows (a tile beyond the capacity HAS overflowed:
     # that is on_overflow's business)
     if 2 * fullest > s.bin_capacity and s.bin_capacity < s.bin_limit and fullest <= s.bin_capacity:

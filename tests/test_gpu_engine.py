@@ -551,3 +551,33 @@ def test_overflow_policy_is_honoured_when_the_bins_are_at_their_budget(dev, poli
     assert eng.void_steps == void and eng.steps_done == 4 - void + 3 and eng.stats()["overflow"] == 0
     assert int(eng._step_dev[0].item()) == eng.steps_done
     assert all(torch.isfinite(v).all() for v in r.splats.values())
+
+
+def test_sort_in_the_rasteriser_prologue_gives_the_same_lists_images_and_gradients(dev):
+    """so_step_desc.sort_in_rasteriser (round 5): the forward rasteriser's workgroups sort their own tile lists -- one wave in
+    registers up to 256 keys, the workgroup up to 2048, a scratch-free rank sort beyond -- instead of the sort kernels.  Same
+    lists bit for bit, same image bit for bit, gradients equal up to atomic order; all three in-kernel paths are walked (a
+    cloud gathered in the middle of a small image makes tiles of 30 ... 3000+ keys)."""
+    from splat_one_amd.engine import FusedEngine
+    N, W, H = 30_000, 256, 160
+    out = {}
+    for fold in (False, True):
+        r, c2w, Ks, pixels = _make(dev, N, W, H, "ref")
+        with torch.no_grad():
+            r.splats["means"].mul_(0.25)
+        eng = FusedEngine(r.splats, r.optimizers, W, H, 1, sh_degree=3, use_graph=False, fuse_adam=False)
+        eng.set_views(c2w, Ks, pixels)           # (capacity probe, kernel choice)
+        eng.sort_fold_ok, eng._fold = fold, fold
+        eng.fwd_bwd()
+        torch.cuda.synchronize()
+        assert eng._desc().sort_in_rasteriser == int(fold) and eng.binned
+        offs, ids = eng.tile_lists()
+        lens = torch.tensor(offs[1:]) - torch.tensor(offs[:-1])
+        out[fold] = dict(offs=offs, ids=ids.clone(), img=eng.ws["render_colors"].clone(), last=eng.ws["last_ids"].clone(),
+                         grads={k: v.grad.detach().clone() for k, v in r.splats.items()}, lens=lens)
+    a, b = out[False], out[True]
+    assert int(b["lens"].max()) > 2048 and int(((b["lens"] > 256) & (b["lens"] <= 2048)).sum()) > 0 and int(((b["lens"] > 0) & (b["lens"] <= 256)).sum()) > 0
+    assert a["offs"] == b["offs"] and torch.equal(a["ids"], b["ids"])
+    assert torch.equal(a["img"], b["img"]) and torch.equal(a["last"], b["last"])
+    for k in a["grads"]:
+        assert rel_err(b["grads"][k], a["grads"][k]) < 1e-5, k

@@ -12,39 +12,45 @@ from splat_one_amd import list_policy as LP
 
 S = LP.ListState
 BINNED = dict(binned=True, bin_capacity=1024, bin_limit=8192, capacity=8160 * 1024, raster_impl=0, lpt=False, on_overflow="grow")
+SHORT = dict(BINNED, fold=True)          # short lists everywhere: the sort runs in the forward rasteriser's prologue
 AT_LIMIT = dict(BINNED, bin_capacity=8192)
 COMPACT = dict(binned=False, bin_capacity=0, bin_limit=0, capacity=1 << 20, raster_impl=0, lpt=False, on_overflow="grow")
 
 # (row, state, event, arguments, expected actions)
 TABLE = [
     # ---- capacity probe of a new workspace (headroom 8) / after a refinement (headroom 2)
-    ("probe: short even lists fit", BINNED, "probe", dict(fullest=97, mean_list=31.0, n_isects=0, headroom=8), []),
-    ("probe: bins too small -> 8x the fullest tile", BINNED, "probe", dict(fullest=200, mean_list=60.0, n_isects=0, headroom=8),
+    ("probe: short even lists -> the sort moves into the forward rasteriser", BINNED, "probe", dict(fullest=97, mean_list=31.0, n_isects=0, headroom=8),
+     [("set_kernels", 0, False, True)]),
+    ("probe: short even lists, already so", SHORT, "probe", dict(fullest=97, mean_list=31.0, n_isects=0, headroom=2), []),
+    ("probe: bins too small -> 8x the fullest tile", SHORT, "probe", dict(fullest=200, mean_list=60.0, n_isects=0, headroom=8),
      [("rebuild_bins", 1792), ("restage",)]),
     ("probe: long lists everywhere -> one wave per tile, longest first", BINNED, "probe", dict(fullest=900, mean_list=520.0, n_isects=0, headroom=2),
-     [("set_kernels", 1, True), ("rebuild_bins", 7424), ("restage",)]),
+     [("set_kernels", 1, True, False), ("rebuild_bins", 7424), ("restage",)]),
     ("probe: skewed lists -> quadrant waves, longest first", BINNED, "probe", dict(fullest=1000, mean_list=30.0, n_isects=0, headroom=2),
-     [("set_kernels", 0, True), ("rebuild_bins", 8192), ("restage",)]),
+     [("set_kernels", 0, True, False), ("rebuild_bins", 8192), ("restage",)]),
     ("probe: fullest tile beyond the bin budget -> compact lists", BINNED, "probe", dict(fullest=5000, mean_list=40.0, n_isects=0, headroom=8),
-     [("set_kernels", 0, True), ("fall_back_to_compact", 5000), ("restage",)]),
+     [("set_kernels", 0, True, False), ("fall_back_to_compact", 5000), ("restage",)]),
     ("probe: absgrad keeps the quadrant kernel", dict(BINNED, absgrad=True), "probe", dict(fullest=900, mean_list=520.0, n_isects=0, headroom=2),
      [("rebuild_bins", 7424), ("restage",)]),
     ("probe (compact): buffers hold 1.25x the count", COMPACT, "probe", dict(fullest=0, mean_list=0.0, n_isects=800_000, headroom=8), []),
     ("probe (compact): too small -> 2x the count", COMPACT, "probe", dict(fullest=0, mean_list=0.0, n_isects=900_000, headroom=8),
      [("grow", 1_800_000), ("restage",)]),
     # ---- list statistics published by the device (no read-back), binned layout
-    ("lists: nothing to do", BINNED, "lists", dict(fullest=300, total=8160 * 100, n_tiles=8160), []),
+    ("lists: nothing to do", BINNED, "lists", dict(fullest=400, total=8160 * 100, n_tiles=8160), []),
+    ("lists: hysteresis keeps the sort in the rasteriser up to 384", SHORT, "lists", dict(fullest=300, total=8160 * 100, n_tiles=8160), []),
+    ("lists: lists outgrew the prologue sort -> back to the sort kernels", SHORT, "lists", dict(fullest=400, total=8160 * 100, n_tiles=8160),
+     [("set_kernels", 0, False, False)]),
     ("lists: headroom below 2x -> rebuild at 8x before a tile overflows", BINNED, "lists", dict(fullest=600, total=8160 * 150, n_tiles=8160),
      [("rebuild_bins", 4864)]),
     ("lists: a tile beyond the capacity is the overflow path's business (bins untouched)", BINNED, "lists", dict(fullest=1500, total=8160 * 250, n_tiles=8160), []),
     ("lists: one hot tile -> longest list first with the quadrant waves (and roomier bins)", BINNED, "lists", dict(fullest=900, total=8160 * 60, n_tiles=8160),
-     [("set_kernels", 0, True), ("rebuild_bins", 7424)]),
+     [("set_kernels", 0, True, False), ("rebuild_bins", 7424)]),
     ("lists: grown to long lists -> switch kernels (graphs dropped)", BINNED, "lists", dict(fullest=500, total=8160 * 300, n_tiles=8160),
-     [("set_kernels", 1, True)]),
+     [("set_kernels", 1, True, False)]),
     ("lists: hysteresis keeps one wave per tile at 200 entries", dict(BINNED, raster_impl=1, lpt=True), "lists", dict(fullest=400, total=8160 * 200, n_tiles=8160), []),
     ("lists: back to quadrant waves below 192", dict(BINNED, raster_impl=1, lpt=True), "lists", dict(fullest=400, total=8160 * 150, n_tiles=8160),
-     [("set_kernels", 0, False)]),
-    ("lists: bins at their limit are left alone", AT_LIMIT, "lists", dict(fullest=6000, total=8160 * 700, n_tiles=8160), [("set_kernels", 0, True)]),
+     [("set_kernels", 0, False, False)]),
+    ("lists: bins at their limit are left alone", AT_LIMIT, "lists", dict(fullest=6000, total=8160 * 700, n_tiles=8160), [("set_kernels", 0, True, False)]),
     ("lists (compact): ignored", COMPACT, "lists", dict(fullest=600, total=8160 * 150, n_tiles=8160), []),
     # ---- an overflow found one step late
     ("overflow, grow: one void iteration", BINNED, "overflow", dict(kind="train", n_prev=1500, n_last=1500, ov_last=False), [("take_back", 1, 1500, False)]),
@@ -100,7 +106,7 @@ def test_engine_executes_the_actions_in_order_with_a_stubbed_engine():
     from splat_one_amd.engine import FusedEngine
     log = []
     eng = types.SimpleNamespace(
-        cfg={"raster_impl": 0, "tile_size": 16, "absgrad": False}, _lpt=False, binned=True, bin_capacity=8192, _bin_limit=8192, capacity=1,
+        cfg={"raster_impl": 0, "tile_size": 16, "absgrad": False}, _lpt=False, _fold=True, binned=True, bin_capacity=8192, _bin_limit=8192, capacity=1,
         on_overflow="grow", _compact_pending=False, _local_overflow_seen=0, _graph=1, _graph_fb=1, _graph_opt=1, _graphs={1: 1}, _graphs_fb={1: 1},
         _graphs_head={1: 1}, _rows_desc=1, _bin_hint=None, _probe_capacity=True,
         _build_workspace=lambda: log.append("build"), _grow=lambda n: log.append(("grow", n)),
@@ -108,8 +114,8 @@ def test_engine_executes_the_actions_in_order_with_a_stubbed_engine():
     eng._list_state = lambda: FusedEngine._list_state(eng)
     eng._apply = lambda acts: FusedEngine._apply(eng, acts)
     eng.take_back = lambda *a, **k: FusedEngine.take_back(eng, *a, **k)
-    assert FusedEngine._apply(eng, [("set_kernels", 1, True), ("rebuild_bins", 2048), ("restage",)]) is True
-    assert eng.cfg["raster_impl"] == 1 and eng._lpt and eng._graphs == {} and eng._graph is None and eng._rows_desc is None
+    assert FusedEngine._apply(eng, [("set_kernels", 1, True, False), ("rebuild_bins", 2048), ("restage",)]) is True
+    assert eng.cfg["raster_impl"] == 1 and eng._lpt and not eng._fold and eng._graphs == {} and eng._graph is None and eng._rows_desc is None
     assert eng._bin_hint == 2048 and eng._probe_capacity is False and log == ["build"]
     del log[:]
     with warnings.catch_warnings(record=True) as caught:
