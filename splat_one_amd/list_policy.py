@@ -36,6 +36,7 @@ class ListState:
     lpt: bool                    # rasterisers take their tiles longest list first
     on_overflow: str             # "grow" | "raise" | "defer"
     fold: bool = False           # the per-tile sort runs in the forward rasteriser's prologue (no sort launch)
+    fold_allowed: bool = True    # FusedEngine.sort_fold_ok (off by default: measured equal, profiles/r05_experiments.json)
     tile16: bool = True          # 16x16 tiles (the one-wave-per-tile kernel exists for them only)
     absgrad: bool = False
     compact_pending: bool = False      # a deferred overflow happened with the bins at their limit
@@ -85,7 +86,7 @@ def on_probe(s: ListState, fullest: int, mean_list: float, n_isects: int, headro
     if s.binned:
         impl = pick_raster_impl(s.raster_impl, mean_list, fullest, s.tile16, s.absgrad, first=True)
         lpt = pick_tile_order(False, impl, mean_list, fullest)
-        fold = pick_sort_fold(False, s.binned, s.tile16, fullest)
+        fold = s.fold_allowed and pick_sort_fold(False, s.binned, s.tile16, fullest)
         if (impl, lpt, fold) != (s.raster_impl, s.lpt, s.fold):
             acts.append(("set_kernels", impl, lpt, fold))
         if headroom * fullest > s.bin_capacity:
@@ -107,7 +108,7 @@ def on_lists(s: ListState, fullest: int, total: int, n_tiles: int) -> List[Actio
     mean = total / max(n_tiles, 1)
     impl = pick_raster_impl(s.raster_impl, mean, fullest, s.tile16, s.absgrad)
     lpt = pick_tile_order(s.lpt, impl, mean, fullest)
-    fold = pick_sort_fold(s.fold, s.binned, s.tile16, fullest)
+    fold = s.fold_allowed and pick_sort_fold(s.fold, s.binned, s.tile16, fullest)
     if (impl, lpt, fold) != (s.raster_impl, s.lpt, s.fold):
         acts.append(("set_kernels", impl, lpt, fold))
     # bins kept at >= 2x the fullest tile, rebuilt at 8x BEFORE a tile overflows (a tile beyond the capacity HAS overflowed:

@@ -22,6 +22,8 @@ TABLE = [
     ("probe: short even lists -> the sort moves into the forward rasteriser", BINNED, "probe", dict(fullest=97, mean_list=31.0, n_isects=0, headroom=8),
      [("set_kernels", 0, False, True)]),
     ("probe: short even lists, already so", SHORT, "probe", dict(fullest=97, mean_list=31.0, n_isects=0, headroom=2), []),
+    ("probe: short even lists, prologue sort not allowed (the default)", dict(BINNED, fold_allowed=False), "probe",
+     dict(fullest=97, mean_list=31.0, n_isects=0, headroom=8), []),
     ("probe: bins too small -> 8x the fullest tile", SHORT, "probe", dict(fullest=200, mean_list=60.0, n_isects=0, headroom=8),
      [("rebuild_bins", 1792), ("restage",)]),
     ("probe: long lists everywhere -> one wave per tile, longest first", BINNED, "probe", dict(fullest=900, mean_list=520.0, n_isects=0, headroom=2),
@@ -106,7 +108,7 @@ def test_engine_executes_the_actions_in_order_with_a_stubbed_engine():
     from splat_one_amd.engine import FusedEngine
     log = []
     eng = types.SimpleNamespace(
-        cfg={"raster_impl": 0, "tile_size": 16, "absgrad": False}, _lpt=False, _fold=True, binned=True, bin_capacity=8192, _bin_limit=8192, capacity=1,
+        cfg={"raster_impl": 0, "tile_size": 16, "absgrad": False}, _lpt=False, _fold=True, sort_fold_ok=True, binned=True, bin_capacity=8192, _bin_limit=8192, capacity=1,
         on_overflow="grow", _compact_pending=False, _local_overflow_seen=0, _graph=1, _graph_fb=1, _graph_opt=1, _graphs={1: 1}, _graphs_fb={1: 1},
         _graphs_head={1: 1}, _rows_desc=1, _bin_hint=None, _probe_capacity=True,
         _build_workspace=lambda: log.append("build"), _grow=lambda n: log.append(("grow", n)),
