@@ -581,3 +581,36 @@ def test_sort_in_the_rasteriser_prologue_gives_the_same_lists_images_and_gradien
     assert torch.equal(a["img"], b["img"]) and torch.equal(a["last"], b["last"])
     for k in a["grads"]:
         assert rel_err(b["grads"][k], a["grads"][k]) < 1e-5, k
+
+
+def test_tile_order_is_a_permutation_longest_list_first_and_changes_nothing(dev):
+    """so_step_desc.tile_order (round 5): k_tile_order's workgroup -> tile table is a permutation of the tiles in which list
+    lengths never increase by more than one length class (a counting sort over 256 classes of fullest / 256 entries each; empty
+    tiles last), and a step that takes its tiles in that order gives the same image bit for bit and the same gradients up to
+    atomic order -- with one wave per tile and with four."""
+    from splat_one_amd.engine import FusedEngine
+    N, W, H = 20_000, 320, 192
+    for impl in (0, 1):
+        res = {}
+        for lpt in (False, True):
+            r, c2w, Ks, pixels = _make(dev, N, W, H, "ref")
+            with torch.no_grad():
+                r.splats["means"].mul_(0.3)              # skewed: full tiles in the middle, empty ones at the rim
+            eng = FusedEngine(r.splats, r.optimizers, W, H, 1, sh_degree=3, use_graph=False, fuse_adam=False)
+            eng.set_views(c2w, Ks, pixels)
+            eng.cfg["raster_impl"], eng._lpt, eng.tile_order_lpt = impl, lpt, True
+            eng.fwd_bwd()
+            torch.cuda.synchronize()
+            offs, _ = eng.tile_lists()
+            lens = torch.tensor(offs[1:]) - torch.tensor(offs[:-1])
+            res[lpt] = dict(img=eng.ws["render_colors"].clone(), grads={k: v.grad.detach().clone() for k, v in r.splats.items()})
+            if lpt:
+                order = eng.ws["tile_order"].cpu().long()
+                assert torch.equal(torch.sort(order).values, torch.arange(eng.M))                  # a permutation
+                got = lens[order]
+                cls = int(lens.max()) // 256 + 1                                                   # entries per length class
+                assert bool((got[1:] <= got[:-1] + cls).all()), "lengths rise by more than one class along the order"
+                assert int(got[0]) >= int(lens.max()) - cls and int((lens == 0).sum()) > 0 and bool((got[-int((lens == 0).sum()):] == 0).all())
+        assert torch.equal(res[False]["img"], res[True]["img"])
+        for k in res[False]["grads"]:
+            assert rel_err(res[True]["grads"][k], res[False]["grads"][k]) < 1e-5, (impl, k)
