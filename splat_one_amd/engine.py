@@ -529,9 +529,9 @@ class FusedEngine:
     def refresh_attrs(self) -> None:
         """Rebuild the float16 attribute rows from the float32 masters (after anything but the engine's own
         optimiser step wrote quats / scales / sh0 / shN: densification, relocation, a loaded checkpoint)."""
-        self._params_ready()
         if self.attr_dtype != "f16":
             return
+        self._params_ready()
         s, p = self.splats, _lib.ptr
         if self.device_refine:      # the active set's capacity-sized masters, live rows only (N on the device)
             a = self.sets[self.active]["p"]
