@@ -154,6 +154,7 @@ class FusedEngine:
     def _build_model_sets(self, cap: int) -> None:
         """Two sets of capacity-sized buffers {p, m, v}[tensor]; the current Gaussians move into set 0 (or keep their
         place when the capacity grows) and the torch-side handles become views of it."""
+        self._params_ready()          # (replicas: the rows are copied below)
         dev = self.device
         n = self.splats["means"].shape[0]
         cap = max(int(cap), n)
@@ -762,6 +763,7 @@ class FusedEngine:
         profiles/r04_experiments.json -- and only where they are long EVERYWHERE: a cloud gathered in 250 tiles of 12 000 entries
         has a mean of 390 too and leaves three quarters of the SIMDs idle with one wave per tile), and whether the bins hold
         `headroom` times the fullest tile (else: rebuilt at 8x, or -- past the memory budget -- the compact lists)."""
+        self._params_ready()
         d = self._desc()
         _lib.call("so_render_forward", ctypes.byref(d), _lib.stream())
         if self.binned:
@@ -985,6 +987,7 @@ class FusedEngine:
     def _warm_fwd_bwd(self) -> None:
         """Un-captured launch before a capture (module load, LDS attribute calls): gradients only, with the
         densification statistics and the staging flags of the pending step left as they were."""
+        self._params_ready()          # (replicas: this un-captured launch reads the parameters like any other)
         torch.cuda.synchronize()
         pending = (self._staged, self._sched_staged)
         side = torch.cuda.Stream()
