@@ -251,6 +251,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rewarm-steps", type=int, default=None,
+                    help="untimed iterations between the read-backs that precede the warm-up and the --warmup steps (counted in "
+                         "config.preparation_steps); default: at least 16 and at least 50 ms of them")
     ap.add_argument("--n", "--gaussians", dest="n", type=int, default=100_000)   # (--gaussians: torchrun's own parser trips over "--n")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -510,9 +513,17 @@ def main():
     if preparation_steps:
         # ... and the GPU gets its load back before the W warm-up steps: after the read-backs above it runs ~5 % slower for its
         # next ~30 iterations (--step-trace), more than a small --warmup covers.  Untimed, named in the line.
-        for _ in range(2 * len(views)):
+        # (how long: tools/gpu_r05_m.sh -- with 16 such iterations (4 ms) the 20 timed steps of the driver's command line run at
+        # 268 us, with 64 at 263, with 128 or 256 (35 / 70 ms) at 258, the long-run rate: the card needs ~40 ms of load to
+        # reach its clocks.  Default: at least 16 iterations and at least 50 ms; the host runs at most two iterations ahead of the
+        # GPU (engine.py: the status words), so its clock is the GPU's here.)
+        # With several ranks every rank must run the same count (the steps hold collectives): a fixed 128 there.
+        n_rewarm, t_rewarm = 0, time.time()
+        fixed = args.rewarm_steps if args.rewarm_steps is not None else (128 if world > 1 else None)
+        while (n_rewarm < fixed) if fixed is not None else (n_rewarm < 16 or (time.time() - t_rewarm < 0.05 and n_rewarm < 1024)):
             step_once()
-        preparation_steps += 2 * len(views)
+            n_rewarm += 1
+        preparation_steps += n_rewarm
 
     # warm-up
     if not fused:

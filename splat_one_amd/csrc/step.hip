@@ -144,6 +144,7 @@ k_step_inputs(int C, const float *__restrict__ c2w, const float *__restrict__ Ks
   // them and not as long as their sum: the status report waits for its stores to reach host memory, the schedule runs
   // three double-precision pow() per group
   const unsigned b_status = gridDim.x > 1 ? 1u : 0u, b_sched = gridDim.x > 2 ? 2u : 0u;
+#ifndef SO_SI_NO_STATUS      // (SO_SI_NO_*: ablation builds of tools/gpu_r05_l.sh -- what of this kernel's 4.7 us is which job)
   if (blockIdx.x == b_status && status_out && threadIdx.x == 0) {
     const int32_t n_prev = (int32_t)counters[status_at], ov_prev = (int32_t)counters[status_at + 1];
     if (status_at < n_zero) counters[status_at] = 0u;
@@ -160,14 +161,19 @@ k_step_inputs(int C, const float *__restrict__ c2w, const float *__restrict__ Ks
     __threadfence_system();
     status_out[2] = seq;      // written last: the host trusts [0], [1] once it sees its own sequence number here
   }
+#endif
+#ifndef SO_SI_NO_CAM
   if (blockIdx.x == 0) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) camera_inverse_one(c2w + 16 * c, w2c + 16 * c);
     if (Ks_dst)
       for (int i = threadIdx.x; i < 9 * C; i += blockDim.x) Ks_dst[i] = Ks_src[i];
     if (pixels_slot && threadIdx.x == 0) *pixels_slot = pixels;
   }
+#endif
+#ifndef SO_SI_NO_SCHED
   if (blockIdx.x == b_sched && n_groups > 0)   // (block-uniform: adam_schedule_block has a barrier)
     adam_schedule_block(sch.lr0, sch.lr_gamma, n_groups, beta1, beta2, step_ptr, reinterpret_cast<float2 *>(step_ptr + 2));
+#endif
 }
 
 static inline void zero_async(void *p, int64_t n_words, hipStream_t st) {
