@@ -52,3 +52,11 @@ for k in range(4):
     print("%-52s mean %6.2f  p50 %6.2f  p95 %6.2f  max %6.2f us" % (names[k], d.mean(), np.median(d), np.percentile(d, 95), d.max()))
 life = rel[:, 4] - rel[:, 0]
 print("wave life: mean %.2f p50 %.2f p95 %.2f max %.2f us;  start spread p95 %.2f us" % (life.mean(), np.median(life), np.percentile(life, 95), life.max(), np.percentile(rel[:, 0], 95)))
+
+# when do the working waves START (workgroup = 4 consecutive waves; the grid is capacity-sized, the working workgroups come first)
+starts = rel[:, 0]
+print("k_preprocess_bwd wave starts, deciles (us):", [round(float(np.percentile(starts, q)), 1) for q in range(0, 101, 10)])
+wg = starts[: (real // 4) * 4].reshape(-1, 4).min(axis=1)
+ends = rel[: (real // 4) * 4, 4].reshape(-1, 4).max(axis=1)
+for a in range(0, len(wg), 64):
+    print("  workgroups %4d..%4d: start mean %5.1f  min %5.1f  max %5.1f   end mean %5.1f us" % (a, min(a + 63, len(wg) - 1), wg[a:a + 64].mean(), wg[a:a + 64].min(), wg[a:a + 64].max(), ends[a:a + 64].mean()))
