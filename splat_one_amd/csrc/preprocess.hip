@@ -837,7 +837,7 @@ static int preprocess_fwd_impl(const char *what, int C, int N, int K, int sh_deg
                                      (int64_t)C * cam_stride < ((int64_t)1 << 31)),
              "%s: bin_keys need tile_counts, bin_overflow, bin_cap > 0, C * cam_stride < 2^31 and no tile_slots", what);
   const int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
-  const dim3 grid(pp_grid((int64_t)C * N)), block(256);
+  const dim3 grid(pp_grid((int64_t)C * N)), block(256);   // (128 / 64 threads measured equal or slower here: tools/gpu_r05_n2.sh)
   hipStream_t st = as_stream(stream);
   const bool sph = camera_model_has_spherical(camera_model, C);
   // shN rows through LDS (COOP, see CoefsLdsRow): float32 SoA attributes, SH degree >= 1, a workgroup's 256 rows within the
@@ -905,15 +905,21 @@ static int preprocess_bwd_impl(const char *what, int C, int N, int K, int sh_deg
              "%s: row range [%lld, %lld) must start at a multiple of 64 (and is not available with the fused optimiser)", what,
              (long long)row_begin, (long long)row_end);
   if (row_begin >= N || (row_end > 0 && row_end == row_begin)) return SO_OK;
-  const dim3 grid(pp_grid((row_end > 0 && row_end < N ? row_end : (int64_t)N) - row_begin)), block(256);
+  // Workgroups of 128 threads (the kernel's LDS exchange is per wave, so any multiple of 64 works; SPLAT_ONE_AMD_PPB_BLOCK = 64 /
+  // 128 / 256): tools/gpu_r05_n.sh, _n3.sh -- 1M at 1440p 311 / 298 / 297 us with 256 / 128 / 64 threads, 2M 615 / 607 / 639, 500k 162 /
+  // 160, c2 42 all three, float16 rows 669 / 666.
+  // The limits on K stay those of 256-thread workgroups within 64 KB (22; 18 with float16 rows), whatever the workgroup size.
+  static const int ppb_block = [] { const char *e = getenv("SPLAT_ONE_AMD_PPB_BLOCK"); const int b = e ? atoi(e) : 128; return (b == 64 || b == 256) ? b : 128; }();
+  const int64_t ppb_rows = (row_end > 0 && row_end < N ? row_end : (int64_t)N) - row_begin;
+  const dim3 grid((unsigned)std::min<int64_t>(std::max<int64_t>(ceil_div(ppb_rows, ppb_block), 1), 4096 * (256 / ppb_block))), block(ppb_block);
   hipStream_t st = as_stream(stream);
   const float sx = 0.5f * (float)width * (float)C, sy = 0.5f * (float)height * (float)C;
   // v_shN rows go through LDS when a workgroup's 256 rows fit the default 64 KB (K <= 22) and the run is 16-byte aligned
-  const size_t stage_bytes = (size_t)256 * 3 * (K - 1) * sizeof(float);
-  const bool stage = K > 1 && stage_bytes <= 64 * 1024 && (((uintptr_t)v_shN) & 15) == 0;
+  const size_t stage_bytes = (size_t)ppb_block * 3 * (K - 1) * sizeof(float);
+  const bool stage = K > 1 && K <= 22 && (((uintptr_t)v_shN) & 15) == 0;
   SO_REQUIRE(!(fuse && A::kActivated), "%s: the fused optimiser needs the raw parameters", what);
   if (fuse) {   // the fused optimiser sweeps the staged rows: same conditions, on the parameter / moment tensors
-    SO_REQUIRE(K > 1 && stage_bytes <= 64 * 1024, "%s: fused Adam needs 2 <= K <= 22", what);
+    SO_REQUIRE(K > 1 && K <= 22, "%s: fused Adam needs 2 <= K <= 22", what);
     uintptr_t bits = 0;
     for (int g = 0; g < 6; ++g) {
       SO_REQUIRE(fuse->p[g] && fuse->m[g] && fuse->v[g], "%s: fused Adam: null parameter / moment pointer (group %d)", what, g);
@@ -921,11 +927,11 @@ static int preprocess_bwd_impl(const char *what, int C, int N, int K, int sh_deg
     }
     SO_REQUIRE((bits & 15) == 0 && fuse->hyper, "%s: fused Adam: tensors must be 16-byte aligned, hyper non-null", what);
     SO_REQUIRE(!fuse->half_rows || (A::kHalfRows && (((uintptr_t)fuse->half_rows) & 15) == 0 && fuse->half_stride16 == attr_rec_stride_bytes(K) / 16 &&
-                                    stage_bytes + (size_t)256 * kHalfHdr * sizeof(float) <= 64 * 1024),
+                                    K <= 18),
                "%s: fused Adam with float16 rows: rows 16-byte aligned, stride of K, and K <= 18", what);
   }
   // (float16 rows re-packed by the fused optimiser: 11 more floats of LDS per Gaussian for the row header)
-  const size_t lds_bytes = stage_bytes + ((fuse && fuse->half_rows) ? (size_t)256 * kHalfHdr * sizeof(float) : 0);
+  const size_t lds_bytes = stage_bytes + ((fuse && fuse->half_rows) ? (size_t)ppb_block * kHalfHdr * sizeof(float) : 0);
   const bool sph = camera_model_has_spherical(camera_model, C);
 #define SO_LAUNCH(D)                                                                                              \
   if (sph) { SO_LAUNCH_(D, true); } else { SO_LAUNCH_(D, false); }
