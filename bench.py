@@ -385,6 +385,11 @@ def main():
         if args.densify:
             from splat_one_amd.strategy import DefaultStrategy
             cfg.strategy = DefaultStrategy(refine_start_iter=0, refine_every=args.densify, reset_every=3000, verbose=False)
+        else:
+            # a fixed model: the strategy's per-iteration hooks run (the densification statistics are gathered, as in the reference's
+            # step), but it never refines -- the reference's default starts at iteration 500, which the untimed passes of a long
+            # run would cross (and then N, V and I of the counters pass are no longer those of the timed region)
+            cfg.strategy.refine_start_iter = 10 ** 9
         r = Runner(local_rank, rank, world, cfg, scene_scale=1.0 / 1.1)   # effective scene_scale 1.0
         if args.cloud_scale != 1.0:
             with torch.no_grad():
