@@ -114,10 +114,9 @@ def _engine_case(seed):
     return case
 
 
-@pytest.mark.parametrize("seed", list(range(24)))
-def test_random_engine_configuration_against_the_oracle(dev, seed):
-    """The fused engine (one training iteration's forward + loss + backward) on random combinations of per-view camera
-    models, view counts, image sizes, SH degree, antialiasing, list layout, tile culling, float16 rows and regularisers."""
+def _engine_against_the_oracle(dev, seed):
+    """-> (cfg, engine gradients, oracle gradients (None where the oracle has none), K, forward |difference| map, (engine losses,
+    oracle L1, oracle SSIM loss)): the two legs of the engine fuzz test (also tools/dbg_fuzz_one.py)."""
     from oracle import ssim_oracle as SSO
     from splat_one_amd.engine import FusedEngine
     from splat_one_amd.trainer import Config, Runner
@@ -175,16 +174,24 @@ def test_random_engine_configuration_against_the_oracle(dev, seed):
     loss_o = loss_o + oreg * torch.sigmoid(p["opacities"]).abs().mean() + sreg * torch.exp(p["scales"]).abs().mean()
     loss_o.backward()
     fwd = (eng.ws["render_colors"].cpu().double() - rc.detach()).abs()
+    return cfg, g_eng, {k: p[k].grad for k in p}, K, fwd, (loss_eng, l1_o, ss_o)
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_engine_configuration_against_the_oracle(dev, seed):
+    """The fused engine (one training iteration's forward + loss + backward) on random combinations of per-view camera
+    models, view counts, image sizes, SH degree, antialiasing, list layout, tile culling, float16 rows and regularisers."""
+    cfg, g_eng, g_ref, K, fwd, (loss_eng, l1_o, ss_o) = _engine_against_the_oracle(dev, seed)
     assert fwd.mean().item() <= 1e-4, (cfg, "forward L1", fwd.mean().item(), "max", fwd.max().item(), "pixels > 1e-3", int((fwd > 1e-3).sum()))
     assert abs(loss_eng[1].item() - l1_o.item()) < 2e-5 and abs(loss_eng[2].item() - ss_o.item()) < 2e-5, \
         (cfg, "loss", loss_eng.tolist(), l1_o.item(), ss_o.item())
     bar = float(os.environ.get("SPLAT_ONE_AMD_FUZZ_BAR", 1e-3))     # every camera model: the north_star bar
     for k in g_eng:
-        ref = p[k].grad
+        ref = g_ref[k]
         if ref is None:
             assert not g_eng[k].any(), (cfg, k)
             continue
         if k == "shN" and K < 16:
             assert not g_eng[k][:, K - 1:].any(), (cfg, k)
-        floor = 1e-5 * p["scales"].grad.norm().item() if k == "quats" else 1e-12
+        floor = 1e-5 * g_ref["scales"].norm().item() if k == "quats" else 1e-12
         assert (g_eng[k] - ref).norm().item() <= bar * ref.norm().item() + floor, (cfg, k, (g_eng[k] - ref).norm().item(), ref.norm().item())
