@@ -57,7 +57,8 @@ def block_means(x, block=100):
 
 def run(path="engine", strategy="default", attr_dtype="f32", steps=600, res=256, teacher_n=20_000, teacher_scale=1.0,
         teacher_opacity=0.6, student_n=20_000, refine_every=100, refine_start=100, oracle_steps=0, seed=7, device="cuda:0",
-        result_dir=None, return_runner=False, train_views=8, init="random"):
+        result_dir=None, return_runner=False, train_views=8, init="random", reset_every=100_000, sh_interval=100, refine_stop=None,
+        max_steps=None, time_blocks=0, scene_scale=1.0 / 1.1):
     """init="random": the reference's random initialisation (init_type="random", :224-257).  init="sfm": init_type="sfm" (:216-223) --
     what the reference does on real data: the student starts from a sparse point cloud with colours, here `student_n` of the
     ground-truth centres displaced by N(0, 0.05^2) with their base colours."""
@@ -74,15 +75,15 @@ def run(path="engine", strategy="default", attr_dtype="f32", steps=600, res=256,
     as_view = lambda i: {"camtoworld": ring[i], "K": K, "image": images[i] * 255.0}
     held = [as_view(i) for i in held_ids]
     if strategy == "default":
-        strat = DefaultStrategy(refine_start_iter=refine_start, refine_every=refine_every, refine_stop_iter=steps - 50,
-                                reset_every=100_000, verbose=False)
+        strat = DefaultStrategy(refine_start_iter=refine_start, refine_every=refine_every,
+                                refine_stop_iter=(steps - 50 if refine_stop is None else refine_stop), reset_every=reset_every, verbose=False)
         kw = dict(init_opa=0.1, init_scale=1.0)                                   # the `default` preset, :117-119
     else:
-        strat = MCMCStrategy(refine_start_iter=refine_start, refine_every=refine_every, refine_stop_iter=steps - 50,
+        strat = MCMCStrategy(refine_start_iter=refine_start, refine_every=refine_every, refine_stop_iter=(steps - 50 if refine_stop is None else refine_stop),
                              cap_max=int(1.5 * student_n), verbose=False)
         kw = dict(init_opa=0.5, init_scale=0.1, opacity_reg=0.01, scale_reg=0.01)  # the `mcmc` preset, :977-983
     tmp = result_dir or tempfile.mkdtemp(prefix="train_demo_")
-    cfg = Config(init_num_pts=student_n, strategy=strat, sh_degree_interval=100, max_steps=steps, fused=(path == "engine"),
+    cfg = Config(init_num_pts=student_n, strategy=strat, sh_degree_interval=sh_interval, max_steps=(max_steps or steps), fused=(path == "engine"),
                  attr_dtype=attr_dtype, result_dir=tmp, init_type=init, **kw)
     pts = rgbs = None
     if init == "sfm":
@@ -91,16 +92,27 @@ def run(path="engine", strategy="default", attr_dtype="f32", steps=600, res=256,
         pick = torch.randperm(teacher_n, generator=gi)[:min(student_n, teacher_n)]
         pts = teacher["means"].cpu()[pick] + torch.randn(len(pick), 3, generator=gi) * 0.05
         rgbs = (teacher["sh0"].cpu()[pick, 0] * SH_C0 + 0.5).clamp(0.0, 1.0)
-    r = Runner(0, 0, 1, cfg, scene_scale=1.0 / 1.1, points=pts, rgbs=rgbs)
+    r = Runner(0, 0, 1, cfg, scene_scale=scene_scale, points=pts, rgbs=rgbs)
     init_params = {k: v.detach().clone() for k, v in r.splats.items()}
     cams = [ring[i][None].contiguous().to(dev) for i in train_ids]
     Ks = K[None].to(dev)
     tg = [images[i][None].contiguous() for i in train_ids]
     psnr0 = r.eval(0, dataset=held, save_images=False)["psnr"]
     losses, mid = [], None
+    import time
+    blocks, t_block = [], None
+    if time_blocks:
+        torch.cuda.synchronize()
+        t_block = time.time()
     for it in range(steps):
         v = it % len(cams)
         losses.append(r.train_step(cams[v], Ks, tg[v]).detach().clone())
+        if time_blocks and (it + 1) % time_blocks == 0:      # wall clock per block of iterations (one synchronisation per block)
+            torch.cuda.synchronize()
+            now = time.time()
+            blocks.append({"steps": it + 1, "seconds": round(now - t_block, 3), "it_s": round(time_blocks / (now - t_block), 1),
+                           "gaussians": int(len(r.splats["means"]))})
+            t_block = now
         if oracle_steps and it + 1 == oracle_steps:
             mid = {k: v_.detach().clone().cpu().double() for k, v_ in r.splats.items()}
     torch.cuda.synchronize()
@@ -115,6 +127,9 @@ def run(path="engine", strategy="default", attr_dtype="f32", steps=600, res=256,
            "loss_monotone": all(b < a for a, b in zip(bm, bm[1:])),
            "void_steps": getattr(getattr(r, "_engine", None), "void_steps", 0),
            "fused_engine_ran": getattr(r, "_engine", None) is not None}
+    if blocks:
+        out["blocks"] = blocks
+        out["wall_seconds"] = round(sum(b["seconds"] for b in blocks), 2)
     if oracle_steps:
         out["oracle"] = oracle_leg(init_params, mid, [ring[i] for i in train_ids], [images[i].cpu() for i in train_ids],
                                    [ring[i] for i in held_ids], [images[i].cpu() for i in held_ids], K, res, oracle_steps, steps, cfg)
@@ -174,6 +189,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sweep", action="store_true")
     ap.add_argument("--sweep2", action="store_true")
+    ap.add_argument("--long", action="store_true",
+                    help="the reference's OWN schedule to its first evaluation: 7000 iterations, DefaultStrategy defaults (refine from 500 every 100, "
+                         "opacity reset every 3000), SH degree +1 every 1000, max_steps 30000; wall clock per 1000 iterations")
+    ap.add_argument("--res", type=int, default=256)
+    ap.add_argument("--path", default="engine", choices=["engine", "operator"])
     ap.add_argument("--train-views", type=int, default=8)
     ap.add_argument("--init", default="random", choices=["random", "sfm"])
     ap.add_argument("--steps", type=int, default=600)
@@ -182,6 +202,18 @@ def main():
     ap.add_argument("--teacher-scale", type=float, default=1.0)
     ap.add_argument("--student-n", type=int, default=20_000)
     args = ap.parse_args()
+    if args.long:
+        for strategy in ("default", "mcmc"):
+            o = run(args.path, strategy, steps=7000, res=args.res, teacher_n=args.teacher_n, teacher_scale=args.teacher_scale, student_n=args.student_n,
+                    train_views=args.train_views, init=args.init, refine_start=500, refine_every=100, reset_every=3000, sh_interval=1000,
+                    refine_stop=15000, max_steps=30000, time_blocks=1000,
+                    # the parser's scene scale: the largest distance of a camera from the cameras' centroid (opensfm.py:300-304) = the ring's
+                    # radius, 9.  (With the 1 / 1.1 of the short runs every splat of this cloud is "too big" -- larger than prune_scale3d x
+                    # scene_scale = 0.1 -- once step > reset_every, and DefaultStrategy prunes the model away: seen in both paths.)
+                    scene_scale=9.0)
+            o["loss_block_means"] = [round(x, 5) for x in o["loss_block_means"][::5]]
+            print(json.dumps(o), flush=True)
+        return
     if args.sweep:
         for tn, ts, sn in [(20_000, 1.0, 20_000), (20_000, 1.5, 20_000), (20_000, 1.0, 50_000), (5_000, 1.5, 20_000), (2_000, 2.0, 20_000),
                            (20_000, 0.5, 50_000)]:
