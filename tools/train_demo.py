@@ -58,7 +58,7 @@ def block_means(x, block=100):
 def run(path="engine", strategy="default", attr_dtype="f32", steps=600, res=256, teacher_n=20_000, teacher_scale=1.0,
         teacher_opacity=0.6, student_n=20_000, refine_every=100, refine_start=100, oracle_steps=0, seed=7, device="cuda:0",
         result_dir=None, return_runner=False, train_views=8, init="random", reset_every=100_000, sh_interval=100, refine_stop=None,
-        max_steps=None, time_blocks=0, scene_scale=1.0 / 1.1):
+        max_steps=None, time_blocks=0, scene_scale=1.0 / 1.1, world_rank=0, world_size=1):
     """init="random": the reference's random initialisation (init_type="random", :224-257).  init="sfm": init_type="sfm" (:216-223) --
     what the reference does on real data: the student starts from a sparse point cloud with colours, here `student_n` of the
     ground-truth centres displaced by N(0, 0.05^2) with their base colours."""
@@ -84,7 +84,7 @@ def run(path="engine", strategy="default", attr_dtype="f32", steps=600, res=256,
         kw = dict(init_opa=0.5, init_scale=0.1, opacity_reg=0.01, scale_reg=0.01)  # the `mcmc` preset, :977-983
     tmp = result_dir or tempfile.mkdtemp(prefix="train_demo_")
     cfg = Config(init_num_pts=student_n, strategy=strat, sh_degree_interval=sh_interval, max_steps=(max_steps or steps), fused=(path == "engine"),
-                 attr_dtype=attr_dtype, result_dir=tmp, init_type=init, **kw)
+                 attr_dtype=attr_dtype, result_dir=tmp, init_type=init, **(dict(dp_mode="allreduce") if world_size > 1 else {}), **kw)
     pts = rgbs = None
     if init == "sfm":
         from splat_one_amd.scene import SH_C0
@@ -92,12 +92,14 @@ def run(path="engine", strategy="default", attr_dtype="f32", steps=600, res=256,
         pick = torch.randperm(teacher_n, generator=gi)[:min(student_n, teacher_n)]
         pts = teacher["means"].cpu()[pick] + torch.randn(len(pick), 3, generator=gi) * 0.05
         rgbs = (teacher["sh0"].cpu()[pick, 0] * SH_C0 + 0.5).clamp(0.0, 1.0)
-    r = Runner(0, 0, 1, cfg, scene_scale=scene_scale, points=pts, rgbs=rgbs)
+    # world_size > 1 (called from inside an initialised process group): replicated data parallelism, rank r trains on view
+    # (it * world_size + r) of the cycle -- one view per rank and iteration, the north_star's scheme
+    r = Runner(0, world_rank, world_size, cfg, scene_scale=scene_scale, points=pts, rgbs=rgbs)
     init_params = {k: v.detach().clone() for k, v in r.splats.items()}
     cams = [ring[i][None].contiguous().to(dev) for i in train_ids]
     Ks = K[None].to(dev)
     tg = [images[i][None].contiguous() for i in train_ids]
-    psnr0 = r.eval(0, dataset=held, save_images=False)["psnr"]
+    psnr0 = r.eval(0, dataset=held, save_images=False).get("psnr")     # (rank 0 scores, as in the reference)
     losses, mid = [], None
     import time
     blocks, t_block = [], None
@@ -105,7 +107,7 @@ def run(path="engine", strategy="default", attr_dtype="f32", steps=600, res=256,
         torch.cuda.synchronize()
         t_block = time.time()
     for it in range(steps):
-        v = it % len(cams)
+        v = (it * world_size + world_rank) % len(cams)
         losses.append(r.train_step(cams[v], Ks, tg[v]).detach().clone())
         if time_blocks and (it + 1) % time_blocks == 0:      # wall clock per block of iterations (one synchronisation per block)
             torch.cuda.synchronize()
@@ -122,7 +124,7 @@ def run(path="engine", strategy="default", attr_dtype="f32", steps=600, res=256,
     bm = block_means(losses, refine_every)       # (one refinement period per block: a refinement's new children bump the loss)
     out = {"path": path, "strategy": strategy, "attr_dtype": attr_dtype, "steps": steps, "res": res, "teacher_n": teacher_n,
            "teacher_scale": teacher_scale, "student_n": student_n, "train_views": train_views, "init": init, "n_final": int(len(r.splats["means"])),
-           "psnr_heldout_before": psnr0, "psnr_heldout": st["psnr"], "ssim_heldout": st["ssim"], "psnr_train": st_train["psnr"],
+           "psnr_heldout_before": psnr0, "psnr_heldout": st.get("psnr"), "ssim_heldout": st.get("ssim"), "psnr_train": st_train.get("psnr"),
            "loss_first": losses[0], "loss_last": losses[-1], "loss_block_means": bm,
            "loss_monotone": all(b < a for a, b in zip(bm, bm[1:])),
            "void_steps": getattr(getattr(r, "_engine", None), "void_steps", 0),
