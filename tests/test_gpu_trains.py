@@ -91,19 +91,15 @@ def test_the_references_own_schedule_through_the_first_opacity_reset(dev, tmp_pa
 
 def _dp_train_worker(local_rank, world_rank, world_size, args):
     import torch
-    out_dir, steps = args
+    out_dir, steps, dp_mode = args
     out, r = _demo().run("engine", "default", steps=steps, train_views=VIEWS, return_runner=True, world_rank=world_rank, world_size=world_size,
-                         result_dir=os.path.join(out_dir, f"r{world_rank}"))
+                         dp_mode=dp_mode, result_dir=os.path.join(out_dir, f"r{world_rank}"))
     torch.cuda.synchronize()
     out["splats"] = {k: v.detach().cpu() for k, v in r.splats.items()}
     torch.save(out, os.path.join(out_dir, f"rank{world_rank}.pt"))
 
 
-def test_two_replicas_train_the_scene_together(dev, tmp_path, runs):
-    """Replicated data parallelism END TO END (SURVEY.md 8e): two ranks (gloo, sharing the one GPU), one view per rank and
-    iteration, reduce-scatter / row-sharded Adam / all-gather every step, DefaultStrategy refining on the device every 100 iterations
-    from the all-reduced statistics -- 400 iterations (= 800 views, what the one-GPU run of this file sees).  The replicas stay
-    bit-identical through every refinement and reach the one-GPU run's quality."""
+def _two_ranks(tmp_path, dp_mode):
     import socket
     import torch
     from splat_one_amd import distributed as sdist
@@ -112,12 +108,34 @@ def test_two_replicas_train_the_scene_together(dev, tmp_path, runs):
         port = s_.getsockname()[1]
     env_backup = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     try:
-        sdist.cli(_dp_train_worker, (str(tmp_path), STEPS // 2), world_size=2, backend="gloo", port=port)
+        sdist.cli(_dp_train_worker, (str(tmp_path), STEPS // 2, dp_mode), world_size=2, backend="gloo", port=port)
     finally:
         for k, v in env_backup.items():
             if v is not None:
                 os.environ[k] = v
-    a, b = torch.load(os.path.join(tmp_path, "rank0.pt")), torch.load(os.path.join(tmp_path, "rank1.pt"))
+    return torch.load(os.path.join(tmp_path, "rank0.pt")), torch.load(os.path.join(tmp_path, "rank1.pt"))
+
+
+def test_two_gaussian_shards_train_the_scene_together(dev, tmp_path, runs):
+    """The reference's own multi-GPU scheme END TO END (gsplat's `distributed=True`; gsplat_trainer.py:204-281 strides the initial
+    points over the ranks): each of two ranks (gloo, sharing the one GPU) holds half of the Gaussians, projects them for the cameras of
+    BOTH ranks, exchanges the 64-byte records in one all-to-all each way and refines its own shard -- 400 iterations."""
+    a, b = _two_ranks(tmp_path, "gaussian_sharded")
+    one = runs["engine"]
+    print(f"two Gaussian shards x {STEPS // 2} iterations: {a['psnr_heldout']:.2f} dB, {a['n_final']} + {b['n_final']} Gaussians;  one GPU x {STEPS}: "
+          f"{one['psnr_heldout']:.2f} dB, {one['n_final']}")
+    assert a["fused_engine_ran"] and a["void_steps"] == 0 and b["void_steps"] == 0
+    assert a["n_final"] + b["n_final"] > a["student_n"], (a["n_final"], b["n_final"])
+    assert a["psnr_heldout"] >= 24.0 and a["psnr_heldout"] >= one["psnr_heldout"] - 2.5, (a["psnr_heldout"], one["psnr_heldout"])
+
+
+def test_two_replicas_train_the_scene_together(dev, tmp_path, runs):
+    """Replicated data parallelism END TO END (SURVEY.md 8e): two ranks (gloo, sharing the one GPU), one view per rank and
+    iteration, reduce-scatter / row-sharded Adam / all-gather every step, DefaultStrategy refining on the device every 100 iterations
+    from the all-reduced statistics -- 400 iterations (= 800 views, what the one-GPU run of this file sees).  The replicas stay
+    bit-identical through every refinement and reach the one-GPU run's quality."""
+    import torch
+    a, b = _two_ranks(tmp_path, "allreduce")
     assert a["fused_engine_ran"] and a["void_steps"] == 0 and b["void_steps"] == 0
     assert a["n_final"] == b["n_final"] and a["n_final"] > a["student_n"], (a["n_final"], b["n_final"])
     for k in a["splats"]:

@@ -58,7 +58,7 @@ def block_means(x, block=100):
 def run(path="engine", strategy="default", attr_dtype="f32", steps=600, res=256, teacher_n=20_000, teacher_scale=1.0,
         teacher_opacity=0.6, student_n=20_000, refine_every=100, refine_start=100, oracle_steps=0, seed=7, device="cuda:0",
         result_dir=None, return_runner=False, train_views=8, init="random", reset_every=100_000, sh_interval=100, refine_stop=None,
-        max_steps=None, time_blocks=0, scene_scale=1.0 / 1.1, world_rank=0, world_size=1):
+        max_steps=None, time_blocks=0, scene_scale=1.0 / 1.1, world_rank=0, world_size=1, dp_mode="allreduce"):
     """init="random": the reference's random initialisation (init_type="random", :224-257).  init="sfm": init_type="sfm" (:216-223) --
     what the reference does on real data: the student starts from a sparse point cloud with colours, here `student_n` of the
     ground-truth centres displaced by N(0, 0.05^2) with their base colours."""
@@ -84,7 +84,7 @@ def run(path="engine", strategy="default", attr_dtype="f32", steps=600, res=256,
         kw = dict(init_opa=0.5, init_scale=0.1, opacity_reg=0.01, scale_reg=0.01)  # the `mcmc` preset, :977-983
     tmp = result_dir or tempfile.mkdtemp(prefix="train_demo_")
     cfg = Config(init_num_pts=student_n, strategy=strat, sh_degree_interval=sh_interval, max_steps=(max_steps or steps), fused=(path == "engine"),
-                 attr_dtype=attr_dtype, result_dir=tmp, init_type=init, **(dict(dp_mode="allreduce") if world_size > 1 else {}), **kw)
+                 attr_dtype=attr_dtype, result_dir=tmp, init_type=init, **(dict(dp_mode=dp_mode) if world_size > 1 else {}), **kw)
     pts = rgbs = None
     if init == "sfm":
         from splat_one_amd.scene import SH_C0
@@ -108,7 +108,11 @@ def run(path="engine", strategy="default", attr_dtype="f32", steps=600, res=256,
         t_block = time.time()
     for it in range(steps):
         v = (it * world_size + world_rank) % len(cams)
-        losses.append(r.train_step(cams[v], Ks, tg[v]).detach().clone())
+        if r.sharded:      # the reference's scheme (Gaussian shards): a step takes the cameras of ALL ranks and the own image
+            vs = [(it * world_size + q) % len(cams) for q in range(world_size)]
+            losses.append(r.train_step(torch.cat([cams[q] for q in vs]), Ks.repeat(world_size, 1, 1), tg[v]).detach().clone())
+        else:
+            losses.append(r.train_step(cams[v], Ks, tg[v]).detach().clone())
         if time_blocks and (it + 1) % time_blocks == 0:      # wall clock per block of iterations (one synchronisation per block)
             torch.cuda.synchronize()
             now = time.time()
