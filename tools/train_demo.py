@@ -38,14 +38,15 @@ def teacher_scene(n, scale_mult, opacity, seed, dev):
     return {k: v.to(dev) for k, v in s.items()}
 
 
-def render_views(splats, cams, K, res, dev):
+def render_views(splats, cams, K, res, dev, camera_model="pinhole"):
     from splat_one_amd import rasterization
     out = []
     with torch.no_grad():
         for c2w in cams:
             rc, _, _ = rasterization(splats["means"], splats["quats"], torch.exp(splats["scales"]), torch.sigmoid(splats["opacities"]),
                                      torch.cat([splats["sh0"], splats["shN"]], 1), torch.linalg.inv(c2w)[None].to(dev), K[None].to(dev),
-                                     res, res, sh_degree=3, near_plane=0.01, far_plane=1e8, packed=False)
+                                     (2 * res if camera_model == "spherical" else res), res, sh_degree=3, near_plane=0.01, far_plane=1e8,
+                                     packed=False, camera_model=camera_model)
             out.append(rc[0, ..., :3].clamp(0.0, 1.0).contiguous())
     return out
 
@@ -58,7 +59,7 @@ def block_means(x, block=100):
 def run(path="engine", strategy="default", attr_dtype="f32", steps=600, res=256, teacher_n=20_000, teacher_scale=1.0,
         teacher_opacity=0.6, student_n=20_000, refine_every=100, refine_start=100, oracle_steps=0, seed=7, device="cuda:0",
         result_dir=None, return_runner=False, train_views=8, init="random", reset_every=100_000, sh_interval=100, refine_stop=None,
-        max_steps=None, time_blocks=0, scene_scale=1.0 / 1.1, world_rank=0, world_size=1, dp_mode="allreduce"):
+        max_steps=None, time_blocks=0, scene_scale=1.0 / 1.1, world_rank=0, world_size=1, dp_mode="allreduce", camera_model="pinhole"):
     """init="random": the reference's random initialisation (init_type="random", :224-257).  init="sfm": init_type="sfm" (:216-223) --
     what the reference does on real data: the student starts from a sparse point cloud with colours, here `student_n` of the
     ground-truth centres displaced by N(0, 0.05^2) with their base colours."""
@@ -69,8 +70,20 @@ def run(path="engine", strategy="default", attr_dtype="f32", steps=600, res=256,
     n_ring = 2 * train_views
     ring = ring_cameras(n_ring)
     K = pinhole_K(res, res)
+    if camera_model == "spherical":
+        # the reference's DEFAULT camera model (gsplat_trainer.py:460-461): 360-degree equirectangular images, 2 res x res, taken from INSIDE
+        # the cloud -- positions on a circle of radius 1 around its centre, a little up and down, each camera turned about the vertical axis
+        K = pinhole_K(2 * res, res)
+        ring = []
+        for k in range(n_ring):
+            th = 2 * math.pi * k / n_ring
+            c2w = torch.eye(4)
+            c2w[0, 0], c2w[0, 2], c2w[2, 0], c2w[2, 2] = math.cos(2 * th), math.sin(2 * th), -math.sin(2 * th), math.cos(2 * th)
+            c2w[:3, 3] = torch.tensor([math.sin(th), 0.3 * math.cos(3 * th), math.cos(th)])
+            ring.append(c2w)
+        ring = torch.stack(ring)
     teacher = teacher_scene(teacher_n, teacher_scale, teacher_opacity, seed, dev)
-    images = render_views(teacher, ring, K, res, dev)
+    images = render_views(teacher, ring, K, res, dev, camera_model)
     train_ids, held_ids = list(range(0, n_ring, 2)), list(range(1, n_ring, 2))
     as_view = lambda i: {"camtoworld": ring[i], "K": K, "image": images[i] * 255.0}
     held = [as_view(i) for i in held_ids]
@@ -84,7 +97,7 @@ def run(path="engine", strategy="default", attr_dtype="f32", steps=600, res=256,
         kw = dict(init_opa=0.5, init_scale=0.1, opacity_reg=0.01, scale_reg=0.01)  # the `mcmc` preset, :977-983
     tmp = result_dir or tempfile.mkdtemp(prefix="train_demo_")
     cfg = Config(init_num_pts=student_n, strategy=strat, sh_degree_interval=sh_interval, max_steps=(max_steps or steps), fused=(path == "engine"),
-                 attr_dtype=attr_dtype, result_dir=tmp, init_type=init, **(dict(dp_mode=dp_mode) if world_size > 1 else {}), **kw)
+                 attr_dtype=attr_dtype, result_dir=tmp, init_type=init, camera_model=camera_model, **(dict(dp_mode=dp_mode) if world_size > 1 else {}), **kw)
     pts = rgbs = None
     if init == "sfm":
         from splat_one_amd.scene import SH_C0
