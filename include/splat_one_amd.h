@@ -516,6 +516,15 @@ typedef struct so_step_desc {
    * rank sort) and writes flatten_ids for the backward.  One launch and one pass over the keys fewer where lists are short
    * everywhere; the same lists, images and gradients either way. */
   int32_t sort_in_rasteriser;
+  /* Replicated bin counters (binned lists; needs n_dev or record-only views; bin_capacity % bin_replicas == 0).  R = bin_replicas
+   * > 1: the returning atomics of ONE counter serialise (~230 ns each on an MI355X), so on images of few tiles with long lists
+   * the binning pass runs at 4 G atomics/s instead of ~19.  With R copies of the counters -- bin_sub_counts: int32[R * C * tiles
+   * + 1], zero on entry, kept zero by the step; the last word is raised to R x the fullest slice when a slice overflows -- a
+   * workgroup of the projection kernel bumps copy (workgroup % R) and fills slice (workgroup % R) of the bin (bin_capacity / R
+   * slots each); one small launch then closes the slices up and writes the list lengths where they always are (`counters`).
+   * Same lists after the sort, same images and gradients; a slice that overflows voids the iteration like a bin that overflows. */
+  int32_t bin_replicas;
+  int32_t *bin_sub_counts;
 } so_step_desc;
 typedef struct so_adam_fuse {
   so_adam_group groups[6]; /* means, log_scales, quats, logit_opacities, sh0, shN: param / exp_avg / exp_avg_sq (grad unused) */

@@ -45,7 +45,8 @@ class StepDesc(ctypes.Structure):
                                 "scale_reg")]
         + [("pixels_indirect", c_ptr), ("inputs_staged", ctypes.c_int32), ("tile_cull", ctypes.c_int32),
            ("overflow_flag_out", c_ptr), ("attr_rows_f16", c_ptr), ("tile_slots", c_ptr), ("bin_capacity", c_i64), ("fuse_adam", c_ptr),
-           ("n_dev", c_ptr), ("tile_order", c_ptr), ("sort_in_rasteriser", ctypes.c_int32)])
+           ("n_dev", c_ptr), ("tile_order", c_ptr), ("sort_in_rasteriser", ctypes.c_int32),
+           ("bin_replicas", ctypes.c_int32), ("bin_sub_counts", c_ptr)])
 
 
 class RasterDesc(ctypes.Structure):

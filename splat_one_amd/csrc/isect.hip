@@ -919,6 +919,60 @@ extern "C" int so_isect_offset_encode(int64_t n_isects, const int64_t *isect_ids
   return so::check_launch("so_isect_offset_encode");
 }
 
+// Replicated bin counters (so_step_desc.bin_replicas = R > 1): k_preprocess_fwd filled R slices of every tile's bin, slice r
+// with sub_counts[r * M + bin_counter_index(t)] keys from slot r * bin_cap / R on.  One wave per tile closes the slices up into one
+// run from slot 0 (slice r moves DOWN to the sum of the clamped counts before it: its destination never reaches the source of a
+// later slice, and inside a slice a chunk is read whole before it is written), writes the run's length where every consumer of
+// binned lists reads it (tile_counts[bin_counter_index(t)]), zeroes the tile's sub-counters for the next iteration, and -- only if a
+// slice overflowed -- raises `eff_fullest` to R x the fullest slice: the bin capacity this tile would have needed.
+namespace so {
+__global__ void __launch_bounds__(256)
+k_bins_gather(int M, int R, int32_t *__restrict__ sub_counts, int32_t *__restrict__ tile_counts, uint64_t *__restrict__ bin_keys,
+              int64_t bin_cap, int32_t *__restrict__ eff_fullest) {
+  const int lane = threadIdx.x & 63;
+  const int t = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (t >= M) return;                       // (wave-uniform)
+  const int64_t at = bin_counter_index(t, M);
+  const int cap_r = (int)(bin_cap / R);
+  int raw = 0;
+  if (lane < R) {
+    raw = sub_counts[(int64_t)lane * M + at];
+    sub_counts[(int64_t)lane * M + at] = 0;
+  }
+  const int cnt = raw < cap_r ? raw : cap_r;
+  int inc = cnt;                            // inclusive scan over the R <= 64 slices
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  const int total = __shfl(inc, 63, 64);
+  const int fullest = wave_max_i32(raw);
+  if (lane == 0) {
+    tile_counts[at] = total;
+    if (fullest > cap_r) atomicMax(eff_fullest, fullest * R);
+  }
+  uint64_t *const keys = bin_keys + (int64_t)t * bin_cap;
+  for (int r = 1; r < R; ++r) {             // (wave-uniform trip counts: the counts come from lane r)
+    const int n = __shfl(cnt, r, 64), dst = __shfl(inc - cnt, r, 64), src = r * cap_r;
+    if (dst == src) continue;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const uint64_t k = i0 + lane < n ? keys[src + i0 + lane] : 0ull;
+      if (i0 + lane < n) keys[dst + i0 + lane] = k;      // (one wave: the loads of a chunk are complete before its stores issue)
+    }
+  }
+}
+
+int bins_gather_launch(int64_t M, int R, int32_t *sub_counts, int32_t *tile_counts, uint64_t *bin_keys, int64_t bin_cap,
+                       int32_t *eff_fullest, hipStream_t st) {
+  SO_REQUIRE(M > 0 && M < ((int64_t)1 << 25) && R > 1 && R <= 64 && bin_cap % R == 0 && sub_counts && tile_counts && bin_keys && eff_fullest,
+             "so_train_step_fwd_bwd: bad replicated-counter arguments");
+  hipLaunchKernelGGL(k_bins_gather, dim3((unsigned)((M * 64 + 255) / 256)), dim3(256), 0, st, (int)M, R, sub_counts, tile_counts, bin_keys,
+                     bin_cap, eff_fullest);
+  return check_launch("so_train_step_fwd_bwd (bins gather)");
+}
+}  // namespace so
+
 // Binned lists (so_preprocess_fwd bin_keys): sorts every tile's min(tile_counts[t], bin_cap) keys in place and writes
 // flatten_ids[t * bin_cap + i].  long_list: int32[M + 1] scratch whose LAST element is zero on entry.
 extern "C" int so_isect_sort_bins(int C, int tile_width, int tile_height, const int32_t *tile_counts, int64_t bin_cap,

@@ -136,12 +136,20 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
                  int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ tile_counts,
                  float4 *__restrict__ rec, float4 *__restrict__ vrec, int64_t cam_stride,
                  int32_t *__restrict__ tile_slots, int tile_cull, uint64_t *__restrict__ bin_keys, int64_t bin_cap,
-                 int32_t *__restrict__ bin_overflow, const int32_t *__restrict__ n_dev, int wrap_ok) {
+                 int32_t *__restrict__ bin_overflow, const int32_t *__restrict__ n_dev, int wrap_ok,
+                 int32_t *__restrict__ sub_counts, int replicas) {
   // n_dev (nullable): the number of Gaussians lives in device memory (device-side densification, so_refine_default):
   // N is then the CAPACITY of the buffers, rows n >= *n_dev are idle -- a captured launch follows N without re-capture
   const int n_live = n_dev ? min(*n_dev, N) : N;
   const int64_t total = (int64_t)C * N;
   const int n_tiles = tile_w * tile_h;
+  // Replicated bin counters (so_step_desc.bin_replicas > 1: images of few tiles, where the returning atomics of one counter
+  // serialise -- tools/census/xcd_atomics.hip: 4.4 G/s on 1024 counters against 17 G/s on eight copies of them): this workgroup
+  // bumps copy `rep` of a tile's counter and fills slice `rep` of the tile's bin; k_bins_gather closes the slices up before the sort.
+  const int rep = replicas > 1 ? (int)(blockIdx.x % (unsigned)replicas) : 0;
+  int32_t *const bcnt = replicas > 1 ? sub_counts + (int64_t)rep * ((int64_t)C * n_tiles) : tile_counts;
+  const int64_t bcap = replicas > 1 ? bin_cap / replicas : bin_cap;      // slots of a slice
+  const int64_t boff = (int64_t)rep * bcap;
   // the trip count is uniform over the workgroup: the histogram section below needs every lane of a wave
   for (int64_t lin0 = (int64_t)blockIdx.x * blockDim.x; lin0 < total; lin0 += (int64_t)gridDim.x * blockDim.x) {
     const int64_t lin = lin0 + threadIdx.x;
@@ -256,7 +264,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
         got[i] = -1;
         if (i < cnt) {
           if (!tile_cull || tile_touches(cmx, cmy, cqa, cqb, cqc, ctau, x, y, tile_size))
-            got[i] = atomicAdd(tile_counts + bin_counter_index((int64_t)c * n_tiles + y * tile_w + wrapx(x, tile_w), (int64_t)C * n_tiles), 1);
+            got[i] = atomicAdd(bcnt + bin_counter_index((int64_t)c * n_tiles + y * tile_w + wrapx(x, tile_w), (int64_t)C * n_tiles), 1);
           if (++x == bx1) { x = bx0; ++y; }
         }
       }
@@ -339,7 +347,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
               got[i] = -1;
               if (i < cnt) {
                 if (!tile_cull || tile_touches(cmx, cmy, cqa, cqb, cqc, ctau, x, y, tile_size))
-                  got[i] = atomicAdd(tile_counts + bin_counter_index((int64_t)c * n_tiles + y * tile_w + wrapx(x, tile_w), (int64_t)C * n_tiles), 1);
+                  got[i] = atomicAdd(bcnt + bin_counter_index((int64_t)c * n_tiles + y * tile_w + wrapx(x, tile_w), (int64_t)C * n_tiles), 1);
                 if (++x == bx1) { x = bx0; ++y; }
               }
             }
@@ -352,7 +360,7 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
               const int32_t s = got[i];
               if (s >= 0) {
                 const int64_t t = (int64_t)c * n_tiles + y * tile_w + wrapx(x, tile_w);
-                if (s < bin_cap) bin_keys[t * bin_cap + s] = key;
+                if (s < bcap) bin_keys[t * bin_cap + boff + s] = key;
                 else over = true;
               }
               if (++x == bx1) { x = bx0; ++y; }
@@ -401,8 +409,8 @@ k_preprocess_fwd(int C, int N, const float *__restrict__ means, const float *__r
             if (!tile_cull || tile_touches(smx, smy, sqa, sqb, sqc, stau, x, y, tile_size)) {
               if (bin_keys) {
                 const int64_t t = srow + y * tile_w + wrapx(x, tile_w);
-                const int32_t s = atomicAdd(tile_counts + bin_counter_index(t, (int64_t)C * n_tiles), 1);
-                if (s < bin_cap) bin_keys[t * bin_cap + s] = skey;
+                const int32_t s = atomicAdd(bcnt + bin_counter_index(t, (int64_t)C * n_tiles), 1);
+                if (s < bcap) bin_keys[t * bin_cap + boff + s] = skey;
                 else *bin_overflow = 1;
               } else {
                 atomicAdd(row + y * tile_w + wrapx(x, tile_w), 1);
@@ -816,8 +824,10 @@ static int preprocess_fwd_impl(const char *what, int C, int N, int K, int sh_deg
                                float *depths, float *conics, float *opacities, float *colors, int32_t *tiles_per_gauss,
                                int32_t *tile_counts, float *rec, float *vrec, int64_t cam_stride, int32_t *tile_slots,
                                int tile_cull, uint64_t *bin_keys, int64_t bin_cap, int32_t *bin_overflow, void *stream,
-                               const int32_t *n_dev = nullptr) {
+                               const int32_t *n_dev = nullptr, int32_t *sub_counts = nullptr, int replicas = 1) {
   SO_REQUIRE(C >= 0 && N >= 0 && K >= 1 && width > 0 && height > 0 && tile_size > 0, "%s: bad sizes", what);
+  SO_REQUIRE(replicas <= 1 || (bin_keys && sub_counts && replicas <= 64 && bin_cap % replicas == 0),
+             "%s: replicated bin counters need binned lists, the counter copies and bin_cap %% replicas == 0", what);
   SO_REQUIRE(tile_slots == nullptr || tile_counts != nullptr, "%s: tile_slots need the histogram (tile_counts)", what);
   SO_REQUIRE(sh_degree >= 0 && sh_degree <= 4 && (sh_degree + 1) * (sh_degree + 1) <= K,
              "%s: sh_degree %d does not fit K=%d", what, sh_degree, K);
@@ -857,7 +867,7 @@ static int preprocess_fwd_impl(const char *what, int C, int N, int K, int sh_deg
                      Ks, width, height, eps2d, near_plane, far_plane, radius_clip, camera_model, antialiased,      \
                      (float)tile_size, tile_w, tile_h, radii, means2d, depths, conics, opacities, colors,          \
                      tiles_per_gauss, tile_counts, reinterpret_cast<float4 *>(rec), reinterpret_cast<float4 *>(vrec), \
-                     cam_stride, tile_slots, tile_cull, bin_keys, bin_cap, bin_overflow, n_dev, (int)(width % tile_size == 0))
+                     cam_stride, tile_slots, tile_cull, bin_keys, bin_cap, bin_overflow, n_dev, (int)(width % tile_size == 0), sub_counts, replicas)
   switch (sh_degree) {
     case 0: SO_LAUNCH(0); break;
     case 1: SO_LAUNCH(1); break;
@@ -1078,13 +1088,13 @@ int preprocess_fwd_n(int C, int N, int K, int sh_degree, const float *means, con
                      int antialiased, int tile_size, int32_t *radii, float *means2d, float *depths, float *conics,
                      float *opacities, float *colors, int32_t *tiles_per_gauss, int32_t *tile_counts, float *rec, float *vrec,
                      int32_t *tile_slots, int tile_cull, uint64_t *bin_keys, int64_t bin_cap, int32_t *bin_overflow,
-                     const int32_t *n_dev, void *stream) {
+                     const int32_t *n_dev, void *stream, int32_t *sub_counts, int replicas) {
   SO_REQUIRE((int64_t)C * N == 0 || (log_scales && quats && sh0 && (shN || K == 1)), "so_preprocess_fwd: null pointer");
   const AttrSoA attrs{log_scales, quats, sh0, shN, K};
   return preprocess_fwd_impl("so_preprocess_fwd", C, N, K, sh_degree, means, logit_opacities, attrs, viewmats, Ks, width, height,
                              eps2d, near_plane, far_plane, radius_clip, camera_model, antialiased, tile_size, radii, means2d,
                              depths, conics, opacities, colors, tiles_per_gauss, tile_counts, rec, vrec, 0, tile_slots, tile_cull,
-                             bin_keys, bin_cap, bin_overflow, stream, n_dev);
+                             bin_keys, bin_cap, bin_overflow, stream, n_dev, sub_counts, replicas);
 }
 int preprocess_bwd_n(int C, int N, int K, int sh_degree, const float *means, const float *log_scales, const float *quats,
                      const float *logit_opacities, const float *sh0, const float *shN, const float *viewmats, const float *Ks,
@@ -1143,13 +1153,13 @@ int preprocess_fwd_n_f16(int C, int N, int K, int sh_degree, const float *means,
                          float far_plane, float radius_clip, int camera_model, int antialiased, int tile_size, int32_t *radii,
                          float *means2d, float *depths, float *conics, float *opacities, float *colors, int32_t *tiles_per_gauss,
                          int32_t *tile_counts, float *rec, float *vrec, int32_t *tile_slots, int tile_cull, uint64_t *bin_keys,
-                         int64_t bin_cap, int32_t *bin_overflow, const int32_t *n_dev, void *stream) {
+                         int64_t bin_cap, int32_t *bin_overflow, const int32_t *n_dev, void *stream, int32_t *sub_counts, int replicas) {
   SO_REQUIRE((int64_t)C * N == 0 || attr_rec_ok(arec), "so_preprocess_fwd_f16: arec must be non-null and 16-byte aligned");
   const AttrRec attrs{reinterpret_cast<const uint4 *>(arec), attr_rec_stride_bytes(K < 1 ? 1 : K) / 16};
   return preprocess_fwd_impl("so_preprocess_fwd_f16", C, N, K, sh_degree, means, logit_opacities, attrs, viewmats, Ks, width,
                              height, eps2d, near_plane, far_plane, radius_clip, camera_model, antialiased, tile_size, radii,
                              means2d, depths, conics, opacities, colors, tiles_per_gauss, tile_counts, rec, vrec, 0, tile_slots,
-                             tile_cull, bin_keys, bin_cap, bin_overflow, stream, n_dev);
+                             tile_cull, bin_keys, bin_cap, bin_overflow, stream, n_dev, sub_counts, replicas);
 }
 int preprocess_bwd_n_f16(int C, int N, int K, int sh_degree, const float *means, const float *logit_opacities, const void *arec,
                          const float *viewmats, const float *Ks, int width, int height, float eps2d, int camera_model,

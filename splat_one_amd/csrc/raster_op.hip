@@ -33,7 +33,7 @@ int preprocess_fwd_n(int C, int N, int K, int sh_degree, const float *means, con
                      int antialiased, int tile_size, int32_t *radii, float *means2d, float *depths, float *conics,
                      float *opacities, float *colors, int32_t *tiles_per_gauss, int32_t *tile_counts, float *rec, float *vrec,
                      int32_t *tile_slots, int tile_cull, uint64_t *bin_keys, int64_t bin_cap, int32_t *bin_overflow,
-                     const int32_t *n_dev, void *stream);
+                     const int32_t *n_dev, void *stream, int32_t *sub_counts = nullptr, int replicas = 1);
 int preprocess_bwd_n(int C, int N, int K, int sh_degree, const float *means, const float *log_scales, const float *quats,
                      const float *logit_opacities, const float *sh0, const float *shN, const float *viewmats, const float *Ks,
                      int width, int height, float eps2d, int camera_model, int antialiased, const int32_t *radii,

@@ -86,7 +86,7 @@ int preprocess_fwd_n(int C, int N, int K, int sh_degree, const float *means, con
                      int antialiased, int tile_size, int32_t *radii, float *means2d, float *depths, float *conics,
                      float *opacities, float *colors, int32_t *tiles_per_gauss, int32_t *tile_counts, float *rec, float *vrec,
                      int32_t *tile_slots, int tile_cull, uint64_t *bin_keys, int64_t bin_cap, int32_t *bin_overflow,
-                     const int32_t *n_dev, void *stream);
+                     const int32_t *n_dev, void *stream, int32_t *sub_counts = nullptr, int replicas = 1);
 int preprocess_bwd_n(int C, int N, int K, int sh_degree, const float *means, const float *log_scales, const float *quats,
                      const float *logit_opacities, const float *sh0, const float *shN, const float *viewmats, const float *Ks,
                      int width, int height, float eps2d, int camera_model, int antialiased, const int32_t *radii,
@@ -99,7 +99,8 @@ int preprocess_fwd_n_f16(int C, int N, int K, int sh_degree, const float *means,
                          float far_plane, float radius_clip, int camera_model, int antialiased, int tile_size, int32_t *radii,
                          float *means2d, float *depths, float *conics, float *opacities, float *colors, int32_t *tiles_per_gauss,
                          int32_t *tile_counts, float *rec, float *vrec, int32_t *tile_slots, int tile_cull, uint64_t *bin_keys,
-                         int64_t bin_cap, int32_t *bin_overflow, const int32_t *n_dev, void *stream);
+                         int64_t bin_cap, int32_t *bin_overflow, const int32_t *n_dev, void *stream, int32_t *sub_counts = nullptr,
+                         int replicas = 1);
 int preprocess_bwd_n_f16(int C, int N, int K, int sh_degree, const float *means, const float *logit_opacities, const void *arec,
                          const float *viewmats, const float *Ks, int width, int height, float eps2d, int camera_model,
                          int antialiased, const int32_t *radii, const float *opacities, const float *colors, float opacity_reg,
@@ -265,6 +266,10 @@ extern "C" int so_step_inputs(int C, const float *camtoworlds, const float *Ks_s
 // path of gsplat_trainer.py:779-940 on the same static buffers, also hipGraph-capturable.
 extern "C" int so_render_forward(const so_step_desc *d, void *stream) { return step_impl(d, stream, STEP_FORWARD); }
 
+namespace so {
+int bins_gather_launch(int64_t M, int R, int32_t *sub_counts, int32_t *tile_counts, uint64_t *bin_keys, int64_t bin_cap,
+                       int32_t *eff_fullest, hipStream_t st);
+}
 static int step_impl(const so_step_desc *d, void *stream, StepPart part, int64_t row_begin, int64_t row_end) {
   const bool forward_only = part == STEP_FORWARD;
   SO_REQUIRE(d != nullptr, "so_train_step_fwd_bwd: null descriptor");
@@ -311,19 +316,25 @@ static int step_impl(const so_step_desc *d, void *stream, StepPart part, int64_t
   SO_REQUIRE(bins == 0 || M * bins < ((int64_t)1 << 31), "so_train_step_fwd_bwd: C*tiles*bin_capacity does not fit 31 bits");
   int32_t *slots = bins ? nullptr : d->tile_slots;
   uint64_t *bin_keys = bins ? d->key_buf : nullptr;
+  // replicated bin counters (few tiles, see k_bins_gather): the projection bumps copy (workgroup % R) of a tile's counter
+  const int reps = d->bin_replicas > 1 ? d->bin_replicas : 1;
+  SO_REQUIRE(reps == 1 || (bins && d->bin_sub_counts && bins % reps == 0 && (d->n_dev || !d->radii)),
+             "so_train_step_fwd_bwd: bin_replicas needs binned lists with bin_capacity %% bin_replicas == 0, bin_sub_counts, and the "
+             "device-resident count (n_dev) or record-only views");
   SO_REQUIRE(d->radii || (d->rec && !d->attr_rows_f16 && bins), "so_train_step_fwd_bwd: record-only views (radii == NULL) need rec, float32 attributes and binned lists");
   if (d->n_dev && d->attr_rows_f16)
     SO_STAGE(0, so::preprocess_fwd_n_f16(C, N, K, d->sh_degree, d->means, d->logit_opacities, d->attr_rows_f16, d->viewmats, d->Ks,
                                          W, H, d->eps2d, d->near_plane, d->far_plane, d->radius_clip, d->camera_model,
                                          d->antialiased, ts, d->radii, d->means2d, d->depths, d->conics, d->opacities, d->colors,
                                          d->tiles_per_gauss, tile_counts, d->rec, forward_only ? nullptr : d->vrec, slots,
-                                         d->tile_cull, bin_keys, bins, overflow, d->n_dev, stream));
+                                         d->tile_cull, bin_keys, bins, overflow, d->n_dev, stream, d->bin_sub_counts, reps));
   else if (d->n_dev || !d->radii)
     SO_STAGE(0, so::preprocess_fwd_n(C, N, K, d->sh_degree, d->means, d->log_scales, d->quats, d->logit_opacities, d->sh0, d->shN,
                                      d->viewmats, d->Ks, W, H, d->eps2d, d->near_plane, d->far_plane, d->radius_clip,
                                      d->camera_model, d->antialiased, ts, d->radii, d->means2d, d->depths, d->conics,
                                      d->opacities, d->colors, d->tiles_per_gauss, tile_counts, d->rec,
-                                     forward_only ? nullptr : d->vrec, slots, d->tile_cull, bin_keys, bins, overflow, d->n_dev, stream));
+                                     forward_only ? nullptr : d->vrec, slots, d->tile_cull, bin_keys, bins, overflow, d->n_dev, stream,
+                                     d->bin_sub_counts, reps));
   else if (d->attr_rows_f16)
     SO_STAGE(0, so_preprocess_fwd_f16(C, N, K, d->sh_degree, d->means, d->logit_opacities, d->attr_rows_f16, d->viewmats, d->Ks,
                                       W, H, d->eps2d, d->near_plane, d->far_plane, d->radius_clip, d->camera_model,
@@ -336,6 +347,8 @@ static int step_impl(const so_step_desc *d, void *stream, StepPart part, int64_t
                            d->opacities, d->colors, d->tiles_per_gauss, tile_counts, d->rec, forward_only ? nullptr : d->vrec, 0, slots, d->tile_cull, bin_keys, bins, overflow, stream));
   // sort_in_rasteriser: the forward rasteriser's workgroups sort their own lists (binned lists, 16x16 tiles; short lists)
   const bool fold_sort = bins && d->sort_in_rasteriser && ts == 16;
+  if (reps > 1)    // close the R slices of every bin up into one run; tile_counts gets the run lengths (timed with the sort)
+    SO_STAGE(2, so::bins_gather_launch(M, reps, d->bin_sub_counts, tile_counts, d->key_buf, bins, d->bin_sub_counts + (int64_t)reps * M, st));
   if (fold_sort) {
   } else if (bins) {
     SO_STAGE(2, so_isect_sort_bins(C, tile_w, tile_h, tile_counts, bins, d->key_buf, d->flatten_ids, cursor, stream));

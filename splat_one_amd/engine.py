@@ -425,9 +425,15 @@ class FusedEngine:
             limit = min((2 ** 31 - 1) // M, max(16, self.bin_budget_bytes // (12 * M)))
             self.bin_capacity = int(max(16, min(self._bin_hint or 1024, limit)))
             self._bin_limit = int(limit)
+            # replicated bin counters (so_step_desc.bin_replicas): on images of few tiles the returning atomics of a tile's ONE
+            # counter serialise (1024 tiles: 4.4 G/s against 17 with eight copies, tools/census/xcd_atomics.hip)
+            self.bin_replicas = self._pick_bin_replicas(M)
+            if self.bin_replicas > 1:
+                self.bin_capacity = max(self.bin_replicas * 2, self.bin_capacity // self.bin_replicas * self.bin_replicas)
             cap = M * self.bin_capacity
         else:
             self.bin_capacity = 0
+            self.bin_replicas = 1
             cap = self._capacity_hint or max(1 << 20, 8 * C * N)
         self.N, self.K, self.M, self.capacity = N, K, M, int(cap)
         f32, i32 = torch.float32, torch.int32
@@ -451,6 +457,8 @@ class FusedEngine:
         # counters (2M+3 ints) | loss sums (2 floats) | loss, l1, ssimloss (3 floats) | ticket of the loss kernel
         # (1 int, zero at rest) in one allocation
         w["counters"] = torch.zeros(2 * M + 9, dtype=i32, device=dev)
+        # R copies of the per-tile counters + one word (R x the fullest slice, raised only when a slice overflows); kept zero by the step
+        w["bin_sub_counts"] = torch.zeros(self.bin_replicas * M + 1, dtype=i32, device=dev) if self.bin_replicas > 1 else None
         w["isect_offsets"] = e(C, th, tw, dtype=i32)
         # zero-filled once: whatever a list slot holds before its key is written is a valid Gaussian index
         w["key_buf"] = torch.zeros(cap, dtype=torch.int64, device=dev)
@@ -591,6 +599,8 @@ class FusedEngine:
         d.bin_capacity = self.bin_capacity
         d.tile_order = p(w["tile_order"]) if (self._lpt and self.tile_order_lpt) else 0
         d.sort_in_rasteriser = int(bool(self._fold and self.sort_fold_ok and self.binned and c["tile_size"] == 16))
+        if self.binned and self.bin_replicas > 1:
+            d.bin_replicas, d.bin_sub_counts = int(self.bin_replicas), p(w["bin_sub_counts"])
         return d
 
     def _adam_args(self):
@@ -679,8 +689,29 @@ class FusedEngine:
 
     # ------------------------------------------------------------------------------------------ capacity
     def _fullest_tile(self) -> int:
-        """Largest per-tile count of the last binning pass (binned lists: the atomics count past the capacity)."""
-        return int(self.ws["counters"][:self.M].max().item())
+        """Largest per-tile count of the last binning pass (binned lists: the atomics count past the capacity).  With replicated
+        counters a SLICE of a bin may have overflowed below that: the device then left R x its fullest slice -- the bin capacity
+        that would have held it -- in the word behind the counter copies."""
+        fullest = int(self.ws["counters"][:self.M].max().item())
+        sub = self.ws.get("bin_sub_counts")
+        if sub is not None:
+            eff = int(sub[-1].item())
+            if eff:
+                sub[-1:].zero_()
+            fullest = max(fullest, eff)
+        return fullest
+
+    def _pick_bin_replicas(self, M: int) -> int:
+        """Copies of the per-tile bin counters (SPLAT_ONE_AMD_BIN_REPLICAS overrides): 8 up to 2304 tiles (a 768 x 768 image), 4 up
+        to 4608, else 1 -- from 8160 tiles (1080p) on the shared counters run at the chip's rate anyway.  Needs the device-resident
+        count or record-only views (so_step_desc.bin_replicas)."""
+        import os
+        env = os.environ.get("SPLAT_ONE_AMD_BIN_REPLICAS")
+        if not (self.device_refine or self.lean):
+            return 1
+        if env:
+            return max(1, min(64, int(env)))
+        return 8 if M <= 2304 else (4 if M <= 4608 else 1)
 
     def _grow(self, needed: int) -> None:
         if self.binned:                              # `needed`: Gaussians over the fullest tile (bins never shrink)
@@ -830,8 +861,13 @@ class FusedEngine:
         `needed` entries (binned: Gaussians over the fullest tile) and say so.  compact (or a deferred overflow at the bin
         limit): the bins cannot grow -- switch to the compact lists (list_policy.on_take_back)."""
         import warnings
-        what = (f"{needed} Gaussians over one tile exceeded its bin of {self.bin_capacity} slots" if self.binned else
-                f"{needed} tile intersections exceeded the buffer capacity {self.capacity}")
+        if self.binned and getattr(self, "bin_replicas", 1) > 1 and needed <= self.bin_capacity:
+            R = self.bin_replicas
+            what = (f"one of the {R} slices of a tile's bin ({self.bin_capacity // R} of {self.bin_capacity} slots) overflowed: bins of "
+                    f"{needed} slots would have held it")
+        else:
+            what = (f"{needed} Gaussians over one tile exceeded its bin of {self.bin_capacity} slots" if self.binned else
+                    f"{needed} tile intersections exceeded the buffer capacity {self.capacity}")
         actions = list_policy.on_take_back(self._list_state(), int(void), int(needed), bool(grow), bool(compact))
         self._compact_pending = False
         if not grow:      # (a replica whose own buffers held: another rank's view overflowed)

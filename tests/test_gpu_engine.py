@@ -615,3 +615,77 @@ def test_tile_order_is_a_permutation_longest_list_first_and_changes_nothing(dev)
         assert torch.equal(res[False]["img"], res[True]["img"])
         for k in res[False]["grads"]:
             assert rel_err(res[True]["grads"][k], res[False]["grads"][k]) < 1e-5, (impl, k)
+
+
+@pytest.mark.parametrize("f16", [False, True])
+def test_replicated_bin_counters_give_the_same_lists_images_and_gradients(dev, monkeypatch, f16):
+    """so_step_desc.bin_replicas (round 5): on images of few tiles the projection kernel's workgroups bump one of R copies of a
+    tile's counter and fill one of R slices of its bin; k_bins_gather closes the slices up before the sort.  R = 1 / 4 / 8 give the
+    same lists bit for bit, the same image bit for bit, gradients equal up to atomic order -- on a cloud gathered in the middle
+    of a small image (tiles of 0 ... 3000+ keys: empty slices, full slices, slices of one key)."""
+    from splat_one_amd.engine import FusedEngine
+    N, W, H = 30_000, 256, 160
+    out = {}
+    for R in (1, 4, 8):
+        monkeypatch.setenv("SPLAT_ONE_AMD_BIN_REPLICAS", str(R))
+        r, c2w, Ks, pixels = _make(dev, N, W, H, "ref")
+        with torch.no_grad():
+            r.splats["means"].mul_(0.25)
+        # (float16 rows: with the device-resident count, which the replicated counters need where the per-view arrays exist)
+        eng = FusedEngine(r.splats, r.optimizers, W, H, 1, sh_degree=3, use_graph=False, fuse_adam=False, attr_dtype="f16" if f16 else "f32",
+                          device_refine=f16, capacity=(32768 if f16 else None))
+        eng.set_views(c2w, Ks, pixels)
+        eng.fwd_bwd()
+        torch.cuda.synchronize()
+        assert eng.binned and eng.bin_replicas == R and eng._desc().bin_replicas == (R if R > 1 else 0) and eng.stats()["overflow"] == 0
+        if R > 1:
+            assert not eng.ws["bin_sub_counts"].any()              # the step leaves the counter copies zeroed for the next one
+        offs, ids = eng.tile_lists()
+        # (last_ids are positions in flatten_ids = tile * bin_capacity + position in the tile's list, and the capacity is rounded to R)
+        out[R] = dict(offs=offs, ids=ids.clone(), img=eng.ws["render_colors"].clone(), last=eng.ws["last_ids"].clone() % eng.bin_capacity,
+                      grads={k: v[:N].clone() for k, v in eng.ws["grads"].items()}, n=eng.stats()["n_isects"])
+        eng.fwd_bwd()                                              # a second iteration on the same counters
+        torch.cuda.synchronize()
+        assert torch.equal(eng.ws["render_colors"], out[R]["img"]) and eng.stats()["n_isects"] == out[R]["n"]
+    lens = torch.tensor(out[1]["offs"][1:]) - torch.tensor(out[1]["offs"][:-1])
+    assert int(lens.max()) > 2048 and int((lens == 0).sum()) > 0 and int(((lens > 0) & (lens < 8)).sum()) > 0
+    for R in (4, 8):
+        a, b = out[1], out[R]
+        assert a["n"] == b["n"] and a["offs"] == b["offs"] and torch.equal(a["ids"], b["ids"])
+        assert torch.equal(a["img"], b["img"]) and torch.equal(a["last"], b["last"])
+        for k in a["grads"]:
+            assert rel_err(b["grads"][k], a["grads"][k]) < 1e-5, (R, k)
+
+
+def test_a_bin_slice_that_overflows_voids_the_iteration_and_the_bins_grow(dev, monkeypatch):
+    """Replicated counters: a slice holds bin_capacity / R keys, and one that overflows (while the tile's total is well below the
+    bin's capacity) must void the iteration and size the new bins by R x the fullest slice."""
+    from splat_one_amd.engine import FusedEngine
+    monkeypatch.setenv("SPLAT_ONE_AMD_BIN_REPLICAS", "8")
+    N, W, H = 20_000, 256, 160
+    r, c2w, Ks, pixels = _make(dev, N, W, H, "ref")
+    eng = FusedEngine(r.splats, r.optimizers, W, H, 1, sh_degree=3, use_graph=False)
+    eng.set_views(c2w, Ks, pixels)
+    eng.step()
+    torch.cuda.synchronize()
+    fullest = eng._fullest_tile()
+    # bins that hold the fullest tile 1.05 times over: its eight slices hold 0.13 of it each and the fuller ones overflow
+    eng._bin_hint = None
+    eng.bin_capacity = 0
+    eng._bin_hint = max(64, int(1.05 * fullest) // 8 * 8)
+    eng._build_workspace()
+    eng._probe_capacity = False
+    cap0 = eng.bin_capacity
+    assert cap0 >= fullest and cap0 < 1.2 * fullest and eng.bin_replicas == 8
+    eng.set_views(c2w, Ks, pixels)
+    steps0, void0 = eng.steps_done, eng.void_steps
+    for _ in range(4):
+        eng.set_views(c2w, Ks, pixels)
+        eng.step()
+    torch.cuda.synchronize()
+    eng.set_views(c2w, Ks, pixels)          # (the check of the last iterations)
+    assert eng.void_steps > void0 and eng.bin_capacity > cap0, (eng.void_steps, eng.bin_capacity, cap0, fullest)
+    assert eng.steps_done == steps0 + 4 - (eng.void_steps - void0)
+    eng.step()
+    torch.cuda.synchronize()
+    assert eng.stats()["overflow"] == 0

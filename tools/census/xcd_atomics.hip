@@ -70,6 +70,13 @@ void run(const char *name, int n_gauss, int per, int n_tiles) {
 }
 
 int main() {
+  // few tiles (a 512 x 512 image: 1024): the atomics of a line serialise, and a private copy of the counters per XCD (= 8 replicas) spreads them
+  for (auto cfg : {std::pair<int, int>{60000, 9}, {1000000, 1}}) {
+    run<0>("1024 tiles, shared counters", cfg.first, cfg.second, 1024);
+    run<1>("1024 tiles, 8 copies (one per XCD)", cfg.first, cfg.second, 1024);
+    run<0>("2040 tiles, shared counters", cfg.first, cfg.second, 2040);
+    run<1>("2040 tiles, 8 copies (one per XCD)", cfg.first, cfg.second, 2040);
+  }
   for (auto cfg : {std::pair<int, int>{100000, 4}, {100000, 42}, {1700000, 3}}) {
     run<0>("device scope, shared counters", cfg.first, cfg.second, 8160);
     run<1>("device scope, per-XCD counters", cfg.first, cfg.second, 8160);
