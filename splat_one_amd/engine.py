@@ -748,7 +748,7 @@ class FusedEngine:
     def _list_state(self) -> "list_policy.ListState":
         return list_policy.ListState(binned=self.binned, bin_capacity=int(self.bin_capacity), bin_limit=int(getattr(self, "_bin_limit", 0)),
                                      capacity=int(self.capacity), raster_impl=int(self.cfg["raster_impl"]), lpt=bool(self._lpt), fold=bool(self._fold), fold_allowed=bool(self.sort_fold_ok),
-                                     on_overflow=self.on_overflow, tile16=self.cfg["tile_size"] == 16, absgrad=bool(self.cfg["absgrad"]),
+                                     on_overflow=self.on_overflow, tile16=self.cfg["tile_size"] == 16, absgrad=bool(self.cfg["absgrad"]), n_tiles=int(self.M),
                                      compact_pending=bool(self._compact_pending), local_overflow_seen=int(self._local_overflow_seen))
 
     def _apply(self, actions) -> bool:

@@ -41,16 +41,23 @@ class ListState:
     absgrad: bool = False
     compact_pending: bool = False      # a deferred overflow happened with the bins at their limit
     local_overflow_seen: int = 0       # replicas: entries this rank saw overflow since the last take-back
+    n_tiles: int = 1 << 30             # C x tiles of the views (one wave per tile needs enough tiles to fill the chip)
 
 
 def _round_up(x: int, m: int) -> int:
     return -(-int(x) // m) * m
 
 
-def pick_raster_impl(now: int, mean_list: float, fullest: int, tile16: bool, absgrad: bool, first: bool = False) -> int:
+MIN_TILES_FOR_TILE_WAVES = 3072     # 3 waves on each of the MI355X's 1024 SIMDs
+
+
+def pick_raster_impl(now: int, mean_list: float, fullest: int, tile16: bool, absgrad: bool, first: bool = False,
+                     n_tiles: int = 1 << 30) -> int:
     """One wave per tile (1) for lists that are long EVERYWHERE -- mean >= 256 entries per tile and the fullest tile within 6x
-    of the mean -- else one wave per 8x8 quadrant (0); hysteresis once running (back to 0 below 192 entries or beyond 8x)."""
-    if not tile16 or absgrad:
+    of the mean -- else one wave per 8x8 quadrant (0); hysteresis once running (back to 0 below 192 entries or beyond 8x).
+    Never on images of fewer than 3072 tiles: one wave per tile is then less than three waves per SIMD (tools/gpu_r05_y.sh, dense
+    lists: 512 x 512 = 1024 tiles 368 us against 201 with four waves per tile; 960 x 540 346 / 305; 1440 x 720 = 4050 tiles 417 / 497)."""
+    if not tile16 or absgrad or n_tiles < MIN_TILES_FOR_TILE_WAVES:
         return 0
     if mean_list >= 256.0 and fullest <= 6.0 * mean_list:
         return 1
@@ -84,7 +91,7 @@ def on_probe(s: ListState, fullest: int, mean_list: float, n_isects: int, headro
     """A forward-only pass on the first view of a workspace (headroom 8) or after a refinement (headroom 2) measured the lists."""
     acts: List[Action] = []
     if s.binned:
-        impl = pick_raster_impl(s.raster_impl, mean_list, fullest, s.tile16, s.absgrad, first=True)
+        impl = pick_raster_impl(s.raster_impl, mean_list, fullest, s.tile16, s.absgrad, first=True, n_tiles=s.n_tiles)
         lpt = pick_tile_order(False, impl, mean_list, fullest)
         fold = s.fold_allowed and pick_sort_fold(False, s.binned, s.tile16, fullest)
         if (impl, lpt, fold) != (s.raster_impl, s.lpt, s.fold):
@@ -106,7 +113,7 @@ def on_lists(s: ListState, fullest: int, total: int, n_tiles: int) -> List[Actio
         return []
     acts: List[Action] = []
     mean = total / max(n_tiles, 1)
-    impl = pick_raster_impl(s.raster_impl, mean, fullest, s.tile16, s.absgrad)
+    impl = pick_raster_impl(s.raster_impl, mean, fullest, s.tile16, s.absgrad, n_tiles=s.n_tiles)
     lpt = pick_tile_order(s.lpt, impl, mean, fullest)
     fold = s.fold_allowed and pick_sort_fold(s.fold, s.binned, s.tile16, fullest)
     if (impl, lpt, fold) != (s.raster_impl, s.lpt, s.fold):

@@ -415,14 +415,17 @@ def test_tile_wave_backward_equals_the_quadrant_wave_backward(dev, regime, C, mo
         assert ((grads[1][k].cpu().double() - v.grad).norm() / (v.grad.norm() + floor)).item() <= 1e-3, k
 
 
-def test_bins_and_backward_rasteriser_follow_growing_lists_without_a_read_back(dev):
+def test_bins_and_backward_rasteriser_follow_growing_lists_without_a_read_back(dev, monkeypatch):
     """A device-side refinement can multiply the per-tile lists (BASELINE configs[3]: 1M -> 1.8M Gaussians over the timed
     region, 145 -> 337 entries per tile).  so_step_inputs gathers the maximum and the sum of the list lengths while it zeroes
     the counters and publishes them to host-mapped memory one call later; from those the engine rebuilds its bins at 8x the
     fullest tile as soon as they hold less than 2x of it -- BEFORE a tile overflows: no void iteration -- and moves the
     backward to one wave per tile once the mean list reaches 256 entries.  No synchronising call in the steps that only look
     (torch's sync debug mode); `reprobe_capacity()` is the explicit, synchronising form."""
+    from splat_one_amd import list_policy
     from splat_one_amd.engine import FusedEngine
+    # (one wave per tile is for images of >= 3072 tiles; this test follows the policy on a small image)
+    monkeypatch.setattr(list_policy, "MIN_TILES_FOR_TILE_WAVES", 0)
     N, W, H = 6000, 176, 112
     r, c2w, Ks, pixels = _make(dev, N, W, H, "mcmc")
     st = r.cfg.strategy.initialize_state(1.0)

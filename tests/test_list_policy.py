@@ -28,6 +28,8 @@ TABLE = [
      [("rebuild_bins", 1792), ("restage",)]),
     ("probe: long lists everywhere -> one wave per tile, longest first", BINNED, "probe", dict(fullest=900, mean_list=520.0, n_isects=0, headroom=2),
      [("set_kernels", 1, True, False), ("rebuild_bins", 7424), ("restage",)]),
+    ("probe: long lists everywhere on an image of few tiles (512 x 512) -> quadrant waves: one wave per tile would be one wave per SIMD",
+     dict(BINNED, n_tiles=1024), "probe", dict(fullest=900, mean_list=520.0, n_isects=0, headroom=2), [("rebuild_bins", 7424), ("restage",)]),
     ("probe: skewed lists -> quadrant waves, longest first", BINNED, "probe", dict(fullest=1000, mean_list=30.0, n_isects=0, headroom=2),
      [("set_kernels", 0, True, False), ("rebuild_bins", 8192), ("restage",)]),
     ("probe: fullest tile beyond the bin budget -> compact lists", BINNED, "probe", dict(fullest=5000, mean_list=40.0, n_isects=0, headroom=8),
@@ -49,6 +51,8 @@ TABLE = [
      [("set_kernels", 0, True, False), ("rebuild_bins", 7424)]),
     ("lists: grown to long lists -> switch kernels (graphs dropped)", BINNED, "lists", dict(fullest=500, total=8160 * 300, n_tiles=8160),
      [("set_kernels", 1, True, False)]),
+    ("lists: grown to long lists on an image of few tiles -> the quadrant waves stay", dict(BINNED, n_tiles=2040), "lists",
+     dict(fullest=500, total=2040 * 300, n_tiles=2040), []),
     ("lists: hysteresis keeps one wave per tile at 200 entries", dict(BINNED, raster_impl=1, lpt=True), "lists", dict(fullest=400, total=8160 * 200, n_tiles=8160), []),
     ("lists: back to quadrant waves below 192", dict(BINNED, raster_impl=1, lpt=True), "lists", dict(fullest=400, total=8160 * 150, n_tiles=8160),
      [("set_kernels", 0, False, False)]),
@@ -109,7 +113,7 @@ def test_engine_executes_the_actions_in_order_with_a_stubbed_engine():
     log = []
     eng = types.SimpleNamespace(
         cfg={"raster_impl": 0, "tile_size": 16, "absgrad": False}, _lpt=False, _fold=True, sort_fold_ok=True, binned=True, bin_capacity=8192, _bin_limit=8192, capacity=1,
-        on_overflow="grow", _compact_pending=False, _local_overflow_seen=0, _graph=1, _graph_fb=1, _graph_opt=1, _graphs={1: 1}, _graphs_fb={1: 1},
+        on_overflow="grow", M=8160, bin_replicas=1, _compact_pending=False, _local_overflow_seen=0, _graph=1, _graph_fb=1, _graph_opt=1, _graphs={1: 1}, _graphs_fb={1: 1},
         _graphs_head={1: 1}, _rows_desc=1, _bin_hint=None, _probe_capacity=True,
         _build_workspace=lambda: log.append("build"), _grow=lambda n: log.append(("grow", n)),
         _fall_back_to_compact_lists=lambda n: log.append(("compact", n)), _void=lambda n: log.append(("void", n)))
