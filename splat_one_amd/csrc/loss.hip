@@ -873,7 +873,10 @@ int so::ssim_l1_fused_launch(int B, int H, int W, int CH, const float *img1, con
     const int64_t slots = (int64_t)cus * so::kFusedWaves * 4 / (so::kFusedT / 64);   // workgroups resident at once
     const int64_t ny_max = slots / ((int64_t)nx * B) > 0 ? slots / ((int64_t)nx * B) : 1;
     rows = (int)((H + ny_max - 1) / ny_max);
-    if (rows < 24) rows = 24;
+    // (a floor of 8 rows per workgroup -- 28 row steps with the halo; it was 24 until round 5, which left small images on a third of
+    // the CUs: 512 x 512 40.5 -> 32.1 us, 960 x 540 42.5 -> 36.5, 256 x 256 39.2 -> 25.8; from 1440 x 720 on the floor is not reached,
+    // tools/gpu_r05_aa.sh)
+    if (rows < 8) rows = 8;
   }
   const int ny = (H + rows - 1) / rows;
   SO_REQUIRE(ny <= 65535 && B <= 65535, "so_ssim_l1_fused: grid too large");
