@@ -756,6 +756,9 @@ def main():
 
     # the dominant kernel's algorithmic bytes as the per-kernel table states them (a fused launch carries the traffic of
     # everything fused into it: Adam inside so_preprocess_bwd, the key writes inside so_preprocess_fwd)
+    if dominant not in by_kernel and dominant not in ab:      # the operator path's two whole-path entry points
+        ab["so_rasterization_fwd"] = ab["so_preprocess_fwd"] + 20 * I + ab["so_rasterize_fwd"]
+        ab["so_rasterization_bwd"] = ab["so_rasterize_bwd"] + ab["so_preprocess_bwd"]
     dom_bytes = by_kernel[dominant]["algorithmic_bytes"] if dominant in by_kernel else ab[dominant]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
     # The other roof of the dominant kernel: vector-instruction issue.  Wave-instructions per launch come from the committed

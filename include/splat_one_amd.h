@@ -615,6 +615,10 @@ typedef struct so_raster_desc {
   /* backward */
   const float *v_render_colors, *v_render_alphas;
   float *v_means, *v_quats, *v_scales, *v_opacities, *v_sh0, *v_shN, *v_means2d /* nullable */, *v_means2d_abs /* nullable */;
+  /* replicated bin counters, as so_step_desc.bin_replicas / bin_sub_counts (int32[R * C * tiles + 1], zero on entry, kept zero):
+   * for images of few tiles; status_out[0] then reports max(fullest list, R x fullest slice of a bin that overflowed) */
+  int32_t *bin_sub_counts;
+  int32_t bin_replicas;
 } so_raster_desc;
 int so_rasterization_fwd(const so_raster_desc *desc, void *stream);
 int so_rasterization_bwd(const so_raster_desc *desc, void *stream);

@@ -60,7 +60,8 @@ class RasterDesc(ctypes.Structure):
                                         "render_colors", "render_alphas", "last_ids",
                                         "v_render_colors", "v_render_alphas",
                                         "v_means", "v_quats", "v_scales", "v_opacities", "v_sh0", "v_shN", "v_means2d",
-                                        "v_means2d_abs")])
+                                        "v_means2d_abs", "bin_sub_counts")]
+                + [("bin_replicas", ctypes.c_int32)])
 
 
 class AdamFuse(ctypes.Structure):

@@ -1117,13 +1117,13 @@ int preprocess_fwd_act(int C, int N, int K, int sh_degree, const float *means, c
                        const float *opacities_in, const float *coeffs, const float *viewmats, const float *Ks, int width,
                        int height, float eps2d, float near_plane, float far_plane, float radius_clip, int camera_model,
                        int antialiased, int tile_size, int32_t *tile_counts, float *rec, float *vrec, int tile_cull,
-                       uint64_t *bin_keys, int64_t bin_cap, int32_t *bin_overflow, void *stream) {
+                       uint64_t *bin_keys, int64_t bin_cap, int32_t *bin_overflow, void *stream, int32_t *sub_counts, int replicas) {
   SO_REQUIRE((int64_t)C * N == 0 || (scales && quats && coeffs), "so_rasterization_fwd: null pointer");
   const AttrAct attrs{scales, quats, coeffs, K};
   return preprocess_fwd_impl("so_rasterization_fwd", C, N, K, sh_degree, means, opacities_in, attrs, viewmats, Ks, width, height,
                              eps2d, near_plane, far_plane, radius_clip, camera_model, antialiased, tile_size, nullptr, nullptr,
                              nullptr, nullptr, nullptr, nullptr, nullptr, tile_counts, rec, vrec, 0, nullptr, tile_cull,
-                             bin_keys, bin_cap, bin_overflow, stream, nullptr);
+                             bin_keys, bin_cap, bin_overflow, stream, nullptr, sub_counts, replicas);
 }
 int preprocess_bwd_act(int C, int N, int K, int sh_degree, const float *means, const float *scales, const float *quats,
                        const float *opacities_in, const float *coeffs, const float *viewmats, const float *Ks, int width,

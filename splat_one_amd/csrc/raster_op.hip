@@ -21,7 +21,10 @@ int preprocess_fwd_act(int C, int N, int K, int sh_degree, const float *means, c
                        const float *opacities_in, const float *coeffs, const float *viewmats, const float *Ks, int width,
                        int height, float eps2d, float near_plane, float far_plane, float radius_clip, int camera_model,
                        int antialiased, int tile_size, int32_t *tile_counts, float *rec, float *vrec, int tile_cull,
-                       uint64_t *bin_keys, int64_t bin_cap, int32_t *bin_overflow, void *stream);
+                       uint64_t *bin_keys, int64_t bin_cap, int32_t *bin_overflow, void *stream, int32_t *sub_counts = nullptr,
+                       int replicas = 1);
+int bins_gather_launch(int64_t M, int R, int32_t *sub_counts, int32_t *tile_counts, uint64_t *bin_keys, int64_t bin_cap,
+                       int32_t *eff_fullest, hipStream_t st);
 int preprocess_bwd_act(int C, int N, int K, int sh_degree, const float *means, const float *scales, const float *quats,
                        const float *opacities_in, const float *coeffs, const float *viewmats, const float *Ks, int width,
                        int height, float eps2d, int camera_model, int antialiased, float *v_means, float *v_scales,
@@ -52,7 +55,7 @@ int rec_unpack_means2d(int64_t n, const float *vrec, float *v_means2d, float *v_
 // {max tile count, overflow, seq, total intersections (clamped counts)}: one workgroup, a strided max over the M counts.
 __global__ void __launch_bounds__(1024)
 k_bins_status(const int32_t *__restrict__ tile_counts, int64_t M, int64_t bin_cap, const int32_t *__restrict__ overflow,
-              int32_t *__restrict__ status, int32_t seq) {
+              int32_t *__restrict__ status, int32_t seq, int32_t *__restrict__ eff_fullest) {
   __shared__ int s_max[16];
   __shared__ unsigned long long s_sum[16];
   int mx = 0;
@@ -72,6 +75,11 @@ k_bins_status(const int32_t *__restrict__ tile_counts, int64_t M, int64_t bin_ca
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { mx = s_max[w] > mx ? s_max[w] : mx; sum += s_sum[w]; }
+    if (eff_fullest) {        // replicated counters: R x the fullest SLICE, left by k_bins_gather when a slice overflowed
+      const int e = *eff_fullest;
+      mx = e > mx ? e : mx;
+      *eff_fullest = 0;
+    }
     status[0] = mx;
     status[1] = *overflow;
     status[3] = (int32_t)(sum > 0x7fffffffull ? 0x7fffffffull : sum);
@@ -105,6 +113,8 @@ static int check_desc(const so_raster_desc *d, const char *what) {
   const int tile_w = (d->width + d->tile_size - 1) / d->tile_size, tile_h = (d->height + d->tile_size - 1) / d->tile_size;
   SO_REQUIRE((int64_t)d->C * tile_w * tile_h * d->bin_capacity < ((int64_t)1 << 31), "%s: C*tiles*bin_capacity does not fit 31 bits", what);
   SO_REQUIRE(d->counters && d->flatten_ids && d->rec, "%s: null workspace pointer", what);
+  SO_REQUIRE(d->bin_replicas <= 1 || (d->bin_sub_counts && d->bin_replicas <= 64 && d->bin_capacity % d->bin_replicas == 0),
+             "%s: bin_replicas needs bin_sub_counts and bin_capacity %% bin_replicas == 0", what);
   return SO_OK;
 }
 }  // namespace so
@@ -119,6 +129,7 @@ extern "C" int so_rasterization_fwd(const so_raster_desc *d, void *stream) {
   hipStream_t st = so::as_stream(stream);
   // counters: tile_counts[M] | long-list scratch of the sort [M + 1] | n_isects (unused) | overflow
   int32_t *tile_counts = d->counters, *cursor = d->counters + M, *overflow = d->counters + 2 * M + 2;
+  const int reps = d->bin_replicas > 1 ? d->bin_replicas : 1;
   {
     int64_t g = (2 * M + 3 + 255) / 256;
     if (g > 1024) g = 1024;
@@ -128,13 +139,18 @@ extern "C" int so_rasterization_fwd(const so_raster_desc *d, void *stream) {
     if (d->activated)
       rc = so::preprocess_fwd_act(C, N, d->K, d->sh_degree, d->means, d->scales, d->quats, d->opacities, d->sh0, d->viewmats, d->Ks,
                                   W, H, d->eps2d, d->near_plane, d->far_plane, d->radius_clip, d->camera_model, d->antialiased, ts,
-                                  tile_counts, d->rec, d->vrec, d->tile_cull, d->key_buf, d->bin_capacity, overflow, stream);
+                                  tile_counts, d->rec, d->vrec, d->tile_cull, d->key_buf, d->bin_capacity, overflow, stream,
+                                  d->bin_sub_counts, reps);
     else
       rc = so::preprocess_fwd_n(C, N, d->K, d->sh_degree, d->means, d->scales, d->quats, d->opacities, d->sh0, d->shN, d->viewmats,
                                 d->Ks, W, H, d->eps2d, d->near_plane, d->far_plane, d->radius_clip, d->camera_model, d->antialiased,
                                 ts, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tile_counts, d->rec, d->vrec,
-                                nullptr, d->tile_cull, d->key_buf, d->bin_capacity, overflow, nullptr, stream);
+                                nullptr, d->tile_cull, d->key_buf, d->bin_capacity, overflow, nullptr, stream, d->bin_sub_counts, reps);
     if (rc != SO_OK) return rc;
+    if (reps > 1) {      // (replicated bin counters, see so_step_desc.bin_replicas: close the slices of every bin up before the sort)
+      rc = so::bins_gather_launch(M, reps, d->bin_sub_counts, tile_counts, d->key_buf, d->bin_capacity, d->bin_sub_counts + (int64_t)reps * M, st);
+      if (rc != SO_OK) return rc;
+    }
     rc = so_isect_sort_bins(C, tile_w, tile_h, tile_counts, d->bin_capacity, d->key_buf, d->flatten_ids, cursor, stream);
     if (rc != SO_OK) return rc;
   }
@@ -143,7 +159,8 @@ extern "C" int so_rasterization_fwd(const so_raster_desc *d, void *stream) {
                                -d->bin_capacity, d->render_colors, d->render_alphas, d->last_ids, stream);
   if (rc != SO_OK) return rc;
   if (d->status_out) {
-    hipLaunchKernelGGL(so::k_bins_status, dim3(1), dim3(1024), 0, st, tile_counts, M, d->bin_capacity, overflow, d->status_out, d->seq);
+    hipLaunchKernelGGL(so::k_bins_status, dim3(1), dim3(1024), 0, st, tile_counts, M, d->bin_capacity, overflow, d->status_out, d->seq,
+                       reps > 1 ? d->bin_sub_counts + (int64_t)reps * M : (int32_t *)nullptr);
     rc = so::check_launch("so_rasterization_fwd (status)");
   }
   return rc;

@@ -52,8 +52,15 @@ class _Bins:
     def __init__(self, device: torch.device, M: int):
         self.device, self.M = device, M
         self.lock = threading.Lock()
-        self.limit = int(max(16, min((2 ** 31 - 1) // M, int(32e9) // (12 * M))))
-        self.slots = int(min(_MIN_SLOTS, self.limit))
+        # replicated bin counters on images of few tiles (so_raster_desc.bin_replicas; the rule of FusedEngine._pick_bin_replicas):
+        # the returning atomics of ONE counter serialise, eight copies of the counters run the binning pass ~4x faster there
+        import os
+        env = os.environ.get("SPLAT_ONE_AMD_BIN_REPLICAS")
+        self.replicas = max(1, min(64, int(env))) if env else (8 if M <= 2304 else (4 if M <= 4608 else 1))
+        self.sub_counts = torch.zeros(self.replicas * M + 1, dtype=torch.int32, device=device) if self.replicas > 1 else None
+        R = self.replicas
+        self.limit = int(max(16, min((2 ** 31 - 1) // M, int(32e9) // (12 * M)))) // R * R
+        self.slots = int(min(_MIN_SLOTS, self.limit)) // R * R
         self.key_buf: Optional[Tensor] = None
         self.status = torch.zeros(4, dtype=torch.int32).pin_memory()
         self.status_np = self.status.numpy()         # (the same host-mapped words, read without a torch dispatch)
@@ -74,7 +81,7 @@ class _Bins:
 
     def grow_to(self, fullest: int, factor: int) -> None:
         want = -(-int(factor * fullest + 16) // 256) * 256
-        self.slots = int(min(max(self.slots, want), self.limit))
+        self.slots = int(min(max(self.slots, want), self.limit)) // self.replicas * self.replicas
 
     def look_at_previous(self) -> None:
         """The status word of the last forward issued on these bins, if that forward has finished (no synchronisation: a
@@ -208,10 +215,14 @@ class _Rasterization(torch.autograd.Function):
         with bins.lock:                      # (the key scratch and the status word are shared by the calls on this stream)
             bins.look_at_previous()
             while True:
+                if bins.replicas > 1:        # (every slice of a bin the same size)
+                    bins.slots = max(bins.replicas, bins.slots // bins.replicas * bins.replicas)
                 flatten_ids = torch.empty(M * bins.slots, dtype=i32, device=dev)
                 bins.seq = (bins.seq + 1) & 0x3FFFFFFF
                 d.bin_capacity, d.seq = bins.slots, bins.seq
                 d.key_buf, d.flatten_ids = bins.keys().data_ptr(), flatten_ids.data_ptr()
+                if bins.replicas > 1:
+                    d.bin_replicas, d.bin_sub_counts = bins.replicas, bins.sub_counts.data_ptr()
                 _lib.call("so_rasterization_fwd", ctypes.byref(d), _lib.stream())
                 # measure (ONE synchronisation): the first call on this tile grid, a model 1.5x denser than the one the bins
                 # were sized on, and every call that needs no gradient (eval / viewer: exact, see the module docstring)
