@@ -20,6 +20,7 @@ Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -258,6 +259,9 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--regime", default="mcmc", choices=["mcmc", "ref"])
+    ap.add_argument("--camera-model", default="pinhole", choices=["pinhole", "fisheye", "spherical"],
+                    help="not a BASELINE configuration (always 'custom'): the same step through another camera model; spherical = the reference's "
+                         "default (360-degree equirectangular images; give --width 2 x --height), cameras INSIDE the cloud")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--operator-path", action="store_true",
                     help="time the operator-level autograd path instead of the fused engine")
@@ -345,6 +349,15 @@ def main():
     # views: step i of rank r renders ring camera (i mod 8) * world + r against its own resident target image
     NV = max(1, args.views)
     ring = ring_cameras(NV * world) if NV * world > 1 else front_camera()[None]
+    if args.camera_model == "spherical":      # panorama cameras on a circle of radius 1 inside the cloud, each turned about the vertical axis
+        ring = []
+        for k in range(NV * world):
+            th = 2 * math.pi * k / (NV * world)
+            c2w = torch.eye(4)
+            c2w[0, 0], c2w[0, 2], c2w[2, 0], c2w[2, 2] = math.cos(2 * th), math.sin(2 * th), -math.sin(2 * th), math.cos(2 * th)
+            c2w[:3, 3] = torch.tensor([math.sin(th), 0.3 * math.cos(3 * th), math.cos(th)])
+            ring.append(c2w)
+        ring = torch.stack(ring)
     g = torch.Generator().manual_seed(100 + rank)
     teacher = args.targets == "teacher" and not args.densify
     if args.densify:      # a smooth target (a shifted colour ramp per view): gradients that make densification grow the set
@@ -379,7 +392,7 @@ def main():
 
     def make_runner(dp_mode):
         cfg = Config(init_num_pts=N, init_scale=init_scale, init_opa=init_opa, batch_size=1, shN_init_std=0.1,
-                     camera_model="pinhole", sh_degree_interval=1,    # SH degree 3 from step 3 on
+                     camera_model=args.camera_model, sh_degree_interval=1,    # SH degree 3 from step 3 on
                      fused=not args.operator_path, dp_mode=dp_mode, attr_dtype=args.attr_dtype,
                      loss_kernels=args.loss_kernels, max_gaussians=args.max_gaussians)
         if args.densify:
@@ -707,7 +720,7 @@ def main():
         return collected_near(col, what, tol=0.15)
 
     # which BASELINE configuration this is (profiles/*.json keep one counter collection per key under "_by_workload")
-    wl = (N0, W, H, bool(args.densify), args.regime, args.attr_dtype, args.cloud_scale)
+    wl = (N0, W, H, bool(args.densify), args.regime if args.camera_model == "pinhole" else args.regime + "/" + args.camera_model, args.attr_dtype, args.cloud_scale)
     workload_key = {(100_000, 1920, 1080, False, "mcmc", "f32", 1.0): "c2",
                     (100_000, 1920, 1080, False, "ref", "f32", 1.0): "c2-ref (the reference's default preset)",
                     (500_000, 1920, 1080, False, "mcmc", "f32", 1.0): "c3 (per-GPU share: 500k Gaussians, one view)",
@@ -798,7 +811,7 @@ def main():
                  "fused engine (hipGraph replay)" if fused else "operator-level autograd path"),
         "config": {"workload": f"{workload_key}: {N0} Gaussians "
                                f"(reference random init, '{args.regime}' preset), "
-                               f"{W}x{H}, SH degree 3, 1 view per GPU per step ({len(views)} ring cameras and targets cycled), pinhole"
+                               f"{W}x{H}, SH degree 3, 1 view per GPU per step ({len(views)} ring cameras and targets cycled), {args.camera_model}"
                                + (f", DefaultStrategy refining every {args.densify} iterations ({n_before_timed or N0} -> {N} Gaussians "
                                   f"over the timed region and the stage-timer pass)" if args.densify else "")
                                + (", float16 attribute rows" if args.attr_dtype == "f16" else "")
