@@ -53,15 +53,23 @@ MIN_TILES_FOR_TILE_WAVES = 3072     # 3 waves on each of the MI355X's 1024 SIMDs
 
 def pick_raster_impl(now: int, mean_list: float, fullest: int, tile16: bool, absgrad: bool, first: bool = False,
                      n_tiles: int = 1 << 30) -> int:
-    """One wave per tile (1) for lists that are long EVERYWHERE -- mean >= 256 entries per tile and the fullest tile within 6x
-    of the mean -- else one wave per 8x8 quadrant (0); hysteresis once running (back to 0 below 192 entries or beyond 8x).
+    """One wave per tile (1) for lists that are long EVERYWHERE -- mean >= 256 entries per tile and the fullest tile within
+    min(6, tiles / 2000) x the mean -- else one wave per 8x8 quadrant (0); hysteresis once running (back to 0 below 192 entries or
+    beyond min(8, tiles / 1500) x).
     Never on images of fewer than 3072 tiles: one wave per tile is then less than three waves per SIMD (tools/gpu_r05_y.sh, dense
     lists: 512 x 512 = 1024 tiles 368 us against 201 with four waves per tile; 960 x 540 346 / 305; 1440 x 720 = 4050 tiles 417 / 497)."""
     if not tile16 or absgrad or n_tiles < MIN_TILES_FOR_TILE_WAVES:
         return 0
-    if mean_list >= 256.0 and fullest <= 6.0 * mean_list:
+    # How uneven the lists may be depends on how many tiles there are: with one wave per tile the kernel cannot end before its
+    # fullest tile's serial chain does, and that chain outlasts the rest of the work once fullest > ~(tiles / 2000) x mean (a wave
+    # alone takes ~350 ns per entry, the chip ~0.145 ns per entry and tile).  Measured (tools/gpu_r05_ah.sh): a 1440 x 720 panorama
+    # from inside a 1M cloud, 4050 tiles, mean 377, fullest 1760 (4.7x): 623 us against 317 with quadrant waves; the same tile
+    # count with even lists (1.9x): 417 against 497.
+    enter = min(6.0, n_tiles / 2000.0)
+    leave = min(8.0, n_tiles / 1500.0)
+    if mean_list >= 256.0 and fullest <= enter * mean_list:
         return 1
-    if first or mean_list < 192.0 or fullest > 8.0 * mean_list:
+    if first or mean_list < 192.0 or fullest > leave * mean_list:
         return 0
     return now
 

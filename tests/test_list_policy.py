@@ -30,6 +30,11 @@ TABLE = [
      [("set_kernels", 1, True, False), ("rebuild_bins", 7424), ("restage",)]),
     ("probe: long lists everywhere on an image of few tiles (512 x 512) -> quadrant waves: one wave per tile would be one wave per SIMD",
      dict(BINNED, n_tiles=1024), "probe", dict(fullest=900, mean_list=520.0, n_isects=0, headroom=2), [("rebuild_bins", 7424), ("restage",)]),
+    ("probe: long but UNEVEN lists on 4050 tiles (a panorama from inside the cloud: fullest 4.7x the mean) -> quadrant waves: the fullest "
+     "tile's chain would outlast everything else", dict(BINNED, n_tiles=4050, bin_capacity=16384, bin_limit=65536), "probe",
+     dict(fullest=1760, mean_list=377.0, n_isects=0, headroom=2), []),
+    ("probe: the same tile count with even lists (1.9x) -> one wave per tile", dict(BINNED, n_tiles=4050, bin_capacity=16384, bin_limit=65536), "probe",
+     dict(fullest=1088, mean_list=563.0, n_isects=0, headroom=2), [("set_kernels", 1, True, False)]),
     ("probe: skewed lists -> quadrant waves, longest first", BINNED, "probe", dict(fullest=1000, mean_list=30.0, n_isects=0, headroom=2),
      [("set_kernels", 0, True, False), ("rebuild_bins", 8192), ("restage",)]),
     ("probe: fullest tile beyond the bin budget -> compact lists", BINNED, "probe", dict(fullest=5000, mean_list=40.0, n_isects=0, headroom=8),
