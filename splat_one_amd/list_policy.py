@@ -49,6 +49,7 @@ def _round_up(x: int, m: int) -> int:
 
 
 MIN_TILES_FOR_TILE_WAVES = 3072     # 3 waves on each of the MI355X's 1024 SIMDs
+TILES_PER_UNEVENNESS = (2000.0, 1500.0)   # one wave per tile: fullest <= tiles / 2000 x mean to enter, tiles / 1500 x to stay
 
 
 def pick_raster_impl(now: int, mean_list: float, fullest: int, tile16: bool, absgrad: bool, first: bool = False,
@@ -65,8 +66,8 @@ def pick_raster_impl(now: int, mean_list: float, fullest: int, tile16: bool, abs
     # alone takes ~350 ns per entry, the chip ~0.145 ns per entry and tile).  Measured (tools/gpu_r05_ah.sh): a 1440 x 720 panorama
     # from inside a 1M cloud, 4050 tiles, mean 377, fullest 1760 (4.7x): 623 us against 317 with quadrant waves; the same tile
     # count with even lists (1.9x): 417 against 497.
-    enter = min(6.0, n_tiles / 2000.0)
-    leave = min(8.0, n_tiles / 1500.0)
+    enter = min(6.0, n_tiles / TILES_PER_UNEVENNESS[0])
+    leave = min(8.0, n_tiles / TILES_PER_UNEVENNESS[1])
     if mean_list >= 256.0 and fullest <= enter * mean_list:
         return 1
     if first or mean_list < 192.0 or fullest > leave * mean_list:
@@ -76,9 +77,14 @@ def pick_raster_impl(now: int, mean_list: float, fullest: int, tile16: bool, abs
 
 def pick_tile_order(now: bool, impl: int, mean_list: float, fullest: int) -> bool:
     """Longest list first where a kernel's end is its longest tile: always with one wave per tile; with four waves per tile
-    when the lists are SKEWED (fullest tile >= 512 entries and > 8x the mean), with hysteresis (off below 384 / 6x)."""
+    when the lists are SKEWED (fullest tile >= 512 entries and > 8x the mean; hysteresis: off below 384 / 6x) or simply LONG
+    (mean >= 64 entries per tile, off below 48): the table costs one small launch (~13 us at 1080p) and the two rasterisers get it back
+    from ~60 entries per tile on -- tools/gpu_r05_ak.sh: 500k at 1080p (mean 108) +1.6 %, 960 x 540 / 1M (607) +6.5 %, a 1440 x 720 panorama
+    inside a 1M cloud +11 %, 512 x 512 dense +9 %; c2 (mean 32) would lose 0.8 %."""
     m = max(mean_list, 1.0)
     if impl == 1:
+        return True
+    if mean_list >= 64.0 or (now and mean_list >= 48.0):
         return True
     if fullest >= 512 and fullest > 8.0 * m:
         return True

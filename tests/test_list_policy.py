@@ -29,38 +29,44 @@ TABLE = [
     ("probe: long lists everywhere -> one wave per tile, longest first", BINNED, "probe", dict(fullest=900, mean_list=520.0, n_isects=0, headroom=2),
      [("set_kernels", 1, True, False), ("rebuild_bins", 7424), ("restage",)]),
     ("probe: long lists everywhere on an image of few tiles (512 x 512) -> quadrant waves: one wave per tile would be one wave per SIMD",
-     dict(BINNED, n_tiles=1024), "probe", dict(fullest=900, mean_list=520.0, n_isects=0, headroom=2), [("rebuild_bins", 7424), ("restage",)]),
+     dict(BINNED, n_tiles=1024), "probe", dict(fullest=900, mean_list=520.0, n_isects=0, headroom=2),
+     [("set_kernels", 0, True, False), ("rebuild_bins", 7424), ("restage",)]),
     ("probe: long but UNEVEN lists on 4050 tiles (a panorama from inside the cloud: fullest 4.7x the mean) -> quadrant waves: the fullest "
      "tile's chain would outlast everything else", dict(BINNED, n_tiles=4050, bin_capacity=16384, bin_limit=65536), "probe",
-     dict(fullest=1760, mean_list=377.0, n_isects=0, headroom=2), []),
+     dict(fullest=1760, mean_list=377.0, n_isects=0, headroom=2), [("set_kernels", 0, True, False)]),
     ("probe: the same tile count with even lists (1.9x) -> one wave per tile", dict(BINNED, n_tiles=4050, bin_capacity=16384, bin_limit=65536), "probe",
      dict(fullest=1088, mean_list=563.0, n_isects=0, headroom=2), [("set_kernels", 1, True, False)]),
     ("probe: skewed lists -> quadrant waves, longest first", BINNED, "probe", dict(fullest=1000, mean_list=30.0, n_isects=0, headroom=2),
      [("set_kernels", 0, True, False), ("rebuild_bins", 8192), ("restage",)]),
     ("probe: fullest tile beyond the bin budget -> compact lists", BINNED, "probe", dict(fullest=5000, mean_list=40.0, n_isects=0, headroom=8),
      [("set_kernels", 0, True, False), ("fall_back_to_compact", 5000), ("restage",)]),
-    ("probe: absgrad keeps the quadrant kernel", dict(BINNED, absgrad=True), "probe", dict(fullest=900, mean_list=520.0, n_isects=0, headroom=2),
-     [("rebuild_bins", 7424), ("restage",)]),
+    ("probe: absgrad keeps the quadrant kernel (long lists: longest first)", dict(BINNED, absgrad=True), "probe", dict(fullest=900, mean_list=520.0, n_isects=0, headroom=2),
+     [("set_kernels", 0, True, False), ("rebuild_bins", 7424), ("restage",)]),
     ("probe (compact): buffers hold 1.25x the count", COMPACT, "probe", dict(fullest=0, mean_list=0.0, n_isects=800_000, headroom=8), []),
     ("probe (compact): too small -> 2x the count", COMPACT, "probe", dict(fullest=0, mean_list=0.0, n_isects=900_000, headroom=8),
      [("grow", 1_800_000), ("restage",)]),
     # ---- list statistics published by the device (no read-back), binned layout
-    ("lists: nothing to do", BINNED, "lists", dict(fullest=400, total=8160 * 100, n_tiles=8160), []),
-    ("lists: hysteresis keeps the sort in the rasteriser up to 384", SHORT, "lists", dict(fullest=300, total=8160 * 100, n_tiles=8160), []),
-    ("lists: lists outgrew the prologue sort -> back to the sort kernels", SHORT, "lists", dict(fullest=400, total=8160 * 100, n_tiles=8160),
+    ("lists: nothing to do", BINNED, "lists", dict(fullest=400, total=8160 * 40, n_tiles=8160), []),
+    ("lists: long lists (mean >= 64) with quadrant waves -> longest list first", BINNED, "lists", dict(fullest=400, total=8160 * 100, n_tiles=8160),
+     [("set_kernels", 0, True, False)]),
+    ("lists: hysteresis keeps the longest-first order down to a mean of 48", dict(BINNED, lpt=True), "lists", dict(fullest=300, total=8160 * 50, n_tiles=8160), []),
+    ("lists: ... and drops it below", dict(BINNED, lpt=True), "lists", dict(fullest=300, total=8160 * 40, n_tiles=8160), [("set_kernels", 0, False, False)]),
+    ("lists: hysteresis keeps the sort in the rasteriser up to 384", SHORT, "lists", dict(fullest=300, total=8160 * 40, n_tiles=8160), []),
+    ("lists: lists outgrew the prologue sort -> back to the sort kernels", SHORT, "lists", dict(fullest=400, total=8160 * 40, n_tiles=8160),
      [("set_kernels", 0, False, False)]),
     ("lists: headroom below 2x -> rebuild at 8x before a tile overflows", BINNED, "lists", dict(fullest=600, total=8160 * 150, n_tiles=8160),
-     [("rebuild_bins", 4864)]),
-    ("lists: a tile beyond the capacity is the overflow path's business (bins untouched)", BINNED, "lists", dict(fullest=1500, total=8160 * 250, n_tiles=8160), []),
+     [("set_kernels", 0, True, False), ("rebuild_bins", 4864)]),
+    ("lists: a tile beyond the capacity is the overflow path's business (bins untouched)", BINNED, "lists", dict(fullest=1500, total=8160 * 250, n_tiles=8160),
+     [("set_kernels", 0, True, False)]),
     ("lists: one hot tile -> longest list first with the quadrant waves (and roomier bins)", BINNED, "lists", dict(fullest=900, total=8160 * 60, n_tiles=8160),
      [("set_kernels", 0, True, False), ("rebuild_bins", 7424)]),
     ("lists: grown to long lists -> switch kernels (graphs dropped)", BINNED, "lists", dict(fullest=500, total=8160 * 300, n_tiles=8160),
      [("set_kernels", 1, True, False)]),
     ("lists: grown to long lists on an image of few tiles -> the quadrant waves stay", dict(BINNED, n_tiles=2040), "lists",
-     dict(fullest=500, total=2040 * 300, n_tiles=2040), []),
+     dict(fullest=500, total=2040 * 300, n_tiles=2040), [("set_kernels", 0, True, False)]),
     ("lists: hysteresis keeps one wave per tile at 200 entries", dict(BINNED, raster_impl=1, lpt=True), "lists", dict(fullest=400, total=8160 * 200, n_tiles=8160), []),
     ("lists: back to quadrant waves below 192", dict(BINNED, raster_impl=1, lpt=True), "lists", dict(fullest=400, total=8160 * 150, n_tiles=8160),
-     [("set_kernels", 0, False, False)]),
+     [("set_kernels", 0, True, False)]),
     ("lists: bins at their limit are left alone", AT_LIMIT, "lists", dict(fullest=6000, total=8160 * 700, n_tiles=8160), [("set_kernels", 0, True, False)]),
     ("lists (compact): ignored", COMPACT, "lists", dict(fullest=600, total=8160 * 150, n_tiles=8160), []),
     # ---- an overflow found one step late
