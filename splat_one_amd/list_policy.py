@@ -41,7 +41,7 @@ class ListState:
     absgrad: bool = False
     compact_pending: bool = False      # a deferred overflow happened with the bins at their limit
     local_overflow_seen: int = 0       # replicas: entries this rank saw overflow since the last take-back
-    n_tiles: int = 1 << 30             # C x tiles of the views (one wave per tile needs enough tiles to fill the chip)
+    n_tiles: int = 8160                # C x tiles of the views (default: one 1080p view); the backward kernel is chosen by it
 
 
 def _round_up(x: int, m: int) -> int:
@@ -50,13 +50,16 @@ def _round_up(x: int, m: int) -> int:
 
 MIN_TILES_FOR_TILE_WAVES = 3072     # 3 waves on each of the MI355X's 1024 SIMDs
 TILES_PER_UNEVENNESS = (2000.0, 1500.0)   # one wave per tile: fullest <= tiles / 2000 x mean to enter, tiles / 1500 x to stay
+TILE_WAVES_MIN_ENTRIES = (1.5e6, 1.1e6)   # ... and >= 1.5M list entries per step in all (mean x tiles) to enter, 1.1M to stay
 
 
 def pick_raster_impl(now: int, mean_list: float, fullest: int, tile16: bool, absgrad: bool, first: bool = False,
-                     n_tiles: int = 1 << 30) -> int:
-    """One wave per tile (1) for lists that are long EVERYWHERE -- mean >= 256 entries per tile and the fullest tile within
-    min(6, tiles / 2000) x the mean -- else one wave per 8x8 quadrant (0); hysteresis once running (back to 0 below 192 entries or
-    beyond min(8, tiles / 1500) x).
+                     n_tiles: int = 8160) -> int:
+    """One wave per tile (1) where there is MUCH list work, spread EVENLY -- mean x tiles >= 1.5M entries (1080p: a mean of 184) and
+    the fullest tile within min(6, tiles / 2000) x the mean -- else one wave per 8x8 quadrant (0); hysteresis once running (back to 0
+    below 1.1M entries or beyond min(8, tiles / 1500) x).  The tile waves issue 22 % fewer instructions but walk a tile as one serial
+    chain: they win once the chip is short of issue slots, not of waves -- measured crossovers (tools/gpu_r05_an.sh, uniform clouds):
+    8160 tiles at a mean of ~190, 14400 tiles below 126 (-14 % there), 32400 tiles (4K) below 75 (-19 %): ~1.5M entries each time.
     Never on images of fewer than 3072 tiles: one wave per tile is then less than three waves per SIMD (tools/gpu_r05_y.sh, dense
     lists: 512 x 512 = 1024 tiles 368 us against 201 with four waves per tile; 960 x 540 346 / 305; 1440 x 720 = 4050 tiles 417 / 497)."""
     if not tile16 or absgrad or n_tiles < MIN_TILES_FOR_TILE_WAVES:
@@ -68,9 +71,10 @@ def pick_raster_impl(now: int, mean_list: float, fullest: int, tile16: bool, abs
     # count with even lists (1.9x): 417 against 497.
     enter = min(6.0, n_tiles / TILES_PER_UNEVENNESS[0])
     leave = min(8.0, n_tiles / TILES_PER_UNEVENNESS[1])
-    if mean_list >= 256.0 and fullest <= enter * mean_list:
+    entries = mean_list * n_tiles
+    if entries >= TILE_WAVES_MIN_ENTRIES[0] and fullest <= enter * mean_list:
         return 1
-    if first or mean_list < 192.0 or fullest > leave * mean_list:
+    if first or entries < TILE_WAVES_MIN_ENTRIES[1] or fullest > leave * mean_list:
         return 0
     return now
 

@@ -427,6 +427,7 @@ def test_bins_and_backward_rasteriser_follow_growing_lists_without_a_read_back(d
     # (one wave per tile is for images of >= 3072 tiles; this test follows the policy on a small image)
     monkeypatch.setattr(list_policy, "MIN_TILES_FOR_TILE_WAVES", 0)
     monkeypatch.setattr(list_policy, "TILES_PER_UNEVENNESS", (1e-3, 1e-3))      # (... and lets lists be as uneven as on a large one)
+    monkeypatch.setattr(list_policy, "TILE_WAVES_MIN_ENTRIES", (256.0 * 77, 192.0 * 77))   # (... and as if a mean of 256 entries were much work)
     N, W, H = 6000, 176, 112
     r, c2w, Ks, pixels = _make(dev, N, W, H, "mcmc")
     st = r.cfg.strategy.initialize_state(1.0)

@@ -64,9 +64,11 @@ TABLE = [
      [("set_kernels", 1, True, False)]),
     ("lists: grown to long lists on an image of few tiles -> the quadrant waves stay", dict(BINNED, n_tiles=2040), "lists",
      dict(fullest=500, total=2040 * 300, n_tiles=2040), [("set_kernels", 0, True, False)]),
-    ("lists: hysteresis keeps one wave per tile at 200 entries", dict(BINNED, raster_impl=1, lpt=True), "lists", dict(fullest=400, total=8160 * 200, n_tiles=8160), []),
-    ("lists: back to quadrant waves below 192", dict(BINNED, raster_impl=1, lpt=True), "lists", dict(fullest=400, total=8160 * 150, n_tiles=8160),
+    ("lists: hysteresis keeps one wave per tile at 150 entries", dict(BINNED, raster_impl=1, lpt=True), "lists", dict(fullest=400, total=8160 * 150, n_tiles=8160), []),
+    ("lists: back to quadrant waves below 1.1M entries (1080p: a mean of 135)", dict(BINNED, raster_impl=1, lpt=True), "lists", dict(fullest=400, total=8160 * 120, n_tiles=8160),
      [("set_kernels", 0, True, False)]),
+    ("lists: a 4K view (32400 tiles) moves to one wave per tile at a mean of 75", dict(BINNED, n_tiles=32400, lpt=True), "lists",
+     dict(fullest=300, total=32400 * 75, n_tiles=32400), [("set_kernels", 1, True, False)]),
     ("lists: bins at their limit are left alone", AT_LIMIT, "lists", dict(fullest=6000, total=8160 * 700, n_tiles=8160), [("set_kernels", 0, True, False)]),
     ("lists (compact): ignored", COMPACT, "lists", dict(fullest=600, total=8160 * 150, n_tiles=8160), []),
     # ---- an overflow found one step late
