@@ -274,6 +274,9 @@ def main():
     ap.add_argument("--cloud-scale", type=float, default=1.0,
                     help="multiply the initial positions by this factor (< 1: the splats gather in the middle of the image -- an "
                          "unevenly loaded tile grid, as real scenes have; the default workload is the uniform cube of BASELINE.md)")
+    ap.add_argument("--scale-spread", type=float, default=0.0,
+                    help="not a BASELINE configuration: N(0, S^2) added to every log-scale (per axis) and random rotations -- anisotropic splats whose "
+                         "sizes spread over e^(+-2S): the statistics of a trained scene rather than of the random init")
     ap.add_argument("--views", type=int, default=8, help="ring cameras / target images cycled per GPU (the reference draws a new view per step)")
     ap.add_argument("--attr-dtype", default="f32", choices=["f32", "f16"],
                     help="f16: float16 attribute rows (BASELINE.json configs[4]); float32 arithmetic and masters")
@@ -407,6 +410,11 @@ def main():
         if args.cloud_scale != 1.0:
             with torch.no_grad():
                 r.splats["means"].mul_(args.cloud_scale)
+        if args.scale_spread > 0.0:      # anisotropic splats of very different sizes (a trained scene's statistics rather than the random init's)
+            with torch.no_grad():
+                gs = torch.Generator().manual_seed(777)
+                r.splats["scales"].add_((torch.randn(r.splats["scales"].shape, generator=gs) * args.scale_spread).to(r.splats["scales"].device))
+                r.splats["quats"].copy_(torch.randn(r.splats["quats"].shape, generator=gs).to(r.splats["quats"].device))
         tg = teacher_targets(r) if teacher else targets
         if r.sharded:      # the step takes the cameras of every rank (rank r renders camera r of the step's group)
             views = [(ring[v * world:(v + 1) * world].contiguous().to(dev), K1.repeat(world, 1, 1).to(dev), tg[v]) for v in range(NV)]
@@ -720,7 +728,8 @@ def main():
         return collected_near(col, what, tol=0.15)
 
     # which BASELINE configuration this is (profiles/*.json keep one counter collection per key under "_by_workload")
-    wl = (N0, W, H, bool(args.densify), args.regime if args.camera_model == "pinhole" else args.regime + "/" + args.camera_model, args.attr_dtype, args.cloud_scale)
+    wl = (N0, W, H, bool(args.densify), args.regime if args.camera_model == "pinhole" else args.regime + "/" + args.camera_model, args.attr_dtype,
+          args.cloud_scale if args.scale_spread == 0.0 else (args.cloud_scale, args.scale_spread))
     workload_key = {(100_000, 1920, 1080, False, "mcmc", "f32", 1.0): "c2",
                     (100_000, 1920, 1080, False, "ref", "f32", 1.0): "c2-ref (the reference's default preset)",
                     (500_000, 1920, 1080, False, "mcmc", "f32", 1.0): "c3 (per-GPU share: 500k Gaussians, one view)",
@@ -816,6 +825,7 @@ def main():
                                   f"over the timed region and the stage-timer pass)" if args.densify else "")
                                + (", float16 attribute rows" if args.attr_dtype == "f16" else "")
                                + (f", initial positions scaled by {args.cloud_scale}" if args.cloud_scale != 1.0 else "")
+                               + (f", log-scales spread by N(0, {args.scale_spread}^2) per axis, random rotations" if args.scale_spread > 0.0 else "")
                                + (", targets = renders of the frozen initial model (student: same geometry, re-drawn colours)" if teacher else
                                   (", smooth ramp targets" if args.densify else ", random-noise targets")),
                    "workload_key": workload_key, "targets": ("teacher" if teacher else ("ramp" if args.densify else "noise")),
