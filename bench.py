@@ -689,6 +689,7 @@ def main():
     ab["so_adam_step_dev"] = ab["so_adam_step"]
     ab["so_isect_scan"] = 8 * (W // 16 + 1) * (H // 16 + 1)
     ab["so_tile_order"] = 8 * (W // 16 + 1) * (H // 16 + 1)        # list lengths read, workgroup -> tile table written
+    ab["so_bins_gather"] = 16 * I                                   # replicated bin counters (small images): keys read and written once
     ab["so_ssim_l1_fwd"] = 24 * P + 36 * P
     ab["so_ssim_l1_bwd"] = 60 * P + 12 * P
     ab["so_ssim_l1_fused"] = 24 * P + 12 * P          # two images in, one gradient image out

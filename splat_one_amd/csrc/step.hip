@@ -16,8 +16,8 @@ namespace so {
 // Optional per-stage timing with HIP events on the launch stream (bench.py's roofline leg).
 static const char *kStageNames[] = {"so_preprocess_fwd", "so_isect_scan", "so_isect_fill", "so_rasterize_fwd",
                                     "so_ssim_l1_fwd", "so_ssim_l1_bwd", "so_rasterize_bwd", "so_preprocess_bwd",
-                                    "so_adam_step_dev", "so_ssim_l1_fused", "so_tile_order"};
-constexpr int kNumStages = 11;
+                                    "so_adam_step_dev", "so_ssim_l1_fused", "so_tile_order", "so_bins_gather"};
+constexpr int kNumStages = 12;
 // per calling thread: the trainer thread's timers neither see nor are switched by a viewer thread's renders
 static thread_local bool g_prof_on = false;
 static thread_local std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events[kNumStages];
@@ -347,8 +347,8 @@ static int step_impl(const so_step_desc *d, void *stream, StepPart part, int64_t
                            d->opacities, d->colors, d->tiles_per_gauss, tile_counts, d->rec, forward_only ? nullptr : d->vrec, 0, slots, d->tile_cull, bin_keys, bins, overflow, stream));
   // sort_in_rasteriser: the forward rasteriser's workgroups sort their own lists (binned lists, 16x16 tiles; short lists)
   const bool fold_sort = bins && d->sort_in_rasteriser && ts == 16;
-  if (reps > 1)    // close the R slices of every bin up into one run; tile_counts gets the run lengths (timed with the sort)
-    SO_STAGE(2, so::bins_gather_launch(M, reps, d->bin_sub_counts, tile_counts, d->key_buf, bins, d->bin_sub_counts + (int64_t)reps * M, st));
+  if (reps > 1)    // close the R slices of every bin up into one run; tile_counts gets the run lengths
+    SO_STAGE(11, so::bins_gather_launch(M, reps, d->bin_sub_counts, tile_counts, d->key_buf, bins, d->bin_sub_counts + (int64_t)reps * M, st));
   if (fold_sort) {
   } else if (bins) {
     SO_STAGE(2, so_isect_sort_bins(C, tile_w, tile_h, tile_counts, bins, d->key_buf, d->flatten_ids, cursor, stream));

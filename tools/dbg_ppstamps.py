@@ -11,9 +11,15 @@ dev = torch.device("cuda:0")
 N, W, H = 100000, 1920, 1080
 cfg = Config(init_num_pts=N, init_scale=0.1, init_opa=0.5, shN_init_std=0.1, sh_degree_interval=1, fused=True)
 r = Runner(0, 0, 1, cfg, scene_scale=1 / 1.1)
+SPREAD = float(os.environ.get("DBG_SPREAD", "0"))      # bench.py --scale-spread: anisotropic splats of very different sizes
+if SPREAD > 0:
+    with torch.no_grad():
+        gs = torch.Generator().manual_seed(777)
+        r.splats["scales"].add_((torch.randn(r.splats["scales"].shape, generator=gs) * SPREAD).to(dev))
+        r.splats["quats"].copy_(torch.randn(r.splats["quats"].shape, generator=gs).to(dev))
 ring = ring_cameras(8).to(dev); Ks = pinhole_K(W, H)[None].to(dev)
 targets = [torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(100 + v)).to(dev) for v in range(8)]
-for i in range(220):
+for i in range(int(os.environ.get('DBG_STEPS', '220'))):
     r.train_step(ring[i % 8:i % 8 + 1], Ks, targets[i % 8])
 torch.cuda.synchronize()
 lib = _lib.load()
