@@ -953,12 +953,37 @@ k_bins_gather(int M, int R, int32_t *__restrict__ sub_counts, int32_t *__restric
     if (fullest > cap_r) atomicMax(eff_fullest, fullest * R);
   }
   uint64_t *const keys = bin_keys + (int64_t)t * bin_cap;
+  if (R <= 8 && (fullest < cap_r ? fullest : cap_r) <= 128) {
+    // every slice holds <= 128 keys (the rule on small images): ALL slices' keys are read (two per lane and slice) before the first
+    // one is written -- one memory round trip for the tile instead of one per slice (7 of them: 11 -> ~5 us at 512 x 512)
+    uint64_t k[7][2];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) {
+      const int n = r < R ? __shfl(cnt, r, 64) : 0, src = r * cap_r;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) k[r - 1][u] = 64 * u + lane < n ? keys[src + 64 * u + lane] : 0ull;
+    }
+#pragma unroll
+    for (int r = 1; r < 8; ++r) {
+      const int n = r < R ? __shfl(cnt, r, 64) : 0, dst = r < R ? __shfl(inc - cnt, r, 64) : 0;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (64 * u + lane < n) keys[dst + 64 * u + lane] = k[r - 1][u];
+    }
+    return;
+  }
   for (int r = 1; r < R; ++r) {             // (wave-uniform trip counts: the counts come from lane r)
     const int n = __shfl(cnt, r, 64), dst = __shfl(inc - cnt, r, 64), src = r * cap_r;
     if (dst == src) continue;
-    for (int i0 = 0; i0 < n; i0 += 64) {
-      const uint64_t k = i0 + lane < n ? keys[src + i0 + lane] : 0ull;
-      if (i0 + lane < n) keys[dst + i0 + lane] = k;      // (one wave: the loads of a chunk are complete before its stores issue)
+    // four chunks of 64 keys per round trip: all four loads leave before the first store (a store of chunk k lands below every
+    // key the later chunks still have to read: dst + i <= src + i < src + i' for i' > i) -- 13 -> ~6 us at 512 x 512 with 520 keys per tile
+    for (int i0 = 0; i0 < n; i0 += 256) {
+      uint64_t k[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) k[u] = i0 + 64 * u + lane < n ? keys[src + i0 + 64 * u + lane] : 0ull;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i0 + 64 * u + lane < n) keys[dst + i0 + 64 * u + lane] = k[u];
     }
   }
 }

@@ -711,7 +711,8 @@ class FusedEngine:
             return 1
         if env:
             return max(1, min(64, int(env)))
-        return 8 if M <= 2304 else (4 if M <= 4608 else 1)
+        fullest, mean_list = getattr(self, "_list_stats", (0, 0.0))      # (of the last probe / the last published statistics, if any)
+        return list_policy.pick_bin_replicas(M, fullest, mean_list)
 
     def _grow(self, needed: int) -> None:
         if self.binned:                              # `needed`: Gaussians over the fullest tile (bins never shrink)
@@ -800,6 +801,7 @@ class FusedEngine:
         if self.binned:
             mx = self._fullest_tile()
             mean_list = float(self.ws["counters"][:self.M].clamp(max=self.bin_capacity).float().mean().item())
+            self._list_stats = (int(mx), mean_list)
             return self._apply(list_policy.on_probe(self._list_state(), mx, mean_list, 0, headroom))
         n = int(self.ws["counters"][2 * self.M + 1].item())
         return self._apply(list_policy.on_probe(self._list_state(), 0, 0.0, n, headroom))
@@ -808,6 +810,7 @@ class FusedEngine:
         """The list lengths of an iteration two calls back (so_step_inputs gathers them on the device, no read-back): keep the
         bins at >= 2x the fullest tile -- rebuilt at 8x before a tile overflows, a model that device-side refinements grow
         from 1M to 1.8M Gaussians multiplies its lists -- and the kernels that suit them (list_policy.on_lists)."""
+        self._list_stats = (int(fullest), float(total) / max(self.M, 1))
         self._apply(list_policy.on_lists(self._list_state(), int(fullest), int(total), self.M))
 
     def _check_previous(self) -> None:

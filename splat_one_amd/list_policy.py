@@ -95,6 +95,21 @@ def pick_tile_order(now: bool, impl: int, mean_list: float, fullest: int) -> boo
     return bool(now and fullest >= 384 and fullest > 6.0 * m)
 
 
+def pick_bin_replicas(n_tiles: int, fullest: int = 0, mean_list: float = 0.0) -> int:
+    """Copies of the per-tile bin counters (so_step_desc.bin_replicas), chosen when a workspace is built: the returning atomics of
+    ONE counter serialise at ~230 ns, so what matters is how many entries the busiest counters take.  Few tiles: 8 copies up to
+    2304 tiles (768 x 768), 4 up to 4608 (tools/gpu_r05_w.sh).  Many tiles: 1 -- the chip's atomic rate binds first -- unless one image
+    region is hot (fullest list >= 1024 entries and > 16x the mean: a cloud gathered in a ninth of a 1080p image bins in 30 us
+    instead of 50 with 4 copies, tools/gpu_r05_at.sh)."""
+    if n_tiles <= 2304:
+        return 8
+    if n_tiles <= 4608:
+        return 4
+    if fullest >= 1024 and fullest > 16.0 * max(mean_list, 1.0):
+        return 4
+    return 1
+
+
 def pick_sort_fold(now: bool, binned: bool, tile16: bool, fullest: int) -> bool:
     """The per-tile sort inside the forward rasteriser (one launch fewer) where lists are short EVERYWHERE: fullest tile <= 256
     entries, i.e. every workgroup sorts its list with ONE wave in registers; with hysteresis (back to the sort kernels above

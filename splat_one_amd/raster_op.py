@@ -56,7 +56,8 @@ class _Bins:
         # the returning atomics of ONE counter serialise, eight copies of the counters run the binning pass ~4x faster there
         import os
         env = os.environ.get("SPLAT_ONE_AMD_BIN_REPLICAS")
-        self.replicas = max(1, min(64, int(env))) if env else (8 if M <= 2304 else (4 if M <= 4608 else 1))
+        from .list_policy import pick_bin_replicas
+        self.replicas = max(1, min(64, int(env))) if env else pick_bin_replicas(M)
         self.sub_counts = torch.zeros(self.replicas * M + 1, dtype=torch.int32, device=device) if self.replicas > 1 else None
         R = self.replicas
         self.limit = int(max(16, min((2 ** 31 - 1) // M, int(32e9) // (12 * M)))) // R * R

@@ -154,3 +154,11 @@ def test_engine_executes_the_actions_in_order_with_a_stubbed_engine():
     eng.on_overflow = "raise"
     with pytest.raises(RuntimeError, match="overflowed"):
         FusedEngine._apply(eng, LP.on_overflow(eng._list_state(), "train", 1500, 1500, False))
+
+
+@pytest.mark.parametrize("n_tiles,fullest,mean,expect", [(1024, 0, 0.0, 8), (2304, 900, 500.0, 8), (2305, 0, 0.0, 4), (4608, 0, 0.0, 4), (8160, 0, 0.0, 1),
+                                                          (8160, 900, 512.0, 1), (8160, 1376, 33.0, 4), (8160, 1000, 33.0, 1), (8160, 2000, 200.0, 1),
+                                                          (32400, 5000, 75.0, 4)])
+def test_bin_counter_copies_by_tile_count_and_hot_regions(n_tiles, fullest, mean, expect):
+    """so_step_desc.bin_replicas: by the tile count, and on large images only where one region is hot."""
+    assert LP.pick_bin_replicas(n_tiles, fullest, mean) == expect
