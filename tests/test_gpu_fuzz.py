@@ -37,8 +37,9 @@ def _case(seed):
                 static=static)
 
 
-@pytest.mark.parametrize("seed", list(range(36)))
-def test_random_configuration_against_the_oracle(dev, seed):
+def _operator_against_the_oracle(dev, seed):
+    """-> (cfg, (device image, oracle image), (device alpha, oracle alpha), device gradients, oracle gradients): the two legs of the
+    operator fuzz test (also tools/dbg_fuzz_one.py --operator)."""
     from splat_one_amd import rasterization
     cfg = _case(seed)
     W, H, C, N = cfg["W"], cfg["H"], cfg["C"], cfg["N"]
@@ -80,6 +81,12 @@ def test_random_configuration_against_the_oracle(dev, seed):
         keys = m_h["depths"].detach().cpu().clone()
     rc_o, ra_o, g_o, m_o = run(O.rasterization, "cpu", torch.float64, raster_fn=CO.raster_fn(), sort_depths=keys)
     assert int((m_o["radii"] > 0).sum()) > 0, cfg
+    return cfg, (rc_h, rc_o), (ra_h, ra_o), g_h, g_o
+
+
+@pytest.mark.parametrize("seed", list(range(36)))
+def test_random_configuration_against_the_oracle(dev, seed):
+    cfg, (rc_h, rc_o), (ra_h, ra_o), g_h, g_o = _operator_against_the_oracle(dev, seed)
     # depth channels carry world units (up to ~10): the per-pixel bar scales with the channel's magnitude
     scale_px = max(1.0, float(rc_o.abs().max()))
     assert (rc_h - rc_o).abs().mean().item() <= 1e-4 * scale_px, (cfg, (rc_h - rc_o).abs().mean().item())

@@ -8,9 +8,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import tests.test_gpu_fuzz as F
 
-seed = int(sys.argv[1])
-name = sys.argv[2] if len(sys.argv) > 2 else "means"
-cfg, g_eng, g_ref, K, fwd, (loss_eng, l1_o, ss_o) = F._engine_against_the_oracle(torch.device("cuda:0"), seed)
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+seed = int(args[0])
+name = args[1] if len(args) > 1 else "means"
+if "--operator" in sys.argv:        # the rasterization() fuzz case of this seed
+    cfg, (rc_h, rc_o), (ra_h, ra_o), gh, go = F._operator_against_the_oracle(torch.device("cuda:0"), seed)
+    names = ["means", "quats", "scales", "opacities", "sh"]
+    g_eng, g_ref = dict(zip(names, gh)), dict(zip(names, go))
+    fwd = (rc_h - rc_o).abs()
+else:
+    cfg, g_eng, g_ref, K, fwd, (loss_eng, l1_o, ss_o) = F._engine_against_the_oracle(torch.device("cuda:0"), seed)
 print("case", cfg)
 print("forward: mean |diff| %.3e  max %.3e  pixels > 1e-3: %d  > 1e-4: %d" % (fwd.mean().item(), fwd.max().item(), int((fwd > 1e-3).sum()), int((fwd > 1e-4).sum())))
 for k in g_eng:
