@@ -619,6 +619,9 @@ typedef struct so_raster_desc {
    * for images of few tiles; status_out[0] then reports max(fullest list, R x fullest slice of a bin that overflowed) */
   int32_t *bin_sub_counts;
   int32_t bin_replicas;
+  /* int32[C*tiles] (nullable), as so_step_desc.tile_order: the forward builds the workgroup -> tile table (longest list first) and
+   * both rasterisers follow it; the backward must be given the same buffer, untouched.  Worth it from ~60 list entries per tile on. */
+  int32_t *tile_order;
 } so_raster_desc;
 int so_rasterization_fwd(const so_raster_desc *desc, void *stream);
 int so_rasterization_bwd(const so_raster_desc *desc, void *stream);

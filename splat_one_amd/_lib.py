@@ -61,7 +61,7 @@ class RasterDesc(ctypes.Structure):
                                         "v_render_colors", "v_render_alphas",
                                         "v_means", "v_quats", "v_scales", "v_opacities", "v_sh0", "v_shN", "v_means2d",
                                         "v_means2d_abs", "bin_sub_counts")]
-                + [("bin_replicas", ctypes.c_int32)])
+                + [("bin_replicas", ctypes.c_int32), ("tile_order", c_ptr)])
 
 
 class AdamFuse(ctypes.Structure):

@@ -23,6 +23,12 @@ int preprocess_fwd_act(int C, int N, int K, int sh_degree, const float *means, c
                        int antialiased, int tile_size, int32_t *tile_counts, float *rec, float *vrec, int tile_cull,
                        uint64_t *bin_keys, int64_t bin_cap, int32_t *bin_overflow, void *stream, int32_t *sub_counts = nullptr,
                        int replicas = 1);
+int tile_order_launch(int C, int tile_w, int tile_h, const int32_t *offsets, const int32_t *n_isects_dev, int64_t n_isects_host,
+                      int32_t *order, hipStream_t st);
+int rasterize_fwd_packed_launch(int C, int N, int width, int height, int tile_size, const float *rec, const float *backgrounds,
+                                const int32_t *isect_offsets, const int32_t *flatten_ids, const int32_t *n_isects_dev,
+                                int64_t n_isects_host, float *render_colors, float *render_alphas, int32_t *last_ids,
+                                const int32_t *tile_order, void *stream, const uint64_t *sort_keys = nullptr);
 int bins_gather_launch(int64_t M, int R, int32_t *sub_counts, int32_t *tile_counts, uint64_t *bin_keys, int64_t bin_cap,
                        int32_t *eff_fullest, hipStream_t st);
 int preprocess_bwd_act(int C, int N, int K, int sh_degree, const float *means, const float *scales, const float *quats,
@@ -155,8 +161,13 @@ extern "C" int so_rasterization_fwd(const so_raster_desc *d, void *stream) {
     if (rc != SO_OK) return rc;
   }
   const int wrap = so::wrap_flags_of(d->camera_model, C, W, ts);
-  rc = so_rasterize_fwd_packed(C, N, W, H, ts | wrap, d->rec, d->backgrounds, tile_counts, d->flatten_ids, nullptr,
-                               -d->bin_capacity, d->render_colors, d->render_alphas, d->last_ids, stream);
+  if (d->tile_order && N > 0) {      // longest list first (so_raster_desc.tile_order; the caller asks for it where lists are long)
+    rc = so::tile_order_launch(C, tile_w, tile_h, tile_counts, nullptr, -d->bin_capacity, d->tile_order, st);
+    if (rc != SO_OK) return rc;
+  }
+  rc = so::rasterize_fwd_packed_launch(C, N, W, H, ts | wrap, d->rec, d->backgrounds, tile_counts, d->flatten_ids, nullptr,
+                                       -d->bin_capacity, d->render_colors, d->render_alphas, d->last_ids,
+                                       N > 0 ? d->tile_order : nullptr, stream);
   if (rc != SO_OK) return rc;
   if (d->status_out) {
     hipLaunchKernelGGL(so::k_bins_status, dim3(1), dim3(1024), 0, st, tile_counts, M, d->bin_capacity, overflow, d->status_out, d->seq,
@@ -181,6 +192,7 @@ extern "C" int so_rasterization_bwd(const so_raster_desc *d, void *stream) {
   so::LossFinal fin{};
   fin.skip = d->counters + 2 * M + 2;
   fin.tile_waves = d->raster_impl;           // (-1: the process default; rasterize_bwd.hip)
+  fin.tile_order = d->tile_order;            // (the table the forward of this call built)
   rc = so::rasterize_bwd_packed_launch(C, N, W, H, ts | wrap, d->rec, d->backgrounds, d->counters, d->flatten_ids, nullptr,
                                        -d->bin_capacity, d->render_alphas, d->last_ids, d->v_render_colors, d->v_render_alphas,
                                        d->vrec, d->absgrad, fin, stream);

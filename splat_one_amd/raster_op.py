@@ -41,6 +41,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
+from .list_policy import pick_raster_impl, pick_tile_order
 from .ops import camera_model_code
 
 _MIN_SLOTS = 1024
@@ -224,6 +225,12 @@ class _Rasterization(torch.autograd.Function):
                 d.key_buf, d.flatten_ids = bins.keys().data_ptr(), flatten_ids.data_ptr()
                 if bins.replicas > 1:
                     d.bin_replicas, d.bin_sub_counts = bins.replicas, bins.sub_counts.data_ptr()
+                # longest list first for both rasterisers where the lists are long or uneven (the fused engine's rule, list_policy.py;
+                # decided from the lists of the last call whose status word has been looked at -- no read here)
+                tile_order = None
+                if cfg["tile_size"] == 16 and pick_tile_order(False, 0, bins.mean_list, bins.fullest):
+                    tile_order = torch.empty(M, dtype=i32, device=dev)
+                    d.tile_order = tile_order.data_ptr()
                 _lib.call("so_rasterization_fwd", ctypes.byref(d), _lib.stream())
                 # measure (ONE synchronisation): the first call on this tile grid, a model 1.5x denser than the one the bins
                 # were sized on, and every call that needs no gradient (eval / viewer: exact, see the module docstring)
@@ -252,7 +259,7 @@ class _Rasterization(torch.autograd.Function):
         if need_bwd:
             ctx.save_for_backward(means, quats, scales, opacities, sh0, shN, viewmats, Ks, backgrounds, rec, vrec, counters,
                                   flatten_ids, render_alphas, last_ids)
-            ctx.cfg, ctx.slots, ctx.holder, ctx.bins = cfg, slots, holder, bins
+            ctx.cfg, ctx.slots, ctx.holder, ctx.bins, ctx.tile_order = cfg, slots, holder, bins, tile_order
         holder["tile_counts"], holder["slots"] = counters[:M], slots
         ctx.mark_non_differentiable(radii, depths, conics, opac, rgb)
         return render_colors, render_alphas, means2d, radii, depths, conics, opac, rgb
@@ -278,12 +285,12 @@ class _Rasterization(torch.autograd.Function):
             vrec.view(C, N, 16)[:, :, 0:2].add_(v_m2d)
         d = _desc(cfg, C, N, K)
         d.bin_capacity = ctx.slots
-        # long lists (dense initialisations: >= 256 entries per tile, as the fused engine decides): the backward rasteriser
-        # as one wave per tile; the mean is the one the last looked-at status word of these bins reported -- no read here
-        # (long EVERYWHERE -- the fullest tile within 6x of the mean: a cloud gathered in a few hundred tiles has too few tiles
-        # for one wave each, FusedEngine._pick_raster_impl)
-        d.raster_impl = 1 if (bins.mean_list >= 256.0 and bins.fullest <= 6.0 * bins.mean_list and cfg["tile_size"] == 16
-                              and not cfg["absgrad"]) else -1
+        # which backward rasteriser: the fused engine's rule (list_policy.pick_raster_impl: much list work, evenly spread, enough tiles),
+        # from the lists the last looked-at status word of these bins reported -- no read here
+        d.raster_impl = 1 if pick_raster_impl(0, bins.mean_list, bins.fullest, cfg["tile_size"] == 16, bool(cfg["absgrad"]), first=True,
+                                              n_tiles=bins.M) == 1 else -1
+        if ctx.tile_order is not None:
+            d.tile_order = ctx.tile_order.data_ptr()
         d.means, d.quats, d.scales, d.opacities, d.sh0, d.shN = (means.data_ptr(), quats.data_ptr(), scales.data_ptr(),
                                                                    opacities.data_ptr(), sh0.data_ptr(), _p(shN))
         d.viewmats, d.Ks, d.backgrounds = viewmats.data_ptr(), Ks.data_ptr(), _p(backgrounds)

@@ -78,7 +78,7 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
               "so_model_set": ["p", "m", "v"],
               "so_raster_desc": ["abi_size", "seq", "raster_impl", "eps2d", "radius_clip", "bin_capacity", "means", "shN", "backgrounds", "counters",
                                  "key_buf", "vrec", "status_out", "render_colors", "last_ids", "v_render_colors", "v_means",
-                                 "v_shN", "v_means2d", "v_means2d_abs"],
+                                 "v_shN", "v_means2d", "v_means2d_abs", "bin_sub_counts", "bin_replicas", "tile_order"],
               "so_refine_params": ["grow_grad2d", "grow_scale3d", "prune_opa", "prune_scale3d", "prune_big", "revised_opacity",
                                    "seed", "step"]}
     src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
