@@ -525,6 +525,15 @@ typedef struct so_step_desc {
    * Same lists after the sort, same images and gradients; a slice that overflows voids the iteration like a bin that overflows. */
   int32_t bin_replicas;
   int32_t *bin_sub_counts;
+  /* Backward rasteriser in list SEGMENTS (16x16 tiles, raster_impl 0).  bwd_seg_len > 0 (a multiple of 256): the forward
+   * rasteriser writes every pixel's (live transmittance, accumulated colour) at the boundaries of its tile's list -- after entries
+   * bwd_seg_len, 2 bwd_seg_len, ... -- into bwd_seg_state (float[(bwd_seg_count - 1) * C * H * W * 4], 16-byte aligned), and the
+   * backward runs bwd_seg_count workgroups per tile, each from the state at the far end of its segment: a list of thousands of
+   * entries is no longer ONE serial chain (few tiles, or one hot image region).  The last segment takes everything beyond
+   * (bwd_seg_count - 1) x bwd_seg_len entries (the caller sizes bwd_seg_len by its fullest list).  Same gradients up to the order of
+   * float additions. */
+  int32_t bwd_seg_len, bwd_seg_count;
+  float *bwd_seg_state;
 } so_step_desc;
 typedef struct so_adam_fuse {
   so_adam_group groups[6]; /* means, log_scales, quats, logit_opacities, sh0, shN: param / exp_avg / exp_avg_sq (grad unused) */

@@ -46,7 +46,8 @@ class StepDesc(ctypes.Structure):
         + [("pixels_indirect", c_ptr), ("inputs_staged", ctypes.c_int32), ("tile_cull", ctypes.c_int32),
            ("overflow_flag_out", c_ptr), ("attr_rows_f16", c_ptr), ("tile_slots", c_ptr), ("bin_capacity", c_i64), ("fuse_adam", c_ptr),
            ("n_dev", c_ptr), ("tile_order", c_ptr), ("sort_in_rasteriser", ctypes.c_int32),
-           ("bin_replicas", ctypes.c_int32), ("bin_sub_counts", c_ptr)])
+           ("bin_replicas", ctypes.c_int32), ("bin_sub_counts", c_ptr),
+           ("bwd_seg_len", ctypes.c_int32), ("bwd_seg_count", ctypes.c_int32), ("bwd_seg_state", c_ptr)])
 
 
 class RasterDesc(ctypes.Structure):

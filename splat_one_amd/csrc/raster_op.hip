@@ -28,7 +28,8 @@ int tile_order_launch(int C, int tile_w, int tile_h, const int32_t *offsets, con
 int rasterize_fwd_packed_launch(int C, int N, int width, int height, int tile_size, const float *rec, const float *backgrounds,
                                 const int32_t *isect_offsets, const int32_t *flatten_ids, const int32_t *n_isects_dev,
                                 int64_t n_isects_host, float *render_colors, float *render_alphas, int32_t *last_ids,
-                                const int32_t *tile_order, void *stream, const uint64_t *sort_keys = nullptr);
+                                const int32_t *tile_order, void *stream, const uint64_t *sort_keys = nullptr, float *seg_state = nullptr,
+                                int seg_len = 0, int seg_count = 1);
 int bins_gather_launch(int64_t M, int R, int32_t *sub_counts, int32_t *tile_counts, uint64_t *bin_keys, int64_t bin_cap,
                        int32_t *eff_fullest, hipStream_t st);
 int preprocess_bwd_act(int C, int N, int K, int sh_degree, const float *means, const float *scales, const float *quats,

@@ -62,7 +62,11 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
   // the host checked C * tile_w * tile_h < 2^31 (32-bit index arithmetic)
   const int n_tiles = tile_w * tile_h;
   const int M = C * n_tiles;
-  const int ct = fin.tile_order ? fin.tile_order[blockIdx.x] : (int)xcd_remap(blockIdx.x, M);   // (LossFinal::tile_order: longest list first)
+  // list segments (LossFinal::seg_len): workgroup b of the grid of seg_count x M takes segment b / M of the tile that workgroup
+  // b % M of the plain grid would take -- the first segments of all tiles first, in the tile order
+  const int seg = fin.seg_len > 0 ? (int)(blockIdx.x / (unsigned)M) : 0;
+  const unsigned bt = fin.seg_len > 0 ? blockIdx.x - (unsigned)seg * (unsigned)M : blockIdx.x;
+  const int ct = fin.tile_order ? fin.tile_order[bt] : (int)xcd_remap(bt, M);   // (LossFinal::tile_order: longest list first)
   if (tile_masks && !tile_masks[ct]) return;
   const int c = ct / n_tiles;
   const int t = ct - c * n_tiles;
@@ -84,6 +88,10 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
   int64_t lo, hi;
   tile_list_range(ct, M, offsets, n_isects_dev, n_isects_host, lo, hi);
   if (hi <= lo) return;  // uniform over the block
+  // this workgroup's part of the list: [seg_lo, seg_hi] (the whole list without segments)
+  const int64_t seg_lo = fin.seg_len > 0 ? lo + (int64_t)seg * fin.seg_len : lo;
+  const int64_t seg_hi = (fin.seg_len > 0 && seg < fin.seg_count - 1 && seg_lo + fin.seg_len < hi) ? seg_lo + fin.seg_len - 1 : hi - 1;   // (the last segment: all that is left)
+  if (seg_lo >= hi) return;   // uniform
 
   const float T_final = inside ? 1.f - render_alphas[pix] : 1.f;
   float T = T_final;
@@ -102,6 +110,10 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
   // last contributor of this pixel; pixels that nothing reached keep lo-1 (no Gaussian valid)
   int32_t bin_final = (int32_t)lo - 1;
   if (inside && T_final < 1.f) bin_final = last_ids[pix];
+  // a pixel whose walk goes on behind this segment starts from the state the forward left at the segment's far end; one
+  // whose last contributor lies before the segment has nothing to do here
+  const bool from_boundary = fin.seg_len > 0 && (int64_t)bin_final > seg_hi;
+  if (fin.seg_len > 0) bin_final = (int64_t)bin_final < seg_lo ? (int32_t)lo - 1 : (from_boundary ? (int32_t)seg_hi : bin_final);
   // wave / block maxima
   const int32_t wave_last = wave_max_i32(bin_final);   // wave-uniform (scalar)
   if (lane == 0) s_wave_last[wid] = wave_last;
@@ -146,11 +158,25 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
   const float unscale = (slot < 2 || slot == 9 || slot == 10) ? kConicUnscale : ((slot == 2 || slot == 4) ? 0.5f : 1.f);
   const bwd_v2f pxy = {px, py};
   float behind = tf_bg;   // tf_bg - buf_dot of the scalar form below
+  if constexpr (D == 3) {
+    if (from_boundary) {
+      // (T, colour accumulated up to the boundary) of this pixel; the colour behind it = all that was accumulated - that
+      const float4 st = fin.seg_state[(int64_t)seg * ((int64_t)C * H * W) + pix];
+      T = st.x;
+      float all_dot = 0.f, upto_dot = st.y * v_c[0] + st.z * v_c[1] + st.w * v_c[2];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float acc_k = fin.render_colors[pix * 3 + k] - (backgrounds ? T_final * backgrounds[c * 3 + k] : 0.f);
+        all_dot = fmaf(acc_k, v_c[k], all_dot);
+      }
+      behind = tf_bg - (all_dot - upto_dot);
+    }
+  }
 
-  for (int64_t batch_end = block_last; batch_end >= lo; batch_end -= STAGE) {
+  for (int64_t batch_end = block_last; batch_end >= seg_lo; batch_end -= STAGE) {
     lds_barrier();
     const int64_t idx = batch_end - tid;
-    if (tid < STAGE && idx >= lo) {
+    if (tid < STAGE && idx >= seg_lo) {
       const int32_t g = flatten_ids[idx];
       s_id[tid] = g;
       if (PACKED) {
@@ -188,7 +214,7 @@ k_rasterize_bwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
       }
     }
     lds_barrier();
-    const int batch_size = (int)((batch_end + 1 - lo) < STAGE ? (batch_end + 1 - lo) : STAGE);
+    const int batch_size = (int)((batch_end + 1 - seg_lo) < STAGE ? (batch_end + 1 - seg_lo) : STAGE);
     const int32_t rel_final = (int32_t)(batch_end - bin_final);   // candidate tt contributes to this pixel iff tt >= rel_final
     const int32_t rel_wave = (int32_t)(batch_end - wave_last);
 #pragma unroll 1
@@ -471,8 +497,13 @@ int so::rasterize_bwd_packed_launch(int C, int N, int width, int height, int til
   const int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
   SO_REQUIRE((int64_t)C * tile_w * tile_h < (int64_t)INT32_MAX, "so_rasterize_bwd_packed: C*tiles = %lld does not fit 31 bits",
              (long long)C * tile_w * tile_h);
-  const dim3 grid((unsigned)((int64_t)C * tile_w * tile_h));
   hipStream_t st = so::as_stream(stream);
+  // list segments (LossFinal::seg_len): quadrant waves on 16x16 tiles only; seg_count workgroups per tile
+  const bool tile_waves_asked = fin.tile_waves < 0 ? false : fin.tile_waves != 0;
+  SO_REQUIRE(fin.seg_len == 0 || (fin.seg_len % 256 == 0 && fin.seg_count >= 1 && fin.seg_count <= 64 && fin.seg_state && fin.render_colors &&
+                                  tile_size == 16 && !tile_waves_asked && (int64_t)C * tile_w * tile_h * fin.seg_count < (int64_t)INT32_MAX),
+             "so_rasterize_bwd_packed: list segments need 16x16 tiles, quadrant waves, the forward's segment states and colours");
+  const dim3 grid((unsigned)((int64_t)C * tile_w * tile_h * (fin.seg_len > 0 ? fin.seg_count : 1)));
   // 16x16 tiles without absgrad, on request: one wave per tile, one reduction and one atomic per (tile, Gaussian) --
   // rasterize_bwd_tile.hip.  Measured (profiles/r04_experiments.json: rasterize_bwd_tile_waves): 22 % fewer vector
   // instructions, but a tile is then one wave's serial chain -- 957 -> 803 us on the dense regime's 520-entry lists, 73 ->
@@ -480,7 +511,7 @@ int so::rasterize_bwd_packed_launch(int C, int N, int width, int height, int til
   // entries per tile (so_step_desc.raster_impl = 1); SPLAT_ONE_AMD_BWD_TILE=1 / 0 sets the default of every other caller.
   static const bool env_tile = [] { const char *e = getenv("SPLAT_ONE_AMD_BWD_TILE"); return e && e[0] == '1'; }();
   const bool tile_waves = fin.tile_waves < 0 ? env_tile : fin.tile_waves != 0;
-  if (tile_size == 16 && !absgrad && tile_waves)
+  if (tile_size == 16 && !absgrad && tile_waves && fin.seg_len == 0)
     return so::rasterize_bwd_tile_launch(C, N, width, height, tile_w, tile_h, rec, backgrounds, isect_offsets, flatten_ids, n_isects_dev,
                                          n_isects_host, render_alphas, last_ids, v_render_colors, v_render_alphas, vrec, wrap_flags, fin, st);
   // SMALL: every gradient record lies within 4 GB of `vrec` (C N 64 B): the atomic's address is a 32-bit offset from the base

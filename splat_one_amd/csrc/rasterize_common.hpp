@@ -22,6 +22,14 @@ struct LossFinal {
   // one-wave-per-tile backward -- a tile there is ONE wave's serial chain, so the kernel ends when its longest tile does;
   // started last, a long tile runs on alone over an emptying machine (round 4: 2.5 resident waves per SIMD of 5)
   const int32_t *tile_order = nullptr;
+  // Backward in list SEGMENTS (so_step_desc.bwd_seg_len > 0; quadrant waves, packed RGB, 16x16 tiles): the forward rasteriser left
+  // every pixel's (live transmittance, accumulated colour) at each segment boundary of its tile's list in seg_state
+  // [(boundary b) * pixels + pixel] (boundary b = after list entry (b + 1) * seg_len - 1); a workgroup of the backward takes ONE
+  // segment of one tile and starts from the state at its far end -- long lists become seg_count independent chains.
+  // render_colors: the forward's output (the colour accumulated behind a boundary = what was accumulated in all - up to it).
+  const float4 *seg_state = nullptr;
+  const float *render_colors = nullptr;
+  int seg_len = 0, seg_count = 1;
 };
 
 // Round 3: the RGB passes of both rasteriser kernels work on packed fp32 pairs (v_pk_mul / v_pk_fma are the

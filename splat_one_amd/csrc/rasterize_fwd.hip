@@ -32,7 +32,8 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
                 const int32_t *__restrict__ flatten_ids, const int32_t *__restrict__ n_isects_dev,
                 int64_t n_isects_host, float *__restrict__ render_colors, float *__restrict__ render_alphas,
                 int32_t *__restrict__ last_ids, int wrap_flags, const int32_t *__restrict__ tile_order,
-                const uint64_t *__restrict__ sort_keys = nullptr) {
+                const uint64_t *__restrict__ sort_keys = nullptr, float4 *__restrict__ seg_state = nullptr, int seg_batches = 0,
+                int seg_boundaries = 0) {
   static_assert(!SORT || (PACKED && D == 3 && TS == 16), "the prologue sort exists for the packed RGB 16x16 kernel");
   constexpr int BLOCK = TS * TS;
   // staged per Gaussian: A = (x, y, conic a, conic b), B = (conic c, opacity [, r, g when D == 3]),
@@ -250,6 +251,15 @@ k_rasterize_fwd(int C, int N, int W, int H, int tile_w, int tile_h, const float2
     if (batch_start + BLOCK < hi) {   // uniform; read after the next iteration's barrier, overwritten only after the one below it
       const bool wave_live = __ballot((V2 ? T_live : T) > 0.f) != 0ull;
       if (lane == 0) s_live[wid] = wave_live ? 1 : 0;
+      if constexpr (V2 && TS == 16) {
+        // a segment boundary of the backward (LossFinal::seg_state): this pixel's live transmittance and accumulated colour after
+        // the last entry of the segment (finished pixels: T_live == 0, never read -- their last contributor lies before)
+        if (seg_state) {
+          const int done = (int)((batch_start - lo) / BLOCK) + 1;          // batches walked so far (uniform)
+          if (done % seg_batches == 0 && done / seg_batches <= seg_boundaries && inside)      // (the last segment takes all that is left)
+            seg_state[(int64_t)(done / seg_batches - 1) * ((int64_t)C * H * W) + pix] = make_float4(T_live, acc[0], acc[1], acc[2]);
+        }
+      }
     }
   }
   if (inside) {
@@ -319,7 +329,8 @@ namespace so {
 int rasterize_fwd_packed_launch(int C, int N, int width, int height, int tile_size, const float *rec, const float *backgrounds,
                                 const int32_t *isect_offsets, const int32_t *flatten_ids, const int32_t *n_isects_dev,
                                 int64_t n_isects_host, float *render_colors, float *render_alphas, int32_t *last_ids,
-                                const int32_t *tile_order, void *stream, const uint64_t *sort_keys = nullptr);
+                                const int32_t *tile_order, void *stream, const uint64_t *sort_keys = nullptr, float *seg_state = nullptr,
+                                int seg_len = 0, int seg_count = 1);
 }
 extern "C" int so_rasterize_fwd_packed(int C, int N, int width, int height, int tile_size, const float *rec,
                                        const float *backgrounds, const int32_t *isect_offsets,
@@ -333,8 +344,13 @@ extern "C" int so_rasterize_fwd_packed(int C, int N, int width, int height, int 
 int so::rasterize_fwd_packed_launch(int C, int N, int width, int height, int tile_size, const float *rec, const float *backgrounds,
                                     const int32_t *isect_offsets, const int32_t *flatten_ids, const int32_t *n_isects_dev,
                                     int64_t n_isects_host, float *render_colors, float *render_alphas, int32_t *last_ids,
-                                    const int32_t *tile_order, void *stream, const uint64_t *sort_keys) {
+                                    const int32_t *tile_order, void *stream, const uint64_t *sort_keys, float *seg_state, int seg_len,
+                                    int seg_count) {
   SO_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, "so_rasterize_fwd_packed: bad sizes");
+  SO_REQUIRE(!seg_state || (seg_len > 0 && seg_len % 256 == 0 && so::tile_size_of(tile_size) == 16 && (((uintptr_t)seg_state) & 15) == 0),
+             "so_rasterize_fwd_packed: segment states need 16x16 tiles, seg_len a multiple of 256 and a 16-byte aligned buffer");
+  float4 *const seg4 = reinterpret_cast<float4 *>(seg_state);
+  const int seg_batches = seg_state ? seg_len / 256 : 0;
   // sort_keys (so_step_desc.sort_in_rasteriser): binned lists only (n_isects_dev == NULL, n_isects_host = -slots), 16x16 tiles
   SO_REQUIRE(!sort_keys || (!n_isects_dev && n_isects_host < 0 && so::tile_size_of(tile_size) == 16 && flatten_ids),
              "so_rasterize_fwd_packed: the prologue sort needs binned lists and 16x16 tiles");
@@ -353,11 +369,11 @@ int so::rasterize_fwd_packed_launch(int C, int N, int width, int height, int til
   if (tile_size == 16 && sort_keys)
     hipLaunchKernelGGL((so::k_rasterize_fwd<3, 16, true, true>), grid, dim3(256), 0, st, C, N, width, height, tile_w, tile_h,
                        nullptr, nullptr, rec, nullptr, backgrounds, nullptr, isect_offsets, flatten_ids, n_isects_dev,
-                       n_isects_host, render_colors, render_alphas, last_ids, wrap_flags, tile_order, sort_keys);
+                       n_isects_host, render_colors, render_alphas, last_ids, wrap_flags, tile_order, sort_keys, seg4, seg_batches, seg_count - 1);
   else if (tile_size == 16)
     hipLaunchKernelGGL((so::k_rasterize_fwd<3, 16, true>), grid, dim3(256), 0, st, C, N, width, height, tile_w, tile_h,
                        nullptr, nullptr, rec, nullptr, backgrounds, nullptr, isect_offsets, flatten_ids, n_isects_dev,
-                       n_isects_host, render_colors, render_alphas, last_ids, wrap_flags, tile_order, (const uint64_t *)nullptr);
+                       n_isects_host, render_colors, render_alphas, last_ids, wrap_flags, tile_order, (const uint64_t *)nullptr, seg4, seg_batches, seg_count - 1);
   else
     hipLaunchKernelGGL((so::k_rasterize_fwd<3, 8, true>), grid, dim3(64), 0, st, C, N, width, height, tile_w, tile_h,
                        nullptr, nullptr, rec, nullptr, backgrounds, nullptr, isect_offsets, flatten_ids, n_isects_dev,

@@ -60,7 +60,8 @@ int rasterize_bwd_packed_launch(int C, int N, int width, int height, int tile_si
 int rasterize_fwd_packed_launch(int C, int N, int width, int height, int tile_size, const float *rec, const float *backgrounds,
                                 const int32_t *isect_offsets, const int32_t *flatten_ids, const int32_t *n_isects_dev,
                                 int64_t n_isects_host, float *render_colors, float *render_alphas, int32_t *last_ids,
-                                const int32_t *tile_order, void *stream, const uint64_t *sort_keys = nullptr);
+                                const int32_t *tile_order, void *stream, const uint64_t *sort_keys = nullptr, float *seg_state = nullptr,
+                                int seg_len = 0, int seg_count = 1);
 int tile_order_launch(int C, int tile_w, int tile_h, const int32_t *offsets, const int32_t *n_isects_dev, int64_t n_isects_host,
                       int32_t *order, hipStream_t st);
 int ssim_l1_fused_launch(int B, int H, int W, int CH, const float *img1, const float *img2, const float *const *img2_slot,
@@ -363,9 +364,14 @@ static int step_impl(const so_step_desc *d, void *stream, StepPart part, int64_t
   const int64_t list_cap = bins ? -bins : d->isect_capacity;
   if (d->tile_order)   // longest list first (both rasterisers)
     SO_STAGE(10, so::tile_order_launch(C, tile_w, tile_h, list_off, list_n, list_cap, d->tile_order, st));
+  // the backward in list segments (so_step_desc.bwd_seg_len): the forward leaves the per-pixel state at the segment boundaries
+  const bool segs = d->bwd_seg_len > 0 && d->bwd_seg_count > 1 && !forward_only;
+  SO_REQUIRE(!segs || (ts == 16 && d->raster_impl == 0 && d->bwd_seg_state && d->bwd_seg_len % 256 == 0),
+             "so_train_step_fwd_bwd: bwd_seg_len needs 16x16 tiles, raster_impl 0, bwd_seg_state and a multiple of 256");
     SO_STAGE(3, so::rasterize_fwd_packed_launch(C, N, W, H, ts | wrap_flags, d->rec, d->backgrounds, list_off, d->flatten_ids, list_n,
                                                 list_cap, d->render_colors, d->render_alphas, d->last_ids, d->tile_order, stream,
-                                                fold_sort ? d->key_buf : nullptr));
+                                                fold_sort ? d->key_buf : nullptr, segs ? d->bwd_seg_state : nullptr, segs ? d->bwd_seg_len : 0,
+                                                segs ? d->bwd_seg_count : 1));
   if (forward_only) return SO_OK;
   // loss = (1-l) * mean|.| + l * (1 - mean SSIM_valid)
   const float n_l1 = (float)C * H * W * 3.f, n_ss = (float)C * 3.f * (float)(H - 10) * (float)(W - 10);
@@ -387,6 +393,12 @@ static int step_impl(const so_step_desc *d, void *stream, StepPart part, int64_t
   // forward preprocess kernel): one atomic request per (tile quadrant, Gaussian), or per (tile, Gaussian) with raster_impl 1
   fin.tile_waves = d->raster_impl == 1 ? 1 : 0;
   fin.tile_order = d->tile_order;
+  if (segs) {
+    fin.seg_state = reinterpret_cast<const float4 *>(d->bwd_seg_state);
+    fin.render_colors = d->render_colors;
+    fin.seg_len = d->bwd_seg_len;
+    fin.seg_count = d->bwd_seg_count;
+  }
     SO_STAGE(6, so::rasterize_bwd_packed_launch(C, N, W, H, ts | wrap_flags, d->rec, d->backgrounds, list_off, d->flatten_ids, list_n,
                                                 list_cap, d->render_alphas, d->last_ids, d->v_render_colors, d->zero_v_alphas, d->vrec,
                                                 d->absgrad, fin, stream));

@@ -601,6 +601,12 @@ class FusedEngine:
         d.sort_in_rasteriser = int(bool(self._fold and self.sort_fold_ok and self.binned and c["tile_size"] == 16))
         if self.binned and self.bin_replicas > 1:
             d.bin_replicas, d.bin_sub_counts = int(self.bin_replicas), p(w["bin_sub_counts"])
+        seg_count, seg_len = self._bwd_segments()
+        if seg_count > 1:
+            need = (seg_count - 1) * self.C * self.H * self.W * 4
+            if w.get("bwd_seg_state") is None or w["bwd_seg_state"].numel() < need:
+                w["bwd_seg_state"] = torch.empty(need, dtype=torch.float32, device=self.device)
+            d.bwd_seg_len, d.bwd_seg_count, d.bwd_seg_state = int(seg_len), int(seg_count), p(w["bwd_seg_state"])
         return d
 
     def _adam_args(self):
@@ -700,6 +706,23 @@ class FusedEngine:
                 sub[-1:].zero_()
             fullest = max(fullest, eff)
         return fullest
+
+    def _bwd_segments(self):
+        """(segments per tile, entries per segment) of the backward rasteriser (so_step_desc.bwd_seg_len), from the list statistics
+        the engine has: list_policy.pick_bwd_segments.  (1, 0): the backward walks a tile's list as one chain."""
+        import os
+        if not self.binned or self.cfg["tile_size"] != 16 or int(self.cfg["raster_impl"]) != 0:
+            return 1, 0
+        fullest, mean_list = getattr(self, "_list_stats", (0, 0.0))
+        env = os.environ.get("SPLAT_ONE_AMD_BWD_SEGMENTS")
+        if env is not None:
+            n = max(1, min(16, int(env)))
+            if n == 1 or fullest <= 0:
+                return 1, 0
+            return n, max(256, -(-int(fullest) // n // 256) * 256)
+        seg = list_policy.pick_bwd_segments(self.M, int(fullest), float(mean_list), now=bool(getattr(self, "_seg_on", False)))
+        self._seg_on = seg[0] > 1
+        return seg
 
     def _pick_bin_replicas(self, M: int) -> int:
         """Copies of the per-tile bin counters (SPLAT_ONE_AMD_BIN_REPLICAS overrides): 8 up to 2304 tiles (a 768 x 768 image), 4 up
@@ -975,7 +998,8 @@ class FusedEngine:
             self._consume_staging()
             self._launch_fwd_bwd()
             return
-        key = (self.N, self.cfg["sh_degree"], id(self.ws), self.strategy_state is not None, self.active if self.device_refine else 0)
+        key = (self.N, self.cfg["sh_degree"], id(self.ws), self.strategy_state is not None, self.active if self.device_refine else 0,
+               self._bwd_segments())
         if key not in self._graphs_fb:
             self._capture_split(key)
         self._graph_fb, self._graph_opt = self._graphs_fb[key]
@@ -993,7 +1017,8 @@ class FusedEngine:
             d = self._desc()
             _lib.call("so_train_step_head", ctypes.byref(d), _lib.stream())
             return
-        key = (self.N, self.cfg["sh_degree"], id(self.ws), self.strategy_state is not None, self.active if self.device_refine else 0)
+        key = (self.N, self.cfg["sh_degree"], id(self.ws), self.strategy_state is not None, self.active if self.device_refine else 0,
+               self._bwd_segments())
         if key not in self._graphs_head:
             if not self._staged:
                 self._stage(None, None, None, False)
@@ -1087,7 +1112,8 @@ class FusedEngine:
                 self._launch_fwd_bwd()
                 self._launch_optimize(sched)
         else:
-            key = (self.N, self.cfg["sh_degree"], id(self.ws), self.strategy_state is not None, self.active if self.device_refine else 0)
+            key = (self.N, self.cfg["sh_degree"], id(self.ws), self.strategy_state is not None, self.active if self.device_refine else 0,
+                   self._bwd_segments())
             if key not in self._graphs:
                 self._sched_staged = sched
                 self._capture(key)

@@ -110,6 +110,18 @@ def pick_bin_replicas(n_tiles: int, fullest: int = 0, mean_list: float = 0.0) ->
     return 1
 
 
+def pick_bwd_segments(n_tiles: int, fullest: int, mean_list: float, now: bool = False):
+    """(segments per tile, entries per segment) of the quadrant-wave backward rasteriser (so_step_desc.bwd_seg_len): eight segments where
+    the kernel is bound by the serial chain of its fullest tiles -- fullest list >= 1024 entries and either few tiles (<= 2304) or one
+    hot region (fullest > 16x mean; at 11x -- 400k Gaussians in a sixth of the image -- segments lose 3 %) -- else (1, 0).  Measured (tools/gpu_r05_ax.sh, backward us with 1 / 8 segments): a cloud gathered in
+    a ninth of a 1080p image 123 -> 89, 512 x 512 dense 166 -> 146, 960 x 540 / 1M 209 -> 204; where lists are long EVERYWHERE on many tiles
+    (a 1440 x 720 panorama inside a 1M cloud) segments only add workgroups: 237 -> 267, and on short lists the empty ones cost (c2: 70 -> 124)."""
+    m = max(mean_list, 1.0)       # (hysteresis once running: down to 768 entries / 12x)
+    if fullest >= (768 if now else 1024) and (n_tiles <= 2304 or fullest > (12.0 if now else 16.0) * m):
+        return 8, max(256, -(-int(fullest) // 8 // 256) * 256)
+    return 1, 0
+
+
 def pick_sort_fold(now: bool, binned: bool, tile16: bool, fullest: int) -> bool:
     """The per-tile sort inside the forward rasteriser (one launch fewer) where lists are short EVERYWHERE: fullest tile <= 256
     entries, i.e. every workgroup sorts its list with ONE wave in registers; with hysteresis (back to the sort kernels above

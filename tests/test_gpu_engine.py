@@ -223,10 +223,13 @@ def test_engine_long_binned_lists_equal_the_operator_lists(dev):
 
 
 @pytest.mark.parametrize("regime,C,aa,binned", [("ref", 1, False, True), ("mcmc", 2, True, True), ("ref", 1, False, False)])
-def test_engine_tile_cull_is_exact(dev, regime, C, aa, binned):
+def test_engine_tile_cull_is_exact(dev, monkeypatch, regime, C, aa, binned):
     """Exact tile culling drops (Gaussian, tile) pairs that cannot reach alpha = 1/255 at any pixel of the tile:
     fewer intersections, the SAME image bit for bit, the same gradients up to the order of the atomic sums; the
     surviving lists are subsequences of gsplat's lists (which the engine reproduces exactly with culling off)."""
+    # (the same backward walk in both runs: list segments -- chosen from the list lengths, which the cull changes -- take another
+    # float32 route to the same gradients, 1e-5 ... 3e-5 apart; test_backward_in_list_segments_gives_the_same_gradients)
+    monkeypatch.setenv("SPLAT_ONE_AMD_BWD_SEGMENTS", "1")
     from splat_one_amd.engine import FusedEngine
     from splat_one_amd.rendering import rasterization
     N, W, H = 8000, 200, 136
@@ -694,3 +697,39 @@ def test_a_bin_slice_that_overflows_voids_the_iteration_and_the_bins_grow(dev, m
     eng.step()
     torch.cuda.synchronize()
     assert eng.stats()["overflow"] == 0
+
+
+@pytest.mark.parametrize("segments", [2, 4, 7])
+def test_backward_in_list_segments_gives_the_same_gradients(dev, monkeypatch, segments):
+    """so_step_desc.bwd_seg_len (round 5): the forward rasteriser leaves every pixel's (live transmittance, accumulated colour) at
+    the segment boundaries of its tile's list, and the backward runs one workgroup per (tile, segment), each from the state at the
+    far end of its segment.  Same image (the forward is untouched), same loss, gradients equal up to the order of float additions
+    -- on a cloud gathered in the middle of a small image (lists of 0 ... 3000+ entries: pixels that stop in the first segment,
+    pixels that run through all of them, tiles shorter than one segment, lists longer than all segments together)."""
+    from splat_one_amd.engine import FusedEngine
+    N, W, H = 30_000, 256, 160
+    out = {}
+    for seg in (1, segments):
+        monkeypatch.setenv("SPLAT_ONE_AMD_BWD_SEGMENTS", str(seg))
+        r, c2w, Ks, pixels = _make(dev, N, W, H, "ref")
+        with torch.no_grad():
+            r.splats["means"].mul_(0.25)
+        eng = FusedEngine(r.splats, r.optimizers, W, H, 1, sh_degree=3, use_graph=False, fuse_adam=False)
+        eng.set_views(c2w, Ks, pixels)
+        eng.fwd_bwd()
+        torch.cuda.synchronize()
+        d = eng._desc()
+        assert eng.binned and eng.cfg["raster_impl"] == 0 and (d.bwd_seg_count, d.bwd_seg_len > 0) == ((seg, True) if seg > 1 else (0, False))
+        if seg > 1:     # (the entries per segment are sized by the fullest list of the probe; one test with lists longer than all segments)
+            if segments == 7:
+                eng._list_stats = (eng._list_stats[0] // 3, eng._list_stats[1])
+                eng.fwd_bwd()
+                torch.cuda.synchronize()
+                assert eng._desc().bwd_seg_len * segments < eng._fullest_tile()
+        out[seg] = dict(img=eng.ws["render_colors"].clone(), loss=eng.loss().clone(), grads={k: v.grad.detach().clone() for k, v in r.splats.items()})
+    a, b = out[1], out[segments]
+    assert torch.equal(a["img"], b["img"]) and torch.allclose(a["loss"], b["loss"], rtol=1e-6, atol=0)      # (the loss sums are atomics)
+    for k in a["grads"]:
+        # (a segment starts from the forward's own transmittance; the one-chain walk re-derives it by a product of reciprocals:
+        # measured 1.3e-5 apart with four segments, 3.3e-5 with seven -- two float32 routes to the same number, the oracle's bar is 1e-3)
+        assert rel_err(b["grads"][k], a["grads"][k]) < 1e-4, (segments, k, rel_err(b["grads"][k], a["grads"][k]))

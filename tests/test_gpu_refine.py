@@ -213,11 +213,13 @@ def _runner(dev, N, W, H, **kw):
     return Runner(0, 0, 1, cfg, scene_scale=1.0 / 1.1)
 
 
-def test_engine_refinement_without_host_sync_equals_the_oracle(dev):
+def test_engine_refinement_without_host_sync_equals_the_oracle(dev, monkeypatch):
     """Through Runner.train_step: a refinement step issues no synchronising torch call (sync debug mode "error"), the
     next steps replay captured graphs on the other model set, and the Gaussian set after the refinement equals the
     oracle's on the state the device held before it."""
     W, H, N = 160, 120, 4000
+    # (one backward configuration throughout: the engine would move to list segments as the lists grow -- one more capture, its own test)
+    monkeypatch.setenv("SPLAT_ONE_AMD_BWD_SEGMENTS", "1")
     # (bins given up front with room for the six refinements below: the engine follows growing lists by itself and would
     # rebuild its bins -- allocations, a re-capture -- inside the window that must not synchronise; that path has its own test,
     # test_bins_and_backward_rasteriser_follow_growing_lists_without_a_read_back)

@@ -162,3 +162,11 @@ def test_engine_executes_the_actions_in_order_with_a_stubbed_engine():
 def test_bin_counter_copies_by_tile_count_and_hot_regions(n_tiles, fullest, mean, expect):
     """so_step_desc.bin_replicas: by the tile count, and on large images only where one region is hot."""
     assert LP.pick_bin_replicas(n_tiles, fullest, mean) == expect
+
+
+@pytest.mark.parametrize("n_tiles,fullest,mean,expect", [(1024, 1568, 520.0, (8, 256)), (1024, 900, 500.0, (1, 0)), (8160, 1376, 33.0, (8, 256)),
+                                                          (8160, 900, 512.0, (1, 0)), (4050, 1760, 377.0, (1, 0)), (8160, 5000, 40.0, (8, 768)), (8160, 1100, 100.0, (1, 0)),
+                                                          (2040, 1568, 607.0, (8, 256))])
+def test_backward_segments_where_the_fullest_tiles_chain_binds(n_tiles, fullest, mean, expect):
+    """so_step_desc.bwd_seg_len: few tiles or one hot region, and lists of >= 1024 entries."""
+    assert LP.pick_bwd_segments(n_tiles, fullest, mean) == expect
