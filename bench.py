@@ -843,8 +843,11 @@ def main():
                    "fell_back_to_compact_lists": bool(fused and not runner.sharded and getattr(runner._engine, "fell_back_to_compact", False)),
                    "backward_rasteriser": ("one wave per 16x16 tile" if fused and not runner.sharded and runner._engine.cfg.get("raster_impl") == 1
                                            else "one wave per 8x8 quadrant"),
-                   "tile_order": ("longest list first (device-built table, one launch per step)" if fused and not runner.sharded and getattr(runner._engine, "_lpt", False)
-                                  and getattr(runner._engine, "tile_order_lpt", False) else "XCD-local runs of 8 tiles"),
+                   "tile_order": ({"each": "longest list first (device-built table, one launch per step)",
+                                   "build": "longest list first (table kept per view, rebuilt every 8th visit)",
+                                   "kept": "longest list first (table kept per view, rebuilt every 8th visit)"}.get(
+                                       getattr(runner._engine, "_order_mode", "none"), "XCD-local runs of 8 tiles")
+                                  if fused and not runner.sharded else "XCD-local runs of 8 tiles"),
                    "parallelism": (f"gaussian-sharded dp{world}: one view per GPU, N/{world} Gaussians per GPU, "
                                    "projected Gaussians exchanged by all-to-all" if runner.sharded else
                                    f"view-sharded dp{world}" + ("" if world == 1 else

@@ -534,6 +534,11 @@ typedef struct so_step_desc {
    * float additions. */
   int32_t bwd_seg_len, bwd_seg_count;
   float *bwd_seg_state;
+  /* != 0: tile_order already holds a workgroup -> tile table for these views (any permutation of the C x tiles indices is valid:
+   * the order only schedules) -- the step does not build one.  The engine keeps the table it built the last time it saw a view and
+   * hands it back through so_step_inputs (order_src): list lengths of a view change slowly over training, the table's launch
+   * (~13 us at 1080p) is then paid once every few visits. */
+  int32_t tile_order_ready;
 } so_step_desc;
 typedef struct so_adam_fuse {
   so_adam_group groups[6]; /* means, log_scales, quats, logit_opacities, sh0, shN: param / exp_avg / exp_avg_sq (grad unused) */
@@ -570,7 +575,8 @@ int so_train_step_bwd_rows(const so_step_desc *desc, int64_t row_begin, int64_t 
 int so_step_inputs(int C, const float *camtoworlds, const float *Ks_src, float *viewmats, float *Ks_dst,
                    const float *pixels, const float **pixels_slot, int32_t *counters, int64_t n_zero, int n_groups,
                    const float *lr0, const float *lr_gamma, double beta1, double beta2, int32_t *step_counter,
-                   int32_t *status_out, int64_t status_at, int32_t seq, int64_t n_lists, int32_t *lists_stat, void *stream);
+                   int32_t *status_out, int64_t status_at, int32_t seq, int64_t n_lists, int32_t *lists_stat,
+                   const int32_t *order_src /* nullable */, int32_t *order_dst, int64_t n_order, void *stream);
 /* the forward stages only (preprocess, binning, sort, rasterise) on the same descriptor: the eval /
  * viewer render of gsplat_trainer.py:779-940; pixels, loss and gradient buffers are not touched */
 int so_render_forward(const so_step_desc *desc, void *stream);

@@ -47,7 +47,8 @@ class StepDesc(ctypes.Structure):
            ("overflow_flag_out", c_ptr), ("attr_rows_f16", c_ptr), ("tile_slots", c_ptr), ("bin_capacity", c_i64), ("fuse_adam", c_ptr),
            ("n_dev", c_ptr), ("tile_order", c_ptr), ("sort_in_rasteriser", ctypes.c_int32),
            ("bin_replicas", ctypes.c_int32), ("bin_sub_counts", c_ptr),
-           ("bwd_seg_len", ctypes.c_int32), ("bwd_seg_count", ctypes.c_int32), ("bwd_seg_state", c_ptr)])
+           ("bwd_seg_len", ctypes.c_int32), ("bwd_seg_count", ctypes.c_int32), ("bwd_seg_state", c_ptr),
+           ("tile_order_ready", ctypes.c_int32)])
 
 
 class RasterDesc(ctypes.Structure):
@@ -154,7 +155,8 @@ _SIGS = {
     "so_preprocess_fwd_f16": [c_int] * 4 + [c_ptr] * 5 + [c_int, c_int, c_f32, c_f32, c_f32, c_f32, c_int, c_int, c_int] + [c_ptr] * 10 + [c_i64, c_ptr, c_int, c_ptr, c_i64, c_ptr, c_ptr],
     "so_preprocess_bwd_f16": [c_int] * 4 + [c_ptr] * 5 + [c_int, c_int, c_f32, c_int, c_int] + [c_ptr] * 3 + [c_f32, c_f32] + [c_ptr] * 9 + [c_int, c_i64, c_ptr, c_ptr, c_ptr],
     "so_step_inputs": [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, ctypes.POINTER(c_f32),
-                       ctypes.POINTER(c_f32), ctypes.c_double, ctypes.c_double, c_ptr, c_ptr, c_i64, c_int, c_i64, c_ptr, c_ptr],
+                       ctypes.POINTER(c_f32), ctypes.c_double, ctypes.c_double, c_ptr, c_ptr, c_i64, c_int, c_i64, c_ptr,
+                       c_ptr, c_ptr, c_i64, c_ptr],
     "so_compute_relocation": [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr],
     "so_inject_noise": [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr],
     "so_mcmc_refine": [c_i64, c_int, ctypes.POINTER(ModelSet), c_ptr, c_ptr, c_int, ctypes.POINTER(McmcParams), c_ptr, c_ptr, c_ptr],

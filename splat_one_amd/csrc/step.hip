@@ -116,7 +116,12 @@ __global__ void __launch_bounds__(256)
 k_step_inputs(int C, const float *__restrict__ c2w, const float *__restrict__ Ks_src, float *__restrict__ w2c,
               float *__restrict__ Ks_dst, const float *pixels, const float **pixels_slot, uint32_t *__restrict__ counters,
               int64_t n_zero, AdamSched sch, int n_groups, double beta1, double beta2, int32_t *__restrict__ step_ptr,
-              int32_t *status_out, int64_t status_at, int32_t seq, int64_t n_lists, int32_t *__restrict__ lists_stat) {
+              int32_t *status_out, int64_t status_at, int32_t seq, int64_t n_lists, int32_t *__restrict__ lists_stat,
+              const int32_t *__restrict__ order_src, int32_t *__restrict__ order_dst, int64_t n_order) {
+  // order_src (nullable): a workgroup -> tile table the caller kept for THIS view (so_step_desc.tile_order_ready) -- copied into the
+  // step's table here, in the launch that runs anyway
+  if (order_src)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_order; i += (int64_t)gridDim.x * blockDim.x) order_dst[i] = order_src[i];
   // status_out (host-mapped, nullable): what the PREVIOUS iteration left in counters[status_at], [status_at+1]
   // (n_isects, overflow), read by one thread before that pair is zeroed, so no other workgroup races it
   // lists_stat (device, int32[4], nullable; with status_out): the first n_lists counters are the per-tile list lengths of the
@@ -243,7 +248,8 @@ extern "C" int so_step_inputs(int C, const float *camtoworlds, const float *Ks_s
                               const float *pixels, const float **pixels_slot, int32_t *counters, int64_t n_zero,
                               int n_groups, const float *lr0, const float *lr_gamma, double beta1, double beta2,
                               int32_t *step_counter, int32_t *status_out, int64_t status_at, int32_t seq, int64_t n_lists,
-                              int32_t *lists_stat, void *stream) {
+                              int32_t *lists_stat, const int32_t *order_src, int32_t *order_dst, int64_t n_order, void *stream) {
+  SO_REQUIRE(order_src == nullptr || (order_dst && n_order > 0), "so_step_inputs: order_src needs order_dst and n_order");
   SO_REQUIRE(C >= 0 && n_zero >= 0 && n_groups >= 0 && n_groups <= SO_ADAM_MAX_GROUPS, "so_step_inputs: bad sizes");
   SO_REQUIRE(C == 0 || (camtoworlds && viewmats), "so_step_inputs: null camera pointers");
   SO_REQUIRE((Ks_src == nullptr) == (Ks_dst == nullptr), "so_step_inputs: Ks_src and Ks_dst go together");
@@ -259,7 +265,7 @@ extern "C" int so_step_inputs(int C, const float *camtoworlds, const float *Ks_s
   if (g > 1024) g = 1024;
   hipLaunchKernelGGL(so::k_step_inputs, dim3((unsigned)g), dim3(256), 0, so::as_stream(stream), C, camtoworlds, Ks_src, viewmats,
                      Ks_dst, pixels, pixels_slot, reinterpret_cast<uint32_t *>(counters), n_zero, S, n_groups, beta1, beta2,
-                     step_counter, status_out, status_at, seq, n_lists, lists_stat);
+                     step_counter, status_out, status_at, seq, n_lists, lists_stat, order_src, order_dst, n_order);
   return so::check_launch("so_step_inputs");
 }
 
@@ -362,7 +368,7 @@ static int step_impl(const so_step_desc *d, void *stream, StepPart part, int64_t
   const int32_t *list_off = bins ? tile_counts : d->isect_offsets;
   const int32_t *list_n = bins ? nullptr : n_isects;
   const int64_t list_cap = bins ? -bins : d->isect_capacity;
-  if (d->tile_order)   // longest list first (both rasterisers)
+  if (d->tile_order && !d->tile_order_ready)   // longest list first (both rasterisers); ready: the caller's own table of this view, kept from an earlier visit
     SO_STAGE(10, so::tile_order_launch(C, tile_w, tile_h, list_off, list_n, list_cap, d->tile_order, st));
   // the backward in list segments (so_step_desc.bwd_seg_len): the forward leaves the per-pixel state at the segment boundaries
   const bool segs = d->bwd_seg_len > 0 && d->bwd_seg_count > 1 && !forward_only;

@@ -140,6 +140,16 @@ class FusedEngine:
         import os
         self.tile_order_lpt = os.environ.get("SPLAT_ONE_AMD_TILE_ORDER", "1") != "0"   # (0: keep the XCD-local order, for A/B runs)
         self._lpt = False                # the rasterisers take their tiles longest list first (list_policy.pick_tile_order)
+        # Tables kept per view (so_step_desc.tile_order_ready): {view key: [table, visits since it was built]}.  A view is known by the
+        # key the caller gives (set_views(view_key=...): the trainer's image id) or by the address of its target image when that is
+        # used in place; the table built at one visit schedules the next `order_refresh - 1` visits of the same view (any permutation
+        # is a valid order -- only the speed depends on how well it still fits).  SPLAT_ONE_AMD_ORDER_CACHE=0: off.
+        self._order_cache = {}
+        self._order_key = None
+        self._order_mode = "none"        # "none" | "build" (the step builds the table, kept afterwards) | "kept" | "each" (built every step, no key)
+        self._lpt_kept = False
+        self.order_refresh = 8
+        self.order_cache_on = os.environ.get("SPLAT_ONE_AMD_ORDER_CACHE", "1") != "0"
         self.before_param_access = None  # replicas: RowShardedAdam.wait_gathers (see _params_ready)
         self._fold = False               # the per-tile sort runs in the forward rasteriser's prologue (list_policy.pick_sort_fold)
         # Measured equal (profiles/r05_experiments.json: c2 3 926-3 930 it/s folded against 3 912-3 931; the forward rasteriser takes
@@ -597,7 +607,8 @@ class FusedEngine:
         d.tile_slots = p(w["tile_slots"])
         d.tile_cull = int(self.tile_cull)
         d.bin_capacity = self.bin_capacity
-        d.tile_order = p(w["tile_order"]) if (self._lpt and self.tile_order_lpt) else 0
+        d.tile_order = p(w["tile_order"]) if self._order_mode != "none" else 0
+        d.tile_order_ready = 1 if self._order_mode == "kept" else 0
         d.sort_in_rasteriser = int(bool(self._fold and self.sort_fold_ok and self.binned and c["tile_size"] == 16))
         if self.binned and self.bin_replicas > 1:
             d.bin_replicas, d.bin_sub_counts = int(self.bin_replicas), p(w["bin_sub_counts"])
@@ -666,14 +677,17 @@ class FusedEngine:
                 px = w["pixels"]
             self._pixels_ref = px                    # must stay alive and unchanged until the step has run
         publish = c2w is not None                    # a new iteration: publish what the previous one left behind
+        order_src = 0
         if publish:
             self._status_kind = self._last_launch    # ... which was a training iteration or a forward-only render
             self._seq = (self._seq + 1) & 0x3FFFFFFF
+            order_src = self._pick_order_mode()
         _lib.call("so_step_inputs", self.C if c2w is not None else 0, p(c2w), p(Ks), p(w["viewmats"]), p(w["Ks"]) if c2w is not None else 0,
                   p(px), p(w["pixels_slot"]) if px is not None else 0, p(w["counters"]), 2 * self.M + 5, n_groups, lr0, gam,
                   float(betas[0]), float(betas[1]), _lib.ptr(self._step_dev),
                   self._status.data_ptr() if publish else 0, 2 * self.M + 1, self._seq,
-                  self.M if (publish and self.binned) else 0, p(self._lists_stat) if (publish and self.binned) else 0, _lib.stream())
+                  self.M if (publish and self.binned) else 0, p(self._lists_stat) if (publish and self.binned) else 0,
+                  order_src, p(w["tile_order"]) if order_src else 0, self.M if order_src else 0, _lib.stream())
         if publish:
             self._status_event = torch.cuda.Event()
             self._status_event.record()
@@ -694,6 +708,41 @@ class FusedEngine:
                 self._sched_staged = bool(schedule)
 
     # ------------------------------------------------------------------------------------------ capacity
+    def _pick_order_mode(self) -> int:
+        """Where this iteration's workgroup -> tile table comes from (self._order_mode); returns the address of the kept table to
+        hand to so_step_inputs, or 0."""
+        each = bool(self._lpt and self.tile_order_lpt)                   # list_policy: a table pays even at one launch per step
+        key = self._order_key
+        mean = getattr(self, "_list_stats", (0, 0.0))[1]
+        kept_ok = (key is not None and self.binned and self.tile_order_lpt and self.cfg["tile_size"] == 16
+                   and (each or list_policy.pick_tile_order_kept(self._lpt_kept, mean)))
+        self._lpt_kept = bool(kept_ok)
+        if not kept_ok:
+            self._order_mode = "each" if each else "none"
+            return 0
+        ent = self._order_cache.get(key)
+        if ent is None or ent[0].numel() != self.M or ent[1] >= self.order_refresh - 1:
+            self._order_mode = "build"
+            return 0
+        ent[1] += 1
+        self._order_mode = "kept"
+        return _lib.ptr(ent[0])
+
+    def _order_graph_id(self) -> int:
+        return {"none": 0, "each": 1, "build": 1, "kept": 2}[self._order_mode]
+
+    def _keep_order_table(self) -> None:
+        """After a launch that built the table: keep a copy for the next visits of this view (one device copy of C x tiles words)."""
+        if self._order_mode != "build" or self._order_key is None:
+            return
+        if len(self._order_cache) > 4096:
+            self._order_cache.clear()
+        ent = self._order_cache.get(self._order_key)
+        if ent is None or ent[0].numel() != self.M:
+            ent = self._order_cache[self._order_key] = [torch.empty(self.M, dtype=torch.int32, device=self.device), 0]
+        ent[0].copy_(self.ws["tile_order"])
+        ent[1] = 0
+
     def _fullest_tile(self) -> int:
         """Largest per-tile count of the last binning pass (binned lists: the atomics count past the capacity).  With replicated
         counters a SLICE of a bin may have overflowed below that: the device then left R x its fullest slice -- the bin capacity
@@ -906,7 +955,7 @@ class FusedEngine:
             warnings.warn(f"splat_one_amd: {void} training iteration(s) skipped -- {what}; buffers enlarged", RuntimeWarning)
         self._apply(actions)
 
-    def set_views(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor, schedule: bool = False) -> None:
+    def set_views(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor, schedule: bool = False, view_key=None) -> None:
         """Stage this step's cameras and target images.  camtoworlds[C,4,4] (inverted on the device),
         Ks[C,3,3], pixels[C,H,W,3] in 0..1 -- a contiguous float32 HIP tensor is used IN PLACE (keep it
         unchanged until the step has run).  schedule=True also evaluates the Adam schedule for the
@@ -914,6 +963,10 @@ class FusedEngine:
         gradients are wanted."""
         assert camtoworlds.shape == (self.C, 4, 4) and Ks.shape == (self.C, 3, 3), (camtoworlds.shape, Ks.shape)
         assert pixels.shape == (self.C, self.H, self.W, 3), pixels.shape
+        # which view this is (for the kept tile tables): the caller's key, else the address of a target image that is used in place
+        if view_key is None and pixels.is_cuda and pixels.dtype == torch.float32 and pixels.is_contiguous():
+            view_key = ("px", pixels.data_ptr())
+        self._order_key = view_key if self.order_cache_on else None
         self._stage(camtoworlds, Ks, pixels, schedule)
 
     def _fusable(self, sched: bool) -> bool:
@@ -997,15 +1050,17 @@ class FusedEngine:
         if not self.use_graph:
             self._consume_staging()
             self._launch_fwd_bwd()
+            self._keep_order_table()
             return
         key = (self.N, self.cfg["sh_degree"], id(self.ws), self.strategy_state is not None, self.active if self.device_refine else 0,
-               self._bwd_segments())
+               self._bwd_segments(), self._order_graph_id())
         if key not in self._graphs_fb:
             self._capture_split(key)
         self._graph_fb, self._graph_opt = self._graphs_fb[key]
         self._graph_opt = self._graph_opt or None
         self._consume_staging()
         self._graph_fb.replay()
+        self._keep_order_table()
 
     def fwd_bwd_head(self) -> None:
         """Data-parallel replicas: forward, loss and rasteriser backward of the staged views (so_train_step_head) -- the
@@ -1016,9 +1071,10 @@ class FusedEngine:
             self._consume_staging()
             d = self._desc()
             _lib.call("so_train_step_head", ctypes.byref(d), _lib.stream())
+            self._keep_order_table()
             return
         key = (self.N, self.cfg["sh_degree"], id(self.ws), self.strategy_state is not None, self.active if self.device_refine else 0,
-               self._bwd_segments())
+               self._bwd_segments(), self._order_graph_id())
         if key not in self._graphs_head:
             if not self._staged:
                 self._stage(None, None, None, False)
@@ -1031,6 +1087,7 @@ class FusedEngine:
             self._graphs_head[key] = g
         self._consume_staging()
         self._graphs_head[key].replay()
+        self._keep_order_table()
 
     def bwd_rows(self, a: int, b: int) -> None:
         """The per-Gaussian backward for rows [a, b) (a multiple of 64) of every gradient tensor: so_train_step_bwd_rows on
@@ -1113,13 +1170,14 @@ class FusedEngine:
                 self._launch_optimize(sched)
         else:
             key = (self.N, self.cfg["sh_degree"], id(self.ws), self.strategy_state is not None, self.active if self.device_refine else 0,
-                   self._bwd_segments())
+                   self._bwd_segments(), self._order_graph_id())
             if key not in self._graphs:
                 self._sched_staged = sched
                 self._capture(key)
                 self._sched_staged = False
             self._consume_staging()
             self._graphs[key][sched].replay()
+        self._keep_order_table()
         self._advance_host_counters()
 
     def _capture(self, key) -> None:

@@ -95,6 +95,13 @@ def pick_tile_order(now: bool, impl: int, mean_list: float, fullest: int) -> boo
     return bool(now and fullest >= 384 and fullest > 6.0 * m)
 
 
+def pick_tile_order_kept(now: bool, mean_list: float) -> bool:
+    """Longest list first from a table KEPT per view (so_step_desc.tile_order_ready: built once every few visits of a view, its
+    ~13 us launch amortised): worth it from a mean of 24 entries per tile on (hysteresis 16) -- at c2 (mean 32) the two rasterisers
+    give 7.6 us back (tools/gpu_r05_ak.sh), which the per-step table cost more than."""
+    return mean_list >= (16.0 if now else 24.0)
+
+
 def pick_bin_replicas(n_tiles: int, fullest: int = 0, mean_list: float = 0.0) -> int:
     """Copies of the per-tile bin counters (so_step_desc.bin_replicas), chosen when a workspace is built: the returning atomics of
     ONE counter serialise at ~230 ns, so what matters is how many entries the busiest counters take.  Few tiles: 8 copies up to

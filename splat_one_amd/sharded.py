@@ -237,7 +237,7 @@ class ShardedEngine:
         self._seq = (self._seq + 1) & 0x3FFFFFFF
         _lib.call("so_step_inputs", n, p(c2w), p(Ksd), P("w.viewmats"), P("w.Ks"), 0, 0, P("w.counters"), 2 * M + 5, ng,
                   lr0, gam, float(betas[0]), float(betas[1]), p(self._step_dev), self._status.data_ptr(), 2 * M + 1,
-                  self._seq, 0, 0, st)
+                  self._seq, 0, 0, 0, 0, 0, st)
         self._status_event = torch.cuda.Event()
         self._status_event.record()
         ts = c["tile_size"]

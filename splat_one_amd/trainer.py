@@ -665,7 +665,7 @@ class Runner:
             return c.strategy.refine_scale2d_stop_iter == 0
         return isinstance(c.strategy, MCMCStrategy)
 
-    def _train_step_fused(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor) -> Tensor:
+    def _train_step_fused(self, camtoworlds: Tensor, Ks: Tensor, pixels: Tensor, image_ids: Optional[Tensor] = None) -> Tensor:
         from .engine import FusedEngine
         eng = getattr(self, "_engine", None)
         if self.world_size > 1 and eng is not None:
@@ -715,15 +715,20 @@ class Runner:
         stats_on = isinstance(s, DefaultStrategy) and step < s.refine_stop_iter
         if stats_on != (eng.strategy_state is not None):
             eng.bind_strategy_state(self._strategy_state if stats_on else None)
+        # which training image this is (the engine keeps a tile table per view, FusedEngine.set_views): the loader's image id when it
+        # is on the host (no read-back for it), else the engine goes by the address of the target image
+        vkey = None
+        if image_ids is not None and not getattr(image_ids, "is_cuda", False):
+            vkey = ("id",) + tuple(int(i) for i in torch.as_tensor(image_ids).reshape(-1).tolist())
         if self.world_size == 1:
-            eng.set_views(camtoworlds, Ks, pixels, schedule=True)   # the step below always runs the optimiser
+            eng.set_views(camtoworlds, Ks, pixels, schedule=True, view_key=vkey)   # the step below always runs the optimiser
             eng.step()
         elif eng.device_refine:
             # replicated Gaussians, device-resident model: reduce-scatter / 1/world Adam / all-gather over ROW pieces of the
             # capacity-sized tensors (distributed.RowShardedAdam), the per-Gaussian backward cut into Config.dp_chunks row
             # chunks so that the reduce-scatter of chunk c runs on RCCL's stream under the kernel of chunk c + 1; no
             # collective besides those (the void flag rides in chunk 0).  N is the host's copy (sync_host below)
-            eng.set_views(camtoworlds, Ks, pixels, schedule=False)
+            eng.set_views(camtoworlds, Ks, pixels, schedule=False, view_key=vkey)
             if self._radam is None:
                 self._radam = sdist.RowShardedAdam(n_chunks=self._dp_chunks)
             ra, n = self._radam, eng.n_host
@@ -745,7 +750,7 @@ class Runner:
             # replicated Gaussians, torch-level refinement: reduce-scatter of the FLAT gradient in chunks, Adam on this
             # rank's 1/world of every chunk as it lands, all-gather of the updated parameters (distributed.ShardedFlatAdam);
             # the void flags travel in a 64-byte-per-rank reduce-scatter of their own, issued with the first chunk
-            eng.set_views(camtoworlds, Ks, pixels, schedule=False)
+            eng.set_views(camtoworlds, Ks, pixels, schedule=False, view_key=vkey)
             eng.fwd_bwd()
             if self._sadam is None or self._sadam.total != eng.flat_total:
                 self._sadam = sdist.ShardedFlatAdam(eng.flat_total, n_chunks=self._dp_chunks)
@@ -977,7 +982,7 @@ class Runner:
                 "gaussian_sharded: pass the cameras of all ranks [world,4,4] / [world,3,3] and the own image [1,H,W,3]"
             return self._train_step_sharded(camtoworlds, Ks, pixels)
         if self._fused_ok(masks):
-            return self._train_step_fused(camtoworlds, Ks, pixels)
+            return self._train_step_fused(camtoworlds, Ks, pixels, image_ids)
         cfg, step = self.cfg, self.step
         height, width = pixels.shape[1:3]
         if cfg.pose_noise > 0.0 or cfg.pose_opt:                               # :579-582

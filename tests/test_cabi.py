@@ -72,7 +72,7 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
     fields = {"so_step_desc": ["means", "viewmats", "radii", "key_buf", "rec", "v_means", "grad2d", "isect_capacity", "abi_size",
                                "raster_impl", "eps2d", "scale_reg", "pixels_indirect", "inputs_staged", "tile_cull",
                                "overflow_flag_out", "attr_rows_f16", "tile_slots", "bin_capacity", "fuse_adam", "n_dev", "tile_order", "sort_in_rasteriser",
-                               "bin_replicas", "bin_sub_counts", "bwd_seg_len", "bwd_seg_count", "bwd_seg_state"],
+                               "bin_replicas", "bin_sub_counts", "bwd_seg_len", "bwd_seg_count", "bwd_seg_state", "tile_order_ready"],
               "so_adam_group": ["param", "visibility", "numel", "row_len", "lr_step_size", "bc2_sqrt"],
               "so_attr_shadow": ["arec", "stride_bytes", "offset_bytes"],
               "so_model_set": ["p", "m", "v"],

@@ -733,3 +733,39 @@ def test_backward_in_list_segments_gives_the_same_gradients(dev, monkeypatch, se
         # (a segment starts from the forward's own transmittance; the one-chain walk re-derives it by a product of reciprocals:
         # measured 1.3e-5 apart with four segments, 3.3e-5 with seven -- two float32 routes to the same number, the oracle's bar is 1e-3)
         assert rel_err(b["grads"][k], a["grads"][k]) < 1e-4, (segments, k, rel_err(b["grads"][k], a["grads"][k]))
+
+
+def test_tile_tables_kept_per_view_change_nothing_but_the_launches(dev, monkeypatch):
+    """The engine keeps the workgroup -> tile table it built for a view and hands it back at the next visits of the same view
+    (so_step_desc.tile_order_ready, so_step_inputs order_src): built at the first visit and every `order_refresh`-th one, a valid
+    permutation at all times, and training with kept tables gives the images of training with a table per step (an order only
+    schedules)."""
+    from splat_one_amd.engine import FusedEngine
+    N, W, H = 20_000, 256, 160
+    outs = {}
+    for cache in ("1", "0"):
+        monkeypatch.setenv("SPLAT_ONE_AMD_ORDER_CACHE", cache)
+        r, c2w, Ks, pixels = _make(dev, N, W, H, "ref")
+        views = [(c2w, Ks, pixels), (c2w.clone(), Ks, (pixels * 0.5).contiguous())]
+        eng = FusedEngine(r.splats, r.optimizers, W, H, 1, sh_degree=3, use_graph=True)
+        modes, imgs = [], []
+        for it in range(12):
+            c, k, px = views[it % 2]
+            eng.set_views(c, k, px, schedule=True)
+            modes.append(eng._order_mode)
+            eng.step()
+            torch.cuda.synchronize()
+            order = eng.ws["tile_order"].cpu()
+            assert eng._order_mode == "none" or torch.equal(torch.sort(order).values, torch.arange(eng.M, dtype=torch.int32))
+            imgs.append(eng.ws["render_colors"].clone())
+        outs[cache] = (modes, imgs)
+        if cache == "1":
+            eng.order_refresh = 3
+            assert set(modes[2:]) <= {"build", "kept"} and modes.count("build") >= 2 and modes.count("kept") >= 6, modes
+            assert len(eng._order_cache) == 2
+        else:
+            assert "kept" not in modes and "build" not in modes, modes
+    # (the first image: same parameters, bit for bit; later ones: two trainings whose gradients are atomic sums)
+    assert torch.equal(outs["1"][1][0], outs["0"][1][0])
+    for a, b in zip(outs["1"][1], outs["0"][1]):
+        assert (a - b).abs().max().item() < 1e-3
