@@ -844,8 +844,8 @@ def main():
                    "backward_rasteriser": ("one wave per 16x16 tile" if fused and not runner.sharded and runner._engine.cfg.get("raster_impl") == 1
                                            else "one wave per 8x8 quadrant"),
                    "tile_order": ({"each": "longest list first (device-built table, one launch per step)",
-                                   "build": "longest list first (table kept per view, rebuilt every 8th visit)",
-                                   "kept": "longest list first (table kept per view, rebuilt every 8th visit)"}.get(
+                                   "build": "longest list first (table kept per view, rebuilt every 16th visit)",
+                                   "kept": "longest list first (table kept per view, rebuilt every 16th visit)"}.get(
                                        getattr(runner._engine, "_order_mode", "none"), "XCD-local runs of 8 tiles")
                                   if fused and not runner.sharded else "XCD-local runs of 8 tiles"),
                    "parallelism": (f"gaussian-sharded dp{world}: one view per GPU, N/{world} Gaussians per GPU, "

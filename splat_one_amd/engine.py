@@ -140,7 +140,7 @@ class FusedEngine:
         import os
         self.tile_order_lpt = os.environ.get("SPLAT_ONE_AMD_TILE_ORDER", "1") != "0"   # (0: keep the XCD-local order, for A/B runs)
         self._lpt = False                # the rasterisers take their tiles longest list first (list_policy.pick_tile_order)
-        # Tables kept per view (so_step_desc.tile_order_ready): {view key: [table, visits since it was built]}.  A view is known by the
+        # Tables kept per view (so_step_desc.tile_order_ready): {view key: [table, visits since it was built, iteration it was built at]}.  A view is known by the
         # key the caller gives (set_views(view_key=...): the trainer's image id) or by the address of its target image when that is
         # used in place; the table built at one visit schedules the next `order_refresh - 1` visits of the same view (any permutation
         # is a valid order -- only the speed depends on how well it still fits).  SPLAT_ONE_AMD_ORDER_CACHE=0: off.
@@ -148,7 +148,10 @@ class FusedEngine:
         self._order_key = None
         self._order_mode = "none"        # "none" | "build" (the step builds the table, kept afterwards) | "kept" | "each" (built every step, no key)
         self._lpt_kept = False
-        self.order_refresh = 8
+        # (rebuilt at every 16th visit of a view -- tools/gpu_r05_ba.sh: c2 0.2536 / 0.2521 / 0.2510 / 0.2534 / 0.2619 ms at 4 / 8 / 16 / 32 / 64 --
+        # and in any case when it is more than 2000 iterations old: a large training set revisits an image rarely)
+        self.order_refresh = max(1, int(os.environ.get("SPLAT_ONE_AMD_ORDER_REFRESH", "16")))
+        self.order_max_age = 2000
         self.order_cache_on = os.environ.get("SPLAT_ONE_AMD_ORDER_CACHE", "1") != "0"
         self.before_param_access = None  # replicas: RowShardedAdam.wait_gathers (see _params_ready)
         self._fold = False               # the per-tile sort runs in the forward rasteriser's prologue (list_policy.pick_sort_fold)
@@ -721,12 +724,20 @@ class FusedEngine:
             self._order_mode = "each" if each else "none"
             return 0
         ent = self._order_cache.get(key)
-        if ent is None or ent[0].numel() != self.M or ent[1] >= self.order_refresh - 1:
+        if ent is None or ent[0].numel() != self.M or ent[1] >= self.order_refresh - 1 or self.steps_done - ent[2] > self.order_max_age:
             self._order_mode = "build"
             return 0
         ent[1] += 1
         self._order_mode = "kept"
         return _lib.ptr(ent[0])
+
+    def _order_variants(self, key):
+        """(order mode, graph key) pairs to capture together: a view's table is built at one visit and handed back at the next ones,
+        so the two graphs -- with and without the table's launch -- are captured at the same time (no capture, i.e. no device-wide
+        synchronisation, when the mode flips between iterations)."""
+        modes = ["build", "kept"] if self._order_mode in ("build", "kept") else [self._order_mode]
+        ids = {"none": 0, "each": 1, "build": 1, "kept": 2}
+        return [(m, key[:-1] + (ids[m],)) for m in modes]
 
     def _order_graph_id(self) -> int:
         return {"none": 0, "each": 1, "build": 1, "kept": 2}[self._order_mode]
@@ -739,9 +750,9 @@ class FusedEngine:
             self._order_cache.clear()
         ent = self._order_cache.get(self._order_key)
         if ent is None or ent[0].numel() != self.M:
-            ent = self._order_cache[self._order_key] = [torch.empty(self.M, dtype=torch.int32, device=self.device), 0]
+            ent = self._order_cache[self._order_key] = [torch.empty(self.M, dtype=torch.int32, device=self.device), 0, 0]
         ent[0].copy_(self.ws["tile_order"])
-        ent[1] = 0
+        ent[1], ent[2] = 0, int(self.steps_done)
 
     def _fullest_tile(self) -> int:
         """Largest per-tile count of the last binning pass (binned lists: the atomics count past the capacity).  With replicated
@@ -1079,12 +1090,20 @@ class FusedEngine:
             if not self._staged:
                 self._stage(None, None, None, False)
             self._warm_fwd_bwd()
-            with CAPTURE_LOCK:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    d = self._desc()
-                    _lib.call("so_train_step_head", ctypes.byref(d), _lib.stream())
-            self._graphs_head[key] = g
+            mode_now = self._order_mode
+            try:
+                for mode, k in self._order_variants(key):
+                    if k in self._graphs_head:
+                        continue
+                    self._order_mode = mode
+                    with CAPTURE_LOCK:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g):
+                            d = self._desc()
+                            _lib.call("so_train_step_head", ctypes.byref(d), _lib.stream())
+                    self._graphs_head[k] = g
+            finally:
+                self._order_mode = mode_now
         self._consume_staging()
         self._graphs_head[key].replay()
         self._keep_order_table()
@@ -1134,18 +1153,27 @@ class FusedEngine:
         if not self._staged:
             self._stage(None, None, None, False)
         self._warm_fwd_bwd()
-        with CAPTURE_LOCK:
-            g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                self._launch_fwd_bwd()
-            opt = {}
-            for sched in (False, True):
-                if self.flat_multiple:           # the optimiser of this mode is distributed.ShardedFlatAdam
-                    break
-                opt[sched] = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(opt[sched]):
-                    self._launch_optimize(sched)
-        self._graphs_fb[key] = (g1, opt)
+        mode_now = self._order_mode
+        try:
+            for mode, k in self._order_variants(key):
+                if k in self._graphs_fb:
+                    continue
+                self._order_mode = mode
+                with CAPTURE_LOCK:
+                    g1 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g1):
+                        self._launch_fwd_bwd()
+                    opt = {}
+                    for sched in (False, True):
+                        if self.flat_multiple:           # the optimiser of this mode is distributed.ShardedFlatAdam
+                            break
+                        opt[sched] = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(opt[sched]):
+                            self._launch_optimize(sched)
+                self._graphs_fb[k] = (g1, opt)
+        finally:
+            self._order_mode = mode_now
+        g1, opt = self._graphs_fb[key]
         self._graph_fb, self._graph_opt, self._graph_fb_key = g1, opt, key
 
     def _advance_host_counters(self) -> None:
@@ -1186,18 +1214,26 @@ class FusedEngine:
         if not self._staged:
             self._stage(None, None, None, False)
         self._warm_fwd_bwd()
-        graphs = {}
-        with CAPTURE_LOCK:
-            for sched in (False, True):      # Adam with its own schedule launch / with the schedule staged by set_views
-                graphs[sched] = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graphs[sched]):
-                    if self._fusable(sched):
-                        self._launch_fwd_bwd(fused_adam=True)
-                    else:
-                        self._launch_fwd_bwd()
-                        self._launch_optimize(sched)
-        self._graphs[key] = graphs
-        self._graph, self._graph_key = graphs, key
+        mode_now = self._order_mode
+        try:
+            for mode, k in self._order_variants(key):
+                if k in self._graphs:
+                    continue
+                self._order_mode = mode
+                graphs = {}
+                with CAPTURE_LOCK:
+                    for sched in (False, True):      # Adam with its own schedule launch / with the schedule staged by set_views
+                        graphs[sched] = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(graphs[sched]):
+                            if self._fusable(sched):
+                                self._launch_fwd_bwd(fused_adam=True)
+                            else:
+                                self._launch_fwd_bwd()
+                                self._launch_optimize(sched)
+                self._graphs[k] = graphs
+        finally:
+            self._order_mode = mode_now
+        self._graph, self._graph_key = self._graphs[key], key
 
     # ---------------------------------------------------------------------------------------------
     def set_sh_degree(self, deg: int) -> None:

@@ -501,7 +501,7 @@ def test_step_inputs_one_launch(dev):
     gam = (ctypes.c_float * ng)(0.99985, 1.0, 1.0)
     b1, b2 = 0.9, 0.999
     _lib.call("so_step_inputs", C, _lib.ptr(c2w_d), _lib.ptr(Ks_d), _lib.ptr(vm), _lib.ptr(Kd), _lib.ptr(img), _lib.ptr(slot),
-              _lib.ptr(counters), nz, ng, lr0, gam, b1, b2, _lib.ptr(step_dev), 0, 0, 0, 0, 0, _lib.stream())
+              _lib.ptr(counters), nz, ng, lr0, gam, b1, b2, _lib.ptr(step_dev), 0, 0, 0, 0, 0, 0, 0, 0, _lib.stream())
     torch.cuda.synchronize()
     want = torch.linalg.inv(c2w.double())
     assert (vm.cpu().double() - want).abs().max().item() < 1e-6
@@ -519,7 +519,7 @@ def test_step_inputs_one_launch(dev):
     counters.fill_(9)
     counters[100], counters[101] = 123456, 1
     _lib.call("so_step_inputs", 0, 0, 0, 0, 0, 0, 0, _lib.ptr(counters), nz, 0, None, None, 0.0, 0.0, 0,
-              status.data_ptr(), 100, 77, 0, 0, _lib.stream())
+              status.data_ptr(), 100, 77, 0, 0, 0, 0, 0, _lib.stream())
     torch.cuda.synchronize()
     assert status[:3].tolist() == [123456, 1, 77] and (counters[:nz] == 0).all()
     # per-tile list lengths (the first n_lists counters): maximum and sum gathered while they are zeroed, published by the
@@ -533,7 +533,7 @@ def test_step_inputs_one_launch(dev):
         counters.fill_(4)
         counters[:90] = lens.to(dev)
         _lib.call("so_step_inputs", 0, 0, 0, 0, 0, 0, 0, _lib.ptr(counters), nz, 0, None, None, 0.0, 0.0, 0,
-                  status.data_ptr(), 100, seq, 90, _lib.ptr(stat), _lib.stream())
+                  status.data_ptr(), 100, seq, 90, _lib.ptr(stat), 0, 0, 0, _lib.stream())
         torch.cuda.synchronize()
         assert int(status[2]) == seq and (counters[:nz] == 0).all()
         if seen:
@@ -541,9 +541,16 @@ def test_step_inputs_one_launch(dev):
         seen.append(lens)
     # parts are optional: zero only
     counters.fill_(5)
-    _lib.call("so_step_inputs", 0, 0, 0, 0, 0, 0, 0, _lib.ptr(counters), 10, 0, None, None, 0.0, 0.0, 0, 0, 0, 0, 0, 0, _lib.stream())
+    _lib.call("so_step_inputs", 0, 0, 0, 0, 0, 0, 0, _lib.ptr(counters), 10, 0, None, None, 0.0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0, 0, _lib.stream())
     torch.cuda.synchronize()
     assert (counters[:10] == 0).all() and (counters[10:] == 5).all() and step_dev[0].item() == 42
+    # order_src: a kept workgroup -> tile table copied into the step's table by the same launch
+    src = torch.randperm(5000, device=dev).to(torch.int32)
+    dst = torch.zeros(5000, dtype=torch.int32, device=dev)
+    _lib.call("so_step_inputs", 0, 0, 0, 0, 0, 0, 0, _lib.ptr(counters), nz, 0, None, None, 0.0, 0.0, 0, 0, 0, 0, 0, 0,
+              _lib.ptr(src), _lib.ptr(dst), 5000, _lib.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(src, dst)
 
 
 def test_rec_unpack_and_cam_stride(dev):
