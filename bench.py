@@ -406,6 +406,8 @@ def main():
             # step), but it never refines -- the reference's default starts at iteration 500, which the untimed passes of a long
             # run would cross (and then N, V and I of the counters pass are no longer those of the timed region)
             cfg.strategy.refine_start_iter = 10 ** 9
+            if hasattr(cfg.strategy, "reset_every"):
+                cfg.strategy.reset_every = 10 ** 9          # (... nor resets the opacities at iteration 3000 of a very long run)
         r = Runner(local_rank, rank, world, cfg, scene_scale=1.0 / 1.1)   # effective scene_scale 1.0
         if args.cloud_scale != 1.0:
             with torch.no_grad():
