@@ -74,6 +74,7 @@ class _Bins:
         self.overflows = 0
         self.mean_list = 0.0                         # list entries per tile of the last forward whose status has been looked at
         self.fullest = 0                             # ... and its fullest tile
+        self.last_order: Optional[Tensor] = None     # the workgroup -> tile table of the last forward, if it built one
 
     def keys(self) -> Tensor:
         n = self.M * self.slots
@@ -126,8 +127,11 @@ def pending_overflow(synchronize: bool = True) -> int:
     return n
 
 
-def _bins_for(device: torch.device, M: int) -> _Bins:
-    key = (device.index if device.index is not None else torch.cuda.current_device(), _lib.stream(), M)
+def _bins_for(device: torch.device, M: int, grid: Tuple[int, int, int]) -> _Bins:
+    """The bins of one (device, stream, C x tile_w x tile_h) -- the GRID and not only its tile count M: two image shapes of equal
+    M (one 145 x 33 view and two 71 x 41 views are 30 tiles each) must not inherit each other's measured list lengths (the second
+    would skip its measuring call and cut a 1400-entry list at the first's 1024 slots: fuzz seeds 2222 -> 2344, round 5)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _lib.stream(), M, tuple(grid))
     b = _BINS.get(key)
     if b is None:
         with _BINS_LOCK:
@@ -199,7 +203,7 @@ class _Rasterization(torch.autograd.Function):
         M = C * (-(-W // ts)) * (-(-H // ts))
         need_bwd = any(ctx.needs_input_grad[:6]) or ctx.needs_input_grad[8]
         ctx.set_materialize_grads(False)
-        bins = _bins_for(dev, M)
+        bins = _bins_for(dev, M, (C, -(-W // ts), -(-H // ts)))
         f32, i32 = torch.float32, torch.int32
         d = _desc(cfg, C, N, K)
         d.means, d.quats, d.scales, d.opacities, d.sh0, d.shN = (means.data_ptr(), quats.data_ptr(), scales.data_ptr(),
@@ -231,6 +235,7 @@ class _Rasterization(torch.autograd.Function):
                 if cfg["tile_size"] == 16 and pick_tile_order(False, 0, bins.mean_list, bins.fullest):
                     tile_order = torch.empty(M, dtype=i32, device=dev)
                     d.tile_order = tile_order.data_ptr()
+                bins.last_order = tile_order          # (kept for tools/dbg_order_small.py; replaced by the next call)
                 _lib.call("so_rasterization_fwd", ctypes.byref(d), _lib.stream())
                 # measure (ONE synchronisation): the first call on this tile grid, a model 1.5x denser than the one the bins
                 # were sized on, and every call that needs no gradient (eval / viewer: exact, see the module docstring)
