@@ -75,6 +75,7 @@ class _Bins:
         self.mean_list = 0.0                         # list entries per tile of the last forward whose status has been looked at
         self.fullest = 0                             # ... and its fullest tile
         self.last_order: Optional[Tensor] = None     # the workgroup -> tile table of the last forward, if it built one
+        self.last_used = 0                           # _bins_for's clock at the last call on this grid (eviction order)
 
     def keys(self) -> Tensor:
         n = self.M * self.slots
@@ -111,6 +112,8 @@ class _Bins:
 
 _BINS: Dict[tuple, _Bins] = {}
 _BINS_LOCK = threading.Lock()
+_MAX_BINS = 64
+_BINS_CLOCK = 0
 
 
 def pending_overflow(synchronize: bool = True) -> int:
@@ -131,11 +134,21 @@ def _bins_for(device: torch.device, M: int, grid: Tuple[int, int, int]) -> _Bins
     """The bins of one (device, stream, C x tile_w x tile_h) -- the GRID and not only its tile count M: two image shapes of equal
     M (one 145 x 33 view and two 71 x 41 views are 30 tiles each) must not inherit each other's measured list lengths (the second
     would skip its measuring call and cut a 1400-entry list at the first's 1024 slots: fuzz seeds 2222 -> 2344, round 5)."""
+    global _BINS_CLOCK
     key = (device.index if device.index is not None else torch.cuda.current_device(), _lib.stream(), M, tuple(grid))
     b = _BINS.get(key)
     if b is None:
         with _BINS_LOCK:
-            b = _BINS.setdefault(key, _Bins(device, M))
+            b = _BINS.get(key)
+            if b is None:
+                # a viewer that follows its window renders at many sizes, and a grid's key scratch is M x slots x 8 bytes (67 MB at
+                # 1080p): keep the _MAX_BINS grids used last (a call in flight holds its own reference; an evicted grid is simply
+                # measured again on its next call)
+                while len(_BINS) >= _MAX_BINS:
+                    del _BINS[min(_BINS, key=lambda k: _BINS[k].last_used)]
+                b = _BINS[key] = _Bins(device, M)
+    _BINS_CLOCK += 1
+    b.last_used = _BINS_CLOCK
     return b
 
 
