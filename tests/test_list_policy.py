@@ -170,3 +170,43 @@ def test_bin_counter_copies_by_tile_count_and_hot_regions(n_tiles, fullest, mean
 def test_backward_segments_where_the_fullest_tiles_chain_binds(n_tiles, fullest, mean, expect):
     """so_step_desc.bwd_seg_len: few tiles or one hot region, and lists of >= 1024 entries."""
     assert LP.pick_bwd_segments(n_tiles, fullest, mean) == expect
+
+
+def test_tile_tables_kept_per_view_follow_visits_age_and_size_with_a_stubbed_engine(monkeypatch):
+    """FusedEngine._pick_order_mode / _keep_order_table on a stand-in object (no library, no device): a view's table is built at its
+    first visit, handed back at the next `order_refresh - 1`, rebuilt at the visit after those, when it is more than `order_max_age`
+    iterations old, and when the tile count it was built for is not this workspace's; without a view key nothing is kept."""
+    import torch
+    from splat_one_amd import engine as E
+    monkeypatch.setattr(E._lib, "ptr", lambda t: 1000 + t.numel())
+    eng = types.SimpleNamespace(_lpt=False, tile_order_lpt=True, _order_key=("img", 3), _list_stats=(0, 32.0), binned=True, cfg={"tile_size": 16},
+                                _lpt_kept=False, _order_cache={}, _order_mode="none", M=12, order_refresh=4, order_max_age=2000, steps_done=0,
+                                ws={"tile_order": torch.arange(12, dtype=torch.int32)}, device="cpu")
+    pick = lambda: E.FusedEngine._pick_order_mode(eng)
+    keep = lambda: E.FusedEngine._keep_order_table(eng)
+    modes = []
+    for it in range(9):                                   # nine visits of one view, refresh every 4th
+        eng.steps_done = it
+        src = pick()
+        modes.append(eng._order_mode)
+        assert (src != 0) == (eng._order_mode == "kept")
+        keep()
+    assert modes == ["build", "kept", "kept", "kept", "build", "kept", "kept", "kept", "build"], modes
+    assert torch.equal(eng._order_cache[("img", 3)][0], eng.ws["tile_order"]) and eng._order_cache[("img", 3)][2] == 8
+    eng.steps_done = 8 + 2001                             # too old: rebuilt although only one visit has used it
+    assert pick() == 0 and eng._order_mode == "build"
+    keep()
+    eng.M, eng.ws = 20, {"tile_order": torch.arange(20, dtype=torch.int32)}   # another workspace size: the kept table is not handed out
+    assert pick() == 0 and eng._order_mode == "build"
+    keep()
+    assert eng._order_cache[("img", 3)][0].numel() == 20
+    assert pick() == 1020 and eng._order_mode == "kept"
+    eng._order_key = None                                 # no key (a caller that names no view): nothing kept, and short lists need no table
+    assert pick() == 0 and eng._order_mode == "none"
+    eng._lpt = True                                       # ... long lists: a table every step
+    assert pick() == 0 and eng._order_mode == "each"
+    eng._order_key, eng._lpt, eng._list_stats = ("img", 4), False, (0, 10.0)   # lists too short for a kept table to pay (hysteresis: on from 24, off below 16)
+    assert pick() == 0 and eng._order_mode == "none"
+    assert E.FusedEngine._order_variants(eng, (1, 2, 0)) == [("none", (1, 2, 0))]
+    eng._order_mode = "build"
+    assert E.FusedEngine._order_variants(eng, (1, 2, 1)) == [("build", (1, 2, 1)), ("kept", (1, 2, 2))]
